@@ -1,0 +1,215 @@
+"""CPU oracle loader -- TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see oracle/README.md).
+
+ctypes front-end for ``oracle/liborc.so`` (built by ``make -C oracle`` from orc_tracker.cpp /
+orc_backend.cpp, the plain-C++ restatement of the reference's CPU hot path).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+package; the product (``sdv-loam_amd`` / ``libsdvgn.so``) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liborc.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".hpp"))]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = os.path.join(_HERE, "liborc.so")
+    if not os.path.exists(so):
+        build()
+    L = C.CDLL(so)
+    L.orc_tracker_create.restype = C.c_void_p
+    L.orc_tracker_create.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.orc_tracker_destroy.argtypes = [C.c_void_p]
+    L.orc_tracker_set_settings.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.orc_tracker_make_K.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.orc_tracker_get_K.argtypes = [C.c_void_p, C.c_int, f32p, f32p]
+    L.orc_tracker_set_ref.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, f32p, f32p, f32p]
+    L.orc_tracker_set_ref_frame.argtypes = [C.c_void_p, C.c_float, C.c_double, C.c_double]
+    L.orc_tracker_set_new_image.argtypes = [C.c_void_p, f32p, C.c_float]
+    L.orc_tracker_set_new_pyr.argtypes = [C.c_void_p, C.c_int, f32p, C.c_float]
+    L.orc_tracker_get_pyr.argtypes = [C.c_void_p, C.c_int, f32p]
+    L.orc_make_images.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p]
+    L.orc_calc_res.argtypes = [C.c_void_p, C.c_int, f64p, C.c_double, C.c_double, C.c_float, f64p]
+    L.orc_get_warped.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_get_warped.restype = C.c_int
+    L.orc_calc_gs.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, f64p, f64p]
+    L.orc_track.argtypes = [C.c_void_p, f64p, f64p, C.c_int, f64p, f64p, f64p, C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_track.restype = C.c_int
+    L.orc_trace_stride.restype = C.c_int
+    L.orc_se3_exp.argtypes = [f64p, f64p]
+    L.orc_se3_log.argtypes = [f64p, f64p]
+    L.orc_se3_mul.argtypes = [f64p, f64p, f64p]
+    L.orc_se3_inverse.argtypes = [f64p, f64p]
+    L.orc_se3_matrix.argtypes = [f64p, f64p]
+    L.orc_se3_adj.argtypes = [f64p, f64p]
+    L.orc_ldlt_solve.argtypes = [C.c_int, f64p, f64p, f64p]
+    L.orc_inv3f.argtypes = [f32p, f32p]
+    L.orc_interp33.argtypes = [f32p, C.c_float, C.c_float, C.c_int, f32p]
+    _bind_backend(L)
+    _LIB = L
+    return L
+
+
+def _bind_backend(L):
+    if not hasattr(L, "orc_ef_create"):
+        return
+    from . import backend as _b  # noqa: F401  (binds its own prototypes lazily)
+
+
+# ------------------------------------------------------------------------------------------------
+# maths helpers
+# ------------------------------------------------------------------------------------------------
+def se3_exp(a):
+    out = np.zeros(7)
+    lib().orc_se3_exp(np.ascontiguousarray(a, np.float64), out)
+    return out
+
+
+def se3_log(p):
+    out = np.zeros(6)
+    lib().orc_se3_log(np.ascontiguousarray(p, np.float64), out)
+    return out
+
+
+def se3_mul(a, b):
+    out = np.zeros(7)
+    lib().orc_se3_mul(np.ascontiguousarray(a, np.float64), np.ascontiguousarray(b, np.float64), out)
+    return out
+
+
+def se3_inverse(a):
+    out = np.zeros(7)
+    lib().orc_se3_inverse(np.ascontiguousarray(a, np.float64), out)
+    return out
+
+
+def se3_matrix(a):
+    out = np.zeros(9)
+    lib().orc_se3_matrix(np.ascontiguousarray(a, np.float64), out)
+    return out.reshape(3, 3)
+
+
+def se3_adj(a):
+    out = np.zeros(36)
+    lib().orc_se3_adj(np.ascontiguousarray(a, np.float64), out)
+    return out.reshape(6, 6)
+
+
+def ldlt_solve(A, b):
+    A = np.ascontiguousarray(A, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    x = np.zeros_like(b)
+    lib().orc_ldlt_solve(A.shape[0], A, b, x)
+    return x
+
+
+def make_images(color, w, h, levels):
+    """a1: list of per-level AoS arrays (h_l, w_l, 3) = {I, dx, dy}."""
+    color = np.ascontiguousarray(color, np.float32).reshape(-1)
+    sizes = [(w >> l) * (h >> l) * 3 for l in range(levels)]
+    out = np.zeros(sum(sizes), np.float32)
+    lib().orc_make_images(color, w, h, levels, out)
+    res, off = [], 0
+    for l, s in enumerate(sizes):
+        res.append(out[off:off + s].reshape(h >> l, w >> l, 3).copy())
+        off += s
+    return res
+
+
+IDENTITY_POSE = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
+
+
+class OracleTracker:
+    """Mirror of the reference's CoarseTracker call surface (CoarseTracker.h:17-107) on the CPU oracle."""
+
+    def __init__(self, w, h, levels):
+        self.L = lib()
+        self.w, self.h, self.levels = w, h, levels
+        self.h_ = self.L.orc_tracker_create(w, h, levels)
+
+    def __del__(self):
+        try:
+            self.L.orc_tracker_destroy(self.h_)
+        except Exception:
+            pass
+
+    def set_settings(self, huber=6.0, cutoff=20.0, aff_a=0.0, aff_b=0.0):
+        self.L.orc_tracker_set_settings(self.h_, huber, cutoff, aff_a, aff_b)
+
+    def makeK(self, fx, fy, cx, cy):
+        self.L.orc_tracker_make_K(self.h_, fx, fy, cx, cy)
+
+    def get_K(self, lvl):
+        k4 = np.zeros(4, np.float32)
+        ki = np.zeros(9, np.float32)
+        self.L.orc_tracker_get_K(self.h_, lvl, k4, ki)
+        return k4, ki.reshape(3, 3)
+
+    def set_ref(self, lvl, u, v, idepth, color):
+        u, v, idepth, color = (np.ascontiguousarray(x, np.float32) for x in (u, v, idepth, color))
+        self.L.orc_tracker_set_ref(self.h_, lvl, len(u), u, v, idepth, color)
+
+    def set_ref_frame(self, exposure=1.0, a=0.0, b=0.0):
+        self.L.orc_tracker_set_ref_frame(self.h_, exposure, a, b)
+
+    def set_new_image(self, color, exposure=1.0):
+        self.L.orc_tracker_set_new_image(self.h_, np.ascontiguousarray(color, np.float32).reshape(-1), exposure)
+
+    def set_new_pyr(self, lvl, aos3, exposure=1.0):
+        self.L.orc_tracker_set_new_pyr(self.h_, lvl, np.ascontiguousarray(aos3, np.float32).reshape(-1), exposure)
+
+    def get_pyr(self, lvl):
+        out = np.zeros((self.h >> lvl) * (self.w >> lvl) * 3, np.float32)
+        self.L.orc_tracker_get_pyr(self.h_, lvl, out)
+        return out.reshape(self.h >> lvl, self.w >> lvl, 3)
+
+    def calcRes(self, lvl, pose7, a, b, cutoff):
+        out = np.zeros(6)
+        self.L.orc_calc_res(self.h_, lvl, np.ascontiguousarray(pose7, np.float64), a, b, cutoff, out)
+        return out
+
+    def warped(self):
+        n = self.L.orc_get_warped(self.h_, None)
+        out = np.zeros((8, n), np.float32)
+        if n:
+            self.L.orc_get_warped(self.h_, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def calcGS(self, lvl, a, b):
+        H = np.zeros(64)
+        bb = np.zeros(8)
+        self.L.orc_calc_gs(self.h_, lvl, a, b, H, bb)
+        return H.reshape(8, 8), bb
+
+    def trackNewestCoarse(self, pose7, aff, coarsest, min_res=None, trace_cap=512):
+        pose = np.array(pose7, np.float64)
+        aff = np.array(aff, np.float64)
+        mr = np.full(5, np.nan) if min_res is None else np.array(min_res, np.float64)
+        last_res = np.zeros(5)
+        flow = np.zeros(3)
+        stride = self.L.orc_trace_stride()
+        trace = np.zeros((trace_cap, stride))
+        ntr = C.c_int(0)
+        ok = self.L.orc_track(self.h_, pose, aff, coarsest, mr, last_res, flow,
+                              trace.ctypes.data_as(C.c_void_p), trace_cap, C.byref(ntr))
+        return bool(ok), pose, aff, last_res, flow, trace[:min(ntr.value, trace_cap)]

@@ -1,0 +1,566 @@
+// oracle/orc_tracker.cpp -- TEST INFRASTRUCTURE ONLY (CPU oracle). PARITY UNPINNED.
+//
+// Plain C++ restatement of the reference's photometric coarse tracker, SURVEY.md section 8 rows a1-a9:
+//   a1 FrameHessian::makeImages          src/FullSystem/HessianBlocks.cpp:107-167
+//   a2 CoarseTracker::makeK              src/FullSystem/CoarseTracker.cpp:77-106
+//   a4 CoarseTracker::calcRes            src/FullSystem/CoarseTracker.cpp:486-634
+//   a5 CoarseTracker::calcGSSSE          src/FullSystem/CoarseTracker.cpp:427-484
+//   a6 Accumulator9                      src/OptimizationBackend/MatrixAccumulators.h:934-1115,1273-1292
+//   a7 CoarseTracker::trackNewestCoarse  src/FullSystem/CoarseTracker.cpp:662-838
+//   a8 AffLight::fromToVecExposure       src/util/NumType.h:149-158
+//   a9 getInterpolatedElement33          src/util/globalFuncs.h:51-65
+// The reference itself cannot be compiled in this environment (needs Eigen3, Boost, ROS, OpenCV, PCL,
+// Pangolin -- none installed, no network) and ships no tests/golden vectors for this path, so this
+// oracle is "parity unpinned": it is pinned only by analytic known-answer tests (tests/test_oracle_*.py).
+//
+// Arithmetic follows the reference operation by operation: float32 where the reference uses float,
+// the same operand order, no FMA contraction (build with -ffp-contract=off, baseline SSE2 like the
+// reference's `-O3` x86-64 build), 4-lane SSE-shaped accumulation with the 1k / 1M tiered shift-up.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this library; the
+// product (libsdvgn) never links or loads it.
+#include "orc_math.hpp"
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+namespace orc {
+
+static const int kMaxLvl = 6;  // PYR_LEVELS, src/util/settings.h
+
+// HessianBlocks.h:33-40
+static const float SCALE_XI_ROT = 1.0f, SCALE_XI_TRANS = 0.5f, SCALE_A = 10.0f, SCALE_B = 1000.0f;
+
+// ---- a6: Accumulator9 (MatrixAccumulators.h:934-1292) ------------------------------------------
+struct Accumulator9 {
+    float S[4 * 45], S1k[4 * 45], S1m[4 * 45];
+    float numIn1, numIn1k, numIn1m;
+    size_t num;
+    float H[9][9];
+    void initialize() {
+        std::memset(S, 0, sizeof(S)); std::memset(S1k, 0, sizeof(S1k)); std::memset(S1m, 0, sizeof(S1m));
+        num = 0; numIn1 = numIn1k = numIn1m = 0;
+        std::memset(H, 0, sizeof(H));
+    }
+    void shiftUp(bool force) {  // :1273-1292
+        if (numIn1 > 1000 || force) {
+            for (int i = 0; i < 4 * 45; ++i) S1k[i] = S[i] + S1k[i];
+            numIn1k += numIn1; numIn1 = 0;
+            std::memset(S, 0, sizeof(S));
+        }
+        if (numIn1k > 1000 || force) {
+            for (int i = 0; i < 4 * 45; ++i) S1m[i] = S1k[i] + S1m[i];
+            numIn1m += numIn1k; numIn1k = 0;
+            std::memset(S1k, 0, sizeof(S1k));
+        }
+    }
+    // updateSSE_eighted :1040-1115 -- J[k][lane], w[lane]
+    void updateWeighted(const float J[9][4], const float w[4]) {
+        int idx = 0;
+        for (int r = 0; r < 9; ++r) {
+            float Jw[4];
+            for (int l = 0; l < 4; ++l) Jw[l] = J[r][l] * w[l];
+            for (int c = r; c < 9; ++c) {
+                for (int l = 0; l < 4; ++l) S[idx + l] = S[idx + l] + Jw[l] * J[c][l];
+                idx += 4;
+            }
+        }
+        num += 4; numIn1++;
+        shiftUp(false);
+    }
+    void finish() {  // :953-970
+        std::memset(H, 0, sizeof(H));
+        shiftUp(true);
+        int idx = 0;
+        for (int r = 0; r < 9; ++r)
+            for (int c = r; c < 9; ++c) {
+                float d = S1m[idx + 0] + S1m[idx + 1] + S1m[idx + 2] + S1m[idx + 3];
+                H[r][c] = H[c][r] = d;
+                idx += 4;
+            }
+    }
+};
+
+struct Tracker {
+    int levels;
+    int w[kMaxLvl], h[kMaxLvl];
+    float fx[kMaxLvl], fy[kMaxLvl], cx[kMaxLvl], cy[kMaxLvl];
+    float K[kMaxLvl][9], Ki[kMaxLvl][9];
+    std::vector<float> pc_u[kMaxLvl], pc_v[kMaxLvl], pc_idepth[kMaxLvl], pc_color[kMaxLvl];
+    int pc_n[kMaxLvl];
+    // lastRef: exposure + aff_g2l ; newFrame: exposure + dIp pyramid
+    float ref_exposure, new_exposure;
+    double ref_a, ref_b;
+    std::vector<float> dIp[kMaxLvl];  // AoS {I,dx,dy}
+    // warped buffers (CoarseTracker.h:93-102)
+    std::vector<float> bw_idepth, bw_u, bw_v, bw_dx, bw_dy, bw_res, bw_w, bw_ref;
+    int bw_n;
+    Accumulator9 acc;
+    // settings (src/util/settings.cpp:93-94,101,112; launch/run.launch mode=1 -> affine modes 0)
+    float huberTH, coarseCutoffTH, affineOptModeA, affineOptModeB;
+    // side outputs (CoarseTracker.h:62-65)
+    double lastResiduals[5];
+    double lastFlowIndicators[3];
+};
+
+// ---- a9: getInterpolatedElement33 (globalFuncs.h:51-65) ----------------------------------------
+static inline void interp33(const float* mat, float x, float y, int width, float out[3]) {
+    int ix = (int)x;
+    int iy = (int)y;
+    float dx = x - ix;
+    float dy = y - iy;
+    float dxdy = dx * dy;
+    const float* bp = mat + 3 * (ix + iy * width);
+    const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+    for (int k = 0; k < 3; ++k)
+        out[k] = ((w11 * bp[3 * (1 + width) + k] + w01 * bp[3 * width + k]) + w10 * bp[3 + k]) + w00 * bp[k];
+}
+
+// ---- a1: makeImages (HessianBlocks.cpp:107-167) ------------------------------------------------
+// out[lvl] = AoS float3 {I,dx,dy}.  Gradient rows 0 and hl-1 are uninitialised memory in the
+// reference (loop bounds :145); the oracle fills them with NaN as a canary -- no consumer may read them.
+static void make_images(const float* color, int w0, int h0, int levels, std::vector<float>* out) {
+    for (int l = 0; l < levels; ++l) {
+        int wl = w0 >> l, hl = h0 >> l;
+        out[l].assign((size_t)wl * hl * 3, std::numeric_limits<float>::quiet_NaN());
+    }
+    for (int i = 0; i < w0 * h0; ++i) out[0][3 * i] = color[i];
+    for (int lvl = 0; lvl < levels; ++lvl) {
+        int wl = w0 >> lvl, hl = h0 >> lvl;
+        float* d = out[lvl].data();
+        if (lvl > 0) {
+            int wlm1 = w0 >> (lvl - 1);
+            const float* dm = out[lvl - 1].data();
+            for (int y = 0; y < hl; ++y)
+                for (int x = 0; x < wl; ++x)
+                    d[3 * (x + y * wl)] = 0.25f * (((dm[3 * (2 * x + 2 * y * wlm1)] + dm[3 * (2 * x + 1 + 2 * y * wlm1)]) +
+                                                    dm[3 * (2 * x + 2 * y * wlm1 + wlm1)]) +
+                                                   dm[3 * (2 * x + 1 + 2 * y * wlm1 + wlm1)]);
+        }
+        for (int idx = wl; idx < wl * (hl - 1); ++idx) {
+            float dx = 0.5f * (d[3 * (idx + 1)] - d[3 * (idx - 1)]);
+            float dy = 0.5f * (d[3 * (idx + wl)] - d[3 * (idx - wl)]);
+            if (!std::isfinite(dx)) dx = 0;
+            if (!std::isfinite(dy)) dy = 0;
+            d[3 * idx + 1] = dx;
+            d[3 * idx + 2] = dy;
+        }
+    }
+}
+
+// ---- a2: makeK (CoarseTracker.cpp:77-106) ------------------------------------------------------
+static void make_K(Tracker* T, float fx0, float fy0, float cx0, float cy0) {
+    T->fx[0] = fx0; T->fy[0] = fy0; T->cx[0] = cx0; T->cy[0] = cy0;
+    for (int level = 1; level < T->levels; ++level) {
+        T->fx[level] = T->fx[level - 1] * 0.5;            // float * double -> float
+        T->fy[level] = T->fy[level - 1] * 0.5;
+        T->cx[level] = (T->cx[0] + 0.5) / ((int)1 << level) - 0.5;  // evaluated in double, stored float
+        T->cy[level] = (T->cy[0] + 0.5) / ((int)1 << level) - 0.5;
+    }
+    for (int level = 0; level < T->levels; ++level) {
+        float* K = T->K[level];
+        K[0] = T->fx[level]; K[1] = 0; K[2] = T->cx[level];
+        K[3] = 0; K[4] = T->fy[level]; K[5] = T->cy[level];
+        K[6] = 0; K[7] = 0; K[8] = 1;
+        inv3f(K, T->Ki[level]);
+    }
+}
+
+// ---- a4: calcRes (CoarseTracker.cpp:486-634) ---------------------------------------------------
+static void calc_res(Tracker* T, int lvl, const SE3& refToNew, double aff_a, double aff_b, float cutoffTH, double rs[6]) {
+    float E = 0;
+    int numTermsInE = 0, numTermsInWarped = 0, numSaturated = 0;
+    const int wl = T->w[lvl], hl = T->h[lvl];
+    const float* dINewl = T->dIp[lvl].data();
+    const float fxl = T->fx[lvl], fyl = T->fy[lvl], cxl = T->cx[lvl], cyl = T->cy[lvl];
+    const float* Ki = T->Ki[lvl];
+
+    double Rd[9];
+    quat_to_R(refToNew.q, Rd);
+    float Rf[9], RKi[9], t[3];
+    for (int i = 0; i < 9; ++i) Rf[i] = (float)Rd[i];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            RKi[i * 3 + j] = (Rf[i * 3 + 0] * Ki[0 * 3 + j] + Rf[i * 3 + 1] * Ki[1 * 3 + j]) + Rf[i * 3 + 2] * Ki[2 * 3 + j];
+    for (int i = 0; i < 3; ++i) t[i] = (float)refToNew.t[i];
+    double affd[2];
+    aff_from_to(T->ref_exposure, T->new_exposure, T->ref_a, T->ref_b, aff_a, aff_b, affd);
+    const float affLL0 = (float)affd[0], affLL1 = (float)affd[1];
+
+    float sumSquaredShiftT = 0, sumSquaredShiftRT = 0, sumSquaredShiftNum = 0;
+    const float huber = T->huberTH;
+    const float maxEnergy = 2 * huber * cutoffTH - huber * huber;
+
+    const int nl = T->pc_n[lvl];
+    const float* lpc_u = T->pc_u[lvl].data();
+    const float* lpc_v = T->pc_v[lvl].data();
+    const float* lpc_idepth = T->pc_idepth[lvl].data();
+    const float* lpc_color = T->pc_color[lvl].data();
+
+    const size_t cap = (size_t)nl + 4;
+    if (T->bw_u.size() < cap) {
+        T->bw_idepth.resize(cap); T->bw_u.resize(cap); T->bw_v.resize(cap); T->bw_dx.resize(cap);
+        T->bw_dy.resize(cap); T->bw_res.resize(cap); T->bw_w.resize(cap); T->bw_ref.resize(cap);
+    }
+
+    auto mv = [](const float* M, float x, float y, const float* tt, float id, float sgn, float* o) {
+        for (int r = 0; r < 3; ++r) {
+            float m = (M[r * 3 + 0] * x + M[r * 3 + 1] * y) + M[r * 3 + 2] * 1.0f;
+            o[r] = (sgn > 0) ? (m + tt[r] * id) : (m - tt[r] * id);
+        }
+    };
+
+    for (int i = 0; i < nl; ++i) {
+        float id = lpc_idepth[i];
+        float x = lpc_u[i];
+        float y = lpc_v[i];
+        float pt[3];
+        mv(RKi, x, y, t, id, 1, pt);
+        float u = pt[0] / pt[2];
+        float v = pt[1] / pt[2];
+        float Ku = fxl * u + cxl;
+        float Kv = fyl * v + cyl;
+        float new_idepth = id / pt[2];
+
+        if (lvl == 0 && i % 32 == 0) {  // :538-566
+            float ptT[3], ptT2[3], pt3[3];
+            mv(Ki, x, y, t, id, 1, ptT);
+            float uT = ptT[0] / ptT[2], vT = ptT[1] / ptT[2];
+            float KuT = fxl * uT + cxl, KvT = fyl * vT + cyl;
+            mv(Ki, x, y, t, id, -1, ptT2);
+            float uT2 = ptT2[0] / ptT2[2], vT2 = ptT2[1] / ptT2[2];
+            float KuT2 = fxl * uT2 + cxl, KvT2 = fyl * vT2 + cyl;
+            mv(RKi, x, y, t, id, -1, pt3);
+            float u3 = pt3[0] / pt3[2], v3 = pt3[1] / pt3[2];
+            float Ku3 = fxl * u3 + cxl, Kv3 = fyl * v3 + cyl;
+            sumSquaredShiftT += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
+            sumSquaredShiftT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
+            sumSquaredShiftRT += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
+            sumSquaredShiftRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
+            sumSquaredShiftNum += 2;
+        }
+
+        if (!(Ku > 2 && Kv > 2 && Ku < wl - 3 && Kv < hl - 3 && new_idepth > 0)) continue;
+
+        float refColor = lpc_color[i];
+        float hit[3];
+        interp33(dINewl, Ku, Kv, wl, hit);
+        if (!std::isfinite(hit[0])) continue;
+        float residual = hit[0] - (float)(affLL0 * refColor + affLL1);
+        float hw = std::fabs(residual) < huber ? 1 : huber / std::fabs(residual);
+
+        if (std::fabs(residual) > cutoffTH) {
+            E += maxEnergy;
+            numTermsInE++;
+            numSaturated++;
+        } else {
+            E += hw * residual * residual * (2 - hw);
+            numTermsInE++;
+            T->bw_idepth[numTermsInWarped] = new_idepth;
+            T->bw_u[numTermsInWarped] = u;
+            T->bw_v[numTermsInWarped] = v;
+            T->bw_dx[numTermsInWarped] = hit[1];
+            T->bw_dy[numTermsInWarped] = hit[2];
+            T->bw_res[numTermsInWarped] = residual;
+            T->bw_w[numTermsInWarped] = hw;
+            T->bw_ref[numTermsInWarped] = lpc_color[i];
+            numTermsInWarped++;
+        }
+    }
+    while (numTermsInWarped % 4 != 0) {  // :603-615
+        T->bw_idepth[numTermsInWarped] = 0; T->bw_u[numTermsInWarped] = 0; T->bw_v[numTermsInWarped] = 0;
+        T->bw_dx[numTermsInWarped] = 0; T->bw_dy[numTermsInWarped] = 0; T->bw_res[numTermsInWarped] = 0;
+        T->bw_w[numTermsInWarped] = 0; T->bw_ref[numTermsInWarped] = 0;
+        numTermsInWarped++;
+    }
+    T->bw_n = numTermsInWarped;
+
+    rs[0] = E;
+    rs[1] = numTermsInE;
+    rs[2] = sumSquaredShiftT / (sumSquaredShiftNum + 0.1);
+    rs[3] = 0;
+    rs[4] = sumSquaredShiftRT / (sumSquaredShiftNum + 0.1);
+    rs[5] = numSaturated / (float)numTermsInE;
+}
+
+// ---- a5: calcGSSSE (CoarseTracker.cpp:427-484) -------------------------------------------------
+static void calc_gs(Tracker* T, int lvl, double aff_a, double aff_b, double H_out[64], double b_out[8]) {
+    Accumulator9& acc = T->acc;
+    acc.initialize();
+    const float fxl = T->fx[lvl], fyl = T->fy[lvl];
+    const float b0 = (float)T->ref_b;
+    double affd[2];
+    aff_from_to(T->ref_exposure, T->new_exposure, T->ref_a, T->ref_b, aff_a, aff_b, affd);
+    const float a = (float)affd[0];
+    const int n = T->bw_n;
+    for (int i = 0; i < n; i += 4) {
+        float J[9][4], w[4];
+        for (int l = 0; l < 4; ++l) {
+            float dx = T->bw_dx[i + l] * fxl;
+            float dy = T->bw_dy[i + l] * fyl;
+            float u = T->bw_u[i + l], v = T->bw_v[i + l], id = T->bw_idepth[i + l];
+            J[0][l] = id * dx;
+            J[1][l] = id * dy;
+            J[2][l] = 0.0f - id * (u * dx + v * dy);
+            J[3][l] = 0.0f - ((u * v) * dx + dy * (1.0f + v * v));
+            J[4][l] = (u * v) * dy + dx * (1.0f + u * u);
+            J[5][l] = u * dy - v * dx;
+            J[6][l] = a * (b0 - T->bw_ref[i + l]);
+            J[7][l] = -1.0f;
+            J[8][l] = T->bw_res[i + l];
+            w[l] = T->bw_w[i + l];
+        }
+        acc.updateWeighted(J, w);
+    }
+    acc.finish();
+    const double s = (double)(1.0f / n);
+    double H[8][8], b[8];
+    for (int r = 0; r < 8; ++r) {
+        for (int c = 0; c < 8; ++c) H[r][c] = (double)acc.H[r][c] * s;
+        b[r] = (double)acc.H[r][8] * s;
+    }
+    const float sc[8] = {SCALE_XI_ROT, SCALE_XI_ROT, SCALE_XI_ROT, SCALE_XI_TRANS, SCALE_XI_TRANS, SCALE_XI_TRANS, SCALE_A, SCALE_B};
+    for (int r = 0; r < 8; ++r)
+        for (int c = 0; c < 8; ++c) H[r][c] *= sc[c];  // column blocks :472-475
+    for (int r = 0; r < 8; ++r)
+        for (int c = 0; c < 8; ++c) H[r][c] *= sc[r];  // row blocks :476-479
+    for (int r = 0; r < 8; ++r) b[r] *= sc[r];
+    for (int r = 0; r < 8; ++r) {
+        for (int c = 0; c < 8; ++c) H_out[r * 8 + c] = H[r][c];
+        b_out[r] = b[r];
+    }
+}
+
+// trace record per LM trial: [lvl, iteration, lambda, accept, inc[8], E_new, n_new, cutoffRepeat] = 15 doubles
+static const int kTraceStride = 15;
+
+// ---- a7: trackNewestCoarse (CoarseTracker.cpp:662-838) -----------------------------------------
+static bool track(Tracker* T, SE3& lastToNew_out, double aff_io[2], int coarsestLvl, const double minResForAbort[5],
+                  double* trace, int trace_cap, int* trace_n) {
+    for (int i = 0; i < 5; ++i) T->lastResiduals[i] = NAN;
+    for (int i = 0; i < 3; ++i) T->lastFlowIndicators[i] = 1000;
+    int maxIterations[] = {10, 20, 50, 50, 50};
+    float lambdaExtrapolationLimit = 0.001;
+    SE3 refToNew_current = lastToNew_out;
+    double aff_a = aff_io[0], aff_b = aff_io[1];
+    bool haveRepeated = false;
+    int ntr = 0;
+
+    for (int lvl = coarsestLvl; lvl >= 0; lvl--) {
+        double H[64], b[8];
+        float levelCutoffRepeat = 1;
+        double resOld[6];
+        calc_res(T, lvl, refToNew_current, aff_a, aff_b, T->coarseCutoffTH * levelCutoffRepeat, resOld);
+        while (resOld[5] > 0.6 && levelCutoffRepeat < 50) {
+            levelCutoffRepeat *= 2;
+            calc_res(T, lvl, refToNew_current, aff_a, aff_b, T->coarseCutoffTH * levelCutoffRepeat, resOld);
+        }
+        calc_gs(T, lvl, aff_a, aff_b, H, b);
+        float lambda = 0.01;
+
+        for (int iteration = 0; iteration < maxIterations[lvl]; iteration++) {
+            double Hl[64];
+            std::memcpy(Hl, H, sizeof(Hl));
+            for (int i = 0; i < 8; i++) Hl[i * 8 + i] *= (1 + lambda);
+            double negb[8], inc[8];
+            for (int i = 0; i < 8; ++i) negb[i] = -b[i];
+            ldlt_solve(8, Hl, negb, inc);
+
+            if (T->affineOptModeA < 0 && T->affineOptModeB < 0) {  // fix a, b :726-730
+                double H6[36], x6[6];
+                for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H6[r * 6 + c] = Hl[r * 8 + c];
+                ldlt_solve(6, H6, negb, x6);
+                for (int i = 0; i < 6; ++i) inc[i] = x6[i];
+                inc[6] = inc[7] = 0;
+            }
+            if (!(T->affineOptModeA < 0) && T->affineOptModeB < 0) {  // fix b :731-735
+                double H7[49], x7[7];
+                for (int r = 0; r < 7; ++r) for (int c = 0; c < 7; ++c) H7[r * 7 + c] = Hl[r * 8 + c];
+                ldlt_solve(7, H7, negb, x7);
+                for (int i = 0; i < 7; ++i) inc[i] = x7[i];
+                inc[7] = 0;
+            }
+            if (T->affineOptModeA < 0 && !(T->affineOptModeB < 0)) {  // fix a :736-748
+                double Hs[64], bs[8];
+                std::memcpy(Hs, Hl, sizeof(Hs));
+                for (int i = 0; i < 8; ++i) bs[i] = b[i];
+                for (int r = 0; r < 8; ++r) Hs[r * 8 + 6] = Hs[r * 8 + 7];
+                for (int c = 0; c < 8; ++c) Hs[6 * 8 + c] = Hs[7 * 8 + c];
+                bs[6] = bs[7];
+                double H7[49], nb7[7], x7[7];
+                for (int r = 0; r < 7; ++r) { for (int c = 0; c < 7; ++c) H7[r * 7 + c] = Hs[r * 8 + c]; nb7[r] = -bs[r]; }
+                ldlt_solve(7, H7, nb7, x7);
+                for (int i = 0; i < 8; ++i) inc[i] = 0;
+                for (int i = 0; i < 6; ++i) inc[i] = x7[i];
+                inc[6] = 0; inc[7] = x7[6];
+            }
+
+            float extrapFac = 1;
+            if (lambda < lambdaExtrapolationLimit) extrapFac = std::sqrt(std::sqrt(lambdaExtrapolationLimit / lambda));
+            for (int i = 0; i < 8; ++i) inc[i] *= extrapFac;
+
+            double incScaled[8];
+            for (int i = 0; i < 8; ++i) incScaled[i] = inc[i];
+            for (int i = 0; i < 3; ++i) incScaled[i] *= SCALE_XI_ROT;
+            for (int i = 3; i < 6; ++i) incScaled[i] *= SCALE_XI_TRANS;
+            incScaled[6] *= SCALE_A;
+            incScaled[7] *= SCALE_B;
+            double sum = 0;
+            for (int i = 0; i < 8; ++i) sum += incScaled[i];
+            if (!std::isfinite(sum)) for (int i = 0; i < 8; ++i) incScaled[i] = 0;
+
+            SE3 refToNew_new = se3_mul(se3_exp(incScaled), refToNew_current);
+            double aff_a_new = aff_a + incScaled[6];
+            double aff_b_new = aff_b + incScaled[7];
+
+            double resNew[6];
+            calc_res(T, lvl, refToNew_new, aff_a_new, aff_b_new, T->coarseCutoffTH * levelCutoffRepeat, resNew);
+            bool accept = (resNew[0] / resNew[1]) < (resOld[0] / resOld[1]);
+
+            if (trace && ntr < trace_cap) {
+                double* tr = trace + (size_t)ntr * kTraceStride;
+                tr[0] = lvl; tr[1] = iteration; tr[2] = lambda; tr[3] = accept ? 1 : 0;
+                for (int i = 0; i < 8; ++i) tr[4 + i] = incScaled[i];
+                tr[12] = resNew[0]; tr[13] = resNew[1]; tr[14] = levelCutoffRepeat;
+            }
+            ntr++;
+
+            if (accept) {
+                calc_gs(T, lvl, aff_a_new, aff_b_new, H, b);
+                std::memcpy(resOld, resNew, sizeof(resOld));
+                aff_a = aff_a_new; aff_b = aff_b_new;
+                refToNew_current = refToNew_new;
+                lambda *= 0.5;
+            } else {
+                lambda *= 4;
+                if (lambda < lambdaExtrapolationLimit) lambda = lambdaExtrapolationLimit;
+            }
+            double nrm = 0;
+            for (int i = 0; i < 8; ++i) nrm += inc[i] * inc[i];
+            nrm = std::sqrt(nrm);
+            if (!(nrm > 1e-3)) break;
+        }
+
+        T->lastResiduals[lvl] = sqrtf((float)(resOld[0] / resOld[1]));
+        for (int i = 0; i < 3; ++i) T->lastFlowIndicators[i] = resOld[2 + i];
+        if (T->lastResiduals[lvl] > 1.5 * minResForAbort[lvl]) { if (trace_n) *trace_n = ntr; return false; }
+
+        if (levelCutoffRepeat > 1 && !haveRepeated) {
+            lvl++;
+            haveRepeated = true;
+        }
+    }
+
+    lastToNew_out = refToNew_current;
+    aff_io[0] = aff_a; aff_io[1] = aff_b;
+    if (trace_n) *trace_n = ntr;
+
+    if ((T->affineOptModeA != 0 && (fabsf((float)aff_io[0]) > 1.2)) || (T->affineOptModeB != 0 && (fabsf((float)aff_io[1]) > 200)))
+        return false;
+    double rel[2];
+    aff_from_to(T->ref_exposure, T->new_exposure, T->ref_a, T->ref_b, aff_io[0], aff_io[1], rel);
+    const float relAff0 = (float)rel[0], relAff1 = (float)rel[1];
+    if ((T->affineOptModeA == 0 && (fabsf(logf(relAff0)) > 1.5)) || (T->affineOptModeB == 0 && (fabsf(relAff1) > 200)))
+        return false;
+    if (T->affineOptModeA < 0) aff_io[0] = 0;
+    if (T->affineOptModeB < 0) aff_io[1] = 0;
+    return true;
+}
+
+}  // namespace orc
+
+// ------------------------------- C entry points (ctypes) ---------------------------------------
+using namespace orc;
+extern "C" {
+
+int orc_trace_stride() { return kTraceStride; }
+
+void* orc_tracker_create(int w0, int h0, int levels) {
+    Tracker* T = new Tracker();
+    T->levels = levels;
+    for (int l = 0; l < levels; ++l) { T->w[l] = w0 >> l; T->h[l] = h0 >> l; T->pc_n[l] = 0; }
+    T->ref_exposure = T->new_exposure = 1; T->ref_a = T->ref_b = 0;
+    T->huberTH = 6; T->coarseCutoffTH = 20; T->affineOptModeA = 0; T->affineOptModeB = 0;
+    T->bw_n = 0;
+    return T;
+}
+void orc_tracker_destroy(void* h) { delete (Tracker*)h; }
+void orc_tracker_set_settings(void* h, float huberTH, float coarseCutoffTH, float affA, float affB) {
+    Tracker* T = (Tracker*)h; T->huberTH = huberTH; T->coarseCutoffTH = coarseCutoffTH; T->affineOptModeA = affA; T->affineOptModeB = affB;
+}
+void orc_tracker_make_K(void* h, float fx, float fy, float cx, float cy) { make_K((Tracker*)h, fx, fy, cx, cy); }
+void orc_tracker_get_K(void* h, int lvl, float out4[4], float Ki9[9]) {
+    Tracker* T = (Tracker*)h;
+    out4[0] = T->fx[lvl]; out4[1] = T->fy[lvl]; out4[2] = T->cx[lvl]; out4[3] = T->cy[lvl];
+    std::memcpy(Ki9, T->Ki[lvl], sizeof(float) * 9);
+}
+void orc_tracker_set_ref(void* h, int lvl, int n, const float* u, const float* v, const float* idepth, const float* color) {
+    Tracker* T = (Tracker*)h;
+    T->pc_n[lvl] = n;
+    T->pc_u[lvl].assign(u, u + n); T->pc_v[lvl].assign(v, v + n);
+    T->pc_idepth[lvl].assign(idepth, idepth + n); T->pc_color[lvl].assign(color, color + n);
+}
+void orc_tracker_set_ref_frame(void* h, float exposure, double a, double b) {
+    Tracker* T = (Tracker*)h; T->ref_exposure = exposure; T->ref_a = a; T->ref_b = b;
+}
+// new frame from a raw level-0 image (runs makeImages)
+void orc_tracker_set_new_image(void* h, const float* color, float exposure) {
+    Tracker* T = (Tracker*)h;
+    make_images(color, T->w[0], T->h[0], T->levels, T->dIp);
+    T->new_exposure = exposure;
+}
+// new frame from an existing AoS pyramid level
+void orc_tracker_set_new_pyr(void* h, int lvl, const float* dIp_aos3, float exposure) {
+    Tracker* T = (Tracker*)h;
+    T->dIp[lvl].assign(dIp_aos3, dIp_aos3 + (size_t)T->w[lvl] * T->h[lvl] * 3);
+    T->new_exposure = exposure;
+}
+void orc_tracker_get_pyr(void* h, int lvl, float* out) {
+    Tracker* T = (Tracker*)h;
+    std::memcpy(out, T->dIp[lvl].data(), sizeof(float) * T->dIp[lvl].size());
+}
+void orc_make_images(const float* color, int w0, int h0, int levels, float* out_concat) {
+    std::vector<float> tmp[kMaxLvl];
+    make_images(color, w0, h0, levels, tmp);
+    size_t off = 0;
+    for (int l = 0; l < levels; ++l) { std::memcpy(out_concat + off, tmp[l].data(), sizeof(float) * tmp[l].size()); off += tmp[l].size(); }
+}
+// pose7 = Sophus SE3d::data() layout [qx qy qz qw tx ty tz]
+void orc_calc_res(void* h, int lvl, const double pose7[7], double a, double b, float cutoffTH, double out6[6]) {
+    SE3 T; std::memcpy(T.q, pose7, 4 * sizeof(double)); std::memcpy(T.t, pose7 + 4, 3 * sizeof(double));
+    calc_res((Tracker*)h, lvl, T, a, b, cutoffTH, out6);
+}
+int orc_get_warped(void* h, float* out8) {  // 8 planes x bw_n, plane-major: idepth,u,v,dx,dy,res,w,ref
+    Tracker* T = (Tracker*)h; const int n = T->bw_n;
+    const std::vector<float>* p[8] = {&T->bw_idepth, &T->bw_u, &T->bw_v, &T->bw_dx, &T->bw_dy, &T->bw_res, &T->bw_w, &T->bw_ref};
+    if (out8) for (int k = 0; k < 8; ++k) std::memcpy(out8 + (size_t)k * n, p[k]->data(), sizeof(float) * n);
+    return n;
+}
+void orc_calc_gs(void* h, int lvl, double a, double b, double H64[64], double b8[8]) { calc_gs((Tracker*)h, lvl, a, b, H64, b8); }
+int orc_track(void* h, double pose7_io[7], double aff_io[2], int coarsestLvl, const double minRes[5], double lastRes[5],
+              double flow[3], double* trace, int trace_cap, int* trace_n) {
+    Tracker* T = (Tracker*)h;
+    SE3 P; std::memcpy(P.q, pose7_io, 4 * sizeof(double)); std::memcpy(P.t, pose7_io + 4, 3 * sizeof(double));
+    bool ok = track(T, P, aff_io, coarsestLvl, minRes, trace, trace_cap, trace_n);
+    std::memcpy(pose7_io, P.q, 4 * sizeof(double)); std::memcpy(pose7_io + 4, P.t, 3 * sizeof(double));
+    for (int i = 0; i < 5; ++i) lastRes[i] = T->lastResiduals[i];
+    for (int i = 0; i < 3; ++i) flow[i] = T->lastFlowIndicators[i];
+    return ok ? 1 : 0;
+}
+
+// ---- maths helpers exposed for the known-answer tests ----
+void orc_se3_exp(const double a[6], double pose7[7]) { SE3 T = se3_exp(a); std::memcpy(pose7, T.q, 32); std::memcpy(pose7 + 4, T.t, 24); }
+void orc_se3_log(const double pose7[7], double a[6]) { SE3 T; std::memcpy(T.q, pose7, 32); std::memcpy(T.t, pose7 + 4, 24); se3_log(T, a); }
+void orc_se3_mul(const double A[7], const double B[7], double out[7]) {
+    SE3 a, b; std::memcpy(a.q, A, 32); std::memcpy(a.t, A + 4, 24); std::memcpy(b.q, B, 32); std::memcpy(b.t, B + 4, 24);
+    SE3 r = se3_mul(a, b); std::memcpy(out, r.q, 32); std::memcpy(out + 4, r.t, 24);
+}
+void orc_se3_inverse(const double A[7], double out[7]) {
+    SE3 a; std::memcpy(a.q, A, 32); std::memcpy(a.t, A + 4, 24); SE3 r = se3_inverse(a); std::memcpy(out, r.q, 32); std::memcpy(out + 4, r.t, 24);
+}
+void orc_se3_matrix(const double A[7], double R9[9]) { quat_to_R(A, R9); }
+void orc_se3_adj(const double A[7], double out36[36]) { SE3 a; std::memcpy(a.q, A, 32); std::memcpy(a.t, A + 4, 24); se3_adj(a, out36); }
+void orc_ldlt_solve(int n, const double* A, const double* b, double* x) { ldlt_solve(n, A, b, x); }
+void orc_inv3f(const float* m, float* out) { inv3f(m, out); }
+void orc_interp33(const float* mat, float x, float y, int width, float out[3]) { interp33(mat, x, y, width, out); }
+}

@@ -1,0 +1,469 @@
+// tracker.hip -- host side of the GPU coarse tracker + its C ABI (include/sdvgn.h).
+//
+// Mirrors class CoarseTracker (src/FullSystem/CoarseTracker.h:17-107): makeK, the pc_* reference template,
+// calcRes / calcGSSSE (fused into k_res_gs), and the coarse-to-fine Levenberg-Marquardt driver
+// trackNewestCoarse (CoarseTracker.cpp:662-838).  The photometric work runs in the kernels of
+// tracker_kernels.hpp; the 8x8 LDLT, SE3 exp and accept/reject logic live in gnmath.hpp and run either on the
+// host (sdvgn_tracker_track: one fused launch + one 640-byte read-back per LM trial) or on the device
+// (k_track, sdvgn_tracker_track_batch: whole loop in one launch, one workgroup per pose hypothesis).
+#include "../../include/sdvgn.h"
+#include "gnmath.hpp"
+#include "tracker_kernels.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#define HIPCHK(expr)                                  \
+    do {                                              \
+        hipError_t _e = (expr);                       \
+        if (_e != hipSuccess) return -(int)_e;        \
+    } while (0)
+
+using namespace sdvgn;
+
+namespace sdvgn {
+#include "tracker_track_kernel.inc"
+}
+
+struct sdvgn_tracker {
+    int device = 0;
+    int levels = 0;
+    int w[SDVGN_MAX_LEVELS], h[SDVGN_MAX_LEVELS];
+    int max_points = 0, max_batch = 0, max_chunks = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    // intrinsics pyramid (makeK)
+    float fx[SDVGN_MAX_LEVELS], fy[SDVGN_MAX_LEVELS], cx[SDVGN_MAX_LEVELS], cy[SDVGN_MAX_LEVELS];
+    float Ki[SDVGN_MAX_LEVELS][9];
+    bool haveK = false;
+
+    // settings
+    float huberTH = 6.f, coarseCutoffTH = 20.f, affineOptModeA = 0.f, affineOptModeB = 0.f;
+
+    // reference template pc_* (packed {u,v,idepth,color}) and reference frame state
+    float4* pc_dev[SDVGN_MAX_LEVELS] = {};
+    int pc_n[SDVGN_MAX_LEVELS] = {};
+    float ref_exposure = 1.f;
+    double ref_a = 0, ref_b = 0;
+
+    // new frame
+    float* pyr_dev[SDVGN_MAX_LEVELS] = {};  // AoS {I,dx,dy}
+    float* img_stage_dev = nullptr;         // level-0 float image staging
+    float new_exposure = 1.f;
+    bool haveNew = false;
+
+    // work buffers
+    LevelParams* params_dev = nullptr;
+    LevelParams* params_host = nullptr;  // pinned
+    float* partial_dev = nullptr;
+    double* out_dev = nullptr;
+    double* out_host = nullptr;          // pinned
+    float* terms_dev = nullptr;
+    int* status_dev = nullptr;
+    int terms_lvl = -1;
+    TrackState* track_dev = nullptr;
+    TrackState* track_host = nullptr;    // pinned
+    TrackConst* tconst_dev = nullptr;
+
+    // side outputs of the last track() call
+    std::vector<double> trace;
+};
+
+static int chunks_for(const sdvgn_tracker* t, int n, int B) {
+    // one point per lane while the launch is small; otherwise enough workgroups to cover the chip ~8x
+    int c = (n + 255) / 256;
+    if (c < 1) c = 1;
+    const int want = (2048 + B - 1) / B;
+    if (c > want) c = want < 1 ? 1 : want;
+    if (c > t->max_chunks) c = t->max_chunks;
+    return c;
+}
+
+static void fill_params(const sdvgn_tracker* t, int lvl, const double* pose7, double aff_a, double aff_b,
+                        float cutoffTH, LevelParams& P) {
+    // head of calcRes (:499-513) and calcGSSSE (:431-434)
+    double R[9];
+    gn::rotation_matrix(pose7, R);
+    float Rf[9];
+    for (int i = 0; i < 9; ++i) Rf[i] = (float)R[i];
+    const float* Ki = t->Ki[lvl];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            P.RKi[i * 3 + j] = (Rf[i * 3 + 0] * Ki[j] + Rf[i * 3 + 1] * Ki[3 + j]) + Rf[i * 3 + 2] * Ki[6 + j];
+    for (int i = 0; i < 3; ++i) P.t[i] = (float)pose7[4 + i];
+    for (int i = 0; i < 9; ++i) P.Ki[i] = Ki[i];
+    P.fx = t->fx[lvl]; P.fy = t->fy[lvl]; P.cx = t->cx[lvl]; P.cy = t->cy[lvl];
+    double ab[2];
+    gn::aff_from_to(t->ref_exposure, t->new_exposure, t->ref_a, t->ref_b, aff_a, aff_b, ab);
+    P.affLL0 = (float)ab[0]; P.affLL1 = (float)ab[1];
+    P.b0 = (float)t->ref_b;
+    P.cutoff = cutoffTH;
+    P.huber = t->huberTH;
+    P.maxEnergy = 2 * t->huberTH * cutoffTH - t->huberTH * t->huberTH;
+    P.wl = t->w[lvl]; P.hl = t->h[lvl]; P.lvl = lvl; P.n = t->pc_n[lvl];
+}
+
+// launches k_res_gs + k_finalize for B problems; results in t->out_dev
+static int launch_res_gs(sdvgn_tracker* t, int lvl, int B, const double* pose7, const double* aff, float cutoffTH,
+                         bool write_terms, double* out_dev) {
+    if (!t->haveK || !t->haveNew) return SDVGN_E_STATE;
+    if (lvl < 0 || lvl >= t->levels || B < 1 || B > t->max_batch) return SDVGN_E_ARG;
+    if (write_terms && B != 1) return SDVGN_E_ARG;
+    for (int b = 0; b < B; ++b) fill_params(t, lvl, pose7 + 7 * b, aff[2 * b], aff[2 * b + 1], cutoffTH, t->params_host[b]);
+    HIPCHK(hipMemcpyAsync(t->params_dev, t->params_host, sizeof(LevelParams) * B, hipMemcpyHostToDevice, t->stream));
+    const int n = t->pc_n[lvl];
+    const int chunks = chunks_for(t, n, B);
+    dim3 grid(chunks, B), block(256);
+    if (write_terms) {
+        k_res_gs<true><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], t->pyr_dev[lvl], t->params_dev, t->partial_dev,
+                                                      t->terms_dev, t->status_dev);
+        t->terms_lvl = lvl;
+    } else {
+        k_res_gs<false><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], t->pyr_dev[lvl], t->params_dev, t->partial_dev,
+                                                       nullptr, nullptr);
+    }
+    k_finalize<<<B, 128, 0, t->stream>>>(t->partial_dev, chunks, out_dev);
+    HIPCHK(hipGetLastError());
+    return SDVGN_OK;
+}
+
+static int res_gs_sync(sdvgn_tracker* t, int lvl, const double* pose7, double a, double b, float cutoffTH,
+                       bool write_terms, double* out6, double* H, double* bv) {
+    const double aff[2] = {a, b};
+    int rc = launch_res_gs(t, lvl, 1, pose7, aff, cutoffTH, write_terms, t->out_dev);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(t->out_host, t->out_dev, sizeof(double) * kOutStride, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    if (out6) std::memcpy(out6, t->out_host, 6 * sizeof(double));
+    if (H) std::memcpy(H, t->out_host + 6, 64 * sizeof(double));
+    if (bv) std::memcpy(bv, t->out_host + 70, 8 * sizeof(double));
+    return SDVGN_OK;
+}
+
+// ---- trackNewestCoarse, host-driven (CoarseTracker.cpp:662-838) ---------------------------------------
+static int track_host_driven(sdvgn_tracker* t, double* pose7_io, double* aff_io, int coarsestLvl, const double* minRes,
+                             double* lastResiduals, double* lastFlow) {
+    if (coarsestLvl < 0 || coarsestLvl >= 5 || coarsestLvl >= t->levels) return SDVGN_E_ARG;  // assert :672
+    for (int i = 0; i < 5; ++i) lastResiduals[i] = NAN;
+    for (int i = 0; i < 3; ++i) lastFlow[i] = 1000;
+    t->trace.clear();
+    const int maxIterations[] = {10, 20, 50, 50, 50};
+    const float lambdaExtrapolationLimit = 0.001f;
+    gn::Pose cur;
+    gn::pose_load(cur, pose7_io);
+    double aff_a = aff_io[0], aff_b = aff_io[1];
+    bool haveRepeated = false;
+    double p7[7];
+
+    for (int lvl = coarsestLvl; lvl >= 0; lvl--) {
+        double H[64], b[8], resOld[6];
+        float levelCutoffRepeat = 1;
+        gn::pose_store(cur, p7);
+        int rc = res_gs_sync(t, lvl, p7, aff_a, aff_b, t->coarseCutoffTH * levelCutoffRepeat, false, resOld, H, b);
+        if (rc) return rc;
+        while (resOld[5] > 0.6 && levelCutoffRepeat < 50) {
+            levelCutoffRepeat *= 2;
+            rc = res_gs_sync(t, lvl, p7, aff_a, aff_b, t->coarseCutoffTH * levelCutoffRepeat, false, resOld, H, b);
+            if (rc) return rc;
+        }
+        float lambda = 0.01f;
+        for (int iteration = 0; iteration < maxIterations[lvl]; iteration++) {
+            double inc[8], incScaled[8];
+            lm_step(H, b, lambda, lambdaExtrapolationLimit, t->affineOptModeA, t->affineOptModeB, inc, incScaled);
+            const gn::Pose cand = gn::compose(gn::exp_se3(incScaled), cur);
+            const double a_new = aff_a + incScaled[6], b_new = aff_b + incScaled[7];
+            double resNew[6], Hn[64], bn[8];
+            gn::pose_store(cand, p7);
+            rc = res_gs_sync(t, lvl, p7, a_new, b_new, t->coarseCutoffTH * levelCutoffRepeat, false, resNew, Hn, bn);
+            if (rc) return rc;
+            const bool accept = (resNew[0] / resNew[1]) < (resOld[0] / resOld[1]);
+            {
+                double row[15] = {(double)lvl, (double)iteration, (double)lambda, accept ? 1.0 : 0.0};
+                for (int i = 0; i < 8; ++i) row[4 + i] = incScaled[i];
+                row[12] = resNew[0]; row[13] = resNew[1]; row[14] = levelCutoffRepeat;
+                t->trace.insert(t->trace.end(), row, row + 15);
+            }
+            if (accept) {
+                std::memcpy(H, Hn, sizeof(H));
+                std::memcpy(b, bn, sizeof(b));
+                std::memcpy(resOld, resNew, sizeof(resOld));
+                aff_a = a_new; aff_b = b_new;
+                cur = cand;
+                lambda *= 0.5;
+            } else {
+                lambda *= 4;
+                if (lambda < lambdaExtrapolationLimit) lambda = lambdaExtrapolationLimit;
+            }
+            double nrm = 0;
+            for (int i = 0; i < 8; ++i) nrm += inc[i] * inc[i];
+            if (!(sqrt(nrm) > 1e-3)) break;
+        }
+        lastResiduals[lvl] = sqrtf((float)(resOld[0] / resOld[1]));
+        for (int i = 0; i < 3; ++i) lastFlow[i] = resOld[2 + i];
+        if (lastResiduals[lvl] > 1.5 * minRes[lvl]) return 0;
+        if (levelCutoffRepeat > 1 && !haveRepeated) { lvl++; haveRepeated = true; }
+    }
+    gn::pose_store(cur, pose7_io);
+    aff_io[0] = aff_a; aff_io[1] = aff_b;
+    return track_final_checks(t->affineOptModeA, t->affineOptModeB, t->ref_exposure, t->new_exposure, t->ref_a, t->ref_b,
+                              aff_io) ? 1 : 0;
+}
+
+// =========================================== C ABI =====================================================
+extern "C" {
+
+const char* sdvgn_version(void) { return "sdvgn 0.1 (gfx950)"; }
+
+const char* sdvgn_error_string(int code) {
+    switch (code) {
+        case SDVGN_OK: return "ok";
+        case SDVGN_E_ARG: return "bad argument";
+        case SDVGN_E_STATE: return "call order violated";
+        case SDVGN_E_NODEVICE: return "no usable HIP device";
+        default: return code < 0 ? hipGetErrorString((hipError_t)(-code)) : "unknown";
+    }
+}
+
+int sdvgn_tracker_create(sdvgn_tracker** out, int device, int w0, int h0, int levels, int max_points, int max_batch,
+                         void* stream) {
+    if (!out || levels < 1 || levels > SDVGN_MAX_LEVELS || w0 < 16 || h0 < 16 || max_points < 1 || max_batch < 1)
+        return SDVGN_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) return SDVGN_E_NODEVICE;
+    HIPCHK(hipSetDevice(device));
+    sdvgn_tracker* t = new (std::nothrow) sdvgn_tracker();
+    if (!t) return SDVGN_E_ARG;
+    t->device = device; t->levels = levels; t->max_points = max_points; t->max_batch = max_batch;
+    t->max_chunks = 256;
+    for (int l = 0; l < levels; ++l) { t->w[l] = w0 >> l; t->h[l] = h0 >> l; }
+    if (stream) t->stream = (hipStream_t)stream;
+    else { HIPCHK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking)); t->own_stream = true; }
+    for (int l = 0; l < levels; ++l) {
+        HIPCHK(hipMalloc(&t->pc_dev[l], sizeof(float4) * max_points));
+        HIPCHK(hipMalloc(&t->pyr_dev[l], sizeof(float) * 3 * (size_t)t->w[l] * t->h[l]));
+        HIPCHK(hipMemsetAsync(t->pyr_dev[l], 0, sizeof(float) * 3 * (size_t)t->w[l] * t->h[l], t->stream));
+    }
+    HIPCHK(hipMalloc(&t->img_stage_dev, sizeof(float) * (size_t)w0 * h0));
+    HIPCHK(hipMalloc(&t->params_dev, sizeof(LevelParams) * max_batch));
+    HIPCHK(hipHostMalloc(&t->params_host, sizeof(LevelParams) * max_batch));
+    HIPCHK(hipMalloc(&t->partial_dev, sizeof(float) * kNRed * (size_t)t->max_chunks * max_batch));
+    HIPCHK(hipMalloc(&t->out_dev, sizeof(double) * kOutStride * max_batch));
+    HIPCHK(hipHostMalloc(&t->out_host, sizeof(double) * kOutStride * max_batch));
+    HIPCHK(hipMalloc(&t->terms_dev, sizeof(float) * 8 * (size_t)max_points));
+    HIPCHK(hipMalloc(&t->status_dev, sizeof(int) * (size_t)max_points));
+    HIPCHK(hipMalloc(&t->track_dev, sizeof(TrackState) * max_batch));
+    HIPCHK(hipHostMalloc(&t->track_host, sizeof(TrackState) * max_batch));
+    HIPCHK(hipMalloc(&t->tconst_dev, sizeof(TrackConst)));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    *out = t;
+    return SDVGN_OK;
+}
+
+void sdvgn_tracker_destroy(sdvgn_tracker* t) {
+    if (!t) return;
+    hipSetDevice(t->device);
+    hipStreamSynchronize(t->stream);
+    for (int l = 0; l < t->levels; ++l) { hipFree(t->pc_dev[l]); hipFree(t->pyr_dev[l]); }
+    hipFree(t->img_stage_dev); hipFree(t->params_dev); hipHostFree(t->params_host); hipFree(t->partial_dev);
+    hipFree(t->out_dev); hipHostFree(t->out_host); hipFree(t->terms_dev); hipFree(t->status_dev);
+    hipFree(t->track_dev); hipHostFree(t->track_host); hipFree(t->tconst_dev);
+    if (t->own_stream) hipStreamDestroy(t->stream);
+    delete t;
+}
+
+void* sdvgn_tracker_stream(sdvgn_tracker* t) { return t ? (void*)t->stream : nullptr; }
+
+int sdvgn_tracker_set_settings(sdvgn_tracker* t, float huberTH, float coarseCutoffTH, float affA, float affB) {
+    if (!t) return SDVGN_E_ARG;
+    t->huberTH = huberTH; t->coarseCutoffTH = coarseCutoffTH; t->affineOptModeA = affA; t->affineOptModeB = affB;
+    return SDVGN_OK;
+}
+
+int sdvgn_tracker_make_K(sdvgn_tracker* t, float fx, float fy, float cx, float cy) {  // CoarseTracker.cpp:77-106
+    if (!t) return SDVGN_E_ARG;
+    t->fx[0] = fx; t->fy[0] = fy; t->cx[0] = cx; t->cy[0] = cy;
+    for (int l = 1; l < t->levels; ++l) {
+        t->fx[l] = t->fx[l - 1] * 0.5;
+        t->fy[l] = t->fy[l - 1] * 0.5;
+        t->cx[l] = (t->cx[0] + 0.5) / ((int)1 << l) - 0.5;
+        t->cy[l] = (t->cy[0] + 0.5) / ((int)1 << l) - 0.5;
+    }
+    for (int l = 0; l < t->levels; ++l) {
+        const float K[9] = {t->fx[l], 0, t->cx[l], 0, t->fy[l], t->cy[l], 0, 0, 1};
+        gn::inverse3f(K, t->Ki[l]);
+    }
+    t->haveK = true;
+    return SDVGN_OK;
+}
+
+int sdvgn_tracker_get_K(sdvgn_tracker* t, int lvl, float k4[4], float Ki9[9]) {
+    if (!t || lvl < 0 || lvl >= t->levels || !t->haveK) return SDVGN_E_ARG;
+    k4[0] = t->fx[lvl]; k4[1] = t->fy[lvl]; k4[2] = t->cx[lvl]; k4[3] = t->cy[lvl];
+    std::memcpy(Ki9, t->Ki[lvl], sizeof(float) * 9);
+    return SDVGN_OK;
+}
+
+int sdvgn_tracker_set_ref(sdvgn_tracker* t, int lvl, int n, const float* u, const float* v, const float* idepth,
+                          const float* color) {
+    if (!t || lvl < 0 || lvl >= t->levels || n < 0 || n > t->max_points) return SDVGN_E_ARG;
+    if (n > 0 && (!u || !v || !idepth || !color)) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    std::vector<float4> packed(n);
+    for (int i = 0; i < n; ++i) packed[i] = make_float4(u[i], v[i], idepth[i], color[i]);
+    if (n) HIPCHK(hipMemcpyAsync(t->pc_dev[lvl], packed.data(), sizeof(float4) * n, hipMemcpyHostToDevice, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    t->pc_n[lvl] = n;
+    return SDVGN_OK;
+}
+
+int sdvgn_tracker_set_ref_frame(sdvgn_tracker* t, float exposure, double a, double b) {
+    if (!t) return SDVGN_E_ARG;
+    t->ref_exposure = exposure; t->ref_a = a; t->ref_b = b;
+    return SDVGN_OK;
+}
+
+static int build_pyramid(sdvgn_tracker* t, const float* img_dev) {
+    for (int l = 0; l < t->levels; ++l) {
+        const int wl = t->w[l], hl = t->h[l];
+        const int qw = (wl + 1) >> 1, qh = (hl + 1) >> 1;
+        dim3 grid((qw + 255) / 256, qh), block(256);
+        const int has_next = (l + 1 < t->levels) ? 1 : 0;
+        k_pyr_level<<<grid, block, 0, t->stream>>>(l == 0 ? img_dev : nullptr, t->pyr_dev[l],
+                                                   has_next ? t->pyr_dev[l + 1] : nullptr, wl, hl, has_next);
+    }
+    HIPCHK(hipGetLastError());
+    return SDVGN_OK;
+}
+
+int sdvgn_tracker_set_new_image(sdvgn_tracker* t, const float* image, float exposure) {
+    if (!t || !image) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    HIPCHK(hipMemcpyAsync(t->img_stage_dev, image, sizeof(float) * (size_t)t->w[0] * t->h[0], hipMemcpyHostToDevice, t->stream));
+    int rc = build_pyramid(t, t->img_stage_dev);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(t->stream));  // `image` may be pageable: do not return before the copy is done
+    t->new_exposure = exposure; t->haveNew = true;
+    return SDVGN_OK;
+}
+
+int sdvgn_tracker_set_new_image_dev(sdvgn_tracker* t, const float* image_dev, float exposure) {
+    if (!t || !image_dev) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    int rc = build_pyramid(t, image_dev);
+    if (rc) return rc;
+    t->new_exposure = exposure; t->haveNew = true;
+    return SDVGN_OK;
+}
+
+int sdvgn_tracker_set_new_pyr(sdvgn_tracker* t, int lvl, const float* aos3, float exposure) {
+    if (!t || !aos3 || lvl < 0 || lvl >= t->levels) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    HIPCHK(hipMemcpyAsync(t->pyr_dev[lvl], aos3, sizeof(float) * 3 * (size_t)t->w[lvl] * t->h[lvl], hipMemcpyHostToDevice, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    t->new_exposure = exposure; t->haveNew = true;
+    return SDVGN_OK;
+}
+
+int sdvgn_tracker_get_pyr(sdvgn_tracker* t, int lvl, float* out) {
+    if (!t || !out || lvl < 0 || lvl >= t->levels) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    HIPCHK(hipMemcpyAsync(out, t->pyr_dev[lvl], sizeof(float) * 3 * (size_t)t->w[lvl] * t->h[lvl], hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    return SDVGN_OK;
+}
+
+int sdvgn_tracker_calc_res(sdvgn_tracker* t, int lvl, const double pose7[7], double a, double b, float cutoffTH, double out6[6]) {
+    if (!t || !pose7 || !out6) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    return res_gs_sync(t, lvl, pose7, a, b, cutoffTH, true, out6, nullptr, nullptr);
+}
+
+int sdvgn_tracker_calc_gs(sdvgn_tracker* t, int lvl, const double pose7[7], double a, double b, float cutoffTH, double H[64], double b8[8]) {
+    if (!t || !pose7 || !H || !b8) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    return res_gs_sync(t, lvl, pose7, a, b, cutoffTH, false, nullptr, H, b8);
+}
+
+int sdvgn_tracker_res_and_gs(sdvgn_tracker* t, int lvl, const double pose7[7], double a, double b, float cutoffTH,
+                             double out6[6], double H[64], double b8[8]) {
+    if (!t || !pose7) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    return res_gs_sync(t, lvl, pose7, a, b, cutoffTH, false, out6, H, b8);
+}
+
+int sdvgn_tracker_res_and_gs_batch(sdvgn_tracker* t, int lvl, int B, const double* pose7, const double* aff, float cutoffTH,
+                                   double* out_dev) {
+    if (!t || !pose7 || !aff) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    return launch_res_gs(t, lvl, B, pose7, aff, cutoffTH, false, out_dev ? out_dev : t->out_dev);
+}
+
+int sdvgn_tracker_get_point_terms(sdvgn_tracker* t, int lvl, float* terms, int* status) {
+    if (!t || !terms || !status || lvl != t->terms_lvl) return SDVGN_E_STATE;
+    HIPCHK(hipSetDevice(t->device));
+    const int n = t->pc_n[lvl];
+    HIPCHK(hipMemcpyAsync(terms, t->terms_dev, sizeof(float) * 8 * (size_t)n, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipMemcpyAsync(status, t->status_dev, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    return SDVGN_OK;
+}
+
+int sdvgn_tracker_track(sdvgn_tracker* t, double pose7_io[7], double aff_io[2], int coarsestLvl, const double minRes[5],
+                        double lastResiduals[5], double lastFlow[3]) {
+    if (!t || !pose7_io || !aff_io || !minRes || !lastResiduals || !lastFlow) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    return track_host_driven(t, pose7_io, aff_io, coarsestLvl, minRes, lastResiduals, lastFlow);
+}
+
+int sdvgn_tracker_get_trace(sdvgn_tracker* t, double* rows, int cap) {
+    if (!t) return SDVGN_E_ARG;
+    const int n = (int)(t->trace.size() / 15);
+    const int m = n < cap ? n : cap;
+    if (rows && m > 0) std::memcpy(rows, t->trace.data(), sizeof(double) * 15 * m);
+    return n;
+}
+
+int sdvgn_tracker_track_batch(sdvgn_tracker* t, int B, double* pose7_io, double* aff_io, int coarsestLvl,
+                              const double* minRes, double* lastResiduals, double* lastFlow, int* ok) {
+    if (!t || !pose7_io || !aff_io || !lastResiduals || !lastFlow || !ok || B < 1 || B > t->max_batch) return SDVGN_E_ARG;
+    if (coarsestLvl < 0 || coarsestLvl >= 5 || coarsestLvl >= t->levels) return SDVGN_E_ARG;
+    if (!t->haveK || !t->haveNew) return SDVGN_E_STATE;
+    HIPCHK(hipSetDevice(t->device));
+    TrackConst tc;
+    tc.levels = t->levels;
+    for (int l = 0; l < t->levels; ++l) {
+        tc.w[l] = t->w[l]; tc.h[l] = t->h[l]; tc.fx[l] = t->fx[l]; tc.fy[l] = t->fy[l]; tc.cx[l] = t->cx[l]; tc.cy[l] = t->cy[l];
+        std::memcpy(tc.Ki[l], t->Ki[l], sizeof(float) * 9);
+        tc.pc[l] = t->pc_dev[l]; tc.pc_n[l] = t->pc_n[l]; tc.img[l] = t->pyr_dev[l];
+    }
+    tc.huberTH = t->huberTH; tc.coarseCutoffTH = t->coarseCutoffTH; tc.affA = t->affineOptModeA; tc.affB = t->affineOptModeB;
+    tc.ref_exposure = t->ref_exposure; tc.new_exposure = t->new_exposure; tc.ref_a = t->ref_a; tc.ref_b = t->ref_b;
+    tc.coarsestLvl = coarsestLvl;
+    for (int b = 0; b < B; ++b) {
+        TrackState& s = t->track_host[b];
+        std::memcpy(s.pose, pose7_io + 7 * b, sizeof(double) * 7);
+        s.aff[0] = aff_io[2 * b]; s.aff[1] = aff_io[2 * b + 1];
+        for (int i = 0; i < 5; ++i) s.minRes[i] = minRes ? minRes[5 * b + i] : NAN;
+        s.ok = 0; s.ntrials = 0;
+    }
+    HIPCHK(hipMemcpyAsync(t->tconst_dev, &tc, sizeof(tc), hipMemcpyHostToDevice, t->stream));
+    HIPCHK(hipMemcpyAsync(t->track_dev, t->track_host, sizeof(TrackState) * B, hipMemcpyHostToDevice, t->stream));
+    k_track<<<B, kTrackThreads, 0, t->stream>>>(t->tconst_dev, t->track_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(t->track_host, t->track_dev, sizeof(TrackState) * B, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    for (int b = 0; b < B; ++b) {
+        const TrackState& s = t->track_host[b];
+        std::memcpy(pose7_io + 7 * b, s.pose, sizeof(double) * 7);
+        aff_io[2 * b] = s.aff[0]; aff_io[2 * b + 1] = s.aff[1];
+        for (int i = 0; i < 5; ++i) lastResiduals[5 * b + i] = s.lastRes[i];
+        for (int i = 0; i < 3; ++i) lastFlow[3 * b + i] = s.flow[i];
+        ok[b] = s.ok;
+    }
+    return SDVGN_OK;
+}
+
+}  // extern "C"

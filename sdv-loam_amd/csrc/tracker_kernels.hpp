@@ -1,0 +1,299 @@
+// tracker_kernels.hpp -- gfx950 kernels of the photometric coarse tracker.
+//
+//   k_pyr_level   a1  FrameHessian::makeImages               src/FullSystem/HessianBlocks.cpp:107-167
+//   k_res_gs      a4  CoarseTracker::calcRes                 src/FullSystem/CoarseTracker.cpp:486-634
+//                 a5  CoarseTracker::calcGSSSE               src/FullSystem/CoarseTracker.cpp:427-484
+//                 a6  Accumulator9 (the 45-term sum)         src/OptimizationBackend/MatrixAccumulators.h:934-1115
+//                 a9  getInterpolatedElement33               src/util/globalFuncs.h:51-65
+//   k_finalize        1/n normalisation + SCALE_* of H,b     CoarseTracker.cpp:468-483, Vec6 of :625-633
+//
+// Design (MI355X): the reference runs calcRes (scalar loop writing 8 warped planes) and calcGSSSE (SSE loop
+// re-reading them into an in-memory 45x4-lane accumulator).  Here one pass does both: a lane owns a reference
+// point, loads its packed {u,v,idepth,colour} with one coalesced 16-B load, gathers the 2x2 {I,dx,dy} taps of
+// the target level, forms residual / Huber weight / the 8 Jacobian entries in registers and keeps the 45
+// weighted products + energy + counters in 52 VGPRs.  Reduction: DPP row/bcast adds inside the 64-lane wave,
+// one LDS stage across the waves of a workgroup, one float partial row per workgroup; k_finalize adds the
+// partial rows in a fixed order in fp64 (deterministic, no atomics) and emits the scaled 8x8 H, b and the Vec6.
+//
+// Per-point arithmetic is written operation by operation like the reference and the translation unit is built
+// with -ffp-contract=off, so residuals, weights and Jacobian entries are bit-identical to the CPU path; only
+// the order of the sums differs (tree instead of sequential/tiered).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+namespace sdvgn {
+
+constexpr int kNAcc = 45;                 // upper triangle of the 9x9 [J r][J r]^T
+constexpr int kNRed = 52;                 // 45 + E + nE + nSat + nWarped + flowT + flowRT + flowNum
+constexpr int kRedE = 45, kRedNE = 46, kRedNSat = 47, kRedNW = 48, kRedFT = 49, kRedFRT = 50, kRedFN = 51;
+constexpr int kOutStride = 80;            // doubles per problem: out6[6] H[64] b[8] pad[2]
+
+// HessianBlocks.h:33-40
+#define SDVGN_SCALE_XI_ROT 1.0f
+#define SDVGN_SCALE_XI_TRANS 0.5f
+#define SDVGN_SCALE_A 10.0f
+#define SDVGN_SCALE_B 1000.0f
+
+struct LevelParams {  // everything calcRes/calcGSSSE derive from (lvl, refToNew, aff_g2l) before their loops
+    float RKi[9];
+    float t[3];
+    float Ki[9];
+    float fx, fy, cx, cy;
+    float affLL0, affLL1;  // AffLight::fromToVecExposure(...).cast<float>()
+    float b0;              // lastRef_aff_g2l.b
+    float cutoff, huber, maxEnergy;
+    int wl, hl, lvl, n;
+};
+
+// ----------------------------------------------------------------------------------------------------
+// 64-lane sum with DPP: 4 butterfly steps inside each row of 16 lanes, then row_bcast:15 / row_bcast:31.
+// The total lands in lane 63.
+// ----------------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);  // row_mirror
+    v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1,3
+    v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2,3
+    return v;
+}
+
+// a9: bilinear {I,dx,dy} with truncating index and the reference's weight/tap order
+__device__ __forceinline__ void interp33(const float* __restrict__ img, float x, float y, int width, float& o0,
+                                         float& o1, float& o2) {
+    const int ix = (int)x;
+    const int iy = (int)y;
+    const float dx = x - ix;
+    const float dy = y - iy;
+    const float dxdy = dx * dy;
+    const float* bp = img + 3 * (ix + iy * width);
+    const float* bq = bp + 3 * width;
+    const float a0 = bp[0], a1 = bp[1], a2 = bp[2], b0 = bp[3], b1 = bp[4], b2 = bp[5];
+    const float c0 = bq[0], c1 = bq[1], c2 = bq[2], d0 = bq[3], d1 = bq[4], d2 = bq[5];
+    const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+    o0 = ((w11 * d0 + w01 * c0) + w10 * b0) + w00 * a0;
+    o1 = ((w11 * d1 + w01 * c1) + w10 * b1) + w00 * a1;
+    o2 = ((w11 * d2 + w01 * c2) + w10 * b2) + w00 * a2;
+}
+
+__device__ __forceinline__ void project(const float* M, const float* t, float x, float y, float id, bool plus,
+                                        float& p0, float& p1, float& p2) {
+    const float m0 = (M[0] * x + M[1] * y) + M[2] * 1.0f;
+    const float m1 = (M[3] * x + M[4] * y) + M[5] * 1.0f;
+    const float m2 = (M[6] * x + M[7] * y) + M[8] * 1.0f;
+    if (plus) { p0 = m0 + t[0] * id; p1 = m1 + t[1] * id; p2 = m2 + t[2] * id; }
+    else      { p0 = m0 - t[0] * id; p1 = m1 - t[1] * id; p2 = m2 - t[2] * id; }
+}
+
+// One reference point: calcRes body (:517-600) followed by the calcGSSSE body (:444-465) on the values that
+// calcRes would have appended to the warped buffers.  acc[] is the lane's private accumulator row.
+template <bool WRITE_TERMS>
+__device__ __forceinline__ void point_res_gs(const LevelParams& P, const float* __restrict__ img, float4 pc, int i,
+                                             float* acc, float* __restrict__ terms, int* __restrict__ status) {
+    const float x = pc.x, y = pc.y, id = pc.z, refColor = pc.w;
+    float p0, p1, p2;
+    project(P.RKi, P.t, x, y, id, true, p0, p1, p2);
+    const float u = p0 / p2;
+    const float v = p1 / p2;
+    const float Ku = P.fx * u + P.cx;
+    const float Kv = P.fy * v + P.cy;
+    const float new_idepth = id / p2;
+
+    if (P.lvl == 0 && (i & 31) == 0) {  // flow indicators :538-566
+        float q0, q1, q2;
+        project(P.Ki, P.t, x, y, id, true, q0, q1, q2);
+        const float KuT = P.fx * (q0 / q2) + P.cx, KvT = P.fy * (q1 / q2) + P.cy;
+        project(P.Ki, P.t, x, y, id, false, q0, q1, q2);
+        const float KuT2 = P.fx * (q0 / q2) + P.cx, KvT2 = P.fy * (q1 / q2) + P.cy;
+        project(P.RKi, P.t, x, y, id, false, q0, q1, q2);
+        const float Ku3 = P.fx * (q0 / q2) + P.cx, Kv3 = P.fy * (q1 / q2) + P.cy;
+        acc[kRedFT] += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
+        acc[kRedFT] += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
+        acc[kRedFRT] += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
+        acc[kRedFRT] += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
+        acc[kRedFN] += 2;
+    }
+
+    int st = 0;
+    float hit0 = 0, hit1 = 0, hit2 = 0, residual = 0, hw = 0;
+    if (Ku > 2 && Kv > 2 && Ku < P.wl - 3 && Kv < P.hl - 3 && new_idepth > 0) {
+        interp33(img, Ku, Kv, P.wl, hit0, hit1, hit2);
+        if (isfinite(hit0)) {
+            residual = hit0 - (float)(P.affLL0 * refColor + P.affLL1);
+            const float ar = fabsf(residual);
+            hw = ar < P.huber ? 1.0f : P.huber / ar;
+            if (ar > P.cutoff) {
+                st = 2;
+                acc[kRedE] += P.maxEnergy;
+                acc[kRedNE] += 1;
+                acc[kRedNSat] += 1;
+            } else {
+                st = 1;
+                acc[kRedE] += hw * residual * residual * (2 - hw);
+                acc[kRedNE] += 1;
+                acc[kRedNW] += 1;
+                const float dx = hit1 * P.fx;
+                const float dy = hit2 * P.fy;
+                float J[9];
+                J[0] = new_idepth * dx;
+                J[1] = new_idepth * dy;
+                J[2] = 0.0f - new_idepth * (u * dx + v * dy);
+                J[3] = 0.0f - ((u * v) * dx + dy * (1.0f + v * v));
+                J[4] = (u * v) * dy + dx * (1.0f + u * u);
+                J[5] = u * dy - v * dx;
+                J[6] = P.affLL0 * (P.b0 - refColor);
+                J[7] = -1.0f;
+                J[8] = residual;
+                int k = 0;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    const float Jw = J[r] * hw;
+#pragma unroll
+                    for (int c = r; c < 9; ++c) { acc[k] += Jw * J[c]; ++k; }
+                }
+            }
+        }
+    }
+    if (WRITE_TERMS) {
+        const int n = P.n;
+        const bool in = (st == 1);
+        terms[0 * n + i] = in ? new_idepth : 0.0f;
+        terms[1 * n + i] = in ? u : 0.0f;
+        terms[2 * n + i] = in ? v : 0.0f;
+        terms[3 * n + i] = in ? hit1 : 0.0f;
+        terms[4 * n + i] = in ? hit2 : 0.0f;
+        terms[5 * n + i] = in ? residual : 0.0f;
+        terms[6 * n + i] = in ? hw : 0.0f;
+        terms[7 * n + i] = in ? refColor : 0.0f;
+        status[i] = st;
+    }
+}
+
+// Block-level reduction of the per-lane accumulator rows: thread k < kNRed writes the block total of value k
+// to dst[k].  smem: [nwaves][kNRed] floats.  (Callers must __syncthreads() before reading dst if it is in LDS.)
+template <typename OutT>
+__device__ __forceinline__ void block_reduce_to(float* acc, float* smem, OutT* __restrict__ dst) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kNRed; ++k) {
+        const float s = wave_sum_to_lane63(acc[k]);
+        if (lane == 63) smem[wave * kNRed + k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNRed) {
+        double s = 0;
+        for (int w = 0; w < nwaves; ++w) s += (double)smem[w * kNRed + threadIdx.x];
+        dst[threadIdx.x] = (OutT)s;
+    }
+}
+
+// Tail of calcGSSSE (:468-483: 1/n, cast to double, SCALE_* on rows and columns) and of calcRes (:625-633: the Vec6)
+// from the 52 totals S.  Threads 0..72 of the calling workgroup each write a few of the kOutStride doubles of o.
+__device__ __forceinline__ void finalize_outputs(const double* S, int tid, double* o) {
+    const int nW = (int)S[kRedNW];
+    const int n = (nW + 3) & ~3;              // zero-padded to a multiple of 4 (:603-615)
+    const double inv_n = (double)(1.0f / n);  // `* (1.0f/n)` :469-470
+    const float sc[8] = {SDVGN_SCALE_XI_ROT, SDVGN_SCALE_XI_ROT, SDVGN_SCALE_XI_ROT, SDVGN_SCALE_XI_TRANS,
+                         SDVGN_SCALE_XI_TRANS, SDVGN_SCALE_XI_TRANS, SDVGN_SCALE_A, SDVGN_SCALE_B};
+    if (tid < 72) {
+        int r, c;
+        if (tid < 64) { r = tid >> 3; c = tid & 7; } else { r = tid - 64; c = 8; }
+        const int lo = r < c ? r : c, hi = r < c ? c : r;
+        const int idx = lo * 9 - (lo * (lo - 1)) / 2 + (hi - lo);  // upper-triangular row-major index
+        double v = S[idx] * inv_n;
+        if (c < 8) { v *= sc[c]; v *= sc[r]; o[6 + r * 8 + c] = v; }
+        else       { v *= sc[r]; o[6 + 64 + r] = v; }
+    }
+    if (tid == 72) {
+        const float E = (float)S[kRedE];
+        const float fT = (float)S[kRedFT], fRT = (float)S[kRedFRT], fN = (float)S[kRedFN];
+        const int nE = (int)S[kRedNE], nSat = (int)S[kRedNSat];
+        o[0] = E;
+        o[1] = nE;
+        o[2] = fT / (fN + 0.1);
+        o[3] = 0;
+        o[4] = fRT / (fN + 0.1);
+        o[5] = nSat / (float)nE;
+        o[78] = nW;
+        o[79] = n;
+    }
+}
+
+// grid = (chunks, B).  params[b] describes problem b (pose/affine specific); all problems share the reference
+// points `pc` and the target level image `img`.  partial: [B][chunks][kNRed] floats.
+template <bool WRITE_TERMS>
+__global__ void __launch_bounds__(256) k_res_gs(const float4* __restrict__ pc, const float* __restrict__ img,
+                                                const LevelParams* __restrict__ params, float* __restrict__ partial,
+                                                float* __restrict__ terms, int* __restrict__ status) {
+    __shared__ float smem[4 * kNRed];
+    const LevelParams P = params[blockIdx.y];
+    float acc[kNRed];
+#pragma unroll
+    for (int k = 0; k < kNRed; ++k) acc[k] = 0.0f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += gridDim.x * blockDim.x)
+        point_res_gs<WRITE_TERMS>(P, img, pc[i], i, acc, terms, status);
+    block_reduce_to<float>(acc, smem, partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kNRed);
+}
+
+// Deterministic fp64 combine of the partial rows + the tail of calcGSSSE (:468-483) and calcRes (:625-633).
+// grid = B, block = 128.  out: [B][kOutStride] doubles.
+__global__ void __launch_bounds__(128) k_finalize(const float* __restrict__ partial, int chunks, double* __restrict__ out) {
+    __shared__ double S[kNRed];
+    const int b = blockIdx.x;
+    if (threadIdx.x < kNRed) {
+        double s = 0;
+        const float* p = partial + (size_t)b * chunks * kNRed + threadIdx.x;
+        for (int c = 0; c < chunks; ++c) s += (double)p[(size_t)c * kNRed];
+        S[threadIdx.x] = s;
+    }
+    __syncthreads();
+    finalize_outputs(S, threadIdx.x, out + (size_t)b * kOutStride);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// a1: one pyramid level per launch.  A thread owns a 2x2 quad of level-l pixels: it writes their {I,dx,dy}
+// (I is copied from `src_plane` on level 0, already in place otherwise) and the 2x2 mean into level l+1.
+// Gradients use flat indices like the reference (idx+-1 wraps across rows at x=0 / x=wl-1); rows 0 and hl-1,
+// which the reference leaves uninitialised, are written as 0.
+// ----------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pyr_level(const float* __restrict__ src_plane, float* __restrict__ aos,
+                                                   float* __restrict__ aos_next, int wl, int hl, int has_next) {
+    const int qx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int qy = blockIdx.y;
+    const int qw = (wl + 1) >> 1;
+    if (qx >= qw) return;
+    const int wn = wl >> 1, hn = hl >> 1;
+    const int total = wl * hl;
+    float Iq[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = 2 * qx + (k & 1), y = 2 * qy + (k >> 1);
+        if (x >= wl || y >= hl) continue;
+        const int idx = x + y * wl;
+        auto I_at = [&](int j) -> float { return src_plane ? src_plane[j] : aos[3 * j]; };
+        const float I = I_at(idx);
+        Iq[k] = I;
+        float dx = 0.0f, dy = 0.0f;
+        if (idx >= wl && idx < total - wl) {
+            dx = 0.5f * (I_at(idx + 1) - I_at(idx - 1));
+            dy = 0.5f * (I_at(idx + wl) - I_at(idx - wl));
+            if (!isfinite(dx)) dx = 0;
+            if (!isfinite(dy)) dy = 0;
+        }
+        if (src_plane) aos[3 * idx] = I;
+        aos[3 * idx + 1] = dx;
+        aos[3 * idx + 2] = dy;
+    }
+    if (has_next && qx < wn && qy < hn)
+        aos_next[3 * (qx + qy * wn)] = 0.25f * (((Iq[0] + Iq[1]) + Iq[2]) + Iq[3]);
+}
+
+}  // namespace sdvgn
