@@ -74,7 +74,7 @@ def check_res_gs(G, O, lvl, pose, a, b, cutoff):
     else:
         assert np.all(np.isnan(Hg)) == np.all(np.isnan(Ho))
     r2, H2, b2 = G.resAndGS(lvl, pose, a, b, cutoff)
-    assert np.array_equal(r2, rg) and np.array_equal(H2, Hg) and np.array_equal(b2, bg)   # deterministic
+    assert np.array_equal(r2, rg, equal_nan=True) and np.array_equal(H2, Hg, equal_nan=True) and np.array_equal(b2, bg, equal_nan=True)   # deterministic
     return rg, ro
 
 
