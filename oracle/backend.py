@@ -1,0 +1,164 @@
+"""ctypes front-end of the back-end oracle (oracle/orc_backend.cpp) -- TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+
+import numpy as np
+
+from . import f32p, f64p, i32p, lib
+
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+vp = C.c_void_p
+_bound = False
+
+
+def _L():
+    global _bound
+    L = lib()
+    if not _bound:
+        L.orc_ef_create.restype = vp
+        L.orc_ef_create.argtypes = [C.c_int, C.c_int]
+        L.orc_ef_destroy.argtypes = [vp]
+        L.orc_ef_set_calib.argtypes = [vp, f64p, f64p]
+        L.orc_ef_set_frames.argtypes = [vp, C.c_int, f64p, f64p, f64p, i32p, f32p, f32p]
+        L.orc_ef_set_frame_state.argtypes = [vp, C.c_int, f64p]
+        L.orc_ef_set_frame_image.argtypes = [vp, C.c_int, f32p]
+        L.orc_ef_set_points.argtypes = [vp, C.c_int, i32p, f32p, f32p, f32p, f32p, f32p, f32p, u8p, u8p]
+        L.orc_ef_set_point_idepth.argtypes = [vp, f32p, f32p]
+        L.orc_ef_set_residuals.argtypes = [vp, C.c_int, i32p, i32p, i32p, u8p, f64p, u8p, u8p]
+        L.orc_ef_set_marg_prior.argtypes = [vp, f64p, f64p]
+        L.orc_ef_set_nullspaces.argtypes = [vp, C.c_int, f64p]
+        L.orc_ef_set_precalc.argtypes = [vp]
+        L.orc_ef_set_adjoints.argtypes = [vp]
+        L.orc_ef_linearize_all.argtypes = [vp]
+        L.orc_ef_linearize_all.restype = C.c_double
+        L.orc_ef_apply_res.argtypes = [vp]
+        L.orc_ef_solve_system.argtypes = [vp, C.c_int, C.c_double]
+        L.orc_ef_dim.argtypes = [vp]
+        L.orc_ef_dim.restype = C.c_int
+        L.orc_ef_get_system.argtypes = [vp] + [vp] * 7
+        L.orc_ef_get_residual_J.argtypes = [vp, C.c_int, f32p]
+        L.orc_ef_get_residual_state.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.orc_ef_get_points.argtypes = [vp, f32p]
+        L.orc_ef_get_frame_steps.argtypes = [vp, f64p, f64p]
+        L.orc_ef_get_top_acc.argtypes = [vp, f32p]
+        L.orc_ef_get_precalc.argtypes = [vp, C.c_int, C.c_int, f32p]
+        L.orc_ef_get_adjoints.argtypes = [vp, f64p, f64p]
+        L.orc_ef_res_in_A.argtypes = [vp]
+        L.orc_ef_res_in_A.restype = C.c_int
+        _bound = True
+    return L
+
+
+class OracleEF:
+    """Flattened EnergyFunctional window on the CPU oracle; method names follow the reference
+    (EnergyFunctional.h:51-72, FullSystemOptimize.cpp)."""
+
+    def __init__(self, w, h):
+        self.L = _L()
+        self.w, self.h = w, h
+        self.h_ = self.L.orc_ef_create(w, h)
+
+    def __del__(self):
+        try:
+            self.L.orc_ef_destroy(self.h_)
+        except Exception:
+            pass
+
+    def load(self, W):
+        c = np.ascontiguousarray
+        self.nF, self.nP, self.nR = W.nF, W.nP, W.nR
+        self.L.orc_ef_set_calib(self.h_, c(W.value_scaled, np.float64), c(W.value_minus_value_zero, np.float64))
+        self.L.orc_ef_set_frames(self.h_, W.nF, c(W.evalPT, np.float64).reshape(-1), c(W.state, np.float64).reshape(-1),
+                                 c(W.state_zero, np.float64).reshape(-1), c(W.frameID, np.int32), c(W.ab_exposure, np.float32),
+                                 c(W.frameEnergyTH, np.float32))
+        for k in range(W.nF):
+            self.L.orc_ef_set_frame_image(self.h_, k, c(W.pyr0[k], np.float32).reshape(-1))
+        self.L.orc_ef_set_points(self.h_, W.nP, c(W.host, np.int32), c(W.u, np.float32), c(W.v, np.float32), c(W.idepth, np.float32),
+                                 c(W.idepth_zero, np.float32), c(W.color, np.float32).reshape(-1), c(W.weights, np.float32).reshape(-1),
+                                 c(W.hasDepthPrior, np.uint8), c(W.isFromSensor, np.uint8))
+        self.L.orc_ef_set_residuals(self.h_, W.nR, c(W.r_point, np.int32), c(W.r_target, np.int32), c(W.r_state, np.int32),
+                                    c(W.r_hasMatcher, np.uint8), c(W.r_matcher, np.float64).reshape(-1), c(W.r_isLinearized, np.uint8),
+                                    c(W.r_isActive, np.uint8))
+        self.L.orc_ef_set_marg_prior(self.h_, c(W.HM, np.float64).reshape(-1), c(W.bM, np.float64))
+        if getattr(W, "nullspaces", None) is not None:
+            ns = c(W.nullspaces, np.float64)
+            self.L.orc_ef_set_nullspaces(self.h_, ns.shape[0], ns.reshape(-1))
+        self.setAdjointsF()
+        self.setPrecalcValues()
+        return self
+
+    def setPrecalcValues(self):
+        self.L.orc_ef_set_precalc(self.h_)
+
+    def setAdjointsF(self):
+        self.L.orc_ef_set_adjoints(self.h_)
+
+    def set_frame_state(self, idx, state10):
+        self.L.orc_ef_set_frame_state(self.h_, idx, np.ascontiguousarray(state10, np.float64))
+
+    def set_point_idepth(self, idepth, idepth_zero):
+        self.L.orc_ef_set_point_idepth(self.h_, np.ascontiguousarray(idepth, np.float32), np.ascontiguousarray(idepth_zero, np.float32))
+
+    def linearizeAll(self):
+        return self.L.orc_ef_linearize_all(self.h_)
+
+    def applyRes(self):
+        self.L.orc_ef_apply_res(self.h_)
+
+    def solveSystemF(self, iteration, lam):
+        self.L.orc_ef_solve_system(self.h_, iteration, lam)
+
+    @property
+    def dim(self):
+        return self.L.orc_ef_dim(self.h_)
+
+    def system(self):
+        n = self.dim
+        out = dict(HA=np.zeros((n, n)), bA=np.zeros(n), Hsc=np.zeros((n, n)), bsc=np.zeros(n), HFinal=np.zeros((n, n)),
+                   bFinal=np.zeros(n), x=np.zeros(n))
+        self.L.orc_ef_get_system(self.h_, *[out[k].ctypes.data_as(vp) for k in ("HA", "bA", "Hsc", "bsc", "HFinal", "bFinal", "x")])
+        return out
+
+    def residual_J(self, which):
+        out = np.zeros((self.nR, 24), np.float32)
+        self.L.orc_ef_get_residual_J(self.h_, which, out.reshape(-1))
+        return out
+
+    def residual_state(self):
+        ss = np.zeros(self.nR, np.int32)
+        sn = np.zeros(self.nR, np.int32)
+        en = np.zeros(self.nR, np.float64)
+        eo = np.zeros(self.nR, np.float64)
+        ac = np.zeros(self.nR, np.uint8)
+        self.L.orc_ef_get_residual_state(self.h_, ss.ctypes.data_as(vp), sn.ctypes.data_as(vp), en.ctypes.data_as(vp),
+                                         eo.ctypes.data_as(vp), ac.ctypes.data_as(vp))
+        return dict(state=ss, new_state=sn, new_energy=en, energy_with_outlier=eo, active=ac)
+
+    def points(self):
+        out = np.zeros((self.nP, 9), np.float32)
+        self.L.orc_ef_get_points(self.h_, out.reshape(-1))
+        return out
+
+    def frame_steps(self):
+        s = np.zeros(6 * self.nF)
+        c4 = np.zeros(4)
+        self.L.orc_ef_get_frame_steps(self.h_, s, c4)
+        return s.reshape(self.nF, 6), c4
+
+    def top_acc(self):
+        out = np.zeros((self.nF * self.nF, 13, 13), np.float32)
+        self.L.orc_ef_get_top_acc(self.h_, out.reshape(-1))
+        return out
+
+    def precalc(self, h, t):
+        out = np.zeros(27, np.float32)
+        self.L.orc_ef_get_precalc(self.h_, h, t, out)
+        return out
+
+    def adjoints(self):
+        a = np.zeros(self.nF * self.nF * 36)
+        b = np.zeros(self.nF * self.nF * 36)
+        self.L.orc_ef_get_adjoints(self.h_, a, b)
+        return a.reshape(-1, 6, 6), b.reshape(-1, 6, 6)
+
+    def resInA(self):
+        return self.L.orc_ef_res_in_A(self.h_)

@@ -1,0 +1,992 @@
+// oracle/orc_backend.cpp -- TEST INFRASTRUCTURE ONLY (CPU oracle). PARITY UNPINNED.
+//
+// Plain C++ restatement of the reference's sliding-window back end, SURVEY.md section 8 rows b1-b7, on a
+// flattened copy of the EnergyFunctional graph (frames / points / residuals in the reference's iteration
+// order: `for f in frames, for p in f->points, for r in p->residualsAll`):
+//   b1 PointFrameResidual::linearize / applyRes      src/FullSystem/Residuals.cpp:60-224, 252-275
+//      projectPoint helpers                          src/FullSystem/ResidualProjections.h:20-59
+//      FrameFramePrecalc::set                        src/FullSystem/HessianBlocks.cpp:169-195
+//   b2 AccumulatedTopHessianSSE::addPoint<0/1>       src/OptimizationBackend/AccumulatedTopHessian.cpp:14-112
+//   b3 AccumulatorApprox                             src/OptimizationBackend/MatrixAccumulators.h:560-932
+//   b4 stitchDoubleInternal / stitchDoubleMT         AccumulatedTopHessian.cpp:181-242, .h:63-114
+//   b5 setAdjointsF / setDeltaF                      src/OptimizationBackend/EnergyFunctional.cpp:21-71,131-156
+//   b6 solveSystemF / resubstituteF_MT               EnergyFunctional.cpp:650-759, 221-282
+//   b7 AccumulatedSCHessianSSE::addPoint / stitch    src/OptimizationBackend/AccumulatedSCHessian.cpp:10-135
+//      AccumulatorXX / AccumulatorX                  MatrixAccumulators.h:13-66,148-208
+// The reference cannot be compiled here (Eigen3/Boost/ROS/OpenCV absent) and has no tests for this path:
+// "parity unpinned"; pinned by analytic known-answer tests in tests/test_oracle_backend.py.
+// Float32 / float64 usage, operand order and the 1k/1M tiered accumulation follow the reference.
+#include "orc_math.hpp"
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+
+namespace orcb {
+using namespace orc;
+
+static const int CPARS = 4;
+static const float SCALE_XI_ROT = 1.0f, SCALE_XI_TRANS = 0.5f, SCALE_F = 50.0f, SCALE_C = 50.0f, SCALE_A = 10.0f,
+                   SCALE_B = 1000.0f, SCALE_IDEPTH = 1.0f;
+// settings.cpp:21-27,65,101
+static const float setting_idepthFixPrior = 50 * 50, setting_initialRotPrior = 1e11, setting_initialTransPrior = 1e10,
+                   setting_initialCalibHessian = 5e9, setting_outlierTHSumComponent = 50 * 50, setting_huberTH = 6;
+static const int patternNum = 8;
+static const int patternP[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};  // settings.cpp:250
+
+enum ResState { IN = 0, OOB = 1, OUTLIER = 2 };
+
+// ---- b3: AccumulatorApprox (MatrixAccumulators.h:560-932) ---------------------------------------------
+struct AccumulatorApprox {
+    float Data[60], Data1k[60], Data1m[60];
+    float TR[32], TR1k[32], TR1m[32];
+    float BR[8], BR1k[8], BR1m[8];
+    float numIn1, numIn1k, numIn1m;
+    size_t num;
+    float H[13][13];
+    void initialize() {
+        std::memset(this, 0, sizeof(*this));
+    }
+    void shiftUp(bool force) {
+        if (numIn1 > 1000 || force) {
+            for (int i = 0; i < 60; ++i) Data1k[i] = Data[i] + Data1k[i];
+            for (int i = 0; i < 32; ++i) TR1k[i] = TR[i] + TR1k[i];
+            for (int i = 0; i < 8; ++i) BR1k[i] = BR[i] + BR1k[i];
+            numIn1k += numIn1; numIn1 = 0;
+            std::memset(Data, 0, sizeof(Data)); std::memset(TR, 0, sizeof(TR)); std::memset(BR, 0, sizeof(BR));
+        }
+        if (numIn1k > 1000 || force) {
+            for (int i = 0; i < 60; ++i) Data1m[i] = Data1k[i] + Data1m[i];
+            for (int i = 0; i < 32; ++i) TR1m[i] = TR1k[i] + TR1m[i];
+            for (int i = 0; i < 8; ++i) BR1m[i] = BR1k[i] + BR1m[i];
+            numIn1m += numIn1k; numIn1k = 0;
+            std::memset(Data1k, 0, sizeof(Data1k)); std::memset(TR1k, 0, sizeof(TR1k)); std::memset(BR1k, 0, sizeof(BR1k));
+        }
+    }
+    // update(x4,x6,y4,y6,a,b,c) :715-808 with x = [x4;x6], y = [y4;y6]
+    void update(const float* x4, const float* x6, const float* y4, const float* y6, float a, float b, float c) {
+        float x[10], y[10];
+        for (int i = 0; i < 4; ++i) { x[i] = x4[i]; y[i] = y4[i]; }
+        for (int i = 0; i < 6; ++i) { x[4 + i] = x6[i]; y[4 + i] = y6[i]; }
+        int idx = 0;
+        for (int r = 0; r < 10; ++r)
+            for (int cc = r; cc < 10; ++cc) {
+                Data[idx] += a * x[cc] * x[r] + c * y[cc] * y[r] + b * (x[cc] * y[r] + y[cc] * x[r]);
+                idx++;
+            }
+        num++; numIn1++;
+        shiftUp(false);
+    }
+    void updateTopRight(const float* x4, const float* x6, const float* y4, const float* y6, float TR00, float TR10,
+                        float TR01, float TR11, float TR02, float TR12) {  // :810-859
+        float x[10], y[10];
+        for (int i = 0; i < 4; ++i) { x[i] = x4[i]; y[i] = y4[i]; }
+        for (int i = 0; i < 6; ++i) { x[4 + i] = x6[i]; y[4 + i] = y6[i]; }
+        for (int i = 0; i < 10; ++i) {
+            TR[3 * i + 0] += x[i] * TR00 + y[i] * TR10;
+            TR[3 * i + 1] += x[i] * TR01 + y[i] * TR11;
+            TR[3 * i + 2] += x[i] * TR02 + y[i] * TR12;
+        }
+    }
+    void updateBotRight(float a00, float a01, float a02, float a11, float a12, float a22) {  // :861-875
+        BR[0] += a00; BR[1] += a01; BR[2] += a02; BR[3] += a11; BR[4] += a12; BR[5] += a22;
+    }
+    void finish() {  // :584-616
+        std::memset(H, 0, sizeof(H));
+        shiftUp(true);
+        int idx = 0;
+        for (int r = 0; r < 10; ++r)
+            for (int c = r; c < 10; ++c) { H[r][c] = H[c][r] = Data1m[idx]; idx++; }
+        idx = 0;
+        for (int r = 0; r < 10; ++r)
+            for (int c = 0; c < 3; ++c) { H[r][c + 10] = H[c + 10][r] = TR1m[idx]; idx++; }
+        H[10][10] = BR1m[0];
+        H[10][11] = H[11][10] = BR1m[1];
+        H[10][12] = H[12][10] = BR1m[2];
+        H[11][11] = BR1m[3];
+        H[11][12] = H[12][11] = BR1m[4];
+        H[12][12] = BR1m[5];
+        num = (size_t)(numIn1 + numIn1k + numIn1m);
+    }
+};
+
+// ---- AccumulatorXX<i,j> / AccumulatorX<i> (MatrixAccumulators.h:13-66,148-208), i,j <= 8 ---------------
+struct AccXX {
+    int I, J;
+    float A[64], A1k[64], A1m[64];
+    float numIn1, numIn1k, numIn1m;
+    size_t num;
+    void initialize(int i, int j) { std::memset(this, 0, sizeof(*this)); I = i; J = j; }
+    void shiftUp(bool force) {
+        if (numIn1 > 1000 || force) {
+            for (int k = 0; k < I * J; ++k) { A1k[k] += A[k]; A[k] = 0; }
+            numIn1k += numIn1; numIn1 = 0;
+        }
+        if (numIn1k > 1000 || force) {
+            for (int k = 0; k < I * J; ++k) { A1m[k] += A1k[k]; A1k[k] = 0; }
+            numIn1m += numIn1k; numIn1k = 0;
+        }
+    }
+    void update(const float* L, const float* R, float w) {  // A += w*L*R^T
+        for (int r = 0; r < I; ++r) {
+            const float wl = w * L[r];
+            for (int c = 0; c < J; ++c) A[r * J + c] += wl * R[c];
+        }
+        numIn1++;
+        shiftUp(false);
+    }
+    void updateVec(const float* L, float w) {  // AccumulatorX::update: A += w*L   (J == 1)
+        for (int r = 0; r < I; ++r) A[r] += w * L[r];
+        numIn1++;
+        shiftUp(false);
+    }
+    void finish() { shiftUp(true); num = (size_t)(numIn1 + numIn1k + numIn1m); }
+};
+
+struct Precalc {  // FrameFramePrecalc, HessianBlocks.h:51-79
+    float PRE_RTll[9], PRE_KRKiTll[9], PRE_RKiTll[9], PRE_RTll_0[9];
+    float PRE_aff_mode[2], PRE_b0_mode;
+    float PRE_tTll[3], PRE_KtTll[3], PRE_tTll_0[3];
+};
+
+struct RawJ {  // live part of RawResidualJacobian (RawResidualJacobian.h:7-36)
+    float resF[2];
+    float Jpdxi[2][6];
+    float Jpdc[2][4];
+    float Jpdd[2];
+};
+
+struct Frame {
+    SE3 evalPT, PRE_worldToCam, PRE_camToWorld;
+    double state[10], state_zero[10], state_scaled[10];
+    double prior[6], delta_prior[6], delta[6];
+    double step[10];
+    int frameID;
+    float ab_exposure, frameEnergyTH;
+    std::vector<float> dI;  // level-0 AoS {I,dx,dy}
+};
+
+struct Point {
+    int host;
+    float u, v, idepth, idepth_zero, idepth_scaled, idepth_zero_scaled;
+    float color[8], weights[8];
+    bool hasDepthPrior, isFromSensor;
+    int r0, r1;  // residual range
+    // EFPoint
+    float priorF, deltaF, bdSumF, HdiF, Hdd_accLF, Hcd_accLF[4], bd_accLF, Hdd_accAF, Hcd_accAF[4], bd_accAF;
+    float step, idepth_hessian;
+};
+
+struct Residual {
+    int point, host, target;
+    int state_state, state_NewState;
+    double state_energy, state_NewEnergy, state_NewEnergyWithOutlier;
+    bool hasMatcher;
+    double matcher[2];
+    RawJ Jnew;   // PointFrameResidual::J
+    RawJ Jef;    // EFResidual::J
+    float res_toZeroF[2];
+    float JpJdF[8];
+    bool isLinearized, isActive;
+    float centerProjectedTo[3];
+};
+
+struct EF {
+    int w, h, nF;
+    // CalibHessian
+    double value_scaled[4], value_minus_value_zero[4];
+    float fxl, fyl, cxl, cyl, fxli, fyli, cxli, cyli;
+    float wM3G, hM3G;
+    std::vector<Frame> frames;
+    std::vector<Point> points;
+    std::vector<Residual> res;
+    std::vector<Precalc> precalc;            // [host*nF + target]
+    std::vector<double> adHost, adTarget;    // [h + t*nF][36]
+    std::vector<float> adHostF, adTargetF;
+    std::vector<float> adHTdeltaF;           // [h + t*nF][6]
+    float cDeltaF[4];
+    double cPrior[4];
+    float cPriorF[4];
+    std::vector<double> HM, bM;
+    std::vector<std::vector<double>> nullspaces;
+    // outputs of the last solve
+    std::vector<double> HA, bA, Hsc, bsc, HFinal, bFinal, lastX;
+    std::vector<AccumulatorApprox> accA, accL;
+    int resInA, resInL;
+    double calibStep[4];
+};
+
+static void mat3f_mul(const float* A, const float* B, float* C) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) C[i * 3 + j] = (A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j]) + A[i * 3 + 2] * B[6 + j];
+}
+static void mat3f_vec(const float* A, const float* v, float* o) {
+    for (int i = 0; i < 3; ++i) o[i] = (A[i * 3] * v[0] + A[i * 3 + 1] * v[1]) + A[i * 3 + 2] * v[2];
+}
+
+// FrameHessian::setState (HessianBlocks.h:131-143)
+static void frame_set_state(Frame& f, const double* state) {
+    for (int i = 0; i < 10; ++i) f.state[i] = state[i];
+    for (int i = 0; i < 3; ++i) f.state_scaled[i] = SCALE_XI_TRANS * state[i];
+    for (int i = 3; i < 6; ++i) f.state_scaled[i] = SCALE_XI_ROT * state[i];
+    f.state_scaled[6] = SCALE_A * state[6]; f.state_scaled[7] = SCALE_B * state[7];
+    f.state_scaled[8] = SCALE_A * state[8]; f.state_scaled[9] = SCALE_B * state[9];
+    f.PRE_worldToCam = se3_mul(se3_exp(f.state_scaled), f.evalPT);
+    f.PRE_camToWorld = se3_inverse(f.PRE_worldToCam);
+}
+
+// CalibHessian::setValueScaled-equivalent for the float views (HessianBlocks.h:302-330)
+static void calib_update(EF* E) {
+    E->fxl = (float)E->value_scaled[0]; E->fyl = (float)E->value_scaled[1];
+    E->cxl = (float)E->value_scaled[2]; E->cyl = (float)E->value_scaled[3];
+    E->fxli = 1.0f / E->fxl; E->fyli = 1.0f / E->fyl;
+    E->cxli = -E->cxl / E->fxl; E->cyli = -E->cyl / E->fyl;
+}
+
+// FrameFramePrecalc::set (HessianBlocks.cpp:169-195) for every (host,target) + EnergyFunctional::setDeltaF
+static void set_precalc(EF* E) {
+    const int nF = E->nF;
+    E->precalc.resize((size_t)nF * nF);
+    float K[9] = {E->fxl, 0, E->cxl, 0, E->fyl, E->cyl, 0, 0, 1};
+    float Ki[9];
+    inv3f(K, Ki);
+    for (int h = 0; h < nF; ++h)
+        for (int t = 0; t < nF; ++t) {
+            Precalc& P = E->precalc[(size_t)h * nF + t];
+            const Frame& host = E->frames[h];
+            const Frame& target = E->frames[t];
+            SE3 l0 = se3_mul(target.evalPT, se3_inverse(host.evalPT));
+            double R[9];
+            quat_to_R(l0.q, R);
+            for (int i = 0; i < 9; ++i) P.PRE_RTll_0[i] = (float)R[i];
+            for (int i = 0; i < 3; ++i) P.PRE_tTll_0[i] = (float)l0.t[i];
+            SE3 l = se3_mul(target.PRE_worldToCam, host.PRE_camToWorld);
+            quat_to_R(l.q, R);
+            for (int i = 0; i < 9; ++i) P.PRE_RTll[i] = (float)R[i];
+            for (int i = 0; i < 3; ++i) P.PRE_tTll[i] = (float)l.t[i];
+            float KR[9];
+            mat3f_mul(K, P.PRE_RTll, KR);
+            mat3f_mul(KR, Ki, P.PRE_KRKiTll);
+            mat3f_mul(P.PRE_RTll, Ki, P.PRE_RKiTll);
+            mat3f_vec(K, P.PRE_tTll, P.PRE_KtTll);
+            double ab[2];
+            aff_from_to(host.ab_exposure, target.ab_exposure, host.state_scaled[6], host.state_scaled[7],
+                        target.state_scaled[6], target.state_scaled[7], ab);
+            P.PRE_aff_mode[0] = (float)ab[0]; P.PRE_aff_mode[1] = (float)ab[1];
+            P.PRE_b0_mode = (float)(host.state_zero[7] * SCALE_B);
+        }
+}
+
+// EnergyFunctional::setAdjointsF (EnergyFunctional.cpp:21-71)
+static void set_adjoints(EF* E) {
+    const int nF = E->nF;
+    E->adHost.assign((size_t)nF * nF * 36, 0); E->adTarget.assign((size_t)nF * nF * 36, 0);
+    E->adHostF.assign((size_t)nF * nF * 36, 0); E->adTargetF.assign((size_t)nF * nF * 36, 0);
+    for (int h = 0; h < nF; ++h)
+        for (int t = 0; t < nF; ++t) {
+            SE3 hostToTarget = se3_mul(E->frames[t].evalPT, se3_inverse(E->frames[h].evalPT));
+            double Adj[36];
+            se3_adj(hostToTarget, Adj);
+            double* AH = &E->adHost[(size_t)(h + t * nF) * 36];
+            double* AT = &E->adTarget[(size_t)(h + t * nF) * 36];
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) { AH[r * 6 + c] = -Adj[c * 6 + r]; AT[r * 6 + c] = (r == c) ? 1.0 : 0.0; }
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 6; ++c) { AH[r * 6 + c] *= SCALE_XI_TRANS; AT[r * 6 + c] *= SCALE_XI_TRANS; }
+            for (int r = 3; r < 6; ++r) for (int c = 0; c < 6; ++c) { AH[r * 6 + c] *= SCALE_XI_ROT; AT[r * 6 + c] *= SCALE_XI_ROT; }
+            for (int i = 0; i < 36; ++i) {
+                E->adHostF[(size_t)(h + t * nF) * 36 + i] = (float)AH[i];
+                E->adTargetF[(size_t)(h + t * nF) * 36 + i] = (float)AT[i];
+            }
+        }
+    for (int i = 0; i < 4; ++i) { E->cPrior[i] = setting_initialCalibHessian; E->cPriorF[i] = (float)E->cPrior[i]; }
+}
+
+// EnergyFunctional::setDeltaF (EnergyFunctional.cpp:131-156) + EFFrame::takeData / EFPoint::takeData
+static void set_delta(EF* E) {
+    const int nF = E->nF;
+    E->adHTdeltaF.assign((size_t)nF * nF * 6, 0);
+    for (int h = 0; h < nF; ++h)
+        for (int t = 0; t < nF; ++t) {
+            const int idx = h + t * nF;
+            float dh[6], dt[6];
+            for (int i = 0; i < 6; ++i) {
+                dh[i] = (float)(E->frames[h].state[i] - E->frames[h].state_zero[i]);
+                dt[i] = (float)(E->frames[t].state[i] - E->frames[t].state_zero[i]);
+            }
+            const float* AH = &E->adHostF[(size_t)idx * 36];
+            const float* AT = &E->adTargetF[(size_t)idx * 36];
+            for (int c = 0; c < 6; ++c) {
+                float a = 0, b = 0;
+                for (int k = 0; k < 6; ++k) { a += dh[k] * AH[k * 6 + c]; b += dt[k] * AT[k * 6 + c]; }
+                E->adHTdeltaF[(size_t)idx * 6 + c] = a + b;
+            }
+        }
+    for (int i = 0; i < 4; ++i) E->cDeltaF[i] = (float)E->value_minus_value_zero[i];
+    for (Frame& f : E->frames)
+        for (int i = 0; i < 6; ++i) { f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i] - 0.0; }
+    for (Point& p : E->points) p.deltaF = p.idepth - p.idepth_zero;
+}
+
+// a9 again (globalFuncs.h:51-65)
+static inline void interp33(const float* mat, float x, float y, int width, float out[3]) {
+    int ix = (int)x, iy = (int)y;
+    float dx = x - ix, dy = y - iy, dxdy = dx * dy;
+    const float* bp = mat + 3 * (ix + iy * width);
+    const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+    for (int k = 0; k < 3; ++k)
+        out[k] = ((w11 * bp[3 * (1 + width) + k] + w01 * bp[3 * width + k]) + w10 * bp[3 + k]) + w00 * bp[k];
+}
+
+// ---- b1: PointFrameResidual::linearize (Residuals.cpp:60-224) -------------------------------------------
+static double linearize(EF* E, Residual& r) {
+    r.state_NewEnergyWithOutlier = -1;
+    if (r.state_state == OOB) { r.state_NewState = OOB; return r.state_energy; }
+    const Point& pt = E->points[r.point];
+    const Frame& host = E->frames[r.host];
+    const Frame& target = E->frames[r.target];
+    const Precalc& pc = E->precalc[(size_t)r.host * E->nF + r.target];
+    float energyLeft = 0;
+    const float* KRKi = pc.PRE_KRKiTll;
+    const float* Kt = pc.PRE_KtTll;
+    const float* R0 = pc.PRE_RTll_0;
+    const float* t0 = pc.PRE_tTll_0;
+    const float* dIl = target.dI.data();
+    const float affLL0 = pc.PRE_aff_mode[0], affLL1 = pc.PRE_aff_mode[1];
+    const float fxl = E->fxl, fyl = E->fyl, cxl = E->cxl, cyl = E->cyl, fxli = E->fxli, fyli = E->fyli;
+
+    float d_xi_x[6], d_xi_y[6], d_C_x[4], d_C_y[4], d_d_x, d_d_y, Ku, Kv;
+    {
+        if (!r.hasMatcher) { r.state_NewState = OOB; return r.state_energy; }
+        // projectPoint(u,v,idepth_zero_scaled,0,0,HCalib,R0,t0,...)  ResidualProjections.h:32-59
+        float KliP[3] = {(pt.u + 0 - cxl) * fxli, (pt.v + 0 - cyl) * fyli, 1};
+        float ptp[3];
+        for (int i = 0; i < 3; ++i) ptp[i] = ((R0[i * 3] * KliP[0] + R0[i * 3 + 1] * KliP[1]) + R0[i * 3 + 2] * KliP[2]) + t0[i] * pt.idepth_zero_scaled;
+        float drescale = 1.0f / ptp[2];
+        float new_idepth = pt.idepth_zero_scaled * drescale;
+        bool ok = true;
+        float u = 0, v = 0;
+        if (!(drescale > 0)) ok = false;
+        else {
+            u = ptp[0] * drescale; v = ptp[1] * drescale;
+            Ku = u * fxl + cxl; Kv = v * fyl + cyl;
+            ok = Ku > 1.1f && Kv > 1.1f && Ku < E->wM3G && Kv < E->hM3G;
+        }
+        if (!ok) { r.state_NewState = OOB; return r.state_energy; }
+        r.centerProjectedTo[0] = Ku; r.centerProjectedTo[1] = Kv; r.centerProjectedTo[2] = new_idepth;
+
+        d_d_x = drescale * (t0[0] - t0[2] * u) * SCALE_IDEPTH * fxl;
+        d_d_y = drescale * (t0[1] - t0[2] * v) * SCALE_IDEPTH * fyl;
+
+        d_C_x[2] = drescale * (R0[2 * 3 + 0] * u - R0[0 * 3 + 0]);
+        d_C_x[3] = fxl * drescale * (R0[2 * 3 + 1] * u - R0[0 * 3 + 1]) * fyli;
+        d_C_x[0] = KliP[0] * d_C_x[2];
+        d_C_x[1] = KliP[1] * d_C_x[3];
+
+        d_C_y[2] = fyl * drescale * (R0[2 * 3 + 0] * v - R0[1 * 3 + 0]) * fxli;
+        d_C_y[3] = drescale * (R0[2 * 3 + 1] * v - R0[1 * 3 + 1]);
+        d_C_y[0] = KliP[0] * d_C_y[2];
+        d_C_y[1] = KliP[1] * d_C_y[3];
+
+        d_C_x[0] = (d_C_x[0] + u) * SCALE_F;
+        d_C_x[1] *= SCALE_F;
+        d_C_x[2] = (d_C_x[2] + 1) * SCALE_C;
+        d_C_x[3] *= SCALE_C;
+
+        d_C_y[0] *= SCALE_F;
+        d_C_y[1] = (d_C_y[1] + v) * SCALE_F;
+        d_C_y[2] *= SCALE_C;
+        d_C_y[3] = (d_C_y[3] + 1) * SCALE_C;
+
+        d_xi_x[0] = new_idepth * fxl;
+        d_xi_x[1] = 0;
+        d_xi_x[2] = -new_idepth * u * fxl;
+        d_xi_x[3] = -u * v * fxl;
+        d_xi_x[4] = (1 + u * u) * fxl;
+        d_xi_x[5] = -v * fxl;
+
+        d_xi_y[0] = 0;
+        d_xi_y[1] = new_idepth * fyl;
+        d_xi_y[2] = -new_idepth * v * fyl;
+        d_xi_y[3] = -(1 + v * v) * fyl;
+        d_xi_y[4] = u * v * fyl;
+        d_xi_y[5] = u * fyl;
+    }
+    RawJ& J = r.Jnew;
+    for (int i = 0; i < 6; ++i) { J.Jpdxi[0][i] = d_xi_x[i]; J.Jpdxi[1][i] = d_xi_y[i]; }
+    for (int i = 0; i < 4; ++i) { J.Jpdc[0][i] = d_C_x[i]; J.Jpdc[1][i] = d_C_y[i]; }
+    J.Jpdd[0] = d_d_x; J.Jpdd[1] = d_d_y;
+
+    float wJI2_sum = 0;
+    float energyLeft2 = 0.0;
+    for (int idx = 0; idx < patternNum; idx++) {
+        // projectPoint(u+dx, v+dy, idepth_scaled, KRKi, Kt, Ku2, Kv2)  ResidualProjections.h:20-30
+        const float up = pt.u + patternP[idx][0], vp = pt.v + patternP[idx][1];
+        float ptp[3];
+        for (int i = 0; i < 3; ++i) ptp[i] = ((KRKi[i * 3] * up + KRKi[i * 3 + 1] * vp) + KRKi[i * 3 + 2] * 1.0f) + Kt[i] * pt.idepth_scaled;
+        float Ku2 = ptp[0] / ptp[2];
+        float Kv2 = ptp[1] / ptp[2];
+        if (!(Ku2 > 1.1f && Kv2 > 1.1f && Ku2 < E->wM3G && Kv2 < E->hM3G)) break;
+        float hit[3];
+        interp33(dIl, Ku2, Kv2, E->w, hit);
+        float residual = hit[0] - (float)(affLL0 * pt.color[idx] + affLL1);
+        if (!std::isfinite(hit[0])) break;
+        float w = sqrtf(setting_outlierTHSumComponent / (setting_outlierTHSumComponent + (hit[1] * hit[1] + hit[2] * hit[2])));
+        w = 0.5f * (w + pt.weights[idx]);
+        float hw = fabsf(residual) < setting_huberTH ? 1 : setting_huberTH / fabsf(residual);
+        energyLeft2 += w * w * hw * residual * residual * (2 - hw);
+        {
+            if (hw < 1) hw = sqrtf(hw);
+            hw = hw * w;
+            hit[1] *= hw;
+            hit[2] *= hw;
+            wJI2_sum += hw * hw * (hit[1] * hit[1] + hit[2] * hit[2]);
+        }
+    }
+    float res0 = Ku - (float)r.matcher[0];
+    float res1 = Kv - (float)r.matcher[1];
+    float nrm = std::sqrt(res0 * res0 + res1 * res1);
+    float hw = fabsf(nrm) < setting_huberTH ? 1 : setting_huberTH / fabsf(nrm);
+    energyLeft = hw * (res0 * res0 + res1 * res1) * (2 - hw);
+    if (hw < 1) hw = sqrtf(hw);
+    J.resF[0] = res0 * hw; J.resF[1] = res1 * hw;
+    for (int i = 0; i < 6; ++i) { J.Jpdxi[0][i] = J.Jpdxi[0][i] * hw; J.Jpdxi[1][i] = J.Jpdxi[1][i] * hw; }
+    for (int i = 0; i < 4; ++i) { J.Jpdc[0][i] = J.Jpdc[0][i] * hw; J.Jpdc[1][i] = J.Jpdc[1][i] * hw; }
+    J.Jpdd[0] = J.Jpdd[0] * hw; J.Jpdd[1] = J.Jpdd[1] * hw;
+
+    r.state_NewEnergyWithOutlier = energyLeft2;
+    const float th = std::max<float>(host.frameEnergyTH, target.frameEnergyTH);
+    if (energyLeft2 > th || wJI2_sum < 2) { energyLeft2 = th; r.state_NewState = OUTLIER; }
+    else r.state_NewState = IN;
+    r.state_NewEnergy = energyLeft2;
+    return energyLeft;
+}
+
+// PointFrameResidual::applyRes(true) (Residuals.cpp:252-275) + EFResidual::takeDataF (EnergyFunctionalStructs.cpp:15-25)
+static void apply_res(Residual& r) {
+    if (r.state_state == OOB) return;
+    if (r.state_NewState == IN) {
+        r.isActive = true;
+        std::swap(r.Jef, r.Jnew);
+        for (int i = 0; i < 6; i++) r.JpJdF[i] = r.Jef.Jpdxi[0][i] * r.Jef.Jpdd[0] + r.Jef.Jpdxi[1][i] * r.Jef.Jpdd[1];
+        r.JpJdF[6] = r.JpJdF[7] = 0;
+    } else {
+        r.isActive = false;
+    }
+    r.state_state = r.state_NewState;
+    r.state_energy = r.state_NewEnergy;
+}
+
+// ---- b2: AccumulatedTopHessianSSE::addPoint<mode> (AccumulatedTopHessian.cpp:14-112), mode 0 / 1 ---------
+static void add_point_top(EF* E, std::vector<AccumulatorApprox>& acc, Point& p, int mode, int& nres) {
+    const float* dc = E->cDeltaF;
+    const float dd = p.deltaF;
+    float bd_acc = 0, Hdd_acc = 0, Hcd_acc[4] = {0, 0, 0, 0};
+    for (int ri = p.r0; ri < p.r1; ++ri) {
+        Residual& r = E->res[ri];
+        if (mode == 0) { if (r.isLinearized || !r.isActive) continue; }
+        if (mode == 1) { if (!r.isLinearized || !r.isActive) continue; }
+        const RawJ& rJ = r.Jef;
+        const int htIDX = r.host + r.target * E->nF;
+        const float* dp = &E->adHTdeltaF[(size_t)htIDX * 6];
+        float resApprox[2];
+        if (mode == 0) { resApprox[0] = rJ.resF[0]; resApprox[1] = rJ.resF[1]; }
+        else {
+            float dx = 0, dy = 0;
+            for (int i = 0; i < 6; ++i) { dx += rJ.Jpdxi[0][i] * dp[i]; dy += rJ.Jpdxi[1][i] * dp[i]; }
+            float cx = 0, cy = 0;
+            for (int i = 0; i < 4; ++i) { cx += rJ.Jpdc[0][i] * dc[i]; cy += rJ.Jpdc[1][i] * dc[i]; }
+            const float Jp_delta_x = dx + cx + rJ.Jpdd[0] * dd;
+            const float Jp_delta_y = dy + cy + rJ.Jpdd[1] * dd;
+            resApprox[0] = r.res_toZeroF[0] + Jp_delta_x;
+            resApprox[1] = r.res_toZeroF[1] + Jp_delta_y;
+        }
+        const float rr = resApprox[0] * resApprox[0] + resApprox[1] * resApprox[1];
+        acc[htIDX].update(rJ.Jpdc[0], rJ.Jpdxi[0], rJ.Jpdc[1], rJ.Jpdxi[1], 1, 0, 1);
+        acc[htIDX].updateBotRight(0, 0, 0, 0, 0, rr);
+        acc[htIDX].updateTopRight(rJ.Jpdc[0], rJ.Jpdxi[0], rJ.Jpdc[1], rJ.Jpdxi[1], 0, 0, 0, 0, resApprox[0], resApprox[1]);
+        bd_acc += resApprox[0] * rJ.Jpdd[0] + resApprox[1] * rJ.Jpdd[1];
+        Hdd_acc += rJ.Jpdd[0] * rJ.Jpdd[0] + rJ.Jpdd[1] * rJ.Jpdd[1];
+        for (int i = 0; i < 4; ++i) Hcd_acc[i] += rJ.Jpdc[0][i] * rJ.Jpdd[0] + rJ.Jpdc[1][i] * rJ.Jpdd[1];
+        nres++;
+    }
+    if (mode == 0) { p.Hdd_accAF = Hdd_acc; p.bd_accAF = bd_acc; for (int i = 0; i < 4; ++i) p.Hcd_accAF[i] = Hcd_acc[i]; }
+    else { p.Hdd_accLF = Hdd_acc; p.bd_accLF = bd_acc; for (int i = 0; i < 4; ++i) p.Hcd_accLF[i] = Hcd_acc[i]; }
+}
+
+static inline double* blk(std::vector<double>& H, int n, int r, int c) { return &H[(size_t)r * n + c]; }
+
+// C(6x6) += A(6x6) * M(6x6 stored with leading dim ldm) * B^T(6x6)
+static void add_AMBt(std::vector<double>& H, int n, int r0, int c0, const double* A, const double* M, int ldm, const double* B) {
+    double T[36];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double s = 0;
+            for (int k = 0; k < 6; ++k) s += A[i * 6 + k] * M[k * ldm + j];
+            T[i * 6 + j] = s;
+        }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double s = 0;
+            for (int k = 0; k < 6; ++k) s += T[i * 6 + k] * B[j * 6 + k];
+            H[(size_t)(r0 + i) * n + c0 + j] += s;
+        }
+}
+
+// ---- b4: stitchDoubleInternal(tid=-1) + tail of stitchDoubleMT ------------------------------------------
+static void stitch_top(EF* E, std::vector<AccumulatorApprox>& acc, std::vector<double>& H, std::vector<double>& b, bool usePrior) {
+    const int nF = E->nF, n = CPARS + 6 * nF;
+    H.assign((size_t)n * n, 0); b.assign(n, 0);
+    for (int k = 0; k < nF * nF; ++k) {
+        const int h = k % nF, t = k / nF;
+        const int hIdx = CPARS + h * 6, tIdx = CPARS + t * 6, aidx = h + nF * t;
+        double accH[13 * 13];
+        std::memset(accH, 0, sizeof(accH));
+        acc[aidx].finish();
+        if (acc[aidx].num != 0)
+            for (int r = 0; r < 13; ++r) for (int c = 0; c < 13; ++c) accH[r * 13 + c] += (double)acc[aidx].H[r][c];
+        const double* AH = &E->adHost[(size_t)aidx * 36];
+        const double* AT = &E->adTarget[(size_t)aidx * 36];
+        const double* A66 = &accH[CPARS * 13 + CPARS];
+        add_AMBt(H, n, hIdx, hIdx, AH, A66, 13, AH);
+        add_AMBt(H, n, tIdx, tIdx, AT, A66, 13, AT);
+        add_AMBt(H, n, hIdx, tIdx, AH, A66, 13, AT);
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < CPARS; ++j) {
+                double sh = 0, st = 0;
+                for (int kk = 0; kk < 6; ++kk) { sh += AH[i * 6 + kk] * accH[(CPARS + kk) * 13 + j]; st += AT[i * 6 + kk] * accH[(CPARS + kk) * 13 + j]; }
+                H[(size_t)(hIdx + i) * n + j] += sh;
+                H[(size_t)(tIdx + i) * n + j] += st;
+            }
+        for (int i = 0; i < CPARS; ++i) for (int j = 0; j < CPARS; ++j) H[(size_t)i * n + j] += accH[i * 13 + j];
+        for (int i = 0; i < 6; ++i) {
+            double sh = 0, st = 0;
+            for (int kk = 0; kk < 6; ++kk) { sh += AH[i * 6 + kk] * accH[(CPARS + kk) * 13 + (CPARS + 8)]; st += AT[i * 6 + kk] * accH[(CPARS + kk) * 13 + (CPARS + 8)]; }
+            b[hIdx + i] += sh;
+            b[tIdx + i] += st;
+        }
+        for (int i = 0; i < CPARS; ++i) b[i] += accH[i * 13 + (CPARS + 8)];
+    }
+    if (usePrior) {
+        for (int i = 0; i < CPARS; ++i) { H[(size_t)i * n + i] += E->cPrior[i]; b[i] += E->cPrior[i] * (double)E->cDeltaF[i]; }
+        for (int h = 0; h < nF; ++h)
+            for (int i = 0; i < 6; ++i) {
+                H[(size_t)(CPARS + h * 6 + i) * n + (CPARS + h * 6 + i)] += E->frames[h].prior[i];
+                b[CPARS + h * 6 + i] += E->frames[h].prior[i] * E->frames[h].delta_prior[i];
+            }
+    }
+    // stitchDoubleMT tail (.h:100-113)
+    for (int h = 0; h < nF; ++h) {
+        const int hIdx = CPARS + h * 6;
+        for (int i = 0; i < CPARS; ++i) for (int j = 0; j < 6; ++j) H[(size_t)i * n + hIdx + j] = H[(size_t)(hIdx + j) * n + i];
+        for (int t = h + 1; t < nF; ++t) {
+            const int tIdx = CPARS + t * 6;
+            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) H[(size_t)(hIdx + i) * n + tIdx + j] += H[(size_t)(tIdx + j) * n + hIdx + i];
+            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) H[(size_t)(tIdx + i) * n + hIdx + j] = H[(size_t)(hIdx + j) * n + tIdx + i];
+        }
+    }
+}
+
+// ---- b7: AccumulatedSCHessianSSE::addPoint + stitchDoubleInternal(tid=-1) + MT tail ------------------------
+struct SCAcc {
+    int nF;
+    std::vector<AccXX> accE, accEB, accD;
+    AccXX accHcc, accbc;
+    void setZero(int n) {
+        nF = n;
+        accE.resize((size_t)n * n); accEB.resize((size_t)n * n); accD.resize((size_t)n * n * n);
+        for (auto& a : accE) a.initialize(8, CPARS);
+        for (auto& a : accEB) a.initialize(8, 1);
+        for (auto& a : accD) a.initialize(8, 8);
+        accHcc.initialize(CPARS, CPARS); accbc.initialize(CPARS, 1);
+    }
+};
+
+static void add_point_sc(EF* E, SCAcc& S, Point& p, bool shiftPriorToZero) {
+    int ngoodres = 0;
+    for (int ri = p.r0; ri < p.r1; ++ri) if (E->res[ri].isActive) ngoodres++;
+    if (ngoodres == 0) { p.HdiF = 0; p.bdSumF = 0; p.idepth_hessian = 0; return; }
+    float H = p.Hdd_accAF + p.Hdd_accLF + p.priorF;
+    if (H < 1e-10) H = 1e-10;
+    p.idepth_hessian = H;
+    p.HdiF = 1.0 / H;
+    p.bdSumF = p.bd_accAF + p.bd_accLF;
+    if (shiftPriorToZero) p.bdSumF += p.priorF * p.deltaF;
+    float Hcd[4];
+    for (int i = 0; i < 4; ++i) Hcd[i] = p.Hcd_accAF[i] + p.Hcd_accLF[i];
+    if (p.isFromSensor) return;
+    S.accHcc.update(Hcd, Hcd, p.HdiF);
+    S.accbc.updateVec(Hcd, p.bdSumF * p.HdiF);
+    const int nF = S.nF, nFrames2 = nF * nF;
+    for (int r1i = p.r0; r1i < p.r1; ++r1i) {
+        Residual& r1 = E->res[r1i];
+        if (!r1.isActive) continue;
+        const int r1ht = r1.host + r1.target * nF;
+        for (int r2i = p.r0; r2i < p.r1; ++r2i) {
+            Residual& r2 = E->res[r2i];
+            if (!r2.isActive) continue;
+            S.accD[r1ht + r2.target * nFrames2].update(r1.JpJdF, r2.JpJdF, p.HdiF);
+        }
+        S.accE[r1ht].update(r1.JpJdF, Hcd, p.HdiF);
+        S.accEB[r1ht].updateVec(r1.JpJdF, p.HdiF * p.bdSumF);
+    }
+}
+
+static void add_AMBt6(std::vector<double>& H, int n, int r0, int c0, const double* A, const double* M8, const double* B) {
+    add_AMBt(H, n, r0, c0, A, M8, 8, B);
+}
+
+static void stitch_sc(EF* E, SCAcc& S, std::vector<double>& H, std::vector<double>& b) {
+    const int nF = S.nF, n = CPARS + 6 * nF, nframes2 = nF * nF;
+    H.assign((size_t)n * n, 0); b.assign(n, 0);
+    for (int k = 0; k < nframes2; ++k) {
+        const int i = k % nF, j = k / nF;
+        const int iIdx = CPARS + i * 6, jIdx = CPARS + j * 6, ijIdx = i + nF * j;
+        S.accE[ijIdx].finish(); S.accEB[ijIdx].finish();
+        double Hpc[8 * CPARS], bp[8];
+        for (int q = 0; q < 8 * CPARS; ++q) Hpc[q] = (double)S.accE[ijIdx].A1m[q];
+        for (int q = 0; q < 8; ++q) bp[q] = (double)S.accEB[ijIdx].A1m[q];
+        const double* AH = &E->adHost[(size_t)ijIdx * 36];
+        const double* AT = &E->adTarget[(size_t)ijIdx * 36];
+        for (int r = 0; r < 6; ++r) {
+            for (int c = 0; c < CPARS; ++c) {
+                double sh = 0, st = 0;
+                for (int q = 0; q < 6; ++q) { sh += AH[r * 6 + q] * Hpc[q * CPARS + c]; st += AT[r * 6 + q] * Hpc[q * CPARS + c]; }
+                H[(size_t)(iIdx + r) * n + c] += sh;
+                H[(size_t)(jIdx + r) * n + c] += st;
+            }
+            double sh = 0, st = 0;
+            for (int q = 0; q < 6; ++q) { sh += AH[r * 6 + q] * bp[q]; st += AT[r * 6 + q] * bp[q]; }
+            b[iIdx + r] += sh;
+            b[jIdx + r] += st;
+        }
+        for (int kk = 0; kk < nF; ++kk) {
+            const int kIdx = CPARS + kk * 6, ijkIdx = ijIdx + kk * nframes2, ikIdx = i + nF * kk;
+            double accDM[64];
+            std::memset(accDM, 0, sizeof(accDM));
+            S.accD[ijkIdx].finish();
+            if (S.accD[ijkIdx].num != 0) for (int q = 0; q < 64; ++q) accDM[q] += (double)S.accD[ijkIdx].A1m[q];
+            const double* AHk = &E->adHost[(size_t)ikIdx * 36];
+            const double* ATk = &E->adTarget[(size_t)ikIdx * 36];
+            add_AMBt6(H, n, iIdx, iIdx, AH, accDM, AHk);
+            add_AMBt6(H, n, jIdx, kIdx, AT, accDM, ATk);
+            add_AMBt6(H, n, jIdx, iIdx, AT, accDM, AHk);
+            add_AMBt6(H, n, iIdx, kIdx, AH, accDM, ATk);
+        }
+    }
+    S.accHcc.finish(); S.accbc.finish();
+    for (int r = 0; r < CPARS; ++r) {
+        for (int c = 0; c < CPARS; ++c) H[(size_t)r * n + c] += (double)S.accHcc.A1m[r * CPARS + c];
+        b[r] += (double)S.accbc.A1m[r];
+    }
+    for (int h = 0; h < nF; ++h) {
+        const int hIdx = CPARS + h * 6;
+        for (int i = 0; i < CPARS; ++i) for (int j = 0; j < 6; ++j) H[(size_t)i * n + hIdx + j] = H[(size_t)(hIdx + j) * n + i];
+    }
+}
+
+// One-sided Jacobi SVD of an m x k (k <= m) matrix: A = U diag(s) V^T  (stands in for Eigen::JacobiSVD in
+// EnergyFunctional::orthogonalize, EnergyFunctional.cpp:615-648).
+static void jacobi_svd(int m, int k, std::vector<double> A, std::vector<double>& U, std::vector<double>& s, std::vector<double>& V) {
+    V.assign((size_t)k * k, 0);
+    for (int i = 0; i < k; ++i) V[(size_t)i * k + i] = 1;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < k; ++p)
+            for (int q = p + 1; q < k; ++q) {
+                double a = 0, bb = 0, c = 0;
+                for (int i = 0; i < m; ++i) { a += A[(size_t)i * k + p] * A[(size_t)i * k + p]; bb += A[(size_t)i * k + q] * A[(size_t)i * k + q]; c += A[(size_t)i * k + p] * A[(size_t)i * k + q]; }
+                off = std::max(off, std::fabs(c) / std::sqrt(std::max(a * bb, 1e-300)));
+                if (std::fabs(c) < 1e-300) continue;
+                const double zeta = (bb - a) / (2 * c);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1 + zeta * zeta));
+                const double cs = 1 / std::sqrt(1 + t * t), sn = cs * t;
+                for (int i = 0; i < m; ++i) {
+                    const double x = A[(size_t)i * k + p], y = A[(size_t)i * k + q];
+                    A[(size_t)i * k + p] = cs * x - sn * y; A[(size_t)i * k + q] = sn * x + cs * y;
+                }
+                for (int i = 0; i < k; ++i) {
+                    const double x = V[(size_t)i * k + p], y = V[(size_t)i * k + q];
+                    V[(size_t)i * k + p] = cs * x - sn * y; V[(size_t)i * k + q] = sn * x + cs * y;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    s.assign(k, 0); U.assign((size_t)m * k, 0);
+    for (int j = 0; j < k; ++j) {
+        double nn = 0;
+        for (int i = 0; i < m; ++i) nn += A[(size_t)i * k + j] * A[(size_t)i * k + j];
+        s[j] = std::sqrt(nn);
+        for (int i = 0; i < m; ++i) U[(size_t)i * k + j] = s[j] > 0 ? A[(size_t)i * k + j] / s[j] : 0;
+    }
+}
+
+// EnergyFunctional::orthogonalize(VecX* b, 0)  (EnergyFunctional.cpp:615-648), setting_solverModeDelta=1e-5
+static void orthogonalize_x(EF* E, std::vector<double>& x) {
+    const int n = (int)x.size(), k = (int)E->nullspaces.size();
+    if (k == 0) return;
+    std::vector<double> N((size_t)n * k);
+    for (int j = 0; j < k; ++j) {
+        double nn = 0;
+        for (int i = 0; i < n; ++i) nn += E->nullspaces[j][i] * E->nullspaces[j][i];
+        nn = std::sqrt(nn);
+        for (int i = 0; i < n; ++i) N[(size_t)i * k + j] = E->nullspaces[j][i] / nn;
+    }
+    std::vector<double> U, s, V;
+    jacobi_svd(n, k, N, U, s, V);
+    double maxSv = 0;
+    for (double v : s) maxSv = std::max(maxSv, v);
+    for (double& v : s) v = (v > 1e-5 * maxSv) ? 1.0 / v : 0;
+    // Npi = U diag(s) V^T ; NNpiT = N Npi^T ; NNpiTS = 0.5 (NNpiT + NNpiT^T)
+    std::vector<double> Npi((size_t)n * k, 0), M((size_t)n * n, 0);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < k; ++j) { double a = 0; for (int q = 0; q < k; ++q) a += U[(size_t)i * k + q] * s[q] * V[(size_t)j * k + q]; Npi[(size_t)i * k + j] = a; }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double a = 0; for (int q = 0; q < k; ++q) a += N[(size_t)i * k + q] * Npi[(size_t)j * k + q]; M[(size_t)i * n + j] = a; }
+    std::vector<double> y(n, 0);
+    for (int i = 0; i < n; ++i) { double a = 0; for (int j = 0; j < n; ++j) a += 0.5 * (M[(size_t)i * n + j] + M[(size_t)j * n + i]) * x[j]; y[i] = a; }
+    for (int i = 0; i < n; ++i) x[i] -= y[i];
+}
+
+// ---- b6: EnergyFunctional::solveSystemF (EnergyFunctional.cpp:650-759), default solver mode -------------
+static void solve_system(EF* E, int iteration, double lambda) {
+    const int nF = E->nF, n = CPARS + 6 * nF;
+    // accumulateAF_MT (MT=false)
+    E->accA.resize((size_t)nF * nF);
+    for (auto& a : E->accA) a.initialize();
+    E->resInA = 0;
+    for (Point& p : E->points) add_point_top(E, E->accA, p, 0, E->resInA);
+    stitch_top(E, E->accA, E->HA, E->bA, true);
+    // accumulateLF_MT: result discarded, but it (re)sets p->*_accLF
+    E->accL.resize((size_t)nF * nF);
+    for (auto& a : E->accL) a.initialize();
+    E->resInL = 0;
+    for (Point& p : E->points) add_point_top(E, E->accL, p, 1, E->resInL);
+    // accumulateSCF_MT
+    SCAcc S;
+    S.setZero(nF);
+    for (Point& p : E->points) add_point_sc(E, S, p, true);
+    stitch_sc(E, S, E->Hsc, E->bsc);
+    // bM_top = bM + HM * delta
+    std::vector<double> d(n), bM_top(n);
+    for (int i = 0; i < CPARS; ++i) d[i] = (double)E->cDeltaF[i];
+    for (int h = 0; h < nF; ++h) for (int i = 0; i < 6; ++i) d[CPARS + 6 * h + i] = E->frames[h].delta[i];
+    for (int i = 0; i < n; ++i) { double a = 0; for (int j = 0; j < n; ++j) a += E->HM[(size_t)i * n + j] * d[j]; bM_top[i] = E->bM[i] + a; }
+    E->HFinal.assign((size_t)n * n, 0); E->bFinal.assign(n, 0);
+    for (size_t i = 0; i < (size_t)n * n; ++i) E->HFinal[i] = E->HA[i] + E->HM[i] - E->Hsc[i];
+    for (int i = 0; i < n; ++i) E->bFinal[i] = E->bA[i] + bM_top[i] - E->bsc[i];
+    std::vector<double> Hd = E->HFinal;   // lastHS keeps the undamped matrix
+    for (int i = 0; i < n; ++i) Hd[(size_t)i * n + i] *= (1 + lambda);
+    std::vector<double> SVecI(n), Hs((size_t)n * n), bs(n), xs(n);
+    for (int i = 0; i < n; ++i) SVecI[i] = 1.0 / std::sqrt(Hd[(size_t)i * n + i] + 10);
+    for (int i = 0; i < n; ++i) { for (int j = 0; j < n; ++j) Hs[(size_t)i * n + j] = SVecI[i] * Hd[(size_t)i * n + j] * SVecI[j]; bs[i] = SVecI[i] * E->bFinal[i]; }
+    ldlt_solve(n, Hs.data(), bs.data(), xs.data());
+    E->lastX.assign(n, 0);
+    for (int i = 0; i < n; ++i) E->lastX[i] = SVecI[i] * xs[i];
+    if (iteration >= 2) orthogonalize_x(E, E->lastX);  // SOLVER_ORTHOGONALIZE_X_LATER (settings.cpp:34)
+    // resubstituteF_MT (:221-282)
+    std::vector<float> xF(n);
+    for (int i = 0; i < n; ++i) xF[i] = (float)E->lastX[i];
+    for (int i = 0; i < CPARS; ++i) E->calibStep[i] = -E->lastX[i];
+    std::vector<float> xAd((size_t)nF * nF * 6);
+    for (int h = 0; h < nF; ++h) {
+        for (int i = 0; i < 6; ++i) E->frames[h].step[i] = -E->lastX[CPARS + 6 * h + i];
+        for (int i = 6; i < 10; ++i) E->frames[h].step[i] = 0;
+        for (int t = 0; t < nF; ++t) {
+            const float* AH = &E->adHostF[(size_t)(h + nF * t) * 36];
+            const float* AT = &E->adTargetF[(size_t)(h + nF * t) * 36];
+            for (int c = 0; c < 6; ++c) {
+                float a = 0, bb = 0;
+                for (int k = 0; k < 6; ++k) { a += xF[CPARS + 6 * h + k] * AH[k * 6 + c]; bb += xF[CPARS + 6 * t + k] * AT[k * 6 + c]; }
+                xAd[(size_t)(nF * h + t) * 6 + c] = a + bb;
+            }
+        }
+    }
+    for (Point& p : E->points) {
+        int ngoodres = 0;
+        for (int ri = p.r0; ri < p.r1; ++ri) if (E->res[ri].isActive) ngoodres++;
+        if (ngoodres == 0) { p.step = 0; continue; }
+        float b = p.bdSumF;
+        float dot = 0;
+        for (int i = 0; i < 4; ++i) dot += xF[i] * p.Hcd_accAF[i];
+        b -= dot;
+        for (int ri = p.r0; ri < p.r1; ++ri) {
+            const Residual& r = E->res[ri];
+            if (!r.isActive) continue;
+            const float* xa = &xAd[(size_t)(r.host * nF + r.target) * 6];
+            float s = 0;
+            for (int i = 0; i < 6; ++i) s += xa[i] * r.JpJdF[i];
+            b -= s;
+        }
+        p.step = p.isFromSensor ? 0 : -b * p.HdiF;
+    }
+}
+
+}  // namespace orcb
+
+using namespace orcb;
+extern "C" {
+
+void* orc_ef_create(int w, int h) {
+    EF* E = new EF();
+    E->w = w; E->h = h; E->nF = 0; E->wM3G = w - 3; E->hM3G = h - 3;
+    return E;
+}
+void orc_ef_destroy(void* e) { delete (EF*)e; }
+
+void orc_ef_set_calib(void* e, const double value_scaled[4], const double value_minus_value_zero[4]) {
+    EF* E = (EF*)e;
+    for (int i = 0; i < 4; ++i) { E->value_scaled[i] = value_scaled[i]; E->value_minus_value_zero[i] = value_minus_value_zero[i]; }
+    calib_update(E);
+}
+
+void orc_ef_set_frames(void* e, int nF, const double* evalPT7, const double* state10, const double* state_zero10,
+                       const int* frameID, const float* ab_exposure, const float* frameEnergyTH) {
+    EF* E = (EF*)e;
+    E->nF = nF;
+    E->frames.resize(nF);
+    for (int i = 0; i < nF; ++i) {
+        Frame& f = E->frames[i];
+        std::memcpy(f.evalPT.q, evalPT7 + 7 * i, 32); std::memcpy(f.evalPT.t, evalPT7 + 7 * i + 4, 24);
+        for (int k = 0; k < 10; ++k) f.state_zero[k] = state_zero10[10 * i + k];
+        frame_set_state(f, state10 + 10 * i);
+        f.frameID = frameID[i]; f.ab_exposure = ab_exposure[i]; f.frameEnergyTH = frameEnergyTH[i];
+        // EFFrame::takeData / FrameHessian::getPrior (HessianBlocks.h:220-250)
+        for (int k = 0; k < 6; ++k) f.prior[k] = 0;
+        if (f.frameID == 0) { for (int k = 0; k < 3; ++k) f.prior[k] = setting_initialTransPrior; for (int k = 3; k < 6; ++k) f.prior[k] = setting_initialRotPrior; }
+        for (int k = 0; k < 10; ++k) f.step[k] = 0;
+    }
+    const int n = CPARS + 6 * nF;
+    E->HM.assign((size_t)n * n, 0); E->bM.assign(n, 0);
+}
+void orc_ef_set_frame_state(void* e, int idx, const double* state10) { frame_set_state(((EF*)e)->frames[idx], state10); }
+void orc_ef_set_frame_image(void* e, int idx, const float* dI) {
+    EF* E = (EF*)e;
+    E->frames[idx].dI.assign(dI, dI + (size_t)E->w * E->h * 3);
+}
+void orc_ef_set_points(void* e, int nP, const int* host, const float* u, const float* v, const float* idepth, const float* idepth_zero,
+                       const float* color8, const float* weights8, const uint8_t* hasDepthPrior, const uint8_t* isFromSensor) {
+    EF* E = (EF*)e;
+    E->points.resize(nP);
+    for (int i = 0; i < nP; ++i) {
+        Point& p = E->points[i];
+        std::memset(&p, 0, sizeof(p));
+        p.host = host[i]; p.u = u[i]; p.v = v[i];
+        p.idepth = idepth[i]; p.idepth_scaled = SCALE_IDEPTH * idepth[i];
+        p.idepth_zero = idepth_zero[i]; p.idepth_zero_scaled = SCALE_IDEPTH * idepth_zero[i];
+        for (int k = 0; k < 8; ++k) { p.color[k] = color8[8 * i + k]; p.weights[k] = weights8[8 * i + k]; }
+        p.hasDepthPrior = hasDepthPrior[i]; p.isFromSensor = isFromSensor[i];
+        p.priorF = p.hasDepthPrior ? setting_idepthFixPrior * SCALE_IDEPTH * SCALE_IDEPTH : 0;  // EFPoint::takeData
+        p.r0 = p.r1 = 0;
+    }
+}
+void orc_ef_set_point_idepth(void* e, const float* idepth, const float* idepth_zero) {
+    EF* E = (EF*)e;
+    for (size_t i = 0; i < E->points.size(); ++i) {
+        Point& p = E->points[i];
+        p.idepth = idepth[i]; p.idepth_scaled = SCALE_IDEPTH * idepth[i];
+        p.idepth_zero = idepth_zero[i]; p.idepth_zero_scaled = SCALE_IDEPTH * idepth_zero[i];
+    }
+}
+// residuals sorted by point (a point's residualsAll order = order given here)
+void orc_ef_set_residuals(void* e, int nR, const int* point, const int* target, const int* state_state, const uint8_t* hasMatcher,
+                          const double* matcher2, const uint8_t* isLinearized, const uint8_t* isActive) {
+    EF* E = (EF*)e;
+    E->res.resize(nR);
+    for (Point& p : E->points) p.r0 = p.r1 = 0;
+    for (int i = 0; i < nR; ++i) {
+        Residual& r = E->res[i];
+        std::memset(&r, 0, sizeof(r));
+        r.point = point[i]; r.host = E->points[point[i]].host; r.target = target[i];
+        r.state_state = state_state[i]; r.state_NewState = OUTLIER;
+        r.hasMatcher = hasMatcher[i]; r.matcher[0] = matcher2[2 * i]; r.matcher[1] = matcher2[2 * i + 1];
+        r.isLinearized = isLinearized[i]; r.isActive = isActive[i];
+        Point& p = E->points[point[i]];
+        if (p.r1 == 0 && p.r0 == 0) { p.r0 = i; p.r1 = i + 1; }
+        else p.r1 = i + 1;
+    }
+}
+void orc_ef_set_marg_prior(void* e, const double* HM, const double* bM) {
+    EF* E = (EF*)e; const int n = CPARS + 6 * E->nF;
+    E->HM.assign(HM, HM + (size_t)n * n); E->bM.assign(bM, bM + n);
+}
+void orc_ef_set_nullspaces(void* e, int k, const double* ns) {
+    EF* E = (EF*)e; const int n = CPARS + 6 * E->nF;
+    E->nullspaces.clear();
+    for (int j = 0; j < k; ++j) E->nullspaces.emplace_back(ns + (size_t)j * n, ns + (size_t)(j + 1) * n);
+}
+void orc_ef_set_precalc(void* e) { set_precalc((EF*)e); set_delta((EF*)e); }
+void orc_ef_set_adjoints(void* e) { set_adjoints((EF*)e); }
+double orc_ef_linearize_all(void* e) {
+    EF* E = (EF*)e;
+    double s = 0;
+    for (Residual& r : E->res) if (!r.isLinearized) s += linearize(E, r);
+    return s;
+}
+void orc_ef_apply_res(void* e) { for (Residual& r : ((EF*)e)->res) if (!r.isLinearized) apply_res(r); }
+void orc_ef_solve_system(void* e, int iteration, double lambda) { solve_system((EF*)e, iteration, lambda); }
+
+int orc_ef_dim(void* e) { return CPARS + 6 * ((EF*)e)->nF; }
+void orc_ef_get_system(void* e, double* HA, double* bA, double* Hsc, double* bsc, double* HFinal, double* bFinal, double* x) {
+    EF* E = (EF*)e; const int n = CPARS + 6 * E->nF;
+    if (HA) std::memcpy(HA, E->HA.data(), sizeof(double) * n * n);
+    if (bA) std::memcpy(bA, E->bA.data(), sizeof(double) * n);
+    if (Hsc) std::memcpy(Hsc, E->Hsc.data(), sizeof(double) * n * n);
+    if (bsc) std::memcpy(bsc, E->bsc.data(), sizeof(double) * n);
+    if (HFinal) std::memcpy(HFinal, E->HFinal.data(), sizeof(double) * n * n);
+    if (bFinal) std::memcpy(bFinal, E->bFinal.data(), sizeof(double) * n);
+    if (x) std::memcpy(x, E->lastX.data(), sizeof(double) * n);
+}
+// per residual: J (24 floats: resF2, Jpdxi 12, Jpdc 8, Jpdd 2), which = 0 new / 1 EF ; states
+void orc_ef_get_residual_J(void* e, int which, float* out24) {
+    EF* E = (EF*)e;
+    for (size_t i = 0; i < E->res.size(); ++i) {
+        const RawJ& J = which ? E->res[i].Jef : E->res[i].Jnew;
+        float* o = out24 + 24 * i;
+        o[0] = J.resF[0]; o[1] = J.resF[1];
+        for (int k = 0; k < 6; ++k) { o[2 + k] = J.Jpdxi[0][k]; o[8 + k] = J.Jpdxi[1][k]; }
+        for (int k = 0; k < 4; ++k) { o[14 + k] = J.Jpdc[0][k]; o[18 + k] = J.Jpdc[1][k]; }
+        o[22] = J.Jpdd[0]; o[23] = J.Jpdd[1];
+    }
+}
+void orc_ef_get_residual_state(void* e, int* state_state, int* state_new, double* energy_new, double* energy_with_outlier, uint8_t* isActive) {
+    EF* E = (EF*)e;
+    for (size_t i = 0; i < E->res.size(); ++i) {
+        const Residual& r = E->res[i];
+        if (state_state) state_state[i] = r.state_state;
+        if (state_new) state_new[i] = r.state_NewState;
+        if (energy_new) energy_new[i] = r.state_NewEnergy;
+        if (energy_with_outlier) energy_with_outlier[i] = r.state_NewEnergyWithOutlier;
+        if (isActive) isActive[i] = r.isActive;
+    }
+}
+// per point: [Hdd_accAF, bd_accAF, Hcd_accAF(4), HdiF, bdSumF, step] = 9 floats
+void orc_ef_get_points(void* e, float* out9) {
+    EF* E = (EF*)e;
+    for (size_t i = 0; i < E->points.size(); ++i) {
+        const Point& p = E->points[i];
+        float* o = out9 + 9 * i;
+        o[0] = p.Hdd_accAF; o[1] = p.bd_accAF;
+        for (int k = 0; k < 4; ++k) o[2 + k] = p.Hcd_accAF[k];
+        o[6] = p.HdiF; o[7] = p.bdSumF; o[8] = p.step;
+    }
+}
+void orc_ef_get_frame_steps(void* e, double* steps6, double* calibStep4) {
+    EF* E = (EF*)e;
+    for (int h = 0; h < E->nF; ++h) for (int i = 0; i < 6; ++i) steps6[6 * h + i] = E->frames[h].step[i];
+    for (int i = 0; i < 4; ++i) calibStep4[i] = E->calibStep[i];
+}
+// top accumulators after the last solve: nF*nF x 13 x 13 floats (index h + nF*t)
+void orc_ef_get_top_acc(void* e, float* out) {
+    EF* E = (EF*)e;
+    for (size_t k = 0; k < E->accA.size(); ++k)
+        for (int r = 0; r < 13; ++r) for (int c = 0; c < 13; ++c) out[k * 169 + r * 13 + c] = E->accA[k].H[r][c];
+}
+void orc_ef_get_precalc(void* e, int h, int t, float* out) {  // KRKi9, Kt3, R0 9, t0 3, aff2, b0 = 27
+    EF* E = (EF*)e; const Precalc& P = E->precalc[(size_t)h * E->nF + t];
+    std::memcpy(out, P.PRE_KRKiTll, 36); std::memcpy(out + 9, P.PRE_KtTll, 12); std::memcpy(out + 12, P.PRE_RTll_0, 36);
+    std::memcpy(out + 21, P.PRE_tTll_0, 12); out[24] = P.PRE_aff_mode[0]; out[25] = P.PRE_aff_mode[1]; out[26] = P.PRE_b0_mode;
+}
+void orc_ef_get_adjoints(void* e, double* adHost, double* adTarget) {
+    EF* E = (EF*)e;
+    std::memcpy(adHost, E->adHost.data(), sizeof(double) * E->adHost.size());
+    std::memcpy(adTarget, E->adTarget.data(), sizeof(double) * E->adTarget.size());
+}
+int orc_ef_res_in_A(void* e) { return ((EF*)e)->resInA; }
+}

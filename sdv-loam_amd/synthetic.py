@@ -150,3 +150,166 @@ def make_tracker_problem(w=1241, h=376, levels=4, n_points=2000, seed=0, calib=K
 def perturbation(seed=0, sigma_t=0.05, sigma_r=0.005):
     rng = np.random.default_rng(seed + 2000)
     return np.concatenate([rng.normal(0, sigma_t, 3), rng.normal(0, sigma_r, 3)])
+
+
+# =====================================================================================================
+# Sliding-window back end: nF key-frames looking at a slanted textured plane.
+# =====================================================================================================
+PATTERN8 = np.array([[0, -2], [-1, -1], [1, -1], [-2, 0], [0, 0], [2, 0], [-1, 1], [0, 2]], np.int32)  # settings.cpp:250
+
+
+class Window:
+    pass
+
+
+def _se3_inv_np(p):
+    q = np.array([-p[0], -p[1], -p[2], p[3]])
+    R = quat_to_R(q)
+    return np.concatenate([q, -R @ p[4:]])
+
+
+def _se3_mul_np(a, b):
+    ax, ay, az, aw = a[:4]
+    bx, by, bz, bw = b[:4]
+    q = np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by + ay * bw + az * bx - ax * bz,
+                  aw * bz + az * bw + ax * by - ay * bx, aw * bw - ax * bx - ay * by - az * bz])
+    q /= np.linalg.norm(q)
+    return np.concatenate([q, a[4:] + quat_to_R(a[:4]) @ b[4:]])
+
+
+def make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=KITTI00, sensor_frac=0.3, matcher_sigma=0.3,
+                state_sigma=1e-3, idepth_sigma=0.02, evalpt_sigma=(0.01, 0.001), spacing=1.0, marg_prior=True):
+    """Synthetic EnergyFunctional window.  Ground truth: camera k at z = k*spacing with a small yaw, all frames see the
+    plane n.X = d; frame images are rendered from one texture so that the 8-pixel photometric outlier test of
+    linearize() sees consistent data.  Returns a Window with flat numpy arrays in the reference's iteration order
+    (frames -> points hosted in the frame -> one residual per other frame)."""
+    from scipy.ndimage import gaussian_filter, map_coordinates
+    rng = np.random.default_rng(seed + 5000)
+    W = Window()
+    W.w, W.h, W.nF, W.calib = w, h, nF, dict(calib)
+    fx, fy, cx, cy = (np.float64(np.float32(calib[k])) for k in ("fx", "fy", "cx", "cy"))
+    # texture on the plane, 40 px/m, +-25 m
+    tex_res, tex_half = 40.0, 25.0
+    tn = int(2 * tex_half * tex_res)
+    tex = np.zeros((tn, tn))
+    for sigma, amp in ((12.0, 1.0), (4.0, 0.6), (1.8, 0.35)):
+        o = gaussian_filter(rng.random((tn, tn)), sigma, mode="wrap")
+        tex += amp * (o - o.mean()) / o.std()
+    tex = 20.0 + 215.0 * (tex - tex.min()) / (tex.max() - tex.min())
+    n = np.array([0.25, 0.45, 1.0])
+    n /= np.linalg.norm(n)
+    d = 14.0
+    e1 = np.cross(n, [0, 1, 0]); e1 /= np.linalg.norm(e1)
+    e2 = np.cross(n, e1)
+
+    # ground-truth world->cam poses
+    gt = []
+    for k in range(nF):
+        yaw = 0.01 * k
+        camToWorld = se3_exp_np([0.05 * np.sin(k), 0.02 * k, spacing * k, 0.0, yaw, 0.002 * k])
+        gt.append(_se3_inv_np(camToWorld))
+    W.gt_worldToCam = np.array(gt)
+
+    def render(p):  # image of frame with world->cam pose p, and its depth map
+        R = quat_to_R(p[:4]); t = p[4:]
+        C = -R.T @ t
+        ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+        rays = np.stack([(xs - cx) / fx, (ys - cy) / fy, np.ones_like(xs)], -1) @ R  # rows: R^T r
+        lam = (d - n @ C) / (rays @ n)
+        X = C + lam[..., None] * rays
+        s = (X @ e1 + tex_half) * tex_res
+        tt = (X @ e2 + tex_half) * tex_res
+        img = map_coordinates(tex, [tt, s], order=1, mode="nearest")
+        return img.astype(np.float32), lam  # lam == depth z in the camera (ray has z=1)
+
+    W.images, depths = [], []
+    for k in range(nF):
+        img, z = render(gt[k])
+        W.images.append(img)
+        depths.append(z)
+    W.pyr0 = [pyramid_numpy(img, 1)[0] for img in W.images]  # level-0 AoS {I,dx,dy}
+
+    # frames: evaluation point = GT perturbed; state = small non-zero increment on top; state_zero = 0 except b
+    W.evalPT = np.array([_se3_mul_np(se3_exp_np(np.concatenate([rng.normal(0, evalpt_sigma[0], 3), rng.normal(0, evalpt_sigma[1], 3)])), gt[k])
+                         for k in range(nF)])
+    W.evalPT[0] = gt[0]
+    W.state = np.zeros((nF, 10))
+    W.state[:, :6] = rng.normal(0, state_sigma, (nF, 6))
+    W.state[0, :6] = 0
+    W.state[:, 6] = 0.001 * rng.normal(0, 1, nF)   # a (scaled x10)
+    W.state[:, 7] = 0.0005 * rng.normal(0, 1, nF)  # b (scaled x1000)
+    W.state_zero = np.zeros((nF, 10))
+    W.state_zero[:, 6:8] = W.state[:, 6:8]
+    W.frameID = np.arange(nF, dtype=np.int32)
+    W.ab_exposure = np.ones(nF, np.float32)
+    W.frameEnergyTH = np.full(nF, 8 * 8 * 8, np.float32)  # FrameHessian ctor: 8*8*patternNum
+    W.value_scaled = np.array([fx, fy, cx, cy], np.float64)
+    W.value_minus_value_zero = np.array([1e-3, -5e-4, 2e-3, 1e-3]) / np.array([50., 50., 50., 50.])
+
+    # points + residuals
+    host, us, vs, idp, col, wts, prior, sensor = [], [], [], [], [], [], [], []
+    r_point, r_target, r_match = [], [], []
+    for hk in range(nF):
+        I = W.pyr0[hk]
+        g2 = I[..., 1].astype(np.float64) ** 2 + I[..., 2].astype(np.float64) ** 2
+        m = 6 * pts_per_kf
+        xs = rng.integers(8, w - 8, m)
+        ys = rng.integers(8, h - 8, m)
+        order = np.argsort(~(g2[ys, xs] > 30), kind="stable")[:pts_per_kf]
+        order = np.sort(order)
+        xs, ys = xs[order], ys[order]
+        z = depths[hk][ys, xs]
+        true_id = 1.0 / z
+        Rh = quat_to_R(gt[hk][:4]); th = gt[hk][4:]
+        Xc = np.stack([(xs - cx) / fx * z, (ys - cy) / fy * z, z], -1)
+        Xw = (Xc - th) @ Rh  # R^T (Xc - t)
+        base = len(host)
+        for i in range(len(xs)):
+            host.append(hk)
+        us += list(xs.astype(np.float32)); vs += list(ys.astype(np.float32))
+        idp += list((true_id * (1 + rng.normal(0, idepth_sigma, len(xs)))).astype(np.float32))
+        px = xs[:, None] + PATTERN8[None, :, 0]
+        py = ys[:, None] + PATTERN8[None, :, 1]
+        col += list(I[py, px, 0].astype(np.float32))
+        wts += list(np.sqrt(2500.0 / (2500.0 + g2[py, px])).astype(np.float32))
+        prior += [hk == 0] * len(xs)
+        sensor += list(rng.random(len(xs)) < sensor_frac)
+        for tk in range(nF):
+            if tk == hk:
+                continue
+            Rt = quat_to_R(gt[tk][:4]); tt = gt[tk][4:]
+            Xt = Xw @ Rt.T + tt
+            proj = np.stack([fx * Xt[:, 0] / Xt[:, 2] + cx, fy * Xt[:, 1] / Xt[:, 2] + cy], -1)
+            r_match.append((tk, proj + rng.normal(0, matcher_sigma, proj.shape)))
+        # residual order: point-major, targets ascending
+        for i in range(len(xs)):
+            for j, tk in enumerate([t for t in range(nF) if t != hk]):
+                r_point.append(base + i)
+                r_target.append(tk)
+        W._match_blocks = getattr(W, "_match_blocks", []) + [np.stack([mm[1] for mm in r_match[-(nF - 1):]], 1)]  # (P, nF-1, 2)
+    W.host = np.array(host, np.int32)
+    W.u = np.array(us, np.float32); W.v = np.array(vs, np.float32)
+    W.idepth = np.array(idp, np.float32)
+    W.idepth_zero = W.idepth.copy()
+    W.color = np.array(col, np.float32).reshape(-1, 8)
+    W.weights = np.array(wts, np.float32).reshape(-1, 8)
+    W.hasDepthPrior = np.array(prior, np.uint8)
+    W.isFromSensor = np.array(sensor, np.uint8)
+    W.r_point = np.array(r_point, np.int32)
+    W.r_target = np.array(r_target, np.int32)
+    W.r_matcher = np.concatenate([b.reshape(-1, 2) for b in W._match_blocks]).astype(np.float64)
+    del W._match_blocks
+    nR = len(W.r_point)
+    W.r_state = np.zeros(nR, np.int32)          # ResState::IN after resetOOB()
+    W.r_hasMatcher = np.ones(nR, np.uint8)
+    W.r_isLinearized = np.zeros(nR, np.uint8)
+    W.r_isActive = np.zeros(nR, np.uint8)
+    W.nP, W.nR = len(W.host), nR
+    ndim = 4 + 6 * nF
+    if marg_prior:
+        A = rng.normal(0, 1, (ndim, ndim))
+        W.HM = 1e2 * (A @ A.T) / ndim
+        W.bM = rng.normal(0, 10, ndim)
+    else:
+        W.HM = np.zeros((ndim, ndim)); W.bM = np.zeros(ndim)
+    return W
