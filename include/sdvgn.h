@@ -115,6 +115,89 @@ int sdvgn_tracker_res_and_gs_batch(sdvgn_tracker* t, int lvl, int B, const doubl
                                    float cutoffTH, double* out_dev);
 void* sdvgn_tracker_stream(sdvgn_tracker* t);
 
+/* ===================================================================================================
+ * Sliding-window back end -- replaces the data-parallel part of class EnergyFunctional
+ * (src/OptimizationBackend/EnergyFunctional.h:36-138) and of FullSystem::linearizeAll
+ * (src/FullSystem/FullSystemOptimize.cpp:99-159) on a flattened copy of the EF graph.
+ *
+ * The shim flattens the pointer graph once per makeIDX() (EnergyFunctional.cpp:761-782):
+ * frames in EF order, points grouped by host frame, one residual row per (point, target frame).
+ * =================================================================================================== */
+typedef struct sdvgn_ef sdvgn_ef;
+
+#define SDVGN_MAX_FRAMES 8 /* setting_maxFrames = 7 in the reference (src/util/settings.cpp:46-47) */
+
+/* EnergyFunctional::EnergyFunctional + the level-0 images of the window.  w,h = wG[0],hG[0]. */
+int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, void* stream);
+void sdvgn_ef_destroy(sdvgn_ef* ef);
+void* sdvgn_ef_stream(sdvgn_ef* ef);
+
+/* CalibHessian: value_scaled = {fx,fy,cx,cy} and value_minus_value_zero (HessianBlocks.h:262-330). */
+int sdvgn_ef_set_calib(sdvgn_ef* ef, const double value_scaled[4], const double value_minus_value_zero[4]);
+/* FrameHessian / EFFrame state of the nF window frames (insertFrame, EFFrame::takeData, FrameHessian::setState):
+ * evalPT7 = worldToCam_evalPT (Sophus data() layout), state10/state_zero10 = FrameHessian::state / state_zero
+ * (unscaled), frameID (0 => initial pose prior, HessianBlocks.h:220-232), ab_exposure, frameEnergyTH. */
+int sdvgn_ef_set_frames(sdvgn_ef* ef, int nF, const double* evalPT7, const double* state10, const double* state_zero10,
+                        const int* frameID, const float* ab_exposure, const float* frameEnergyTH);
+/* FrameHessian::dI (level-0 AoS {I,dx,dy}, w*h*3 floats) of frame idx; _raw builds it on the GPU from the float
+ * image like FrameHessian::makeImages (HessianBlocks.cpp:107-167). */
+int sdvgn_ef_set_frame_image(sdvgn_ef* ef, int idx, const float* dI_aos3);
+int sdvgn_ef_set_frame_image_raw(sdvgn_ef* ef, int idx, const float* image);
+/* PointHessian / EFPoint (insertPoint, EFPoint::takeData): host frame index, integer pixel u,v, idepth,
+ * idepth_zero, color[8], weights[8] (ImmaturePoint.cpp:14-27), hasDepthPrior, isFromSensor.  Points must be
+ * grouped by host frame (ascending). */
+int sdvgn_ef_set_points(sdvgn_ef* ef, int nP, const int* host, const float* u, const float* v, const float* idepth,
+                        const float* idepth_zero, const float* color8, const float* weights8,
+                        const unsigned char* hasDepthPrior, const unsigned char* isFromSensor);
+/* PointFrameResidual / EFResidual (insertResidual): point index, target frame index, state_state (ResState),
+ * hasMatcher + matcher pixel (Residuals.cpp:44-58), isLinearized, isActiveAndIsGoodNEW.  At most one residual per
+ * (point,target). */
+int sdvgn_ef_set_residuals(sdvgn_ef* ef, int nR, const int* point, const int* target, const int* state_state,
+                           const unsigned char* hasMatcher, const double* matcher_xy, const unsigned char* isLinearized,
+                           const unsigned char* isActive);
+/* EnergyFunctional::HM, bM (marginalisation prior) and lastNullspaces_pose + _scale (EnergyFunctional.h:96-119). */
+int sdvgn_ef_set_marg_prior(sdvgn_ef* ef, const double* HM, const double* bM);
+int sdvgn_ef_set_nullspaces(sdvgn_ef* ef, int k, const double* vectors);
+
+/* FullSystem::setPrecalcValues (FrameFramePrecalc::set for every pair, HessianBlocks.cpp:169-195) +
+ * EnergyFunctional::setDeltaF (EnergyFunctional.cpp:131-156). */
+int sdvgn_ef_set_precalc(sdvgn_ef* ef);
+/* EnergyFunctional::setAdjointsF (EnergyFunctional.cpp:21-71). */
+int sdvgn_ef_set_adjoints(sdvgn_ef* ef);
+
+/* Vec3 FullSystem::linearizeAll(false)[0]: PointFrameResidual::linearize over all non-linearised residuals
+ * (FullSystemOptimize.cpp:99-118, Residuals.cpp:60-224).  energy_out = stats[0]. */
+int sdvgn_ef_linearize_all(sdvgn_ef* ef, double* energy_out);
+/* FullSystem::applyRes_Reductor(true): PointFrameResidual::applyRes over the same residuals (Residuals.cpp:252-275). */
+int sdvgn_ef_apply_res(sdvgn_ef* ef);
+/* void EnergyFunctional::solveSystemF(int iteration, double lambda, CalibHessian*)   EnergyFunctional.cpp:650-759
+ * (accumulateAF/LF/SCF, HM/bM, damped Jacobi-preconditioned LDLT, orthogonalize for iteration >= 2, resubstitute).
+ * x_out[4+6nF] = lastX; frame/calib steps are -x, point steps stay on the device (sdvgn_ef_get_points). */
+int sdvgn_ef_solve_system(sdvgn_ef* ef, int iteration, double lambda, double* x_out);
+/* doStepFromBackup / backupState / loadSateBackup for the per-point idepths (FullSystemOptimize.cpp:165-321):
+ * mode 0: backup = idepth; mode 1: idepth = idepth_zero = backup + stepfac*step; mode 2: idepth = idepth_zero = backup */
+int sdvgn_ef_point_step(sdvgn_ef* ef, int mode, float stepfacD);
+/* new frame states after a step (FrameHessian::setState) -- follow with sdvgn_ef_set_precalc */
+int sdvgn_ef_set_frame_states(sdvgn_ef* ef, const double* state10);
+
+/* parity / read-back hooks */
+int sdvgn_ef_dim(sdvgn_ef* ef);
+int sdvgn_ef_get_system(sdvgn_ef* ef, double* HA, double* bA, double* Hsc, double* bsc, double* HFinal, double* bFinal);
+int sdvgn_ef_get_residual_J(sdvgn_ef* ef, int which /*0 new, 1 EF*/, float* out24 /*[nR][24]*/);
+int sdvgn_ef_get_residual_state(sdvgn_ef* ef, int* state_state, int* state_new, float* energy_new,
+                                float* energy_with_outlier, unsigned char* isActive);
+int sdvgn_ef_get_points(sdvgn_ef* ef, float* out9 /*[nP][Hdd_accAF,bd_accAF,Hcd_accAF x4,HdiF,bdSumF,step]*/);
+int sdvgn_ef_get_top_acc(sdvgn_ef* ef, double* out /*[nF*nF][11*11], index h + nF*t*/, int* resInA);
+/* device pointer + element count of the packed accumulator buffer that cfg4 all-reduces across ranks (doubles):
+ * top Gram [nF*nF][256] followed by SC Gram [nF][10][256] followed by {energy, resInA}. */
+int sdvgn_ef_accumulators_dev(sdvgn_ef* ef, double** buf_dev, int* count);
+/* solve_system split for multi-GPU: accumulate only (fills the packed buffer), then finish (stitch, solve, resubstitute)
+ * after the caller has all-reduced the buffer. */
+int sdvgn_ef_accumulate(sdvgn_ef* ef);
+int sdvgn_ef_finish_solve(sdvgn_ef* ef, int iteration, double lambda, double* x_out);
+/* restrict this rank's work to host frames [h0,h1) (cfg4: frames sharded across GPUs); default all. */
+int sdvgn_ef_set_host_range(sdvgn_ef* ef, int h0, int h1);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,181 @@
+"""ctypes binding of the sdvgn_ef_* entry points (include/sdvgn.h) + a Python mirror of the EnergyFunctional surface."""
+import ctypes as C
+
+import numpy as np
+
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+vp = C.c_void_p
+
+PROTOTYPES = [
+    ("sdvgn_ef_create", C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    ("sdvgn_ef_destroy", None, [vp]),
+    ("sdvgn_ef_stream", vp, [vp]),
+    ("sdvgn_ef_set_calib", C.c_int, [vp, f64p, f64p]),
+    ("sdvgn_ef_set_frames", C.c_int, [vp, C.c_int, f64p, f64p, f64p, i32p, f32p, f32p]),
+    ("sdvgn_ef_set_frame_image", C.c_int, [vp, C.c_int, f32p]),
+    ("sdvgn_ef_set_frame_image_raw", C.c_int, [vp, C.c_int, f32p]),
+    ("sdvgn_ef_set_points", C.c_int, [vp, C.c_int, i32p, f32p, f32p, f32p, f32p, f32p, f32p, u8p, u8p]),
+    ("sdvgn_ef_set_residuals", C.c_int, [vp, C.c_int, i32p, i32p, i32p, u8p, f64p, u8p, u8p]),
+    ("sdvgn_ef_set_marg_prior", C.c_int, [vp, f64p, f64p]),
+    ("sdvgn_ef_set_nullspaces", C.c_int, [vp, C.c_int, f64p]),
+    ("sdvgn_ef_set_precalc", C.c_int, [vp]),
+    ("sdvgn_ef_set_adjoints", C.c_int, [vp]),
+    ("sdvgn_ef_linearize_all", C.c_int, [vp, vp]),
+    ("sdvgn_ef_apply_res", C.c_int, [vp]),
+    ("sdvgn_ef_solve_system", C.c_int, [vp, C.c_int, C.c_double, vp]),
+    ("sdvgn_ef_point_step", C.c_int, [vp, C.c_int, C.c_float]),
+    ("sdvgn_ef_set_frame_states", C.c_int, [vp, f64p]),
+    ("sdvgn_ef_dim", C.c_int, [vp]),
+    ("sdvgn_ef_get_system", C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
+    ("sdvgn_ef_get_residual_J", C.c_int, [vp, C.c_int, f32p]),
+    ("sdvgn_ef_get_residual_state", C.c_int, [vp, vp, vp, vp, vp, vp]),
+    ("sdvgn_ef_get_points", C.c_int, [vp, f32p]),
+    ("sdvgn_ef_get_top_acc", C.c_int, [vp, f64p, vp]),
+    ("sdvgn_ef_accumulators_dev", C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int)]),
+    ("sdvgn_ef_accumulate", C.c_int, [vp]),
+    ("sdvgn_ef_finish_solve", C.c_int, [vp, C.c_int, C.c_double, vp]),
+    ("sdvgn_ef_set_host_range", C.c_int, [vp, C.c_int, C.c_int]),
+]
+
+
+class EnergyFunctional:
+    """Flattened EnergyFunctional window on the GPU; method names follow the reference
+    (EnergyFunctional.h:51-72, FullSystemOptimize.cpp:99-159, 504-520)."""
+
+    def __init__(self, w, h, max_points, device=0, stream=None):
+        from .api import check, load_library
+        self.L = load_library()
+        self._check = check
+        self.w, self.h = w, h
+        hnd = vp()
+        check(self.L.sdvgn_ef_create(C.byref(hnd), device, w, h, max_points, stream))
+        self.h_ = hnd
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.L.sdvgn_ef_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load(self, W, raw_images=False):
+        c = np.ascontiguousarray
+        ck = self._check
+        self.nF, self.nP, self.nR = W.nF, W.nP, W.nR
+        ck(self.L.sdvgn_ef_set_calib(self.h_, c(W.value_scaled, np.float64), c(W.value_minus_value_zero, np.float64)))
+        ck(self.L.sdvgn_ef_set_frames(self.h_, W.nF, c(W.evalPT, np.float64).reshape(-1), c(W.state, np.float64).reshape(-1),
+                                      c(W.state_zero, np.float64).reshape(-1), c(W.frameID, np.int32), c(W.ab_exposure, np.float32),
+                                      c(W.frameEnergyTH, np.float32)))
+        for k in range(W.nF):
+            if raw_images:
+                ck(self.L.sdvgn_ef_set_frame_image_raw(self.h_, k, c(W.images[k], np.float32).reshape(-1)))
+            else:
+                ck(self.L.sdvgn_ef_set_frame_image(self.h_, k, c(W.pyr0[k], np.float32).reshape(-1)))
+        ck(self.L.sdvgn_ef_set_points(self.h_, W.nP, c(W.host, np.int32), c(W.u, np.float32), c(W.v, np.float32), c(W.idepth, np.float32),
+                                      c(W.idepth_zero, np.float32), c(W.color, np.float32).reshape(-1), c(W.weights, np.float32).reshape(-1),
+                                      c(W.hasDepthPrior, np.uint8), c(W.isFromSensor, np.uint8)))
+        ck(self.L.sdvgn_ef_set_residuals(self.h_, W.nR, c(W.r_point, np.int32), c(W.r_target, np.int32), c(W.r_state, np.int32),
+                                         c(W.r_hasMatcher, np.uint8), c(W.r_matcher, np.float64).reshape(-1), c(W.r_isLinearized, np.uint8),
+                                         c(W.r_isActive, np.uint8)))
+        ck(self.L.sdvgn_ef_set_marg_prior(self.h_, c(W.HM, np.float64).reshape(-1), c(W.bM, np.float64)))
+        if getattr(W, "nullspaces", None) is not None:
+            ns = c(W.nullspaces, np.float64)
+            ck(self.L.sdvgn_ef_set_nullspaces(self.h_, ns.shape[0], ns.reshape(-1)))
+        self.setAdjointsF()
+        self.setPrecalcValues()
+        return self
+
+    def setPrecalcValues(self):
+        self._check(self.L.sdvgn_ef_set_precalc(self.h_))
+
+    def setAdjointsF(self):
+        self._check(self.L.sdvgn_ef_set_adjoints(self.h_))
+
+    def set_marg_prior(self, HM, bM):
+        self._check(self.L.sdvgn_ef_set_marg_prior(self.h_, np.ascontiguousarray(HM, np.float64).reshape(-1), np.ascontiguousarray(bM, np.float64)))
+
+    def set_nullspaces(self, ns):
+        ns = np.ascontiguousarray(ns, np.float64)
+        self._check(self.L.sdvgn_ef_set_nullspaces(self.h_, ns.shape[0], ns.reshape(-1)))
+
+    def set_frame_states(self, state10):
+        self._check(self.L.sdvgn_ef_set_frame_states(self.h_, np.ascontiguousarray(state10, np.float64).reshape(-1)))
+
+    def set_host_range(self, h0, h1):
+        self._check(self.L.sdvgn_ef_set_host_range(self.h_, h0, h1))
+
+    def linearizeAll(self, want_energy=True):
+        e = C.c_double(0)
+        self._check(self.L.sdvgn_ef_linearize_all(self.h_, C.byref(e) if want_energy else None))
+        return e.value
+
+    def applyRes(self):
+        self._check(self.L.sdvgn_ef_apply_res(self.h_))
+
+    def solveSystemF(self, iteration, lam):
+        x = np.zeros(self.dim)
+        self._check(self.L.sdvgn_ef_solve_system(self.h_, iteration, lam, x.ctypes.data_as(vp)))
+        return x
+
+    def accumulate(self):
+        self._check(self.L.sdvgn_ef_accumulate(self.h_))
+
+    def finish_solve(self, iteration, lam):
+        x = np.zeros(self.dim)
+        self._check(self.L.sdvgn_ef_finish_solve(self.h_, iteration, lam, x.ctypes.data_as(vp)))
+        return x
+
+    def accumulators_dev(self):
+        p = vp()
+        n = C.c_int(0)
+        self._check(self.L.sdvgn_ef_accumulators_dev(self.h_, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def point_step(self, mode, fac=1.0):
+        self._check(self.L.sdvgn_ef_point_step(self.h_, mode, fac))
+
+    @property
+    def dim(self):
+        return self.L.sdvgn_ef_dim(self.h_)
+
+    def system(self):
+        n = self.dim
+        out = dict(HA=np.zeros((n, n)), bA=np.zeros(n), Hsc=np.zeros((n, n)), bsc=np.zeros(n), HFinal=np.zeros((n, n)), bFinal=np.zeros(n))
+        self._check(self.L.sdvgn_ef_get_system(self.h_, *[out[k].ctypes.data_as(vp) for k in ("HA", "bA", "Hsc", "bsc", "HFinal", "bFinal")]))
+        return out
+
+    def residual_J(self, which):
+        out = np.zeros((self.nR, 24), np.float32)
+        self._check(self.L.sdvgn_ef_get_residual_J(self.h_, which, out.reshape(-1)))
+        return out
+
+    def residual_state(self):
+        ss = np.zeros(self.nR, np.int32)
+        sn = np.zeros(self.nR, np.int32)
+        en = np.zeros(self.nR, np.float32)
+        eo = np.zeros(self.nR, np.float32)
+        ac = np.zeros(self.nR, np.uint8)
+        self._check(self.L.sdvgn_ef_get_residual_state(self.h_, ss.ctypes.data_as(vp), sn.ctypes.data_as(vp), en.ctypes.data_as(vp),
+                                                       eo.ctypes.data_as(vp), ac.ctypes.data_as(vp)))
+        return dict(state=ss, new_state=sn, new_energy=en, energy_with_outlier=eo, active=ac)
+
+    def points(self):
+        out = np.zeros((self.nP, 9), np.float32)
+        self._check(self.L.sdvgn_ef_get_points(self.h_, out.reshape(-1)))
+        return out
+
+    def top_acc(self):
+        out = np.zeros((self.nF * self.nF, 11, 11))
+        n = C.c_int(0)
+        self._check(self.L.sdvgn_ef_get_top_acc(self.h_, out.reshape(-1), C.byref(n)))
+        return out, n.value
+
+    def stream(self):
+        return self.L.sdvgn_ef_stream(self.h_)

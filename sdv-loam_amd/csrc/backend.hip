@@ -1,0 +1,888 @@
+// backend.hip -- host side of the GPU sliding-window back end + its C ABI (include/sdvgn.h, sdvgn_ef_*).
+//
+// Mirrors the data-parallel part of class EnergyFunctional (src/OptimizationBackend/EnergyFunctional.{h,cpp}) and of
+// FullSystem::linearizeAll / applyRes_Reductor (src/FullSystem/FullSystemOptimize.cpp:23-159) on a flattened window:
+//   device: linearize, applyRes, per-point sums, the (host,target) 13x13 accumulators and the Schur-complement
+//           accumulators (as MFMA Gram matrices), resubstitution of the point steps;
+//   host:   FrameFramePrecalc / adjoints / deltas (nF^2 tiny 3x3 / 6x6 products), the double-precision stitch of the
+//           (4+6nF)^2 system, the Jacobi-preconditioned LDLT solve and the null-space projection -- all O(nF^3) and
+//           independent of the number of points ("tiny; keep on host").
+#include "../../include/sdvgn.h"
+#include "backend_kernels.hpp"
+#include "gnmath.hpp"
+#include "tracker_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#define HIPCHK(expr)                                  \
+    do {                                              \
+        hipError_t _e = (expr);                       \
+        if (_e != hipSuccess) return -(int)_e;        \
+    } while (0)
+
+using namespace sdvgn;
+
+namespace {
+
+constexpr int CPARS = 4;
+constexpr int kTopE = 256;        // one 16x16 tile per (host,target)
+constexpr int kScE = 10 * 256;    // 10 upper tiles of the 64x64 Gram per host
+constexpr int kMaxChunks = 64;
+const float kScaleXiRot = 1.0f, kScaleXiTrans = 0.5f, kScaleA = 10.0f, kScaleB = 1000.0f;
+const float kInitialRotPrior = 1e11f, kInitialTransPrior = 1e10f, kInitialCalibHessian = 5e9f, kIdepthFixPrior = 50 * 50;
+
+struct FrameH {
+    gn::Pose evalPT, PRE_worldToCam, PRE_camToWorld;
+    double state[10], state_zero[10], state_scaled[10];
+    double prior[6], delta[6], delta_prior[6];
+    int frameID;
+    float ab_exposure, frameEnergyTH;
+};
+
+template <typename T>
+int dev_alloc(T** p, size_t n) { return hipMalloc((void**)p, sizeof(T) * (n ? n : 1)) == hipSuccess ? 0 : -1; }
+
+}  // namespace
+
+struct sdvgn_ef {
+    int device = 0, w = 0, h = 0, max_points = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int nF = 0, nP = 0, nR = 0;
+    int h0 = 0, h1 = SDVGN_MAX_FRAMES;   // host-frame shard of this rank
+    // calib
+    double value_scaled[4] = {0, 0, 0, 0}, value_minus_value_zero[4] = {0, 0, 0, 0};
+    EFConst C{};
+    std::vector<FrameH> frames;
+    std::vector<int> phost, hostP0, r_slot;
+    std::vector<double> adHost, adTarget;      // [h + t*nF][36]
+    std::vector<float> adHostF, adTargetF;
+    double cPrior[4];
+    std::vector<double> HM, bM;
+    std::vector<std::vector<double>> nullspaces;
+    std::vector<double> HA, bA, Hsc, bsc, HFinal, bFinal, lastX;
+    int resInA = 0;
+    // device
+    EFArrays A{};
+    float *pu = nullptr, *pv = nullptr, *pidz = nullptr, *pid = nullptr, *pidepth_backup = nullptr, *ppriorF = nullptr, *pdeltaF = nullptr;
+    float4 *pcolor = nullptr, *pweights = nullptr;
+    uint8_t* psensor = nullptr;
+    uint8_t* rflags = nullptr;
+    int8_t *rstate = nullptr, *rstate_new = nullptr;
+    float2* rmatcher = nullptr;
+    float *renergy = nullptr, *renergy_new = nullptr, *renergy_wo = nullptr, *rres_toZero = nullptr, *J = nullptr, *JpJd = nullptr;
+    float *pHddA = nullptr, *pbdA = nullptr, *pHcdA = nullptr, *pHddL = nullptr, *pbdL = nullptr, *pHcdL = nullptr, *pHdi = nullptr,
+          *pbdSum = nullptr, *pHcd = nullptr, *pstep = nullptr;
+    float* images = nullptr;
+    float* img_stage = nullptr;
+    int *phost_dev = nullptr, *hostP0_dev = nullptr;
+    PrecalcDev* precalc_dev = nullptr;
+    PrecalcDev* precalc_host = nullptr;  // pinned
+    double* energy_partial = nullptr;
+    float *top_partial = nullptr, *sc_partial = nullptr;
+    int* nres_partial = nullptr;
+    double* acc_dev = nullptr;    // packed: top [nF*nF][256] | sc [nF][2560] | energy | resInA
+    double* acc_host = nullptr;   // pinned mirror
+    float *xc_dev = nullptr, *xAd_dev = nullptr;
+    float* x_host = nullptr;      // pinned: xc(4) + xAd(nF*nF*6)
+    size_t slots_cap = 0;
+    bool havePrecalc = false, haveAdjoints = false;
+};
+
+static size_t acc_count(const sdvgn_ef* e) { return (size_t)e->nF * e->nF * kTopE + (size_t)e->nF * kScE + 2; }
+
+static void frame_set_state(FrameH& f, const double* state) {  // FrameHessian::setState, HessianBlocks.h:131-143
+    for (int i = 0; i < 10; ++i) f.state[i] = state[i];
+    for (int i = 0; i < 3; ++i) f.state_scaled[i] = kScaleXiTrans * state[i];
+    for (int i = 3; i < 6; ++i) f.state_scaled[i] = kScaleXiRot * state[i];
+    f.state_scaled[6] = kScaleA * state[6]; f.state_scaled[7] = kScaleB * state[7];
+    f.state_scaled[8] = kScaleA * state[8]; f.state_scaled[9] = kScaleB * state[9];
+    f.PRE_worldToCam = gn::compose(gn::exp_se3(f.state_scaled), f.evalPT);
+    f.PRE_camToWorld = gn::inverse(f.PRE_worldToCam);
+}
+
+static void m3f_mul(const float* A, const float* B, float* C) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) C[i * 3 + j] = (A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j]) + A[i * 3 + 2] * B[6 + j];
+}
+
+static void ef_fill_arrays(sdvgn_ef* e) {
+    EFArrays& A = e->A;
+    A.pu = e->pu; A.pv = e->pv; A.pidz = e->pidz; A.pid = e->pid; A.pcolor = e->pcolor; A.pweights = e->pweights;
+    A.ppriorF = e->ppriorF; A.pdeltaF = e->pdeltaF; A.psensor = e->psensor;
+    A.rflags = e->rflags; A.rstate = e->rstate; A.rstate_new = e->rstate_new; A.rmatcher = e->rmatcher;
+    A.renergy = e->renergy; A.renergy_new = e->renergy_new; A.renergy_wo = e->renergy_wo; A.rres_toZero = e->rres_toZero;
+    A.J = e->J; A.JpJd = e->JpJd;
+    A.pHddA = e->pHddA; A.pbdA = e->pbdA; A.pHcdA = e->pHcdA; A.pHddL = e->pHddL; A.pbdL = e->pbdL; A.pHcdL = e->pHcdL;
+    A.pHdi = e->pHdi; A.pbdSum = e->pbdSum; A.pHcd = e->pHcd; A.pstep = e->pstep;
+    A.images = e->images;
+}
+
+static void ef_update_const(sdvgn_ef* e) {  // CalibHessian float views, HessianBlocks.h:302-330
+    EFConst& C = e->C;
+    C.nF = e->nF; C.nP = e->nP; C.w = e->w; C.h = e->h;
+    C.fxl = (float)e->value_scaled[0]; C.fyl = (float)e->value_scaled[1];
+    C.cxl = (float)e->value_scaled[2]; C.cyl = (float)e->value_scaled[3];
+    C.fxli = 1.0f / C.fxl; C.fyli = 1.0f / C.fyl;
+    C.wM3G = e->w - 3; C.hM3G = e->h - 3;
+    for (int i = 0; i < 4; ++i) C.cDeltaF[i] = (float)e->value_minus_value_zero[i];
+    C.huberTH = 6.0f; C.outlierTHSumComponent = 50 * 50;
+}
+
+// ---------------- host stitch: top (AccumulatedTopHessian.cpp:181-242 + .h:100-113) --------------------------
+static void stitch_top(sdvgn_ef* e, const double* G /*[nF*nF][256]*/) {
+    const int nF = e->nF, n = CPARS + 6 * nF;
+    std::vector<double>& H = e->HA;
+    std::vector<double>& b = e->bA;
+    H.assign((size_t)n * n, 0); b.assign(n, 0);
+    for (int k = 0; k < nF * nF; ++k) {
+        const int h = k % nF, t = k / nF;
+        if (h == t) continue;
+        const int hIdx = CPARS + h * 6, tIdx = CPARS + t * 6;
+        const double* g = G + (size_t)(h * nF + t) * kTopE;   // device pair index = h*nF + t, 16x16 row-major
+        const double* AH = &e->adHost[(size_t)(h + t * nF) * 36];
+        const double* AT = &e->adTarget[(size_t)(h + t * nF) * 36];
+        // T1 = AH * A66, T2 = AT * A66   (A66 = g[4..9][4..9])
+        double T1[36], T2[36];
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j) {
+                double s1 = 0, s2 = 0;
+                for (int q = 0; q < 6; ++q) { s1 += AH[i * 6 + q] * g[(4 + q) * 16 + 4 + j]; s2 += AT[i * 6 + q] * g[(4 + q) * 16 + 4 + j]; }
+                T1[i * 6 + j] = s1; T2[i * 6 + j] = s2;
+            }
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j) {
+                double hh = 0, tt = 0, ht = 0;
+                for (int q = 0; q < 6; ++q) { hh += T1[i * 6 + q] * AH[j * 6 + q]; tt += T2[i * 6 + q] * AT[j * 6 + q]; ht += T1[i * 6 + q] * AT[j * 6 + q]; }
+                H[(size_t)(hIdx + i) * n + hIdx + j] += hh;
+                H[(size_t)(tIdx + i) * n + tIdx + j] += tt;
+                H[(size_t)(hIdx + i) * n + tIdx + j] += ht;
+            }
+        for (int i = 0; i < 6; ++i) {
+            for (int j = 0; j < CPARS; ++j) {
+                double sh = 0, st = 0;
+                for (int q = 0; q < 6; ++q) { sh += AH[i * 6 + q] * g[(4 + q) * 16 + j]; st += AT[i * 6 + q] * g[(4 + q) * 16 + j]; }
+                H[(size_t)(hIdx + i) * n + j] += sh;
+                H[(size_t)(tIdx + i) * n + j] += st;
+            }
+            double sh = 0, st = 0;
+            for (int q = 0; q < 6; ++q) { sh += AH[i * 6 + q] * g[(4 + q) * 16 + 10]; st += AT[i * 6 + q] * g[(4 + q) * 16 + 10]; }
+            b[hIdx + i] += sh;
+            b[tIdx + i] += st;
+        }
+        for (int i = 0; i < CPARS; ++i) {
+            for (int j = 0; j < CPARS; ++j) H[(size_t)i * n + j] += g[i * 16 + j];
+            b[i] += g[i * 16 + 10];
+        }
+    }
+    // priors (usePrior)
+    for (int i = 0; i < CPARS; ++i) { H[(size_t)i * n + i] += e->cPrior[i]; b[i] += e->cPrior[i] * (double)e->C.cDeltaF[i]; }
+    for (int h = 0; h < nF; ++h)
+        for (int i = 0; i < 6; ++i) {
+            H[(size_t)(CPARS + h * 6 + i) * n + CPARS + h * 6 + i] += e->frames[h].prior[i];
+            b[CPARS + h * 6 + i] += e->frames[h].prior[i] * e->frames[h].delta_prior[i];
+        }
+    for (int h = 0; h < nF; ++h) {
+        const int hIdx = CPARS + h * 6;
+        for (int i = 0; i < CPARS; ++i) for (int j = 0; j < 6; ++j) H[(size_t)i * n + hIdx + j] = H[(size_t)(hIdx + j) * n + i];
+        for (int t = h + 1; t < nF; ++t) {
+            const int tIdx = CPARS + t * 6;
+            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) H[(size_t)(hIdx + i) * n + tIdx + j] += H[(size_t)(tIdx + j) * n + hIdx + i];
+            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) H[(size_t)(tIdx + i) * n + hIdx + j] = H[(size_t)(hIdx + j) * n + tIdx + i];
+        }
+    }
+}
+
+// ---------------- host stitch: Schur complement (AccumulatedSCHessian.cpp:64-135 + .h:108-113) ----------------
+// G_h is the 64x64 Gram of host h (upper 16x16 tiles); features 6t+i (JpJdF of target t), 48-51 Hcd, 52 bdSum.
+// Uses A_h = [AH_h0 | ... | AH_h,nF-1] (6 x 6nF) so that all  AH D AH^T / AH D AT^T / AT D AH^T  terms of one host come
+// from B = A_h * D_h (6 x 6nF) instead of nF^2 separate 6x6x6 products.
+static void stitch_sc(sdvgn_ef* e, const double* Gall /*[nF][10][256]*/) {
+    const int nF = e->nF, n = CPARS + 6 * nF, nf6 = 6 * nF;
+    std::vector<double>& H = e->Hsc;
+    std::vector<double>& b = e->bsc;
+    H.assign((size_t)n * n, 0); b.assign(n, 0);
+    const double sT[6] = {kScaleXiTrans, kScaleXiTrans, kScaleXiTrans, kScaleXiRot, kScaleXiRot, kScaleXiRot};  // adTarget = diag
+    std::vector<double> G(64 * 64), Ah((size_t)6 * nf6), B((size_t)6 * nf6);
+    for (int h = 0; h < nF; ++h) {
+        const double* gt = Gall + (size_t)h * kScE;
+        int a = 0;
+        for (int ti = 0; ti < 4; ++ti)
+            for (int tj = ti; tj < 4; ++tj) {
+                const double* tile = gt + (size_t)a * 256;
+                for (int r = 0; r < 16; ++r)
+                    for (int c = 0; c < 16; ++c) {
+                        G[(size_t)(ti * 16 + r) * 64 + tj * 16 + c] = tile[r * 16 + c];
+                        if (ti != tj) G[(size_t)(tj * 16 + c) * 64 + ti * 16 + r] = tile[r * 16 + c];
+                    }
+                ++a;
+            }
+        const int iIdx = CPARS + h * 6;
+        for (int j = 0; j < nF; ++j) {
+            const double* AH = &e->adHost[(size_t)(h + nF * j) * 36];
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Ah[(size_t)r * nf6 + 6 * j + c] = AH[r * 6 + c];
+        }
+        // B = A_h * D (D = G[0:nf6, 0:nf6])
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < nf6; ++c) {
+                double s = 0;
+                for (int q = 0; q < nf6; ++q) s += Ah[(size_t)r * nf6 + q] * G[(size_t)q * 64 + c];
+                B[(size_t)r * nf6 + c] = s;
+            }
+        // H[i,i] += sum_jk AH_ij D_jk AH_ik^T = B A_h^T
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) {
+                double s = 0;
+                for (int q = 0; q < nf6; ++q) s += B[(size_t)r * nf6 + q] * Ah[(size_t)c * nf6 + q];
+                H[(size_t)(iIdx + r) * n + iIdx + c] += s;
+            }
+        for (int k = 0; k < nF; ++k) {
+            const int kIdx = CPARS + k * 6;
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) {
+                    const double v = B[(size_t)r * nf6 + 6 * k + c];
+                    H[(size_t)(iIdx + r) * n + kIdx + c] += v * sT[c];       // AH_ij D_jk AT^T summed over j
+                    H[(size_t)(kIdx + c) * n + iIdx + r] += sT[c] * v;       // AT D_kj AH_ij^T summed over j (D symmetric)
+                }
+            for (int j = 0; j < nF; ++j) {
+                const int jIdx = CPARS + j * 6;
+                for (int r = 0; r < 6; ++r)
+                    for (int c = 0; c < 6; ++c) H[(size_t)(jIdx + r) * n + kIdx + c] += sT[r] * G[(size_t)(6 * j + r) * 64 + 6 * k + c] * sT[c];
+            }
+        }
+        // E (6nF x 4), EB (6nF)
+        for (int j = 0; j < nF; ++j) {
+            const int jIdx = CPARS + j * 6;
+            const double* AH = &e->adHost[(size_t)(h + nF * j) * 36];
+            for (int r = 0; r < 6; ++r) {
+                for (int c = 0; c < CPARS; ++c) {
+                    double sh = 0;
+                    for (int q = 0; q < 6; ++q) sh += AH[r * 6 + q] * G[(size_t)(6 * j + q) * 64 + 48 + c];
+                    H[(size_t)(iIdx + r) * n + c] += sh;
+                    H[(size_t)(jIdx + r) * n + c] += sT[r] * G[(size_t)(6 * j + r) * 64 + 48 + c];
+                }
+                double sh = 0;
+                for (int q = 0; q < 6; ++q) sh += AH[r * 6 + q] * G[(size_t)(6 * j + q) * 64 + 52];
+                b[iIdx + r] += sh;
+                b[jIdx + r] += sT[r] * G[(size_t)(6 * j + r) * 64 + 52];
+            }
+        }
+        for (int r = 0; r < CPARS; ++r) {
+            for (int c = 0; c < CPARS; ++c) H[(size_t)r * n + c] += G[(size_t)(48 + r) * 64 + 48 + c];
+            b[r] += G[(size_t)(48 + r) * 64 + 52];
+        }
+    }
+    for (int h = 0; h < nF; ++h) {
+        const int hIdx = CPARS + h * 6;
+        for (int i = 0; i < CPARS; ++i) for (int j = 0; j < 6; ++j) H[(size_t)i * n + hIdx + j] = H[(size_t)(hIdx + j) * n + i];
+    }
+}
+
+// one-sided Jacobi SVD (m x k, k small) used by the null-space projection
+static void svd_jacobi(int m, int k, std::vector<double>& A, std::vector<double>& s, std::vector<double>& V) {
+    V.assign((size_t)k * k, 0);
+    for (int i = 0; i < k; ++i) V[(size_t)i * k + i] = 1;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < k; ++p)
+            for (int q = p + 1; q < k; ++q) {
+                double a = 0, bb = 0, c = 0;
+                for (int i = 0; i < m; ++i) { const double x = A[(size_t)i * k + p], y = A[(size_t)i * k + q]; a += x * x; bb += y * y; c += x * y; }
+                off = std::max(off, std::fabs(c) / std::sqrt(std::max(a * bb, 1e-300)));
+                if (std::fabs(c) < 1e-300) continue;
+                const double zeta = (bb - a) / (2 * c);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1 + zeta * zeta));
+                const double cs = 1 / std::sqrt(1 + t * t), sn = cs * t;
+                for (int i = 0; i < m; ++i) { const double x = A[(size_t)i * k + p], y = A[(size_t)i * k + q]; A[(size_t)i * k + p] = cs * x - sn * y; A[(size_t)i * k + q] = sn * x + cs * y; }
+                for (int i = 0; i < k; ++i) { const double x = V[(size_t)i * k + p], y = V[(size_t)i * k + q]; V[(size_t)i * k + p] = cs * x - sn * y; V[(size_t)i * k + q] = sn * x + cs * y; }
+            }
+        if (off < 1e-15) break;
+    }
+    s.assign(k, 0);
+    for (int j = 0; j < k; ++j) {
+        double nn = 0;
+        for (int i = 0; i < m; ++i) nn += A[(size_t)i * k + j] * A[(size_t)i * k + j];
+        s[j] = std::sqrt(nn);
+        for (int i = 0; i < m; ++i) A[(size_t)i * k + j] = s[j] > 0 ? A[(size_t)i * k + j] / s[j] : 0;  // A becomes U
+    }
+}
+
+// EnergyFunctional::orthogonalize(&x, 0)  EnergyFunctional.cpp:615-648
+static void orthogonalize_x(sdvgn_ef* e, std::vector<double>& x) {
+    const int n = (int)x.size(), k = (int)e->nullspaces.size();
+    if (k == 0) return;
+    std::vector<double> N((size_t)n * k), U, s, V;
+    for (int j = 0; j < k; ++j) {
+        double nn = 0;
+        for (int i = 0; i < n; ++i) nn += e->nullspaces[j][i] * e->nullspaces[j][i];
+        nn = std::sqrt(nn);
+        for (int i = 0; i < n; ++i) N[(size_t)i * k + j] = e->nullspaces[j][i] / nn;
+    }
+    U = N;
+    svd_jacobi(n, k, U, s, V);
+    double maxSv = 0;
+    for (double v : s) maxSv = std::max(maxSv, v);
+    for (double& v : s) v = (v > 1e-5 * maxSv) ? 1.0 / v : 0;   // setting_solverModeDelta
+    // Npi = U S V^T ; y = 0.5 (N Npi^T + Npi N^T) x
+    std::vector<double> Npi((size_t)n * k, 0), tN(k, 0), tP(k, 0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < k; ++j) { double a = 0; for (int q = 0; q < k; ++q) a += U[(size_t)i * k + q] * s[q] * V[(size_t)j * k + q]; Npi[(size_t)i * k + j] = a; }
+    for (int j = 0; j < k; ++j) { double a = 0, c = 0; for (int i = 0; i < n; ++i) { a += N[(size_t)i * k + j] * x[i]; c += Npi[(size_t)i * k + j] * x[i]; } tN[j] = a; tP[j] = c; }
+    for (int i = 0; i < n; ++i) { double a = 0; for (int j = 0; j < k; ++j) a += N[(size_t)i * k + j] * tP[j] + Npi[(size_t)i * k + j] * tN[j]; x[i] -= 0.5 * a; }
+}
+
+static int ef_upload_precalc(sdvgn_ef* e) {
+    const int nF = e->nF;
+    const EFConst& C = e->C;
+    const float K[9] = {C.fxl, 0, C.cxl, 0, C.fyl, C.cyl, 0, 0, 1};
+    float Ki[9];
+    gn::inverse3f(K, Ki);
+    for (int h = 0; h < nF; ++h)
+        for (int t = 0; t < nF; ++t) {
+            PrecalcDev& P = e->precalc_host[h * nF + t];
+            const FrameH& host = e->frames[h];
+            const FrameH& target = e->frames[t];
+            double R[9];
+            const gn::Pose l0 = gn::compose(target.evalPT, gn::inverse(host.evalPT));
+            gn::rotation_matrix(l0.q, R);
+            for (int i = 0; i < 9; ++i) P.R0[i] = (float)R[i];
+            for (int i = 0; i < 3; ++i) P.t0[i] = (float)l0.t[i];
+            const gn::Pose l = gn::compose(target.PRE_worldToCam, host.PRE_camToWorld);
+            gn::rotation_matrix(l.q, R);
+            float Rf[9], tf[3], KR[9];
+            for (int i = 0; i < 9; ++i) Rf[i] = (float)R[i];
+            for (int i = 0; i < 3; ++i) tf[i] = (float)l.t[i];
+            m3f_mul(K, Rf, KR);
+            m3f_mul(KR, Ki, P.KRKi);
+            for (int i = 0; i < 3; ++i) P.Kt[i] = (K[i * 3] * tf[0] + K[i * 3 + 1] * tf[1]) + K[i * 3 + 2] * tf[2];
+            double ab[2];
+            gn::aff_from_to(host.ab_exposure, target.ab_exposure, host.state_scaled[6], host.state_scaled[7], target.state_scaled[6],
+                            target.state_scaled[7], ab);
+            P.aff0 = (float)ab[0]; P.aff1 = (float)ab[1];
+            P.b0 = (float)(host.state_zero[7] * kScaleB);
+            P.frameEnergyTH = std::max<float>(host.frameEnergyTH, target.frameEnergyTH);
+            // setDeltaF: adHTdeltaF[h + t*nF]
+            const float* AHf = &e->adHostF[(size_t)(h + t * nF) * 36];
+            const float* ATf = &e->adTargetF[(size_t)(h + t * nF) * 36];
+            float dh[6], dt[6];
+            for (int i = 0; i < 6; ++i) { dh[i] = (float)(host.state[i] - host.state_zero[i]); dt[i] = (float)(target.state[i] - target.state_zero[i]); }
+            for (int c = 0; c < 6; ++c) {
+                float a = 0, b = 0;
+                for (int q = 0; q < 6; ++q) { a += dh[q] * AHf[q * 6 + c]; b += dt[q] * ATf[q * 6 + c]; }
+                P.dp[c] = a + b;
+            }
+            P.P0 = e->hostP0.empty() ? 0 : e->hostP0[h];
+            P.np = e->hostP0.empty() ? 0 : e->hostP0[h + 1] - e->hostP0[h];
+            if (h < e->h0 || h >= e->h1) P.np = 0;   // not this rank's shard
+        }
+    for (FrameH& f : e->frames)
+        for (int i = 0; i < 6; ++i) { f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i]; }
+    HIPCHK(hipMemcpyAsync(e->precalc_dev, e->precalc_host, sizeof(PrecalcDev) * nF * nF, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->havePrecalc = true;
+    return 0;
+}
+
+__global__ void k_ef_sum_energy(const double* __restrict__ partial, int n, double* __restrict__ out) {
+    __shared__ double s[256];
+    double a = 0;
+    for (int i = threadIdx.x; i < n; i += 256) a += partial[i];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = s[0];
+}
+__global__ void k_ef_sum_nres(const int* __restrict__ partial, int n, double* __restrict__ out) {
+    __shared__ int s[256];
+    int a = 0;
+    for (int i = threadIdx.x; i < n; i += 256) a += partial[i];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = (double)s[0];
+}
+// mode 0: backup = idepth ; 1: idepth = idepth_zero = backup + fac*step ; 2: idepth = idepth_zero = backup
+__global__ void k_ef_point_step(int nP, int mode, float fac, float* __restrict__ pid, float* __restrict__ pidz, float* __restrict__ backup,
+                                const float* __restrict__ step, float* __restrict__ pdeltaF) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nP) return;
+    if (mode == 0) { backup[p] = pid[p]; return; }
+    const float v = (mode == 1) ? backup[p] + fac * step[p] : backup[p];
+    pid[p] = SDVGN_SCALE_IDEPTH * v;
+    pidz[p] = SDVGN_SCALE_IDEPTH * v;
+    pdeltaF[p] = v - v;   // idepth - idepth_zero
+}
+
+static int chunks_for_np(const sdvgn_ef* e) {
+    int mx = 1;
+    for (int h = 0; h < e->nF; ++h) mx = std::max(mx, e->hostP0[h + 1] - e->hostP0[h]);
+    return std::min(kMaxChunks, (mx + 255) / 256);
+}
+
+extern "C" {
+
+int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, void* stream) {
+    if (!out || w < 16 || h < 16 || max_points < 1) return SDVGN_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) return SDVGN_E_NODEVICE;
+    HIPCHK(hipSetDevice(device));
+    sdvgn_ef* e = new (std::nothrow) sdvgn_ef();
+    if (!e) return SDVGN_E_ARG;
+    e->device = device; e->w = w; e->h = h; e->max_points = max_points;
+    if (stream) e->stream = (hipStream_t)stream;
+    else { HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)); e->own_stream = true; }
+    const size_t mp = max_points, slots = mp * SDVGN_MAX_FRAMES;
+    e->slots_cap = slots;
+    int bad = 0;
+    bad |= dev_alloc(&e->pu, mp) | dev_alloc(&e->pv, mp) | dev_alloc(&e->pidz, mp) | dev_alloc(&e->pid, mp) | dev_alloc(&e->pidepth_backup, mp);
+    bad |= dev_alloc(&e->ppriorF, mp) | dev_alloc(&e->pdeltaF, mp) | dev_alloc(&e->pcolor, 2 * mp) | dev_alloc(&e->pweights, 2 * mp) | dev_alloc(&e->psensor, mp);
+    bad |= dev_alloc(&e->rflags, slots) | dev_alloc(&e->rstate, slots) | dev_alloc(&e->rstate_new, slots) | dev_alloc(&e->rmatcher, slots);
+    bad |= dev_alloc(&e->renergy, slots) | dev_alloc(&e->renergy_new, slots) | dev_alloc(&e->renergy_wo, slots) | dev_alloc(&e->rres_toZero, 2 * slots);
+    bad |= dev_alloc(&e->J, 2 * (size_t)kJPlanes * slots) | dev_alloc(&e->JpJd, 6 * slots);
+    bad |= dev_alloc(&e->pHddA, mp) | dev_alloc(&e->pbdA, mp) | dev_alloc(&e->pHcdA, 4 * mp) | dev_alloc(&e->pHddL, mp) | dev_alloc(&e->pbdL, mp) | dev_alloc(&e->pHcdL, 4 * mp);
+    bad |= dev_alloc(&e->pHdi, mp) | dev_alloc(&e->pbdSum, mp) | dev_alloc(&e->pHcd, 4 * mp) | dev_alloc(&e->pstep, mp);
+    bad |= dev_alloc(&e->images, (size_t)SDVGN_MAX_FRAMES * w * h * 3) | dev_alloc(&e->img_stage, (size_t)w * h);
+    bad |= dev_alloc(&e->phost_dev, mp) | dev_alloc(&e->hostP0_dev, SDVGN_MAX_FRAMES + 1);
+    bad |= dev_alloc(&e->precalc_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES);
+    bad |= dev_alloc(&e->energy_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks);
+    bad |= dev_alloc(&e->top_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * kTopE);
+    bad |= dev_alloc(&e->sc_partial, (size_t)SDVGN_MAX_FRAMES * kMaxChunks * kScE);
+    bad |= dev_alloc(&e->nres_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks);
+    const size_t accmax = (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kTopE + (size_t)SDVGN_MAX_FRAMES * kScE + 2;
+    bad |= dev_alloc(&e->acc_dev, accmax);
+    bad |= dev_alloc(&e->xc_dev, 4) | dev_alloc(&e->xAd_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6);
+    if (bad) { sdvgn_ef_destroy(e); return -(int)hipErrorOutOfMemory; }
+    HIPCHK(hipHostMalloc(&e->precalc_host, sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
+    HIPCHK(hipHostMalloc(&e->acc_host, sizeof(double) * accmax));
+    HIPCHK(hipHostMalloc(&e->x_host, sizeof(float) * (4 + SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6)));
+    HIPCHK(hipMemsetAsync(e->rflags, 0, slots, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    ef_fill_arrays(e);
+    *out = e;
+    return SDVGN_OK;
+}
+
+void sdvgn_ef_destroy(sdvgn_ef* e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    hipStreamSynchronize(e->stream);
+    void* ptrs[] = {e->pu, e->pv, e->pidz, e->pid, e->pidepth_backup, e->ppriorF, e->pdeltaF, e->pcolor, e->pweights, e->psensor, e->rflags,
+                    e->rstate, e->rstate_new, e->rmatcher, e->renergy, e->renergy_new, e->renergy_wo, e->rres_toZero, e->J, e->JpJd, e->pHddA,
+                    e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->images, e->img_stage,
+                    e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
+                    e->xc_dev, e->xAd_dev};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (e->precalc_host) hipHostFree(e->precalc_host);
+    if (e->acc_host) hipHostFree(e->acc_host);
+    if (e->x_host) hipHostFree(e->x_host);
+    if (e->own_stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+void* sdvgn_ef_stream(sdvgn_ef* e) { return e ? (void*)e->stream : nullptr; }
+
+int sdvgn_ef_set_calib(sdvgn_ef* e, const double vs[4], const double vmz[4]) {
+    if (!e || !vs || !vmz) return SDVGN_E_ARG;
+    for (int i = 0; i < 4; ++i) { e->value_scaled[i] = vs[i]; e->value_minus_value_zero[i] = vmz[i]; }
+    ef_update_const(e);
+    e->havePrecalc = false;
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_set_frames(sdvgn_ef* e, int nF, const double* evalPT7, const double* state10, const double* state_zero10,
+                        const int* frameID, const float* ab_exposure, const float* frameEnergyTH) {
+    if (!e || nF < 1 || nF > SDVGN_MAX_FRAMES || !evalPT7 || !state10 || !state_zero10 || !frameID || !ab_exposure || !frameEnergyTH)
+        return SDVGN_E_ARG;
+    e->nF = nF;
+    e->frames.resize(nF);
+    for (int i = 0; i < nF; ++i) {
+        FrameH& f = e->frames[i];
+        gn::pose_load(f.evalPT, evalPT7 + 7 * i);
+        for (int k = 0; k < 10; ++k) f.state_zero[k] = state_zero10[10 * i + k];
+        frame_set_state(f, state10 + 10 * i);
+        f.frameID = frameID[i]; f.ab_exposure = ab_exposure[i]; f.frameEnergyTH = frameEnergyTH[i];
+        for (int k = 0; k < 6; ++k) f.prior[k] = 0;   // FrameHessian::getPrior, HessianBlocks.h:220-250
+        if (f.frameID == 0) { for (int k = 0; k < 3; ++k) f.prior[k] = kInitialTransPrior; for (int k = 3; k < 6; ++k) f.prior[k] = kInitialRotPrior; }
+    }
+    const int n = CPARS + 6 * nF;
+    e->HM.assign((size_t)n * n, 0); e->bM.assign(n, 0);
+    e->h1 = std::min(e->h1, nF);
+    if (e->h0 == 0 && e->h1 >= nF) e->h1 = nF;
+    ef_update_const(e);
+    e->havePrecalc = e->haveAdjoints = false;
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_set_frame_states(sdvgn_ef* e, const double* state10) {
+    if (!e || !state10) return SDVGN_E_ARG;
+    for (int i = 0; i < e->nF; ++i) frame_set_state(e->frames[i], state10 + 10 * i);
+    e->havePrecalc = false;
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_set_host_range(sdvgn_ef* e, int h0, int h1) {
+    if (!e || h0 < 0 || h1 < h0 || h1 > SDVGN_MAX_FRAMES) return SDVGN_E_ARG;
+    e->h0 = h0; e->h1 = h1;
+    e->havePrecalc = false;
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_set_frame_image(sdvgn_ef* e, int idx, const float* dI) {
+    if (!e || !dI || idx < 0 || idx >= SDVGN_MAX_FRAMES) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    const size_t n = (size_t)e->w * e->h * 3;
+    HIPCHK(hipMemcpyAsync(e->images + n * idx, dI, sizeof(float) * n, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_set_frame_image_raw(sdvgn_ef* e, int idx, const float* image) {
+    if (!e || !image || idx < 0 || idx >= SDVGN_MAX_FRAMES) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    const size_t n = (size_t)e->w * e->h;
+    HIPCHK(hipMemcpyAsync(e->img_stage, image, sizeof(float) * n, hipMemcpyHostToDevice, e->stream));
+    const int qw = (e->w + 1) >> 1, qh = (e->h + 1) >> 1;
+    k_pyr_level<<<dim3((qw + 255) / 256, qh), 256, 0, e->stream>>>(e->img_stage, e->images + 3 * n * idx, nullptr, e->w, e->h, 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_set_points(sdvgn_ef* e, int nP, const int* host, const float* u, const float* v, const float* idepth, const float* idepth_zero,
+                        const float* color8, const float* weights8, const unsigned char* hasDepthPrior, const unsigned char* isFromSensor) {
+    if (!e || nP < 0 || nP > e->max_points || e->nF < 1) return SDVGN_E_ARG;
+    if (nP > 0 && (!host || !u || !v || !idepth || !idepth_zero || !color8 || !weights8 || !hasDepthPrior || !isFromSensor)) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    e->phost.assign(host, host + nP);
+    e->hostP0.assign(e->nF + 1, 0);
+    for (int i = 0; i < nP; ++i) {
+        if (host[i] < 0 || host[i] >= e->nF || (i > 0 && host[i] < host[i - 1])) return SDVGN_E_ARG;  // grouped by host, ascending
+        e->hostP0[host[i] + 1]++;
+    }
+    for (int h = 0; h < e->nF; ++h) e->hostP0[h + 1] += e->hostP0[h];
+    e->nP = nP;
+    std::vector<float> prior(nP), delta(nP), ids(nP), idz(nP);
+    for (int i = 0; i < nP; ++i) {
+        prior[i] = hasDepthPrior[i] ? kIdepthFixPrior * SDVGN_SCALE_IDEPTH * SDVGN_SCALE_IDEPTH : 0;   // EFPoint::takeData
+        delta[i] = idepth[i] - idepth_zero[i];
+        ids[i] = SDVGN_SCALE_IDEPTH * idepth[i]; idz[i] = SDVGN_SCALE_IDEPTH * idepth_zero[i];
+    }
+    const hipStream_t s = e->stream;
+    HIPCHK(hipMemcpyAsync(e->pu, u, 4 * nP, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->pv, v, 4 * nP, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->pid, ids.data(), 4 * nP, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->pidz, idz.data(), 4 * nP, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->pcolor, color8, 32 * (size_t)nP, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->pweights, weights8, 32 * (size_t)nP, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->ppriorF, prior.data(), 4 * nP, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->pdeltaF, delta.data(), 4 * nP, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->psensor, isFromSensor, nP, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->phost_dev, host, 4 * nP, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->hostP0_dev, e->hostP0.data(), 4 * (e->nF + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(e->rflags, 0, (size_t)e->nF * nP, s));
+    HIPCHK(hipMemsetAsync(e->pstep, 0, 4 * (size_t)nP, s));
+    HIPCHK(hipStreamSynchronize(s));
+    ef_update_const(e);
+    e->havePrecalc = false;
+    e->nR = 0;
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_set_residuals(sdvgn_ef* e, int nR, const int* point, const int* target, const int* state_state, const unsigned char* hasMatcher,
+                           const double* matcher, const unsigned char* isLinearized, const unsigned char* isActive) {
+    if (!e || nR < 0 || e->nP < 1) return SDVGN_E_ARG;
+    if (nR > 0 && (!point || !target || !state_state || !hasMatcher || !matcher || !isLinearized || !isActive)) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    const size_t slots = (size_t)e->nF * e->nP;
+    std::vector<uint8_t> flags(slots, 0);
+    std::vector<int8_t> st(slots, 0);
+    std::vector<float2> m(slots, make_float2(0, 0));
+    e->r_slot.resize(nR);
+    for (int i = 0; i < nR; ++i) {
+        if (point[i] < 0 || point[i] >= e->nP || target[i] < 0 || target[i] >= e->nF || target[i] == e->phost[point[i]]) return SDVGN_E_ARG;
+        const size_t s = (size_t)target[i] * e->nP + point[i];
+        if (flags[s] & RF_EXISTS) return SDVGN_E_ARG;
+        flags[s] = RF_EXISTS | (hasMatcher[i] ? RF_MATCHER : 0) | (isLinearized[i] ? RF_LINEARIZED : 0) | (isActive[i] ? RF_ACTIVE : 0);
+        st[s] = (int8_t)state_state[i];
+        m[s] = make_float2((float)matcher[2 * i], (float)matcher[2 * i + 1]);   // `matcher.cast<float>()`, Residuals.cpp:196
+        e->r_slot[i] = (int)s;
+    }
+    const hipStream_t s = e->stream;
+    HIPCHK(hipMemcpyAsync(e->rflags, flags.data(), slots, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->rstate, st.data(), slots, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->rmatcher, m.data(), sizeof(float2) * slots, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(e->rstate_new, RS_OUTLIER, slots, s));
+    HIPCHK(hipMemsetAsync(e->renergy, 0, 4 * slots, s));
+    HIPCHK(hipMemsetAsync(e->renergy_new, 0, 4 * slots, s));
+    HIPCHK(hipMemsetAsync(e->renergy_wo, 0, 4 * slots, s));
+    HIPCHK(hipMemsetAsync(e->rres_toZero, 0, 8 * slots, s));
+    HIPCHK(hipMemsetAsync(e->J, 0, sizeof(float) * 2 * kJPlanes * slots, s));
+    HIPCHK(hipMemsetAsync(e->JpJd, 0, sizeof(float) * 6 * slots, s));
+    HIPCHK(hipStreamSynchronize(s));
+    e->nR = nR;
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_set_marg_prior(sdvgn_ef* e, const double* HM, const double* bM) {
+    if (!e || !HM || !bM || e->nF < 1) return SDVGN_E_ARG;
+    const int n = CPARS + 6 * e->nF;
+    e->HM.assign(HM, HM + (size_t)n * n); e->bM.assign(bM, bM + n);
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_set_nullspaces(sdvgn_ef* e, int k, const double* v) {
+    if (!e || k < 0 || (k > 0 && !v) || e->nF < 1) return SDVGN_E_ARG;
+    const int n = CPARS + 6 * e->nF;
+    e->nullspaces.clear();
+    for (int j = 0; j < k; ++j) e->nullspaces.emplace_back(v + (size_t)j * n, v + (size_t)(j + 1) * n);
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_set_adjoints(sdvgn_ef* e) {  // EnergyFunctional::setAdjointsF
+    if (!e || e->nF < 1) return SDVGN_E_STATE;
+    const int nF = e->nF;
+    e->adHost.assign((size_t)nF * nF * 36, 0); e->adTarget.assign((size_t)nF * nF * 36, 0);
+    e->adHostF.assign((size_t)nF * nF * 36, 0); e->adTargetF.assign((size_t)nF * nF * 36, 0);
+    for (int h = 0; h < nF; ++h)
+        for (int t = 0; t < nF; ++t) {
+            const gn::Pose hostToTarget = gn::compose(e->frames[t].evalPT, gn::inverse(e->frames[h].evalPT));
+            double Adj[36];
+            gn::adjoint(hostToTarget, Adj);
+            double* AH = &e->adHost[(size_t)(h + t * nF) * 36];
+            double* AT = &e->adTarget[(size_t)(h + t * nF) * 36];
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) { AH[r * 6 + c] = -Adj[c * 6 + r]; AT[r * 6 + c] = (r == c) ? 1.0 : 0.0; }
+            for (int r = 0; r < 6; ++r) {
+                const float sc = r < 3 ? kScaleXiTrans : kScaleXiRot;
+                for (int c = 0; c < 6; ++c) { AH[r * 6 + c] *= sc; AT[r * 6 + c] *= sc; }
+            }
+            for (int i = 0; i < 36; ++i) { e->adHostF[(size_t)(h + t * nF) * 36 + i] = (float)AH[i]; e->adTargetF[(size_t)(h + t * nF) * 36 + i] = (float)AT[i]; }
+        }
+    for (int i = 0; i < 4; ++i) e->cPrior[i] = kInitialCalibHessian;
+    e->haveAdjoints = true;
+    e->havePrecalc = false;
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_set_precalc(sdvgn_ef* e) {
+    if (!e || e->nF < 1 || !e->haveAdjoints) return SDVGN_E_STATE;
+    HIPCHK(hipSetDevice(e->device));
+    return ef_upload_precalc(e);
+}
+
+int sdvgn_ef_linearize_all(sdvgn_ef* e, double* energy_out) {
+    if (!e || !e->havePrecalc || e->nR < 0) return SDVGN_E_STATE;
+    HIPCHK(hipSetDevice(e->device));
+    const int chunks = chunks_for_np(e);
+    const int pairs = e->nF * e->nF;
+    k_ef_linearize<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
+    double* edst = e->acc_dev + acc_count(e) - 2;
+    k_ef_sum_energy<<<1, 256, 0, e->stream>>>(e->energy_partial, chunks * pairs, edst);
+    HIPCHK(hipGetLastError());
+    if (energy_out) {
+        HIPCHK(hipMemcpyAsync(e->acc_host, edst, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        *energy_out = e->acc_host[0];
+    }
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_apply_res(sdvgn_ef* e) {
+    if (!e || e->nP < 1) return SDVGN_E_STATE;
+    HIPCHK(hipSetDevice(e->device));
+    const size_t slots = (size_t)e->nF * e->nP;
+    k_ef_apply<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->nF, e->nP, e->A, e->precalc_dev, e->phost_dev);
+    HIPCHK(hipGetLastError());
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_accumulate(sdvgn_ef* e) {
+    if (!e || !e->havePrecalc) return SDVGN_E_STATE;
+    HIPCHK(hipSetDevice(e->device));
+    const int nF = e->nF, pairs = nF * nF, chunks = chunks_for_np(e);
+    k_ef_point<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev);
+    k_ef_top_gram<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->top_partial, e->nres_partial);
+    const size_t smem = sizeof(float) * ((size_t)4 * 64 * kTileStride + 256 + 1024);
+    // hosts outside this rank's shard contribute nothing: their chunk loops are empty because the shard is applied below
+    k_ef_sc_gram<<<dim3(chunks, nF), 256, smem, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial);
+    k_ef_gram_reduce<<<pairs, 256, 0, e->stream>>>(e->top_partial, chunks, kTopE, e->acc_dev);
+    k_ef_gram_reduce<<<nF, 256, 0, e->stream>>>(e->sc_partial, chunks, kScE, e->acc_dev + (size_t)pairs * kTopE);
+    k_ef_sum_nres<<<1, 256, 0, e->stream>>>(e->nres_partial, chunks * pairs, e->acc_dev + acc_count(e) - 1);
+    HIPCHK(hipGetLastError());
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_accumulators_dev(sdvgn_ef* e, double** buf, int* count) {
+    if (!e || !buf || !count) return SDVGN_E_ARG;
+    *buf = e->acc_dev; *count = (int)acc_count(e);
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_out) {
+    if (!e || !e->havePrecalc) return SDVGN_E_STATE;
+    HIPCHK(hipSetDevice(e->device));
+    const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
+    HIPCHK(hipMemcpyAsync(e->acc_host, e->acc_dev, sizeof(double) * acc_count(e), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->resInA = (int)e->acc_host[acc_count(e) - 1];
+    stitch_top(e, e->acc_host);
+    stitch_sc(e, e->acc_host + (size_t)pairs * kTopE);
+    // bM_top = bM + HM * delta ; HFinal = HA + HM - Hsc ; bFinal = bA + bM_top - bsc   (EnergyFunctional.cpp:668-699)
+    std::vector<double> d(n), bM_top(n);
+    for (int i = 0; i < CPARS; ++i) d[i] = (double)e->C.cDeltaF[i];
+    for (int h = 0; h < nF; ++h) for (int i = 0; i < 6; ++i) d[CPARS + 6 * h + i] = e->frames[h].delta[i];
+    for (int i = 0; i < n; ++i) { double a = 0; for (int j = 0; j < n; ++j) a += e->HM[(size_t)i * n + j] * d[j]; bM_top[i] = e->bM[i] + a; }
+    e->HFinal.resize((size_t)n * n); e->bFinal.resize(n);
+    for (size_t i = 0; i < (size_t)n * n; ++i) e->HFinal[i] = e->HA[i] + e->HM[i] - e->Hsc[i];
+    for (int i = 0; i < n; ++i) e->bFinal[i] = e->bA[i] + bM_top[i] - e->bsc[i];
+    std::vector<double> Hs((size_t)n * n), xs(n), sv(n);
+    for (int i = 0; i < n; ++i) sv[i] = 1.0 / std::sqrt(e->HFinal[(size_t)i * n + i] * (1 + lambda) + 10);
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) {
+            const double hij = (i == j) ? e->HFinal[(size_t)i * n + j] * (1 + lambda) : e->HFinal[(size_t)i * n + j];
+            Hs[(size_t)i * n + j] = sv[i] * hij * sv[j];
+        }
+        xs[i] = sv[i] * e->bFinal[i];
+    }
+    gn::ldlt_solve_inplace<CPARS + 6 * SDVGN_MAX_FRAMES>(n, Hs.data(), n, xs.data());
+    e->lastX.resize(n);
+    for (int i = 0; i < n; ++i) e->lastX[i] = sv[i] * xs[i];
+    if (iteration >= 2) orthogonalize_x(e, e->lastX);   // SOLVER_ORTHOGONALIZE_X_LATER
+    if (x_out) std::memcpy(x_out, e->lastX.data(), sizeof(double) * n);
+    // resubstituteF_MT (:221-247): xc, xAd[nF*h + t]
+    float* xc = e->x_host;
+    float* xAd = e->x_host + 4;
+    std::vector<float> xF(n);
+    for (int i = 0; i < n; ++i) xF[i] = (float)e->lastX[i];
+    for (int i = 0; i < 4; ++i) xc[i] = xF[i];
+    for (int h = 0; h < nF; ++h)
+        for (int t = 0; t < nF; ++t) {
+            const float* AH = &e->adHostF[(size_t)(h + nF * t) * 36];
+            const float* AT = &e->adTargetF[(size_t)(h + nF * t) * 36];
+            for (int c = 0; c < 6; ++c) {
+                float a = 0, b = 0;
+                for (int q = 0; q < 6; ++q) { a += xF[CPARS + 6 * h + q] * AH[q * 6 + c]; b += xF[CPARS + 6 * t + q] * AT[q * 6 + c]; }
+                xAd[(size_t)(nF * h + t) * 6 + c] = a + b;
+            }
+        }
+    HIPCHK(hipMemcpyAsync(e->xc_dev, xc, sizeof(float) * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->xAd_dev, xAd, sizeof(float) * pairs * 6, hipMemcpyHostToDevice, e->stream));
+    k_ef_resubstitute<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->xc_dev, e->xAd_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));   // x_host is reused by the next call
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_solve_system(sdvgn_ef* e, int iteration, double lambda, double* x_out) {
+    int rc = sdvgn_ef_accumulate(e);
+    if (rc) return rc;
+    return sdvgn_ef_finish_solve(e, iteration, lambda, x_out);
+}
+
+int sdvgn_ef_point_step(sdvgn_ef* e, int mode, float stepfacD) {
+    if (!e || mode < 0 || mode > 2 || e->nP < 1) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    k_ef_point_step<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->nP, mode, stepfacD, e->pid, e->pidz, e->pidepth_backup, e->pstep, e->pdeltaF);
+    HIPCHK(hipGetLastError());
+    return SDVGN_OK;
+}
+
+// ------------------------------------- read-back hooks ------------------------------------------------------
+int sdvgn_ef_dim(sdvgn_ef* e) { return e ? CPARS + 6 * e->nF : SDVGN_E_ARG; }
+
+int sdvgn_ef_get_system(sdvgn_ef* e, double* HA, double* bA, double* Hsc, double* bsc, double* HFinal, double* bFinal) {
+    if (!e || e->HFinal.empty()) return SDVGN_E_STATE;
+    const size_t n = CPARS + 6 * e->nF;
+    if (HA) std::memcpy(HA, e->HA.data(), 8 * n * n);
+    if (bA) std::memcpy(bA, e->bA.data(), 8 * n);
+    if (Hsc) std::memcpy(Hsc, e->Hsc.data(), 8 * n * n);
+    if (bsc) std::memcpy(bsc, e->bsc.data(), 8 * n);
+    if (HFinal) std::memcpy(HFinal, e->HFinal.data(), 8 * n * n);
+    if (bFinal) std::memcpy(bFinal, e->bFinal.data(), 8 * n);
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_get_residual_J(sdvgn_ef* e, int which, float* out24) {
+    if (!e || !out24 || e->nR < 1) return SDVGN_E_STATE;
+    HIPCHK(hipSetDevice(e->device));
+    const size_t slots = (size_t)e->nF * e->nP;
+    std::vector<float> J(2 * (size_t)kJPlanes * slots);
+    std::vector<uint8_t> fl(slots);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(J.data(), e->J, sizeof(float) * J.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(fl.data(), e->rflags, slots, hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->nR; ++i) {
+        const size_t s = e->r_slot[i];
+        const int sel = (fl[s] & RF_SEL) ? 1 : 0;
+        const int buf = which ? sel : 1 - sel;
+        const float* src = J.data() + (size_t)buf * kJPlanes * slots + s;
+        for (int k = 0; k < kJPlanes; ++k) out24[(size_t)i * 24 + k] = src[(size_t)k * slots];
+    }
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_get_residual_state(sdvgn_ef* e, int* state_state, int* state_new, float* energy_new, float* energy_wo, unsigned char* isActive) {
+    if (!e || e->nR < 1) return SDVGN_E_STATE;
+    HIPCHK(hipSetDevice(e->device));
+    const size_t slots = (size_t)e->nF * e->nP;
+    std::vector<int8_t> st(slots), sn(slots);
+    std::vector<float> en(slots), ew(slots);
+    std::vector<uint8_t> fl(slots);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(st.data(), e->rstate, slots, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sn.data(), e->rstate_new, slots, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(en.data(), e->renergy_new, 4 * slots, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ew.data(), e->renergy_wo, 4 * slots, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(fl.data(), e->rflags, slots, hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->nR; ++i) {
+        const size_t s = e->r_slot[i];
+        if (state_state) state_state[i] = st[s];
+        if (state_new) state_new[i] = sn[s];
+        if (energy_new) energy_new[i] = en[s];
+        if (energy_wo) energy_wo[i] = ew[s];
+        if (isActive) isActive[i] = (fl[s] & RF_ACTIVE) ? 1 : 0;
+    }
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_get_points(sdvgn_ef* e, float* out9) {
+    if (!e || !out9 || e->nP < 1) return SDVGN_E_STATE;
+    HIPCHK(hipSetDevice(e->device));
+    const size_t nP = e->nP;
+    std::vector<float> a(nP), b(nP), c(4 * nP), d(nP), f(nP), g(nP);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(a.data(), e->pHddA, 4 * nP, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(b.data(), e->pbdA, 4 * nP, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(c.data(), e->pHcdA, 16 * nP, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(d.data(), e->pHdi, 4 * nP, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(f.data(), e->pbdSum, 4 * nP, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(g.data(), e->pstep, 4 * nP, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nP; ++i) {
+        float* o = out9 + 9 * i;
+        o[0] = a[i]; o[1] = b[i];
+        for (int k = 0; k < 4; ++k) o[2 + k] = c[(size_t)k * nP + i];
+        o[6] = d[i]; o[7] = f[i]; o[8] = g[i];
+    }
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_get_top_acc(sdvgn_ef* e, double* out, int* resInA) {
+    if (!e || !out) return SDVGN_E_STATE;
+    HIPCHK(hipSetDevice(e->device));
+    const int nF = e->nF;
+    std::vector<double> g((size_t)nF * nF * kTopE);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(g.data(), e->acc_dev, 8 * g.size(), hipMemcpyDeviceToHost));
+    for (int h = 0; h < nF; ++h)
+        for (int t = 0; t < nF; ++t)
+            for (int r = 0; r < 11; ++r)
+                for (int c = 0; c < 11; ++c) out[(size_t)(h + nF * t) * 121 + r * 11 + c] = g[(size_t)(h * nF + t) * kTopE + r * 16 + c];
+    if (resInA) *resInA = e->resInA;
+    return SDVGN_OK;
+}
+
+}  // extern "C"

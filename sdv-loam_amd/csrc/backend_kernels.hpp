@@ -1,0 +1,523 @@
+// backend_kernels.hpp -- gfx950 kernels of the sliding-window back end.
+//
+//   k_ef_linearize   b1  PointFrameResidual::linearize            src/FullSystem/Residuals.cpp:60-224
+//                        projectPoint (both overloads)             src/FullSystem/ResidualProjections.h:20-59
+//   k_ef_apply       b1  PointFrameResidual::applyRes(true)        src/FullSystem/Residuals.cpp:252-275
+//                        EFResidual::takeDataF                     src/OptimizationBackend/EnergyFunctionalStructs.cpp:15-25
+//   k_ef_point       b2  per-point part of addPoint<0>/<1>         src/OptimizationBackend/AccumulatedTopHessian.cpp:26-110
+//                    b7  head of AccumulatedSCHessianSSE::addPoint src/OptimizationBackend/AccumulatedSCHessian.cpp:10-37
+//   k_ef_top_gram    b2  acc[h,t].update/updateTopRight/BotRight   AccumulatedTopHessian.cpp:68-82 (AccumulatorApprox, b3)
+//   k_ef_sc_gram     b7  accD / accE / accEB / accHcc / accbc      AccumulatedSCHessian.cpp:39-61
+//   k_ef_gram_reduce     fixed-order fp64 sum of the per-workgroup partial Gram tiles
+//   k_ef_resubstitute b6 EnergyFunctional::resubstituteFPt         src/OptimizationBackend/EnergyFunctional.cpp:250-282
+//   k_ef_step            doStepFromBackup / loadSateBackup on the per-point idepths  FullSystemOptimize.cpp:165-262
+//
+// Data layout in HBM (one window): points are sorted by host frame; the residual of point p in target frame t
+// lives in slot s = t*nP + p of every per-residual plane ("dense residual table": for a fixed (host,target) pair the
+// slots are contiguous, for a fixed point they are nP apart) -- both the per-pair reductions and the per-point loops are
+// coalesced.  Jacobians are kept as 24 SoA planes x 2 buffers; `sel` says which buffer the EnergyFunctional side owns
+// (the reference swaps two heap pointers per residual in takeDataF; here a bit flips).
+//
+// The two reductions are Gram matrices and run on the matrix cores (v_mfma_f32_16x16x4_f32: exact f32 products, f32
+// accumulate -- the same numerics class as the reference's float accumulators, in a different order):
+//   top:  for a pair (h,t)   G = sum_r [Jc;Jxi;res]_x [..]_x^T + [..]_y [..]_y^T        11 x 11  (AccumulatorApprox)
+//   SC:   for a host h       G = sum_p HdiF_p f_p f_p^T, f_p = [JpJdF_t(6) t=0..7 | Hcd(4) | bdSum]   53 x 53
+// Operands are staged through LDS as [feature][row] tiles (row stride 66 floats: conflict-free for the fragment reads).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+namespace sdvgn {
+
+constexpr int kMaxFrames = 8;
+constexpr int kJPlanes = 24;   // resF(2) Jpdxi[0](6) Jpdxi[1](6) Jpdc[0](4) Jpdc[1](4) Jpdd(2)
+constexpr int kTileStride = 66;
+
+enum : int { RS_IN = 0, RS_OOB = 1, RS_OUTLIER = 2 };
+enum : uint8_t { RF_EXISTS = 1, RF_MATCHER = 2, RF_LINEARIZED = 4, RF_ACTIVE = 8, RF_SEL = 16 };
+
+#define SDVGN_SCALE_F 50.0f
+#define SDVGN_SCALE_C 50.0f
+#define SDVGN_SCALE_IDEPTH 1.0f
+
+struct PrecalcDev {  // FrameFramePrecalc fields linearize reads (HessianBlocks.h:51-79), one per (host,target)
+    float KRKi[9], Kt[3], R0[9], t0[3];
+    float aff0, aff1, b0;
+    float frameEnergyTH;  // max(host->frameEnergyTH, target->frameEnergyTH)
+    float dp[6];          // adHTdeltaF[h + t*nF]  (EnergyFunctional.cpp:140-141)
+    int P0, np;           // point range of the host frame
+    int pad[2];
+};
+
+struct EFConst {
+    int nF, nP, w, h;
+    float fxl, fyl, cxl, cyl, fxli, fyli;
+    float wM3G, hM3G;
+    float cDeltaF[4];
+    float huberTH, outlierTHSumComponent;
+};
+
+struct EFArrays {
+    // points (sorted by host)
+    const float* pu; const float* pv; const float* pidz; const float* pid;  // u, v, idepth_zero_scaled, idepth_scaled
+    const float4* pcolor;   // [nP][2]
+    const float4* pweights; // [nP][2]
+    const float* ppriorF; const float* pdeltaF; const uint8_t* psensor;
+    // residual slots
+    uint8_t* rflags; int8_t* rstate; int8_t* rstate_new;
+    const float2* rmatcher;
+    float* renergy; float* renergy_new; float* renergy_wo;
+    float* rres_toZero;      // [2][slots]
+    float* J;                // [2 buffers][24][slots]
+    float* JpJd;             // [6][slots]
+    // per point outputs
+    float* pHddA; float* pbdA; float* pHcdA;  // Hcd: [4][nP]
+    float* pHddL; float* pbdL; float* pHcdL;
+    float* pHdi; float* pbdSum; float* pHcd;  // SC inputs (Hcd = A + L)
+    float* pstep;
+    // images
+    const float* images;     // [nF][w*h*3]
+};
+
+// 64-lane double sum (for the energy), result valid in lane 63
+__device__ __forceinline__ double wave_sum_double(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ void interp33_b(const float* __restrict__ img, float x, float y, int width, float& o0, float& o1, float& o2) {
+    const int ix = (int)x, iy = (int)y;
+    const float dx = x - ix, dy = y - iy, dxdy = dx * dy;
+    const float* bp = img + 3 * (ix + iy * width);
+    const float* bq = bp + 3 * width;
+    const float a0 = bp[0], a1 = bp[1], a2 = bp[2], b0 = bp[3], b1 = bp[4], b2 = bp[5];
+    const float c0 = bq[0], c1 = bq[1], c2 = bq[2], d0 = bq[3], d1 = bq[4], d2 = bq[5];
+    const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+    o0 = ((w11 * d0 + w01 * c0) + w10 * b0) + w00 * a0;
+    o1 = ((w11 * d1 + w01 * c1) + w10 * b1) + w00 * a1;
+    o2 = ((w11 * d2 + w01 * c2) + w10 * b2) + w00 * a2;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// b1: one thread = one residual slot of pair (h,t).  grid = (chunks, nF*nF), block = 256.
+// energy_partial[blockIdx.y * gridDim.x + blockIdx.x] = sum of the return values of linearize() in this block.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                      double* __restrict__ energy_partial) {
+    __shared__ double s_e[4];
+    const int pair = blockIdx.y;
+    const int h = pair / C.nF, t = pair % C.nF;
+    const PrecalcDev pc = precalc[pair];
+    const int pl = blockIdx.x * blockDim.x + threadIdx.x;
+    double my_e = 0.0;
+    if (h != t && pl < pc.np) {
+        const int p = pc.P0 + pl;
+        const size_t slots = (size_t)C.nF * C.nP;
+        const size_t s = (size_t)t * C.nP + p;
+        const uint8_t fl = A.rflags[s];
+        if ((fl & RF_EXISTS) && !(fl & RF_LINEARIZED)) {
+            A.renergy_wo[s] = -1.0f;
+            const int st = A.rstate[s];
+            bool oob = (st == RS_OOB) || !(fl & RF_MATCHER);
+            float Ku = 0, Kv = 0, u = 0, v = 0, drescale = 0, new_idepth = 0, KliP0 = 0, KliP1 = 0;
+            const float pu = A.pu[p], pv = A.pv[p];
+            if (!oob) {
+                KliP0 = (pu + 0 - C.cxl) * C.fxli;
+                KliP1 = (pv + 0 - C.cyl) * C.fyli;
+                const float idz = A.pidz[p];
+                const float q0 = ((pc.R0[0] * KliP0 + pc.R0[1] * KliP1) + pc.R0[2] * 1.0f) + pc.t0[0] * idz;
+                const float q1 = ((pc.R0[3] * KliP0 + pc.R0[4] * KliP1) + pc.R0[5] * 1.0f) + pc.t0[1] * idz;
+                const float q2 = ((pc.R0[6] * KliP0 + pc.R0[7] * KliP1) + pc.R0[8] * 1.0f) + pc.t0[2] * idz;
+                drescale = 1.0f / q2;
+                new_idepth = idz * drescale;
+                if (!(drescale > 0)) oob = true;
+                else {
+                    u = q0 * drescale; v = q1 * drescale;
+                    Ku = u * C.fxl + C.cxl; Kv = v * C.fyl + C.cyl;
+                    oob = !(Ku > 1.1f && Kv > 1.1f && Ku < C.wM3G && Kv < C.hM3G);
+                }
+            }
+            if (oob) {
+                A.rstate_new[s] = RS_OOB;
+                my_e = (double)A.renergy[s];   // `return state_energy`
+            } else {
+                float Jx[6], Jy[6], Cx[4], Cy[4], ddx, ddy;
+                ddx = drescale * (pc.t0[0] - pc.t0[2] * u) * SDVGN_SCALE_IDEPTH * C.fxl;
+                ddy = drescale * (pc.t0[1] - pc.t0[2] * v) * SDVGN_SCALE_IDEPTH * C.fyl;
+                Cx[2] = drescale * (pc.R0[6] * u - pc.R0[0]);
+                Cx[3] = C.fxl * drescale * (pc.R0[7] * u - pc.R0[1]) * C.fyli;
+                Cx[0] = KliP0 * Cx[2];
+                Cx[1] = KliP1 * Cx[3];
+                Cy[2] = C.fyl * drescale * (pc.R0[6] * v - pc.R0[3]) * C.fxli;
+                Cy[3] = drescale * (pc.R0[7] * v - pc.R0[4]);
+                Cy[0] = KliP0 * Cy[2];
+                Cy[1] = KliP1 * Cy[3];
+                Cx[0] = (Cx[0] + u) * SDVGN_SCALE_F;
+                Cx[1] *= SDVGN_SCALE_F;
+                Cx[2] = (Cx[2] + 1) * SDVGN_SCALE_C;
+                Cx[3] *= SDVGN_SCALE_C;
+                Cy[0] *= SDVGN_SCALE_F;
+                Cy[1] = (Cy[1] + v) * SDVGN_SCALE_F;
+                Cy[2] *= SDVGN_SCALE_C;
+                Cy[3] = (Cy[3] + 1) * SDVGN_SCALE_C;
+                Jx[0] = new_idepth * C.fxl; Jx[1] = 0; Jx[2] = -new_idepth * u * C.fxl;
+                Jx[3] = -u * v * C.fxl; Jx[4] = (1 + u * u) * C.fxl; Jx[5] = -v * C.fxl;
+                Jy[0] = 0; Jy[1] = new_idepth * C.fyl; Jy[2] = -new_idepth * v * C.fyl;
+                Jy[3] = -(1 + v * v) * C.fyl; Jy[4] = u * v * C.fyl; Jy[5] = u * C.fyl;
+
+                // 8-pixel photometric pattern: only classifies the residual (:157-194)
+                const float* __restrict__ img = A.images + (size_t)t * C.w * C.h * 3;
+                const float4 c0 = A.pcolor[2 * p], c1 = A.pcolor[2 * p + 1];
+                const float4 w0 = A.pweights[2 * p], w1 = A.pweights[2 * p + 1];
+                const float col[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                const float wts[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                const int pat[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};
+                const float ids = A.pid[p];
+                float wJI2_sum = 0, energyLeft2 = 0;
+                bool alive = true;
+#pragma unroll
+                for (int idx = 0; idx < 8; ++idx) {
+                    if (alive) {
+                        const float up = pu + pat[idx][0], vp = pv + pat[idx][1];
+                        const float r0 = ((pc.KRKi[0] * up + pc.KRKi[1] * vp) + pc.KRKi[2] * 1.0f) + pc.Kt[0] * ids;
+                        const float r1 = ((pc.KRKi[3] * up + pc.KRKi[4] * vp) + pc.KRKi[5] * 1.0f) + pc.Kt[1] * ids;
+                        const float r2 = ((pc.KRKi[6] * up + pc.KRKi[7] * vp) + pc.KRKi[8] * 1.0f) + pc.Kt[2] * ids;
+                        const float Ku2 = r0 / r2, Kv2 = r1 / r2;
+                        if (!(Ku2 > 1.1f && Kv2 > 1.1f && Ku2 < C.wM3G && Kv2 < C.hM3G)) alive = false;
+                        else {
+                            float h0, h1, h2;
+                            interp33_b(img, Ku2, Kv2, C.w, h0, h1, h2);
+                            if (!isfinite(h0)) alive = false;
+                            else {
+                                const float residual = h0 - (float)(pc.aff0 * col[idx] + pc.aff1);
+                                float w = sqrtf(C.outlierTHSumComponent / (C.outlierTHSumComponent + (h1 * h1 + h2 * h2)));
+                                w = 0.5f * (w + wts[idx]);
+                                float hw = fabsf(residual) < C.huberTH ? 1.0f : C.huberTH / fabsf(residual);
+                                energyLeft2 += w * w * hw * residual * residual * (2 - hw);
+                                if (hw < 1) hw = sqrtf(hw);
+                                hw = hw * w;
+                                h1 *= hw; h2 *= hw;
+                                wJI2_sum += hw * hw * (h1 * h1 + h2 * h2);
+                            }
+                        }
+                    }
+                }
+                const float2 m = A.rmatcher[s];
+                const float res0 = Ku - m.x, res1 = Kv - m.y;
+                const float nrm = sqrtf(res0 * res0 + res1 * res1);
+                float hw = fabsf(nrm) < C.huberTH ? 1.0f : C.huberTH / fabsf(nrm);
+                const float energyLeft = hw * (res0 * res0 + res1 * res1) * (2 - hw);
+                if (hw < 1) hw = sqrtf(hw);
+                // new Jacobian goes to the buffer the EnergyFunctional side does NOT own
+                const int buf = (fl & RF_SEL) ? 0 : 1;
+                float* Jn = A.J + (size_t)buf * kJPlanes * slots + s;
+                Jn[0 * slots] = res0 * hw; Jn[1 * slots] = res1 * hw;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { Jn[(2 + i) * slots] = Jx[i] * hw; Jn[(8 + i) * slots] = Jy[i] * hw; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { Jn[(14 + i) * slots] = Cx[i] * hw; Jn[(18 + i) * slots] = Cy[i] * hw; }
+                Jn[22 * slots] = ddx * hw; Jn[23 * slots] = ddy * hw;
+                A.renergy_wo[s] = energyLeft2;
+                if (energyLeft2 > pc.frameEnergyTH || wJI2_sum < 2) { energyLeft2 = pc.frameEnergyTH; A.rstate_new[s] = RS_OUTLIER; }
+                else A.rstate_new[s] = RS_IN;
+                A.renergy_new[s] = energyLeft2;
+                my_e = (double)energyLeft;
+            }
+        }
+    }
+    const double ws = wave_sum_double(my_e);
+    if ((threadIdx.x & 63) == 63) s_e[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) energy_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (s_e[0] + s_e[1]) + (s_e[2] + s_e[3]);
+}
+
+// applyRes(true): one thread per slot
+__global__ void __launch_bounds__(256) k_ef_apply(int nF, int nP, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                  const int* __restrict__ phost) {
+    const size_t slots = (size_t)nF * nP;
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= slots) return;
+    const int hh = phost[s % nP];
+    if (precalc[hh * nF + hh].np == 0) return;   // host frame not in this rank's shard
+    uint8_t fl = A.rflags[s];
+    if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED)) return;
+    if (A.rstate[s] == RS_OOB) return;
+    const int sn = A.rstate_new[s];
+    if (sn == RS_IN) {
+        fl |= RF_ACTIVE;
+        fl ^= RF_SEL;                                   // takeDataF: swap J with the residual's freshly linearised J
+        const int buf = (fl & RF_SEL) ? 1 : 0;
+        const float* Je = A.J + (size_t)buf * kJPlanes * slots + s;
+        const float d0 = Je[22 * slots], d1 = Je[23 * slots];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) A.JpJd[(size_t)i * slots + s] = Je[(2 + i) * slots] * d0 + Je[(8 + i) * slots] * d1;
+    } else {
+        fl &= (uint8_t)~RF_ACTIVE;
+    }
+    A.rflags[s] = fl;
+    A.rstate[s] = (int8_t)sn;
+    A.renergy[s] = A.renergy_new[s];
+}
+
+// Per-point sums of addPoint<0> (active, not linearised) and addPoint<1> (active, linearised), then the head of the
+// Schur accumulation: HdiF, bdSumF, Hcd.  One thread per point, residuals visited in target order.
+__global__ void __launch_bounds__(256) k_ef_point(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                  const int* __restrict__ phost) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= C.nP) return;
+    const size_t slots = (size_t)C.nF * C.nP;
+    const int h = phost[p];
+    if (precalc[h * C.nF + h].np == 0) return;   // host frame not in this rank's shard
+    const float dd = A.pdeltaF[p];
+    float bdA = 0, HddA = 0, HcdA[4] = {0, 0, 0, 0}, bdL = 0, HddL = 0, HcdL[4] = {0, 0, 0, 0};
+    int ngood = 0;
+    for (int t = 0; t < C.nF; ++t) {
+        const size_t s = (size_t)t * C.nP + p;
+        const uint8_t fl = A.rflags[s];
+        if (!(fl & RF_EXISTS) || !(fl & RF_ACTIVE)) continue;
+        ngood++;
+        const float* Je = A.J + (size_t)((fl & RF_SEL) ? 1 : 0) * kJPlanes * slots + s;
+        const float d0 = Je[22 * slots], d1 = Je[23 * slots];
+        float c0[4], c1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { c0[i] = Je[(14 + i) * slots]; c1[i] = Je[(18 + i) * slots]; }
+        if (!(fl & RF_LINEARIZED)) {
+            const float r0 = Je[0], r1 = Je[slots];
+            bdA += r0 * d0 + r1 * d1;
+            HddA += d0 * d0 + d1 * d1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) HcdA[i] += c0[i] * d0 + c1[i] * d1;
+        } else {
+            const PrecalcDev& pc = precalc[h * C.nF + t];
+            float dx = 0, dy = 0, cx = 0, cy = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { dx += Je[(2 + i) * slots] * pc.dp[i]; dy += Je[(8 + i) * slots] * pc.dp[i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { cx += c0[i] * C.cDeltaF[i]; cy += c1[i] * C.cDeltaF[i]; }
+            const float r0 = A.rres_toZero[s] + (dx + cx + d0 * dd);
+            const float r1 = A.rres_toZero[slots + s] + (dy + cy + d1 * dd);
+            bdL += r0 * d0 + r1 * d1;
+            HddL += d0 * d0 + d1 * d1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) HcdL[i] += c0[i] * d0 + c1[i] * d1;
+        }
+    }
+    A.pHddA[p] = HddA; A.pbdA[p] = bdA; A.pHddL[p] = HddL; A.pbdL[p] = bdL;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { A.pHcdA[(size_t)i * C.nP + p] = HcdA[i]; A.pHcdL[(size_t)i * C.nP + p] = HcdL[i]; }
+    // AccumulatedSCHessian.cpp:12-34
+    if (ngood == 0) {
+        A.pHdi[p] = 0; A.pbdSum[p] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) A.pHcd[(size_t)i * C.nP + p] = 0;
+        return;
+    }
+    const float prior = A.ppriorF[p];
+    float H = HddA + HddL + prior;
+    if (H < 1e-10) H = 1e-10;
+    A.pHdi[p] = (float)(1.0 / H);
+    float bds = bdA + bdL;
+    bds += prior * dd;  // shiftPriorToZero == true in accumulateSCF_MT
+    A.pbdSum[p] = bds;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) A.pHcd[(size_t)i * C.nP + p] = HcdA[i] + HcdL[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// MFMA Gram accumulation.  One wave owns 64 rows (K) of a [NT*16 features][64 rows] LDS tile and accumulates the upper
+// triangle of tiles of  G += (w .* F) F^T  with v_mfma_f32_16x16x4_f32.
+// Fragment maps (cdna guide section 3): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D: col=l&15, row=4*(l>>4)+reg.
+// ------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT>
+__device__ __forceinline__ void gram_tile_accumulate(const float* __restrict__ tileF, const float* __restrict__ tileW,
+                                                     f32x4* acc) {
+    const int lane = threadIdx.x & 63;
+    const int f = lane & 15, kq = lane >> 4;
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+        const int k = ks * 4 + kq;
+        float frag[NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) frag[ti] = tileF[(ti * 16 + f) * kTileStride + k];
+        const float w = tileW ? tileW[k] : 1.0f;
+        int a = 0;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = ti; tj < NT; ++tj) {
+                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ti] * w, frag[tj], acc[a], 0, 0, 0);
+                ++a;
+            }
+    }
+}
+
+// top Gram: grid = (chunks, nF*nF), block = 256 (4 waves x 64 residual slots).  Features (16, 11 live):
+// 0-3 Jpdc, 4-9 Jpdxi, 10 res; two row sets (x and y).  partial: [pair][chunk][256] floats (row-major 16x16).
+__global__ void __launch_bounds__(256) k_ef_top_gram(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                     float* __restrict__ partial, int* __restrict__ nres_partial) {
+    __shared__ float tile[4][2][16 * kTileStride];
+    __shared__ float red[4][256];
+    __shared__ int s_n[4];
+    const int pair = blockIdx.y;
+    const int h = pair / C.nF, t = pair % C.nF;
+    const PrecalcDev& pc = precalc[pair];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int P0 = pc.P0, np = pc.np;
+    const size_t slots = (size_t)C.nF * C.nP;
+    f32x4 acc[1] = {{0, 0, 0, 0}};
+    int cnt = 0;
+    if (h != t) {
+        for (int base = blockIdx.x * 256 + wave * 64; base < np; base += gridDim.x * 256) {
+            const int pl = base + lane;
+            bool use = false;
+            size_t s = 0;
+            uint8_t fl = 0;
+            if (pl < np) {
+                s = (size_t)t * C.nP + (P0 + pl);
+                fl = A.rflags[s];
+                use = (fl & RF_EXISTS) && (fl & RF_ACTIVE) && !(fl & RF_LINEARIZED);
+            }
+            const float* Je = A.J + (size_t)((fl & RF_SEL) ? 1 : 0) * kJPlanes * slots + s;
+            float* tx = tile[wave][0];
+            float* ty = tile[wave][1];
+            // feature f of row `lane`
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                tx[i * kTileStride + lane] = use ? Je[(14 + i) * slots] : 0.0f;
+                ty[i * kTileStride + lane] = use ? Je[(18 + i) * slots] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                tx[(4 + i) * kTileStride + lane] = use ? Je[(2 + i) * slots] : 0.0f;
+                ty[(4 + i) * kTileStride + lane] = use ? Je[(8 + i) * slots] : 0.0f;
+            }
+            tx[10 * kTileStride + lane] = use ? Je[0] : 0.0f;
+            ty[10 * kTileStride + lane] = use ? Je[slots] : 0.0f;
+#pragma unroll
+            for (int i = 11; i < 16; ++i) { tx[i * kTileStride + lane] = 0.0f; ty[i * kTileStride + lane] = 0.0f; }
+            cnt += use ? 1 : 0;
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed (wave-private tile)
+            __builtin_amdgcn_wave_barrier();
+            gram_tile_accumulate<1>(tx, nullptr, acc);
+            gram_tile_accumulate<1>(ty, nullptr, acc);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // D fragment -> LDS (row = 4*(lane>>4)+reg, col = lane&15), then 256 threads add the 4 waves
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[0][r];
+    int wc = cnt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wc += __shfl_xor(wc, off);
+    if (lane == 0) s_n[wave] = wc;
+    __syncthreads();
+    const size_t o = ((size_t)pair * gridDim.x + blockIdx.x);
+    partial[o * 256 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x == 0) nres_partial[o] = (s_n[0] + s_n[1]) + (s_n[2] + s_n[3]);
+}
+
+// SC Gram: grid = (chunks, nF hosts), block = 256 (4 waves x 64 points).  Features (64, 53 live):
+// 6*t+i: JpJdF of the residual in target t (0 if absent/inactive); 48-51: Hcd; 52: bdSumF.  Row weight = HdiF (0 for
+// LiDAR points -> excluded from the Schur complement, AccumulatedSCHessian.cpp:36-37).
+// partial: [host][chunk][10 tiles][256] floats.
+__global__ void __launch_bounds__(256) k_ef_sc_gram(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                    float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // layout: tile[4 waves][64*kTileStride] | w[4][64] | red[10*256]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* tile = smem + (size_t)wave * 64 * kTileStride;
+    float* wrow = smem + (size_t)4 * 64 * kTileStride + wave * 64;
+    float* red = smem + (size_t)4 * 64 * kTileStride + 256;
+    const int h = blockIdx.y;
+    const int P0 = precalc[h * C.nF + h].P0, np = precalc[h * C.nF + h].np;   // np == 0 outside this rank's shard
+    const size_t slots = (size_t)C.nF * C.nP;
+    f32x4 acc[10];
+#pragma unroll
+    for (int a = 0; a < 10; ++a) acc[a] = (f32x4){0, 0, 0, 0};
+    for (int base = blockIdx.x * 256 + wave * 64; base < np; base += gridDim.x * 256) {
+        const int pl = base + lane;
+        const bool in = pl < np;
+        const int p = P0 + (in ? pl : 0);
+        float w = 0.0f;
+        if (in && !A.psensor[p]) w = A.pHdi[p];
+#pragma unroll
+        for (int t = 0; t < kMaxFrames; ++t) {
+            bool act = false;
+            size_t s = 0;
+            if (in && t < C.nF) {
+                s = (size_t)t * C.nP + p;
+                const uint8_t fl = A.rflags[s];
+                act = (fl & RF_EXISTS) && (fl & RF_ACTIVE);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) tile[(6 * t + i) * kTileStride + lane] = act ? A.JpJd[(size_t)i * slots + s] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tile[(48 + i) * kTileStride + lane] = in ? A.pHcd[(size_t)i * C.nP + p] : 0.0f;
+        tile[52 * kTileStride + lane] = in ? A.pbdSum[p] : 0.0f;
+#pragma unroll
+        for (int i = 53; i < 64; ++i) tile[i * kTileStride + lane] = 0.0f;
+        wrow[lane] = w;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        gram_tile_accumulate<4>(tile, wrow, acc);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // cross-wave reduction through LDS, one tile at a time (red holds 4 waves x 256 floats would be too much; reuse)
+    float* out = partial + ((size_t)h * gridDim.x + blockIdx.x) * 10 * 256;
+    for (int a = 0; a < 10; ++a) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[a][r];
+        __syncthreads();
+        out[a * 256 + threadIdx.x] = (red[threadIdx.x] + red[256 + threadIdx.x]) + (red[512 + threadIdx.x] + red[768 + threadIdx.x]);
+    }
+}
+
+// out[g][e] = sum over chunks of partial[g][chunk][e] in fp64, fixed order.  grid = groups, block = 256, E elements.
+__global__ void __launch_bounds__(256) k_ef_gram_reduce(const float* __restrict__ partial, int chunks, int E,
+                                                        double* __restrict__ out) {
+    const int g = blockIdx.x;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        double s = 0;
+        for (int c = 0; c < chunks; ++c) s += (double)partial[((size_t)g * chunks + c) * E + e];
+        out[(size_t)g * E + e] = s;
+    }
+}
+
+// resubstituteFPt: one thread per point.  xAd: [nF(host)][nF(target)][6] floats (index nF*h + t), xc: 4 floats.
+__global__ void __launch_bounds__(256) k_ef_resubstitute(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                         const int* __restrict__ phost, const float* __restrict__ xc,
+                                                         const float* __restrict__ xAd) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= C.nP) return;
+    const size_t slots = (size_t)C.nF * C.nP;
+    const int h = phost[p];
+    if (precalc[h * C.nF + h].np == 0) return;
+    int ngood = 0;
+    float b = A.pbdSum[p];
+    float dot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dot += xc[i] * A.pHcdA[(size_t)i * C.nP + p];
+    b -= dot;
+    for (int t = 0; t < C.nF; ++t) {
+        const size_t s = (size_t)t * C.nP + p;
+        const uint8_t fl = A.rflags[s];
+        if (!(fl & RF_EXISTS) || !(fl & RF_ACTIVE)) continue;
+        ngood++;
+        const float* xa = xAd + (size_t)(C.nF * h + t) * 6;
+        float sum = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sum += xa[i] * A.JpJd[(size_t)i * slots + s];
+        b -= sum;
+    }
+    float step = 0.0f;
+    if (ngood > 0 && !A.psensor[p]) step = -b * A.pHdi[p];
+    A.pstep[p] = step;
+}
+
+}  // namespace sdvgn

@@ -103,6 +103,32 @@ GN_HD Pose exp_se3(const double* a) {
     return P;
 }
 
+
+// inverse of a rigid transform (Sophus SE3::inverse, se3.hpp:169-173)
+GN_HD Pose inverse(const Pose& A) {
+    Pose R;
+    R.q[0] = -A.q[0]; R.q[1] = -A.q[1]; R.q[2] = -A.q[2]; R.q[3] = A.q[3];
+    const double mt[3] = {-A.t[0], -A.t[1], -A.t[2]};
+    quat_rotate(R.q, mt, R.t);
+    return R;
+}
+
+// 6x6 adjoint [R, hat(t) R; 0, R], row-major (Sophus SE3::Adj, se3.hpp:131-139)
+GN_HD void adjoint(const Pose& T, double* A) {
+    double R[9];
+    rotation_matrix(T.q, R);
+    const double th[9] = {0, -T.t[2], T.t[1], T.t[2], 0, -T.t[0], -T.t[1], T.t[0], 0};
+    for (int i = 0; i < 36; ++i) A[i] = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            A[i * 6 + j] = R[i * 3 + j];
+            A[(i + 3) * 6 + (j + 3)] = R[i * 3 + j];
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += th[i * 3 + k] * R[k * 3 + j];
+            A[i * 6 + (j + 3)] = s;
+        }
+}
+
 // float 3x3 inverse by cofactors * (1/det), row-major  (what Matrix3f::inverse() evaluates)
 GN_HD float cofactor3(const float* m, int i, int j) {
     const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;

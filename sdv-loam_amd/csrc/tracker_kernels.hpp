@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) k_res_gs(const float4* __restrict__ pc, c
 
 // Deterministic fp64 combine of the partial rows + the tail of calcGSSSE (:468-483) and calcRes (:625-633).
 // grid = B, block = 128.  out: [B][kOutStride] doubles.
-__global__ void __launch_bounds__(128) k_finalize(const float* __restrict__ partial, int chunks, double* __restrict__ out) {
+static __global__ void __launch_bounds__(128) k_finalize(const float* __restrict__ partial, int chunks, double* __restrict__ out) {
     __shared__ double S[kNRed];
     const int b = blockIdx.x;
     if (threadIdx.x < kNRed) {
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(128) k_finalize(const float* __restrict__ part
 // Gradients use flat indices like the reference (idx+-1 wraps across rows at x=0 / x=wl-1); rows 0 and hl-1,
 // which the reference leaves uninitialised, are written as 0.
 // ----------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_pyr_level(const float* __restrict__ src_plane, float* __restrict__ aos,
+static __global__ void __launch_bounds__(256) k_pyr_level(const float* __restrict__ src_plane, float* __restrict__ aos,
                                                    float* __restrict__ aos_next, int wl, int hl, int has_next) {
     const int qx = blockIdx.x * blockDim.x + threadIdx.x;
     const int qy = blockIdx.y;
