@@ -180,6 +180,15 @@ int sdvgn_ef_point_step(sdvgn_ef* ef, int mode, float stepfacD);
 /* new frame states after a step (FrameHessian::setState) -- follow with sdvgn_ef_set_precalc */
 int sdvgn_ef_set_frame_states(sdvgn_ef* ef, const double* state10);
 
+/* The loop of FullSystem::optimize (FullSystemOptimize.cpp:344-458): resetOOB, linearizeAll + calcLEnergy/calcMEnergy,
+ * then per iteration backupState / solveSystem / doStepFromBackup / linearizeAll / accept (applyRes, lambda*0.25) or
+ * reject (loadSateBackup, re-linearise, lambda*100), break on a tiny step.  One loop body = one "Gauss-Newton
+ * iteration" of BASELINE.json's metric.  trace rows: {iteration, lambda, accepted, E, E_L, E_M, canbreak, x[4+6nF]}.
+ * Returns the number of iterations run (>= 0) or an error (< 0). */
+int sdvgn_ef_optimize(sdvgn_ef* ef, int mnumOptIts, double* trace, int trace_stride, int trace_cap);
+/* state after optimize: CalibHessian::value_scaled, FrameHessian::state (nF x 10), PointHessian::idepth (nP) */
+int sdvgn_ef_get_state(sdvgn_ef* ef, double* value_scaled4, double* state10, float* idepth);
+
 /* parity / read-back hooks */
 int sdvgn_ef_dim(sdvgn_ef* ef);
 int sdvgn_ef_get_system(sdvgn_ef* ef, double* HA, double* bA, double* Hsc, double* bsc, double* HFinal, double* bFinal);

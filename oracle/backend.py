@@ -44,6 +44,13 @@ def _L():
         L.orc_ef_get_adjoints.argtypes = [vp, f64p, f64p]
         L.orc_ef_res_in_A.argtypes = [vp]
         L.orc_ef_res_in_A.restype = C.c_int
+        L.orc_ef_optimize.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
+        L.orc_ef_optimize.restype = C.c_int
+        L.orc_ef_calc_L_energy.argtypes = [vp]
+        L.orc_ef_calc_L_energy.restype = C.c_double
+        L.orc_ef_calc_M_energy.argtypes = [vp]
+        L.orc_ef_calc_M_energy.restype = C.c_double
+        L.orc_ef_get_state.argtypes = [vp, f64p, f64p, f32p]
         _bound = True
     return L
 
@@ -162,3 +169,22 @@ class OracleEF:
 
     def resInA(self):
         return self.L.orc_ef_res_in_A(self.h_)
+
+    def optimize(self, its=6, cap=128):
+        stride = 7 + self.dim
+        trace = np.zeros((cap, stride))
+        n = self.L.orc_ef_optimize(self.h_, its, trace.ctypes.data_as(vp), stride, cap)
+        return trace[:n]
+
+    def calcLEnergy(self):
+        return self.L.orc_ef_calc_L_energy(self.h_)
+
+    def calcMEnergy(self):
+        return self.L.orc_ef_calc_M_energy(self.h_)
+
+    def state(self):
+        vs = np.zeros(4)
+        st = np.zeros(10 * self.nF)
+        idp = np.zeros(self.nP, np.float32)
+        self.L.orc_ef_get_state(self.h_, vs, st, idp)
+        return vs, st.reshape(self.nF, 10), idp

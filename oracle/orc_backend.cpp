@@ -159,7 +159,7 @@ struct Frame {
     SE3 evalPT, PRE_worldToCam, PRE_camToWorld;
     double state[10], state_zero[10], state_scaled[10];
     double prior[6], delta_prior[6], delta[6];
-    double step[10];
+    double step[10], state_backup[10];
     int frameID;
     float ab_exposure, frameEnergyTH;
     std::vector<float> dI;  // level-0 AoS {I,dx,dy}
@@ -173,7 +173,7 @@ struct Point {
     int r0, r1;  // residual range
     // EFPoint
     float priorF, deltaF, bdSumF, HdiF, Hdd_accLF, Hcd_accLF[4], bd_accLF, Hdd_accAF, Hcd_accAF[4], bd_accAF;
-    float step, idepth_hessian;
+    float step, idepth_hessian, idepth_backup;
 };
 
 struct Residual {
@@ -193,7 +193,7 @@ struct Residual {
 struct EF {
     int w, h, nF;
     // CalibHessian
-    double value_scaled[4], value_minus_value_zero[4];
+    double value_scaled[4], value_minus_value_zero[4], value[4], value_zero[4], value_backup[4];
     float fxl, fyl, cxl, cyl, fxli, fyli, cxli, cyli;
     float wM3G, hM3G;
     std::vector<Frame> frames;
@@ -818,6 +818,128 @@ static void solve_system(EF* E, int iteration, double lambda) {
     }
 }
 
+
+// CalibHessian::setValue (HessianBlocks.h:302-316)
+static void calib_set_value(EF* E, const double* v) {
+    for (int i = 0; i < 4; ++i) E->value[i] = v[i];
+    E->value_scaled[0] = SCALE_F * v[0]; E->value_scaled[1] = SCALE_F * v[1];
+    E->value_scaled[2] = SCALE_C * v[2]; E->value_scaled[3] = SCALE_C * v[3];
+    calib_update(E);
+    for (int i = 0; i < 4; ++i) E->value_minus_value_zero[i] = E->value[i] - E->value_zero[i];
+}
+
+// EnergyFunctional::calcLEnergyF_MT (:333-351) + calcLEnergyPt (:297-331)
+static double calc_L_energy(EF* E) {
+    double En = 0;
+    for (const Frame& f : E->frames) for (int i = 0; i < 6; ++i) En += f.delta_prior[i] * f.prior[i] * f.delta_prior[i];
+    { float a = 0; for (int i = 0; i < 4; ++i) a += E->cDeltaF[i] * E->cPriorF[i] * E->cDeltaF[i]; En += a; }
+    float acc = 0;   // Accumulator11 (float, tiered) -- only priors of points and linearised residuals contribute
+    for (const Point& p : E->points) {
+        for (int ri = p.r0; ri < p.r1; ++ri) {
+            const Residual& r = E->res[ri];
+            if (!r.isLinearized || !r.isActive) continue;
+            const float* dp = &E->adHTdeltaF[(size_t)(r.host + E->nF * r.target) * 6];
+            float dx = 0, dy = 0, cx = 0, cy = 0;
+            for (int i = 0; i < 6; ++i) { dx += r.Jef.Jpdxi[0][i] * dp[i]; dy += r.Jef.Jpdxi[1][i] * dp[i]; }
+            for (int i = 0; i < 4; ++i) { cx += r.Jef.Jpdc[0][i] * E->cDeltaF[i]; cy += r.Jef.Jpdc[1][i] * E->cDeltaF[i]; }
+            const float jx = dx + cx + r.Jef.Jpdd[0] * p.deltaF, jy = dy + cy + r.Jef.Jpdd[1] * p.deltaF;
+            acc += (r.res_toZeroF[0] * jx + r.res_toZeroF[1] * jy) + (jx * r.res_toZeroF[0] + jy * r.res_toZeroF[1]) + (jx * jx + jy * jy);
+        }
+        acc += p.deltaF * p.deltaF * p.priorF;
+    }
+    return En + acc;
+}
+// EnergyFunctional::calcMEnergyF (:284-295)
+static double calc_M_energy(EF* E) {
+    const int n = CPARS + 6 * E->nF;
+    std::vector<double> d(n);
+    for (int i = 0; i < CPARS; ++i) d[i] = (double)E->cDeltaF[i];
+    for (int h = 0; h < E->nF; ++h) for (int i = 0; i < 6; ++i) d[CPARS + 6 * h + i] = E->frames[h].delta[i];
+    double s = 0;
+    for (int i = 0; i < n; ++i) { double a = 2 * E->bM[i]; for (int j = 0; j < n; ++j) a += E->HM[(size_t)i * n + j] * d[j]; s += d[i] * a; }
+    return s;
+}
+static double linearize_all(EF* E) {
+    double s = 0;
+    for (Residual& r : E->res) if (!r.isLinearized) s += linearize(E, r);
+    return s;
+}
+
+// FullSystem::optimize loop (FullSystemOptimize.cpp:344-458): backupState / solveSystem / doStepFromBackup /
+// linearizeAll / accept-reject.  trace rows: {iteration, lambda, accepted, E_new, EL_new, EM_new, canbreak, x[n]...}
+static int optimize(EF* E, int mnumOptIts, double* trace, int trace_stride, int trace_cap) {
+    const int nF = E->nF, n = CPARS + 6 * nF;
+    if (nF < 2) return 0;
+    if (nF < 3) mnumOptIts = 100;
+    if (nF < 4) mnumOptIts = 75;
+    for (Residual& r : E->res) if (!r.isLinearized) { r.state_NewEnergy = r.state_energy = 0; r.state_NewState = OUTLIER; r.state_state = IN; }  // resetOOB
+    double lastEnergy = linearize_all(E);
+    double lastEnergyL = calc_L_energy(E), lastEnergyM = calc_M_energy(E);
+    for (Residual& r : E->res) if (!r.isLinearized) apply_res(r);
+    double lambda = 1e-1;
+    const float stepsize = 1;
+    const float thOpt = 1.2f;  // setting_thOptIterations
+    int it = 0;
+    for (int iteration = 0; iteration < mnumOptIts; iteration++) {
+        // backupState (non-momentum branch :297-306)
+        for (int i = 0; i < 4; ++i) E->value_backup[i] = E->value[i];
+        for (Frame& f : E->frames) for (int i = 0; i < 10; ++i) f.state_backup[i] = f.state[i];
+        for (Point& p : E->points) p.idepth_backup = p.idepth;
+        solve_system(E, iteration, lambda);
+        // doStepFromBackup(stepsize x5)  :212-262
+        float sumT = 0, sumR = 0, sumID = 0, numID = 0, sumNID = 0;
+        double v[4];
+        for (int i = 0; i < 4; ++i) v[i] = E->value_backup[i] + stepsize * E->calibStep[i];
+        calib_set_value(E, v);
+        for (Frame& f : E->frames) {
+            double st[10];
+            for (int i = 0; i < 10; ++i) st[i] = f.state_backup[i] + (double)stepsize * f.step[i];
+            frame_set_state(f, st);
+            for (int i = 0; i < 3; ++i) sumT += (float)(f.step[i] * f.step[i]);
+            for (int i = 3; i < 6; ++i) sumR += (float)(f.step[i] * f.step[i]);
+        }
+        for (Point& p : E->points) {
+            const float nid = p.idepth_backup + stepsize * p.step;
+            p.idepth = nid; p.idepth_scaled = SCALE_IDEPTH * nid;
+            sumID += p.step * p.step;
+            sumNID += fabsf(p.idepth_backup);
+            numID++;
+            p.idepth_zero = nid; p.idepth_zero_scaled = SCALE_IDEPTH * nid;
+        }
+        sumR /= nF; sumT /= nF; sumID /= numID; sumNID /= numID;
+        set_precalc(E); set_delta(E);
+        const bool canbreak = sqrtf(sumR) < 0.00005 * thOpt && sqrtf(sumT) * sumNID < 0.00005 * thOpt;
+        const double newEnergy = linearize_all(E);
+        const double newEnergyL = calc_L_energy(E), newEnergyM = calc_M_energy(E);
+        const bool accept = newEnergy + newEnergyL + newEnergyM < lastEnergy + lastEnergyL + lastEnergyM;
+        if (trace && iteration < trace_cap) {
+            double* tr = trace + (size_t)iteration * trace_stride;
+            tr[0] = iteration; tr[1] = lambda; tr[2] = accept; tr[3] = newEnergy; tr[4] = newEnergyL; tr[5] = newEnergyM; tr[6] = canbreak;
+            for (int i = 0; i < n && 7 + i < trace_stride; ++i) tr[7 + i] = E->lastX[i];
+        }
+        it = iteration + 1;
+        if (accept) {
+            for (Residual& r : E->res) if (!r.isLinearized) apply_res(r);
+            lastEnergy = newEnergy; lastEnergyL = newEnergyL; lastEnergyM = newEnergyM;
+            lambda *= 0.25;
+        } else {
+            // loadSateBackup :264-282
+            calib_set_value(E, E->value_backup);
+            for (Frame& f : E->frames) frame_set_state(f, f.state_backup);
+            for (Point& p : E->points) {
+                p.idepth = p.idepth_backup; p.idepth_scaled = SCALE_IDEPTH * p.idepth_backup;
+                p.idepth_zero = p.idepth_backup; p.idepth_zero_scaled = SCALE_IDEPTH * p.idepth_backup;
+            }
+            set_precalc(E); set_delta(E);
+            lastEnergy = linearize_all(E);
+            lastEnergyL = calc_L_energy(E); lastEnergyM = calc_M_energy(E);
+            lambda *= 1e2;
+        }
+        if (canbreak && iteration >= 1) break;   // setting_minOptIterations = 1
+    }
+    return it;
+}
+
 }  // namespace orcb
 
 using namespace orcb;
@@ -833,6 +955,10 @@ void orc_ef_destroy(void* e) { delete (EF*)e; }
 void orc_ef_set_calib(void* e, const double value_scaled[4], const double value_minus_value_zero[4]) {
     EF* E = (EF*)e;
     for (int i = 0; i < 4; ++i) { E->value_scaled[i] = value_scaled[i]; E->value_minus_value_zero[i] = value_minus_value_zero[i]; }
+    // CalibHessian::setValueScaled (HessianBlocks.h:318-330): value = SCALE_*_INVERSE * value_scaled
+    E->value[0] = (1.0f / SCALE_F) * value_scaled[0]; E->value[1] = (1.0f / SCALE_F) * value_scaled[1];
+    E->value[2] = (1.0f / SCALE_C) * value_scaled[2]; E->value[3] = (1.0f / SCALE_C) * value_scaled[3];
+    for (int i = 0; i < 4; ++i) E->value_zero[i] = E->value[i] - value_minus_value_zero[i];
     calib_update(E);
 }
 
@@ -989,4 +1115,13 @@ void orc_ef_get_adjoints(void* e, double* adHost, double* adTarget) {
     std::memcpy(adTarget, E->adTarget.data(), sizeof(double) * E->adTarget.size());
 }
 int orc_ef_res_in_A(void* e) { return ((EF*)e)->resInA; }
+int orc_ef_optimize(void* e, int its, double* trace, int stride, int cap) { return optimize((EF*)e, its, trace, stride, cap); }
+double orc_ef_calc_L_energy(void* e) { return calc_L_energy((EF*)e); }
+double orc_ef_calc_M_energy(void* e) { return calc_M_energy((EF*)e); }
+void orc_ef_get_state(void* e, double* value_scaled4, double* state10, float* idepth) {
+    EF* E = (EF*)e;
+    for (int i = 0; i < 4; ++i) value_scaled4[i] = E->value_scaled[i];
+    for (int h = 0; h < E->nF; ++h) for (int i = 0; i < 10; ++i) state10[10 * h + i] = E->frames[h].state[i];
+    for (size_t i = 0; i < E->points.size(); ++i) idepth[i] = E->points[i].idepth;
+}
 }

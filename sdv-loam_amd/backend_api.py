@@ -38,6 +38,8 @@ PROTOTYPES = [
     ("sdvgn_ef_accumulate", C.c_int, [vp]),
     ("sdvgn_ef_finish_solve", C.c_int, [vp, C.c_int, C.c_double, vp]),
     ("sdvgn_ef_set_host_range", C.c_int, [vp, C.c_int, C.c_int]),
+    ("sdvgn_ef_optimize", C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int]),
+    ("sdvgn_ef_get_state", C.c_int, [vp, vp, vp, vp]),
 ]
 
 
@@ -179,3 +181,16 @@ class EnergyFunctional:
 
     def stream(self):
         return self.L.sdvgn_ef_stream(self.h_)
+
+    def optimize(self, its=6, cap=128, want_trace=True):
+        stride = 7 + self.dim
+        trace = np.zeros((cap, stride))
+        n = self._check(self.L.sdvgn_ef_optimize(self.h_, its, trace.ctypes.data_as(vp) if want_trace else None, stride, cap))
+        return trace[:n]
+
+    def state(self):
+        vs = np.zeros(4)
+        st = np.zeros(10 * self.nF)
+        idp = np.zeros(self.nP, np.float32)
+        self._check(self.L.sdvgn_ef_get_state(self.h_, vs.ctypes.data_as(vp), st.ctypes.data_as(vp), idp.ctypes.data_as(vp)))
+        return vs, st.reshape(self.nF, 10), idp

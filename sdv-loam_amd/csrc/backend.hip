@@ -38,7 +38,7 @@ const float kInitialRotPrior = 1e11f, kInitialTransPrior = 1e10f, kInitialCalibH
 struct FrameH {
     gn::Pose evalPT, PRE_worldToCam, PRE_camToWorld;
     double state[10], state_zero[10], state_scaled[10];
-    double prior[6], delta[6], delta_prior[6];
+    double prior[6], delta[6], delta_prior[6], state_backup[10];
     int frameID;
     float ab_exposure, frameEnergyTH;
 };
@@ -56,6 +56,7 @@ struct sdvgn_ef {
     int h0 = 0, h1 = SDVGN_MAX_FRAMES;   // host-frame shard of this rank
     // calib
     double value_scaled[4] = {0, 0, 0, 0}, value_minus_value_zero[4] = {0, 0, 0, 0};
+    double value[4] = {0, 0, 0, 0}, value_zero[4] = {0, 0, 0, 0}, value_backup[4] = {0, 0, 0, 0};
     EFConst C{};
     std::vector<FrameH> frames;
     std::vector<int> phost, hostP0, r_slot;
@@ -89,6 +90,8 @@ struct sdvgn_ef {
     double* acc_host = nullptr;   // pinned mirror
     float *xc_dev = nullptr, *xAd_dev = nullptr;
     float* x_host = nullptr;      // pinned: xc(4) + xAd(nF*nF*6)
+    double* stats_dev = nullptr;   // {L-energy point part, sum step^2, sum |idepth_backup|}
+    double* stats_partial = nullptr;
     size_t slots_cap = 0;
     bool havePrecalc = false, haveAdjoints = false;
 };
@@ -417,6 +420,69 @@ __global__ void k_ef_point_step(int nP, int mode, float fac, float* __restrict__
     pdeltaF[p] = v - v;   // idepth - idepth_zero
 }
 
+
+// PointFrameResidual::resetOOB for every non-linearised residual (start of FullSystem::optimize, :353-364)
+__global__ void k_ef_reset_oob(size_t slots, EFArrays A) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= slots) return;
+    const uint8_t fl = A.rflags[s];
+    if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED)) return;
+    A.renergy[s] = 0; A.renergy_new[s] = 0;
+    A.rstate_new[s] = RS_OUTLIER;
+    A.rstate[s] = RS_IN;
+}
+
+// per-block partial sums of: [0] calcLEnergyPt (EnergyFunctional.cpp:297-331), [1] step^2, [2] |idepth_backup|
+__global__ void __launch_bounds__(256) k_ef_point_stats(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                       const int* __restrict__ phost, const float* __restrict__ backup,
+                                                       double* __restrict__ partial) {
+    __shared__ double sh[3][4];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    double e = 0, s2 = 0, sa = 0;
+    if (p < C.nP) {
+        const int h = phost[p];
+        if (precalc[h * C.nF + h].np != 0) {
+            const size_t slots = (size_t)C.nF * C.nP;
+            const float dd = A.pdeltaF[p];
+            float acc = 0;
+            for (int t = 0; t < C.nF; ++t) {
+                const size_t s = (size_t)t * C.nP + p;
+                const uint8_t fl = A.rflags[s];
+                if (!(fl & RF_EXISTS) || !(fl & RF_ACTIVE) || !(fl & RF_LINEARIZED)) continue;
+                const PrecalcDev& pc = precalc[h * C.nF + t];
+                const float* Je = A.J + (size_t)((fl & RF_SEL) ? 1 : 0) * kJPlanes * slots + s;
+                float dx = 0, dy = 0, cx = 0, cy = 0;
+                for (int i = 0; i < 6; ++i) { dx += Je[(2 + i) * slots] * pc.dp[i]; dy += Je[(8 + i) * slots] * pc.dp[i]; }
+                for (int i = 0; i < 4; ++i) { cx += Je[(14 + i) * slots] * C.cDeltaF[i]; cy += Je[(18 + i) * slots] * C.cDeltaF[i]; }
+                const float jx = dx + cx + Je[22 * slots] * dd, jy = dy + cy + Je[23 * slots] * dd;
+                const float r0 = A.rres_toZero[s], r1 = A.rres_toZero[slots + s];
+                acc += (r0 * jx + r1 * jy) + (jx * r0 + jy * r1) + (jx * jx + jy * jy);
+            }
+            acc += dd * dd * A.ppriorF[p];
+            e = acc;
+            const float st = A.pstep[p];
+            s2 = (double)(st * st);
+            sa = (double)fabsf(backup[p]);
+        }
+    }
+    e = wave_sum_double(e); s2 = wave_sum_double(s2); sa = wave_sum_double(sa);
+    if ((threadIdx.x & 63) == 63) { sh[0][threadIdx.x >> 6] = e; sh[1][threadIdx.x >> 6] = s2; sh[2][threadIdx.x >> 6] = sa; }
+    __syncthreads();
+    if (threadIdx.x < 3) partial[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+__global__ void k_ef_sum3(const double* __restrict__ partial, int n, double* __restrict__ out) {
+    __shared__ double s[256];
+    for (int q = 0; q < 3; ++q) {
+        double a = 0;
+        for (int i = threadIdx.x; i < n; i += 256) a += partial[(size_t)q * n + i];
+        s[threadIdx.x] = a;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) out[q] = s[0];
+        __syncthreads();
+    }
+}
+
 static int chunks_for_np(const sdvgn_ef* e) {
     int mx = 1;
     for (int h = 0; h < e->nF; ++h) mx = std::max(mx, e->hostP0[h + 1] - e->hostP0[h]);
@@ -455,6 +521,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     const size_t accmax = (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kTopE + (size_t)SDVGN_MAX_FRAMES * kScE + 2;
     bad |= dev_alloc(&e->acc_dev, accmax);
     bad |= dev_alloc(&e->xc_dev, 4) | dev_alloc(&e->xAd_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6);
+    bad |= dev_alloc(&e->stats_dev, 4) | dev_alloc(&e->stats_partial, 3 * (mp / 256 + 2));
     if (bad) { sdvgn_ef_destroy(e); return -(int)hipErrorOutOfMemory; }
     HIPCHK(hipHostMalloc(&e->precalc_host, sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
     HIPCHK(hipHostMalloc(&e->acc_host, sizeof(double) * accmax));
@@ -474,7 +541,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->rstate, e->rstate_new, e->rmatcher, e->renergy, e->renergy_new, e->renergy_wo, e->rres_toZero, e->J, e->JpJd, e->pHddA,
                     e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->images, e->img_stage,
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
-                    e->xc_dev, e->xAd_dev};
+                    e->xc_dev, e->xAd_dev, e->stats_dev, e->stats_partial};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->precalc_host) hipHostFree(e->precalc_host);
     if (e->acc_host) hipHostFree(e->acc_host);
@@ -488,6 +555,10 @@ void* sdvgn_ef_stream(sdvgn_ef* e) { return e ? (void*)e->stream : nullptr; }
 int sdvgn_ef_set_calib(sdvgn_ef* e, const double vs[4], const double vmz[4]) {
     if (!e || !vs || !vmz) return SDVGN_E_ARG;
     for (int i = 0; i < 4; ++i) { e->value_scaled[i] = vs[i]; e->value_minus_value_zero[i] = vmz[i]; }
+    // CalibHessian::setValueScaled: value = SCALE_*_INVERSE * value_scaled (HessianBlocks.h:318-330)
+    e->value[0] = (1.0f / SDVGN_SCALE_F) * vs[0]; e->value[1] = (1.0f / SDVGN_SCALE_F) * vs[1];
+    e->value[2] = (1.0f / SDVGN_SCALE_C) * vs[2]; e->value[3] = (1.0f / SDVGN_SCALE_C) * vs[3];
+    for (int i = 0; i < 4; ++i) e->value_zero[i] = e->value[i] - vmz[i];
     ef_update_const(e);
     e->havePrecalc = false;
     return SDVGN_OK;
@@ -788,6 +859,129 @@ int sdvgn_ef_point_step(sdvgn_ef* e, int mode, float stepfacD) {
     HIPCHK(hipSetDevice(e->device));
     k_ef_point_step<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->nP, mode, stepfacD, e->pid, e->pidz, e->pidepth_backup, e->pstep, e->pdeltaF);
     HIPCHK(hipGetLastError());
+    return SDVGN_OK;
+}
+
+
+// ---- FullSystem::optimize loop body pieces (FullSystemOptimize.cpp:165-321, 344-458) ------------------------
+static void calib_set_value(sdvgn_ef* e, const double* v) {   // CalibHessian::setValue
+    for (int i = 0; i < 4; ++i) e->value[i] = v[i];
+    e->value_scaled[0] = SDVGN_SCALE_F * v[0]; e->value_scaled[1] = SDVGN_SCALE_F * v[1];
+    e->value_scaled[2] = SDVGN_SCALE_C * v[2]; e->value_scaled[3] = SDVGN_SCALE_C * v[3];
+    for (int i = 0; i < 4; ++i) e->value_minus_value_zero[i] = e->value[i] - e->value_zero[i];
+    ef_update_const(e);
+}
+static double calc_M_energy(sdvgn_ef* e) {   // EnergyFunctional::calcMEnergyF
+    const int nF = e->nF, n = CPARS + 6 * nF;
+    std::vector<double> d(n);
+    for (int i = 0; i < CPARS; ++i) d[i] = (double)e->C.cDeltaF[i];
+    for (int h = 0; h < nF; ++h) for (int i = 0; i < 6; ++i) d[CPARS + 6 * h + i] = e->frames[h].delta[i];
+    double s = 0;
+    for (int i = 0; i < n; ++i) { double a = 2 * e->bM[i]; for (int j = 0; j < n; ++j) a += e->HM[(size_t)i * n + j] * d[j]; s += d[i] * a; }
+    return s;
+}
+// launches linearizeAll + the point statistics; returns {energy, L-energy, sum step^2, sum |idepth_backup|} after ONE sync
+static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* sumID, double* sumNID) {
+    int rc = sdvgn_ef_linearize_all(e, nullptr);
+    if (rc) return rc;
+    const int nb = (e->nP + 255) / 256;
+    k_ef_point_stats<<<nb, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial);
+    k_ef_sum3<<<1, 256, 0, e->stream>>>(e->stats_partial, nb, e->stats_dev);
+    HIPCHK(hipGetLastError());
+    double* edst = e->acc_dev + acc_count(e) - 2;
+    HIPCHK(hipMemcpyAsync(e->acc_host, edst, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->acc_host + 1, e->stats_dev, 3 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *energy = e->acc_host[0];
+    double En = 0;   // calcLEnergyF_MT: frame + calib priors on the host, point part from the device
+    for (const FrameH& f : e->frames) for (int i = 0; i < 6; ++i) En += f.delta_prior[i] * f.prior[i] * f.delta_prior[i];
+    { float a = 0; for (int i = 0; i < 4; ++i) a += e->C.cDeltaF[i] * (float)e->cPrior[i] * e->C.cDeltaF[i]; En += a; }
+    *EL = En + (double)(float)e->acc_host[1];
+    if (sumID) *sumID = e->acc_host[2];
+    if (sumNID) *sumNID = e->acc_host[3];
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, double* trace, int trace_stride, int trace_cap) {
+    if (!e || !e->haveAdjoints || e->nP < 1) return SDVGN_E_STATE;
+    HIPCHK(hipSetDevice(e->device));
+    const int nF = e->nF, n = CPARS + 6 * nF;
+    if (nF < 2) return 0;
+    if (nF < 3) mnumOptIts = 100;
+    if (nF < 4) mnumOptIts = 75;
+    const size_t slots = (size_t)nF * e->nP;
+    int rc;
+    if (!e->havePrecalc && (rc = ef_upload_precalc(e))) return rc;
+    k_ef_reset_oob<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(slots, e->A);
+    double lastEnergy, lastEnergyL, lastEnergyM;
+    if ((rc = linearize_and_stats(e, &lastEnergy, &lastEnergyL, nullptr, nullptr))) return rc;
+    lastEnergyM = calc_M_energy(e);
+    if ((rc = sdvgn_ef_apply_res(e))) return rc;
+    double lambda = 1e-1;
+    const float stepsize = 1, thOpt = 1.2f;
+    std::vector<double> x(n);
+    int it = 0;
+    for (int iteration = 0; iteration < mnumOptIts; iteration++) {
+        for (int i = 0; i < 4; ++i) e->value_backup[i] = e->value[i];                     // backupState
+        for (FrameH& f : e->frames) for (int i = 0; i < 10; ++i) f.state_backup[i] = f.state[i];
+        if ((rc = sdvgn_ef_point_step(e, 0, 0.f))) return rc;
+        if ((rc = sdvgn_ef_solve_system(e, iteration, lambda, x.data()))) return rc;
+        // doStepFromBackup
+        double v[4];
+        for (int i = 0; i < 4; ++i) v[i] = e->value_backup[i] + stepsize * (-x[i]);
+        calib_set_value(e, v);
+        float sumT = 0, sumR = 0;
+        for (int h = 0; h < nF; ++h) {
+            FrameH& f = e->frames[h];
+            double st[10];
+            for (int i = 0; i < 6; ++i) st[i] = f.state_backup[i] + (double)stepsize * (-x[CPARS + 6 * h + i]);
+            for (int i = 6; i < 10; ++i) st[i] = f.state_backup[i];
+            frame_set_state(f, st);
+            for (int i = 0; i < 3; ++i) sumT += (float)(x[CPARS + 6 * h + i] * x[CPARS + 6 * h + i]);
+            for (int i = 3; i < 6; ++i) sumR += (float)(x[CPARS + 6 * h + i] * x[CPARS + 6 * h + i]);
+        }
+        if ((rc = sdvgn_ef_point_step(e, 1, stepsize))) return rc;
+        if ((rc = ef_upload_precalc(e))) return rc;                                       // setPrecalcValues + setDeltaF
+        double newEnergy, newEnergyL, sID, sNID;
+        if ((rc = linearize_and_stats(e, &newEnergy, &newEnergyL, &sID, &sNID))) return rc;
+        const double newEnergyM = calc_M_energy(e);
+        sumR /= nF; sumT /= nF;
+        const float sumNID = (float)sNID / (float)e->nP;
+        const bool canbreak = sqrtf(sumR) < 0.00005 * thOpt && sqrtf(sumT) * sumNID < 0.00005 * thOpt;
+        const bool accept = newEnergy + newEnergyL + newEnergyM < lastEnergy + lastEnergyL + lastEnergyM;
+        if (trace && iteration < trace_cap) {
+            double* tr = trace + (size_t)iteration * trace_stride;
+            tr[0] = iteration; tr[1] = lambda; tr[2] = accept; tr[3] = newEnergy; tr[4] = newEnergyL; tr[5] = newEnergyM; tr[6] = canbreak;
+            for (int i = 0; i < n && 7 + i < trace_stride; ++i) tr[7 + i] = x[i];
+        }
+        it = iteration + 1;
+        if (accept) {
+            if ((rc = sdvgn_ef_apply_res(e))) return rc;
+            lastEnergy = newEnergy; lastEnergyL = newEnergyL; lastEnergyM = newEnergyM;
+            lambda *= 0.25;
+        } else {
+            calib_set_value(e, e->value_backup);                                          // loadSateBackup
+            for (FrameH& f : e->frames) frame_set_state(f, f.state_backup);
+            if ((rc = sdvgn_ef_point_step(e, 2, 0.f))) return rc;
+            if ((rc = ef_upload_precalc(e))) return rc;
+            if ((rc = linearize_and_stats(e, &lastEnergy, &lastEnergyL, nullptr, nullptr))) return rc;
+            lastEnergyM = calc_M_energy(e);
+            lambda *= 1e2;
+        }
+        if (canbreak && iteration >= 1) break;
+    }
+    return it;
+}
+
+int sdvgn_ef_get_state(sdvgn_ef* e, double* value_scaled4, double* state10, float* idepth) {
+    if (!e) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    if (value_scaled4) for (int i = 0; i < 4; ++i) value_scaled4[i] = e->value_scaled[i];
+    if (state10) for (int h = 0; h < e->nF; ++h) for (int i = 0; i < 10; ++i) state10[10 * h + i] = e->frames[h].state[i];
+    if (idepth) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpy(idepth, e->pid, sizeof(float) * e->nP, hipMemcpyDeviceToHost));
+    }
     return SDVGN_OK;
 }
 

@@ -145,3 +145,22 @@ def test_full_size_cfg3(api, orc):
     n = G.dim
     Hd = s["HFinal"].copy(); Hd[np.arange(n), np.arange(n)] *= 1.1
     assert rel_err(Hd @ x, s["bFinal"]) < 1e-6
+
+
+@pytest.mark.parametrize("seed", [2, 3])
+def test_optimize_loop_parity(api, orc, seed):
+    """Whole FullSystem::optimize loop (b8): same accept/reject sequence, lambda schedule, x per iteration and final state."""
+    from sdv_loam_amd import synthetic as syn
+    W = syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=seed, calib=dict(fx=400., fy=410., cx=319.5, cy=119.5))
+    G, O = pair(api, orc, W)
+    tg = G.optimize(6)
+    to = O.optimize(6)
+    assert len(tg) == len(to) and len(to) >= 1
+    assert np.array_equal(tg[:, [0, 1, 2, 6]], to[:, [0, 1, 2, 6]])          # iteration, lambda, accepted, canbreak
+    assert np.allclose(tg[:, 3:6], to[:, 3:6], rtol=1e-5, atol=1e-6)          # energies
+    for i in range(len(to)):
+        assert rel_err(tg[i, 7:], to[i, 7:]) < 1e-4                           # increments x of every iteration
+    vg, sg, ig = G.state()
+    vo, so, io = O.state()
+    assert np.allclose(vg, vo, rtol=1e-9) and np.allclose(sg, so, rtol=1e-6, atol=1e-10)
+    assert rel_err(ig, io) < 1e-6
