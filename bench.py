@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
-"""bench.py -- Gauss-Newton iterations/s of the SDV-LOAM hot path on MI355X (contract: see DESIGN.md "Measurement").
+"""bench.py -- Gauss-Newton iterations/s of the SDV-LOAM hot path on MI355X (contract: DESIGN.md "Measurement").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload tracker|tracker_batch] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu] [--quick]
 
-One "step" = one Gauss-Newton iteration: for the tracker, one LM trial at pyramid level 0 =
-fused calcRes + calcGSSSE over the 2000 reference points of BASELINE.json configs[1] (1241x376, KITTI-00 calib),
-including the read-back of the 8x8 H, b and the Vec6 that the host LM logic needs before it can issue the next trial.
-Inputs (pyramid, reference points) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+Headline workload (BASELINE.json metric "Gauss-Newton iters/sec (KITTI res, 8 KF x 2000 pts)" = configs[2]):
+one step = one body of the FullSystem::optimize loop (FullSystemOptimize.cpp:395-458) on a synthetic KITTI-00
+1241x376 window of 8 key-frames x 2000 points = 112 000 residuals:
+    backupState -> solveSystemF (accumulate A/L/SC, stitch, (4+6*8)^2 LDLT, resubstitute) -> doStepFromBackup
+    -> linearizeAll -> accept (applyRes) | reject (loadSateBackup + re-linearise)
+Window images, points and residual tables are resident in HBM before the timed region.
+Extra fields report the coarse tracker (configs[1]) and the roofline of the dominant kernel.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -19,8 +23,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-BYTES_PER_POINT = 64           # 16 B point record + 4 taps x 12 B {I,dx,dy}
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+TRACKER_BYTES_PER_POINT = 64     # 16 B point record + 4 taps x 12 B {I,dx,dy}
+LINEARIZE_BYTES_PER_RES = 584    # 76 point + 16 matcher + 384 gathers + 96 J out + 12 state
 
 
 def parse():
@@ -28,25 +33,23 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="tracker")
-    ap.add_argument("--batch", type=int, default=2048, help="problems per launch for the batched roofline run")
+    ap.add_argument("--batch", type=int, default=2048, help="LM trials per launch for the batched tracker roofline run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--quick", action="store_true", help="skip the tracker extras")
     return ap.parse_args()
 
 
-def dist_setup(n):
+def dist_setup():
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(0)
     return rank, local, world
 
 
@@ -68,110 +71,168 @@ def max_over_ranks(x, world):
     return float(t.item())
 
 
-def tracker_setup(device, max_batch):
+def event_ms(torch, stream, fn, reps):
+    """median duration of fn() in ms, HIP events recorded on `stream` (the stream the library launches on)."""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record(stream)
+        fn()
+        b.record(stream)
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in evs]))
+
+
+# ------------------------------------------------------------------------------------------------------------
+def backend_setup(device):
+    from sdv_loam_amd import backend_api, synthetic as syn
+    W = syn.make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=syn.KITTI00)
+    G = backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP, device=device).load(W)
+    return W, G
+
+
+def cpu_baseline_backend(W, budget_s=12.0):
+    """The oracle (CPU restatement, 1 thread: reference default multiThreading=false, settings.cpp:164) running the
+    same optimize-loop bodies on the same window."""
+    from oracle.backend import OracleEF
+    O = OracleEF(W.w, W.h).load(W)
+    O.optimize(2)                      # warm-up
+    # time only the optimize calls (loading is setup)
+    reps, its, tt = 0, 0, 0.0
+    while tt < budget_s * 0.5:
+        O.load(W)
+        t1 = time.perf_counter()
+        tr = O.optimize(6)
+        tt += time.perf_counter() - t1
+        its += len(tr)
+        reps += 1
+    return dict(value=its / tt, unit="GN iters/s", cores=1, kind="port",
+                sample="%d optimize-loop bodies (8 KF x 2000 pts, 112000 residuals) in %.1f s on 1 host thread; "
+                       "host has %d logical CPUs" % (its, tt, os.cpu_count()))
+
+
+def tracker_extras(torch, local, batch, oracle, want_cpu):
     from sdv_loam_amd import api, synthetic as syn
     P = syn.make_tracker_problem(1241, 376, 4, 2000, seed=0, calib=syn.KITTI00,
                                  gt_xi=[0.1, -0.05, 0.2, 0.01, -0.02, 0.005], gt_aff=(0.05, 3.0))
-    G = api.CoarseTracker(P.w, P.h, P.levels, max_points=4096, max_batch=max_batch, device=device)
+    rng = np.random.default_rng(9)
+    for r in P.ref:
+        r["color"] = (r["color"] + rng.normal(0, 1.0, r["color"].shape)).astype(np.float32)
+    G = api.CoarseTracker(P.w, P.h, P.levels, max_points=4096, max_batch=max(batch, 64), device=local)
     G.makeK(**P.calib)
     for l in range(P.levels):
         G.set_ref(l, **P.ref[l])
     G.set_ref_frame(1.0, 0.0, 0.0)
     G.set_new_image(P.image, 1.0)
-    return P, G, syn
-
-
-def cpu_baseline_tracker(P, syn, budget_s=10.0):
-    """The oracle (CPU restatement, 1 thread -- reference default multiThreading=false) on the same LM-trial workload."""
-    import oracle
-    O = oracle.OracleTracker(P.w, P.h, P.levels)
-    O.makeK(**P.calib)
-    for l in range(P.levels):
-        O.set_ref(l, **P.ref[l])
-    O.set_ref_frame(1.0, 0.0, 0.0)
-    O.set_new_image(P.image, 1.0)
+    ext = torch.cuda.ExternalStream(G.stream(), device=torch.device("cuda", local))
     start = oracle.se3_mul(oracle.se3_exp(syn.perturbation(0)), P.gt_pose)
+    out = {}
+    # (i) host-driven LM trial: fused launch + 640-B read-back per trial
     for _ in range(20):
-        O.calcRes(0, start, 0.02, 2.0, 20.0)
-        O.calcGS(0, 0.02, 2.0)
-    n = 0
+        G.resAndGS(0, start, 0.02, 2.0, 20.0)
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < budget_s and n < 200000:
-        for _ in range(100):
-            O.calcRes(0, start, 0.02, 2.0, 20.0)
-            O.calcGS(0, 0.02, 2.0)
-        n += 100
-    dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="GN iters/s", cores=1, kind="port",
-                sample="%d LM trials (calcRes+calcGSSSE, level 0, 2000 pts, 1241x376) in %.1f s on 1 host thread; host has %d logical CPUs"
-                       % (n, dt, os.cpu_count()))
+    for _ in range(300):
+        G.resAndGS(0, start, 0.02, 2.0, 20.0)
+    out["host_driven_trials_per_s"] = 300 / (time.perf_counter() - t0)
+    # (ii) whole trackNewestCoarse calls: host-driven and device-resident (1 and 31 hypotheses)
+    _, _, _, _, _, tr = G.trackNewestCoarse(start, (0.02, 2.0), 3)
+    ntr = max(len(tr), 1)
+    t0 = time.perf_counter()
+    for _ in range(30):
+        G.trackNewestCoarse(start, (0.02, 2.0), 3)
+    dt = (time.perf_counter() - t0) / 30
+    out["track_call_host_driven_ms"] = 1e3 * dt
+    out["track_call_lm_trials"] = ntr
+    for B in (1, 31):
+        starts = np.stack([oracle.se3_mul(oracle.se3_exp(syn.perturbation(i)), P.gt_pose) for i in range(B)])
+        affs = np.tile([0.02, 2.0], (B, 1))
+        G.trackBatch(starts, affs, 3)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            G.trackBatch(starts, affs, 3)
+        out["track_call_device_resident_B%d_ms" % B] = 1e3 * (time.perf_counter() - t0) / 20
+    # (iii) batched roofline run of the fused tracker kernel
+    poses = np.stack([oracle.se3_mul(oracle.se3_exp(syn.perturbation(1000 + i)), P.gt_pose) for i in range(batch)])
+    affs = np.tile([0.02, 2.0], (batch, 1))
+    for _ in range(3):
+        G.resAndGSBatch(0, poses, affs, 20.0)
+    torch.cuda.synchronize()
+    ms = event_ms(torch, ext, lambda: G.resAndGSBatch(0, poses, affs, 20.0), 20)
+    alg = batch * P.ref[0]["u"].size * TRACKER_BYTES_PER_POINT
+    out["batched"] = dict(kernel="k_res_gs+k_finalize", lm_trials_per_launch=batch, ms_per_launch=ms, gn_iters_per_s=batch / (ms * 1e-3),
+                          algorithmic_GBps=alg / (ms * 1e-3) / 1e9, frac_of_hbm_peak=alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+    if want_cpu:
+        O = oracle.OracleTracker(P.w, P.h, P.levels)
+        O.makeK(**P.calib)
+        for l in range(P.levels):
+            O.set_ref(l, **P.ref[l])
+        O.set_ref_frame(1.0, 0.0, 0.0)
+        O.set_new_image(P.image, 1.0)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 3.0:
+            for _ in range(200):
+                O.calcRes(0, start, 0.02, 2.0, 20.0)
+                O.calcGS(0, 0.02, 2.0)
+            n += 200
+        out["cpu_trials_per_s_1thread"] = n / (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            O.trackNewestCoarse(start, (0.02, 2.0), 3)
+        out["cpu_track_call_ms_1thread"] = 1e3 * (time.perf_counter() - t0) / 50
+    return out
 
 
 def main():
     args = parse()
     import torch
-    rank, local, world = dist_setup(args.gpus)
-    import oracle  # only for start-pose maths of the synthetic workload and the cpu_baseline leg
-    P, G, syn = tracker_setup(local, max(args.batch, 64))
+    rank, local, world = dist_setup()
+    K, Wm = args.steps, args.warmup
+    W, G = backend_setup(local)
     ext = torch.cuda.ExternalStream(G.stream(), device=torch.device("cuda", local))
-    start = oracle.se3_mul(oracle.se3_exp(syn.perturbation(rank)), P.gt_pose)
-    K, W = args.steps, args.warmup
 
-    # ---- timed region: K sequential LM trials (kernel + finalize + 640-B read-back + sync each) --------------
-    for _ in range(W):
-        G.resAndGS(0, start, 0.02, 2.0, 20.0)
+    # ---- timed region: K optimize-loop bodies (+ the one initial linearizeAll/applyRes of the optimize call) ----
+    G.optimize(Wm, want_trace=False, fixed_its=True)
+    G.load(W)
     barrier_sync(world)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    e0.record(ext)
-    for _ in range(K):
-        G.resAndGS(0, start, 0.02, 2.0, 20.0)
-    e1.record(ext)
+    G.optimize(K, want_trace=False, fixed_its=True)
     barrier_sync(world)
-    dt = time.perf_counter() - t0
-    dt = max_over_ranks(dt, world)
-    ms_per_step = 1e3 * dt / K
+    dt = max_over_ranks(time.perf_counter() - t0, world)
     value = world * K / dt
 
-    # ---- roofline of the dominant kernel (k_res_gs): batched launch, HIP events on the tracker's stream ---------
-    B = args.batch
-    poses = np.stack([oracle.se3_mul(oracle.se3_exp(syn.perturbation(1000 + i)), P.gt_pose) for i in range(B)])
-    affs = np.tile([0.02, 2.0], (B, 1))
-    for _ in range(3):
-        G.resAndGSBatch(0, poses, affs, 20.0)
+    # ---- dominant kernel: k_ef_linearize, HIP events on the library's stream -----------------------------------
+    for _ in range(5):
+        G.linearizeAll(want_energy=False)
     torch.cuda.synchronize()
-    reps = 20
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for a, b in evs:
-        a.record(ext)
-        G.resAndGSBatch(0, poses, affs, 20.0)
-        b.record(ext)
-    torch.cuda.synchronize()
-    ms = np.median([a.elapsed_time(b) for a, b in evs])
-    alg_bytes = B * P.ref[0]["u"].size * BYTES_PER_POINT
-    achieved = alg_bytes / (ms * 1e-3) / 1e9
-    roof = dict(bound="hbm", kernel="k_res_gs(+k_finalize)", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=achieved / HBM_PEAK_GBS, traffic=None,
-                note="batched launch: %d LM trials x 2000 pts x 64 B algorithmic = %.1f MB per launch, %.3f ms per launch "
-                     "(events bracket k_res_gs + k_finalize + the params upload)" % (B, alg_bytes / 1e6, ms))
-    batched_its = B / (ms * 1e-3)
+    ms_lin = event_ms(torch, ext, lambda: G.linearizeAll(want_energy=False), 50)
+    alg = W.nR * LINEARIZE_BYTES_PER_RES
+    achieved = alg / (ms_lin * 1e-3) / 1e9
+    roof = dict(bound="hbm", kernel="k_ef_linearize", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                traffic=None,
+                note="%d residuals x %d B algorithmic = %.1f MB per launch; %.4f ms per launch (HIP events around "
+                     "k_ef_linearize + the 1-block energy sum, on the library stream)" % (W.nR, LINEARIZE_BYTES_PER_RES, alg / 1e6, ms_lin))
+    ms_acc = event_ms(torch, ext, lambda: G.accumulate(), 50)
 
     out = {
-        "metric": "Gauss-Newton iters/sec (KITTI res, 2000 pts tracker LM trial)",
-        "value": value, "unit": "GN iters/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step,
+        "metric": "Gauss-Newton iters/sec (KITTI res, 8 KF x 2000 pts)",
+        "value": value, "unit": "GN iters/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": 1e3 * dt / K,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: synthetic 1241x376 4-level pyramid, 1 ref + 1 target frame, 2000 points, "
-                               "coarse tracker LM trial at level 0 (fused calcRes+calcGSSSE + read-back)",
-                   "parallelism": "replicas" if world > 1 else "single"},
+        "config": {"workload": "configs[2]: KITTI-00 calib 1241x376, 8-keyframe window, 2000 points/KF, 112000 residuals; "
+                               "one step = one FullSystem::optimize loop body (solveSystemF + step + linearizeAll + accept/reject)",
+                   "parallelism": "replicas x%d (one window per GPU)" % world if world > 1 else "single GPU"},
         "roofline": roof,
-        "batched_gn_iters_per_s": batched_its,
+        "kernel_ms": {"linearizeAll": ms_lin, "accumulate(point+top+sc+reduce)": ms_acc},
     }
+    if rank == 0 and not args.quick:
+        import oracle
+        out["tracker"] = tracker_extras(torch, local, args.batch, oracle, not args.no_cpu)
     if rank == 0 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline_tracker(P, syn)
+        out["cpu_baseline"] = cpu_baseline_backend(W)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -185,7 +185,8 @@ int sdvgn_ef_set_frame_states(sdvgn_ef* ef, const double* state10);
  * reject (loadSateBackup, re-linearise, lambda*100), break on a tiny step.  One loop body = one "Gauss-Newton
  * iteration" of BASELINE.json's metric.  trace rows: {iteration, lambda, accepted, E, E_L, E_M, canbreak, x[4+6nF]}.
  * Returns the number of iterations run (>= 0) or an error (< 0). */
-int sdvgn_ef_optimize(sdvgn_ef* ef, int mnumOptIts, double* trace, int trace_stride, int trace_cap);
+int sdvgn_ef_optimize(sdvgn_ef* ef, int mnumOptIts, int flags /* bit0: run exactly mnumOptIts bodies (bench) */,
+                      double* trace, int trace_stride, int trace_cap);
 /* state after optimize: CalibHessian::value_scaled, FrameHessian::state (nF x 10), PointHessian::idepth (nP) */
 int sdvgn_ef_get_state(sdvgn_ef* ef, double* value_scaled4, double* state10, float* idepth);
 

@@ -38,7 +38,7 @@ PROTOTYPES = [
     ("sdvgn_ef_accumulate", C.c_int, [vp]),
     ("sdvgn_ef_finish_solve", C.c_int, [vp, C.c_int, C.c_double, vp]),
     ("sdvgn_ef_set_host_range", C.c_int, [vp, C.c_int, C.c_int]),
-    ("sdvgn_ef_optimize", C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int]),
+    ("sdvgn_ef_optimize", C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
     ("sdvgn_ef_get_state", C.c_int, [vp, vp, vp, vp]),
 ]
 
@@ -182,10 +182,10 @@ class EnergyFunctional:
     def stream(self):
         return self.L.sdvgn_ef_stream(self.h_)
 
-    def optimize(self, its=6, cap=128, want_trace=True):
+    def optimize(self, its=6, cap=128, want_trace=True, fixed_its=False):
         stride = 7 + self.dim
         trace = np.zeros((cap, stride))
-        n = self._check(self.L.sdvgn_ef_optimize(self.h_, its, trace.ctypes.data_as(vp) if want_trace else None, stride, cap))
+        n = self._check(self.L.sdvgn_ef_optimize(self.h_, its, 1 if fixed_its else 0, trace.ctypes.data_as(vp) if want_trace else None, stride, cap))
         return trace[:n]
 
     def state(self):

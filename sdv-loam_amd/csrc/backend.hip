@@ -902,13 +902,14 @@ static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* 
     return SDVGN_OK;
 }
 
-int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, double* trace, int trace_stride, int trace_cap) {
+int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int trace_stride, int trace_cap) {
     if (!e || !e->haveAdjoints || e->nP < 1) return SDVGN_E_STATE;
     HIPCHK(hipSetDevice(e->device));
     const int nF = e->nF, n = CPARS + 6 * nF;
     if (nF < 2) return 0;
-    if (nF < 3) mnumOptIts = 100;
-    if (nF < 4) mnumOptIts = 75;
+    const bool fixed_its = (flags & 1) != 0;   // benchmark mode: exactly mnumOptIts loop bodies, no early break
+    if (!fixed_its && nF < 3) mnumOptIts = 100;
+    if (!fixed_its && nF < 4) mnumOptIts = 75;
     const size_t slots = (size_t)nF * e->nP;
     int rc;
     if (!e->havePrecalc && (rc = ef_upload_precalc(e))) return rc;
@@ -968,7 +969,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, double* trace, int trace_stri
             lastEnergyM = calc_M_energy(e);
             lambda *= 1e2;
         }
-        if (canbreak && iteration >= 1) break;
+        if (!fixed_its && canbreak && iteration >= 1) break;
     }
     return it;
 }
