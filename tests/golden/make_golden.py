@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the CPU oracle (NOT from the reference, which cannot be built here -- see
+oracle/README.md: parity unpinned).  The vectors pin the oracle against accidental change and give the GPU tests a
+fixture that does not depend on scipy's image synthesis.  Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle  # noqa: E402
+from oracle.backend import OracleEF  # noqa: E402
+from sdv_loam_amd import synthetic as syn  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def tracker_golden():
+    calib = dict(fx=140.0, fy=145.0, cx=79.3, cy=59.6)
+    P = syn.make_tracker_problem(w=160, h=120, levels=3, n_points=150, seed=21, calib=calib,
+                                 gt_xi=[0.03, -0.02, 0.04, 0.004, -0.003, 0.002], gt_aff=(0.03, 1.5))
+    rng = np.random.default_rng(5)
+    for r in P.ref:
+        r["color"] = (r["color"] + rng.normal(0, 1.5, r["color"].shape)).astype(np.float32)
+    T = oracle.OracleTracker(P.w, P.h, P.levels)
+    T.makeK(**calib)
+    for l in range(P.levels):
+        T.set_ref(l, **P.ref[l])
+    T.set_ref_frame(1.0, 0.01, 0.5)
+    T.set_new_image(P.image, 1.0)
+    start = oracle.se3_mul(oracle.se3_exp(syn.perturbation(21, 0.02, 0.003)), P.gt_pose)
+    out = dict(image=P.image, calib=np.array([calib[k] for k in ("fx", "fy", "cx", "cy")]), start=start,
+               ref_aff=np.array([0.01, 0.5]))
+    for l in range(P.levels):
+        for k in ("u", "v", "idepth", "color"):
+            out["ref%d_%s" % (l, k)] = P.ref[l][k]
+        out["res%d" % l] = T.calcRes(l, start, 0.02, 1.0, 20.0)
+        out["warped%d" % l] = T.warped()
+        H, b = T.calcGS(l, 0.02, 1.0)
+        out["H%d" % l] = H
+        out["b%d" % l] = b
+        out["pyr%d" % l] = T.get_pyr(l)
+    ok, pose, aff, last_res, flow, trace = T.trackNewestCoarse(start, (0.0, 0.0), P.levels - 1)
+    out.update(track_ok=np.array(ok), track_pose=pose, track_aff=aff, track_lastres=last_res, track_flow=flow, track_trace=trace)
+    np.savez_compressed(os.path.join(HERE, "tracker_small.npz"), **out)
+
+
+def backend_golden():
+    W = syn.make_window(w=200, h=96, nF=3, pts_per_kf=60, seed=4, calib=dict(fx=150., fy=152., cx=99.5, cy=47.5))
+    E = OracleEF(W.w, W.h).load(W)
+    energy = E.linearizeAll()
+    st = E.residual_state()
+    Jnew = E.residual_J(0)
+    E.applyRes()
+    E.solveSystemF(0, 0.1)
+    s = E.system()
+    pts = E.points()
+    E2 = OracleEF(W.w, W.h).load(W)
+    tr = E2.optimize(6)
+    vs, state, idp = E2.state()
+    keys = ["w", "h", "nF", "nP", "nR", "evalPT", "state", "state_zero", "frameID", "ab_exposure", "frameEnergyTH", "value_scaled",
+            "value_minus_value_zero", "host", "u", "v", "idepth", "idepth_zero", "color", "weights", "hasDepthPrior", "isFromSensor",
+            "r_point", "r_target", "r_matcher", "r_state", "r_hasMatcher", "r_isLinearized", "r_isActive", "HM", "bM"]
+    out = {k: np.asarray(getattr(W, k)) for k in keys}
+    out["images"] = np.stack(W.images)
+    out.update(energy=np.array(energy), new_state=st["new_state"], new_energy=st["new_energy"], Jnew=Jnew, HFinal=s["HFinal"],
+               bFinal=s["bFinal"], x=s["x"], HA=s["HA"], bA=s["bA"], Hsc=s["Hsc"], bsc=s["bsc"], points=pts, opt_trace=tr,
+               opt_value_scaled=vs, opt_state=state, opt_idepth=idp)
+    np.savez_compressed(os.path.join(HERE, "backend_small.npz"), **out)
+
+
+if __name__ == "__main__":
+    tracker_golden()
+    backend_golden()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

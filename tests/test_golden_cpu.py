@@ -1,0 +1,38 @@
+"""The oracle reproduces the committed golden vectors (regression pin; CPU only)."""
+import numpy as np
+
+from golden_util import load_tracker, load_window, setup_tracker
+
+
+def test_tracker_oracle_matches_golden(orc):
+    g = load_tracker()
+    T = setup_tracker(orc.OracleTracker(160, 120, 3), g)
+    for l in range(3):
+        assert np.array_equal(T.get_pyr(l)[1:-1], g["pyr%d" % l][1:-1])
+        r = T.calcRes(l, g["start"], 0.02, 1.0, 20.0)
+        assert np.allclose(r, g["res%d" % l], rtol=1e-12, equal_nan=True)
+        assert np.array_equal(T.warped(), g["warped%d" % l])
+        H, b = T.calcGS(l, 0.02, 1.0)
+        assert np.allclose(H, g["H%d" % l], rtol=1e-12) and np.allclose(b, g["b%d" % l], rtol=1e-12)
+    ok, pose, aff, last_res, flow, trace = T.trackNewestCoarse(g["start"], (0.0, 0.0), 2)
+    assert ok == bool(g["track_ok"])
+    assert np.allclose(pose, g["track_pose"], rtol=1e-10, atol=1e-12) and np.allclose(aff, g["track_aff"], rtol=1e-10)
+    assert np.allclose(trace, g["track_trace"], rtol=1e-9, atol=1e-12)
+
+
+def test_backend_oracle_matches_golden(orc):
+    from oracle.backend import OracleEF
+    W, g = load_window()
+    E = OracleEF(W.w, W.h).load(W)
+    assert np.isclose(E.linearizeAll(), float(g["energy"]), rtol=1e-12)
+    st = E.residual_state()
+    assert np.array_equal(st["new_state"], g["new_state"]) and np.array_equal(st["new_energy"], g["new_energy"])
+    assert np.array_equal(E.residual_J(0), g["Jnew"])
+    E.applyRes()
+    E.solveSystemF(0, 0.1)
+    s = E.system()
+    for k in ("HA", "bA", "Hsc", "bsc", "HFinal", "bFinal", "x"):
+        assert np.allclose(s[k], g[k], rtol=1e-10, atol=1e-300), k
+    assert np.array_equal(E.points(), g["points"])
+    E2 = OracleEF(W.w, W.h).load(W)
+    assert np.allclose(E2.optimize(6), g["opt_trace"], rtol=1e-9, atol=1e-12)

@@ -1,0 +1,50 @@
+"""HIP path vs the committed golden vectors (same tolerances as against the live oracle)."""
+import numpy as np
+import pytest
+
+from common import rel_err
+from golden_util import load_tracker, load_window, setup_tracker
+
+pytestmark = pytest.mark.gpu
+
+
+def test_tracker_gpu_matches_golden(sdvgn_lib):
+    from sdv_loam_amd import api
+    g = load_tracker()
+    T = setup_tracker(api.CoarseTracker(160, 120, 3, max_points=1024, max_batch=4), g)
+    for l in range(3):
+        assert np.array_equal(T.get_pyr(l)[1:-1], g["pyr%d" % l][1:-1])
+        r = T.calcRes(l, g["start"], 0.02, 1.0, 20.0)
+        Wg, _ = T.warped(l)
+        assert np.array_equal(Wg, g["warped%d" % l])
+        assert r[1] == g["res%d" % l][1] and rel_err(r[0], g["res%d" % l][0]) < 1e-5
+        H, b = T.calcGS(l, g["start"], 0.02, 1.0, 20.0)
+        assert rel_err(H, g["H%d" % l]) < 1e-5 and rel_err(b, g["b%d" % l]) < 1e-5
+    ok, pose, aff, last_res, flow, trace = T.trackNewestCoarse(g["start"], (0.0, 0.0), 2)
+    assert ok == bool(g["track_ok"])
+    assert rel_err(pose, g["track_pose"]) < 1e-5 and np.allclose(aff, g["track_aff"], rtol=1e-4, atol=1e-5)
+    assert len(trace) == len(g["track_trace"]) and np.array_equal(trace[:, 3], g["track_trace"][:, 3])
+    okb, pb, ab, _, _ = T.trackBatch(np.stack([g["start"]] * 2), np.zeros((2, 2)), 2)
+    assert bool(okb[0]) == bool(g["track_ok"]) and rel_err(pb[0], g["track_pose"]) < 1e-5
+
+
+def test_backend_gpu_matches_golden(sdvgn_lib):
+    from sdv_loam_amd import backend_api
+    W, g = load_window()
+    E = backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+    assert rel_err(E.linearizeAll(), float(g["energy"])) < 1e-6
+    st = E.residual_state()
+    assert np.array_equal(st["new_state"], g["new_state"]) and np.array_equal(st["new_energy"], g["new_energy"].astype(np.float32))
+    touched = g["new_state"] != 1
+    assert np.array_equal(E.residual_J(0)[touched], g["Jnew"][touched])
+    E.applyRes()
+    x = E.solveSystemF(0, 0.1)
+    s = E.system()
+    for k in ("HA", "bA", "Hsc", "HFinal"):
+        assert rel_err(s[k], g[k]) < 1e-5, k
+    assert rel_err(x, g["x"]) < 1e-4
+    E2 = backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+    tr = E2.optimize(6)
+    assert len(tr) == len(g["opt_trace"]) and np.array_equal(tr[:, 2], g["opt_trace"][:, 2])
+    vs, state, idp = E2.state()
+    assert rel_err(idp, g["opt_idepth"]) < 1e-6 and rel_err(state, g["opt_state"]) < 1e-4
