@@ -189,16 +189,28 @@ def main():
     K, Wm = args.steps, args.warmup
     W, G = backend_setup(local)
     ext = torch.cuda.ExternalStream(G.stream(), device=torch.device("cuda", local))
+    parallelism, scaling = "single GPU", "strong"
+    runner = G
+    if world > 1:
+        # configs[3]: the SAME window, key-frames sharded by host frame across the ranks, one RCCL all-reduce of the packed
+        # accumulators per GN iteration (strong scaling: total work fixed).  Falls back to replicas if the collective path fails.
+        try:
+            from sdv_loam_amd.parallel import ShardedEnergyFunctional, shard_hosts
+            runner = ShardedEnergyFunctional(W, rank, world, local)
+            parallelism = "host-keyframe shards %s + 1 all-reduce(295 kB fp64)/iteration over RCCL" % (shard_hosts(W.nF, world),)
+        except Exception as ex:  # noqa: BLE001
+            runner = G
+            parallelism, scaling = "replicas x%d (sharded path unavailable: %r)" % (world, ex), "weak"
 
     # ---- timed region: K optimize-loop bodies (+ the one initial linearizeAll/applyRes of the optimize call) ----
-    G.optimize(Wm, want_trace=False, fixed_its=True)
-    G.load(W)
+    runner.optimize(Wm, want_trace=False, fixed_its=True)
+    (runner.reload if hasattr(runner, "reload") else runner.load)(W)
     barrier_sync(world)
     t0 = time.perf_counter()
-    G.optimize(K, want_trace=False, fixed_its=True)
+    runner.optimize(K, want_trace=False, fixed_its=True)
     barrier_sync(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)
-    value = world * K / dt
+    value = (world if scaling == "weak" else 1) * K / dt
 
     # ---- dominant kernel: k_ef_linearize, HIP events on the library's stream -----------------------------------
     for _ in range(5):
@@ -216,10 +228,10 @@ def main():
     out = {
         "metric": "Gauss-Newton iters/sec (KITTI res, 8 KF x 2000 pts)",
         "value": value, "unit": "GN iters/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": 1e3 * dt / K,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[2]: KITTI-00 calib 1241x376, 8-keyframe window, 2000 points/KF, 112000 residuals; "
                                "one step = one FullSystem::optimize loop body (solveSystemF + step + linearizeAll + accept/reject)",
-                   "parallelism": "replicas x%d (one window per GPU)" % world if world > 1 else "single GPU"},
+                   "parallelism": parallelism},
         "roofline": roof,
         "kernel_ms": {"linearizeAll": ms_lin, "accumulate(point+top+sc+reduce)": ms_acc},
     }

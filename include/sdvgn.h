@@ -199,12 +199,22 @@ int sdvgn_ef_get_residual_state(sdvgn_ef* ef, int* state_state, int* state_new, 
 int sdvgn_ef_get_points(sdvgn_ef* ef, float* out9 /*[nP][Hdd_accAF,bd_accAF,Hcd_accAF x4,HdiF,bdSumF,step]*/);
 int sdvgn_ef_get_top_acc(sdvgn_ef* ef, double* out /*[nF*nF][11*11], index h + nF*t*/, int* resInA);
 /* device pointer + element count of the packed accumulator buffer that cfg4 all-reduces across ranks (doubles):
- * top Gram [nF*nF][256] followed by SC Gram [nF][10][256] followed by {energy, resInA}. */
+ * top Gram [nF*nF][256] followed by SC Gram [nF][10][256] followed by resInA. */
 int sdvgn_ef_accumulators_dev(sdvgn_ef* ef, double** buf_dev, int* count);
 /* solve_system split for multi-GPU: accumulate only (fills the packed buffer), then finish (stitch, solve, resubstitute)
  * after the caller has all-reduced the buffer. */
 int sdvgn_ef_accumulate(sdvgn_ef* ef);
 int sdvgn_ef_finish_solve(sdvgn_ef* ef, int iteration, double lambda, double* x_out);
+/* host part of solveSystemF on a caller-supplied (e.g. all-reduced) accumulator buffer in host memory; works on a
+ * host-only handle (sdvgn_ef_create with device = -1: no kernels, only frames/adjoints/priors and this function). */
+int sdvgn_ef_stitch_solve_host(sdvgn_ef* ef, const double* acc_host, int iteration, double lambda, double* x_out);
+int sdvgn_ef_accumulator_count(sdvgn_ef* ef);
+/* cfg4 plumbing: let the caller own the two reducible device buffers (e.g. torch tensors), and register the
+ * collective: fn(user, buf_dev, count) must sum buf_dev[0..count) over all ranks in stream order (RCCL all-reduce).
+ * With a callback registered, sdvgn_ef_solve_system / sdvgn_ef_optimize all-reduce the packed accumulators (once per
+ * GN iteration) and the 4 energy/step statistics (once per linearizeAll). */
+int sdvgn_ef_set_external_buffers(sdvgn_ef* ef, double* acc_dev, int acc_capacity, double* stats4_dev);
+int sdvgn_ef_set_allreduce(sdvgn_ef* ef, void (*fn)(void* user, double* buf_dev, int count), void* user);
 /* restrict this rank's work to host frames [h0,h1) (cfg4: frames sharded across GPUs); default all. */
 int sdvgn_ef_set_host_range(sdvgn_ef* ef, int h0, int h1);
 

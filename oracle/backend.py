@@ -44,6 +44,7 @@ def _L():
         L.orc_ef_get_adjoints.argtypes = [vp, f64p, f64p]
         L.orc_ef_res_in_A.argtypes = [vp]
         L.orc_ef_res_in_A.restype = C.c_int
+        L.orc_ef_get_sc_acc.argtypes = [vp, f32p, f32p, f32p, f32p, f32p]
         L.orc_ef_optimize.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
         L.orc_ef_optimize.restype = C.c_int
         L.orc_ef_calc_L_energy.argtypes = [vp]
@@ -188,3 +189,13 @@ class OracleEF:
         idp = np.zeros(self.nP, np.float32)
         self.L.orc_ef_get_state(self.h_, vs, st, idp)
         return vs, st.reshape(self.nF, 10), idp
+
+    def sc_acc(self):
+        nF = self.nF
+        accE = np.zeros((nF * nF, 8, 4), np.float32)
+        accEB = np.zeros((nF * nF, 8), np.float32)
+        accD = np.zeros((nF ** 3, 8, 8), np.float32)
+        Hcc = np.zeros((4, 4), np.float32)
+        bc = np.zeros(4, np.float32)
+        self.L.orc_ef_get_sc_acc(self.h_, accE.reshape(-1), accEB.reshape(-1), accD.reshape(-1), Hcc.reshape(-1), bc)
+        return accE, accEB, accD, Hcc, bc

@@ -212,6 +212,7 @@ struct EF {
     std::vector<double> HA, bA, Hsc, bsc, HFinal, bFinal, lastX;
     std::vector<AccumulatorApprox> accA, accL;
     int resInA, resInL;
+    std::vector<float> scE, scEB, scD, scHcc, scbc;   // finished SC accumulators of the last solve
     double calibStep[4];
 };
 
@@ -763,6 +764,12 @@ static void solve_system(EF* E, int iteration, double lambda) {
     S.setZero(nF);
     for (Point& p : E->points) add_point_sc(E, S, p, true);
     stitch_sc(E, S, E->Hsc, E->bsc);
+    {
+        E->scE.assign((size_t)nF * nF * 32, 0); E->scEB.assign((size_t)nF * nF * 8, 0); E->scD.assign((size_t)nF * nF * nF * 64, 0);
+        for (int k = 0; k < nF * nF; ++k) { std::memcpy(&E->scE[(size_t)k * 32], S.accE[k].A1m, 32 * 4); std::memcpy(&E->scEB[(size_t)k * 8], S.accEB[k].A1m, 8 * 4); }
+        for (int k = 0; k < nF * nF * nF; ++k) std::memcpy(&E->scD[(size_t)k * 64], S.accD[k].A1m, 64 * 4);
+        E->scHcc.assign(S.accHcc.A1m, S.accHcc.A1m + 16); E->scbc.assign(S.accbc.A1m, S.accbc.A1m + 4);
+    }
     // bM_top = bM + HM * delta
     std::vector<double> d(n), bM_top(n);
     for (int i = 0; i < CPARS; ++i) d[i] = (double)E->cDeltaF[i];
@@ -1115,6 +1122,12 @@ void orc_ef_get_adjoints(void* e, double* adHost, double* adTarget) {
     std::memcpy(adTarget, E->adTarget.data(), sizeof(double) * E->adTarget.size());
 }
 int orc_ef_res_in_A(void* e) { return ((EF*)e)->resInA; }
+// SC accumulators after the last solve: accE [nF*nF][8][4], accEB [nF*nF][8], accD [nF^3][8][8], accHcc [4][4], accbc [4]
+void orc_ef_get_sc_acc(void* e, float* accE, float* accEB, float* accD, float* Hcc, float* bc) {
+    EF* E = (EF*)e;
+    std::memcpy(accE, E->scE.data(), 4 * E->scE.size()); std::memcpy(accEB, E->scEB.data(), 4 * E->scEB.size());
+    std::memcpy(accD, E->scD.data(), 4 * E->scD.size()); std::memcpy(Hcc, E->scHcc.data(), 64); std::memcpy(bc, E->scbc.data(), 16);
+}
 int orc_ef_optimize(void* e, int its, double* trace, int stride, int cap) { return optimize((EF*)e, its, trace, stride, cap); }
 double orc_ef_calc_L_energy(void* e) { return calc_L_energy((EF*)e); }
 double orc_ef_calc_M_energy(void* e) { return calc_M_energy((EF*)e); }

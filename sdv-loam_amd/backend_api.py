@@ -38,6 +38,10 @@ PROTOTYPES = [
     ("sdvgn_ef_accumulate", C.c_int, [vp]),
     ("sdvgn_ef_finish_solve", C.c_int, [vp, C.c_int, C.c_double, vp]),
     ("sdvgn_ef_set_host_range", C.c_int, [vp, C.c_int, C.c_int]),
+    ("sdvgn_ef_stitch_solve_host", C.c_int, [vp, f64p, C.c_int, C.c_double, vp]),
+    ("sdvgn_ef_accumulator_count", C.c_int, [vp]),
+    ("sdvgn_ef_set_external_buffers", C.c_int, [vp, vp, C.c_int, vp]),
+    ("sdvgn_ef_set_allreduce", C.c_int, [vp, vp, vp]),
     ("sdvgn_ef_optimize", C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
     ("sdvgn_ef_get_state", C.c_int, [vp, vp, vp, vp]),
 ]

@@ -24,6 +24,12 @@
         if (_e != hipSuccess) return -(int)_e;        \
     } while (0)
 
+#define EF_DEVICE(e)                                         \
+    do {                                                     \
+        if ((e)->host_only) return SDVGN_E_STATE;            \
+        HIPCHK(hipSetDevice((e)->device));                   \
+    } while (0)
+
 using namespace sdvgn;
 
 namespace {
@@ -86,17 +92,21 @@ struct sdvgn_ef {
     double* energy_partial = nullptr;
     float *top_partial = nullptr, *sc_partial = nullptr;
     int* nres_partial = nullptr;
-    double* acc_dev = nullptr;    // packed: top [nF*nF][256] | sc [nF][2560] | energy | resInA
+    double* acc_dev = nullptr;    // packed: top [nF*nF][256] | sc [nF][2560] | resInA
     double* acc_host = nullptr;   // pinned mirror
     float *xc_dev = nullptr, *xAd_dev = nullptr;
     float* x_host = nullptr;      // pinned: xc(4) + xAd(nF*nF*6)
-    double* stats_dev = nullptr;   // {L-energy point part, sum step^2, sum |idepth_backup|}
+    double* stats_dev = nullptr;   // {linearize energy, L-energy point part, sum step^2, sum |idepth_backup|}
+    bool own_acc = true, own_stats = true;
+    void (*allreduce)(void*, double*, int) = nullptr;   // cfg4: sum a device buffer over the ranks (RCCL), in stream order
+    void* allreduce_user = nullptr;
+    bool host_only = false;
     double* stats_partial = nullptr;
     size_t slots_cap = 0;
     bool havePrecalc = false, haveAdjoints = false;
 };
 
-static size_t acc_count(const sdvgn_ef* e) { return (size_t)e->nF * e->nF * kTopE + (size_t)e->nF * kScE + 2; }
+static size_t acc_count(const sdvgn_ef* e) { return (size_t)e->nF * e->nF * kTopE + (size_t)e->nF * kScE + 1; }
 
 static void frame_set_state(FrameH& f, const double* state) {  // FrameHessian::setState, HessianBlocks.h:131-143
     for (int i = 0; i < 10; ++i) f.state[i] = state[i];
@@ -384,8 +394,10 @@ static int ef_upload_precalc(sdvgn_ef* e) {
         }
     for (FrameH& f : e->frames)
         for (int i = 0; i < 6; ++i) { f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i]; }
-    HIPCHK(hipMemcpyAsync(e->precalc_dev, e->precalc_host, sizeof(PrecalcDev) * nF * nF, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    if (!e->host_only) {
+        HIPCHK(hipMemcpyAsync(e->precalc_dev, e->precalc_host, sizeof(PrecalcDev) * nF * nF, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
     e->havePrecalc = true;
     return 0;
 }
@@ -493,6 +505,16 @@ extern "C" {
 
 int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, void* stream) {
     if (!out || w < 16 || h < 16 || max_points < 1) return SDVGN_E_ARG;
+    if (device < 0) {
+        // host-only handle: frames / adjoints / priors / sdvgn_ef_stitch_solve_host work, nothing that launches a kernel does.
+        // Used by the rank that only combines all-reduced accumulators and by the CPU (gloo) tests of the multi-GPU host logic.
+        sdvgn_ef* e = new (std::nothrow) sdvgn_ef();
+        if (!e) return SDVGN_E_ARG;
+        e->device = -1; e->w = w; e->h = h; e->max_points = max_points; e->host_only = true;
+        e->precalc_host = (PrecalcDev*)calloc(SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES, sizeof(PrecalcDev));
+        *out = e;
+        return SDVGN_OK;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) return SDVGN_E_NODEVICE;
     HIPCHK(hipSetDevice(device));
@@ -518,7 +540,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->top_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * kTopE);
     bad |= dev_alloc(&e->sc_partial, (size_t)SDVGN_MAX_FRAMES * kMaxChunks * kScE);
     bad |= dev_alloc(&e->nres_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks);
-    const size_t accmax = (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kTopE + (size_t)SDVGN_MAX_FRAMES * kScE + 2;
+    const size_t accmax = (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kTopE + (size_t)SDVGN_MAX_FRAMES * kScE + 1;
     bad |= dev_alloc(&e->acc_dev, accmax);
     bad |= dev_alloc(&e->xc_dev, 4) | dev_alloc(&e->xAd_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6);
     bad |= dev_alloc(&e->stats_dev, 4) | dev_alloc(&e->stats_partial, 3 * (mp / 256 + 2));
@@ -535,6 +557,9 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
 
 void sdvgn_ef_destroy(sdvgn_ef* e) {
     if (!e) return;
+    if (e->host_only) { free(e->precalc_host); delete e; return; }
+    if (!e->own_acc) e->acc_dev = nullptr;
+    if (!e->own_stats) e->stats_dev = nullptr;
     hipSetDevice(e->device);
     hipStreamSynchronize(e->stream);
     void* ptrs[] = {e->pu, e->pv, e->pidz, e->pid, e->pidepth_backup, e->ppriorF, e->pdeltaF, e->pcolor, e->pweights, e->psensor, e->rflags,
@@ -604,7 +629,7 @@ int sdvgn_ef_set_host_range(sdvgn_ef* e, int h0, int h1) {
 
 int sdvgn_ef_set_frame_image(sdvgn_ef* e, int idx, const float* dI) {
     if (!e || !dI || idx < 0 || idx >= SDVGN_MAX_FRAMES) return SDVGN_E_ARG;
-    HIPCHK(hipSetDevice(e->device));
+    EF_DEVICE(e);
     const size_t n = (size_t)e->w * e->h * 3;
     HIPCHK(hipMemcpyAsync(e->images + n * idx, dI, sizeof(float) * n, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -613,7 +638,7 @@ int sdvgn_ef_set_frame_image(sdvgn_ef* e, int idx, const float* dI) {
 
 int sdvgn_ef_set_frame_image_raw(sdvgn_ef* e, int idx, const float* image) {
     if (!e || !image || idx < 0 || idx >= SDVGN_MAX_FRAMES) return SDVGN_E_ARG;
-    HIPCHK(hipSetDevice(e->device));
+    EF_DEVICE(e);
     const size_t n = (size_t)e->w * e->h;
     HIPCHK(hipMemcpyAsync(e->img_stage, image, sizeof(float) * n, hipMemcpyHostToDevice, e->stream));
     const int qw = (e->w + 1) >> 1, qh = (e->h + 1) >> 1;
@@ -627,7 +652,7 @@ int sdvgn_ef_set_points(sdvgn_ef* e, int nP, const int* host, const float* u, co
                         const float* color8, const float* weights8, const unsigned char* hasDepthPrior, const unsigned char* isFromSensor) {
     if (!e || nP < 0 || nP > e->max_points || e->nF < 1) return SDVGN_E_ARG;
     if (nP > 0 && (!host || !u || !v || !idepth || !idepth_zero || !color8 || !weights8 || !hasDepthPrior || !isFromSensor)) return SDVGN_E_ARG;
-    HIPCHK(hipSetDevice(e->device));
+    EF_DEVICE(e);
     e->phost.assign(host, host + nP);
     e->hostP0.assign(e->nF + 1, 0);
     for (int i = 0; i < nP; ++i) {
@@ -667,7 +692,7 @@ int sdvgn_ef_set_residuals(sdvgn_ef* e, int nR, const int* point, const int* tar
                            const double* matcher, const unsigned char* isLinearized, const unsigned char* isActive) {
     if (!e || nR < 0 || e->nP < 1) return SDVGN_E_ARG;
     if (nR > 0 && (!point || !target || !state_state || !hasMatcher || !matcher || !isLinearized || !isActive)) return SDVGN_E_ARG;
-    HIPCHK(hipSetDevice(e->device));
+    EF_DEVICE(e);
     const size_t slots = (size_t)e->nF * e->nP;
     std::vector<uint8_t> flags(slots, 0);
     std::vector<int8_t> st(slots, 0);
@@ -741,17 +766,17 @@ int sdvgn_ef_set_adjoints(sdvgn_ef* e) {  // EnergyFunctional::setAdjointsF
 
 int sdvgn_ef_set_precalc(sdvgn_ef* e) {
     if (!e || e->nF < 1 || !e->haveAdjoints) return SDVGN_E_STATE;
-    HIPCHK(hipSetDevice(e->device));
+    if (!e->host_only) HIPCHK(hipSetDevice(e->device));
     return ef_upload_precalc(e);
 }
 
 int sdvgn_ef_linearize_all(sdvgn_ef* e, double* energy_out) {
-    if (!e || !e->havePrecalc || e->nR < 0) return SDVGN_E_STATE;
-    HIPCHK(hipSetDevice(e->device));
+    if (!e || e->host_only || !e->havePrecalc || e->nR < 0) return SDVGN_E_STATE;
+    EF_DEVICE(e);
     const int chunks = chunks_for_np(e);
     const int pairs = e->nF * e->nF;
     k_ef_linearize<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
-    double* edst = e->acc_dev + acc_count(e) - 2;
+    double* edst = e->stats_dev;
     k_ef_sum_energy<<<1, 256, 0, e->stream>>>(e->energy_partial, chunks * pairs, edst);
     HIPCHK(hipGetLastError());
     if (energy_out) {
@@ -764,7 +789,7 @@ int sdvgn_ef_linearize_all(sdvgn_ef* e, double* energy_out) {
 
 int sdvgn_ef_apply_res(sdvgn_ef* e) {
     if (!e || e->nP < 1) return SDVGN_E_STATE;
-    HIPCHK(hipSetDevice(e->device));
+    EF_DEVICE(e);
     const size_t slots = (size_t)e->nF * e->nP;
     k_ef_apply<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->nF, e->nP, e->A, e->precalc_dev, e->phost_dev);
     HIPCHK(hipGetLastError());
@@ -772,8 +797,8 @@ int sdvgn_ef_apply_res(sdvgn_ef* e) {
 }
 
 int sdvgn_ef_accumulate(sdvgn_ef* e) {
-    if (!e || !e->havePrecalc) return SDVGN_E_STATE;
-    HIPCHK(hipSetDevice(e->device));
+    if (!e || e->host_only || !e->havePrecalc) return SDVGN_E_STATE;
+    EF_DEVICE(e);
     const int nF = e->nF, pairs = nF * nF, chunks = chunks_for_np(e);
     k_ef_point<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev);
     k_ef_top_gram<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->top_partial, e->nres_partial);
@@ -787,21 +812,40 @@ int sdvgn_ef_accumulate(sdvgn_ef* e) {
     return SDVGN_OK;
 }
 
+int sdvgn_ef_set_external_buffers(sdvgn_ef* e, double* acc_dev, int acc_capacity, double* stats_dev) {
+    if (!e || e->host_only || !acc_dev || !stats_dev) return SDVGN_E_ARG;
+    const size_t accmax = (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kTopE + (size_t)SDVGN_MAX_FRAMES * kScE + 1;
+    if ((size_t)acc_capacity < accmax) return SDVGN_E_ARG;
+    EF_DEVICE(e);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->own_acc) hipFree(e->acc_dev);
+    if (e->own_stats) hipFree(e->stats_dev);
+    e->acc_dev = acc_dev; e->stats_dev = stats_dev;
+    e->own_acc = e->own_stats = false;
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_set_allreduce(sdvgn_ef* e, void (*fn)(void*, double*, int), void* user) {
+    if (!e) return SDVGN_E_ARG;
+    e->allreduce = fn; e->allreduce_user = user;
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_accumulator_count(sdvgn_ef* e) { return e ? (int)acc_count(e) : SDVGN_E_ARG; }
+
 int sdvgn_ef_accumulators_dev(sdvgn_ef* e, double** buf, int* count) {
     if (!e || !buf || !count) return SDVGN_E_ARG;
     *buf = e->acc_dev; *count = (int)acc_count(e);
     return SDVGN_OK;
 }
 
-int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_out) {
-    if (!e || !e->havePrecalc) return SDVGN_E_STATE;
-    HIPCHK(hipSetDevice(e->device));
+// host part of solveSystemF on an accumulator buffer (own or all-reduced): stitch, HM/bM, damped preconditioned LDLT,
+// null-space projection.  Pure host code -- also the entry point of the CPU (gloo) test of the multi-GPU logic.
+static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, double lambda, double* x_out) {
     const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
-    HIPCHK(hipMemcpyAsync(e->acc_host, e->acc_dev, sizeof(double) * acc_count(e), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    e->resInA = (int)e->acc_host[acc_count(e) - 1];
-    stitch_top(e, e->acc_host);
-    stitch_sc(e, e->acc_host + (size_t)pairs * kTopE);
+    e->resInA = (int)acc[acc_count(e) - 1];
+    stitch_top(e, acc);
+    stitch_sc(e, acc + (size_t)pairs * kTopE);
     // bM_top = bM + HM * delta ; HFinal = HA + HM - Hsc ; bFinal = bA + bM_top - bsc   (EnergyFunctional.cpp:668-699)
     std::vector<double> d(n), bM_top(n);
     for (int i = 0; i < CPARS; ++i) d[i] = (double)e->C.cDeltaF[i];
@@ -824,6 +868,22 @@ int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
     for (int i = 0; i < n; ++i) e->lastX[i] = sv[i] * xs[i];
     if (iteration >= 2) orthogonalize_x(e, e->lastX);   // SOLVER_ORTHOGONALIZE_X_LATER
     if (x_out) std::memcpy(x_out, e->lastX.data(), sizeof(double) * n);
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, double lambda, double* x_out) {
+    if (!e || !acc || !e->haveAdjoints || !e->havePrecalc) return SDVGN_E_STATE;
+    return ef_stitch_solve_host(e, acc, iteration, lambda, x_out);
+}
+
+int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_out) {
+    if (!e || e->host_only || !e->havePrecalc) return SDVGN_E_STATE;
+    EF_DEVICE(e);
+    const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
+    HIPCHK(hipMemcpyAsync(e->acc_host, e->acc_dev, sizeof(double) * acc_count(e), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int rc = ef_stitch_solve_host(e, e->acc_host, iteration, lambda, x_out);
+    if (rc) return rc;
     // resubstituteF_MT (:221-247): xc, xAd[nF*h + t]
     float* xc = e->x_host;
     float* xAd = e->x_host + 4;
@@ -851,12 +911,13 @@ int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
 int sdvgn_ef_solve_system(sdvgn_ef* e, int iteration, double lambda, double* x_out) {
     int rc = sdvgn_ef_accumulate(e);
     if (rc) return rc;
+    if (e->allreduce) e->allreduce(e->allreduce_user, e->acc_dev, (int)acc_count(e));   // cfg4: one all-reduce per GN iteration
     return sdvgn_ef_finish_solve(e, iteration, lambda, x_out);
 }
 
 int sdvgn_ef_point_step(sdvgn_ef* e, int mode, float stepfacD) {
     if (!e || mode < 0 || mode > 2 || e->nP < 1) return SDVGN_E_ARG;
-    HIPCHK(hipSetDevice(e->device));
+    EF_DEVICE(e);
     k_ef_point_step<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->nP, mode, stepfacD, e->pid, e->pidz, e->pidepth_backup, e->pstep, e->pdeltaF);
     HIPCHK(hipGetLastError());
     return SDVGN_OK;
@@ -886,11 +947,10 @@ static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* 
     if (rc) return rc;
     const int nb = (e->nP + 255) / 256;
     k_ef_point_stats<<<nb, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial);
-    k_ef_sum3<<<1, 256, 0, e->stream>>>(e->stats_partial, nb, e->stats_dev);
+    k_ef_sum3<<<1, 256, 0, e->stream>>>(e->stats_partial, nb, e->stats_dev + 1);
     HIPCHK(hipGetLastError());
-    double* edst = e->acc_dev + acc_count(e) - 2;
-    HIPCHK(hipMemcpyAsync(e->acc_host, edst, sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(e->acc_host + 1, e->stats_dev, 3 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if (e->allreduce) e->allreduce(e->allreduce_user, e->stats_dev, 4);   // ranks hold disjoint host-frame shards
+    HIPCHK(hipMemcpyAsync(e->acc_host, e->stats_dev, 4 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     *energy = e->acc_host[0];
     double En = 0;   // calcLEnergyF_MT: frame + calib priors on the host, point part from the device
@@ -904,7 +964,7 @@ static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* 
 
 int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int trace_stride, int trace_cap) {
     if (!e || !e->haveAdjoints || e->nP < 1) return SDVGN_E_STATE;
-    HIPCHK(hipSetDevice(e->device));
+    EF_DEVICE(e);
     const int nF = e->nF, n = CPARS + 6 * nF;
     if (nF < 2) return 0;
     const bool fixed_its = (flags & 1) != 0;   // benchmark mode: exactly mnumOptIts loop bodies, no early break
@@ -976,7 +1036,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
 
 int sdvgn_ef_get_state(sdvgn_ef* e, double* value_scaled4, double* state10, float* idepth) {
     if (!e) return SDVGN_E_ARG;
-    HIPCHK(hipSetDevice(e->device));
+    EF_DEVICE(e);
     if (value_scaled4) for (int i = 0; i < 4; ++i) value_scaled4[i] = e->value_scaled[i];
     if (state10) for (int h = 0; h < e->nF; ++h) for (int i = 0; i < 10; ++i) state10[10 * h + i] = e->frames[h].state[i];
     if (idepth) {
@@ -1003,7 +1063,7 @@ int sdvgn_ef_get_system(sdvgn_ef* e, double* HA, double* bA, double* Hsc, double
 
 int sdvgn_ef_get_residual_J(sdvgn_ef* e, int which, float* out24) {
     if (!e || !out24 || e->nR < 1) return SDVGN_E_STATE;
-    HIPCHK(hipSetDevice(e->device));
+    EF_DEVICE(e);
     const size_t slots = (size_t)e->nF * e->nP;
     std::vector<float> J(2 * (size_t)kJPlanes * slots);
     std::vector<uint8_t> fl(slots);
@@ -1022,7 +1082,7 @@ int sdvgn_ef_get_residual_J(sdvgn_ef* e, int which, float* out24) {
 
 int sdvgn_ef_get_residual_state(sdvgn_ef* e, int* state_state, int* state_new, float* energy_new, float* energy_wo, unsigned char* isActive) {
     if (!e || e->nR < 1) return SDVGN_E_STATE;
-    HIPCHK(hipSetDevice(e->device));
+    EF_DEVICE(e);
     const size_t slots = (size_t)e->nF * e->nP;
     std::vector<int8_t> st(slots), sn(slots);
     std::vector<float> en(slots), ew(slots);
@@ -1046,7 +1106,7 @@ int sdvgn_ef_get_residual_state(sdvgn_ef* e, int* state_state, int* state_new, f
 
 int sdvgn_ef_get_points(sdvgn_ef* e, float* out9) {
     if (!e || !out9 || e->nP < 1) return SDVGN_E_STATE;
-    HIPCHK(hipSetDevice(e->device));
+    EF_DEVICE(e);
     const size_t nP = e->nP;
     std::vector<float> a(nP), b(nP), c(4 * nP), d(nP), f(nP), g(nP);
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1067,7 +1127,7 @@ int sdvgn_ef_get_points(sdvgn_ef* e, float* out9) {
 
 int sdvgn_ef_get_top_acc(sdvgn_ef* e, double* out, int* resInA) {
     if (!e || !out) return SDVGN_E_STATE;
-    HIPCHK(hipSetDevice(e->device));
+    EF_DEVICE(e);
     const int nF = e->nF;
     std::vector<double> g((size_t)nF * nF * kTopE);
     HIPCHK(hipStreamSynchronize(e->stream));

@@ -1,0 +1,113 @@
+"""Multi-GPU plumbing for the sliding-window back end (BASELINE.json configs[3]).
+
+One process per GPU.  Key-frames are sharded by HOST frame: rank r linearises / accumulates only the residuals whose
+host frame lies in its range (target images are replicated on every rank).  Per Gauss-Newton iteration the ranks sum
+one packed fp64 accumulator buffer (top Gram nF^2 x 256 | Schur Gram nF x 2560 | resInA -- 295 kB at nF = 8) with a
+single all-reduce (RCCL over xGMI through torch.distributed's "nccl" backend; latency-bound at this size), and 4
+doubles of energy / step statistics once per linearizeAll.  The small solve then runs redundantly on every rank on
+bitwise-identical inputs, so all ranks take the same accept / reject decisions without further communication.
+"""
+import ctypes as C
+
+import numpy as np
+
+TOP_E = 256          # one 16x16 tile per (host,target) pair
+SC_E = 10 * 256      # 10 upper 16x16 tiles of the 64x64 Gram per host frame
+MAX_FRAMES = 8
+
+
+def shard_hosts(nF, world):
+    """Contiguous host-frame ranges, as even as possible: rank r owns [lo[r], hi[r])."""
+    base, extra = divmod(nF, world)
+    out, lo = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((lo, lo + n))
+        lo += n
+    return out
+
+
+def acc_count(nF):
+    return nF * nF * TOP_E + nF * SC_E + 1
+
+
+def acc_capacity():
+    return acc_count(MAX_FRAMES)
+
+
+def pack_accumulators(nF, top13, accE, accEB, accD, Hcc, bc, res_in_A):
+    """Pack reference-layout accumulators (oracle getters) into the library's buffer layout -- used by the CPU tests.
+    top13: [nF*nF][13][13] indexed h + nF*t ; accE [nF*nF][8][4], accEB [nF*nF][8], accD [nF^3][8][8] indexed
+    (h + nF*t1) + nF^2*t2."""
+    buf = np.zeros(acc_count(nF))
+    top = buf[:nF * nF * TOP_E].reshape(nF, nF, 16, 16)                  # device pair index h*nF + t
+    idx = list(range(10)) + [12]
+    for h in range(nF):
+        for t in range(nF):
+            top[h, t, :11, :11] = top13[h + nF * t][np.ix_(idx, idx)]
+    sc = buf[nF * nF * TOP_E: nF * nF * TOP_E + nF * SC_E].reshape(nF, 10, 16, 16)
+    for h in range(nF):
+        G = np.zeros((64, 64))
+        for t1 in range(nF):
+            for t2 in range(nF):
+                G[6 * t1:6 * t1 + 6, 6 * t2:6 * t2 + 6] = accD[(h + nF * t1) + nF * nF * t2][:6, :6]
+            G[6 * t1:6 * t1 + 6, 48:52] = accE[h + nF * t1][:6, :]
+            G[6 * t1:6 * t1 + 6, 52] = accEB[h + nF * t1][:6]
+        G[48:52, 48:52] = 0      # Hcc / bc are per-window totals in the reference; they are attributed to host 0 below
+        a = 0
+        for ti in range(4):
+            for tj in range(ti, 4):
+                sc[h, a] = G[16 * ti:16 * ti + 16, 16 * tj:16 * tj + 16]
+                a += 1
+    # accHcc / accbc: window totals -> put them into host 0's Gram (the stitch only uses their sum over hosts)
+    sc[0, 9, 0:4, 0:4] += Hcc           # tile (3,3): features 48..51
+    sc[0, 9, 0:4, 4] += bc              # column 52
+    buf[-1] = res_in_A
+    return buf
+
+
+class ShardedEnergyFunctional:
+    """EnergyFunctional on this rank's GPU restricted to its host-frame shard, wired to torch.distributed.
+
+    All library work and the collectives are issued on one torch stream (`self.stream`), so the all-reduce is ordered
+    after the accumulate kernels and before the read-back of the packed buffer without host synchronisation."""
+
+    def __init__(self, W, rank, world, device, group=None, force_collective=False):
+        import torch
+        import torch.distributed as dist
+        from .backend_api import EnergyFunctional
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank, self.world = rank, world
+        torch.cuda.set_device(device)
+        self.stream = torch.cuda.Stream(device=device)
+        self.ef = EnergyFunctional(W.w, W.h, max_points=W.nP, device=device, stream=self.stream.cuda_stream)
+        with torch.cuda.stream(self.stream):
+            self.acc = torch.zeros(acc_capacity(), dtype=torch.float64, device="cuda")
+            self.stats = torch.zeros(4, dtype=torch.float64, device="cuda")
+        self.stream.synchronize()
+        L = self.ef.L
+        self.ef._check(L.sdvgn_ef_set_external_buffers(self.ef.h_, self.acc.data_ptr(), self.acc.numel(), self.stats.data_ptr()))
+        self.lo, self.hi = shard_hosts(W.nF, world)[rank]
+        self.ef.set_host_range(self.lo, self.hi)
+        self.ef.load(W)
+        self._cb = None
+        self.n_allreduce = 0
+        if world > 1 or force_collective:
+            acc_ptr, stats_ptr = self.acc.data_ptr(), self.stats.data_ptr()
+
+            def _allreduce(user, buf, count):
+                assert buf in (acc_ptr, stats_ptr)
+                t = self.acc[:count] if buf == acc_ptr else self.stats[:count]
+                with torch.cuda.stream(self.stream):
+                    dist.all_reduce(t, group=self.group)
+                self.n_allreduce += 1
+
+            self._cb = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)(_allreduce)
+            self.ef._check(L.sdvgn_ef_set_allreduce(self.ef.h_, C.cast(self._cb, C.c_void_p), None))
+
+    def reload(self, W):
+        self.ef.load(W)
+
+    def optimize(self, its, fixed_its=False, want_trace=False):
+        with self.torch.cuda.stream(self.stream):
+            return self.ef.optimize(its, want_trace=want_trace, fixed_its=fixed_its)

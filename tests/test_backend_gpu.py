@@ -164,3 +164,23 @@ def test_optimize_loop_parity(api, orc, seed):
     vo, so, io = O.state()
     assert np.allclose(vg, vo, rtol=1e-9) and rel_err(sg, so) < 1e-4
     assert rel_err(ig, io) < 1e-6
+
+
+def test_sharded_path_single_rank_nccl(api, orc, window):
+    """cfg4 plumbing on one GPU: external torch buffers, torch stream, and the all-reduce callback going through a
+    1-rank RCCL process group -- must give exactly the single-GPU result."""
+    import torch
+    import torch.distributed as dist
+    from sdv_loam_amd.parallel import ShardedEnergyFunctional
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29733", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        S = ShardedEnergyFunctional(window, 0, 1, 0, force_collective=True)
+        ts = S.optimize(6, want_trace=True)
+        assert S.n_allreduce >= 2 * len(ts)
+        G = api.EnergyFunctional(window.w, window.h, max_points=window.nP).load(window)
+        tg = G.optimize(6)
+        assert np.array_equal(ts, tg)
+        assert np.array_equal(S.ef.state()[2], G.state()[2])
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,92 @@
+"""Multi-GPU host logic on CPU (world_size 2, gloo): host-frame sharding, accumulator packing, one all-reduce of the
+packed buffer, then the product's own host-side stitch + solve (host-only sdvgn_ef handle) -- compared with the
+single-process oracle solve of the full window."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_hosts():
+    from sdv_loam_amd.parallel import shard_hosts
+    assert shard_hosts(8, 1) == [(0, 8)]
+    assert shard_hosts(8, 2) == [(0, 4), (4, 8)]
+    assert shard_hosts(8, 8) == [(i, i + 1) for i in range(8)]
+    assert shard_hosts(7, 4) == [(0, 2), (2, 4), (4, 6), (6, 7)]
+    for nF in range(1, 9):
+        for w in range(1, 9):
+            r = shard_hosts(nF, w)
+            assert r[0][0] == 0 and r[-1][1] == nF and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+    from oracle.backend import OracleEF
+    from sdv_loam_amd import api, parallel, synthetic as syn
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    W = syn.make_window(w=320, h=160, nF=4, pts_per_kf=120, seed=7, calib=dict(fx=200., fy=205., cx=159.5, cy=79.5))
+    lo, hi = parallel.shard_hosts(W.nF, world)[rank]
+    # this rank's shard: only residuals hosted in [lo, hi) exist
+    Ws = copy.copy(W)
+    keep = (W.host[W.r_point] >= lo) & (W.host[W.r_point] < hi)
+    for name in ("r_point", "r_target", "r_matcher", "r_state", "r_hasMatcher", "r_isLinearized", "r_isActive"):
+        setattr(Ws, name, getattr(W, name)[keep])
+    Ws.nR = int(keep.sum())
+    O = OracleEF(Ws.w, Ws.h).load(Ws)
+    O.linearizeAll(); O.applyRes(); O.solveSystemF(0, 0.1)
+    buf = parallel.pack_accumulators(W.nF, O.top_acc().astype(np.float64), *[a.astype(np.float64) for a in O.sc_acc()], O.resInA())
+    t = torch.from_numpy(buf)
+    dist.all_reduce(t)                                   # the one collective of a GN iteration
+    # product host logic on the reduced buffer (host-only handle: no GPU needed)
+    L = api.load_library()
+    h = C.c_void_p()
+    assert L.sdvgn_ef_create(C.byref(h), -1, W.w, W.h, W.nP, None) == 0
+    c = np.ascontiguousarray
+    assert L.sdvgn_ef_set_calib(h, c(W.value_scaled, np.float64), c(W.value_minus_value_zero, np.float64)) == 0
+    assert L.sdvgn_ef_set_frames(h, W.nF, c(W.evalPT, np.float64).reshape(-1), c(W.state, np.float64).reshape(-1), c(W.state_zero, np.float64).reshape(-1),
+                                 c(W.frameID, np.int32), c(W.ab_exposure, np.float32), c(W.frameEnergyTH, np.float32)) == 0
+    assert L.sdvgn_ef_set_marg_prior(h, c(W.HM, np.float64).reshape(-1), c(W.bM, np.float64)) == 0
+    assert L.sdvgn_ef_set_adjoints(h) == 0 and L.sdvgn_ef_set_precalc(h) == 0
+    assert L.sdvgn_ef_accumulator_count(h) == parallel.acc_count(W.nF) == t.numel()
+    x = np.zeros(4 + 6 * W.nF)
+    assert L.sdvgn_ef_stitch_solve_host(h, t.numpy(), 0, 0.1, x.ctypes.data_as(C.c_void_p)) == 0
+    # a device-only entry point must refuse to run on a host-only handle (no silent CPU fallback)
+    assert L.sdvgn_ef_apply_res(h) < 0
+    L.sdvgn_ef_destroy(h)
+    if rank == 0:
+        Of = OracleEF(W.w, W.h).load(W)
+        Of.linearizeAll(); Of.applyRes(); Of.solveSystemF(0, 0.1)
+        q.put((x, Of.system()["x"], int(t.numpy()[-1]), Of.resInA()))
+    else:
+        q.put((x, None, None, None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_accumulate_allreduce_solve_gloo(orc, sdvgn_lib):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    xs = [r[0] for r in res]
+    ref = [r for r in res if r[1] is not None][0]
+    assert np.array_equal(xs[0], xs[1])                                   # every rank solves the same system
+    assert np.linalg.norm(xs[0] - ref[1]) / np.linalg.norm(ref[1]) < 1e-6  # == single-process solve of the full window
+    assert ref[2] == ref[3]
