@@ -51,6 +51,13 @@ def load_library(path=LIB_PATH):
     global _LIB
     if _LIB is not None:
         return _LIB
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (same SONAME as /opt/rocm's).  When this
+    # library is dlopen'ed first, torch later binds to a second runtime copy and sees no GPUs (RCCL refuses to start).
+    # Importing torch first makes libsdvgn resolve libamdhip64 to the copy torch already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise ImportError("libsdvgn.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C sdv-loam_amd/csrc` (%s)" % path)
