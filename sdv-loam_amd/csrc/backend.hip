@@ -13,7 +13,10 @@
 #include "tracker_kernels.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -104,7 +107,21 @@ struct sdvgn_ef {
     double* stats_partial = nullptr;
     size_t slots_cap = 0;
     bool havePrecalc = false, haveAdjoints = false;
+    bool deltaF_nonzero = false, has_linearized = false;   // when both are false the point part of calcLEnergy is exactly 0
+    int precalc_flip = 0;                                  // two pinned staging halves -> no host sync per upload
 };
+
+struct PhaseTimer {   // SDVGN_PROFILE=1: host wall time per phase of the optimize loop, printed by sdvgn_ef_optimize
+    bool on = getenv("SDVGN_PROFILE") != nullptr;
+    double acc[16] = {0};
+    long cnt[16] = {0};
+    std::chrono::steady_clock::time_point t0;
+    void start() { if (on) t0 = std::chrono::steady_clock::now(); }
+    void stop(int k) { if (on) { auto t1 = std::chrono::steady_clock::now(); acc[k] += std::chrono::duration<double, std::micro>(t1 - t0).count(); cnt[k]++; t0 = t1; } }
+};
+static PhaseTimer g_pt;
+enum { PT_ACCUM = 0, PT_D2H, PT_STITCH_TOP, PT_STITCH_SC, PT_SOLVE, PT_RESUB, PT_STEP, PT_PRECALC, PT_LIN, PT_APPLY, PT_N };
+static const char* kPtNames[PT_N] = {"accumulate(launch)", "acc D2H+sync", "stitch_top", "stitch_sc", "HM+LDLT", "xAd+H2D+resub+sync", "state step", "precalc upload", "linearize+stats+sync", "apply/restore"};
 
 static size_t acc_count(const sdvgn_ef* e) { return (size_t)e->nF * e->nF * kTopE + (size_t)e->nF * kScE + 1; }
 
@@ -354,9 +371,13 @@ static int ef_upload_precalc(sdvgn_ef* e) {
     const float K[9] = {C.fxl, 0, C.cxl, 0, C.fyl, C.cyl, 0, 0, 1};
     float Ki[9];
     gn::inverse3f(K, Ki);
+    // the previous upload from the other half has completed: every caller synchronises the stream at least once between
+    // two uploads (linearize read-back), so alternating halves is enough
+    e->precalc_flip ^= 1;
+    PrecalcDev* pch = e->precalc_host + (size_t)e->precalc_flip * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES;
     for (int h = 0; h < nF; ++h)
         for (int t = 0; t < nF; ++t) {
-            PrecalcDev& P = e->precalc_host[h * nF + t];
+            PrecalcDev& P = pch[h * nF + t];
             const FrameH& host = e->frames[h];
             const FrameH& target = e->frames[t];
             double R[9];
@@ -394,10 +415,8 @@ static int ef_upload_precalc(sdvgn_ef* e) {
         }
     for (FrameH& f : e->frames)
         for (int i = 0; i < 6; ++i) { f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i]; }
-    if (!e->host_only) {
-        HIPCHK(hipMemcpyAsync(e->precalc_dev, e->precalc_host, sizeof(PrecalcDev) * nF * nF, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
-    }
+    if (!e->host_only)
+        HIPCHK(hipMemcpyAsync(e->precalc_dev, pch, sizeof(PrecalcDev) * nF * nF, hipMemcpyHostToDevice, e->stream));
     e->havePrecalc = true;
     return 0;
 }
@@ -444,13 +463,13 @@ __global__ void k_ef_reset_oob(size_t slots, EFArrays A) {
     A.rstate[s] = RS_IN;
 }
 
-// per-block partial sums of: [0] calcLEnergyPt (EnergyFunctional.cpp:297-331), [1] step^2, [2] |idepth_backup|
+// per-block partial sums of calcLEnergyPt (EnergyFunctional.cpp:297-331); only launched when some residual is linearised
+// or some point has deltaF != 0 (otherwise the sum is exactly 0)
 __global__ void __launch_bounds__(256) k_ef_point_stats(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
-                                                       const int* __restrict__ phost, const float* __restrict__ backup,
-                                                       double* __restrict__ partial) {
-    __shared__ double sh[3][4];
+                                                       const int* __restrict__ phost, double* __restrict__ partial) {
+    __shared__ double sh[4];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    double e = 0, s2 = 0, sa = 0;
+    double e = 0;
     if (p < C.nP) {
         const int h = phost[p];
         if (precalc[h * C.nF + h].np != 0) {
@@ -472,27 +491,29 @@ __global__ void __launch_bounds__(256) k_ef_point_stats(EFConst C, EFArrays A, c
             }
             acc += dd * dd * A.ppriorF[p];
             e = acc;
-            const float st = A.pstep[p];
-            s2 = (double)(st * st);
-            sa = (double)fabsf(backup[p]);
         }
     }
-    e = wave_sum_double(e); s2 = wave_sum_double(s2); sa = wave_sum_double(sa);
-    if ((threadIdx.x & 63) == 63) { sh[0][threadIdx.x >> 6] = e; sh[1][threadIdx.x >> 6] = s2; sh[2][threadIdx.x >> 6] = sa; }
+    e = wave_sum_double(e);
+    if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = e;
     __syncthreads();
-    if (threadIdx.x < 3) partial[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+    if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
-__global__ void k_ef_sum3(const double* __restrict__ partial, int n, double* __restrict__ out) {
-    __shared__ double s[256];
-    for (int q = 0; q < 3; ++q) {
-        double a = 0;
-        for (int i = threadIdx.x; i < n; i += 256) a += partial[(size_t)q * n + i];
-        s[threadIdx.x] = a;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o]; __syncthreads(); }
-        if (threadIdx.x == 0) out[q] = s[0];
+// out[0] = sum energy partials, out[1] = sum L partials (nL may be 0), out[2], out[3] = sums of the two halves of the
+// resubstitute partials (step^2, |idepth_backup|): one launch instead of four tiny ones
+__global__ void k_ef_sum_stats(const double* __restrict__ pe, int nE, const double* __restrict__ pl, int nL,
+                               const double* __restrict__ ps, int nS, double* __restrict__ out) {
+    __shared__ double s[4][256];
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int i = threadIdx.x; i < nE; i += 256) a0 += pe[i];
+    for (int i = threadIdx.x; i < nL; i += 256) a1 += pl[i];
+    for (int i = threadIdx.x; i < nS; i += 256) { a2 += ps[i]; a3 += ps[nS + i]; }
+    s[0][threadIdx.x] = a0; s[1][threadIdx.x] = a1; s[2][threadIdx.x] = a2; s[3][threadIdx.x] = a3;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) for (int q = 0; q < 4; ++q) s[q][threadIdx.x] += s[q][threadIdx.x + o];
         __syncthreads();
     }
+    if (threadIdx.x < 4) out[threadIdx.x] = s[threadIdx.x][0];
 }
 
 static int chunks_for_np(const sdvgn_ef* e) {
@@ -511,7 +532,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
         sdvgn_ef* e = new (std::nothrow) sdvgn_ef();
         if (!e) return SDVGN_E_ARG;
         e->device = -1; e->w = w; e->h = h; e->max_points = max_points; e->host_only = true;
-        e->precalc_host = (PrecalcDev*)calloc(SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES, sizeof(PrecalcDev));
+        e->precalc_host = (PrecalcDev*)calloc(2 * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES, sizeof(PrecalcDev));
         *out = e;
         return SDVGN_OK;
     }
@@ -543,12 +564,13 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     const size_t accmax = (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kTopE + (size_t)SDVGN_MAX_FRAMES * kScE + 1;
     bad |= dev_alloc(&e->acc_dev, accmax);
     bad |= dev_alloc(&e->xc_dev, 4) | dev_alloc(&e->xAd_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6);
-    bad |= dev_alloc(&e->stats_dev, 4) | dev_alloc(&e->stats_partial, 3 * (mp / 256 + 2));
+    bad |= dev_alloc(&e->stats_dev, 4) | dev_alloc(&e->stats_partial, 3 * (mp / 64 + 2));
     if (bad) { sdvgn_ef_destroy(e); return -(int)hipErrorOutOfMemory; }
-    HIPCHK(hipHostMalloc(&e->precalc_host, sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
+    HIPCHK(hipHostMalloc(&e->precalc_host, 2 * sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
     HIPCHK(hipHostMalloc(&e->acc_host, sizeof(double) * accmax));
     HIPCHK(hipHostMalloc(&e->x_host, sizeof(float) * (4 + SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6)));
     HIPCHK(hipMemsetAsync(e->rflags, 0, slots, e->stream));
+    HIPCHK(hipMemsetAsync(e->stats_partial, 0, sizeof(double) * 3 * (mp / 64 + 2), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     ef_fill_arrays(e);
     *out = e;
@@ -662,9 +684,11 @@ int sdvgn_ef_set_points(sdvgn_ef* e, int nP, const int* host, const float* u, co
     for (int h = 0; h < e->nF; ++h) e->hostP0[h + 1] += e->hostP0[h];
     e->nP = nP;
     std::vector<float> prior(nP), delta(nP), ids(nP), idz(nP);
+    bool any_delta = false;
     for (int i = 0; i < nP; ++i) {
         prior[i] = hasDepthPrior[i] ? kIdepthFixPrior * SDVGN_SCALE_IDEPTH * SDVGN_SCALE_IDEPTH : 0;   // EFPoint::takeData
         delta[i] = idepth[i] - idepth_zero[i];
+        if (delta[i] != 0.0f) any_delta = true;
         ids[i] = SDVGN_SCALE_IDEPTH * idepth[i]; idz[i] = SDVGN_SCALE_IDEPTH * idepth_zero[i];
     }
     const hipStream_t s = e->stream;
@@ -685,6 +709,7 @@ int sdvgn_ef_set_points(sdvgn_ef* e, int nP, const int* host, const float* u, co
     ef_update_const(e);
     e->havePrecalc = false;
     e->nR = 0;
+    e->deltaF_nonzero = any_delta;
     return SDVGN_OK;
 }
 
@@ -698,6 +723,7 @@ int sdvgn_ef_set_residuals(sdvgn_ef* e, int nR, const int* point, const int* tar
     std::vector<int8_t> st(slots, 0);
     std::vector<float2> m(slots, make_float2(0, 0));
     e->r_slot.resize(nR);
+    bool any_lin = false;
     for (int i = 0; i < nR; ++i) {
         if (point[i] < 0 || point[i] >= e->nP || target[i] < 0 || target[i] >= e->nF || target[i] == e->phost[point[i]]) return SDVGN_E_ARG;
         const size_t s = (size_t)target[i] * e->nP + point[i];
@@ -705,6 +731,7 @@ int sdvgn_ef_set_residuals(sdvgn_ef* e, int nR, const int* point, const int* tar
         flags[s] = RF_EXISTS | (hasMatcher[i] ? RF_MATCHER : 0) | (isLinearized[i] ? RF_LINEARIZED : 0) | (isActive[i] ? RF_ACTIVE : 0);
         st[s] = (int8_t)state_state[i];
         m[s] = make_float2((float)matcher[2 * i], (float)matcher[2 * i + 1]);   // `matcher.cast<float>()`, Residuals.cpp:196
+        if (isLinearized[i]) any_lin = true;
         e->r_slot[i] = (int)s;
     }
     const hipStream_t s = e->stream;
@@ -720,6 +747,7 @@ int sdvgn_ef_set_residuals(sdvgn_ef* e, int nR, const int* point, const int* tar
     HIPCHK(hipMemsetAsync(e->JpJd, 0, sizeof(float) * 6 * slots, s));
     HIPCHK(hipStreamSynchronize(s));
     e->nR = nR;
+    e->has_linearized = any_lin;
     return SDVGN_OK;
 }
 
@@ -800,14 +828,15 @@ int sdvgn_ef_accumulate(sdvgn_ef* e) {
     if (!e || e->host_only || !e->havePrecalc) return SDVGN_E_STATE;
     EF_DEVICE(e);
     const int nF = e->nF, pairs = nF * nF, chunks = chunks_for_np(e);
-    k_ef_point<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev);
+    int mx = 1;
+    for (int h = 0; h < nF; ++h) mx = std::max(mx, e->hostP0[h + 1] - e->hostP0[h]);
+    const int sc_chunks = std::min(kMaxChunks, (mx + 127) / 128);
+    const int sc_ppb = ((mx + sc_chunks - 1) / sc_chunks + 63) / 64 * 64;
+    k_ef_point<<<(e->nP + 63) / 64, 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev);
     k_ef_top_gram<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->top_partial, e->nres_partial);
-    const size_t smem = sizeof(float) * ((size_t)4 * 64 * kTileStride + 256 + 1024);
-    // hosts outside this rank's shard contribute nothing: their chunk loops are empty because the shard is applied below
-    k_ef_sc_gram<<<dim3(chunks, nF), 256, smem, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial);
-    k_ef_gram_reduce<<<pairs, 256, 0, e->stream>>>(e->top_partial, chunks, kTopE, e->acc_dev);
-    k_ef_gram_reduce<<<nF, 256, 0, e->stream>>>(e->sc_partial, chunks, kScE, e->acc_dev + (size_t)pairs * kTopE);
-    k_ef_sum_nres<<<1, 256, 0, e->stream>>>(e->nres_partial, chunks * pairs, e->acc_dev + acc_count(e) - 1);
+    k_ef_sc_gram<<<dim3(sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, sc_ppb);
+    const int nred = pairs * kTopE + nF * kScE + 1;
+    k_ef_acc_reduce<<<(nred + 255) / 256, 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks, e->nres_partial, e->acc_dev);
     HIPCHK(hipGetLastError());
     return SDVGN_OK;
 }
@@ -844,8 +873,11 @@ int sdvgn_ef_accumulators_dev(sdvgn_ef* e, double** buf, int* count) {
 static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, double lambda, double* x_out) {
     const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
     e->resInA = (int)acc[acc_count(e) - 1];
+    g_pt.start();
     stitch_top(e, acc);
+    g_pt.stop(PT_STITCH_TOP);
     stitch_sc(e, acc + (size_t)pairs * kTopE);
+    g_pt.stop(PT_STITCH_SC);
     // bM_top = bM + HM * delta ; HFinal = HA + HM - Hsc ; bFinal = bA + bM_top - bsc   (EnergyFunctional.cpp:668-699)
     std::vector<double> d(n), bM_top(n);
     for (int i = 0; i < CPARS; ++i) d[i] = (double)e->C.cDeltaF[i];
@@ -868,6 +900,7 @@ static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, d
     for (int i = 0; i < n; ++i) e->lastX[i] = sv[i] * xs[i];
     if (iteration >= 2) orthogonalize_x(e, e->lastX);   // SOLVER_ORTHOGONALIZE_X_LATER
     if (x_out) std::memcpy(x_out, e->lastX.data(), sizeof(double) * n);
+    g_pt.stop(PT_SOLVE);
     return SDVGN_OK;
 }
 
@@ -880,9 +913,12 @@ int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
     if (!e || e->host_only || !e->havePrecalc) return SDVGN_E_STATE;
     EF_DEVICE(e);
     const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
+    g_pt.start();
     HIPCHK(hipMemcpyAsync(e->acc_host, e->acc_dev, sizeof(double) * acc_count(e), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    g_pt.stop(PT_D2H);
     int rc = ef_stitch_solve_host(e, e->acc_host, iteration, lambda, x_out);
+    g_pt.start();
     if (rc) return rc;
     // resubstituteF_MT (:221-247): xc, xAd[nF*h + t]
     float* xc = e->x_host;
@@ -902,14 +938,18 @@ int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
         }
     HIPCHK(hipMemcpyAsync(e->xc_dev, xc, sizeof(float) * 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->xAd_dev, xAd, sizeof(float) * pairs * 6, hipMemcpyHostToDevice, e->stream));
-    k_ef_resubstitute<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->xc_dev, e->xAd_dev);
+    k_ef_resubstitute<<<(e->nP + 63) / 64, 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->xc_dev, e->xAd_dev,
+                                                             e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));   // x_host is reused by the next call
+    g_pt.stop(PT_RESUB);
     return SDVGN_OK;
 }
 
 int sdvgn_ef_solve_system(sdvgn_ef* e, int iteration, double lambda, double* x_out) {
+    g_pt.start();
     int rc = sdvgn_ef_accumulate(e);
+    g_pt.stop(PT_ACCUM);
     if (rc) return rc;
     if (e->allreduce) e->allreduce(e->allreduce_user, e->acc_dev, (int)acc_count(e));   // cfg4: one all-reduce per GN iteration
     return sdvgn_ef_finish_solve(e, iteration, lambda, x_out);
@@ -920,6 +960,7 @@ int sdvgn_ef_point_step(sdvgn_ef* e, int mode, float stepfacD) {
     EF_DEVICE(e);
     k_ef_point_step<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->nP, mode, stepfacD, e->pid, e->pidz, e->pidepth_backup, e->pstep, e->pdeltaF);
     HIPCHK(hipGetLastError());
+    if (mode != 0) e->deltaF_nonzero = false;
     return SDVGN_OK;
 }
 
@@ -943,11 +984,16 @@ static double calc_M_energy(sdvgn_ef* e) {   // EnergyFunctional::calcMEnergyF
 }
 // launches linearizeAll + the point statistics; returns {energy, L-energy, sum step^2, sum |idepth_backup|} after ONE sync
 static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* sumID, double* sumNID) {
-    int rc = sdvgn_ef_linearize_all(e, nullptr);
-    if (rc) return rc;
-    const int nb = (e->nP + 255) / 256;
-    k_ef_point_stats<<<nb, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial);
-    k_ef_sum3<<<1, 256, 0, e->stream>>>(e->stats_partial, nb, e->stats_dev + 1);
+    if (!e->havePrecalc) return SDVGN_E_STATE;
+    const int chunks = chunks_for_np(e), pairs = e->nF * e->nF;
+    k_ef_linearize<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
+    int nL = 0;
+    if (e->deltaF_nonzero || e->has_linearized) {
+        nL = (e->nP + 255) / 256;
+        k_ef_point_stats<<<nL, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->stats_partial);
+    }
+    const int nS = (e->nP + 63) / 64;
+    k_ef_sum_stats<<<1, 256, 0, e->stream>>>(e->energy_partial, chunks * pairs, e->stats_partial, nL, e->stats_partial + (e->nP / 64 + 2), nS, e->stats_dev);
     HIPCHK(hipGetLastError());
     if (e->allreduce) e->allreduce(e->allreduce_user, e->stats_dev, 4);   // ranks hold disjoint host-frame shards
     HIPCHK(hipMemcpyAsync(e->acc_host, e->stats_dev, 4 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -985,9 +1031,9 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     for (int iteration = 0; iteration < mnumOptIts; iteration++) {
         for (int i = 0; i < 4; ++i) e->value_backup[i] = e->value[i];                     // backupState
         for (FrameH& f : e->frames) for (int i = 0; i < 10; ++i) f.state_backup[i] = f.state[i];
-        if ((rc = sdvgn_ef_point_step(e, 0, 0.f))) return rc;
-        if ((rc = sdvgn_ef_solve_system(e, iteration, lambda, x.data()))) return rc;
+        if ((rc = sdvgn_ef_solve_system(e, iteration, lambda, x.data()))) return rc;   // its resubstitute also backs up the idepths
         // doStepFromBackup
+        g_pt.start();
         double v[4];
         for (int i = 0; i < 4; ++i) v[i] = e->value_backup[i] + stepsize * (-x[i]);
         calib_set_value(e, v);
@@ -1002,9 +1048,12 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             for (int i = 3; i < 6; ++i) sumR += (float)(x[CPARS + 6 * h + i] * x[CPARS + 6 * h + i]);
         }
         if ((rc = sdvgn_ef_point_step(e, 1, stepsize))) return rc;
+        g_pt.stop(PT_STEP);
         if ((rc = ef_upload_precalc(e))) return rc;                                       // setPrecalcValues + setDeltaF
+        g_pt.stop(PT_PRECALC);
         double newEnergy, newEnergyL, sID, sNID;
         if ((rc = linearize_and_stats(e, &newEnergy, &newEnergyL, &sID, &sNID))) return rc;
+        g_pt.stop(PT_LIN);
         const double newEnergyM = calc_M_energy(e);
         sumR /= nF; sumT /= nF;
         const float sumNID = (float)sNID / (float)e->nP;
@@ -1016,6 +1065,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             for (int i = 0; i < n && 7 + i < trace_stride; ++i) tr[7 + i] = x[i];
         }
         it = iteration + 1;
+        g_pt.start();
         if (accept) {
             if ((rc = sdvgn_ef_apply_res(e))) return rc;
             lastEnergy = newEnergy; lastEnergyL = newEnergyL; lastEnergyM = newEnergyM;
@@ -1029,7 +1079,13 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             lastEnergyM = calc_M_energy(e);
             lambda *= 1e2;
         }
+        g_pt.stop(PT_APPLY);
         if (!fixed_its && canbreak && iteration >= 1) break;
+    }
+    if (g_pt.on) {
+        fprintf(stderr, "[sdvgn profile] %d iterations\n", it);
+        for (int k = 0; k < PT_N; ++k) if (g_pt.cnt[k]) fprintf(stderr, "  %-24s %8.1f us/iter  (%ld calls, %.1f us each)\n", kPtNames[k], g_pt.acc[k] / it, g_pt.cnt[k], g_pt.acc[k] / g_pt.cnt[k]);
+        for (int k = 0; k < PT_N; ++k) { g_pt.acc[k] = 0; g_pt.cnt[k] = 0; }
     }
     return it;
 }

@@ -175,32 +175,40 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, con
                 const float wts[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
                 const int pat[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};
                 const float ids = A.pid[p];
+                // (1) project all 8 pattern pixels (ALU only); (2) gather all of them with branch-free, independent loads
+                // (out-of-image projections read a safe in-image address and are ignored) so that the 96 tap loads are in
+                // flight together; (3) replay the reference's sequential loop with its `break`s on the gathered values.
+                float Ku2[8], Kv2[8], g0[8], g1[8], g2[8];
+                bool inb[8];
+#pragma unroll
+                for (int idx = 0; idx < 8; ++idx) {
+                    const float up = pu + pat[idx][0], vp = pv + pat[idx][1];
+                    const float r0 = ((pc.KRKi[0] * up + pc.KRKi[1] * vp) + pc.KRKi[2] * 1.0f) + pc.Kt[0] * ids;
+                    const float r1 = ((pc.KRKi[3] * up + pc.KRKi[4] * vp) + pc.KRKi[5] * 1.0f) + pc.Kt[1] * ids;
+                    const float r2 = ((pc.KRKi[6] * up + pc.KRKi[7] * vp) + pc.KRKi[8] * 1.0f) + pc.Kt[2] * ids;
+                    Ku2[idx] = r0 / r2; Kv2[idx] = r1 / r2;
+                    inb[idx] = (Ku2[idx] > 1.1f && Kv2[idx] > 1.1f && Ku2[idx] < C.wM3G && Kv2[idx] < C.hM3G);
+                }
+#pragma unroll
+                for (int idx = 0; idx < 8; ++idx)
+                    interp33_b(img, inb[idx] ? Ku2[idx] : 2.0f, inb[idx] ? Kv2[idx] : 2.0f, C.w, g0[idx], g1[idx], g2[idx]);
                 float wJI2_sum = 0, energyLeft2 = 0;
                 bool alive = true;
 #pragma unroll
                 for (int idx = 0; idx < 8; ++idx) {
                     if (alive) {
-                        const float up = pu + pat[idx][0], vp = pv + pat[idx][1];
-                        const float r0 = ((pc.KRKi[0] * up + pc.KRKi[1] * vp) + pc.KRKi[2] * 1.0f) + pc.Kt[0] * ids;
-                        const float r1 = ((pc.KRKi[3] * up + pc.KRKi[4] * vp) + pc.KRKi[5] * 1.0f) + pc.Kt[1] * ids;
-                        const float r2 = ((pc.KRKi[6] * up + pc.KRKi[7] * vp) + pc.KRKi[8] * 1.0f) + pc.Kt[2] * ids;
-                        const float Ku2 = r0 / r2, Kv2 = r1 / r2;
-                        if (!(Ku2 > 1.1f && Kv2 > 1.1f && Ku2 < C.wM3G && Kv2 < C.hM3G)) alive = false;
+                        if (!inb[idx] || !isfinite(g0[idx])) alive = false;
                         else {
-                            float h0, h1, h2;
-                            interp33_b(img, Ku2, Kv2, C.w, h0, h1, h2);
-                            if (!isfinite(h0)) alive = false;
-                            else {
-                                const float residual = h0 - (float)(pc.aff0 * col[idx] + pc.aff1);
-                                float w = sqrtf(C.outlierTHSumComponent / (C.outlierTHSumComponent + (h1 * h1 + h2 * h2)));
-                                w = 0.5f * (w + wts[idx]);
-                                float hw = fabsf(residual) < C.huberTH ? 1.0f : C.huberTH / fabsf(residual);
-                                energyLeft2 += w * w * hw * residual * residual * (2 - hw);
-                                if (hw < 1) hw = sqrtf(hw);
-                                hw = hw * w;
-                                h1 *= hw; h2 *= hw;
-                                wJI2_sum += hw * hw * (h1 * h1 + h2 * h2);
-                            }
+                            float h1 = g1[idx], h2 = g2[idx];
+                            const float residual = g0[idx] - (float)(pc.aff0 * col[idx] + pc.aff1);
+                            float w = sqrtf(C.outlierTHSumComponent / (C.outlierTHSumComponent + (h1 * h1 + h2 * h2)));
+                            w = 0.5f * (w + wts[idx]);
+                            float hw = fabsf(residual) < C.huberTH ? 1.0f : C.huberTH / fabsf(residual);
+                            energyLeft2 += w * w * hw * residual * residual * (2 - hw);
+                            if (hw < 1) hw = sqrtf(hw);
+                            hw = hw * w;
+                            h1 *= hw; h2 *= hw;
+                            wJI2_sum += hw * hw * (h1 * h1 + h2 * h2);
                         }
                     }
                 }
@@ -262,53 +270,72 @@ __global__ void __launch_bounds__(256) k_ef_apply(int nF, int nP, EFArrays A, co
 }
 
 // Per-point sums of addPoint<0> (active, not linearised) and addPoint<1> (active, linearised), then the head of the
-// Schur accumulation: HdiF, bdSumF, Hcd.  One thread per point, residuals visited in target order.
-__global__ void __launch_bounds__(256) k_ef_point(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+// Schur accumulation: HdiF, bdSumF, Hcd.  Workgroup = 64 points x 8 waves; wave t reads the residual slot of target
+// frame t (coalesced: consecutive lanes = consecutive points), lanes of wave 0 add the 8 targets in ascending order.
+__global__ void __launch_bounds__(512) k_ef_point(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
                                                   const int* __restrict__ phost) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= C.nP) return;
+    __shared__ float part[kMaxFrames][13][64];
+    const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
     const size_t slots = (size_t)C.nF * C.nP;
-    const int h = phost[p];
-    if (precalc[h * C.nF + h].np == 0) return;   // host frame not in this rank's shard
-    const float dd = A.pdeltaF[p];
-    float bdA = 0, HddA = 0, HcdA[4] = {0, 0, 0, 0}, bdL = 0, HddL = 0, HcdL[4] = {0, 0, 0, 0};
-    int ngood = 0;
-    for (int t = 0; t < C.nF; ++t) {
+    float v[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) v[i] = 0.0f;   // bdA HddA HcdA[4] bdL HddL HcdL[4] ngood
+    int h = 0;
+    bool mine = false;
+    if (p < C.nP) {
+        h = phost[p];
+        mine = precalc[h * C.nF + h].np != 0;   // host frame in this rank's shard
+    }
+    if (mine && t < C.nF) {
         const size_t s = (size_t)t * C.nP + p;
         const uint8_t fl = A.rflags[s];
-        if (!(fl & RF_EXISTS) || !(fl & RF_ACTIVE)) continue;
-        ngood++;
-        const float* Je = A.J + (size_t)((fl & RF_SEL) ? 1 : 0) * kJPlanes * slots + s;
-        const float d0 = Je[22 * slots], d1 = Je[23 * slots];
-        float c0[4], c1[4];
+        if ((fl & RF_EXISTS) && (fl & RF_ACTIVE)) {
+            v[12] = 1.0f;
+            const float* Je = A.J + (size_t)((fl & RF_SEL) ? 1 : 0) * kJPlanes * slots + s;
+            const float d0 = Je[22 * slots], d1 = Je[23 * slots];
+            float c0[4], c1[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { c0[i] = Je[(14 + i) * slots]; c1[i] = Je[(18 + i) * slots]; }
-        if (!(fl & RF_LINEARIZED)) {
-            const float r0 = Je[0], r1 = Je[slots];
-            bdA += r0 * d0 + r1 * d1;
-            HddA += d0 * d0 + d1 * d1;
+            for (int i = 0; i < 4; ++i) { c0[i] = Je[(14 + i) * slots]; c1[i] = Je[(18 + i) * slots]; }
+            if (!(fl & RF_LINEARIZED)) {
+                const float r0 = Je[0], r1 = Je[slots];
+                v[0] = r0 * d0 + r1 * d1;
+                v[1] = d0 * d0 + d1 * d1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) HcdA[i] += c0[i] * d0 + c1[i] * d1;
-        } else {
-            const PrecalcDev& pc = precalc[h * C.nF + t];
-            float dx = 0, dy = 0, cx = 0, cy = 0;
+                for (int i = 0; i < 4; ++i) v[2 + i] = c0[i] * d0 + c1[i] * d1;
+            } else {
+                const PrecalcDev& pc = precalc[h * C.nF + t];
+                const float dd = A.pdeltaF[p];
+                float dx = 0, dy = 0, cx = 0, cy = 0;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { dx += Je[(2 + i) * slots] * pc.dp[i]; dy += Je[(8 + i) * slots] * pc.dp[i]; }
+                for (int i = 0; i < 6; ++i) { dx += Je[(2 + i) * slots] * pc.dp[i]; dy += Je[(8 + i) * slots] * pc.dp[i]; }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { cx += c0[i] * C.cDeltaF[i]; cy += c1[i] * C.cDeltaF[i]; }
-            const float r0 = A.rres_toZero[s] + (dx + cx + d0 * dd);
-            const float r1 = A.rres_toZero[slots + s] + (dy + cy + d1 * dd);
-            bdL += r0 * d0 + r1 * d1;
-            HddL += d0 * d0 + d1 * d1;
+                for (int i = 0; i < 4; ++i) { cx += c0[i] * C.cDeltaF[i]; cy += c1[i] * C.cDeltaF[i]; }
+                const float r0 = A.rres_toZero[s] + (dx + cx + d0 * dd);
+                const float r1 = A.rres_toZero[slots + s] + (dy + cy + d1 * dd);
+                v[6] = r0 * d0 + r1 * d1;
+                v[7] = d0 * d0 + d1 * d1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) HcdL[i] += c0[i] * d0 + c1[i] * d1;
+                for (int i = 0; i < 4; ++i) v[8 + i] = c0[i] * d0 + c1[i] * d1;
+            }
         }
     }
+#pragma unroll
+    for (int i = 0; i < 13; ++i) part[t][i][lane] = v[i];
+    __syncthreads();
+    if (t != 0 || !mine) return;
+    float sum[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) sum[i] = 0.0f;
+    for (int tt = 0; tt < C.nF; ++tt)
+#pragma unroll
+        for (int i = 0; i < 13; ++i) sum[i] += part[tt][i][lane];
+    const float bdA = sum[0], HddA = sum[1], bdL = sum[6], HddL = sum[7];
     A.pHddA[p] = HddA; A.pbdA[p] = bdA; A.pHddL[p] = HddL; A.pbdL[p] = bdL;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { A.pHcdA[(size_t)i * C.nP + p] = HcdA[i]; A.pHcdL[(size_t)i * C.nP + p] = HcdL[i]; }
+    for (int i = 0; i < 4; ++i) { A.pHcdA[(size_t)i * C.nP + p] = sum[2 + i]; A.pHcdL[(size_t)i * C.nP + p] = sum[8 + i]; }
     // AccumulatedSCHessian.cpp:12-34
-    if (ngood == 0) {
+    if (sum[12] == 0.0f) {
         A.pHdi[p] = 0; A.pbdSum[p] = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) A.pHcd[(size_t)i * C.nP + p] = 0;
@@ -319,10 +346,10 @@ __global__ void __launch_bounds__(256) k_ef_point(EFConst C, EFArrays A, const P
     if (H < 1e-10) H = 1e-10;
     A.pHdi[p] = (float)(1.0 / H);
     float bds = bdA + bdL;
-    bds += prior * dd;  // shiftPriorToZero == true in accumulateSCF_MT
+    bds += prior * A.pdeltaF[p];  // shiftPriorToZero == true in accumulateSCF_MT
     A.pbdSum[p] = bds;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) A.pHcd[(size_t)i * C.nP + p] = HcdA[i] + HcdL[i];
+    for (int i = 0; i < 4; ++i) A.pHcd[(size_t)i * C.nP + p] = sum[2 + i] + sum[8 + i];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -420,61 +447,121 @@ __global__ void __launch_bounds__(256) k_ef_top_gram(EFConst C, EFArrays A, cons
     if (threadIdx.x == 0) nres_partial[o] = (s_n[0] + s_n[1]) + (s_n[2] + s_n[3]);
 }
 
-// SC Gram: grid = (chunks, nF hosts), block = 256 (4 waves x 64 points).  Features (64, 53 live):
-// 6*t+i: JpJdF of the residual in target t (0 if absent/inactive); 48-51: Hcd; 52: bdSumF.  Row weight = HdiF (0 for
-// LiDAR points -> excluded from the Schur complement, AccumulatedSCHessian.cpp:36-37).
-// partial: [host][chunk][10 tiles][256] floats.
+// SC Gram: grid = (chunks, nF hosts), block = 256.  Features (64, 53 live): 6*t+i = JpJdF of the residual in target t
+// (0 if absent/inactive); 48-51 = Hcd; 52 = bdSumF.  Row weight = HdiF (0 for LiDAR points -> excluded from the Schur
+// complement, AccumulatedSCHessian.cpp:36-37).  The workgroup walks its points in tiles of 64: all 256 lanes stage the
+// [64 feat][64 pts] tile (lane = point, wave = 16-feature group; next tile's values are fetched into registers while the
+// current one is multiplied), then each wave accumulates the 2-3 output tiles it owns (10 upper 16x16 tiles over 4
+// waves), so no cross-wave reduction is needed.  partial: [host][chunk][10 tiles][256] floats.
+template <int A> struct ScTile {   // a-th upper tile of the 4x4 tile grid, row-major: (0,0)(0,1)(0,2)(0,3)(1,1)(1,2)(1,3)(2,2)(2,3)(3,3)
+    static constexpr int ti = A < 4 ? 0 : (A < 7 ? 1 : (A < 9 ? 2 : 3));
+    static constexpr int tj = A < 4 ? A : (A < 7 ? A - 3 : (A < 9 ? A - 5 : 3));
+};
+
+// body of k_ef_sc_gram for one wave; WAVE is a compile-time constant so that feature / tile indices fold
+template <int WAVE>
+__device__ __forceinline__ void sc_gram_wave(const EFConst& C, const EFArrays& A, int P0, int begin, int end, float* tile, float* wrow,
+                                             float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const size_t slots = (size_t)C.nF * C.nP;
+    constexpr int NQ = (WAVE + 8 < 10) ? 3 : 2;   // tiles WAVE, WAVE+4, WAVE+8 (< 10)
+    f32x4 acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q] = (f32x4){0, 0, 0, 0};
+    float stage[16];
+    float stage_w = 0.0f;
+    auto fetch = [&](int base) {   // features WAVE*16 .. WAVE*16+15 of point base+lane
+        const int pl = base + lane;
+        const bool in = pl < end;
+        const int p = P0 + (in ? pl : 0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            constexpr int f0 = WAVE * 16;
+            const int f = f0 + j;
+            float v = 0.0f;
+            if (f < 48) {
+                const int t = f / 6, i = f - 6 * t;
+                if (in && t < C.nF) {
+                    const size_t s = (size_t)t * C.nP + p;
+                    const uint8_t fl = A.rflags[s];
+                    if ((fl & RF_EXISTS) && (fl & RF_ACTIVE)) v = A.JpJd[(size_t)i * slots + s];
+                }
+            } else if (f < 52) {
+                if (in) v = A.pHcd[(size_t)(f - 48) * C.nP + p];
+            } else if (f == 52) {
+                if (in) v = A.pbdSum[p];
+            }
+            stage[j] = v;
+        }
+        if (WAVE == 3) stage_w = (in && !A.psensor[p]) ? A.pHdi[p] : 0.0f;
+    };
+    if (begin < end) fetch(begin);
+    for (int base = begin; base < end; base += 64) {
+        __syncthreads();   // previous tile fully consumed
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tile[(WAVE * 16 + j) * kTileStride + lane] = stage[j];
+        if (WAVE == 3) wrow[lane] = stage_w;
+        __syncthreads();
+        if (base + 64 < end) fetch(base + 64);   // next tile's loads fly while this one is multiplied
+        const int f = lane & 15, kq = lane >> 4;
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+            const int k = ks * 4 + kq;
+            float frag[4];
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) frag[ti] = tile[(ti * 16 + f) * kTileStride + k];
+            const float w = wrow[k];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ScTile<WAVE>::ti] * w, frag[ScTile<WAVE>::tj], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ScTile<WAVE + 4>::ti] * w, frag[ScTile<WAVE + 4>::tj], acc[1], 0, 0, 0);
+            if (NQ == 3) acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ScTile<(WAVE + 8) % 10>::ti] * w, frag[ScTile<(WAVE + 8) % 10>::tj], acc[2], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int a = WAVE + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[a * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[q][r];
+    }
+}
+
 __global__ void __launch_bounds__(256) k_ef_sc_gram(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
-                                                    float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    // layout: tile[4 waves][64*kTileStride] | w[4][64] | red[10*256]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* tile = smem + (size_t)wave * 64 * kTileStride;
-    float* wrow = smem + (size_t)4 * 64 * kTileStride + wave * 64;
-    float* red = smem + (size_t)4 * 64 * kTileStride + 256;
+                                                    float* __restrict__ partial, int pts_per_block) {
+    __shared__ float tile[64 * kTileStride];
+    __shared__ float wrow[64];
+    const int wave = threadIdx.x >> 6;
     const int h = blockIdx.y;
     const int P0 = precalc[h * C.nF + h].P0, np = precalc[h * C.nF + h].np;   // np == 0 outside this rank's shard
-    const size_t slots = (size_t)C.nF * C.nP;
-    f32x4 acc[10];
-#pragma unroll
-    for (int a = 0; a < 10; ++a) acc[a] = (f32x4){0, 0, 0, 0};
-    for (int base = blockIdx.x * 256 + wave * 64; base < np; base += gridDim.x * 256) {
-        const int pl = base + lane;
-        const bool in = pl < np;
-        const int p = P0 + (in ? pl : 0);
-        float w = 0.0f;
-        if (in && !A.psensor[p]) w = A.pHdi[p];
-#pragma unroll
-        for (int t = 0; t < kMaxFrames; ++t) {
-            bool act = false;
-            size_t s = 0;
-            if (in && t < C.nF) {
-                s = (size_t)t * C.nP + p;
-                const uint8_t fl = A.rflags[s];
-                act = (fl & RF_EXISTS) && (fl & RF_ACTIVE);
-            }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) tile[(6 * t + i) * kTileStride + lane] = act ? A.JpJd[(size_t)i * slots + s] : 0.0f;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tile[(48 + i) * kTileStride + lane] = in ? A.pHcd[(size_t)i * C.nP + p] : 0.0f;
-        tile[52 * kTileStride + lane] = in ? A.pbdSum[p] : 0.0f;
-#pragma unroll
-        for (int i = 53; i < 64; ++i) tile[i * kTileStride + lane] = 0.0f;
-        wrow[lane] = w;
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        gram_tile_accumulate<4>(tile, wrow, acc);
-        __builtin_amdgcn_wave_barrier();
-    }
-    // cross-wave reduction through LDS, one tile at a time (red holds 4 waves x 256 floats would be too much; reuse)
+    const int begin = blockIdx.x * pts_per_block, end = min(np, begin + pts_per_block);
     float* out = partial + ((size_t)h * gridDim.x + blockIdx.x) * 10 * 256;
-    for (int a = 0; a < 10; ++a) {
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[a][r];
-        __syncthreads();
-        out[a * 256 + threadIdx.x] = (red[threadIdx.x] + red[256 + threadIdx.x]) + (red[512 + threadIdx.x] + red[768 + threadIdx.x]);
+    switch (wave) {   // wave-uniform: every wave runs straight-line code specialised for the tiles / features it owns
+        case 0: sc_gram_wave<0>(C, A, P0, begin, end, tile, wrow, out); break;
+        case 1: sc_gram_wave<1>(C, A, P0, begin, end, tile, wrow, out); break;
+        case 2: sc_gram_wave<2>(C, A, P0, begin, end, tile, wrow, out); break;
+        default: sc_gram_wave<3>(C, A, P0, begin, end, tile, wrow, out); break;
+    }
+}
+
+// Fixed-order fp64 sum of the per-workgroup partials into the packed accumulator buffer, all three parts in one launch:
+// top Gram [pairs][256] (top_chunks partials each), SC Gram [nF][2560] (sc_chunks partials each), resInA.
+__global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__ top_partial, int pairs, int top_chunks,
+                                                       const float* __restrict__ sc_partial, int nF, int sc_chunks,
+                                                       const int* __restrict__ nres_partial, double* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ntop = pairs * 256, nsc = nF * 2560;
+    if (e < ntop) {
+        const int g = e >> 8, k = e & 255;
+        double s = 0;
+        for (int c = 0; c < top_chunks; ++c) s += (double)top_partial[((size_t)g * top_chunks + c) * 256 + k];
+        out[e] = s;
+    } else if (e < ntop + nsc) {
+        const int r = e - ntop, g = r / 2560, k = r - g * 2560;
+        double s = 0;
+        for (int c = 0; c < sc_chunks; ++c) s += (double)sc_partial[((size_t)g * sc_chunks + c) * 2560 + k];
+        out[e] = s;
+    } else if (e == ntop + nsc) {
+        int n = 0;
+        for (int c = 0; c < pairs * top_chunks; ++c) n += nres_partial[c];
+        out[e] = (double)n;
     }
 }
 
@@ -489,35 +576,58 @@ __global__ void __launch_bounds__(256) k_ef_gram_reduce(const float* __restrict_
     }
 }
 
-// resubstituteFPt: one thread per point.  xAd: [nF(host)][nF(target)][6] floats (index nF*h + t), xc: 4 floats.
-__global__ void __launch_bounds__(256) k_ef_resubstitute(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+// resubstituteFPt (EnergyFunctional.cpp:250-282): workgroup = 64 points x 8 waves; wave t forms xAd[h,t] . JpJdF of the
+// residual in target t, wave 0 subtracts the 8 terms in ascending target order.  Also does backupState for the point
+// (idepth_backup = idepth, FullSystemOptimize.cpp:300-305) and the per-block partial sums of step^2 and |idepth_backup|
+// that doStepFromBackup needs (:236-249).  xAd: [nF(host)][nF(target)][6] floats (index nF*h + t), xc: 4 floats.
+__global__ void __launch_bounds__(512) k_ef_resubstitute(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
                                                          const int* __restrict__ phost, const float* __restrict__ xc,
-                                                         const float* __restrict__ xAd) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= C.nP) return;
+                                                         const float* __restrict__ xAd, float* __restrict__ backup,
+                                                         double* __restrict__ stats_partial) {
+    __shared__ float part[kMaxFrames][2][64];
+    const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
     const size_t slots = (size_t)C.nF * C.nP;
-    const int h = phost[p];
-    if (precalc[h * C.nF + h].np == 0) return;
-    int ngood = 0;
-    float b = A.pbdSum[p];
-    float dot = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dot += xc[i] * A.pHcdA[(size_t)i * C.nP + p];
-    b -= dot;
-    for (int t = 0; t < C.nF; ++t) {
+    int h = 0;
+    bool mine = false;
+    if (p < C.nP) { h = phost[p]; mine = precalc[h * C.nF + h].np != 0; }
+    float dotv = 0.0f, good = 0.0f;
+    if (mine && t < C.nF) {
         const size_t s = (size_t)t * C.nP + p;
         const uint8_t fl = A.rflags[s];
-        if (!(fl & RF_EXISTS) || !(fl & RF_ACTIVE)) continue;
-        ngood++;
-        const float* xa = xAd + (size_t)(C.nF * h + t) * 6;
-        float sum = 0;
+        if ((fl & RF_EXISTS) && (fl & RF_ACTIVE)) {
+            good = 1.0f;
+            const float* xa = xAd + (size_t)(C.nF * h + t) * 6;
+            float sum = 0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) sum += xa[i] * A.JpJd[(size_t)i * slots + s];
-        b -= sum;
+            for (int i = 0; i < 6; ++i) sum += xa[i] * A.JpJd[(size_t)i * slots + s];
+            dotv = sum;
+        }
     }
-    float step = 0.0f;
-    if (ngood > 0 && !A.psensor[p]) step = -b * A.pHdi[p];
-    A.pstep[p] = step;
+    part[t][0][lane] = dotv; part[t][1][lane] = good;
+    __syncthreads();
+    if (t != 0) return;
+    double s2 = 0, sa = 0;
+    if (mine) {
+        float b = A.pbdSum[p];
+        float dot = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dot += xc[i] * A.pHcdA[(size_t)i * C.nP + p];
+        b -= dot;
+        float ngood = 0;
+        for (int tt = 0; tt < C.nF; ++tt) {
+            if (part[tt][1][lane] != 0.0f) { b -= part[tt][0][lane]; ngood += 1.0f; }
+        }
+        float step = 0.0f;
+        if (ngood > 0 && !A.psensor[p]) step = -b * A.pHdi[p];
+        A.pstep[p] = step;
+        const float idb = A.pid[p] * (1.0f / SDVGN_SCALE_IDEPTH);
+        backup[p] = idb;
+        s2 = (double)(step * step);
+        sa = (double)fabsf(idb);
+    }
+    s2 = wave_sum_double(s2); sa = wave_sum_double(sa);
+    if (lane == 63) { stats_partial[blockIdx.x] = s2; stats_partial[gridDim.x + blockIdx.x] = sa; }
 }
 
 }  // namespace sdvgn

@@ -178,7 +178,7 @@ def _se3_mul_np(a, b):
 
 
 def make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=KITTI00, sensor_frac=0.3, matcher_sigma=0.3,
-                state_sigma=1e-3, idepth_sigma=0.02, evalpt_sigma=(0.01, 0.001), spacing=1.0, marg_prior=True):
+                state_sigma=2e-4, idepth_sigma=0.003, evalpt_sigma=(2e-3, 2e-4), spacing=1.0, marg_prior=True):
     """Synthetic EnergyFunctional window.  Ground truth: camera k at z = k*spacing with a small yaw, all frames see the
     plane n.X = d; frame images are rendered from one texture so that the 8-pixel photometric outlier test of
     linearize() sees consistent data.  Returns a Window with flat numpy arrays in the reference's iteration order
