@@ -9,6 +9,7 @@
 //           independent of the number of points ("tiny; keep on host").
 #include "../../include/sdvgn.h"
 #include "backend_kernels.hpp"
+#include "backend_stitch.hpp"
 #include "gnmath.hpp"
 #include "tracker_kernels.hpp"
 
@@ -106,6 +107,12 @@ struct sdvgn_ef {
     bool host_only = false;
     double* stats_partial = nullptr;
     size_t slots_cap = 0;
+    // device stitch (k_ef_stitch)
+    double *adH_dev = nullptr, *HM_dev = nullptr, *bM_dev = nullptr, *sys_dev = nullptr;
+    double* sys_host = nullptr;            // pinned: HFinal | bFinal | resInA
+    StitchState* stitch_dev = nullptr;
+    StitchState* stitch_host = nullptr;    // pinned, 2 halves
+    bool host_stitch_valid = false, use_host_stitch = false;
     bool havePrecalc = false, haveAdjoints = false;
     bool deltaF_nonzero = false, has_linearized = false;   // when both are false the point part of calcLEnergy is exactly 0
     int precalc_flip = 0;                                  // two pinned staging halves -> no host sync per upload
@@ -161,6 +168,7 @@ static void ef_update_const(sdvgn_ef* e) {  // CalibHessian float views, Hessian
     C.wM3G = e->w - 3; C.hM3G = e->h - 3;
     for (int i = 0; i < 4; ++i) C.cDeltaF[i] = (float)e->value_minus_value_zero[i];
     C.huberTH = 6.0f; C.outlierTHSumComponent = 50 * 50;
+    C.debug_flags = getenv("SDVGN_DEBUG_FLAGS") ? atoi(getenv("SDVGN_DEBUG_FLAGS")) : 0;
 }
 
 // ---------------- host stitch: top (AccumulatedTopHessian.cpp:181-242 + .h:100-113) --------------------------
@@ -415,8 +423,18 @@ static int ef_upload_precalc(sdvgn_ef* e) {
         }
     for (FrameH& f : e->frames)
         for (int i = 0; i < 6; ++i) { f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i]; }
-    if (!e->host_only)
+    if (!e->host_only) {
         HIPCHK(hipMemcpyAsync(e->precalc_dev, pch, sizeof(PrecalcDev) * nF * nF, hipMemcpyHostToDevice, e->stream));
+        StitchState& S = e->stitch_host[e->precalc_flip];
+        for (int i = 0; i < CPARS; ++i) { S.delta[i] = (double)e->C.cDeltaF[i]; S.cPrior[i] = e->cPrior[i]; S.cDelta[i] = (double)e->C.cDeltaF[i]; }
+        for (int h = 0; h < nF; ++h)
+            for (int i = 0; i < 6; ++i) {
+                S.delta[CPARS + 6 * h + i] = e->frames[h].delta[i];
+                S.prior[h * 6 + i] = e->frames[h].prior[i];
+                S.delta_prior[h * 6 + i] = e->frames[h].delta_prior[i];
+            }
+        HIPCHK(hipMemcpyAsync(e->stitch_dev, &S, sizeof(StitchState), hipMemcpyHostToDevice, e->stream));
+    }
     e->havePrecalc = true;
     return 0;
 }
@@ -565,9 +583,15 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->acc_dev, accmax);
     bad |= dev_alloc(&e->xc_dev, 4) | dev_alloc(&e->xAd_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6);
     bad |= dev_alloc(&e->stats_dev, 4) | dev_alloc(&e->stats_partial, 3 * (mp / 64 + 2));
+    bad |= dev_alloc(&e->adH_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 36) | dev_alloc(&e->HM_dev, kMaxDim * kMaxDim) | dev_alloc(&e->bM_dev, kMaxDim);
+    bad |= dev_alloc(&e->sys_dev, kMaxDim * kMaxDim + kMaxDim + 1) | dev_alloc(&e->stitch_dev, 1);
     if (bad) { sdvgn_ef_destroy(e); return -(int)hipErrorOutOfMemory; }
     HIPCHK(hipHostMalloc(&e->precalc_host, 2 * sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
     HIPCHK(hipHostMalloc(&e->acc_host, sizeof(double) * accmax));
+    HIPCHK(hipHostMalloc(&e->sys_host, sizeof(double) * (kMaxDim * kMaxDim + kMaxDim + 1)));
+    HIPCHK(hipHostMalloc(&e->stitch_host, 2 * sizeof(StitchState)));
+    e->use_host_stitch = getenv("SDVGN_HOST_STITCH") != nullptr;
+    HIPCHK(hipFuncSetAttribute((const void*)k_ef_stitch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stitch_smem_bytes(SDVGN_MAX_FRAMES)));
     HIPCHK(hipHostMalloc(&e->x_host, sizeof(float) * (4 + SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6)));
     HIPCHK(hipMemsetAsync(e->rflags, 0, slots, e->stream));
     HIPCHK(hipMemsetAsync(e->stats_partial, 0, sizeof(double) * 3 * (mp / 64 + 2), e->stream));
@@ -588,10 +612,12 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->rstate, e->rstate_new, e->rmatcher, e->renergy, e->renergy_new, e->renergy_wo, e->rres_toZero, e->J, e->JpJd, e->pHddA,
                     e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->images, e->img_stage,
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
-                    e->xc_dev, e->xAd_dev, e->stats_dev, e->stats_partial};
+                    e->xc_dev, e->xAd_dev, e->stats_dev, e->stats_partial, e->adH_dev, e->HM_dev, e->bM_dev, e->sys_dev, e->stitch_dev};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->precalc_host) hipHostFree(e->precalc_host);
     if (e->acc_host) hipHostFree(e->acc_host);
+    if (e->sys_host) hipHostFree(e->sys_host);
+    if (e->stitch_host) hipHostFree(e->stitch_host);
     if (e->x_host) hipHostFree(e->x_host);
     if (e->own_stream) hipStreamDestroy(e->stream);
     delete e;
@@ -628,6 +654,11 @@ int sdvgn_ef_set_frames(sdvgn_ef* e, int nF, const double* evalPT7, const double
     }
     const int n = CPARS + 6 * nF;
     e->HM.assign((size_t)n * n, 0); e->bM.assign(n, 0);
+    if (!e->host_only) {
+        HIPCHK(hipSetDevice(e->device));
+        HIPCHK(hipMemsetAsync(e->HM_dev, 0, sizeof(double) * kMaxDim * kMaxDim, e->stream));
+        HIPCHK(hipMemsetAsync(e->bM_dev, 0, sizeof(double) * kMaxDim, e->stream));
+    }
     e->h1 = std::min(e->h1, nF);
     if (e->h0 == 0 && e->h1 >= nF) e->h1 = nF;
     ef_update_const(e);
@@ -755,6 +786,12 @@ int sdvgn_ef_set_marg_prior(sdvgn_ef* e, const double* HM, const double* bM) {
     if (!e || !HM || !bM || e->nF < 1) return SDVGN_E_ARG;
     const int n = CPARS + 6 * e->nF;
     e->HM.assign(HM, HM + (size_t)n * n); e->bM.assign(bM, bM + n);
+    if (!e->host_only) {
+        HIPCHK(hipSetDevice(e->device));
+        HIPCHK(hipMemcpyAsync(e->HM_dev, e->HM.data(), sizeof(double) * n * n, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->bM_dev, e->bM.data(), sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
     return SDVGN_OK;
 }
 
@@ -787,6 +824,11 @@ int sdvgn_ef_set_adjoints(sdvgn_ef* e) {  // EnergyFunctional::setAdjointsF
             for (int i = 0; i < 36; ++i) { e->adHostF[(size_t)(h + t * nF) * 36 + i] = (float)AH[i]; e->adTargetF[(size_t)(h + t * nF) * 36 + i] = (float)AT[i]; }
         }
     for (int i = 0; i < 4; ++i) e->cPrior[i] = kInitialCalibHessian;
+    if (!e->host_only) {
+        HIPCHK(hipSetDevice(e->device));
+        HIPCHK(hipMemcpyAsync(e->adH_dev, e->adHost.data(), sizeof(double) * e->adHost.size(), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
     e->haveAdjoints = true;
     e->havePrecalc = false;
     return SDVGN_OK;
@@ -870,7 +912,7 @@ int sdvgn_ef_accumulators_dev(sdvgn_ef* e, double** buf, int* count) {
 
 // host part of solveSystemF on an accumulator buffer (own or all-reduced): stitch, HM/bM, damped preconditioned LDLT,
 // null-space projection.  Pure host code -- also the entry point of the CPU (gloo) test of the multi-GPU logic.
-static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, double lambda, double* x_out) {
+static void ef_host_stitch(sdvgn_ef* e, const double* acc) {
     const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
     e->resInA = (int)acc[acc_count(e) - 1];
     g_pt.start();
@@ -886,6 +928,13 @@ static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, d
     e->HFinal.resize((size_t)n * n); e->bFinal.resize(n);
     for (size_t i = 0; i < (size_t)n * n; ++i) e->HFinal[i] = e->HA[i] + e->HM[i] - e->Hsc[i];
     for (int i = 0; i < n; ++i) e->bFinal[i] = e->bA[i] + bM_top[i] - e->bsc[i];
+    e->host_stitch_valid = true;
+}
+
+// damped, Jacobi-preconditioned LDLT on HFinal/bFinal + null-space projection (EnergyFunctional.cpp:703-750)
+static void ef_host_solve(sdvgn_ef* e, int iteration, double lambda, double* x_out) {
+    const int n = CPARS + 6 * e->nF;
+    g_pt.start();
     std::vector<double> Hs((size_t)n * n), xs(n), sv(n);
     for (int i = 0; i < n; ++i) sv[i] = 1.0 / std::sqrt(e->HFinal[(size_t)i * n + i] * (1 + lambda) + 10);
     for (int i = 0; i < n; ++i) {
@@ -901,6 +950,13 @@ static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, d
     if (iteration >= 2) orthogonalize_x(e, e->lastX);   // SOLVER_ORTHOGONALIZE_X_LATER
     if (x_out) std::memcpy(x_out, e->lastX.data(), sizeof(double) * n);
     g_pt.stop(PT_SOLVE);
+}
+
+// host part of solveSystemF on an accumulator buffer (own or all-reduced).  Pure host code -- also the entry point of the
+// CPU (gloo) test of the multi-GPU logic.
+static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, double lambda, double* x_out) {
+    ef_host_stitch(e, acc);
+    ef_host_solve(e, iteration, lambda, x_out);
     return SDVGN_OK;
 }
 
@@ -914,12 +970,27 @@ int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
     EF_DEVICE(e);
     const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
     g_pt.start();
-    HIPCHK(hipMemcpyAsync(e->acc_host, e->acc_dev, sizeof(double) * acc_count(e), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    g_pt.stop(PT_D2H);
-    int rc = ef_stitch_solve_host(e, e->acc_host, iteration, lambda, x_out);
+    if (e->use_host_stitch) {
+        HIPCHK(hipMemcpyAsync(e->acc_host, e->acc_dev, sizeof(double) * acc_count(e), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        g_pt.stop(PT_D2H);
+        int rc = ef_stitch_solve_host(e, e->acc_host, iteration, lambda, x_out);
+        if (rc) return rc;
+    } else {
+        // stitch on the device, read back only HFinal | bFinal | resInA (22 kB instead of the 295 kB accumulator buffer)
+        k_ef_stitch<<<1, kStitchThreads, stitch_smem_bytes(nF), e->stream>>>(nF, e->acc_dev, e->adH_dev, e->stitch_dev, e->HM_dev, e->bM_dev, e->sys_dev);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(e->sys_host, e->sys_dev, sizeof(double) * ((size_t)n * n + n), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(e->sys_host + (size_t)n * n + n, e->acc_dev + acc_count(e) - 1, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        g_pt.stop(PT_D2H);
+        e->HFinal.assign(e->sys_host, e->sys_host + (size_t)n * n);
+        e->bFinal.assign(e->sys_host + (size_t)n * n, e->sys_host + (size_t)n * n + n);
+        e->resInA = (int)e->sys_host[(size_t)n * n + n];
+        e->host_stitch_valid = false;
+        ef_host_solve(e, iteration, lambda, x_out);
+    }
     g_pt.start();
-    if (rc) return rc;
     // resubstituteF_MT (:221-247): xc, xAd[nF*h + t]
     float* xc = e->x_host;
     float* xAd = e->x_host + 4;
@@ -1108,6 +1179,15 @@ int sdvgn_ef_dim(sdvgn_ef* e) { return e ? CPARS + 6 * e->nF : SDVGN_E_ARG; }
 int sdvgn_ef_get_system(sdvgn_ef* e, double* HA, double* bA, double* Hsc, double* bsc, double* HFinal, double* bFinal) {
     if (!e || e->HFinal.empty()) return SDVGN_E_STATE;
     const size_t n = CPARS + 6 * e->nF;
+    if (!e->host_stitch_valid && !e->host_only && (HA || bA || Hsc || bsc)) {
+        // parity hook: the separate HA / Hsc blocks are only formed by the host stitch; HFinal/bFinal stay the device result
+        EF_DEVICE(e);
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpy(e->acc_host, e->acc_dev, sizeof(double) * acc_count(e), hipMemcpyDeviceToHost));
+        const std::vector<double> Hf = e->HFinal, bf = e->bFinal;
+        ef_host_stitch(e, e->acc_host);
+        e->HFinal = Hf; e->bFinal = bf;
+    }
     if (HA) std::memcpy(HA, e->HA.data(), 8 * n * n);
     if (bA) std::memcpy(bA, e->bA.data(), 8 * n);
     if (Hsc) std::memcpy(Hsc, e->Hsc.data(), 8 * n * n);

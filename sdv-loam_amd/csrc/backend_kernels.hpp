@@ -56,6 +56,7 @@ struct EFConst {
     float wM3G, hM3G;
     float cDeltaF[4];
     float huberTH, outlierTHSumComponent;
+    int debug_flags;   // bit0: skip the image gathers (profiling experiments only; never set by the product path)
 };
 
 struct EFArrays {
@@ -190,8 +191,10 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, con
                     inb[idx] = (Ku2[idx] > 1.1f && Kv2[idx] > 1.1f && Ku2[idx] < C.wM3G && Kv2[idx] < C.hM3G);
                 }
 #pragma unroll
-                for (int idx = 0; idx < 8; ++idx)
-                    interp33_b(img, inb[idx] ? Ku2[idx] : 2.0f, inb[idx] ? Kv2[idx] : 2.0f, C.w, g0[idx], g1[idx], g2[idx]);
+                for (int idx = 0; idx < 8; ++idx) {
+                    if (C.debug_flags & 1) { g0[idx] = Ku2[idx]; g1[idx] = Kv2[idx]; g2[idx] = 1.0f; }
+                    else interp33_b(img, inb[idx] ? Ku2[idx] : 2.0f, inb[idx] ? Kv2[idx] : 2.0f, C.w, g0[idx], g1[idx], g2[idx]);
+                }
                 float wJI2_sum = 0, energyLeft2 = 0;
                 bool alive = true;
 #pragma unroll

@@ -79,6 +79,11 @@ def test_linearize_apply_solve_parity(api, orc, window):
     assert np.array_equal(s2g["state"], s2o["state"]) and np.array_equal(s2g["active"], s2o["active"])
     assert np.array_equal(G.residual_J(1).view(np.uint32)[s2o["active"] == 1], O.residual_J(1).view(np.uint32)[s2o["active"] == 1])
     check_solve(G, O, 0, 0.1)
+    sg = G.system()
+    # device stitch (k_ef_stitch: HFinal, bFinal) vs the host stitch of the same accumulators (HA, Hsc): fp64 round-off only
+    assert rel_err(sg["HFinal"], sg["HA"] + window.HM - sg["Hsc"]) < 1e-11
+    d = np.concatenate([window.value_minus_value_zero.astype(np.float32).astype(np.float64), (window.state - window.state_zero)[:, :6].reshape(-1)])
+    assert rel_err(sg["bFinal"], sg["bA"] + window.bM + window.HM @ d - sg["bsc"]) < 1e-10
     check_solve(G, O, 1, 1e-3)
     # second linearisation at the same state: new J goes to the other buffer, EF-side J unchanged, deterministic
     check_linearize(G, O)
