@@ -9,7 +9,6 @@
 //           independent of the number of points ("tiny; keep on host").
 #include "../../include/sdvgn.h"
 #include "backend_kernels.hpp"
-#include "backend_stitch.hpp"
 #include "gnmath.hpp"
 #include "tracker_kernels.hpp"
 
@@ -107,12 +106,6 @@ struct sdvgn_ef {
     bool host_only = false;
     double* stats_partial = nullptr;
     size_t slots_cap = 0;
-    // device stitch (k_ef_stitch)
-    double *adH_dev = nullptr, *HM_dev = nullptr, *bM_dev = nullptr, *sys_dev = nullptr;
-    double* sys_host = nullptr;            // pinned: HFinal | bFinal | resInA
-    StitchState* stitch_dev = nullptr;
-    StitchState* stitch_host = nullptr;    // pinned, 2 halves
-    bool host_stitch_valid = false, use_host_stitch = false;
     bool havePrecalc = false, haveAdjoints = false;
     bool deltaF_nonzero = false, has_linearized = false;   // when both are false the point part of calcLEnergy is exactly 0
     int precalc_flip = 0;                                  // two pinned staging halves -> no host sync per upload
@@ -177,40 +170,46 @@ static void stitch_top(sdvgn_ef* e, const double* G /*[nF*nF][256]*/) {
     std::vector<double>& H = e->HA;
     std::vector<double>& b = e->bA;
     H.assign((size_t)n * n, 0); b.assign(n, 0);
+    const double sT[6] = {kScaleXiTrans, kScaleXiTrans, kScaleXiTrans, kScaleXiRot, kScaleXiRot, kScaleXiRot};   // adTarget = diag
     for (int k = 0; k < nF * nF; ++k) {
         const int h = k % nF, t = k / nF;
         if (h == t) continue;
         const int hIdx = CPARS + h * 6, tIdx = CPARS + t * 6;
         const double* g = G + (size_t)(h * nF + t) * kTopE;   // device pair index = h*nF + t, 16x16 row-major
         const double* AH = &e->adHost[(size_t)(h + t * nF) * 36];
-        const double* AT = &e->adTarget[(size_t)(h + t * nF) * 36];
-        // T1 = AH * A66, T2 = AT * A66   (A66 = g[4..9][4..9])
-        double T1[36], T2[36];
-        for (int i = 0; i < 6; ++i)
-            for (int j = 0; j < 6; ++j) {
-                double s1 = 0, s2 = 0;
-                for (int q = 0; q < 6; ++q) { s1 += AH[i * 6 + q] * g[(4 + q) * 16 + 4 + j]; s2 += AT[i * 6 + q] * g[(4 + q) * 16 + 4 + j]; }
-                T1[i * 6 + j] = s1; T2[i * 6 + j] = s2;
+        // adTarget = diag(sT): only AH*A66 and (AH*A66)*AH^T are real 6x6 products
+        double T1[36];
+        for (int i = 0; i < 6; ++i) {
+            double row[6] = {0, 0, 0, 0, 0, 0};
+            for (int q = 0; q < 6; ++q) {
+                const double a = AH[i * 6 + q];
+                const double* gq = g + (4 + q) * 16 + 4;
+                for (int j = 0; j < 6; ++j) row[j] += a * gq[j];
             }
+            for (int j = 0; j < 6; ++j) T1[i * 6 + j] = row[j];
+        }
         for (int i = 0; i < 6; ++i)
             for (int j = 0; j < 6; ++j) {
-                double hh = 0, tt = 0, ht = 0;
-                for (int q = 0; q < 6; ++q) { hh += T1[i * 6 + q] * AH[j * 6 + q]; tt += T2[i * 6 + q] * AT[j * 6 + q]; ht += T1[i * 6 + q] * AT[j * 6 + q]; }
+                double hh = 0;
+                for (int q = 0; q < 6; ++q) hh += T1[i * 6 + q] * AH[j * 6 + q];
                 H[(size_t)(hIdx + i) * n + hIdx + j] += hh;
-                H[(size_t)(tIdx + i) * n + tIdx + j] += tt;
-                H[(size_t)(hIdx + i) * n + tIdx + j] += ht;
+                H[(size_t)(tIdx + i) * n + tIdx + j] += sT[i] * g[(4 + i) * 16 + 4 + j] * sT[j];
+                H[(size_t)(hIdx + i) * n + tIdx + j] += T1[i * 6 + j] * sT[j];
             }
         for (int i = 0; i < 6; ++i) {
-            for (int j = 0; j < CPARS; ++j) {
-                double sh = 0, st = 0;
-                for (int q = 0; q < 6; ++q) { sh += AH[i * 6 + q] * g[(4 + q) * 16 + j]; st += AT[i * 6 + q] * g[(4 + q) * 16 + j]; }
-                H[(size_t)(hIdx + i) * n + j] += sh;
-                H[(size_t)(tIdx + i) * n + j] += st;
+            double sh[CPARS + 1] = {0, 0, 0, 0, 0};
+            for (int q = 0; q < 6; ++q) {
+                const double a = AH[i * 6 + q];
+                const double* gq = g + (4 + q) * 16;
+                for (int j = 0; j < CPARS; ++j) sh[j] += a * gq[j];
+                sh[CPARS] += a * gq[10];
             }
-            double sh = 0, st = 0;
-            for (int q = 0; q < 6; ++q) { sh += AH[i * 6 + q] * g[(4 + q) * 16 + 10]; st += AT[i * 6 + q] * g[(4 + q) * 16 + 10]; }
-            b[hIdx + i] += sh;
-            b[tIdx + i] += st;
+            for (int j = 0; j < CPARS; ++j) {
+                H[(size_t)(hIdx + i) * n + j] += sh[j];
+                H[(size_t)(tIdx + i) * n + j] += sT[i] * g[(4 + i) * 16 + j];
+            }
+            b[hIdx + i] += sh[CPARS];
+            b[tIdx + i] += sT[i] * g[(4 + i) * 16 + 10];
         }
         for (int i = 0; i < CPARS; ++i) {
             for (int j = 0; j < CPARS; ++j) H[(size_t)i * n + j] += g[i * 16 + j];
@@ -264,12 +263,15 @@ static void stitch_sc(sdvgn_ef* e, const double* Gall /*[nF][10][256]*/) {
             const double* AH = &e->adHost[(size_t)(h + nF * j) * 36];
             for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Ah[(size_t)r * nf6 + 6 * j + c] = AH[r * 6 + c];
         }
-        // B = A_h * D (D = G[0:nf6, 0:nf6])
+        // B = A_h * D (D = G[0:nf6, 0:nf6]); inner loop contiguous over c so that it vectorises
+        std::fill(B.begin(), B.end(), 0.0);
         for (int r = 0; r < 6; ++r)
-            for (int c = 0; c < nf6; ++c) {
-                double s = 0;
-                for (int q = 0; q < nf6; ++q) s += Ah[(size_t)r * nf6 + q] * G[(size_t)q * 64 + c];
-                B[(size_t)r * nf6 + c] = s;
+            for (int q = 0; q < nf6; ++q) {
+                const double a = Ah[(size_t)r * nf6 + q];
+                if (a == 0.0) continue;
+                const double* gq = &G[(size_t)q * 64];
+                double* br = &B[(size_t)r * nf6];
+                for (int c = 0; c < nf6; ++c) br[c] += a * gq[c];
             }
         // H[i,i] += sum_jk AH_ij D_jk AH_ik^T = B A_h^T
         for (int r = 0; r < 6; ++r)
@@ -423,18 +425,8 @@ static int ef_upload_precalc(sdvgn_ef* e) {
         }
     for (FrameH& f : e->frames)
         for (int i = 0; i < 6; ++i) { f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i]; }
-    if (!e->host_only) {
+    if (!e->host_only)
         HIPCHK(hipMemcpyAsync(e->precalc_dev, pch, sizeof(PrecalcDev) * nF * nF, hipMemcpyHostToDevice, e->stream));
-        StitchState& S = e->stitch_host[e->precalc_flip];
-        for (int i = 0; i < CPARS; ++i) { S.delta[i] = (double)e->C.cDeltaF[i]; S.cPrior[i] = e->cPrior[i]; S.cDelta[i] = (double)e->C.cDeltaF[i]; }
-        for (int h = 0; h < nF; ++h)
-            for (int i = 0; i < 6; ++i) {
-                S.delta[CPARS + 6 * h + i] = e->frames[h].delta[i];
-                S.prior[h * 6 + i] = e->frames[h].prior[i];
-                S.delta_prior[h * 6 + i] = e->frames[h].delta_prior[i];
-            }
-        HIPCHK(hipMemcpyAsync(e->stitch_dev, &S, sizeof(StitchState), hipMemcpyHostToDevice, e->stream));
-    }
     e->havePrecalc = true;
     return 0;
 }
@@ -583,15 +575,9 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->acc_dev, accmax);
     bad |= dev_alloc(&e->xc_dev, 4) | dev_alloc(&e->xAd_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6);
     bad |= dev_alloc(&e->stats_dev, 4) | dev_alloc(&e->stats_partial, 3 * (mp / 64 + 2));
-    bad |= dev_alloc(&e->adH_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 36) | dev_alloc(&e->HM_dev, kMaxDim * kMaxDim) | dev_alloc(&e->bM_dev, kMaxDim);
-    bad |= dev_alloc(&e->sys_dev, kMaxDim * kMaxDim + kMaxDim + 1) | dev_alloc(&e->stitch_dev, 1);
     if (bad) { sdvgn_ef_destroy(e); return -(int)hipErrorOutOfMemory; }
     HIPCHK(hipHostMalloc(&e->precalc_host, 2 * sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
     HIPCHK(hipHostMalloc(&e->acc_host, sizeof(double) * accmax));
-    HIPCHK(hipHostMalloc(&e->sys_host, sizeof(double) * (kMaxDim * kMaxDim + kMaxDim + 1)));
-    HIPCHK(hipHostMalloc(&e->stitch_host, 2 * sizeof(StitchState)));
-    e->use_host_stitch = getenv("SDVGN_HOST_STITCH") != nullptr;
-    HIPCHK(hipFuncSetAttribute((const void*)k_ef_stitch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stitch_smem_bytes(SDVGN_MAX_FRAMES)));
     HIPCHK(hipHostMalloc(&e->x_host, sizeof(float) * (4 + SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6)));
     HIPCHK(hipMemsetAsync(e->rflags, 0, slots, e->stream));
     HIPCHK(hipMemsetAsync(e->stats_partial, 0, sizeof(double) * 3 * (mp / 64 + 2), e->stream));
@@ -612,12 +598,10 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->rstate, e->rstate_new, e->rmatcher, e->renergy, e->renergy_new, e->renergy_wo, e->rres_toZero, e->J, e->JpJd, e->pHddA,
                     e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->images, e->img_stage,
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
-                    e->xc_dev, e->xAd_dev, e->stats_dev, e->stats_partial, e->adH_dev, e->HM_dev, e->bM_dev, e->sys_dev, e->stitch_dev};
+                    e->xc_dev, e->xAd_dev, e->stats_dev, e->stats_partial};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->precalc_host) hipHostFree(e->precalc_host);
     if (e->acc_host) hipHostFree(e->acc_host);
-    if (e->sys_host) hipHostFree(e->sys_host);
-    if (e->stitch_host) hipHostFree(e->stitch_host);
     if (e->x_host) hipHostFree(e->x_host);
     if (e->own_stream) hipStreamDestroy(e->stream);
     delete e;
@@ -654,11 +638,6 @@ int sdvgn_ef_set_frames(sdvgn_ef* e, int nF, const double* evalPT7, const double
     }
     const int n = CPARS + 6 * nF;
     e->HM.assign((size_t)n * n, 0); e->bM.assign(n, 0);
-    if (!e->host_only) {
-        HIPCHK(hipSetDevice(e->device));
-        HIPCHK(hipMemsetAsync(e->HM_dev, 0, sizeof(double) * kMaxDim * kMaxDim, e->stream));
-        HIPCHK(hipMemsetAsync(e->bM_dev, 0, sizeof(double) * kMaxDim, e->stream));
-    }
     e->h1 = std::min(e->h1, nF);
     if (e->h0 == 0 && e->h1 >= nF) e->h1 = nF;
     ef_update_const(e);
@@ -786,12 +765,6 @@ int sdvgn_ef_set_marg_prior(sdvgn_ef* e, const double* HM, const double* bM) {
     if (!e || !HM || !bM || e->nF < 1) return SDVGN_E_ARG;
     const int n = CPARS + 6 * e->nF;
     e->HM.assign(HM, HM + (size_t)n * n); e->bM.assign(bM, bM + n);
-    if (!e->host_only) {
-        HIPCHK(hipSetDevice(e->device));
-        HIPCHK(hipMemcpyAsync(e->HM_dev, e->HM.data(), sizeof(double) * n * n, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipMemcpyAsync(e->bM_dev, e->bM.data(), sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
-    }
     return SDVGN_OK;
 }
 
@@ -824,11 +797,6 @@ int sdvgn_ef_set_adjoints(sdvgn_ef* e) {  // EnergyFunctional::setAdjointsF
             for (int i = 0; i < 36; ++i) { e->adHostF[(size_t)(h + t * nF) * 36 + i] = (float)AH[i]; e->adTargetF[(size_t)(h + t * nF) * 36 + i] = (float)AT[i]; }
         }
     for (int i = 0; i < 4; ++i) e->cPrior[i] = kInitialCalibHessian;
-    if (!e->host_only) {
-        HIPCHK(hipSetDevice(e->device));
-        HIPCHK(hipMemcpyAsync(e->adH_dev, e->adHost.data(), sizeof(double) * e->adHost.size(), hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
-    }
     e->haveAdjoints = true;
     e->havePrecalc = false;
     return SDVGN_OK;
@@ -912,7 +880,7 @@ int sdvgn_ef_accumulators_dev(sdvgn_ef* e, double** buf, int* count) {
 
 // host part of solveSystemF on an accumulator buffer (own or all-reduced): stitch, HM/bM, damped preconditioned LDLT,
 // null-space projection.  Pure host code -- also the entry point of the CPU (gloo) test of the multi-GPU logic.
-static void ef_host_stitch(sdvgn_ef* e, const double* acc) {
+static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, double lambda, double* x_out) {
     const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
     e->resInA = (int)acc[acc_count(e) - 1];
     g_pt.start();
@@ -928,13 +896,6 @@ static void ef_host_stitch(sdvgn_ef* e, const double* acc) {
     e->HFinal.resize((size_t)n * n); e->bFinal.resize(n);
     for (size_t i = 0; i < (size_t)n * n; ++i) e->HFinal[i] = e->HA[i] + e->HM[i] - e->Hsc[i];
     for (int i = 0; i < n; ++i) e->bFinal[i] = e->bA[i] + bM_top[i] - e->bsc[i];
-    e->host_stitch_valid = true;
-}
-
-// damped, Jacobi-preconditioned LDLT on HFinal/bFinal + null-space projection (EnergyFunctional.cpp:703-750)
-static void ef_host_solve(sdvgn_ef* e, int iteration, double lambda, double* x_out) {
-    const int n = CPARS + 6 * e->nF;
-    g_pt.start();
     std::vector<double> Hs((size_t)n * n), xs(n), sv(n);
     for (int i = 0; i < n; ++i) sv[i] = 1.0 / std::sqrt(e->HFinal[(size_t)i * n + i] * (1 + lambda) + 10);
     for (int i = 0; i < n; ++i) {
@@ -950,13 +911,6 @@ static void ef_host_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
     if (iteration >= 2) orthogonalize_x(e, e->lastX);   // SOLVER_ORTHOGONALIZE_X_LATER
     if (x_out) std::memcpy(x_out, e->lastX.data(), sizeof(double) * n);
     g_pt.stop(PT_SOLVE);
-}
-
-// host part of solveSystemF on an accumulator buffer (own or all-reduced).  Pure host code -- also the entry point of the
-// CPU (gloo) test of the multi-GPU logic.
-static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, double lambda, double* x_out) {
-    ef_host_stitch(e, acc);
-    ef_host_solve(e, iteration, lambda, x_out);
     return SDVGN_OK;
 }
 
@@ -970,27 +924,12 @@ int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
     EF_DEVICE(e);
     const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
     g_pt.start();
-    if (e->use_host_stitch) {
-        HIPCHK(hipMemcpyAsync(e->acc_host, e->acc_dev, sizeof(double) * acc_count(e), hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
-        g_pt.stop(PT_D2H);
-        int rc = ef_stitch_solve_host(e, e->acc_host, iteration, lambda, x_out);
-        if (rc) return rc;
-    } else {
-        // stitch on the device, read back only HFinal | bFinal | resInA (22 kB instead of the 295 kB accumulator buffer)
-        k_ef_stitch<<<1, kStitchThreads, stitch_smem_bytes(nF), e->stream>>>(nF, e->acc_dev, e->adH_dev, e->stitch_dev, e->HM_dev, e->bM_dev, e->sys_dev);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(e->sys_host, e->sys_dev, sizeof(double) * ((size_t)n * n + n), hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipMemcpyAsync(e->sys_host + (size_t)n * n + n, e->acc_dev + acc_count(e) - 1, sizeof(double), hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
-        g_pt.stop(PT_D2H);
-        e->HFinal.assign(e->sys_host, e->sys_host + (size_t)n * n);
-        e->bFinal.assign(e->sys_host + (size_t)n * n, e->sys_host + (size_t)n * n + n);
-        e->resInA = (int)e->sys_host[(size_t)n * n + n];
-        e->host_stitch_valid = false;
-        ef_host_solve(e, iteration, lambda, x_out);
-    }
+    HIPCHK(hipMemcpyAsync(e->acc_host, e->acc_dev, sizeof(double) * acc_count(e), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    g_pt.stop(PT_D2H);
+    int rc = ef_stitch_solve_host(e, e->acc_host, iteration, lambda, x_out);
     g_pt.start();
+    if (rc) return rc;
     // resubstituteF_MT (:221-247): xc, xAd[nF*h + t]
     float* xc = e->x_host;
     float* xAd = e->x_host + 4;
@@ -1179,15 +1118,6 @@ int sdvgn_ef_dim(sdvgn_ef* e) { return e ? CPARS + 6 * e->nF : SDVGN_E_ARG; }
 int sdvgn_ef_get_system(sdvgn_ef* e, double* HA, double* bA, double* Hsc, double* bsc, double* HFinal, double* bFinal) {
     if (!e || e->HFinal.empty()) return SDVGN_E_STATE;
     const size_t n = CPARS + 6 * e->nF;
-    if (!e->host_stitch_valid && !e->host_only && (HA || bA || Hsc || bsc)) {
-        // parity hook: the separate HA / Hsc blocks are only formed by the host stitch; HFinal/bFinal stay the device result
-        EF_DEVICE(e);
-        HIPCHK(hipStreamSynchronize(e->stream));
-        HIPCHK(hipMemcpy(e->acc_host, e->acc_dev, sizeof(double) * acc_count(e), hipMemcpyDeviceToHost));
-        const std::vector<double> Hf = e->HFinal, bf = e->bFinal;
-        ef_host_stitch(e, e->acc_host);
-        e->HFinal = Hf; e->bFinal = bf;
-    }
     if (HA) std::memcpy(HA, e->HA.data(), 8 * n * n);
     if (bA) std::memcpy(bA, e->bA.data(), 8 * n);
     if (Hsc) std::memcpy(Hsc, e->Hsc.data(), 8 * n * n);
