@@ -38,8 +38,11 @@ using namespace sdvgn;
 namespace {
 
 constexpr int CPARS = 4;
-constexpr int kTopE = 256;        // one 16x16 tile per (host,target)
-constexpr int kScE = 10 * 256;    // 10 upper tiles of the 64x64 Gram per host
+constexpr int kTopP = 256;        // partial buffers: one 16x16 tile per (host,target) and workgroup
+constexpr int kScP = 10 * 256;    // partial buffers: 10 upper 16x16 tiles of the 64x64 Gram per host and workgroup
+constexpr int kTopE = 121;        // packed accumulators: the live 11x11 of the top tile, row-major
+constexpr int kScN = 53;          // live features of the Schur Gram
+constexpr int kScE = kScN * (kScN + 1) / 2;   // packed accumulators: upper triangle of 53x53, row-major (1431)
 constexpr int kMaxChunks = 64;
 const float kScaleXiRot = 1.0f, kScaleXiTrans = 0.5f, kScaleA = 10.0f, kScaleB = 1000.0f;
 const float kInitialRotPrior = 1e11f, kInitialTransPrior = 1e10f, kInitialCalibHessian = 5e9f, kIdepthFixPrior = 50 * 50;
@@ -175,7 +178,9 @@ static void stitch_top(sdvgn_ef* e, const double* G /*[nF*nF][256]*/) {
         const int h = k % nF, t = k / nF;
         if (h == t) continue;
         const int hIdx = CPARS + h * 6, tIdx = CPARS + t * 6;
-        const double* g = G + (size_t)(h * nF + t) * kTopE;   // device pair index = h*nF + t, 16x16 row-major
+        const double* g11 = G + (size_t)(h * nF + t) * kTopE;   // device pair index = h*nF + t, packed 11x11
+        double g[11 * 16];                                       // re-strided to 16 so that the code below indexes g[r*16+c]
+        for (int r = 0; r < 11; ++r) for (int c = 0; c < 11; ++c) g[r * 16 + c] = g11[r * 11 + c];
         const double* AH = &e->adHost[(size_t)(h + t * nF) * 36];
         // adTarget = diag(sT): only AH*A66 and (AH*A66)*AH^T are real 6x6 products
         double T1[36];
@@ -246,18 +251,12 @@ static void stitch_sc(sdvgn_ef* e, const double* Gall /*[nF][10][256]*/) {
     const double sT[6] = {kScaleXiTrans, kScaleXiTrans, kScaleXiTrans, kScaleXiRot, kScaleXiRot, kScaleXiRot};  // adTarget = diag
     std::vector<double> G(64 * 64), Ah((size_t)6 * nf6), B((size_t)6 * nf6);
     for (int h = 0; h < nF; ++h) {
-        const double* gt = Gall + (size_t)h * kScE;
-        int a = 0;
-        for (int ti = 0; ti < 4; ++ti)
-            for (int tj = ti; tj < 4; ++tj) {
-                const double* tile = gt + (size_t)a * 256;
-                for (int r = 0; r < 16; ++r)
-                    for (int c = 0; c < 16; ++c) {
-                        G[(size_t)(ti * 16 + r) * 64 + tj * 16 + c] = tile[r * 16 + c];
-                        if (ti != tj) G[(size_t)(tj * 16 + c) * 64 + ti * 16 + r] = tile[r * 16 + c];
-                    }
-                ++a;
-            }
+        const double* gp = Gall + (size_t)h * kScE;   // packed upper triangle of the 53x53 Gram
+        {
+            size_t k = 0;
+            for (int r = 0; r < kScN; ++r)
+                for (int c = r; c < kScN; ++c) { const double v = gp[k++]; G[(size_t)r * 64 + c] = v; G[(size_t)c * 64 + r] = v; }
+        }
         const int iIdx = CPARS + h * 6;
         for (int j = 0; j < nF; ++j) {
             const double* AH = &e->adHost[(size_t)(h + nF * j) * 36];
@@ -568,8 +567,8 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->phost_dev, mp) | dev_alloc(&e->hostP0_dev, SDVGN_MAX_FRAMES + 1);
     bad |= dev_alloc(&e->precalc_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES);
     bad |= dev_alloc(&e->energy_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks);
-    bad |= dev_alloc(&e->top_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * kTopE);
-    bad |= dev_alloc(&e->sc_partial, (size_t)SDVGN_MAX_FRAMES * kMaxChunks * kScE);
+    bad |= dev_alloc(&e->top_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * kTopP);
+    bad |= dev_alloc(&e->sc_partial, (size_t)SDVGN_MAX_FRAMES * kMaxChunks * kScP);
     bad |= dev_alloc(&e->nres_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks);
     const size_t accmax = (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kTopE + (size_t)SDVGN_MAX_FRAMES * kScE + 1;
     bad |= dev_alloc(&e->acc_dev, accmax);
@@ -1201,7 +1200,7 @@ int sdvgn_ef_get_top_acc(sdvgn_ef* e, double* out, int* resInA) {
     for (int h = 0; h < nF; ++h)
         for (int t = 0; t < nF; ++t)
             for (int r = 0; r < 11; ++r)
-                for (int c = 0; c < 11; ++c) out[(size_t)(h + nF * t) * 121 + r * 11 + c] = g[(size_t)(h * nF + t) * kTopE + r * 16 + c];
+                for (int c = 0; c < 11; ++c) out[(size_t)(h + nF * t) * 121 + r * 11 + c] = g[(size_t)(h * nF + t) * kTopE + r * 11 + c];
     if (resInA) *resInA = e->resInA;
     return SDVGN_OK;
 }

@@ -544,26 +544,32 @@ __global__ void __launch_bounds__(256) k_ef_sc_gram(EFConst C, EFArrays A, const
     }
 }
 
-// Fixed-order fp64 sum of the per-workgroup partials into the packed accumulator buffer, all three parts in one launch:
-// top Gram [pairs][256] (top_chunks partials each), SC Gram [nF][2560] (sc_chunks partials each), resInA.
+// Fixed-order fp64 sum of the per-workgroup partials into the PACKED accumulator buffer, all three parts in one launch:
+// top Gram [pairs][121] (the live 11x11), SC Gram [nF][1431] (upper triangle of the live 53x53), resInA.
 __global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__ top_partial, int pairs, int top_chunks,
                                                        const float* __restrict__ sc_partial, int nF, int sc_chunks,
                                                        const int* __restrict__ nres_partial, double* __restrict__ out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const int ntop = pairs * 256, nsc = nF * 2560;
+    const int ntop = pairs * 121, nsc = nF * 1431;
     if (e < ntop) {
-        const int g = e >> 8, k = e & 255;
+        const int g = e / 121, k = e - g * 121, r = k / 11, c = k - r * 11;
         double s = 0;
-        for (int c = 0; c < top_chunks; ++c) s += (double)top_partial[((size_t)g * top_chunks + c) * 256 + k];
+        for (int ch = 0; ch < top_chunks; ++ch) s += (double)top_partial[((size_t)g * top_chunks + ch) * 256 + r * 16 + c];
         out[e] = s;
     } else if (e < ntop + nsc) {
-        const int r = e - ntop, g = r / 2560, k = r - g * 2560;
+        const int q = e - ntop, g = q / 1431;
+        int k = q - g * 1431, r = 0;
+        while (k >= 53 - r) { k -= 53 - r; ++r; }   // row of the packed upper triangle (<= 52 steps)
+        const int c = r + k;
+        const int ti = r >> 4, tj = c >> 4;
+        const int a = ti * 4 - (ti * (ti - 1)) / 2 + (tj - ti);
+        const int off = a * 256 + (r & 15) * 16 + (c & 15);
         double s = 0;
-        for (int c = 0; c < sc_chunks; ++c) s += (double)sc_partial[((size_t)g * sc_chunks + c) * 2560 + k];
+        for (int ch = 0; ch < sc_chunks; ++ch) s += (double)sc_partial[((size_t)g * sc_chunks + ch) * 2560 + off];
         out[e] = s;
     } else if (e == ntop + nsc) {
         int n = 0;
-        for (int c = 0; c < pairs * top_chunks; ++c) n += nres_partial[c];
+        for (int ch = 0; ch < pairs * top_chunks; ++ch) n += nres_partial[ch];
         out[e] = (double)n;
     }
 }
