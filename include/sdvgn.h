@@ -199,7 +199,7 @@ int sdvgn_ef_get_residual_state(sdvgn_ef* ef, int* state_state, int* state_new, 
 int sdvgn_ef_get_points(sdvgn_ef* ef, float* out9 /*[nP][Hdd_accAF,bd_accAF,Hcd_accAF x4,HdiF,bdSumF,step]*/);
 int sdvgn_ef_get_top_acc(sdvgn_ef* ef, double* out /*[nF*nF][11*11], index h + nF*t*/, int* resInA);
 /* device pointer + element count of the packed accumulator buffer that cfg4 all-reduces across ranks (doubles):
- * top Gram [nF*nF][256] followed by SC Gram [nF][10][256] followed by resInA. */
+ * top Gram [nF*nF][121] (live 11x11) followed by SC Gram [nF][1431] (upper triangle of the live 53x53) followed by resInA. */
 int sdvgn_ef_accumulators_dev(sdvgn_ef* ef, double** buf_dev, int* count);
 /* solve_system split for multi-GPU: accumulate only (fills the packed buffer), then finish (stitch, solve, resubstitute)
  * after the caller has all-reduced the buffer. */
