@@ -11,6 +11,7 @@
 #include "tracker_kernels.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -462,6 +463,11 @@ int sdvgn_tracker_track_batch(sdvgn_tracker* t, int B, double* pose7_io, double*
         for (int i = 0; i < 5; ++i) lastResiduals[5 * b + i] = s.lastRes[i];
         for (int i = 0; i < 3; ++i) lastFlow[3 * b + i] = s.flow[i];
         ok[b] = s.ok;
+    }
+    if (getenv("SDVGN_PROFILE")) {
+        const TrackState& s = t->track_host[0];
+        fprintf(stderr, "[sdvgn profile] k_track hyp0: serial %lld cyc, solve %lld cyc, eval %lld cyc over %lld evals, %d trials\n", s.dbg_cycles[0], s.dbg_cycles[1],
+                s.dbg_cycles[2], s.dbg_cycles[3], s.ntrials);
     }
     return SDVGN_OK;
 }

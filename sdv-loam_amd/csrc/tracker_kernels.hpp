@@ -10,10 +10,11 @@
 // Design (MI355X): the reference runs calcRes (scalar loop writing 8 warped planes) and calcGSSSE (SSE loop
 // re-reading them into an in-memory 45x4-lane accumulator).  Here one pass does both: a lane owns a reference
 // point, loads its packed {u,v,idepth,colour} with one coalesced 16-B load, gathers the 2x2 {I,dx,dy} taps of
-// the target level, forms residual / Huber weight / the 8 Jacobian entries in registers and keeps the 45
-// weighted products + energy + counters in 52 VGPRs.  Reduction: DPP row/bcast adds inside the 64-lane wave,
-// one LDS stage across the waves of a workgroup, one float partial row per workgroup; k_finalize adds the
-// partial rows in a fixed order in fp64 (deterministic, no atomics) and emits the scaled 8x8 H, b and the Vec6.
+// the target level and forms residual / Huber weight / the 8 Jacobian entries in registers.  Reduction: the wave
+// stages its 64 rows [J r | E counters flow] as a 16-feature LDS tile and the matrix cores accumulate the weighted Gram
+// (v_mfma_f32_16x16x4_f32, 2 per 4 points) -- no per-lane 45-term accumulator, no shuffle tree; one LDS stage across
+// the waves of a workgroup, one float partial row per workgroup; k_finalize adds the partial rows in a fixed order in
+// fp64 (deterministic, no atomics) and emits the scaled 8x8 H, b and the Vec6.
 //
 // Per-point arithmetic is written operation by operation like the reference and the translation unit is built
 // with -ffp-contract=off, so residuals, weights and Jacobian entries are bit-identical to the CPU path; only
@@ -47,25 +48,6 @@ struct LevelParams {  // everything calcRes/calcGSSSE derive from (lvl, refToNew
     int wl, hl, lvl, n;
 };
 
-// ----------------------------------------------------------------------------------------------------
-// 64-lane sum with DPP: 4 butterfly steps inside each row of 16 lanes, then row_bcast:15 / row_bcast:31.
-// The total lands in lane 63.
-// ----------------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
-    return v + __int_as_float(moved);
-}
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-    v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
-    v = dpp_add<0x140, 0xF>(v);  // row_mirror
-    v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1,3
-    v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2,3
-    return v;
-}
-
 // a9: bilinear {I,dx,dy} with truncating index and the reference's weight/tap order
 __device__ __forceinline__ void interp33(const float* __restrict__ img, float x, float y, int width, float& o0,
                                          float& o1, float& o2) {
@@ -93,11 +75,18 @@ __device__ __forceinline__ void project(const float* M, const float* t, float x,
     else      { p0 = m0 - t[0] * id; p1 = m1 - t[1] * id; p2 = m2 - t[2] * id; }
 }
 
-// One reference point: calcRes body (:517-600) followed by the calcGSSSE body (:444-465) on the values that
-// calcRes would have appended to the warped buffers.  acc[] is the lane's private accumulator row.
+// One reference point: calcRes body (:517-600) followed by the Jacobian row of calcGSSSE (:444-465) on the values that calcRes
+// would have appended to the warped buffers.  Output = the lane's row of the wave's [16 features][64 points] tile:
+//   f[0..7] = J (8 Jacobian entries), f[8] = residual     -- all 0 unless the point is an inlier (st == 1)
+//   f[9] = energy term, f[10] = in-E flag, f[11] = saturated flag, f[12] = in-warped flag, f[13..15] = flow sums (T, RT, count)
+//   w = Huber weight (0 unless st == 1)
 template <bool WRITE_TERMS>
-__device__ __forceinline__ void point_res_gs(const LevelParams& P, const float* __restrict__ img, float4 pc, int i,
-                                             float* acc, float* __restrict__ terms, int* __restrict__ status) {
+__device__ __forceinline__ void point_features(const LevelParams& P, const float* __restrict__ img, float4 pc, int i, bool valid,
+                                               float* f, float& w, float* __restrict__ terms, int* __restrict__ status) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) f[k] = 0.0f;
+    w = 0.0f;
+    if (!valid) return;
     const float x = pc.x, y = pc.y, id = pc.z, refColor = pc.w;
     float p0, p1, p2;
     project(P.RKi, P.t, x, y, id, true, p0, p1, p2);
@@ -115,11 +104,12 @@ __device__ __forceinline__ void point_res_gs(const LevelParams& P, const float* 
         const float KuT2 = P.fx * (q0 / q2) + P.cx, KvT2 = P.fy * (q1 / q2) + P.cy;
         project(P.RKi, P.t, x, y, id, false, q0, q1, q2);
         const float Ku3 = P.fx * (q0 / q2) + P.cx, Kv3 = P.fy * (q1 / q2) + P.cy;
-        acc[kRedFT] += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
-        acc[kRedFT] += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
-        acc[kRedFRT] += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
-        acc[kRedFRT] += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
-        acc[kRedFN] += 2;
+        float fT = 0.0f, fRT = 0.0f;
+        fT += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
+        fT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
+        fRT += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
+        fRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
+        f[13] = fT; f[14] = fRT; f[15] = 2.0f;
     }
 
     int st = 0;
@@ -130,35 +120,27 @@ __device__ __forceinline__ void point_res_gs(const LevelParams& P, const float* 
             residual = hit0 - (float)(P.affLL0 * refColor + P.affLL1);
             const float ar = fabsf(residual);
             hw = ar < P.huber ? 1.0f : P.huber / ar;
+            f[10] = 1.0f;
             if (ar > P.cutoff) {
                 st = 2;
-                acc[kRedE] += P.maxEnergy;
-                acc[kRedNE] += 1;
-                acc[kRedNSat] += 1;
+                f[9] = P.maxEnergy;
+                f[11] = 1.0f;
             } else {
                 st = 1;
-                acc[kRedE] += hw * residual * residual * (2 - hw);
-                acc[kRedNE] += 1;
-                acc[kRedNW] += 1;
+                f[9] = hw * residual * residual * (2 - hw);
+                f[12] = 1.0f;
                 const float dx = hit1 * P.fx;
                 const float dy = hit2 * P.fy;
-                float J[9];
-                J[0] = new_idepth * dx;
-                J[1] = new_idepth * dy;
-                J[2] = 0.0f - new_idepth * (u * dx + v * dy);
-                J[3] = 0.0f - ((u * v) * dx + dy * (1.0f + v * v));
-                J[4] = (u * v) * dy + dx * (1.0f + u * u);
-                J[5] = u * dy - v * dx;
-                J[6] = P.affLL0 * (P.b0 - refColor);
-                J[7] = -1.0f;
-                J[8] = residual;
-                int k = 0;
-#pragma unroll
-                for (int r = 0; r < 9; ++r) {
-                    const float Jw = J[r] * hw;
-#pragma unroll
-                    for (int c = r; c < 9; ++c) { acc[k] += Jw * J[c]; ++k; }
-                }
+                f[0] = new_idepth * dx;
+                f[1] = new_idepth * dy;
+                f[2] = 0.0f - new_idepth * (u * dx + v * dy);
+                f[3] = 0.0f - ((u * v) * dx + dy * (1.0f + v * v));
+                f[4] = (u * v) * dy + dx * (1.0f + u * u);
+                f[5] = u * dy - v * dx;
+                f[6] = P.affLL0 * (P.b0 - refColor);
+                f[7] = -1.0f;
+                f[8] = residual;
+                w = hw;
             }
         }
     }
@@ -177,22 +159,88 @@ __device__ __forceinline__ void point_res_gs(const LevelParams& P, const float* 
     }
 }
 
-// Block-level reduction of the per-lane accumulator rows: thread k < kNRed writes the block total of value k
-// to dst[k].  smem: [nwaves][kNRed] floats.  (Callers must __syncthreads() before reading dst if it is in LDS.)
-template <typename OutT>
-__device__ __forceinline__ void block_reduce_to(float* acc, float* smem, OutT* __restrict__ dst) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+// ----------------------------------------------------------------------------------------------------
+// The 45-term weighted sum of calcGSSSE (Accumulator9) as a Gram matrix on the matrix cores.
+// A wave stages its 64 points as a [16 features][64 points] LDS tile (row stride 66 floats: conflict-free fragment reads),
+// then per 4 points issues two v_mfma_f32_16x16x4_f32:
+//     G  += (w .* F) F^T     upper-left 9x9 = sum_i hw_i [J_i; r_i][J_i; r_i]^T          (A = (J*w), B = J like :1047-1110)
+//     G1 += e0 1^T F^T       row 0 = column sums of F: features 9..15 = E, counters, flow sums
+// The accumulators (2 x 4 VGPRs) persist over all points of the wave, so a lane needs no private 45-term accumulator and the
+// cross-lane reduction is done by the MFMA itself (f32 products, f32 accumulate).
+// Fragment maps (cdna guide section 3): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D: col=l&15, row=4*(l>>4)+reg.
+// ----------------------------------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kTrkTileStride = 66;
+constexpr int kTrkTileFloats = 16 * kTrkTileStride + 64;   // tile + weight row, per wave
+
+__device__ __forceinline__ void wave_gram_points(const float* f, float w, float* tile /*wave-private*/, f32x4_t& G, f32x4_t& G1) {
+    const int lane = threadIdx.x & 63;
+    float* wrow = tile + 16 * kTrkTileStride;
 #pragma unroll
-    for (int k = 0; k < kNRed; ++k) {
-        const float s = wave_sum_to_lane63(acc[k]);
-        if (lane == 63) smem[wave * kNRed + k] = s;
+    for (int k = 0; k < 16; ++k) tile[k * kTrkTileStride + lane] = f[k];
+    wrow[lane] = w;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    const int fi = lane & 15, kq = lane >> 4;
+    const float one = (fi == 0) ? 1.0f : 0.0f;
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+        const int k = ks * 4 + kq;
+        const float fv = tile[fi * kTrkTileStride + k];
+        const float wv = wrow[k];
+        G = __builtin_amdgcn_mfma_f32_16x16x4f32(fv * wv, fv, G, 0, 0, 0);
+        G1 = __builtin_amdgcn_mfma_f32_16x16x4f32(one, fv, G1, 0, 0, 0);
     }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Workgroup-level combine: every wave dumps its two D fragments to LDS, thread k < kNRed adds the waves' entries of value k
+// in a fixed order in fp64 and writes dst[k].  smem: [nwaves][256 + 16] floats (may alias the staging tiles after a barrier).
+template <typename OutT>
+__device__ __forceinline__ void block_gram_reduce_to(const f32x4_t& G, const f32x4_t& G1, float* smem, OutT* __restrict__ dst) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    float* mine = smem + wave * 272;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mine[(4 * (lane >> 4) + r) * 16 + (lane & 15)] = G[r];
+    if (lane < 16) mine[256 + lane] = G1[0];   // row 0 of G1: D row = 4*(lane>>4)+reg -> lanes 0..15, reg 0
     __syncthreads();
     if (threadIdx.x < kNRed) {
+        int off;
+        if (threadIdx.x < kNAcc) {   // upper-triangular (r <= c) index -> (r, c)
+            int k = threadIdx.x, r = 0;
+            while (k >= 9 - r) { k -= 9 - r; ++r; }
+            off = r * 16 + (r + k);
+        } else {
+            off = 256 + 9 + (threadIdx.x - kNAcc);   // E, nE, nSat, nW, flowT, flowRT, flowN = features 9..15
+        }
         double s = 0;
-        for (int w = 0; w < nwaves; ++w) s += (double)smem[w * kNRed + threadIdx.x];
+        for (int wv = 0; wv < nwaves; ++wv) s += (double)smem[wv * 272 + off];
         dst[threadIdx.x] = (OutT)s;
     }
+}
+
+// grid = (chunks, B).  params[b] describes problem b (pose/affine specific); all problems share the reference
+// points `pc` and the target level image `img`.  partial: [B][chunks][kNRed] floats.
+template <bool WRITE_TERMS>
+__global__ void __launch_bounds__(256) k_res_gs(const float4* __restrict__ pc, const float* __restrict__ img,
+                                                const LevelParams* __restrict__ params, float* __restrict__ partial,
+                                                float* __restrict__ terms, int* __restrict__ status) {
+    __shared__ float smem[4 * kTrkTileFloats];
+    const LevelParams P = params[blockIdx.y];
+    const int wave = threadIdx.x >> 6;
+    float* tile = smem + wave * kTrkTileFloats;
+    f32x4_t G = {0, 0, 0, 0}, G1 = {0, 0, 0, 0};
+    const int stride = gridDim.x * blockDim.x;
+    // wave-uniform trip count: every lane of a wave takes part in every MFMA round (out-of-range lanes contribute zeros)
+    for (int base = blockIdx.x * blockDim.x; base < P.n; base += stride) {
+        const int i = base + threadIdx.x;
+        const bool valid = i < P.n;
+        float f[16], w;
+        point_features<WRITE_TERMS>(P, img, valid ? pc[i] : make_float4(0, 0, 0, 0), i, valid, f, w, terms, status);
+        wave_gram_points(f, w, tile, G, G1);
+    }
+    __syncthreads();   // staging tiles are dead: reuse smem for the combine
+    block_gram_reduce_to<float>(G, G1, smem, partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kNRed);
 }
 
 // Tail of calcGSSSE (:468-483: 1/n, cast to double, SCALE_* on rows and columns) and of calcRes (:625-633: the Vec6)
@@ -225,22 +273,6 @@ __device__ __forceinline__ void finalize_outputs(const double* S, int tid, doubl
         o[78] = nW;
         o[79] = n;
     }
-}
-
-// grid = (chunks, B).  params[b] describes problem b (pose/affine specific); all problems share the reference
-// points `pc` and the target level image `img`.  partial: [B][chunks][kNRed] floats.
-template <bool WRITE_TERMS>
-__global__ void __launch_bounds__(256) k_res_gs(const float4* __restrict__ pc, const float* __restrict__ img,
-                                                const LevelParams* __restrict__ params, float* __restrict__ partial,
-                                                float* __restrict__ terms, int* __restrict__ status) {
-    __shared__ float smem[4 * kNRed];
-    const LevelParams P = params[blockIdx.y];
-    float acc[kNRed];
-#pragma unroll
-    for (int k = 0; k < kNRed; ++k) acc[k] = 0.0f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += gridDim.x * blockDim.x)
-        point_res_gs<WRITE_TERMS>(P, img, pc[i], i, acc, terms, status);
-    block_reduce_to<float>(acc, smem, partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kNRed);
 }
 
 // Deterministic fp64 combine of the partial rows + the tail of calcGSSSE (:468-483) and calcRes (:625-633).
