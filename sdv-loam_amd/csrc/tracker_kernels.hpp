@@ -78,7 +78,8 @@ __device__ __forceinline__ void project(const float* M, const float* t, float x,
 // One reference point: calcRes body (:517-600) followed by the Jacobian row of calcGSSSE (:444-465) on the values that calcRes
 // would have appended to the warped buffers.  Output = the lane's row of the wave's [16 features][64 points] tile:
 //   f[0..7] = J (8 Jacobian entries), f[8] = residual     -- all 0 unless the point is an inlier (st == 1)
-//   f[9] = energy term, f[10] = in-E flag, f[11] = saturated flag, f[12] = in-warped flag, f[13..15] = flow sums (T, RT, count)
+//   f[9] = energy term, f[10] = saturated flag, f[11] = in-warped flag (numTermsInE = their sum), f[12..14] = flow sums (T, RT, count),
+//   f[15] = 0 (row 15 of the A operand is the constant 1 that turns the Gram's last row into the column sums)
 //   w = Huber weight (0 unless st == 1)
 template <bool WRITE_TERMS>
 __device__ __forceinline__ void point_features(const LevelParams& P, const float* __restrict__ img, float4 pc, int i, bool valid,
@@ -109,7 +110,7 @@ __device__ __forceinline__ void point_features(const LevelParams& P, const float
         fT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
         fRT += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
         fRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
-        f[13] = fT; f[14] = fRT; f[15] = 2.0f;
+        f[12] = fT; f[13] = fRT; f[14] = 2.0f;
     }
 
     int st = 0;
@@ -120,15 +121,14 @@ __device__ __forceinline__ void point_features(const LevelParams& P, const float
             residual = hit0 - (float)(P.affLL0 * refColor + P.affLL1);
             const float ar = fabsf(residual);
             hw = ar < P.huber ? 1.0f : P.huber / ar;
-            f[10] = 1.0f;
             if (ar > P.cutoff) {
                 st = 2;
                 f[9] = P.maxEnergy;
-                f[11] = 1.0f;
+                f[10] = 1.0f;
             } else {
                 st = 1;
                 f[9] = hw * residual * residual * (2 - hw);
-                f[12] = 1.0f;
+                f[11] = 1.0f;
                 const float dx = hit1 * P.fx;
                 const float dy = hit2 * P.fy;
                 f[0] = new_idepth * dx;
@@ -162,10 +162,10 @@ __device__ __forceinline__ void point_features(const LevelParams& P, const float
 // ----------------------------------------------------------------------------------------------------
 // The 45-term weighted sum of calcGSSSE (Accumulator9) as a Gram matrix on the matrix cores.
 // A wave stages its 64 points as a [16 features][64 points] LDS tile (row stride 66 floats: conflict-free fragment reads),
-// then per 4 points issues two v_mfma_f32_16x16x4_f32:
-//     G  += (w .* F) F^T     upper-left 9x9 = sum_i hw_i [J_i; r_i][J_i; r_i]^T          (A = (J*w), B = J like :1047-1110)
-//     G1 += e0 1^T F^T       row 0 = column sums of F: features 9..15 = E, counters, flow sums
-// The accumulators (2 x 4 VGPRs) persist over all points of the wave, so a lane needs no private 45-term accumulator and the
+// then per 4 points issues ONE v_mfma_f32_16x16x4_f32  G += A F^T  with  A = [w .* F (rows 0..14) ; 1 (row 15)]:
+//     rows/cols 0..8 : sum_i hw_i [J_i; r_i][J_i; r_i]^T            (A = (J*w), B = J like MatrixAccumulators.h:1047-1110)
+//     row 15         : column sums of F: features 9..14 = E, nSat, nWarped, flow sums (unweighted)
+// The accumulator (4 VGPRs) persists over all points of the wave, so a lane needs no private 45-term accumulator and the
 // cross-lane reduction is done by the MFMA itself (f32 products, f32 accumulate).
 // Fragment maps (cdna guide section 3): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D: col=l&15, row=4*(l>>4)+reg.
 // ----------------------------------------------------------------------------------------------------
@@ -173,7 +173,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int kTrkTileStride = 66;
 constexpr int kTrkTileFloats = 16 * kTrkTileStride + 64;   // tile + weight row, per wave
 
-__device__ __forceinline__ void wave_gram_points(const float* f, float w, float* tile /*wave-private*/, f32x4_t& G, f32x4_t& G1) {
+__device__ __forceinline__ void wave_gram_points(const float* f, float w, float* tile /*wave-private*/, f32x4_t& G) {
     const int lane = threadIdx.x & 63;
     float* wrow = tile + 16 * kTrkTileStride;
 #pragma unroll
@@ -182,39 +182,42 @@ __device__ __forceinline__ void wave_gram_points(const float* f, float w, float*
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed
     __builtin_amdgcn_wave_barrier();
     const int fi = lane & 15, kq = lane >> 4;
-    const float one = (fi == 0) ? 1.0f : 0.0f;
 #pragma unroll 4
     for (int ks = 0; ks < 16; ++ks) {
         const int k = ks * 4 + kq;
         const float fv = tile[fi * kTrkTileStride + k];
-        const float wv = wrow[k];
-        G = __builtin_amdgcn_mfma_f32_16x16x4f32(fv * wv, fv, G, 0, 0, 0);
-        G1 = __builtin_amdgcn_mfma_f32_16x16x4f32(one, fv, G1, 0, 0, 0);
+        const float av = (fi == 15) ? 1.0f : fv * wrow[k];
+        G = __builtin_amdgcn_mfma_f32_16x16x4f32(av, fv, G, 0, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
 }
 
-// Workgroup-level combine: every wave dumps its two D fragments to LDS, thread k < kNRed adds the waves' entries of value k
-// in a fixed order in fp64 and writes dst[k].  smem: [nwaves][256 + 16] floats (may alias the staging tiles after a barrier).
+// Workgroup-level combine: every wave dumps its D fragment to LDS, thread k < kNRed adds the waves' entries of value k in a
+// fixed order in fp64 and writes dst[k].  smem: [nwaves][256] floats (may alias the staging tiles after a barrier).
 template <typename OutT>
-__device__ __forceinline__ void block_gram_reduce_to(const f32x4_t& G, const f32x4_t& G1, float* smem, OutT* __restrict__ dst) {
+__device__ __forceinline__ void block_gram_reduce_to(const f32x4_t& G, float* smem, OutT* __restrict__ dst) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    float* mine = smem + wave * 272;
+    float* mine = smem + wave * 256;
 #pragma unroll
     for (int r = 0; r < 4; ++r) mine[(4 * (lane >> 4) + r) * 16 + (lane & 15)] = G[r];
-    if (lane < 16) mine[256 + lane] = G1[0];   // row 0 of G1: D row = 4*(lane>>4)+reg -> lanes 0..15, reg 0
     __syncthreads();
     if (threadIdx.x < kNRed) {
-        int off;
+        int off, off2 = -1;
         if (threadIdx.x < kNAcc) {   // upper-triangular (r <= c) index -> (r, c)
             int k = threadIdx.x, r = 0;
             while (k >= 9 - r) { k -= 9 - r; ++r; }
             off = r * 16 + (r + k);
         } else {
-            off = 256 + 9 + (threadIdx.x - kNAcc);   // E, nE, nSat, nW, flowT, flowRT, flowN = features 9..15
+            // row 15 = column sums.  kRedE..kRedFN = E, nE (= nSat + nW), nSat, nW, flowT, flowRT, flowN
+            const int col[7] = {9, 10, 10, 11, 12, 13, 14};
+            off = 15 * 16 + col[threadIdx.x - kNAcc];
+            if (threadIdx.x == kRedNE) off2 = 15 * 16 + 11;
         }
         double s = 0;
-        for (int wv = 0; wv < nwaves; ++wv) s += (double)smem[wv * 272 + off];
+        for (int wv = 0; wv < nwaves; ++wv) {
+            s += (double)smem[wv * 256 + off];
+            if (off2 >= 0) s += (double)smem[wv * 256 + off2];
+        }
         dst[threadIdx.x] = (OutT)s;
     }
 }
@@ -229,7 +232,7 @@ __global__ void __launch_bounds__(256) k_res_gs(const float4* __restrict__ pc, c
     const LevelParams P = params[blockIdx.y];
     const int wave = threadIdx.x >> 6;
     float* tile = smem + wave * kTrkTileFloats;
-    f32x4_t G = {0, 0, 0, 0}, G1 = {0, 0, 0, 0};
+    f32x4_t G = {0, 0, 0, 0};
     const int stride = gridDim.x * blockDim.x;
     // wave-uniform trip count: every lane of a wave takes part in every MFMA round (out-of-range lanes contribute zeros)
     for (int base = blockIdx.x * blockDim.x; base < P.n; base += stride) {
@@ -237,10 +240,10 @@ __global__ void __launch_bounds__(256) k_res_gs(const float4* __restrict__ pc, c
         const bool valid = i < P.n;
         float f[16], w;
         point_features<WRITE_TERMS>(P, img, valid ? pc[i] : make_float4(0, 0, 0, 0), i, valid, f, w, terms, status);
-        wave_gram_points(f, w, tile, G, G1);
+        wave_gram_points(f, w, tile, G);
     }
     __syncthreads();   // staging tiles are dead: reuse smem for the combine
-    block_gram_reduce_to<float>(G, G1, smem, partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kNRed);
+    block_gram_reduce_to<float>(G, smem, partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kNRed);
 }
 
 // Tail of calcGSSSE (:468-483: 1/n, cast to double, SCALE_* on rows and columns) and of calcRes (:625-633: the Vec6)
