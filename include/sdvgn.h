@@ -51,6 +51,11 @@ void sdvgn_tracker_destroy(sdvgn_tracker* t);
 int sdvgn_tracker_set_settings(sdvgn_tracker* t, float huberTH, float coarseCutoffTH, float affineOptModeA,
                                float affineOptModeB);
 
+/* Tolerance study of BASELINE.json configs[4] (not a reference feature): 0 = fp32 (default, the product path),
+ * 1 = fp16 pyramid, 2 = + fp16 Jacobian/residual operands, 3 = + fp16 accumulation.  Affects calc_gs / res_and_gs /
+ * track (host-driven) only; calc_res (parity hook) and track_batch always run in fp32. */
+int sdvgn_tracker_set_precision(sdvgn_tracker* t, int mode);
+
 /* CoarseTracker::makeK(CalibHessian*)   CoarseTracker.cpp:77-106  (level-0 fx,fy,cx,cy = HCalib->fxl()...) */
 int sdvgn_tracker_make_K(sdvgn_tracker* t, float fx, float fy, float cx, float cy);
 int sdvgn_tracker_get_K(sdvgn_tracker* t, int lvl, float fxfycxcy[4], float Ki9[9]);

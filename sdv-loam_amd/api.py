@@ -24,6 +24,7 @@ PROTOTYPES = [
     ("sdvgn_tracker_create", C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     ("sdvgn_tracker_destroy", None, [vp]),
     ("sdvgn_tracker_set_settings", C.c_int, [vp, C.c_float, C.c_float, C.c_float, C.c_float]),
+    ("sdvgn_tracker_set_precision", C.c_int, [vp, C.c_int]),
     ("sdvgn_tracker_make_K", C.c_int, [vp, C.c_float, C.c_float, C.c_float, C.c_float]),
     ("sdvgn_tracker_get_K", C.c_int, [vp, C.c_int, f32p, f32p]),
     ("sdvgn_tracker_set_ref", C.c_int, [vp, C.c_int, C.c_int, f32p, f32p, f32p, f32p]),
@@ -114,6 +115,9 @@ class CoarseTracker:
     # -- configuration ------------------------------------------------------------------------------
     def set_settings(self, huber=6.0, cutoff=20.0, aff_a=0.0, aff_b=0.0):
         check(self.L.sdvgn_tracker_set_settings(self.h_, huber, cutoff, aff_a, aff_b))
+
+    def set_precision(self, mode):
+        check(self.L.sdvgn_tracker_set_precision(self.h_, mode))
 
     def makeK(self, fx, fy, cx, cy):
         check(self.L.sdvgn_tracker_make_K(self.h_, fx, fy, cx, cy))

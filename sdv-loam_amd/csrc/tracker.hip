@@ -52,6 +52,9 @@ struct sdvgn_tracker {
 
     // new frame
     float* pyr_dev[SDVGN_MAX_LEVELS] = {};  // AoS {I,dx,dy}
+    __half* pyr_half_dev[SDVGN_MAX_LEVELS] = {};  // precision study only: fp16 {I,dx,dy,0}, built lazily
+    bool half_valid = false;
+    int precision = PREC_F32;
     float* img_stage_dev = nullptr;         // level-0 float image staging
     float new_exposure = 1.f;
     bool haveNew = false;
@@ -118,7 +121,22 @@ static int launch_res_gs(sdvgn_tracker* t, int lvl, int B, const double* pose7, 
     const int n = t->pc_n[lvl];
     const int chunks = chunks_for(t, n, B);
     dim3 grid(chunks, B), block(256);
-    if (write_terms) {
+    if (t->precision != PREC_F32) {
+        // tolerance study (configs[4]): same kernel on an fp16 pyramid / fp16 operands / fp16 accumulator
+        if (write_terms) return SDVGN_E_ARG;
+        if (!t->half_valid) {
+            for (int l = 0; l < t->levels; ++l) {
+                const int npix = t->w[l] * t->h[l];
+                if (!t->pyr_half_dev[l]) HIPCHK(hipMalloc(&t->pyr_half_dev[l], sizeof(__half) * 4 * (size_t)npix));
+                k_pyr_to_half<<<(npix + 255) / 256, 256, 0, t->stream>>>(t->pyr_dev[l], t->pyr_half_dev[l], npix);
+            }
+            t->half_valid = true;
+        }
+        const float* himg = reinterpret_cast<const float*>(t->pyr_half_dev[lvl]);
+        if (t->precision == PREC_H_PYR) k_res_gs<false, PREC_H_PYR><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], himg, t->params_dev, t->partial_dev, nullptr, nullptr);
+        else if (t->precision == PREC_H_OPER) k_res_gs<false, PREC_H_OPER><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], himg, t->params_dev, t->partial_dev, nullptr, nullptr);
+        else k_res_gs<false, PREC_H_ACC><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], himg, t->params_dev, t->partial_dev, nullptr, nullptr);
+    } else if (write_terms) {
         k_res_gs<true><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], t->pyr_dev[lvl], t->params_dev, t->partial_dev,
                                                       t->terms_dev, t->status_dev);
         t->terms_lvl = lvl;
@@ -267,7 +285,7 @@ void sdvgn_tracker_destroy(sdvgn_tracker* t) {
     if (!t) return;
     hipSetDevice(t->device);
     hipStreamSynchronize(t->stream);
-    for (int l = 0; l < t->levels; ++l) { hipFree(t->pc_dev[l]); hipFree(t->pyr_dev[l]); }
+    for (int l = 0; l < t->levels; ++l) { hipFree(t->pc_dev[l]); hipFree(t->pyr_dev[l]); if (t->pyr_half_dev[l]) hipFree(t->pyr_half_dev[l]); }
     hipFree(t->img_stage_dev); hipFree(t->params_dev); hipHostFree(t->params_host); hipFree(t->partial_dev);
     hipFree(t->out_dev); hipHostFree(t->out_host); hipFree(t->terms_dev); hipFree(t->status_dev);
     hipFree(t->track_dev); hipHostFree(t->track_host); hipFree(t->tconst_dev);
@@ -280,6 +298,12 @@ void* sdvgn_tracker_stream(sdvgn_tracker* t) { return t ? (void*)t->stream : nul
 int sdvgn_tracker_set_settings(sdvgn_tracker* t, float huberTH, float coarseCutoffTH, float affA, float affB) {
     if (!t) return SDVGN_E_ARG;
     t->huberTH = huberTH; t->coarseCutoffTH = coarseCutoffTH; t->affineOptModeA = affA; t->affineOptModeB = affB;
+    return SDVGN_OK;
+}
+
+int sdvgn_tracker_set_precision(sdvgn_tracker* t, int mode) {
+    if (!t || mode < 0 || mode > 3) return SDVGN_E_ARG;
+    t->precision = mode;
     return SDVGN_OK;
 }
 
@@ -346,7 +370,7 @@ int sdvgn_tracker_set_new_image(sdvgn_tracker* t, const float* image, float expo
     int rc = build_pyramid(t, t->img_stage_dev);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(t->stream));  // `image` may be pageable: do not return before the copy is done
-    t->new_exposure = exposure; t->haveNew = true;
+    t->new_exposure = exposure; t->haveNew = true; t->half_valid = false;
     return SDVGN_OK;
 }
 
@@ -355,7 +379,7 @@ int sdvgn_tracker_set_new_image_dev(sdvgn_tracker* t, const float* image_dev, fl
     HIPCHK(hipSetDevice(t->device));
     int rc = build_pyramid(t, image_dev);
     if (rc) return rc;
-    t->new_exposure = exposure; t->haveNew = true;
+    t->new_exposure = exposure; t->haveNew = true; t->half_valid = false;
     return SDVGN_OK;
 }
 
@@ -364,7 +388,7 @@ int sdvgn_tracker_set_new_pyr(sdvgn_tracker* t, int lvl, const float* aos3, floa
     HIPCHK(hipSetDevice(t->device));
     HIPCHK(hipMemcpyAsync(t->pyr_dev[lvl], aos3, sizeof(float) * 3 * (size_t)t->w[lvl] * t->h[lvl], hipMemcpyHostToDevice, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
-    t->new_exposure = exposure; t->haveNew = true;
+    t->new_exposure = exposure; t->haveNew = true; t->half_valid = false;
     return SDVGN_OK;
 }
 

@@ -20,11 +20,20 @@
 // with -ffp-contract=off, so residuals, weights and Jacobian entries are bit-identical to the CPU path; only
 // the order of the sums differs (tree instead of sequential/tiered).
 #pragma once
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
 
 namespace sdvgn {
+
+// Precision modes of the tolerance study (BASELINE.json configs[4]); mode 0 is the product path, the others exist only
+// to measure what reduced precision would cost (tests/test_fp16_study_gpu.py).
+//   0  fp32 pyramid, fp32 arithmetic, fp32 MFMA accumulation (reference-faithful)
+//   1  fp16 pyramid {I,dx,dy,0} (8 B/px, one 8-B load per tap), everything else fp32
+//   2  mode 1 + Jacobian/residual operands rounded to fp16 before the Gram (== f16-input MFMA, fp32 accumulate)
+//   3  mode 2 + the Gram accumulator rounded to fp16 after every 4-point MFMA step ("fp16 residual accumulation")
+enum { PREC_F32 = 0, PREC_H_PYR = 1, PREC_H_OPER = 2, PREC_H_ACC = 3 };
 
 constexpr int kNAcc = 45;                 // upper triangle of the 9x9 [J r][J r]^T
 constexpr int kNRed = 52;                 // 45 + E + nE + nSat + nWarped + flowT + flowRT + flowNum
@@ -66,6 +75,23 @@ __device__ __forceinline__ void interp33(const float* __restrict__ img, float x,
     o2 = ((w11 * d2 + w01 * c2) + w10 * b2) + w00 * a2;
 }
 
+// mode >= 1: the same bilinear formula on an fp16 {I,dx,dy,pad} pyramid (values widen to fp32 before the arithmetic)
+__device__ __forceinline__ void interp33_h(const __half* __restrict__ img4, float x, float y, int width, float& o0, float& o1, float& o2) {
+    const int ix = (int)x;
+    const int iy = (int)y;
+    const float dx = x - ix;
+    const float dy = y - iy;
+    const float dxdy = dx * dy;
+    const uint2* bp = reinterpret_cast<const uint2*>(img4) + (ix + iy * width);
+    const uint2 ra = bp[0], rb = bp[1], rc = bp[width], rd = bp[width + 1];
+    auto lo = [](unsigned v) { return __half2float(__ushort_as_half((unsigned short)(v & 0xffffu))); };
+    auto hi = [](unsigned v) { return __half2float(__ushort_as_half((unsigned short)(v >> 16))); };
+    const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+    o0 = ((w11 * lo(rd.x) + w01 * lo(rc.x)) + w10 * lo(rb.x)) + w00 * lo(ra.x);
+    o1 = ((w11 * hi(rd.x) + w01 * hi(rc.x)) + w10 * hi(rb.x)) + w00 * hi(ra.x);
+    o2 = ((w11 * lo(rd.y) + w01 * lo(rc.y)) + w10 * lo(rb.y)) + w00 * lo(ra.y);
+}
+
 __device__ __forceinline__ void project(const float* M, const float* t, float x, float y, float id, bool plus,
                                         float& p0, float& p1, float& p2) {
     const float m0 = (M[0] * x + M[1] * y) + M[2] * 1.0f;
@@ -81,7 +107,7 @@ __device__ __forceinline__ void project(const float* M, const float* t, float x,
 //   f[9] = energy term, f[10] = saturated flag, f[11] = in-warped flag (numTermsInE = their sum), f[12..14] = flow sums (T, RT, count),
 //   f[15] = 0 (row 15 of the A operand is the constant 1 that turns the Gram's last row into the column sums)
 //   w = Huber weight (0 unless st == 1)
-template <bool WRITE_TERMS>
+template <bool WRITE_TERMS, int MODE = PREC_F32>
 __device__ __forceinline__ void point_features(const LevelParams& P, const float* __restrict__ img, float4 pc, int i, bool valid,
                                                float* f, float& w, float* __restrict__ terms, int* __restrict__ status) {
 #pragma unroll
@@ -116,7 +142,8 @@ __device__ __forceinline__ void point_features(const LevelParams& P, const float
     int st = 0;
     float hit0 = 0, hit1 = 0, hit2 = 0, residual = 0, hw = 0;
     if (Ku > 2 && Kv > 2 && Ku < P.wl - 3 && Kv < P.hl - 3 && new_idepth > 0) {
-        interp33(img, Ku, Kv, P.wl, hit0, hit1, hit2);
+        if (MODE == PREC_F32) interp33(img, Ku, Kv, P.wl, hit0, hit1, hit2);
+        else interp33_h(reinterpret_cast<const __half*>(img), Ku, Kv, P.wl, hit0, hit1, hit2);
         if (isfinite(hit0)) {
             residual = hit0 - (float)(P.affLL0 * refColor + P.affLL1);
             const float ar = fabsf(residual);
@@ -141,6 +168,10 @@ __device__ __forceinline__ void point_features(const LevelParams& P, const float
                 f[7] = -1.0f;
                 f[8] = residual;
                 w = hw;
+                if (MODE >= PREC_H_OPER) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) f[k] = __half2float(__float2half(f[k]));
+                }
             }
         }
     }
@@ -173,6 +204,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int kTrkTileStride = 66;
 constexpr int kTrkTileFloats = 16 * kTrkTileStride + 64;   // tile + weight row, per wave
 
+template <int MODE = PREC_F32>
 __device__ __forceinline__ void wave_gram_points(const float* f, float w, float* tile /*wave-private*/, f32x4_t& G) {
     const int lane = threadIdx.x & 63;
     float* wrow = tile + 16 * kTrkTileStride;
@@ -188,6 +220,10 @@ __device__ __forceinline__ void wave_gram_points(const float* f, float w, float*
         const float fv = tile[fi * kTrkTileStride + k];
         const float av = (fi == 15) ? 1.0f : fv * wrow[k];
         G = __builtin_amdgcn_mfma_f32_16x16x4f32(av, fv, G, 0, 0, 0);
+        if (MODE == PREC_H_ACC) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) G[q] = __half2float(__float2half(G[q]));
+        }
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -224,7 +260,7 @@ __device__ __forceinline__ void block_gram_reduce_to(const f32x4_t& G, float* sm
 
 // grid = (chunks, B).  params[b] describes problem b (pose/affine specific); all problems share the reference
 // points `pc` and the target level image `img`.  partial: [B][chunks][kNRed] floats.
-template <bool WRITE_TERMS>
+template <bool WRITE_TERMS, int MODE = PREC_F32>
 __global__ void __launch_bounds__(256) k_res_gs(const float4* __restrict__ pc, const float* __restrict__ img,
                                                 const LevelParams* __restrict__ params, float* __restrict__ partial,
                                                 float* __restrict__ terms, int* __restrict__ status) {
@@ -239,8 +275,8 @@ __global__ void __launch_bounds__(256) k_res_gs(const float4* __restrict__ pc, c
         const int i = base + threadIdx.x;
         const bool valid = i < P.n;
         float f[16], w;
-        point_features<WRITE_TERMS>(P, img, valid ? pc[i] : make_float4(0, 0, 0, 0), i, valid, f, w, terms, status);
-        wave_gram_points(f, w, tile, G);
+        point_features<WRITE_TERMS, MODE>(P, img, valid ? pc[i] : make_float4(0, 0, 0, 0), i, valid, f, w, terms, status);
+        wave_gram_points<MODE>(f, w, tile, G);
     }
     __syncthreads();   // staging tiles are dead: reuse smem for the combine
     block_gram_reduce_to<float>(G, smem, partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kNRed);
@@ -329,6 +365,16 @@ static __global__ void __launch_bounds__(256) k_pyr_level(const float* __restric
     }
     if (has_next && qx < wn && qy < hn)
         aos_next[3 * (qx + qy * wn)] = 0.25f * (((Iq[0] + Iq[1]) + Iq[2]) + Iq[3]);
+}
+
+// fp16 copy of one pyramid level for the precision study: AoS float3 -> half4 {I,dx,dy,0}
+static __global__ void __launch_bounds__(256) k_pyr_to_half(const float* __restrict__ aos3, __half* __restrict__ out4, int npix) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    out4[4 * i + 0] = __float2half(aos3[3 * i + 0]);
+    out4[4 * i + 1] = __float2half(aos3[3 * i + 1]);
+    out4[4 * i + 2] = __float2half(aos3[3 * i + 2]);
+    out4[4 * i + 3] = __float2half(0.0f);
 }
 
 }  // namespace sdvgn
