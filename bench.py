@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=2048, help="LM trials per launch for the batched tracker roofline run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--quick", action="store_true", help="skip the tracker extras")
+    ap.add_argument("--quick", action="store_true", help="skip the tracker extras and the PMC traffic passes")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -108,6 +109,48 @@ def cpu_baseline_backend(W, budget_s=12.0):
     return dict(value=its / tt, unit="GN iters/s", cores=1, kind="port",
                 sample="%d optimize-loop bodies (8 KF x 2000 pts, 112000 residuals) in %.1f s on 1 host thread; "
                        "host has %d logical CPUs" % (its, tt, os.cpu_count()))
+
+
+def pmc_child():
+    """Body of the profiled child process: the window is loaded and k_ef_linearize is launched 20 times."""
+    import torch  # noqa: F401
+    W, G = backend_setup(0)
+    for _ in range(20):
+        G.linearizeAll(want_energy=False)
+    torch.cuda.synchronize()
+
+
+def measure_traffic(kernel="k_ef_linearize", timeout=240):
+    """HBM-side bytes per launch of `kernel` from rocprofv3 PMC counters, two separate passes (FETCH_SIZE, WRITE_SIZE; the TCC
+    block cannot hold both), corrected as MI355X_MICROARCH.md prescribes and as profiles/r01_counter_calibration.txt confirms
+    for this project's access patterns: FETCH_SIZE x2 (128-B requests are tallied at 64 B), WRITE_SIZE x1, KiB -> bytes.
+    Returns (bytes_per_launch, detail) or (None, reason)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="sdvgn_pmc_", dir="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--pmc-child"],
+                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            con = sqlite3.connect(dbs[0])
+            row = con.execute("select avg(value), count(*) from counters_collection where counter_name=? and kernel_name like ?",
+                              (ctr, "%" + kernel + "%")).fetchone()
+            vals[ctr] = (float(row[0]), int(row[1]))
+            shutil.rmtree(d, ignore_errors=True)
+        fetch = vals["FETCH_SIZE"][0] * 1024.0 * 2.0
+        write = vals["WRITE_SIZE"][0] * 1024.0
+        return fetch + write, "FETCH_SIZE %.0f KiB x2 + WRITE_SIZE %.0f KiB x1 per launch (avg of %d launches, separate --pmc passes)" % (
+            vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0], vals["FETCH_SIZE"][1])
+    except Exception as ex:  # noqa: BLE001
+        return None, "PMC pass failed: %r" % (ex,)
 
 
 def tracker_extras(torch, local, batch, oracle, want_cpu):
@@ -184,6 +227,9 @@ def tracker_extras(torch, local, batch, oracle, want_cpu):
 
 def main():
     args = parse()
+    if args.pmc_child:
+        pmc_child()
+        return
     import torch
     rank, local, world = dist_setup()
     K, Wm = args.steps, args.warmup
@@ -235,6 +281,10 @@ def main():
         "roofline": roof,
         "kernel_ms": {"linearizeAll": ms_lin, "accumulate(point+top+sc+reduce)": ms_acc},
     }
+    if rank == 0 and world == 1 and not args.quick:
+        traffic, how = measure_traffic()
+        roof["traffic"] = traffic
+        roof["traffic_note"] = how
     if rank == 0 and not args.quick:
         import oracle
         out["tracker"] = tracker_extras(torch, local, args.batch, oracle, not args.no_cpu)
