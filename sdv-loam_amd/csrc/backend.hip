@@ -814,7 +814,7 @@ int sdvgn_ef_linearize_all(sdvgn_ef* e, double* energy_out) {
     const int pairs = e->nF * e->nF;
     k_ef_linearize<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
     double* edst = e->stats_dev;
-    k_ef_sum_energy<<<1, 256, 0, e->stream>>>(e->energy_partial, chunks * pairs, edst);
+    if (energy_out) k_ef_sum_energy<<<1, 256, 0, e->stream>>>(e->energy_partial, chunks * pairs, edst);   // NULL: leave the per-workgroup partials
     HIPCHK(hipGetLastError());
     if (energy_out) {
         HIPCHK(hipMemcpyAsync(e->acc_host, edst, sizeof(double), hipMemcpyDeviceToHost, e->stream));
