@@ -193,6 +193,15 @@ def tracker_extras(torch, local, batch, oracle, want_cpu):
         for _ in range(20):
             G.trackBatch(starts, affs, 3)
         out["track_call_device_resident_B%d_ms" % B] = 1e3 * (time.perf_counter() - t0) / 20
+    # (ii-b) PCIe-inclusive: a new frame handed over as a host buffer (H2D of w*h floats + 4 pyramid launches) followed by one
+    # device-resident track -- what a caller that does not keep images on the device pays per frame.  Never the headline value.
+    st1 = start[None].copy()
+    af1 = np.array([[0.02, 2.0]])
+    t0 = time.perf_counter()
+    for _ in range(20):
+        G.set_new_image(P.image, 1.0)
+        G.trackBatch(st1, af1, 3)
+    out["frame_upload_pyramid_track_ms_pcie_inclusive"] = 1e3 * (time.perf_counter() - t0) / 20
     # (iii) batched roofline run of the fused tracker kernel
     poses = np.stack([oracle.se3_mul(oracle.se3_exp(syn.perturbation(1000 + i)), P.gt_pose) for i in range(batch)])
     affs = np.tile([0.02, 2.0], (batch, 1))

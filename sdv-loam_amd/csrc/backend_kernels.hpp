@@ -108,26 +108,40 @@ __device__ __forceinline__ void interp33_b(const float* __restrict__ img, float 
 __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
                                                       double* __restrict__ energy_partial) {
     __shared__ double s_e[4];
-    const int pair = blockIdx.y;
+    int pair = blockIdx.y, chunk = blockIdx.x;
+    if (C.nF == 8 && !(C.debug_flags & 4)) {
+        // XCD-aware mapping: workgroups go round-robin to the 8 XCDs by linear id, so id % 8 is the XCD.  Let XCD x linearise
+        // every residual whose TARGET is frame x: its 4 MB L2 then only ever gathers from one 5.6 MB image instead of all 8
+        // (measured: -17 % kernel time, profiles/r01_linearize_experiments.txt).
+        const int id = blockIdx.x + gridDim.x * blockIdx.y;
+        const int tt = id % 8, rest = id / 8;
+        pair = (rest / gridDim.x) * C.nF + tt; chunk = rest % gridDim.x;
+    }
     const int h = pair / C.nF, t = pair % C.nF;
     const PrecalcDev pc = precalc[pair];
-    const int pl = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pl = chunk * blockDim.x + threadIdx.x;
     double my_e = 0.0;
     if (h != t && pl < pc.np) {
         const int p = pc.P0 + pl;
         const size_t slots = (size_t)C.nF * C.nP;
         const size_t s = (size_t)t * C.nP + p;
+        // round trip 1: every per-slot / per-point input of this lane in one batch of independent loads (the dense table
+        // has storage behind every slot, so the loads need no flag test); the flag-dependent work starts after them.
         const uint8_t fl = A.rflags[s];
+        const int st = A.rstate[s];
+        const float pu = A.pu[p], pv = A.pv[p], idz = A.pidz[p], ids = A.pid[p];
+        const float4 c0 = A.pcolor[2 * p], c1 = A.pcolor[2 * p + 1];
+        const float4 w0 = A.pweights[2 * p], w1 = A.pweights[2 * p + 1];
+        const float2 m = A.rmatcher[s];
+        const float e_prev = A.renergy[s];
+        __builtin_amdgcn_sched_barrier(0);
         if ((fl & RF_EXISTS) && !(fl & RF_LINEARIZED)) {
             A.renergy_wo[s] = -1.0f;
-            const int st = A.rstate[s];
             bool oob = (st == RS_OOB) || !(fl & RF_MATCHER);
             float Ku = 0, Kv = 0, u = 0, v = 0, drescale = 0, new_idepth = 0, KliP0 = 0, KliP1 = 0;
-            const float pu = A.pu[p], pv = A.pv[p];
             if (!oob) {
                 KliP0 = (pu + 0 - C.cxl) * C.fxli;
                 KliP1 = (pv + 0 - C.cyl) * C.fyli;
-                const float idz = A.pidz[p];
                 const float q0 = ((pc.R0[0] * KliP0 + pc.R0[1] * KliP1) + pc.R0[2] * 1.0f) + pc.t0[0] * idz;
                 const float q1 = ((pc.R0[3] * KliP0 + pc.R0[4] * KliP1) + pc.R0[5] * 1.0f) + pc.t0[1] * idz;
                 const float q2 = ((pc.R0[6] * KliP0 + pc.R0[7] * KliP1) + pc.R0[8] * 1.0f) + pc.t0[2] * idz;
@@ -142,7 +156,7 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, con
             }
             if (oob) {
                 A.rstate_new[s] = RS_OOB;
-                my_e = (double)A.renergy[s];   // `return state_energy`
+                my_e = (double)e_prev;   // `return state_energy`
             } else {
                 float Jx[6], Jy[6], Cx[4], Cy[4], ddx, ddy;
                 ddx = drescale * (pc.t0[0] - pc.t0[2] * u) * SDVGN_SCALE_IDEPTH * C.fxl;
@@ -170,12 +184,9 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, con
 
                 // 8-pixel photometric pattern: only classifies the residual (:157-194)
                 const float* __restrict__ img = A.images + (size_t)t * C.w * C.h * 3;
-                const float4 c0 = A.pcolor[2 * p], c1 = A.pcolor[2 * p + 1];
-                const float4 w0 = A.pweights[2 * p], w1 = A.pweights[2 * p + 1];
                 const float col[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
                 const float wts[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
                 const int pat[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};
-                const float ids = A.pid[p];
                 // (1) project all 8 pattern pixels (ALU only); (2) gather all of them with branch-free, independent loads
                 // (out-of-image projections read a safe in-image address and are ignored) so that the 96 tap loads are in
                 // flight together; (3) replay the reference's sequential loop with its `break`s on the gathered values.
@@ -190,10 +201,40 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, con
                     Ku2[idx] = r0 / r2; Kv2[idx] = r1 / r2;
                     inb[idx] = (Ku2[idx] > 1.1f && Kv2[idx] > 1.1f && Ku2[idx] < C.wM3G && Kv2[idx] < C.hM3G);
                 }
+                // round trip 2: all 8 x (2 rows x 24 B) tap loads issued back to back (the sched_barriers keep the compiler from
+                // sinking each pixel's loads next to its interpolation, which serialised 8 memory round trips per lane)
+                float fx8[8], fy8[8], tp[8][12];
+                const float* bp8[8];
 #pragma unroll
                 for (int idx = 0; idx < 8; ++idx) {
-                    if (C.debug_flags & 1) { g0[idx] = Ku2[idx]; g1[idx] = Kv2[idx]; g2[idx] = 1.0f; }
-                    else interp33_b(img, inb[idx] ? Ku2[idx] : 2.0f, inb[idx] ? Kv2[idx] : 2.0f, C.w, g0[idx], g1[idx], g2[idx]);
+                    const float x = inb[idx] ? Ku2[idx] : 2.0f, y = inb[idx] ? Kv2[idx] : 2.0f;
+                    const int ix = (int)x, iy = (int)y;
+                    fx8[idx] = x - ix; fy8[idx] = y - iy;
+                    bp8[idx] = img + 3 * (ix + iy * C.w);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(C.debug_flags & 1)) {
+#pragma unroll
+                    for (int idx = 0; idx < 8; ++idx) {
+                        const float* bq = bp8[idx] + 3 * C.w;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) { tp[idx][k] = bp8[idx][k]; tp[idx][6 + k] = bq[k]; }
+                    }
+                } else {
+#pragma unroll
+                    for (int idx = 0; idx < 8; ++idx)
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) tp[idx][k] = Ku2[idx];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int idx = 0; idx < 8; ++idx) {   // bilinear, same operation order as interp33_b / getInterpolatedElement33
+                    const float dx = fx8[idx], dy = fy8[idx], dxdy = dx * dy;
+                    const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+                    const float* q = tp[idx];
+                    g0[idx] = ((w11 * q[9] + w01 * q[6]) + w10 * q[3]) + w00 * q[0];
+                    g1[idx] = ((w11 * q[10] + w01 * q[7]) + w10 * q[4]) + w00 * q[1];
+                    g2[idx] = ((w11 * q[11] + w01 * q[8]) + w10 * q[5]) + w00 * q[2];
                 }
                 float wJI2_sum = 0, energyLeft2 = 0;
                 bool alive = true;
@@ -215,7 +256,6 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, con
                         }
                     }
                 }
-                const float2 m = A.rmatcher[s];
                 const float res0 = Ku - m.x, res1 = Kv - m.y;
                 const float nrm = sqrtf(res0 * res0 + res1 * res1);
                 float hw = fabsf(nrm) < C.huberTH ? 1.0f : C.huberTH / fabsf(nrm);
@@ -224,12 +264,14 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, con
                 // new Jacobian goes to the buffer the EnergyFunctional side does NOT own
                 const int buf = (fl & RF_SEL) ? 0 : 1;
                 float* Jn = A.J + (size_t)buf * kJPlanes * slots + s;
+                if (!(C.debug_flags & 2) || hw != hw) {
                 Jn[0 * slots] = res0 * hw; Jn[1 * slots] = res1 * hw;
 #pragma unroll
                 for (int i = 0; i < 6; ++i) { Jn[(2 + i) * slots] = Jx[i] * hw; Jn[(8 + i) * slots] = Jy[i] * hw; }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { Jn[(14 + i) * slots] = Cx[i] * hw; Jn[(18 + i) * slots] = Cy[i] * hw; }
                 Jn[22 * slots] = ddx * hw; Jn[23 * slots] = ddy * hw;
+                }
                 A.renergy_wo[s] = energyLeft2;
                 if (energyLeft2 > pc.frameEnergyTH || wJI2_sum < 2) { energyLeft2 = pc.frameEnergyTH; A.rstate_new[s] = RS_OUTLIER; }
                 else A.rstate_new[s] = RS_IN;
@@ -241,7 +283,7 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, con
     const double ws = wave_sum_double(my_e);
     if ((threadIdx.x & 63) == 63) s_e[threadIdx.x >> 6] = ws;
     __syncthreads();
-    if (threadIdx.x == 0) energy_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (s_e[0] + s_e[1]) + (s_e[2] + s_e[3]);
+    if (threadIdx.x == 0) energy_partial[(size_t)pair * gridDim.x + chunk] = (s_e[0] + s_e[1]) + (s_e[2] + s_e[3]);
 }
 
 // applyRes(true): one thread per slot
