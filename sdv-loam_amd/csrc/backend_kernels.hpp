@@ -56,7 +56,7 @@ struct EFConst {
     float wM3G, hM3G;
     float cDeltaF[4];
     float huberTH, outlierTHSumComponent;
-    int debug_flags;   // bit0: skip the image gathers (profiling experiments only; never set by the product path)
+    int debug_flags;   // profiling experiments only, never set by the product path: bit1 skip the J stores, bit2 disable the XCD mapping
 };
 
 struct EFArrays {
@@ -125,8 +125,8 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, con
         const int p = pc.P0 + pl;
         const size_t slots = (size_t)C.nF * C.nP;
         const size_t s = (size_t)t * C.nP + p;
-        // round trip 1: every per-slot / per-point input of this lane in one batch of independent loads (the dense table
-        // has storage behind every slot, so the loads need no flag test); the flag-dependent work starts after them.
+        // Round trip 1: every per-slot / per-point input of this lane in one batch of independent loads (the dense table has
+        // storage behind every slot, so the loads need no flag test); the flag-dependent work starts after them.
         const uint8_t fl = A.rflags[s];
         const int st = A.rstate[s];
         const float pu = A.pu[p], pv = A.pv[p], idz = A.pidz[p], ids = A.pid[p];
@@ -135,116 +135,117 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, con
         const float2 m = A.rmatcher[s];
         const float e_prev = A.renergy[s];
         __builtin_amdgcn_sched_barrier(0);
-        if ((fl & RF_EXISTS) && !(fl & RF_LINEARIZED)) {
-            A.renergy_wo[s] = -1.0f;
-            bool oob = (st == RS_OOB) || !(fl & RF_MATCHER);
-            float Ku = 0, Kv = 0, u = 0, v = 0, drescale = 0, new_idepth = 0, KliP0 = 0, KliP1 = 0;
-            if (!oob) {
-                KliP0 = (pu + 0 - C.cxl) * C.fxli;
-                KliP1 = (pv + 0 - C.cyl) * C.fyli;
-                const float q0 = ((pc.R0[0] * KliP0 + pc.R0[1] * KliP1) + pc.R0[2] * 1.0f) + pc.t0[0] * idz;
-                const float q1 = ((pc.R0[3] * KliP0 + pc.R0[4] * KliP1) + pc.R0[5] * 1.0f) + pc.t0[1] * idz;
-                const float q2 = ((pc.R0[6] * KliP0 + pc.R0[7] * KliP1) + pc.R0[8] * 1.0f) + pc.t0[2] * idz;
-                drescale = 1.0f / q2;
-                new_idepth = idz * drescale;
-                if (!(drescale > 0)) oob = true;
-                else {
-                    u = q0 * drescale; v = q1 * drescale;
-                    Ku = u * C.fxl + C.cxl; Kv = v * C.fyl + C.cyl;
-                    oob = !(Ku > 1.1f && Kv > 1.1f && Ku < C.wM3G && Kv < C.hM3G);
-                }
+        const bool todo = (fl & RF_EXISTS) && !(fl & RF_LINEARIZED);
+        bool oob = (st == RS_OOB) || !(fl & RF_MATCHER);
+
+        // 8-pixel photometric pattern, which only classifies the residual (Residuals.cpp:157-194).  Order of work in this lane:
+        //   (1) project the 8 pattern pixels (needs only the point and the pair's KRKi/Kt),
+        //   (2) round trip 2: issue all 8 x (2 rows x 24 B) tap loads back to back, branch-free (lanes with nothing to do and
+        //       out-of-image projections read a safe in-image address and ignore the result),
+        //   (3) while they are in flight: centre projection + the geometric Jacobian (:93-155),
+        //   (4) bilinear interpolation and the reference's sequential pattern loop replayed on the gathered values.
+        // The sched_barriers pin that order; without them the compiler sinks each pixel's loads next to its interpolation and
+        // serialises 8 memory round trips per lane (profiles/r01_linearize_experiments.txt).
+        const float* __restrict__ img = A.images + (size_t)t * C.w * C.h * 3;
+        const int pat[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};
+        float Ku2[8], Kv2[8], fx8[8], fy8[8], tp[8][12];
+        const float* bp8[8];
+        bool inb[8];
+        const bool gather = todo && !oob;
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) {
+            const float up = pu + pat[idx][0], vp = pv + pat[idx][1];
+            const float r0 = ((pc.KRKi[0] * up + pc.KRKi[1] * vp) + pc.KRKi[2] * 1.0f) + pc.Kt[0] * ids;
+            const float r1 = ((pc.KRKi[3] * up + pc.KRKi[4] * vp) + pc.KRKi[5] * 1.0f) + pc.Kt[1] * ids;
+            const float r2 = ((pc.KRKi[6] * up + pc.KRKi[7] * vp) + pc.KRKi[8] * 1.0f) + pc.Kt[2] * ids;
+            Ku2[idx] = r0 / r2; Kv2[idx] = r1 / r2;
+            inb[idx] = (Ku2[idx] > 1.1f && Kv2[idx] > 1.1f && Ku2[idx] < C.wM3G && Kv2[idx] < C.hM3G);
+            const bool ld = gather && inb[idx];
+            const float x = ld ? Ku2[idx] : 2.0f, y = ld ? Kv2[idx] : 2.0f;
+            const int ix = (int)x, iy = (int)y;
+            fx8[idx] = x - ix; fy8[idx] = y - iy;
+            bp8[idx] = img + 3 * (ix + iy * C.w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) {
+            const float* bq = bp8[idx] + 3 * C.w;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { tp[idx][k] = bp8[idx][k]; tp[idx][6 + k] = bq[k]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // (3) centre projection and geometric Jacobian
+        float Ku = 0, Kv = 0, u = 0, v = 0, drescale = 0, new_idepth = 0, KliP0 = 0, KliP1 = 0;
+        if (!oob) {
+            KliP0 = (pu + 0 - C.cxl) * C.fxli;
+            KliP1 = (pv + 0 - C.cyl) * C.fyli;
+            const float q0 = ((pc.R0[0] * KliP0 + pc.R0[1] * KliP1) + pc.R0[2] * 1.0f) + pc.t0[0] * idz;
+            const float q1 = ((pc.R0[3] * KliP0 + pc.R0[4] * KliP1) + pc.R0[5] * 1.0f) + pc.t0[1] * idz;
+            const float q2 = ((pc.R0[6] * KliP0 + pc.R0[7] * KliP1) + pc.R0[8] * 1.0f) + pc.t0[2] * idz;
+            drescale = 1.0f / q2;
+            new_idepth = idz * drescale;
+            if (!(drescale > 0)) oob = true;
+            else {
+                u = q0 * drescale; v = q1 * drescale;
+                Ku = u * C.fxl + C.cxl; Kv = v * C.fyl + C.cyl;
+                oob = !(Ku > 1.1f && Kv > 1.1f && Ku < C.wM3G && Kv < C.hM3G);
             }
+        }
+        float Jx[6], Jy[6], Cx[4], Cy[4], ddx, ddy;
+        ddx = drescale * (pc.t0[0] - pc.t0[2] * u) * SDVGN_SCALE_IDEPTH * C.fxl;
+        ddy = drescale * (pc.t0[1] - pc.t0[2] * v) * SDVGN_SCALE_IDEPTH * C.fyl;
+        Cx[2] = drescale * (pc.R0[6] * u - pc.R0[0]);
+        Cx[3] = C.fxl * drescale * (pc.R0[7] * u - pc.R0[1]) * C.fyli;
+        Cx[0] = KliP0 * Cx[2];
+        Cx[1] = KliP1 * Cx[3];
+        Cy[2] = C.fyl * drescale * (pc.R0[6] * v - pc.R0[3]) * C.fxli;
+        Cy[3] = drescale * (pc.R0[7] * v - pc.R0[4]);
+        Cy[0] = KliP0 * Cy[2];
+        Cy[1] = KliP1 * Cy[3];
+        Cx[0] = (Cx[0] + u) * SDVGN_SCALE_F;
+        Cx[1] *= SDVGN_SCALE_F;
+        Cx[2] = (Cx[2] + 1) * SDVGN_SCALE_C;
+        Cx[3] *= SDVGN_SCALE_C;
+        Cy[0] *= SDVGN_SCALE_F;
+        Cy[1] = (Cy[1] + v) * SDVGN_SCALE_F;
+        Cy[2] *= SDVGN_SCALE_C;
+        Cy[3] = (Cy[3] + 1) * SDVGN_SCALE_C;
+        Jx[0] = new_idepth * C.fxl; Jx[1] = 0; Jx[2] = -new_idepth * u * C.fxl;
+        Jx[3] = -u * v * C.fxl; Jx[4] = (1 + u * u) * C.fxl; Jx[5] = -v * C.fxl;
+        Jy[0] = 0; Jy[1] = new_idepth * C.fyl; Jy[2] = -new_idepth * v * C.fyl;
+        Jy[3] = -(1 + v * v) * C.fyl; Jy[4] = u * v * C.fyl; Jy[5] = u * C.fyl;
+        const float res0 = Ku - m.x, res1 = Kv - m.y;
+        const float nrm = sqrtf(res0 * res0 + res1 * res1);
+        float hwm = fabsf(nrm) < C.huberTH ? 1.0f : C.huberTH / fabsf(nrm);
+        const float energyLeft = hwm * (res0 * res0 + res1 * res1) * (2 - hwm);
+        if (hwm < 1) hwm = sqrtf(hwm);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // (4) consume the taps
+        if (todo) {
+            A.renergy_wo[s] = -1.0f;
             if (oob) {
                 A.rstate_new[s] = RS_OOB;
                 my_e = (double)e_prev;   // `return state_energy`
             } else {
-                float Jx[6], Jy[6], Cx[4], Cy[4], ddx, ddy;
-                ddx = drescale * (pc.t0[0] - pc.t0[2] * u) * SDVGN_SCALE_IDEPTH * C.fxl;
-                ddy = drescale * (pc.t0[1] - pc.t0[2] * v) * SDVGN_SCALE_IDEPTH * C.fyl;
-                Cx[2] = drescale * (pc.R0[6] * u - pc.R0[0]);
-                Cx[3] = C.fxl * drescale * (pc.R0[7] * u - pc.R0[1]) * C.fyli;
-                Cx[0] = KliP0 * Cx[2];
-                Cx[1] = KliP1 * Cx[3];
-                Cy[2] = C.fyl * drescale * (pc.R0[6] * v - pc.R0[3]) * C.fxli;
-                Cy[3] = drescale * (pc.R0[7] * v - pc.R0[4]);
-                Cy[0] = KliP0 * Cy[2];
-                Cy[1] = KliP1 * Cy[3];
-                Cx[0] = (Cx[0] + u) * SDVGN_SCALE_F;
-                Cx[1] *= SDVGN_SCALE_F;
-                Cx[2] = (Cx[2] + 1) * SDVGN_SCALE_C;
-                Cx[3] *= SDVGN_SCALE_C;
-                Cy[0] *= SDVGN_SCALE_F;
-                Cy[1] = (Cy[1] + v) * SDVGN_SCALE_F;
-                Cy[2] *= SDVGN_SCALE_C;
-                Cy[3] = (Cy[3] + 1) * SDVGN_SCALE_C;
-                Jx[0] = new_idepth * C.fxl; Jx[1] = 0; Jx[2] = -new_idepth * u * C.fxl;
-                Jx[3] = -u * v * C.fxl; Jx[4] = (1 + u * u) * C.fxl; Jx[5] = -v * C.fxl;
-                Jy[0] = 0; Jy[1] = new_idepth * C.fyl; Jy[2] = -new_idepth * v * C.fyl;
-                Jy[3] = -(1 + v * v) * C.fyl; Jy[4] = u * v * C.fyl; Jy[5] = u * C.fyl;
-
-                // 8-pixel photometric pattern: only classifies the residual (:157-194)
-                const float* __restrict__ img = A.images + (size_t)t * C.w * C.h * 3;
                 const float col[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
                 const float wts[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-                const int pat[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};
-                // (1) project all 8 pattern pixels (ALU only); (2) gather all of them with branch-free, independent loads
-                // (out-of-image projections read a safe in-image address and are ignored) so that the 96 tap loads are in
-                // flight together; (3) replay the reference's sequential loop with its `break`s on the gathered values.
-                float Ku2[8], Kv2[8], g0[8], g1[8], g2[8];
-                bool inb[8];
-#pragma unroll
-                for (int idx = 0; idx < 8; ++idx) {
-                    const float up = pu + pat[idx][0], vp = pv + pat[idx][1];
-                    const float r0 = ((pc.KRKi[0] * up + pc.KRKi[1] * vp) + pc.KRKi[2] * 1.0f) + pc.Kt[0] * ids;
-                    const float r1 = ((pc.KRKi[3] * up + pc.KRKi[4] * vp) + pc.KRKi[5] * 1.0f) + pc.Kt[1] * ids;
-                    const float r2 = ((pc.KRKi[6] * up + pc.KRKi[7] * vp) + pc.KRKi[8] * 1.0f) + pc.Kt[2] * ids;
-                    Ku2[idx] = r0 / r2; Kv2[idx] = r1 / r2;
-                    inb[idx] = (Ku2[idx] > 1.1f && Kv2[idx] > 1.1f && Ku2[idx] < C.wM3G && Kv2[idx] < C.hM3G);
-                }
-                // round trip 2: all 8 x (2 rows x 24 B) tap loads issued back to back (the sched_barriers keep the compiler from
-                // sinking each pixel's loads next to its interpolation, which serialised 8 memory round trips per lane)
-                float fx8[8], fy8[8], tp[8][12];
-                const float* bp8[8];
-#pragma unroll
-                for (int idx = 0; idx < 8; ++idx) {
-                    const float x = inb[idx] ? Ku2[idx] : 2.0f, y = inb[idx] ? Kv2[idx] : 2.0f;
-                    const int ix = (int)x, iy = (int)y;
-                    fx8[idx] = x - ix; fy8[idx] = y - iy;
-                    bp8[idx] = img + 3 * (ix + iy * C.w);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(C.debug_flags & 1)) {
-#pragma unroll
-                    for (int idx = 0; idx < 8; ++idx) {
-                        const float* bq = bp8[idx] + 3 * C.w;
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) { tp[idx][k] = bp8[idx][k]; tp[idx][6 + k] = bq[k]; }
-                    }
-                } else {
-#pragma unroll
-                    for (int idx = 0; idx < 8; ++idx)
-#pragma unroll
-                        for (int k = 0; k < 12; ++k) tp[idx][k] = Ku2[idx];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int idx = 0; idx < 8; ++idx) {   // bilinear, same operation order as interp33_b / getInterpolatedElement33
-                    const float dx = fx8[idx], dy = fy8[idx], dxdy = dx * dy;
-                    const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
-                    const float* q = tp[idx];
-                    g0[idx] = ((w11 * q[9] + w01 * q[6]) + w10 * q[3]) + w00 * q[0];
-                    g1[idx] = ((w11 * q[10] + w01 * q[7]) + w10 * q[4]) + w00 * q[1];
-                    g2[idx] = ((w11 * q[11] + w01 * q[8]) + w10 * q[5]) + w00 * q[2];
-                }
                 float wJI2_sum = 0, energyLeft2 = 0;
                 bool alive = true;
 #pragma unroll
                 for (int idx = 0; idx < 8; ++idx) {
+                    // bilinear, same operation order as getInterpolatedElement33 (globalFuncs.h:51-65)
+                    const float dx = fx8[idx], dy = fy8[idx], dxdy = dx * dy;
+                    const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+                    const float* q = tp[idx];
+                    const float g0 = ((w11 * q[9] + w01 * q[6]) + w10 * q[3]) + w00 * q[0];
+                    float h1 = ((w11 * q[10] + w01 * q[7]) + w10 * q[4]) + w00 * q[1];
+                    float h2 = ((w11 * q[11] + w01 * q[8]) + w10 * q[5]) + w00 * q[2];
                     if (alive) {
-                        if (!inb[idx] || !isfinite(g0[idx])) alive = false;
+                        if (!inb[idx] || !isfinite(g0)) alive = false;
                         else {
-                            float h1 = g1[idx], h2 = g2[idx];
-                            const float residual = g0[idx] - (float)(pc.aff0 * col[idx] + pc.aff1);
+                            const float residual = g0 - (float)(pc.aff0 * col[idx] + pc.aff1);
                             float w = sqrtf(C.outlierTHSumComponent / (C.outlierTHSumComponent + (h1 * h1 + h2 * h2)));
                             w = 0.5f * (w + wts[idx]);
                             float hw = fabsf(residual) < C.huberTH ? 1.0f : C.huberTH / fabsf(residual);
@@ -256,27 +257,25 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, con
                         }
                     }
                 }
-                const float res0 = Ku - m.x, res1 = Kv - m.y;
-                const float nrm = sqrtf(res0 * res0 + res1 * res1);
-                float hw = fabsf(nrm) < C.huberTH ? 1.0f : C.huberTH / fabsf(nrm);
-                const float energyLeft = hw * (res0 * res0 + res1 * res1) * (2 - hw);
-                if (hw < 1) hw = sqrtf(hw);
-                // new Jacobian goes to the buffer the EnergyFunctional side does NOT own
-                const int buf = (fl & RF_SEL) ? 0 : 1;
-                float* Jn = A.J + (size_t)buf * kJPlanes * slots + s;
-                if (!(C.debug_flags & 2) || hw != hw) {
-                Jn[0 * slots] = res0 * hw; Jn[1 * slots] = res1 * hw;
+                {   // a failing pattern pixel only `break`s (:160-176): the partial sums are used as they are
+                    const float hw = hwm;
+                    // new Jacobian goes to the buffer the EnergyFunctional side does NOT own
+                    const int buf = (fl & RF_SEL) ? 0 : 1;
+                    float* Jn = A.J + (size_t)buf * kJPlanes * slots + s;
+                    if (!(C.debug_flags & 2) || hw != hw) {
+                    Jn[0 * slots] = res0 * hw; Jn[1 * slots] = res1 * hw;
 #pragma unroll
-                for (int i = 0; i < 6; ++i) { Jn[(2 + i) * slots] = Jx[i] * hw; Jn[(8 + i) * slots] = Jy[i] * hw; }
+                    for (int i = 0; i < 6; ++i) { Jn[(2 + i) * slots] = Jx[i] * hw; Jn[(8 + i) * slots] = Jy[i] * hw; }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { Jn[(14 + i) * slots] = Cx[i] * hw; Jn[(18 + i) * slots] = Cy[i] * hw; }
-                Jn[22 * slots] = ddx * hw; Jn[23 * slots] = ddy * hw;
+                    for (int i = 0; i < 4; ++i) { Jn[(14 + i) * slots] = Cx[i] * hw; Jn[(18 + i) * slots] = Cy[i] * hw; }
+                    Jn[22 * slots] = ddx * hw; Jn[23 * slots] = ddy * hw;
+                    }
+                    A.renergy_wo[s] = energyLeft2;
+                    if (energyLeft2 > pc.frameEnergyTH || wJI2_sum < 2) { energyLeft2 = pc.frameEnergyTH; A.rstate_new[s] = RS_OUTLIER; }
+                    else A.rstate_new[s] = RS_IN;
+                    A.renergy_new[s] = energyLeft2;
+                    my_e = (double)energyLeft;
                 }
-                A.renergy_wo[s] = energyLeft2;
-                if (energyLeft2 > pc.frameEnergyTH || wJI2_sum < 2) { energyLeft2 = pc.frameEnergyTH; A.rstate_new[s] = RS_OUTLIER; }
-                else A.rstate_new[s] = RS_IN;
-                A.renergy_new[s] = energyLeft2;
-                my_e = (double)energyLeft;
             }
         }
     }
