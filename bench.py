@@ -202,6 +202,17 @@ def tracker_extras(torch, local, batch, oracle, want_cpu):
         G.set_new_image(P.image, 1.0)
         G.trackBatch(st1, af1, 3)
     out["frame_upload_pyramid_track_ms_pcie_inclusive"] = 1e3 * (time.perf_counter() - t0) / 20
+    # (ii-c) structPoseEstimation: 1200 matches, whole 10-iteration LM in one single-workgroup launch; the call
+    # includes packing + H2D of the 34 kB of inputs and the 1.7 kB read-back (host buffers at the boundary)
+    SP = syn.make_struct_problem(n=1200, seed=0)
+    sp_args = (SP.u, SP.v, SP.idepth, SP.host_idx, SP.host_poses7, SP.obs)
+    for _ in range(3):
+        G.structPoseEstimation(SP.init_curToWorld7, *sp_args)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        _, sp_tr, _ = G.structPoseEstimation(SP.init_curToWorld7, *sp_args)
+    out["struct_pose_call_ms"] = 1e3 * (time.perf_counter() - t0) / 50
+    out["struct_pose_lm_iterations"] = len(sp_tr)
     # (iii) batched roofline run of the fused tracker kernel
     poses = np.stack([oracle.se3_mul(oracle.se3_exp(syn.perturbation(1000 + i)), P.gt_pose) for i in range(batch)])
     affs = np.tile([0.02, 2.0], (batch, 1))
@@ -231,6 +242,10 @@ def tracker_extras(torch, local, batch, oracle, want_cpu):
         for _ in range(50):
             O.trackNewestCoarse(start, (0.02, 2.0), 3)
         out["cpu_track_call_ms_1thread"] = 1e3 * (time.perf_counter() - t0) / 50
+        t0 = time.perf_counter()
+        for _ in range(50):
+            O.structPoseEstimation(SP.init_curToWorld7, *sp_args)
+        out["cpu_struct_pose_call_ms_1thread"] = 1e3 * (time.perf_counter() - t0) / 50
     return out
 
 

@@ -120,6 +120,29 @@ int sdvgn_tracker_res_and_gs_batch(sdvgn_tracker* t, int lvl, int B, const doubl
                                    float cutoffTH, double* out_dev);
 void* sdvgn_tracker_stream(sdvgn_tracker* t);
 
+/* CoarseTracker::structPoseEstimation(SE3& curToWorld, overlap_pts)   CoarseTracker.cpp:949-1004, called right after
+ * trackNewestCoarse on every frame (FullSystem.cpp:483-489); with calculateRes (:840-872), calculateWeight (:874-889),
+ * calcHandb (:891-947) and point2world / world2frame / pixel2unit (ResidualProjections.h:61-103).
+ * overlap_pts is flattened: for match i the map point's host pixel u[i], v[i], its `idepth` (PointHessian::idepth, NOT
+ * idepth_scaled), the index host_idx[i] of its host key-frame in host_pose7 (n_hosts x 7, `host->shell->camToWorld.data()`)
+ * and the matched pixel obs[2i], obs[2i+1] (`it->second`).  Needs make_K (level-0 fx,fy,cx,cy,fxi,fyi; wM3G = w-3, hM3G = h-3).
+ * n <= 4096.  curToWorld7 is updated in place by accepted steps only (the reference's SE3& out-parameter).
+ * trace (optional, 10 x sdvgn_struct_trace_stride() doubles): per iteration [it, lambda, resOld, resNew, accept, inc(6), num,
+ * extrapFac, |inc|, 0, 0]; final_res (optional) = the last accepted mean squared pixel error.
+ * Returns the number of LM iterations run (0..10) or a negative error.  The reference's quirks are kept: in-place cumulative
+ * damping (:959), H,b rebuilt at the pose BEFORE an accepted step (:983), no num==0 guard on the first energy (:951-952), the
+ * 1 - u^2 / -(1 - v^2) Jacobian entries (:919,:925); the
+ * reference function has no return statement (:1003) and its caller ignores the value. */
+int sdvgn_tracker_struct_pose(sdvgn_tracker* t, int n, const float* u, const float* v, const float* idepth, const int* host_idx,
+                              int n_hosts, const double* host_pose7, const double* obs, double* curToWorld7, double* trace,
+                              double* final_res);
+/* parity hook: one calcHandb (:891-947) + calculateRes (:840-872) at worldToCur7; H36 row-major, energy = sum of squared pixel
+ * errors (not divided by num). */
+int sdvgn_tracker_struct_res_hb(sdvgn_tracker* t, int n, const float* u, const float* v, const float* idepth, const int* host_idx,
+                                int n_hosts, const double* host_pose7, const double* obs, const double* worldToCur7, double* H36,
+                                double* b6, double* energy, int* num);
+int sdvgn_struct_trace_stride(void);
+
 /* ===================================================================================================
  * Sliding-window back end -- replaces the data-parallel part of class EnergyFunctional
  * (src/OptimizationBackend/EnergyFunctional.h:36-138) and of FullSystem::linearizeAll

@@ -56,6 +56,11 @@ def lib():
     L.orc_track.argtypes = [C.c_void_p, f64p, f64p, C.c_int, f64p, f64p, f64p, C.c_void_p, C.c_int, C.c_void_p]
     L.orc_track.restype = C.c_int
     L.orc_trace_stride.restype = C.c_int
+    i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    L.orc_struct_trace_stride.restype = C.c_int
+    L.orc_struct_pose.argtypes = [C.c_void_p, C.c_int, f32p, f32p, f32p, i32p, f64p, f64p, f64p, C.c_void_p, C.c_void_p]
+    L.orc_struct_pose.restype = C.c_int
+    L.orc_struct_res_Hb.argtypes = [C.c_void_p, C.c_int, f32p, f32p, f32p, i32p, f64p, f64p, f64p, f64p, f64p, C.c_void_p, C.c_void_p]
     L.orc_se3_exp.argtypes = [f64p, f64p]
     L.orc_se3_log.argtypes = [f64p, f64p]
     L.orc_se3_mul.argtypes = [f64p, f64p, f64p]
@@ -213,3 +218,33 @@ class OracleTracker:
         ok = self.L.orc_track(self.h_, pose, aff, coarsest, mr, last_res, flow,
                               trace.ctypes.data_as(C.c_void_p), trace_cap, C.byref(ntr))
         return bool(ok), pose, aff, last_res, flow, trace[:min(ntr.value, trace_cap)]
+
+    # -- f1: structPoseEstimation (CoarseTracker.cpp:840-1007) -------------------------------------------
+    @staticmethod
+    def _struct_args(u, v, idepth, host_idx, host_poses7, obs):
+        u, v, idepth = (np.ascontiguousarray(x, np.float32) for x in (u, v, idepth))
+        host_idx = np.ascontiguousarray(host_idx, np.int32)
+        host_poses7 = np.ascontiguousarray(np.array(host_poses7, np.float64).reshape(-1, 7))
+        obs = np.ascontiguousarray(np.array(obs, np.float64).reshape(-1, 2))
+        assert len(u) == len(v) == len(idepth) == len(host_idx) == len(obs)
+        return u, v, idepth, host_idx, host_poses7, obs
+
+    def structPoseEstimation(self, curToWorld7, u, v, idepth, host_idx, host_poses7, obs):
+        u, v, idepth, host_idx, hp, obs = self._struct_args(u, v, idepth, host_idx, host_poses7, obs)
+        pose = np.array(curToWorld7, np.float64)
+        stride = self.L.orc_struct_trace_stride()
+        trace = np.zeros((10, stride))
+        fr = C.c_double(0)
+        its = self.L.orc_struct_pose(self.h_, len(u), u, v, idepth, host_idx, hp.reshape(-1), obs.reshape(-1), pose,
+                                     trace.ctypes.data_as(C.c_void_p), C.byref(fr))
+        return pose, trace[:its], fr.value
+
+    def structResHb(self, worldToCur7, u, v, idepth, host_idx, host_poses7, obs):
+        u, v, idepth, host_idx, hp, obs = self._struct_args(u, v, idepth, host_idx, host_poses7, obs)
+        H = np.zeros(36)
+        b = np.zeros(6)
+        e = C.c_double(0)
+        n = C.c_int(0)
+        self.L.orc_struct_res_Hb(self.h_, len(u), u, v, idepth, host_idx, hp.reshape(-1), obs.reshape(-1),
+                                 np.ascontiguousarray(worldToCur7, np.float64), H, b, C.byref(e), C.byref(n))
+        return H.reshape(6, 6), b, e.value, n.value

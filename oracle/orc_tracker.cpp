@@ -471,6 +471,177 @@ static bool track(Tracker* T, SE3& lastToNew_out, double aff_io[2], int coarsest
 
 // ------------------------------- C entry points (ctypes) ---------------------------------------
 using namespace orc;
+// ---- f1: structPoseEstimation (CoarseTracker.cpp:840-1007) -------------------------------------------------
+// Runs right after trackNewestCoarse on every frame (FullSystem.cpp:483-489): 6-dof Gauss-Newton / LM on the 2-D
+// reprojection error of <= ~1200 map points against their matched pixel positions, Tukey weights.
+// Restated with the reference's quirks kept:
+//   * H's diagonal is multiplied by (1+lambda) IN PLACE every iteration (:959) -- the damping accumulates over rejected steps;
+//   * on accept H,b are rebuilt at the OLD pose worldToCur_current (:983) before the pose is advanced (:984): the
+//     linearisation point lags one accepted step behind;
+//   * resOld = energy / num with no num==0 guard (:951-952); resNew = 1e6 when num == 0 (:972-975);
+//   * the function falls off its end without a return value (:1003); the caller ignores it (FullSystem.cpp:488);
+//   * d_xi_x[4] = 1 - u^2 and d_xi_y[3] = -(1 - v^2) (:919,:925) where the true derivatives carry a + (calcGSSSE has it right,
+//     :457,:460); kept as written, documented by tests/test_oracle_struct_pose.py::test_jacobian_vs_true_derivative.
+// Eigen expression order assumed where it only affects the last bit of a double: (J^T J) * weight, (J^T res) * weight (:943-944).
+// `sqrt(sqrt(limit/lambda))` (:963) is evaluated in float here (the argument is a float; result is stored to float).
+struct StructPt { float wx, wy, wz; float ox, oy; };   // point2world(...) of the map point, observed pixel (cast to float)
+
+static void struct_points(const Tracker* T, int n, const float* u, const float* v, const float* idepth, const int* host_idx,
+                          const double* host_pose7, const double* obs, std::vector<StructPt>* out) {
+    out->resize(n);
+    const float cx = T->cx[0], cy = T->cy[0], fxi = T->Ki[0][0], fyi = T->Ki[0][4];
+    for (int i = 0; i < n; ++i) {
+        const double* hp = host_pose7 + 7 * host_idx[i];
+        double Rd[9]; quat_to_R(hp, Rd);
+        float R[9], t[3];
+        for (int k = 0; k < 9; ++k) R[k] = (float)Rd[k];
+        for (int k = 0; k < 3; ++k) t[k] = (float)hp[4 + k];
+        // point2world (ResidualProjections.h:61-78): KliP / idepth is an element-wise division
+        const float k0 = (u[i] + 0 - cx) * fxi, k1 = (v[i] + 0 - cy) * fyi, k2 = 1;
+        const float p0 = k0 / idepth[i], p1 = k1 / idepth[i], p2 = k2 / idepth[i];
+        StructPt& P = (*out)[i];
+        P.wx = ((R[0] * p0 + R[1] * p1) + R[2] * p2) + t[0];
+        P.wy = ((R[3] * p0 + R[4] * p1) + R[5] * p2) + t[1];
+        P.wz = ((R[6] * p0 + R[7] * p1) + R[8] * p2) + t[2];
+        P.ox = (float)obs[2 * i]; P.oy = (float)obs[2 * i + 1];
+    }
+}
+
+struct StructCalib { float fx, fy, cx, cy, fxi, fyi, wM3G, hM3G; };
+
+// world2frame (ResidualProjections.h:80-94)
+static inline bool world2frame(const StructPt& P, const StructCalib& C, const float* R, const float* t, float pf[3], float& Ku, float& Kv) {
+    pf[0] = ((R[0] * P.wx + R[1] * P.wy) + R[2] * P.wz) + t[0];
+    pf[1] = ((R[3] * P.wx + R[4] * P.wy) + R[5] * P.wz) + t[1];
+    pf[2] = ((R[6] * P.wx + R[7] * P.wy) + R[8] * P.wz) + t[2];
+    const float u0 = pf[0] / pf[2], u1 = pf[1] / pf[2];
+    Ku = u0 * C.fx + C.cx;
+    Kv = u1 * C.fy + C.cy;
+    return Ku > 1.1f && Kv > 1.1f && Ku < C.wM3G && Kv < C.hM3G;
+}
+
+static void pose_to_Rt_f(const SE3& T, float R[9], float t[3]) {
+    double Rd[9]; quat_to_R(T.q, Rd);
+    for (int k = 0; k < 9; ++k) R[k] = (float)Rd[k];
+    for (int k = 0; k < 3; ++k) t[k] = (float)T.t[k];
+}
+
+// calculateRes (:840-872): float energy summed in point order
+static float struct_calc_res(const std::vector<StructPt>& pts, const StructCalib& C, const SE3& worldToCur, int& num) {
+    float R[9], t[3]; pose_to_Rt_f(worldToCur, R, t);
+    float energy = 0.0f;
+    num = 0;
+    for (const StructPt& P : pts) {
+        float pf[3], Ku, Kv;
+        if (world2frame(P, C, R, t, pf, Ku, Kv)) {
+            const float r0 = Ku - P.ox, r1 = Kv - P.oy;
+            energy = energy + r0 * r0 + r1 * r1;
+            num++;
+        }
+    }
+    return energy;
+}
+
+// calculateWeight (:874-889)
+static inline float struct_weight(float x) {
+    const float b = 4.6851f;
+    const float b_square = b * b;
+    const float x_square = x * x;
+    if (x_square <= b_square) { const float tmp = 1.0f - x_square / b_square; return tmp * tmp; }
+    return 0.0f;
+}
+
+// calcHandb (:891-947): H_out/b_out are ADDED to
+static void struct_calc_Hb(const std::vector<StructPt>& pts, const StructCalib& C, const SE3& worldToCur, double H[36], double b[6]) {
+    float R[9], t[3]; pose_to_Rt_f(worldToCur, R, t);
+    for (const StructPt& P : pts) {
+        float pf[3], Ku, Kv;
+        if (!world2frame(P, C, R, t, pf, Ku, Kv)) continue;
+        float jx[6], jy[6];
+        jx[0] = (float)(1.0 / (double)pf[2]);
+        jx[1] = 0.0f;
+        jx[2] = -pf[0] / (pf[2] * pf[2]);
+        jx[3] = jx[2] * pf[1];
+        jx[4] = 1 + pf[0] * jx[2];
+        jx[5] = -pf[1] / pf[2];
+        jy[0] = 0.0f;
+        jy[1] = (float)(1.0 / (double)pf[2]);
+        jy[2] = -pf[1] / (pf[2] * pf[2]);
+        jy[3] = -(1 + pf[1] * jy[2]);
+        jy[4] = -jx[3];
+        jy[5] = pf[0] / pf[2];
+        const float up = (Ku - C.cx) * C.fxi, vp = (Kv - C.cy) * C.fyi;          // pixel2unit (ResidualProjections.h:96-103)
+        const float uo = (P.ox - C.cx) * C.fxi, vo = (P.oy - C.cy) * C.fyi;
+        const float r0 = up - uo, r1 = vp - vo;
+        const double weight = (double)struct_weight(sqrtf(r0 * r0 + r1 * r1));
+        for (int i = 0; i < 6; ++i) {
+            for (int j = 0; j < 6; ++j)
+                H[6 * i + j] += ((double)jx[i] * (double)jx[j] + (double)jy[i] * (double)jy[j]) * weight;
+            b[i] += ((double)jx[i] * (double)r0 + (double)jy[i] * (double)r1) * weight;
+        }
+    }
+}
+
+static const int kStructTraceStride = 16;   // [it, lambda, resOld, resNew, accept, inc(6), num, extrapFac, |inc|, 0, 0]
+
+static int struct_pose_estimation(const Tracker* T, int n, const float* u, const float* v, const float* idepth, const int* host_idx,
+                                  const double* host_pose7, const double* obs, SE3& curToWorld, double* trace, double* final_res) {
+    std::vector<StructPt> pts;
+    struct_points(T, n, u, v, idepth, host_idx, host_pose7, obs, &pts);
+    StructCalib C{T->fx[0], T->fy[0], T->cx[0], T->cy[0], T->Ki[0][0], T->Ki[0][4], (float)(T->w[0] - 3), (float)(T->h[0] - 3)};
+    SE3 worldToCur_current = se3_inverse(curToWorld);
+    float lambda = 0.01f;
+    const float lambdaExtrapolationLimit = 0.001f;
+    double H[36] = {0}, b[6] = {0};
+    int num;
+    float resNew = 0.0f;
+    float resOld = struct_calc_res(pts, C, worldToCur_current, num);
+    resOld = resOld / num;
+    struct_calc_Hb(pts, C, worldToCur_current, H, b);
+    int its = 0;
+    for (int iteration = 0; iteration < 10; ++iteration) {
+        const float lambda_used = lambda;
+        for (int i = 0; i < 6; ++i) H[7 * i] *= (double)(1 + lambda);
+        double nb[6], inc[6];
+        for (int i = 0; i < 6; ++i) nb[i] = -b[i];
+        ldlt_solve(6, H, nb, inc);
+        float extrapFac = 1;
+        if (lambda < lambdaExtrapolationLimit) extrapFac = sqrtf(sqrtf(lambdaExtrapolationLimit / lambda));
+        for (int i = 0; i < 6; ++i) inc[i] *= (double)extrapFac;
+        const SE3 worldToCur_new = se3_mul(se3_exp(inc), worldToCur_current);
+        resNew = struct_calc_res(pts, C, worldToCur_new, num);
+        if (num == 0) resNew = 1000000.0f;
+        else resNew = resNew / num;
+        const bool accept = (resNew < resOld);
+        double incn = 0;
+        for (int i = 0; i < 6; ++i) incn += inc[i] * inc[i];
+        incn = std::sqrt(incn);
+        if (trace) {
+            double* tr = trace + (size_t)kStructTraceStride * its;
+            tr[0] = iteration; tr[1] = lambda_used; tr[2] = resOld; tr[3] = resNew; tr[4] = accept ? 1 : 0;
+            for (int i = 0; i < 6; ++i) tr[5 + i] = inc[i];
+            tr[11] = num; tr[12] = extrapFac; tr[13] = incn; tr[14] = tr[15] = 0;
+        }
+        ++its;
+        if (accept) {
+            for (int i = 0; i < 36; ++i) H[i] = 0;
+            for (int i = 0; i < 6; ++i) b[i] = 0;
+            resOld = resNew;
+            resNew = 0;
+            struct_calc_Hb(pts, C, worldToCur_current, H, b);     // sic: the pose BEFORE this step (:983)
+            worldToCur_current = worldToCur_new;
+            curToWorld = se3_inverse(worldToCur_new);
+            lambda *= 0.5f;
+        } else {
+            lambda *= 4;
+            if (lambda < lambdaExtrapolationLimit) lambda = lambdaExtrapolationLimit;
+        }
+        if (!(incn > 1e-5)) break;
+    }
+    if (final_res) *final_res = resOld;
+    return its;
+}
+
 extern "C" {
 
 int orc_trace_stride() { return kTraceStride; }
@@ -546,6 +717,30 @@ int orc_track(void* h, double pose7_io[7], double aff_io[2], int coarsestLvl, co
     for (int i = 0; i < 5; ++i) lastRes[i] = T->lastResiduals[i];
     for (int i = 0; i < 3; ++i) flow[i] = T->lastFlowIndicators[i];
     return ok ? 1 : 0;
+}
+
+int orc_struct_trace_stride() { return kStructTraceStride; }
+// returns the number of iterations run; pose7_io = curToWorld (Sophus data() layout), updated only by accepted steps
+int orc_struct_pose(void* h, int n, const float* u, const float* v, const float* idepth, const int* host_idx,
+                    const double* host_pose7, const double* obs, double pose7_io[7], double* trace, double* final_res) {
+    SE3 P; std::memcpy(P.q, pose7_io, 32); std::memcpy(P.t, pose7_io + 4, 24);
+    const int its = struct_pose_estimation((const Tracker*)h, n, u, v, idepth, host_idx, host_pose7, obs, P, trace, final_res);
+    std::memcpy(pose7_io, P.q, 32); std::memcpy(pose7_io + 4, P.t, 24);
+    return its;
+}
+// calcHandb + calculateRes at one pose (parity hooks)
+void orc_struct_res_Hb(void* h, int n, const float* u, const float* v, const float* idepth, const int* host_idx,
+                       const double* host_pose7, const double* obs, const double worldToCur7[7], double H36[36], double b6[6],
+                       double* energy, int* num) {
+    const Tracker* T = (const Tracker*)h;
+    std::vector<StructPt> pts;
+    struct_points(T, n, u, v, idepth, host_idx, host_pose7, obs, &pts);
+    StructCalib C{T->fx[0], T->fy[0], T->cx[0], T->cy[0], T->Ki[0][0], T->Ki[0][4], (float)(T->w[0] - 3), (float)(T->h[0] - 3)};
+    SE3 P; std::memcpy(P.q, worldToCur7, 32); std::memcpy(P.t, worldToCur7 + 4, 24);
+    for (int i = 0; i < 36; ++i) H36[i] = 0;
+    for (int i = 0; i < 6; ++i) b6[i] = 0;
+    struct_calc_Hb(pts, C, P, H36, b6);
+    int nn; *energy = (double)struct_calc_res(pts, C, P, nn); *num = nn;
 }
 
 // ---- maths helpers exposed for the known-answer tests ----

@@ -42,6 +42,9 @@ PROTOTYPES = [
     ("sdvgn_tracker_get_trace", C.c_int, [vp, vp, C.c_int]),
     ("sdvgn_tracker_res_and_gs_batch", C.c_int, [vp, C.c_int, C.c_int, f64p, f64p, C.c_float, vp]),
     ("sdvgn_tracker_stream", vp, [vp]),
+    ("sdvgn_tracker_struct_pose", C.c_int, [vp, C.c_int, f32p, f32p, f32p, i32p, C.c_int, f64p, f64p, f64p, vp, vp]),
+    ("sdvgn_tracker_struct_res_hb", C.c_int, [vp, C.c_int, f32p, f32p, f32p, i32p, C.c_int, f64p, f64p, f64p, f64p, f64p, vp, vp]),
+    ("sdvgn_struct_trace_stride", C.c_int, []),
 ]
 
 _LIB = None
@@ -220,3 +223,33 @@ class CoarseTracker:
 
     def stream(self):
         return self.L.sdvgn_tracker_stream(self.h_)
+
+    # -- structPoseEstimation (CoarseTracker.cpp:840-1007) ----------------------------------------------
+    @staticmethod
+    def _struct_args(u, v, idepth, host_idx, host_poses7, obs):
+        u, v, idepth = (np.ascontiguousarray(x, np.float32) for x in (u, v, idepth))
+        host_idx = np.ascontiguousarray(host_idx, np.int32)
+        hp = np.ascontiguousarray(np.array(host_poses7, np.float64).reshape(-1, 7))
+        obs = np.ascontiguousarray(np.array(obs, np.float64).reshape(-1, 2))
+        assert len(u) == len(v) == len(idepth) == len(host_idx) == len(obs)
+        return u, v, idepth, host_idx, hp, obs
+
+    def structPoseEstimation(self, curToWorld7, u, v, idepth, host_idx, host_poses7, obs):
+        u, v, idepth, host_idx, hp, obs = self._struct_args(u, v, idepth, host_idx, host_poses7, obs)
+        pose = np.array(curToWorld7, np.float64)
+        trace = np.zeros((10, self.L.sdvgn_struct_trace_stride()))
+        fr = C.c_double(0)
+        its = check(self.L.sdvgn_tracker_struct_pose(self.h_, len(u), u, v, idepth, host_idx, hp.shape[0], hp.reshape(-1),
+                                                     obs.reshape(-1), pose, trace.ctypes.data_as(vp), C.cast(C.byref(fr), vp)))
+        return pose, trace[:its], fr.value
+
+    def structResHb(self, worldToCur7, u, v, idepth, host_idx, host_poses7, obs):
+        u, v, idepth, host_idx, hp, obs = self._struct_args(u, v, idepth, host_idx, host_poses7, obs)
+        H = np.zeros(36)
+        b = np.zeros(6)
+        e = C.c_double(0)
+        n = C.c_int(0)
+        check(self.L.sdvgn_tracker_struct_res_hb(self.h_, len(u), u, v, idepth, host_idx, hp.shape[0], hp.reshape(-1), obs.reshape(-1),
+                                                 np.ascontiguousarray(worldToCur7, np.float64), H, b, C.cast(C.byref(e), vp),
+                                                 C.cast(C.byref(n), vp)))
+        return H.reshape(6, 6), b, e.value, n.value

@@ -26,6 +26,7 @@ using namespace sdvgn;
 
 namespace sdvgn {
 #include "tracker_track_kernel.inc"
+#include "tracker_struct_pose.inc"
 }
 
 struct sdvgn_tracker {
@@ -74,6 +75,13 @@ struct sdvgn_tracker {
 
     // side outputs of the last track() call
     std::vector<double> trace;
+
+    // structPoseEstimation (tracker_struct_pose.inc): packed input staging (pinned + device) and the result block
+    void* sp_stage_host = nullptr;   // pinned
+    void* sp_stage_dev = nullptr;
+    size_t sp_cap_bytes = 0;
+    StructIO* sp_io_dev = nullptr;
+    StructIO* sp_io_host = nullptr;  // pinned
 };
 
 static int chunks_for(const sdvgn_tracker* t, int n, int B) {
@@ -289,6 +297,7 @@ void sdvgn_tracker_destroy(sdvgn_tracker* t) {
     hipFree(t->img_stage_dev); hipFree(t->params_dev); hipHostFree(t->params_host); hipFree(t->partial_dev);
     hipFree(t->out_dev); hipHostFree(t->out_host); hipFree(t->terms_dev); hipFree(t->status_dev);
     hipFree(t->track_dev); hipHostFree(t->track_host); hipFree(t->tconst_dev);
+    hipHostFree(t->sp_stage_host); hipFree(t->sp_stage_dev); hipFree(t->sp_io_dev); hipHostFree(t->sp_io_host);
     if (t->own_stream) hipStreamDestroy(t->stream);
     delete t;
 }
@@ -497,3 +506,93 @@ int sdvgn_tracker_track_batch(sdvgn_tracker* t, int B, double* pose7_io, double*
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// structPoseEstimation
+// ---------------------------------------------------------------------------------------------------------------
+static int struct_pose_run(sdvgn_tracker* t, int mode, int n, const float* u, const float* v, const float* idepth, const int* host_idx,
+                           int n_hosts, const double* host_pose7, const double* obs, const double* pose7_in) {
+    if (!t || !t->haveK) return t ? SDVGN_E_STATE : SDVGN_E_ARG;
+    if (n < 0 || n > kStructMaxN || n_hosts < 1 || !host_pose7 || !pose7_in) return SDVGN_E_ARG;
+    if (n > 0 && (!u || !v || !idepth || !host_idx || !obs)) return SDVGN_E_ARG;
+    for (int i = 0; i < n; ++i) if (host_idx[i] < 0 || host_idx[i] >= n_hosts) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    // packed staging: u | v | idepth | host_idx | obs (float2) | hostRt (12 floats per host)
+    const size_t np = (size_t)((n + 3) & ~3);
+    const size_t bytes = np * 4 * 6 + (size_t)n_hosts * 12 * 4;
+    if (bytes > t->sp_cap_bytes) {
+        HIPCHK(hipStreamSynchronize(t->stream));
+        hipHostFree(t->sp_stage_host); hipFree(t->sp_stage_dev);
+        t->sp_stage_host = t->sp_stage_dev = nullptr; t->sp_cap_bytes = 0;
+        const size_t cap = bytes * 2 + 4096;
+        HIPCHK(hipHostMalloc(&t->sp_stage_host, cap));
+        HIPCHK(hipMalloc(&t->sp_stage_dev, cap));
+        t->sp_cap_bytes = cap;
+    }
+    if (!t->sp_io_dev) {
+        HIPCHK(hipMalloc((void**)&t->sp_io_dev, sizeof(StructIO)));
+        HIPCHK(hipHostMalloc((void**)&t->sp_io_host, sizeof(StructIO)));
+    }
+    float* hs = (float*)t->sp_stage_host;
+    float* hu = hs, *hv = hs + np, *hid = hs + 2 * np;
+    int* hh = (int*)(hs + 3 * np);
+    float* hobs = hs + 4 * np;
+    float* hRt = hs + 6 * np;
+    for (int i = 0; i < n; ++i) {
+        hu[i] = u[i]; hv[i] = v[i]; hid[i] = idepth[i]; hh[i] = host_idx[i];
+        hobs[2 * i] = (float)obs[2 * i]; hobs[2 * i + 1] = (float)obs[2 * i + 1];      // `it->second.cast<float>()`
+    }
+    for (int k = 0; k < n_hosts; ++k) {   // camToWorld.rotationMatrix().cast<float>(), translation().cast<float>() (:850-851)
+        double R[9];
+        gn::rotation_matrix(host_pose7 + 7 * k, R);
+        for (int i = 0; i < 9; ++i) hRt[12 * k + i] = (float)R[i];
+        for (int i = 0; i < 3; ++i) hRt[12 * k + 9 + i] = (float)host_pose7[7 * k + 4 + i];
+    }
+    std::memset(t->sp_io_host, 0, sizeof(StructIO));
+    for (int i = 0; i < 7; ++i) t->sp_io_host->pose[i] = pose7_in[i];
+    HIPCHK(hipMemcpyAsync(t->sp_stage_dev, t->sp_stage_host, bytes, hipMemcpyHostToDevice, t->stream));
+    HIPCHK(hipMemcpyAsync(t->sp_io_dev, t->sp_io_host, sizeof(StructIO), hipMemcpyHostToDevice, t->stream));
+    StructConst C;
+    C.fx = t->fx[0]; C.fy = t->fy[0]; C.cx = t->cx[0]; C.cy = t->cy[0];
+    C.fxi = t->Ki[0][0]; C.fyi = t->Ki[0][4];                    // fxi[0] = Ki[0](0,0) (:101-102)
+    C.wM3G = (float)(t->w[0] - 3); C.hM3G = (float)(t->h[0] - 3); // globalCalib.cpp:46-47
+    C.n = n; C.n_hosts = n_hosts; C.mode = mode;
+    float* ds = (float*)t->sp_stage_dev;
+    k_struct_pose<<<1, kStructThreads, 0, t->stream>>>(C, ds, ds + np, ds + 2 * np, (const int*)(ds + 3 * np), ds + 6 * np,
+                                                     (const float2*)(ds + 4 * np), t->sp_io_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(t->sp_io_host, t->sp_io_dev, sizeof(StructIO), hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    return SDVGN_OK;
+}
+
+int sdvgn_tracker_struct_pose(sdvgn_tracker* t, int n, const float* u, const float* v, const float* idepth, const int* host_idx,
+                              int n_hosts, const double* host_pose7, const double* obs, double* curToWorld7, double* trace,
+                              double* final_res) {
+    if (!curToWorld7) return SDVGN_E_ARG;
+    const int rc = struct_pose_run(t, 0, n, u, v, idepth, host_idx, n_hosts, host_pose7, obs, curToWorld7);
+    if (rc < 0) return rc;
+    const StructIO* io = t->sp_io_host;
+    for (int i = 0; i < 7; ++i) curToWorld7[i] = io->pose[i];
+    if (trace) std::memcpy(trace, io->trace, sizeof(double) * kStructTraceStride * (size_t)io->its);
+    if (final_res) *final_res = io->final_res;
+    if (getenv("SDVGN_PROFILE"))
+        fprintf(stderr, "[sdvgn] k_struct_pose cycles: pass %lld reduce %lld logicA %lld solve %lld logicB %lld total %lld (its %d)\n", io->dbg_cycles[0],
+                io->dbg_cycles[1], io->dbg_cycles[2], io->dbg_cycles[3], io->dbg_cycles[4], io->dbg_cycles[5], io->its);
+    return io->its;
+}
+
+int sdvgn_tracker_struct_res_hb(sdvgn_tracker* t, int n, const float* u, const float* v, const float* idepth, const int* host_idx,
+                                int n_hosts, const double* host_pose7, const double* obs, const double* worldToCur7, double* H36,
+                                double* b6, double* energy, int* num) {
+    if (!H36 || !b6 || !energy || !num) return SDVGN_E_ARG;
+    const int rc = struct_pose_run(t, 1, n, u, v, idepth, host_idx, n_hosts, host_pose7, obs, worldToCur7);
+    if (rc < 0) return rc;
+    const StructIO* io = t->sp_io_host;
+    std::memcpy(H36, io->H, sizeof(double) * 36);
+    std::memcpy(b6, io->b, sizeof(double) * 6);
+    *energy = io->energy; *num = io->num;
+    return SDVGN_OK;
+}
+
+int sdvgn_struct_trace_stride(void) { return kStructTraceStride; }

@@ -313,3 +313,53 @@ def make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=KITTI00, sen
     else:
         W.HM = np.zeros((ndim, ndim)); W.bM = np.zeros(ndim)
     return W
+
+
+# =====================================================================================================
+# structPoseEstimation: map points hosted in the window's key-frames, matched 2-D positions
+# in the current frame, and a perturbed initial camToWorld of the current frame.
+# =====================================================================================================
+class StructProblem:
+    pass
+
+
+def make_struct_problem(n=1200, n_hosts=7, w=1241, h=376, seed=0, calib=KITTI00, noise_px=0.3, outlier_frac=0.05,
+                        pose_err=(0.05, 0.004), oob_frac=0.02):
+    """Returns StructProblem with u,v,idepth (float32, host pixel + inverse depth), host_idx (int32), host_poses7
+    (camToWorld per host, Sophus data() layout), obs (n x 2 float64 matched pixels in the current frame),
+    gt_curToWorld7 and init_curToWorld7."""
+    rng = np.random.default_rng(seed + 9000)
+    P = StructProblem()
+    P.w, P.h, P.calib, P.n = w, h, dict(calib), n
+    fx, fy, cx, cy = (np.float64(np.float32(calib[k])) for k in ("fx", "fy", "cx", "cy"))
+    hosts = []
+    for k in range(n_hosts):
+        xi = np.array([0.05 * rng.normal(), 0.02 * rng.normal(), 0.9 * k, 0.004 * rng.normal(), 0.01 * rng.normal(), 0.004 * rng.normal()])
+        hosts.append(se3_exp_np(xi))                       # camToWorld
+    P.host_poses7 = np.array(hosts)
+    gt = se3_exp_np(np.array([0.03, -0.02, 0.9 * n_hosts, 0.003, -0.012, 0.002]))
+    P.gt_curToWorld7 = gt
+    gt_w2c = _se3_inv_np(gt)
+    Rc, tc = quat_to_R(gt_w2c[:4]), gt_w2c[4:]
+    P.host_idx = rng.integers(0, n_hosts, n).astype(np.int32)
+    u = rng.uniform(8, w - 8, n)
+    v = rng.uniform(8, h - 8, n)
+    depth = rng.uniform(6.0, 45.0, n) + 0.9 * (n_hosts - P.host_idx)
+    P.u, P.v, P.idepth = u.astype(np.float32), v.astype(np.float32), (1.0 / depth).astype(np.float32)
+    obs = np.zeros((n, 2))
+    for i in range(n):
+        hp = hosts[P.host_idx[i]]
+        X = quat_to_R(hp[:4]) @ (np.array([(P.u[i] - cx) / fx, (P.v[i] - cy) / fy, 1.0]) / np.float64(P.idepth[i])) + hp[4:]
+        Y = Rc @ X + tc
+        obs[i] = [fx * Y[0] / Y[2] + cx, fy * Y[1] / Y[2] + cy]
+    obs += rng.normal(0, noise_px, obs.shape)
+    out = rng.random(n) < outlier_frac
+    obs[out] += rng.normal(0, 25.0, (int(out.sum()), 2))
+    # a few matches whose map point leaves the current image (Ku >= wM3G fails world2frame's bounds test): near the right
+    # border of the host and close to the camera, so that the forward motion pushes it out of view
+    oob = rng.random(n) < oob_frac
+    P.u[oob] = np.float32(w - 9.0)
+    P.idepth[oob] = np.float32(1.0 / 8.0)
+    P.obs = obs
+    P.init_curToWorld7 = _se3_mul_np(gt, se3_exp_np(np.concatenate([rng.normal(0, pose_err[0], 3), rng.normal(0, pose_err[1], 3)])))
+    return P

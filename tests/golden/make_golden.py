@@ -73,9 +73,24 @@ def backend_golden():
     np.savez_compressed(os.path.join(HERE, "backend_small.npz"), **out)
 
 
+def struct_pose_golden():
+    P = syn.make_struct_problem(n=240, n_hosts=5, w=320, h=200, seed=11, calib=dict(fx=250.0, fy=255.0, cx=160.3, cy=99.1))
+    T = oracle.OracleTracker(P.w, P.h, 3)
+    T.makeK(**P.calib)
+    args = (P.u, P.v, P.idepth, P.host_idx, P.host_poses7, P.obs)
+    w2c = oracle.se3_inverse(P.init_curToWorld7)
+    H, b, e, n = T.structResHb(w2c, *args)
+    pose, trace, fr = T.structPoseEstimation(P.init_curToWorld7, *args)
+    np.savez_compressed(os.path.join(HERE, "struct_pose_small.npz"), w=P.w, h=P.h, calib=np.array([P.calib[k] for k in ("fx", "fy", "cx", "cy")]),
+                        u=P.u, v=P.v, idepth=P.idepth, host_idx=P.host_idx, host_poses7=P.host_poses7, obs=P.obs,
+                        init=P.init_curToWorld7, H=H, b=b, energy=np.array(e), num=np.array(n), pose=pose, trace=trace,
+                        final_res=np.array(fr))
+
+
 if __name__ == "__main__":
     tracker_golden()
     backend_golden()
+    struct_pose_golden()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

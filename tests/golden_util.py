@@ -35,3 +35,10 @@ def load_window():
     W.images = [g["images"][i] for i in range(W.nF)]
     W.pyr0 = [syn.pyramid_numpy(img, 1)[0] for img in W.images]
     return W, g
+
+
+def load_struct_pose():
+    g = np.load(os.path.join(HERE, "struct_pose_small.npz"))
+    fx, fy, cx, cy = (float(x) for x in g["calib"])
+    args = (g["u"], g["v"], g["idepth"], g["host_idx"], g["host_poses7"], g["obs"])
+    return g, dict(fx=fx, fy=fy, cx=cx, cy=cy), args

@@ -36,3 +36,16 @@ def test_backend_oracle_matches_golden(orc):
     assert np.array_equal(E.points(), g["points"])
     E2 = OracleEF(W.w, W.h).load(W)
     assert np.allclose(E2.optimize(6), g["opt_trace"], rtol=1e-9, atol=1e-12)
+
+
+def test_struct_pose_oracle_matches_golden(orc):
+    from golden_util import load_struct_pose
+    g, calib, args = load_struct_pose()
+    T = orc.OracleTracker(int(g["w"]), int(g["h"]), 3)
+    T.makeK(**calib)
+    H, b, e, n = T.structResHb(orc.se3_inverse(g["init"]), *args)
+    assert n == int(g["num"]) and np.allclose(H, g["H"], rtol=1e-12) and np.allclose(b, g["b"], rtol=1e-12)
+    assert np.isclose(e, float(g["energy"]), rtol=1e-12)
+    pose, trace, fr = T.structPoseEstimation(g["init"], *args)
+    assert np.allclose(pose, g["pose"], rtol=1e-12, atol=1e-14) and np.allclose(trace, g["trace"], rtol=1e-10, atol=1e-14)
+    assert np.isclose(fr, float(g["final_res"]), rtol=1e-12)

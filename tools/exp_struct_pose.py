@@ -1,0 +1,26 @@
+"""Profiling experiment (not product): time sdvgn_tracker_struct_pose."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from sdv_loam_amd import api, synthetic as syn
+for n in (1200, 300, 4096, 1200):
+    P = syn.make_struct_problem(n=n, seed=0)
+    G = api.CoarseTracker(P.w, P.h, 4, max_points=1024)
+    G.makeK(**P.calib)
+    a = (P.u, P.v, P.idepth, P.host_idx, P.host_poses7, P.obs)
+    for _ in range(5):
+        G.structPoseEstimation(P.init_curToWorld7, *a)
+    t0 = time.perf_counter()
+    for _ in range(100):
+        _, tr, _ = G.structPoseEstimation(P.init_curToWorld7, *a)
+    t1 = time.perf_counter()
+    w2c = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    ts = []
+    for _ in range(100):
+        ta = time.perf_counter()
+        G.structResHb(w2c, *a)
+        ts.append(1e6 * (time.perf_counter() - ta))
+    ts = np.array(ts)
+    print("n=%d  struct_pose %.1f us/call (%d its)   single pass call min %.1f median %.1f max %.1f us; first 5: %s" % (
+        n, 1e4 * (t1 - t0), len(tr), ts.min(), np.median(ts), ts.max(), np.round(ts[:5], 1)), flush=True)
