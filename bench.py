@@ -269,7 +269,7 @@ def main():
             runner = ShardedEnergyFunctional(W, rank, world, local)
             runner.optimize(2, want_trace=False, fixed_its=True)      # first collectives happen here: fail early, fall back below
             runner.reload(W)
-            parallelism = "host-keyframe shards %s + 1 all-reduce(295 kB fp64)/iteration over RCCL" % (shard_hosts(W.nF, world),)
+            parallelism = "host-keyframe shards %s + 1 all-reduce(154 kB fp64)/iteration over RCCL" % (shard_hosts(W.nF, world),)
         except Exception as ex:  # noqa: BLE001
             runner = G
             parallelism, scaling = "replicas x%d (sharded path unavailable: %r)" % (world, ex), "weak"
