@@ -525,6 +525,11 @@ __global__ void k_ef_sum_stats(const double* __restrict__ pe, int nE, const doub
     if (threadIdx.x < 4) out[threadIdx.x] = s[threadIdx.x][0];
 }
 
+static int lin_chunks_for_np(const sdvgn_ef* e) {   // k_ef_linearize: 128 residuals per workgroup
+    int mx = 1;
+    for (int h = 0; h < e->nF; ++h) mx = std::max(mx, e->hostP0[h + 1] - e->hostP0[h]);
+    return std::min(2 * kMaxChunks, (mx + 127) / 128);
+}
 static int chunks_for_np(const sdvgn_ef* e) {
     int mx = 1;
     for (int h = 0; h < e->nF; ++h) mx = std::max(mx, e->hostP0[h + 1] - e->hostP0[h]);
@@ -566,7 +571,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->images, (size_t)SDVGN_MAX_FRAMES * w * h * 3) | dev_alloc(&e->img_stage, (size_t)w * h);
     bad |= dev_alloc(&e->phost_dev, mp) | dev_alloc(&e->hostP0_dev, SDVGN_MAX_FRAMES + 1);
     bad |= dev_alloc(&e->precalc_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES);
-    bad |= dev_alloc(&e->energy_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks);
+    bad |= dev_alloc(&e->energy_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * 2);
     bad |= dev_alloc(&e->top_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * kTopP);
     bad |= dev_alloc(&e->sc_partial, (size_t)SDVGN_MAX_FRAMES * kMaxChunks * kScP);
     bad |= dev_alloc(&e->nres_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks);
@@ -810,8 +815,8 @@ int sdvgn_ef_set_precalc(sdvgn_ef* e) {
 int sdvgn_ef_linearize_all(sdvgn_ef* e, double* energy_out) {
     if (!e || e->host_only || !e->havePrecalc || e->nR < 0) return SDVGN_E_STATE;
     EF_DEVICE(e);
-    const int chunks = chunks_for_np(e);
     const int pairs = e->nF * e->nF;
+    const int chunks = lin_chunks_for_np(e);
     k_ef_linearize<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
     double* edst = e->stats_dev;
     if (energy_out) k_ef_sum_energy<<<1, 256, 0, e->stream>>>(e->energy_partial, chunks * pairs, edst);   // NULL: leave the per-workgroup partials
@@ -994,7 +999,8 @@ static double calc_M_energy(sdvgn_ef* e) {   // EnergyFunctional::calcMEnergyF
 // launches linearizeAll + the point statistics; returns {energy, L-energy, sum step^2, sum |idepth_backup|} after ONE sync
 static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* sumID, double* sumNID) {
     if (!e->havePrecalc) return SDVGN_E_STATE;
-    const int chunks = chunks_for_np(e), pairs = e->nF * e->nF;
+    const int pairs = e->nF * e->nF;
+    const int chunks = lin_chunks_for_np(e);
     k_ef_linearize<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
     int nL = 0;
     if (e->deltaF_nonzero || e->has_linearized) {

@@ -88,201 +88,236 @@ __device__ __forceinline__ double wave_sum_double(double v) {
     return v;
 }
 
-__device__ __forceinline__ void interp33_b(const float* __restrict__ img, float x, float y, int width, float& o0, float& o1, float& o2) {
-    const int ix = (int)x, iy = (int)y;
-    const float dx = x - ix, dy = y - iy, dxdy = dx * dy;
-    const float* bp = img + 3 * (ix + iy * width);
-    const float* bq = bp + 3 * width;
-    const float a0 = bp[0], a1 = bp[1], a2 = bp[2], b0 = bp[3], b1 = bp[4], b2 = bp[5];
-    const float c0 = bq[0], c1 = bq[1], c2 = bq[2], d0 = bq[3], d1 = bq[4], d2 = bq[5];
-    const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
-    o0 = ((w11 * d0 + w01 * c0) + w10 * b0) + w00 * a0;
-    o1 = ((w11 * d1 + w01 * c1) + w10 * b1) + w00 * a1;
-    o2 = ((w11 * d2 + w01 * c2) + w10 * b2) + w00 * a2;
+// ------------------------------------------------------------------------------------------------------------
+// b1: PointFrameResidual::linearize, two waves per 64 residuals ("role split").  One residual per lane costs ~1900 VALU
+// instructions and 32 tap loads per lane, and the named size (112 000 residuals = 2000 waves) is then exactly 2 waves per SIMD.
+// Here wave 2g+r of a workgroup takes ROLE r of residual group g:
+//   role 0: pattern pixels 0..3, the x row of the Jacobian (resF[0], Jpdxi[0], Jpdc[0], Jpdd[0]), the residual's scalars
+//   role 1: pattern pixels 4..7, the y row
+// The role is wave-uniform (no divergence), every store stays a 256-B coalesced plane segment, the only exchange is 9 floats per
+// residual through LDS (role 1's four energy / wJI2 terms and its alive mask) so that role 0 can replay the reference's
+// sequential `+=` order over all 8 pattern pixels (bit-exact sums).  4 waves per SIMD, ~1100 VALU instructions and 16 tap loads
+// per lane: the gather phase of one wave overlaps the arithmetic of the others.
+// grid = (ceil(max np / 128), nF*nF), block = 256 (2 groups x 2 roles).
+// energy_partial[pair * gridDim.x + chunk] = sum of the return values of linearize() in this workgroup.
+// ------------------------------------------------------------------------------------------------------------
+struct LinLane {
+    bool todo, oob, wrote;
+    float e[4], wj[4];
+    unsigned ok;          // bit k: pattern pixel 4*ROLE+k projected inside the image and gathered a finite intensity
+    float energyLeft, e_prev;
+    uint8_t fl;
+};
+
+template <int ROLE>
+__device__ __forceinline__ void lin_phase1(const EFConst& C, const EFArrays& A, const PrecalcDev& pc, int t, int p, size_t s, size_t slots,
+                                           LinLane& L) {
+    // Round trip 1: every per-slot / per-point input of this lane in one batch of independent loads (the dense table has storage
+    // behind every slot, so the loads need no flag test); the flag-dependent work starts after them.  The sched_barriers pin the
+    // order [loads | pattern projection | 16 tap loads | centre projection + Jacobian row | tap consumption]: without them the
+    // compiler sinks each pixel's loads next to its interpolation and serialises the memory round trips.
+    const uint8_t fl = A.rflags[s];
+    const int st = A.rstate[s];
+    const float pu = A.pu[p], pv = A.pv[p], idz = A.pidz[p], ids = A.pid[p];
+    const float4 c4 = A.pcolor[2 * p + ROLE];
+    const float4 w4 = A.pweights[2 * p + ROLE];
+    const float2 m = A.rmatcher[s];
+    L.e_prev = (ROLE == 0) ? A.renergy[s] : 0.0f;
+    __builtin_amdgcn_sched_barrier(0);
+    L.fl = fl;
+    L.todo = (fl & RF_EXISTS) && !(fl & RF_LINEARIZED);
+    bool oob = (st == RS_OOB) || !(fl & RF_MATCHER);
+
+    const float* __restrict__ img = A.images + (size_t)t * C.w * C.h * 3;
+    // settings.cpp:250 pattern 8, this role's half
+    const int pat[4][2] = {{ROLE ? 0 : 0, ROLE ? 0 : -2}, {ROLE ? 2 : -1, ROLE ? 0 : -1}, {ROLE ? -1 : 1, ROLE ? 1 : -1}, {ROLE ? 0 : -2, ROLE ? 2 : 0}};
+    float Ku2[4], Kv2[4], fx4[4], fy4[4], tp[4][12];
+    const float* bp4[4];
+    bool inb[4];
+    const bool gather = L.todo && !oob;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float up = pu + pat[k][0], vp = pv + pat[k][1];
+        const float r0 = ((pc.KRKi[0] * up + pc.KRKi[1] * vp) + pc.KRKi[2] * 1.0f) + pc.Kt[0] * ids;
+        const float r1 = ((pc.KRKi[3] * up + pc.KRKi[4] * vp) + pc.KRKi[5] * 1.0f) + pc.Kt[1] * ids;
+        const float r2 = ((pc.KRKi[6] * up + pc.KRKi[7] * vp) + pc.KRKi[8] * 1.0f) + pc.Kt[2] * ids;
+        Ku2[k] = r0 / r2; Kv2[k] = r1 / r2;
+        inb[k] = (Ku2[k] > 1.1f && Kv2[k] > 1.1f && Ku2[k] < C.wM3G && Kv2[k] < C.hM3G);
+        const bool ld = gather && inb[k];
+        const float x = ld ? Ku2[k] : 2.0f, y = ld ? Kv2[k] : 2.0f;
+        const int ix = (int)x, iy = (int)y;
+        fx4[k] = x - ix; fy4[k] = y - iy;
+        bp4[k] = img + 3 * (ix + iy * C.w);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // Round trip 2: 4 x (2 rows x 24 B) tap loads back to back
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float* bq = bp4[k] + 3 * C.w;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { tp[k][q] = bp4[k][q]; tp[k][6 + q] = bq[q]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // centre projection (both roles) and this role's row of the geometric Jacobian (Residuals.cpp:93-155), while the taps fly
+    float Ku = 0, Kv = 0, u = 0, v = 0, drescale = 0, new_idepth = 0, KliP0 = 0, KliP1 = 0;
+    if (!oob) {
+        KliP0 = (pu + 0 - C.cxl) * C.fxli;
+        KliP1 = (pv + 0 - C.cyl) * C.fyli;
+        const float q0 = ((pc.R0[0] * KliP0 + pc.R0[1] * KliP1) + pc.R0[2] * 1.0f) + pc.t0[0] * idz;
+        const float q1 = ((pc.R0[3] * KliP0 + pc.R0[4] * KliP1) + pc.R0[5] * 1.0f) + pc.t0[1] * idz;
+        const float q2 = ((pc.R0[6] * KliP0 + pc.R0[7] * KliP1) + pc.R0[8] * 1.0f) + pc.t0[2] * idz;
+        drescale = 1.0f / q2;
+        new_idepth = idz * drescale;
+        if (!(drescale > 0)) oob = true;
+        else {
+            u = q0 * drescale; v = q1 * drescale;
+            Ku = u * C.fxl + C.cxl; Kv = v * C.fyl + C.cyl;
+            oob = !(Ku > 1.1f && Kv > 1.1f && Ku < C.wM3G && Kv < C.hM3G);
+        }
+    }
+    L.oob = oob;
+    float Jr[6], Cr[4], dd;
+    if (ROLE == 0) {
+        dd = drescale * (pc.t0[0] - pc.t0[2] * u) * SDVGN_SCALE_IDEPTH * C.fxl;
+        Cr[2] = drescale * (pc.R0[6] * u - pc.R0[0]);
+        Cr[3] = C.fxl * drescale * (pc.R0[7] * u - pc.R0[1]) * C.fyli;
+        Cr[0] = KliP0 * Cr[2];
+        Cr[1] = KliP1 * Cr[3];
+        Cr[0] = (Cr[0] + u) * SDVGN_SCALE_F;
+        Cr[1] *= SDVGN_SCALE_F;
+        Cr[2] = (Cr[2] + 1) * SDVGN_SCALE_C;
+        Cr[3] *= SDVGN_SCALE_C;
+        Jr[0] = new_idepth * C.fxl; Jr[1] = 0; Jr[2] = -new_idepth * u * C.fxl;
+        Jr[3] = -u * v * C.fxl; Jr[4] = (1 + u * u) * C.fxl; Jr[5] = -v * C.fxl;
+    } else {
+        dd = drescale * (pc.t0[1] - pc.t0[2] * v) * SDVGN_SCALE_IDEPTH * C.fyl;
+        Cr[2] = C.fyl * drescale * (pc.R0[6] * v - pc.R0[3]) * C.fxli;
+        Cr[3] = drescale * (pc.R0[7] * v - pc.R0[4]);
+        Cr[0] = KliP0 * Cr[2];
+        Cr[1] = KliP1 * Cr[3];
+        Cr[0] *= SDVGN_SCALE_F;
+        Cr[1] = (Cr[1] + v) * SDVGN_SCALE_F;
+        Cr[2] *= SDVGN_SCALE_C;
+        Cr[3] = (Cr[3] + 1) * SDVGN_SCALE_C;
+        Jr[0] = 0; Jr[1] = new_idepth * C.fyl; Jr[2] = -new_idepth * v * C.fyl;
+        Jr[3] = -(1 + v * v) * C.fyl; Jr[4] = u * v * C.fyl; Jr[5] = u * C.fyl;
+    }
+    const float res0 = Ku - m.x, res1 = Kv - m.y;
+    const float nrm = sqrtf(res0 * res0 + res1 * res1);
+    float hwm = fabsf(nrm) < C.huberTH ? 1.0f : C.huberTH / fabsf(nrm);
+    L.energyLeft = hwm * (res0 * res0 + res1 * res1) * (2 - hwm);
+    if (hwm < 1) hwm = sqrtf(hwm);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // consume the taps: per-pixel terms of the reference's pattern loop (:157-194); summed later in pixel order by role 0
+    const float col[4] = {c4.x, c4.y, c4.z, c4.w};
+    const float wts[4] = {w4.x, w4.y, w4.z, w4.w};
+    L.ok = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float dx = fx4[k], dy = fy4[k], dxdy = dx * dy;
+        const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+        const float* q = tp[k];
+        const float g0 = ((w11 * q[9] + w01 * q[6]) + w10 * q[3]) + w00 * q[0];
+        float h1 = ((w11 * q[10] + w01 * q[7]) + w10 * q[4]) + w00 * q[1];
+        float h2 = ((w11 * q[11] + w01 * q[8]) + w10 * q[5]) + w00 * q[2];
+        const float residual = g0 - (float)(pc.aff0 * col[k] + pc.aff1);
+        float w = sqrtf(C.outlierTHSumComponent / (C.outlierTHSumComponent + (h1 * h1 + h2 * h2)));
+        w = 0.5f * (w + wts[k]);
+        float hw = fabsf(residual) < C.huberTH ? 1.0f : C.huberTH / fabsf(residual);
+        L.e[k] = w * w * hw * residual * residual * (2 - hw);
+        if (hw < 1) hw = sqrtf(hw);
+        hw = hw * w;
+        h1 *= hw; h2 *= hw;
+        L.wj[k] = hw * hw * (h1 * h1 + h2 * h2);
+        if (inb[k] && isfinite(g0)) L.ok |= 1u << k;
+    }
+    // this role's row of the new Jacobian goes to the buffer the EnergyFunctional side does NOT own
+    L.wrote = L.todo && !oob;
+    if (L.wrote && (!(C.debug_flags & 2) || hwm != hwm)) {
+        const int buf = (fl & RF_SEL) ? 0 : 1;
+        float* Jn = A.J + (size_t)buf * kJPlanes * slots + s;
+        Jn[(0 + ROLE) * slots] = (ROLE == 0 ? res0 : res1) * hwm;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Jn[(2 + 6 * ROLE + i) * slots] = Jr[i] * hwm;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Jn[(14 + 4 * ROLE + i) * slots] = Cr[i] * hwm;
+        Jn[(22 + ROLE) * slots] = dd * hwm;
+    }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// b1: one thread = one residual slot of pair (h,t).  grid = (chunks, nF*nF), block = 256.
-// energy_partial[blockIdx.y * gridDim.x + blockIdx.x] = sum of the return values of linearize() in this block.
-// ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
-                                                      double* __restrict__ energy_partial) {
-    __shared__ double s_e[4];
+                                                       double* __restrict__ energy_partial) {
+    __shared__ double s_e[2];
+    __shared__ float xch[2][9][64];
     int pair = blockIdx.y, chunk = blockIdx.x;
     if (C.nF == 8 && !(C.debug_flags & 4)) {
         // XCD-aware mapping: workgroups go round-robin to the 8 XCDs by linear id, so id % 8 is the XCD.  Let XCD x linearise
         // every residual whose TARGET is frame x: its 4 MB L2 then only ever gathers from one 5.6 MB image instead of all 8
-        // (measured: -17 % kernel time, profiles/r01_linearize_experiments.txt).
+        // (measured: -17 % kernel time, HBM-side fetch 88 -> 43 MB per launch; profiles/r01_linearize_experiments.txt).
         const int id = blockIdx.x + gridDim.x * blockIdx.y;
         const int tt = id % 8, rest = id / 8;
         pair = (rest / gridDim.x) * C.nF + tt; chunk = rest % gridDim.x;
     }
     const int h = pair / C.nF, t = pair % C.nF;
     const PrecalcDev pc = precalc[pair];
-    const int pl = chunk * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int role = wave & 1, grp = wave >> 1;
+    const int pl = chunk * 128 + grp * 64 + lane;
+    const bool active = (h != t && pl < pc.np);
+    const int p = pc.P0 + (active ? pl : 0);
+    const size_t slots = (size_t)C.nF * C.nP;
+    const size_t s = (size_t)t * C.nP + p;
+    LinLane L;
+    L.todo = false; L.oob = true; L.wrote = false; L.ok = 0; L.energyLeft = 0; L.e_prev = 0; L.fl = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { L.e[k] = 0; L.wj[k] = 0; }
+    if (active) {
+        if (role == 0) lin_phase1<0>(C, A, pc, t, p, s, slots, L);
+        else lin_phase1<1>(C, A, pc, t, p, s, slots, L);
+    }
+    if (role == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { xch[grp][k][lane] = L.e[k]; xch[grp][4 + k][lane] = L.wj[k]; }
+        xch[grp][8][lane] = __uint_as_float(L.ok);
+    }
+    __syncthreads();
     double my_e = 0.0;
-    if (h != t && pl < pc.np) {
-        const int p = pc.P0 + pl;
-        const size_t slots = (size_t)C.nF * C.nP;
-        const size_t s = (size_t)t * C.nP + p;
-        // Round trip 1: every per-slot / per-point input of this lane in one batch of independent loads (the dense table has
-        // storage behind every slot, so the loads need no flag test); the flag-dependent work starts after them.
-        const uint8_t fl = A.rflags[s];
-        const int st = A.rstate[s];
-        const float pu = A.pu[p], pv = A.pv[p], idz = A.pidz[p], ids = A.pid[p];
-        const float4 c0 = A.pcolor[2 * p], c1 = A.pcolor[2 * p + 1];
-        const float4 w0 = A.pweights[2 * p], w1 = A.pweights[2 * p + 1];
-        const float2 m = A.rmatcher[s];
-        const float e_prev = A.renergy[s];
-        __builtin_amdgcn_sched_barrier(0);
-        const bool todo = (fl & RF_EXISTS) && !(fl & RF_LINEARIZED);
-        bool oob = (st == RS_OOB) || !(fl & RF_MATCHER);
-
-        // 8-pixel photometric pattern, which only classifies the residual (Residuals.cpp:157-194).  Order of work in this lane:
-        //   (1) project the 8 pattern pixels (needs only the point and the pair's KRKi/Kt),
-        //   (2) round trip 2: issue all 8 x (2 rows x 24 B) tap loads back to back, branch-free (lanes with nothing to do and
-        //       out-of-image projections read a safe in-image address and ignore the result),
-        //   (3) while they are in flight: centre projection + the geometric Jacobian (:93-155),
-        //   (4) bilinear interpolation and the reference's sequential pattern loop replayed on the gathered values.
-        // The sched_barriers pin that order; without them the compiler sinks each pixel's loads next to its interpolation and
-        // serialises 8 memory round trips per lane (profiles/r01_linearize_experiments.txt).
-        const float* __restrict__ img = A.images + (size_t)t * C.w * C.h * 3;
-        const int pat[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};
-        float Ku2[8], Kv2[8], fx8[8], fy8[8], tp[8][12];
-        const float* bp8[8];
-        bool inb[8];
-        const bool gather = todo && !oob;
+    if (role == 0 && active && L.todo) {
+        A.renergy_wo[s] = -1.0f;
+        if (L.oob) {
+            A.rstate_new[s] = RS_OOB;
+            my_e = (double)L.e_prev;   // `return state_energy`
+        } else {
+            // the reference's sequential loop over the 8 pattern pixels, `break` at the first failing one (:160-176)
+            float e8[8], wj8[8];
+            unsigned ok8 = L.ok | (__float_as_uint(xch[grp][8][lane]) << 4);
 #pragma unroll
-        for (int idx = 0; idx < 8; ++idx) {
-            const float up = pu + pat[idx][0], vp = pv + pat[idx][1];
-            const float r0 = ((pc.KRKi[0] * up + pc.KRKi[1] * vp) + pc.KRKi[2] * 1.0f) + pc.Kt[0] * ids;
-            const float r1 = ((pc.KRKi[3] * up + pc.KRKi[4] * vp) + pc.KRKi[5] * 1.0f) + pc.Kt[1] * ids;
-            const float r2 = ((pc.KRKi[6] * up + pc.KRKi[7] * vp) + pc.KRKi[8] * 1.0f) + pc.Kt[2] * ids;
-            Ku2[idx] = r0 / r2; Kv2[idx] = r1 / r2;
-            inb[idx] = (Ku2[idx] > 1.1f && Kv2[idx] > 1.1f && Ku2[idx] < C.wM3G && Kv2[idx] < C.hM3G);
-            const bool ld = gather && inb[idx];
-            const float x = ld ? Ku2[idx] : 2.0f, y = ld ? Kv2[idx] : 2.0f;
-            const int ix = (int)x, iy = (int)y;
-            fx8[idx] = x - ix; fy8[idx] = y - iy;
-            bp8[idx] = img + 3 * (ix + iy * C.w);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int k = 0; k < 4; ++k) { e8[k] = L.e[k]; wj8[k] = L.wj[k]; e8[4 + k] = xch[grp][k][lane]; wj8[4 + k] = xch[grp][4 + k][lane]; }
+            float wJI2_sum = 0, energyLeft2 = 0;
+            bool alive = true;
 #pragma unroll
-        for (int idx = 0; idx < 8; ++idx) {
-            const float* bq = bp8[idx] + 3 * C.w;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { tp[idx][k] = bp8[idx][k]; tp[idx][6 + k] = bq[k]; }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-
-        // (3) centre projection and geometric Jacobian
-        float Ku = 0, Kv = 0, u = 0, v = 0, drescale = 0, new_idepth = 0, KliP0 = 0, KliP1 = 0;
-        if (!oob) {
-            KliP0 = (pu + 0 - C.cxl) * C.fxli;
-            KliP1 = (pv + 0 - C.cyl) * C.fyli;
-            const float q0 = ((pc.R0[0] * KliP0 + pc.R0[1] * KliP1) + pc.R0[2] * 1.0f) + pc.t0[0] * idz;
-            const float q1 = ((pc.R0[3] * KliP0 + pc.R0[4] * KliP1) + pc.R0[5] * 1.0f) + pc.t0[1] * idz;
-            const float q2 = ((pc.R0[6] * KliP0 + pc.R0[7] * KliP1) + pc.R0[8] * 1.0f) + pc.t0[2] * idz;
-            drescale = 1.0f / q2;
-            new_idepth = idz * drescale;
-            if (!(drescale > 0)) oob = true;
-            else {
-                u = q0 * drescale; v = q1 * drescale;
-                Ku = u * C.fxl + C.cxl; Kv = v * C.fyl + C.cyl;
-                oob = !(Ku > 1.1f && Kv > 1.1f && Ku < C.wM3G && Kv < C.hM3G);
-            }
-        }
-        float Jx[6], Jy[6], Cx[4], Cy[4], ddx, ddy;
-        ddx = drescale * (pc.t0[0] - pc.t0[2] * u) * SDVGN_SCALE_IDEPTH * C.fxl;
-        ddy = drescale * (pc.t0[1] - pc.t0[2] * v) * SDVGN_SCALE_IDEPTH * C.fyl;
-        Cx[2] = drescale * (pc.R0[6] * u - pc.R0[0]);
-        Cx[3] = C.fxl * drescale * (pc.R0[7] * u - pc.R0[1]) * C.fyli;
-        Cx[0] = KliP0 * Cx[2];
-        Cx[1] = KliP1 * Cx[3];
-        Cy[2] = C.fyl * drescale * (pc.R0[6] * v - pc.R0[3]) * C.fxli;
-        Cy[3] = drescale * (pc.R0[7] * v - pc.R0[4]);
-        Cy[0] = KliP0 * Cy[2];
-        Cy[1] = KliP1 * Cy[3];
-        Cx[0] = (Cx[0] + u) * SDVGN_SCALE_F;
-        Cx[1] *= SDVGN_SCALE_F;
-        Cx[2] = (Cx[2] + 1) * SDVGN_SCALE_C;
-        Cx[3] *= SDVGN_SCALE_C;
-        Cy[0] *= SDVGN_SCALE_F;
-        Cy[1] = (Cy[1] + v) * SDVGN_SCALE_F;
-        Cy[2] *= SDVGN_SCALE_C;
-        Cy[3] = (Cy[3] + 1) * SDVGN_SCALE_C;
-        Jx[0] = new_idepth * C.fxl; Jx[1] = 0; Jx[2] = -new_idepth * u * C.fxl;
-        Jx[3] = -u * v * C.fxl; Jx[4] = (1 + u * u) * C.fxl; Jx[5] = -v * C.fxl;
-        Jy[0] = 0; Jy[1] = new_idepth * C.fyl; Jy[2] = -new_idepth * v * C.fyl;
-        Jy[3] = -(1 + v * v) * C.fyl; Jy[4] = u * v * C.fyl; Jy[5] = u * C.fyl;
-        const float res0 = Ku - m.x, res1 = Kv - m.y;
-        const float nrm = sqrtf(res0 * res0 + res1 * res1);
-        float hwm = fabsf(nrm) < C.huberTH ? 1.0f : C.huberTH / fabsf(nrm);
-        const float energyLeft = hwm * (res0 * res0 + res1 * res1) * (2 - hwm);
-        if (hwm < 1) hwm = sqrtf(hwm);
-        __builtin_amdgcn_sched_barrier(0);
-
-        // (4) consume the taps
-        if (todo) {
-            A.renergy_wo[s] = -1.0f;
-            if (oob) {
-                A.rstate_new[s] = RS_OOB;
-                my_e = (double)e_prev;   // `return state_energy`
-            } else {
-                const float col[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-                const float wts[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-                float wJI2_sum = 0, energyLeft2 = 0;
-                bool alive = true;
-#pragma unroll
-                for (int idx = 0; idx < 8; ++idx) {
-                    // bilinear, same operation order as getInterpolatedElement33 (globalFuncs.h:51-65)
-                    const float dx = fx8[idx], dy = fy8[idx], dxdy = dx * dy;
-                    const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
-                    const float* q = tp[idx];
-                    const float g0 = ((w11 * q[9] + w01 * q[6]) + w10 * q[3]) + w00 * q[0];
-                    float h1 = ((w11 * q[10] + w01 * q[7]) + w10 * q[4]) + w00 * q[1];
-                    float h2 = ((w11 * q[11] + w01 * q[8]) + w10 * q[5]) + w00 * q[2];
-                    if (alive) {
-                        if (!inb[idx] || !isfinite(g0)) alive = false;
-                        else {
-                            const float residual = g0 - (float)(pc.aff0 * col[idx] + pc.aff1);
-                            float w = sqrtf(C.outlierTHSumComponent / (C.outlierTHSumComponent + (h1 * h1 + h2 * h2)));
-                            w = 0.5f * (w + wts[idx]);
-                            float hw = fabsf(residual) < C.huberTH ? 1.0f : C.huberTH / fabsf(residual);
-                            energyLeft2 += w * w * hw * residual * residual * (2 - hw);
-                            if (hw < 1) hw = sqrtf(hw);
-                            hw = hw * w;
-                            h1 *= hw; h2 *= hw;
-                            wJI2_sum += hw * hw * (h1 * h1 + h2 * h2);
-                        }
-                    }
-                }
-                {   // a failing pattern pixel only `break`s (:160-176): the partial sums are used as they are
-                    const float hw = hwm;
-                    // new Jacobian goes to the buffer the EnergyFunctional side does NOT own
-                    const int buf = (fl & RF_SEL) ? 0 : 1;
-                    float* Jn = A.J + (size_t)buf * kJPlanes * slots + s;
-                    if (!(C.debug_flags & 2) || hw != hw) {
-                    Jn[0 * slots] = res0 * hw; Jn[1 * slots] = res1 * hw;
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) { Jn[(2 + i) * slots] = Jx[i] * hw; Jn[(8 + i) * slots] = Jy[i] * hw; }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { Jn[(14 + i) * slots] = Cx[i] * hw; Jn[(18 + i) * slots] = Cy[i] * hw; }
-                    Jn[22 * slots] = ddx * hw; Jn[23 * slots] = ddy * hw;
-                    }
-                    A.renergy_wo[s] = energyLeft2;
-                    if (energyLeft2 > pc.frameEnergyTH || wJI2_sum < 2) { energyLeft2 = pc.frameEnergyTH; A.rstate_new[s] = RS_OUTLIER; }
-                    else A.rstate_new[s] = RS_IN;
-                    A.renergy_new[s] = energyLeft2;
-                    my_e = (double)energyLeft;
+            for (int k = 0; k < 8; ++k) {
+                if (alive) {
+                    if (!((ok8 >> k) & 1)) alive = false;
+                    else { energyLeft2 += e8[k]; wJI2_sum += wj8[k]; }
                 }
             }
+            A.renergy_wo[s] = energyLeft2;
+            if (energyLeft2 > pc.frameEnergyTH || wJI2_sum < 2) { energyLeft2 = pc.frameEnergyTH; A.rstate_new[s] = RS_OUTLIER; }
+            else A.rstate_new[s] = RS_IN;
+            A.renergy_new[s] = energyLeft2;
+            my_e = (double)L.energyLeft;
         }
     }
-    const double ws = wave_sum_double(my_e);
-    if ((threadIdx.x & 63) == 63) s_e[threadIdx.x >> 6] = ws;
+    if (role == 0) {
+        const double ws = wave_sum_double(my_e);
+        if (lane == 63) s_e[grp] = ws;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) energy_partial[(size_t)pair * gridDim.x + chunk] = (s_e[0] + s_e[1]) + (s_e[2] + s_e[3]);
+    if (threadIdx.x == 0) energy_partial[(size_t)pair * gridDim.x + chunk] = s_e[0] + s_e[1];
 }
 
 // applyRes(true): one thread per slot
