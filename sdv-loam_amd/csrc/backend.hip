@@ -98,10 +98,16 @@ struct sdvgn_ef {
     double* energy_partial = nullptr;
     float *top_partial = nullptr, *sc_partial = nullptr;
     int* nres_partial = nullptr;
+    unsigned short* sc_off_dev = nullptr;   // packed upper-triangle index (53x53) -> offset inside the 10 SC tiles
     double* acc_dev = nullptr;    // packed: top [nF*nF][256] | sc [nF][2560] | resInA
-    double* acc_host = nullptr;   // pinned mirror
+    double* acc_host = nullptr;   // pinned; the reduce kernels write it DIRECTLY (zero-copy) when no all-reduce is installed
+    double* stats_host = nullptr; // pinned, 4 doubles: same for k_ef_sum_stats
     float *xc_dev = nullptr, *xAd_dev = nullptr;
-    float* x_host = nullptr;      // pinned: xc(4) + xAd(nF*nF*6)
+    float* x_host = nullptr;      // pinned, 2 slots used alternately: xc(4) + xAd(nF*nF*6)
+    int x_slot = 0;
+    hipEvent_t ev_top = nullptr;  // split accumulate: the top accumulators have landed in acc_host
+    bool split_pending = false;   // the SC part of acc_host is still in flight on the stream
+    bool acc_in_host = false;     // the last accumulate wrote acc_host directly (acc_dev not updated)
     double* stats_dev = nullptr;   // {linearize energy, L-energy point part, sum step^2, sum |idepth_backup|}
     bool own_acc = true, own_stats = true;
     void (*allreduce)(void*, double*, int) = nullptr;   // cfg4: sum a device buffer over the ranks (RCCL), in stream order
@@ -575,6 +581,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->top_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * kTopP);
     bad |= dev_alloc(&e->sc_partial, (size_t)SDVGN_MAX_FRAMES * kMaxChunks * kScP);
     bad |= dev_alloc(&e->nres_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks);
+    bad |= dev_alloc(&e->sc_off_dev, (size_t)kScE);
     const size_t accmax = (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kTopE + (size_t)SDVGN_MAX_FRAMES * kScE + 1;
     bad |= dev_alloc(&e->acc_dev, accmax);
     bad |= dev_alloc(&e->xc_dev, 4) | dev_alloc(&e->xAd_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6);
@@ -582,7 +589,20 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     if (bad) { sdvgn_ef_destroy(e); return -(int)hipErrorOutOfMemory; }
     HIPCHK(hipHostMalloc(&e->precalc_host, 2 * sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
     HIPCHK(hipHostMalloc(&e->acc_host, sizeof(double) * accmax));
-    HIPCHK(hipHostMalloc(&e->x_host, sizeof(float) * (4 + SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6)));
+    HIPCHK(hipHostMalloc(&e->stats_host, sizeof(double) * 4));
+    HIPCHK(hipHostMalloc(&e->x_host, 2 * sizeof(float) * (4 + SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6)));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_top, hipEventDisableTiming));
+    {   // packed upper triangle of the live 53x53 SC Gram -> offset inside its ten 16x16 tiles (k_ef_sc_gram's layout)
+        unsigned short off[kScE];
+        int k = 0;
+        for (int r = 0; r < 53; ++r)
+            for (int c = r; c < 53; ++c) {
+                const int ti = r >> 4, tj = c >> 4;
+                const int a = ti * 4 - (ti * (ti - 1)) / 2 + (tj - ti);
+                off[k++] = (unsigned short)(a * 256 + (r & 15) * 16 + (c & 15));
+            }
+        HIPCHK(hipMemcpy(e->sc_off_dev, off, sizeof(off), hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMemsetAsync(e->rflags, 0, slots, e->stream));
     HIPCHK(hipMemsetAsync(e->stats_partial, 0, sizeof(double) * 3 * (mp / 64 + 2), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -602,11 +622,13 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->rstate, e->rstate_new, e->rmatcher, e->renergy, e->renergy_new, e->renergy_wo, e->rres_toZero, e->J, e->JpJd, e->pHddA,
                     e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->images, e->img_stage,
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
-                    e->xc_dev, e->xAd_dev, e->stats_dev, e->stats_partial};
+                    e->xc_dev, e->xAd_dev, e->stats_dev, e->stats_partial, e->sc_off_dev};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->precalc_host) hipHostFree(e->precalc_host);
     if (e->acc_host) hipHostFree(e->acc_host);
+    if (e->stats_host) hipHostFree(e->stats_host);
     if (e->x_host) hipHostFree(e->x_host);
+    if (e->ev_top) hipEventDestroy(e->ev_top);
     if (e->own_stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -838,21 +860,44 @@ int sdvgn_ef_apply_res(sdvgn_ef* e) {
     return SDVGN_OK;
 }
 
-int sdvgn_ef_accumulate(sdvgn_ef* e) {
-    if (!e || e->host_only || !e->havePrecalc) return SDVGN_E_STATE;
-    EF_DEVICE(e);
+// split = true (single-GPU solve): the top Gram is reduced into acc_host first and ev_top recorded, so that the host can
+// stitch the top part while the point / SC-Gram kernels still run; the SC part + resInA follow on the stream (split_pending).
+static int ef_accumulate(sdvgn_ef* e, bool split) {
     const int nF = e->nF, pairs = nF * nF, chunks = chunks_for_np(e);
     int mx = 1;
     for (int h = 0; h < nF; ++h) mx = std::max(mx, e->hostP0[h + 1] - e->hostP0[h]);
     const int sc_chunks = std::min(kMaxChunks, (mx + 127) / 128);
     const int sc_ppb = ((mx + sc_chunks - 1) / sc_chunks + 63) / 64 * 64;
-    k_ef_point<<<(e->nP + 63) / 64, 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev);
-    k_ef_top_gram<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->top_partial, e->nres_partial);
-    k_ef_sc_gram<<<dim3(sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, sc_ppb);
-    const int nred = pairs * kTopE + nF * kScE + 1;
-    k_ef_acc_reduce<<<(nred + 255) / 256, 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks, e->nres_partial, e->acc_dev);
+    const int ntop = pairs * kTopE, nsc = nF * kScE;
+    if (split) {
+        // the reduce kernels store straight into the pinned host buffer (fine-grained, visible at kernel completion): no copy
+        // engine in the path -- a small D2H memcpy costs 10-20 us of fixed latency, more than the 154 kB take over PCIe
+        k_ef_top_gram<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->top_partial, e->nres_partial);
+        k_ef_acc_reduce<<<(ntop + 255) / 256, 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks, e->nres_partial,
+                                                                   e->sc_off_dev, e->acc_host, 0, ntop, 0);
+        HIPCHK(hipEventRecord(e->ev_top, e->stream));
+        k_ef_point<<<(e->nP + 63) / 64, 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev);
+        k_ef_sc_gram<<<dim3(sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, sc_ppb);
+        k_ef_acc_reduce<<<(nsc + 255) / 256 + 1, 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks, e->nres_partial,
+                                                                      e->sc_off_dev, e->acc_host, ntop, ntop + nsc, 1);
+        e->split_pending = true;
+        e->acc_in_host = true;
+    } else {
+        e->acc_in_host = false;
+        k_ef_point<<<(e->nP + 63) / 64, 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev);
+        k_ef_top_gram<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->top_partial, e->nres_partial);
+        k_ef_sc_gram<<<dim3(sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, sc_ppb);
+        k_ef_acc_reduce<<<(ntop + nsc + 255) / 256 + 1, 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks,
+                                                                             e->nres_partial, e->sc_off_dev, e->acc_dev, 0, ntop + nsc, 1);
+    }
     HIPCHK(hipGetLastError());
     return SDVGN_OK;
+}
+
+int sdvgn_ef_accumulate(sdvgn_ef* e) {
+    if (!e || e->host_only || !e->havePrecalc) return SDVGN_E_STATE;
+    EF_DEVICE(e);
+    return ef_accumulate(e, false);
 }
 
 int sdvgn_ef_set_external_buffers(sdvgn_ef* e, double* acc_dev, int acc_capacity, double* stats_dev) {
@@ -886,10 +931,15 @@ int sdvgn_ef_accumulators_dev(sdvgn_ef* e, double** buf, int* count) {
 // null-space projection.  Pure host code -- also the entry point of the CPU (gloo) test of the multi-GPU logic.
 static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, double lambda, double* x_out) {
     const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
-    e->resInA = (int)acc[acc_count(e) - 1];
     g_pt.start();
     stitch_top(e, acc);
     g_pt.stop(PT_STITCH_TOP);
+    if (e->split_pending) {   // the SC accumulators were still being produced while the top part was stitched
+        HIPCHK(hipStreamSynchronize(e->stream));
+        e->split_pending = false;
+        g_pt.stop(PT_D2H);
+    }
+    e->resInA = (int)acc[acc_count(e) - 1];
     stitch_sc(e, acc + (size_t)pairs * kTopE);
     g_pt.stop(PT_STITCH_SC);
     // bM_top = bM + HM * delta ; HFinal = HA + HM - Hsc ; bFinal = bA + bM_top - bsc   (EnergyFunctional.cpp:668-699)
@@ -928,15 +978,24 @@ int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
     EF_DEVICE(e);
     const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
     g_pt.start();
-    HIPCHK(hipMemcpyAsync(e->acc_host, e->acc_dev, sizeof(double) * acc_count(e), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->split_pending) {
+        hipError_t q;
+        while ((q = hipEventQuery(e->ev_top)) == hipErrorNotReady) {}   // spin: hipEventSynchronize costs ~20 us of wake-up latency
+        if (q != hipSuccess) return -(int)q;
+    } else {
+        HIPCHK(hipMemcpyAsync(e->acc_host, e->acc_dev, sizeof(double) * acc_count(e), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
     g_pt.stop(PT_D2H);
     int rc = ef_stitch_solve_host(e, e->acc_host, iteration, lambda, x_out);
     g_pt.start();
     if (rc) return rc;
     // resubstituteF_MT (:221-247): xc, xAd[nF*h + t]
-    float* xc = e->x_host;
-    float* xAd = e->x_host + 4;
+    // two pinned slots used alternately: the copies below are still in flight when this function returns, and at least one
+    // stream synchronisation (the statistics read-back of the next linearize) happens before a slot comes round again
+    e->x_slot ^= 1;
+    float* xc = e->x_host + (size_t)e->x_slot * (4 + SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6);
+    float* xAd = xc + 4;
     std::vector<float> xF(n);
     for (int i = 0; i < n; ++i) xF[i] = (float)e->lastX[i];
     for (int i = 0; i < 4; ++i) xc[i] = xF[i];
@@ -955,14 +1014,15 @@ int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
     k_ef_resubstitute<<<(e->nP + 63) / 64, 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->xc_dev, e->xAd_dev,
                                                              e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(e->stream));   // x_host is reused by the next call
     g_pt.stop(PT_RESUB);
     return SDVGN_OK;
 }
 
 int sdvgn_ef_solve_system(sdvgn_ef* e, int iteration, double lambda, double* x_out) {
+    if (!e || e->host_only || !e->havePrecalc) return SDVGN_E_STATE;
+    EF_DEVICE(e);
     g_pt.start();
-    int rc = sdvgn_ef_accumulate(e);
+    int rc = ef_accumulate(e, /*split=*/e->allreduce == nullptr);
     g_pt.stop(PT_ACCUM);
     if (rc) return rc;
     if (e->allreduce) e->allreduce(e->allreduce_user, e->acc_dev, (int)acc_count(e));   // cfg4: one all-reduce per GN iteration
@@ -1008,18 +1068,22 @@ static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* 
         k_ef_point_stats<<<nL, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->stats_partial);
     }
     const int nS = (e->nP + 63) / 64;
-    k_ef_sum_stats<<<1, 256, 0, e->stream>>>(e->energy_partial, chunks * pairs, e->stats_partial, nL, e->stats_partial + (e->nP / 64 + 2), nS, e->stats_dev);
+    // without an all-reduce the four sums go straight into pinned host memory (no copy engine, see ef_accumulate)
+    k_ef_sum_stats<<<1, 256, 0, e->stream>>>(e->energy_partial, chunks * pairs, e->stats_partial, nL, e->stats_partial + (e->nP / 64 + 2), nS,
+                                             e->allreduce ? e->stats_dev : e->stats_host);
     HIPCHK(hipGetLastError());
-    if (e->allreduce) e->allreduce(e->allreduce_user, e->stats_dev, 4);   // ranks hold disjoint host-frame shards
-    HIPCHK(hipMemcpyAsync(e->acc_host, e->stats_dev, 4 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if (e->allreduce) {
+        e->allreduce(e->allreduce_user, e->stats_dev, 4);   // ranks hold disjoint host-frame shards
+        HIPCHK(hipMemcpyAsync(e->stats_host, e->stats_dev, 4 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    }
     HIPCHK(hipStreamSynchronize(e->stream));
-    *energy = e->acc_host[0];
+    *energy = e->stats_host[0];
     double En = 0;   // calcLEnergyF_MT: frame + calib priors on the host, point part from the device
     for (const FrameH& f : e->frames) for (int i = 0; i < 6; ++i) En += f.delta_prior[i] * f.prior[i] * f.delta_prior[i];
     { float a = 0; for (int i = 0; i < 4; ++i) a += e->C.cDeltaF[i] * (float)e->cPrior[i] * e->C.cDeltaF[i]; En += a; }
-    *EL = En + (double)(float)e->acc_host[1];
-    if (sumID) *sumID = e->acc_host[2];
-    if (sumNID) *sumNID = e->acc_host[3];
+    *EL = En + (double)(float)e->stats_host[1];
+    if (sumID) *sumID = e->stats_host[2];
+    if (sumNID) *sumNID = e->stats_host[3];
     return SDVGN_OK;
 }
 
@@ -1202,7 +1266,8 @@ int sdvgn_ef_get_top_acc(sdvgn_ef* e, double* out, int* resInA) {
     const int nF = e->nF;
     std::vector<double> g((size_t)nF * nF * kTopE);
     HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipMemcpy(g.data(), e->acc_dev, 8 * g.size(), hipMemcpyDeviceToHost));
+    if (e->acc_in_host) std::memcpy(g.data(), e->acc_host, 8 * g.size());
+    else HIPCHK(hipMemcpy(g.data(), e->acc_dev, 8 * g.size(), hipMemcpyDeviceToHost));
     for (int h = 0; h < nF; ++h)
         for (int t = 0; t < nF; ++t)
             for (int r = 0; r < 11; ++r)

@@ -622,31 +622,45 @@ __global__ void __launch_bounds__(256) k_ef_sc_gram(EFConst C, EFArrays A, const
 
 // Fixed-order fp64 sum of the per-workgroup partials into the PACKED accumulator buffer, all three parts in one launch:
 // top Gram [pairs][121] (the live 11x11), SC Gram [nF][1431] (upper triangle of the live 53x53), resInA.
+// The partial loads of one output are issued in batches of 8 independent loads (one memory round trip per batch instead of
+// one per chunk); the packed-triangle -> tile offset comes from a table built once on the host (sc_off[1431]).
+// grid = ceil((e_end - e_begin) / 256) (+ 1 if do_nres: the last workgroup sums the integer residual counters).
+template <int STRIDE>
+__device__ __forceinline__ double sum_chunks_f64(const float* __restrict__ base, int chunks) {
+    double s = 0;
+    for (int c0 = 0; c0 < chunks; c0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (c0 + j < chunks) ? base[(size_t)(c0 + j) * STRIDE] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (double)v[j];   // + 0.0 for the absent chunks is exact
+    }
+    return s;
+}
 __global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__ top_partial, int pairs, int top_chunks,
                                                        const float* __restrict__ sc_partial, int nF, int sc_chunks,
-                                                       const int* __restrict__ nres_partial, double* __restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+                                                       const int* __restrict__ nres_partial, const unsigned short* __restrict__ sc_off,
+                                                       double* __restrict__ out, int e_begin, int e_end, int do_nres) {
     const int ntop = pairs * 121, nsc = nF * 1431;
+    if (do_nres && blockIdx.x == gridDim.x - 1) {   // resInA: integer sum, order-free
+        __shared__ int part[4];
+        int n = 0;
+        for (int i = threadIdx.x; i < pairs * top_chunks; i += 256) n += nres_partial[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+        __syncthreads();
+        if (threadIdx.x == 0) out[ntop + nsc] = (double)(part[0] + part[1] + part[2] + part[3]);
+        return;
+    }
+    const int e = e_begin + blockIdx.x * blockDim.x + threadIdx.x;   // outputs [e_begin, e_end) of the packed buffer
+    if (e >= e_end) return;
     if (e < ntop) {
         const int g = e / 121, k = e - g * 121, r = k / 11, c = k - r * 11;
-        double s = 0;
-        for (int ch = 0; ch < top_chunks; ++ch) s += (double)top_partial[((size_t)g * top_chunks + ch) * 256 + r * 16 + c];
-        out[e] = s;
+        out[e] = sum_chunks_f64<256>(top_partial + (size_t)g * top_chunks * 256 + r * 16 + c, top_chunks);
     } else if (e < ntop + nsc) {
-        const int q = e - ntop, g = q / 1431;
-        int k = q - g * 1431, r = 0;
-        while (k >= 53 - r) { k -= 53 - r; ++r; }   // row of the packed upper triangle (<= 52 steps)
-        const int c = r + k;
-        const int ti = r >> 4, tj = c >> 4;
-        const int a = ti * 4 - (ti * (ti - 1)) / 2 + (tj - ti);
-        const int off = a * 256 + (r & 15) * 16 + (c & 15);
-        double s = 0;
-        for (int ch = 0; ch < sc_chunks; ++ch) s += (double)sc_partial[((size_t)g * sc_chunks + ch) * 2560 + off];
-        out[e] = s;
-    } else if (e == ntop + nsc) {
-        int n = 0;
-        for (int ch = 0; ch < pairs * top_chunks; ++ch) n += nres_partial[ch];
-        out[e] = (double)n;
+        const int q = e - ntop, g = q / 1431, k = q - g * 1431;
+        out[e] = sum_chunks_f64<2560>(sc_partial + (size_t)g * sc_chunks * 2560 + sc_off[k], sc_chunks);
     }
 }
 
