@@ -69,19 +69,15 @@ struct sdvgn_tracker {
     float* terms_dev = nullptr;
     int* status_dev = nullptr;
     int terms_lvl = -1;
-    TrackState* track_dev = nullptr;
     TrackState* track_host = nullptr;    // pinned
-    TrackConst* tconst_dev = nullptr;
 
     // side outputs of the last track() call
     std::vector<double> trace;
 
-    // structPoseEstimation (tracker_struct_pose.inc): packed input staging (pinned + device) and the result block
-    void* sp_stage_host = nullptr;   // pinned
-    void* sp_stage_dev = nullptr;
+    // structPoseEstimation (tracker_struct_pose.inc): packed input staging and the result block, both pinned host memory
+    void* sp_stage_host = nullptr;   // pinned, read by the kernel directly
     size_t sp_cap_bytes = 0;
-    StructIO* sp_io_dev = nullptr;
-    StructIO* sp_io_host = nullptr;  // pinned
+    StructIO* sp_io_host = nullptr;  // pinned, read and written by the kernel directly
 };
 
 static int chunks_for(const sdvgn_tracker* t, int n, int B) {
@@ -119,13 +115,17 @@ static void fill_params(const sdvgn_tracker* t, int lvl, const double* pose7, do
 }
 
 // launches k_res_gs + k_finalize for B problems; results in t->out_dev
+// zero_copy (the host-driven single-trial path): the kernels read the 152-B LevelParams record straight from the pinned host
+// buffer and k_finalize stores its 640 B of results straight into pinned host memory -- no copy engine in the loop (a small
+// hipMemcpyAsync costs 10-20 us of fixed latency each way, the PCIe transfers themselves well under 1 us).
 static int launch_res_gs(sdvgn_tracker* t, int lvl, int B, const double* pose7, const double* aff, float cutoffTH,
-                         bool write_terms, double* out_dev) {
+                         bool write_terms, double* out_dev, bool zero_copy = false) {
     if (!t->haveK || !t->haveNew) return SDVGN_E_STATE;
     if (lvl < 0 || lvl >= t->levels || B < 1 || B > t->max_batch) return SDVGN_E_ARG;
     if (write_terms && B != 1) return SDVGN_E_ARG;
     for (int b = 0; b < B; ++b) fill_params(t, lvl, pose7 + 7 * b, aff[2 * b], aff[2 * b + 1], cutoffTH, t->params_host[b]);
-    HIPCHK(hipMemcpyAsync(t->params_dev, t->params_host, sizeof(LevelParams) * B, hipMemcpyHostToDevice, t->stream));
+    const LevelParams* params = zero_copy ? t->params_host : t->params_dev;
+    if (!zero_copy) HIPCHK(hipMemcpyAsync(t->params_dev, t->params_host, sizeof(LevelParams) * B, hipMemcpyHostToDevice, t->stream));
     const int n = t->pc_n[lvl];
     const int chunks = chunks_for(t, n, B);
     dim3 grid(chunks, B), block(256);
@@ -141,15 +141,15 @@ static int launch_res_gs(sdvgn_tracker* t, int lvl, int B, const double* pose7, 
             t->half_valid = true;
         }
         const float* himg = reinterpret_cast<const float*>(t->pyr_half_dev[lvl]);
-        if (t->precision == PREC_H_PYR) k_res_gs<false, PREC_H_PYR><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], himg, t->params_dev, t->partial_dev, nullptr, nullptr);
-        else if (t->precision == PREC_H_OPER) k_res_gs<false, PREC_H_OPER><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], himg, t->params_dev, t->partial_dev, nullptr, nullptr);
-        else k_res_gs<false, PREC_H_ACC><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], himg, t->params_dev, t->partial_dev, nullptr, nullptr);
+        if (t->precision == PREC_H_PYR) k_res_gs<false, PREC_H_PYR><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], himg, params, t->partial_dev, nullptr, nullptr);
+        else if (t->precision == PREC_H_OPER) k_res_gs<false, PREC_H_OPER><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], himg, params, t->partial_dev, nullptr, nullptr);
+        else k_res_gs<false, PREC_H_ACC><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], himg, params, t->partial_dev, nullptr, nullptr);
     } else if (write_terms) {
-        k_res_gs<true><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], t->pyr_dev[lvl], t->params_dev, t->partial_dev,
+        k_res_gs<true><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], t->pyr_dev[lvl], params, t->partial_dev,
                                                       t->terms_dev, t->status_dev);
         t->terms_lvl = lvl;
     } else {
-        k_res_gs<false><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], t->pyr_dev[lvl], t->params_dev, t->partial_dev,
+        k_res_gs<false><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], t->pyr_dev[lvl], params, t->partial_dev,
                                                        nullptr, nullptr);
     }
     k_finalize<<<B, 128, 0, t->stream>>>(t->partial_dev, chunks, out_dev);
@@ -160,9 +160,8 @@ static int launch_res_gs(sdvgn_tracker* t, int lvl, int B, const double* pose7, 
 static int res_gs_sync(sdvgn_tracker* t, int lvl, const double* pose7, double a, double b, float cutoffTH,
                        bool write_terms, double* out6, double* H, double* bv) {
     const double aff[2] = {a, b};
-    int rc = launch_res_gs(t, lvl, 1, pose7, aff, cutoffTH, write_terms, t->out_dev);
+    int rc = launch_res_gs(t, lvl, 1, pose7, aff, cutoffTH, write_terms, t->out_host, /*zero_copy=*/true);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(t->out_host, t->out_dev, sizeof(double) * kOutStride, hipMemcpyDeviceToHost, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     if (out6) std::memcpy(out6, t->out_host, 6 * sizeof(double));
     if (H) std::memcpy(H, t->out_host + 6, 64 * sizeof(double));
@@ -281,9 +280,7 @@ int sdvgn_tracker_create(sdvgn_tracker** out, int device, int w0, int h0, int le
     HIPCHK(hipHostMalloc(&t->out_host, sizeof(double) * kOutStride * max_batch));
     HIPCHK(hipMalloc(&t->terms_dev, sizeof(float) * 8 * (size_t)max_points));
     HIPCHK(hipMalloc(&t->status_dev, sizeof(int) * (size_t)max_points));
-    HIPCHK(hipMalloc(&t->track_dev, sizeof(TrackState) * max_batch));
     HIPCHK(hipHostMalloc(&t->track_host, sizeof(TrackState) * max_batch));
-    HIPCHK(hipMalloc(&t->tconst_dev, sizeof(TrackConst)));
     HIPCHK(hipStreamSynchronize(t->stream));
     *out = t;
     return SDVGN_OK;
@@ -296,8 +293,8 @@ void sdvgn_tracker_destroy(sdvgn_tracker* t) {
     for (int l = 0; l < t->levels; ++l) { hipFree(t->pc_dev[l]); hipFree(t->pyr_dev[l]); if (t->pyr_half_dev[l]) hipFree(t->pyr_half_dev[l]); }
     hipFree(t->img_stage_dev); hipFree(t->params_dev); hipHostFree(t->params_host); hipFree(t->partial_dev);
     hipFree(t->out_dev); hipHostFree(t->out_host); hipFree(t->terms_dev); hipFree(t->status_dev);
-    hipFree(t->track_dev); hipHostFree(t->track_host); hipFree(t->tconst_dev);
-    hipHostFree(t->sp_stage_host); hipFree(t->sp_stage_dev); hipFree(t->sp_io_dev); hipHostFree(t->sp_io_host);
+    hipHostFree(t->track_host);
+    hipHostFree(t->sp_stage_host); hipHostFree(t->sp_io_host);
     if (t->own_stream) hipStreamDestroy(t->stream);
     delete t;
 }
@@ -483,11 +480,9 @@ int sdvgn_tracker_track_batch(sdvgn_tracker* t, int B, double* pose7_io, double*
         for (int i = 0; i < 5; ++i) s.minRes[i] = minRes ? minRes[5 * b + i] : NAN;
         s.ok = 0; s.ntrials = 0;
     }
-    HIPCHK(hipMemcpyAsync(t->tconst_dev, &tc, sizeof(tc), hipMemcpyHostToDevice, t->stream));
-    HIPCHK(hipMemcpyAsync(t->track_dev, t->track_host, sizeof(TrackState) * B, hipMemcpyHostToDevice, t->stream));
-    k_track<<<B, kTrackThreads, 0, t->stream>>>(t->tconst_dev, t->track_dev);
+    // no copy-engine transfers: the constants are a kernel argument, the per-hypothesis state blocks stay in pinned host memory
+    k_track<<<B, kTrackThreads, 0, t->stream>>>(tc, t->track_host);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(t->track_host, t->track_dev, sizeof(TrackState) * B, hipMemcpyDeviceToHost, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     for (int b = 0; b < B; ++b) {
         const TrackState& s = t->track_host[b];
@@ -522,17 +517,13 @@ static int struct_pose_run(sdvgn_tracker* t, int mode, int n, const float* u, co
     const size_t bytes = np * 4 * 6 + (size_t)n_hosts * 12 * 4;
     if (bytes > t->sp_cap_bytes) {
         HIPCHK(hipStreamSynchronize(t->stream));
-        hipHostFree(t->sp_stage_host); hipFree(t->sp_stage_dev);
-        t->sp_stage_host = t->sp_stage_dev = nullptr; t->sp_cap_bytes = 0;
+        hipHostFree(t->sp_stage_host);
+        t->sp_stage_host = nullptr; t->sp_cap_bytes = 0;
         const size_t cap = bytes * 2 + 4096;
         HIPCHK(hipHostMalloc(&t->sp_stage_host, cap));
-        HIPCHK(hipMalloc(&t->sp_stage_dev, cap));
         t->sp_cap_bytes = cap;
     }
-    if (!t->sp_io_dev) {
-        HIPCHK(hipMalloc((void**)&t->sp_io_dev, sizeof(StructIO)));
-        HIPCHK(hipHostMalloc((void**)&t->sp_io_host, sizeof(StructIO)));
-    }
+    if (!t->sp_io_host) HIPCHK(hipHostMalloc((void**)&t->sp_io_host, sizeof(StructIO)));
     float* hs = (float*)t->sp_stage_host;
     float* hu = hs, *hv = hs + np, *hid = hs + 2 * np;
     int* hh = (int*)(hs + 3 * np);
@@ -550,18 +541,17 @@ static int struct_pose_run(sdvgn_tracker* t, int mode, int n, const float* u, co
     }
     std::memset(t->sp_io_host, 0, sizeof(StructIO));
     for (int i = 0; i < 7; ++i) t->sp_io_host->pose[i] = pose7_in[i];
-    HIPCHK(hipMemcpyAsync(t->sp_stage_dev, t->sp_stage_host, bytes, hipMemcpyHostToDevice, t->stream));
-    HIPCHK(hipMemcpyAsync(t->sp_io_dev, t->sp_io_host, sizeof(StructIO), hipMemcpyHostToDevice, t->stream));
+    // zero-copy: the kernel reads the 29 kB of packed inputs once, coalesced, straight from pinned host memory and keeps its
+    // result block there too -- two copy-engine round trips (10-20 us each) would cost more than the whole kernel's arithmetic
     StructConst C;
     C.fx = t->fx[0]; C.fy = t->fy[0]; C.cx = t->cx[0]; C.cy = t->cy[0];
     C.fxi = t->Ki[0][0]; C.fyi = t->Ki[0][4];                    // fxi[0] = Ki[0](0,0) (:101-102)
     C.wM3G = (float)(t->w[0] - 3); C.hM3G = (float)(t->h[0] - 3); // globalCalib.cpp:46-47
     C.n = n; C.n_hosts = n_hosts; C.mode = mode;
-    float* ds = (float*)t->sp_stage_dev;
+    const float* ds = (const float*)t->sp_stage_host;
     k_struct_pose<<<1, kStructThreads, 0, t->stream>>>(C, ds, ds + np, ds + 2 * np, (const int*)(ds + 3 * np), ds + 6 * np,
-                                                     (const float2*)(ds + 4 * np), t->sp_io_dev);
+                                                     (const float2*)(ds + 4 * np), t->sp_io_host);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(t->sp_io_host, t->sp_io_dev, sizeof(StructIO), hipMemcpyDeviceToHost, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     return SDVGN_OK;
 }
