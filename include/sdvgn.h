@@ -144,6 +144,42 @@ int sdvgn_tracker_struct_res_hb(sdvgn_tracker* t, int n, const float* u, const f
 int sdvgn_struct_trace_stride(void);
 
 /* ===================================================================================================
+ * Reprojector -- the per-candidate work of class Reprojector (src/FullSystem/Reprojector.h:17-112); SURVEY.md 8f row 2
+ * =================================================================================================== */
+typedef struct sdvgn_reproj sdvgn_reproj;
+
+/* Reprojector::Reprojector(CalibHessian*, FrameHessian* newframe, std::vector<FrameHessian*>&)   Reprojector.cpp:81-87.
+ * The handle outlives one frame: key-frames are (re)registered with set_frame, the new frame with set_cur / set_cur_level.
+ * max_frames <= 16 (index space of host_idx / ref_idx), max_points bounds n of sdvgn_reproj_match. */
+int sdvgn_reproj_create(sdvgn_reproj** out, int device, int w0, int h0, int levels, int max_frames, int max_points, void* stream);
+void sdvgn_reproj_destroy(sdvgn_reproj* r);
+void* sdvgn_reproj_stream(sdvgn_reproj* r);
+/* K_ = [fxl 0 cxl; 0 fyl cyl; 0 0 1] in double (:85-86); K_.inverse() is taken once, in Eigen's closed cofactor form */
+int sdvgn_reproj_set_calib(sdvgn_reproj* r, float fx, float fy, float cx, float cy);
+/* key-frame idx: shell->camToWorld.data(), its level-0 image `dI` (AoS {I,dx,dy}, w0*h0*3 floats) either as a host buffer
+ * (copied) or as a device pointer that stays valid (e.g. the image the back-end handle already holds) -- pass exactly one, or
+ * neither to keep the image registered earlier; ab_exposure and shell->aff_g2l (a,b) feed AffLight::fromToVecExposure (:253-255) */
+int sdvgn_reproj_set_frame(sdvgn_reproj* r, int idx, const double* camToWorld7, const float* dI_aos3, const float* dI_aos3_dev,
+                           float ab_exposure, double aff_a, double aff_b);
+/* the new frame: pose, exposure, aff_g2l; and its pyramid dIp[lvl] (host copy or device pointer, e.g. sdvgn_tracker's) */
+int sdvgn_reproj_set_cur(sdvgn_reproj* r, const double* camToWorld7, float ab_exposure, double aff_a, double aff_b);
+int sdvgn_reproj_set_cur_level(sdvgn_reproj* r, int lvl, const float* dIp_aos3, const float* dIp_aos3_dev);
+/* For n candidate points (u, v, idepth = PointHessian::idepth, host_idx = index of pt->host, ref_idx = index of the frame the
+ * reference patch is taken from (pt->host when the window has more than two frames, :240-251), type 0 = CORNER / 1 = EDGELET):
+ *   px0[2n], cell[n]   Reprojector::reprojectPoint (:602-616): projection into the new frame; grid cell index
+ *                      (cell_size 25, ceil(w/25) columns) or -1 when outside the 8-pixel border (the point is not a candidate)
+ *   quality[n]         |(dx,dy)| of host->dI at (int)(v*w+u): the key of pointQualityComparator (:186-194)
+ *   success[n], px[2n] Reprojector::findMatchDirect (:236-291) started from px0: getWarpMatrixAffine, getBestSearchLevel,
+ *                      warpAffine, createPatchFromPatchWithBorder, align2D / align1D (10 iterations max); px = the aligned
+ *                      position when success, evaluated for every candidate with cell >= 0
+ *   level[n]           search level used (optional, may be NULL)
+ * The caller replays the reference's selection (per-cell sort by quality, random cell order, first success per cell, stop after
+ * 0.8*setting_desiredImmatureDensity matches, :117-156,196-234) on these arrays.  Deviation: a candidate whose inverse affine
+ * warp is NaN fails here; the reference would align it against the previous candidate's stale patch (:64-68). */
+int sdvgn_reproj_match(sdvgn_reproj* r, int n, const float* u, const float* v, const float* idepth, const int* host_idx, const int* ref_idx,
+                       const int* type, double* px0, int* cell, float* quality, int* success, double* px, int* level);
+
+/* ===================================================================================================
  * Sliding-window back end -- replaces the data-parallel part of class EnergyFunctional
  * (src/OptimizationBackend/EnergyFunctional.h:36-138) and of FullSystem::linearizeAll
  * (src/FullSystem/FullSystemOptimize.cpp:99-159) on a flattened copy of the EF graph.

@@ -75,11 +75,18 @@ def load_library(path=LIB_PATH):
 
 
 def _extra_prototypes():
+    out = []
     try:
         from .backend_api import PROTOTYPES as P2
-        return list(P2)
+        out += list(P2)
     except ImportError:
-        return []
+        pass
+    try:
+        from .reproject_api import PROTOTYPES as P3
+        out += list(P3)
+    except ImportError:
+        pass
+    return out
 
 
 def check(rc):

@@ -363,3 +363,37 @@ def make_struct_problem(n=1200, n_hosts=7, w=1241, h=376, seed=0, calib=KITTI00,
     P.obs = obs
     P.init_curToWorld7 = _se3_mul_np(gt, se3_exp_np(np.concatenate([rng.normal(0, pose_err[0], 3), rng.normal(0, pose_err[1], 3)])))
     return P
+
+
+# =====================================================================================================
+# Reprojector: the last key-frame of a synthetic window plays the new frame; the active
+# points of the other key-frames are the candidates.
+# =====================================================================================================
+class ReprojectProblem:
+    pass
+
+
+def make_reproject_problem(W, levels=3, seed=0, pose_err=(0.01, 0.001), edgelet_frac=0.3):
+    """W: a Window from make_window().  Returns ReprojectProblem with frames (camToWorld7, level-0 AoS image) for key-frames
+    0..nF-2, the current frame (camToWorld7 perturbed from the ground truth so that the alignment has something to do, image
+    pyramid), and the candidate points (u, v, idepth, host_idx, type; ref_idx = host_idx as in a window of > 2 frames)."""
+    rng = np.random.default_rng(seed + 12000)
+    P = ReprojectProblem()
+    P.w, P.h, P.levels, P.calib = W.w, W.h, levels, dict(W.calib)
+    nK = W.nF - 1
+    P.frame_poses7 = np.array([_se3_inv_np(W.gt_worldToCam[k]) for k in range(nK)])
+    P.frame_images = [W.pyr0[k] for k in range(nK)]
+    P.frame_exposure = np.ones(nK, np.float32)
+    P.frame_aff = np.zeros((nK, 2))
+    gt_cur = _se3_inv_np(W.gt_worldToCam[nK])
+    P.gt_cur_pose7 = gt_cur
+    P.cur_pose7 = _se3_mul_np(gt_cur, se3_exp_np(np.concatenate([rng.normal(0, pose_err[0], 3), rng.normal(0, pose_err[1], 3)])))
+    P.cur_pyr = pyramid_numpy(W.images[nK], levels)
+    P.cur_exposure, P.cur_aff = np.float32(1.0), (0.0, 0.0)
+    sel = W.host < nK
+    P.u, P.v, P.idepth = W.u[sel].copy(), W.v[sel].copy(), W.idepth[sel].copy()
+    P.host_idx = W.host[sel].astype(np.int32)
+    P.ref_idx = P.host_idx.copy()
+    P.type = (rng.random(int(sel.sum())) < edgelet_frac).astype(np.int32)      # 0 = CORNER, 1 = EDGELET (HessianBlocks.h:401)
+    P.n = int(sel.sum())
+    return P
