@@ -249,6 +249,43 @@ def tracker_extras(torch, local, batch, oracle, want_cpu):
     return out
 
 
+def reproject_extras(W, G, local, want_cpu):
+    """SURVEY 8f-2 at the named shape: the last key-frame of the window plays the new frame, the 14 000 active points of the other
+    seven are the candidates; one call = reprojectPoint + findMatchDirect for ALL of them (the reference evaluates them lazily, about
+    one to two per grid cell until 0.8*desiredImmatureDensity matches are found)."""
+    from sdv_loam_amd import reproject_api, synthetic as syn
+    P = syn.make_reproject_problem(W, levels=4, seed=0, pose_err=(0.02, 0.002))
+    R = reproject_api.Reprojector(P.w, P.h, P.levels, max_frames=8, max_points=P.n, device=local)
+    R.set_calib(**P.calib)
+    for k in range(len(P.frame_poses7)):
+        R.set_frame(k, P.frame_poses7[k], P.frame_images[k])
+    R.set_cur(P.cur_pose7, P.cur_pyr)
+    a = (P.u, P.v, P.idepth, P.host_idx, P.ref_idx, P.type)
+    for _ in range(3):
+        g = R.match(*a)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        g = R.match(*a)
+    ms = 1e3 * (time.perf_counter() - t0) / 20
+    out = dict(candidates=int(P.n), in_grid=int((g["cell"] >= 0).sum()), matched=int(g["success"].sum()), call_ms=ms,
+               candidates_per_s=P.n / (ms * 1e-3))
+    if want_cpu:
+        from oracle.reproject import OracleReprojector
+        O = OracleReprojector(P.w, P.h, P.levels)
+        O.set_calib(**P.calib)
+        for k in range(len(P.frame_poses7)):
+            O.set_frame(k, P.frame_poses7[k], P.frame_images[k])
+        O.set_cur(P.cur_pose7, P.cur_pyr)
+        t0 = time.perf_counter()
+        px0, cell, q = O.project(P.u, P.v, P.idepth, P.host_idx)
+        sel = cell >= 0
+        ok, pm, _ = O.find_match(P.u[sel], P.v[sel], P.idepth[sel], P.host_idx[sel], P.ref_idx[sel], P.type[sel], px0[sel])
+        dt = time.perf_counter() - t0
+        out["cpu_all_candidates_ms_1thread"] = 1e3 * dt
+        out["cpu_us_per_candidate"] = 1e6 * dt / max(int(sel.sum()), 1)
+    return out
+
+
 def main():
     args = parse()
     if args.pmc_child:
@@ -314,6 +351,8 @@ def main():
     if rank == 0 and not args.quick:
         import oracle
         out["tracker"] = tracker_extras(torch, local, args.batch, oracle, not args.no_cpu)
+    if rank == 0 and not args.quick:
+        out["reprojector"] = reproject_extras(W, G, local, not args.no_cpu)
     if rank == 0 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_backend(W)
     if rank == 0:

@@ -87,10 +87,29 @@ def struct_pose_golden():
                         final_res=np.array(fr))
 
 
+def reproject_golden():
+    from oracle.reproject import OracleReprojector
+    W = syn.make_window(w=200, h=96, nF=3, pts_per_kf=80, seed=9, calib=dict(fx=150., fy=152., cx=99.5, cy=47.5))
+    P = syn.make_reproject_problem(W, levels=2, seed=9, pose_err=(0.01, 0.001), edgelet_frac=0.4)
+    O = OracleReprojector(P.w, P.h, P.levels)
+    O.set_calib(**P.calib)
+    for k in range(len(P.frame_poses7)):
+        O.set_frame(k, P.frame_poses7[k], P.frame_images[k], 1.0, 0.01 * k, 0.3 * k)
+    O.set_cur(P.cur_pose7, P.cur_pyr, 1.0, 0.02, 1.0)
+    px0, cell, q = O.project(P.u, P.v, P.idepth, P.host_idx)
+    ok, pm, lvl = O.find_match(P.u, P.v, P.idepth, P.host_idx, P.ref_idx, P.type, px0)
+    out = dict(w=P.w, h=P.h, levels=P.levels, calib=np.array([P.calib[k] for k in ("fx", "fy", "cx", "cy")]), frame_poses7=P.frame_poses7,
+               frame_I=np.stack([img[..., 0] for img in P.frame_images]), cur_I=P.cur_pyr[0][..., 0], cur_pose7=P.cur_pose7,
+               u=P.u, v=P.v, idepth=P.idepth, host_idx=P.host_idx, ref_idx=P.ref_idx, type=P.type,
+               px0=px0, cell=cell, quality=q, success=ok, px=pm, level=lvl)
+    np.savez_compressed(os.path.join(HERE, "reproject_small.npz"), **out)
+
+
 if __name__ == "__main__":
     tracker_golden()
     backend_golden()
     struct_pose_golden()
+    reproject_golden()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

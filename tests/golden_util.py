@@ -42,3 +42,20 @@ def load_struct_pose():
     fx, fy, cx, cy = (float(x) for x in g["calib"])
     args = (g["u"], g["v"], g["idepth"], g["host_idx"], g["host_poses7"], g["obs"])
     return g, dict(fx=fx, fy=fy, cx=cx, cy=cy), args
+
+
+def load_reproject():
+    """Returns (g, setup) where setup(T) registers calib, key-frames and the new frame on an Oracle/GPU reprojector.  Only the
+    intensities are stored; the {I,dx,dy} images are rebuilt with the (bit-exact, tested) numpy pyramid mirror."""
+    from sdv_loam_amd import synthetic as syn
+    g = np.load(os.path.join(HERE, "reproject_small.npz"))
+    fx, fy, cx, cy = (float(x) for x in g["calib"])
+    levels = int(g["levels"])
+
+    def setup(T):
+        T.set_calib(fx, fy, cx, cy)
+        for k in range(len(g["frame_poses7"])):
+            T.set_frame(k, g["frame_poses7"][k], syn.pyramid_numpy(g["frame_I"][k], 1)[0], 1.0, 0.01 * k, 0.3 * k)
+        T.set_cur(g["cur_pose7"], syn.pyramid_numpy(g["cur_I"], levels), 1.0, 0.02, 1.0)
+        return T
+    return g, setup

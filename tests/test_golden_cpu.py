@@ -49,3 +49,15 @@ def test_struct_pose_oracle_matches_golden(orc):
     pose, trace, fr = T.structPoseEstimation(g["init"], *args)
     assert np.allclose(pose, g["pose"], rtol=1e-12, atol=1e-14) and np.allclose(trace, g["trace"], rtol=1e-10, atol=1e-14)
     assert np.isclose(fr, float(g["final_res"]), rtol=1e-12)
+
+
+def test_reproject_oracle_matches_golden(orc):
+    from golden_util import load_reproject
+    from oracle.reproject import OracleReprojector
+    g, setup = load_reproject()
+    O = setup(OracleReprojector(int(g["w"]), int(g["h"]), int(g["levels"])))
+    a = (g["u"], g["v"], g["idepth"], g["host_idx"])
+    px0, cell, q = O.project(*a)
+    assert np.array_equal(px0, g["px0"]) and np.array_equal(cell, g["cell"]) and np.array_equal(q, g["quality"])
+    ok, pm, lvl = O.find_match(*a, g["ref_idx"], g["type"], px0)
+    assert np.array_equal(ok, g["success"]) and np.array_equal(lvl, g["level"]) and np.array_equal(pm[ok], g["px"][g["success"]])

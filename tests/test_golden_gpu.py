@@ -69,3 +69,16 @@ def test_struct_pose_gpu_matches_golden(sdvgn_lib):
     else:
         assert len(trace) == len(gt) and abs(fr - g["final_res"]) <= 1e-5 * g["final_res"]
     assert rel_err(pose, g["pose"]) < 1e-6
+
+
+def test_reproject_gpu_matches_golden(sdvgn_lib):
+    from golden_util import load_reproject
+    from sdv_loam_amd import reproject_api
+    g, setup = load_reproject()
+    G = setup(reproject_api.Reprojector(int(g["w"]), int(g["h"]), int(g["levels"]), max_frames=4, max_points=1024))
+    r = G.match(g["u"], g["v"], g["idepth"], g["host_idx"], g["ref_idx"], g["type"])
+    cand = g["cell"] >= 0
+    assert np.abs(r["px0"] - g["px0"]).max() < 1e-9 and np.array_equal(r["cell"], g["cell"]) and np.array_equal(r["quality"], g["quality"])
+    assert np.array_equal(r["success"][cand], g["success"][cand]) and np.array_equal(r["level"][cand], g["level"][cand])
+    good = cand & g["success"]
+    assert good.sum() > 20 and np.array_equal(r["px"][good], g["px"][good])
