@@ -12,8 +12,8 @@
 //
 // One lane = one candidate.  The lane runs the reference's loops in the reference's order (sequential float accumulation over the
 // 8x8 patch), which makes success flags and sub-pixel positions bit-identical to the CPU restatement; the 10x10 uint8 reference
-// patch of every lane lives in LDS ([100 bytes][64 lanes]), its gradients are recomputed from it on the fly (exact: halves of
-// integer differences).  Geometry is fp64 like the reference's Eigen::Vector3d / SE3 code.  Memory behaviour: ~400 scattered 4-B
+// patch of every lane is assembled in LDS ([100 bytes][64 lanes]) and then packed, with its integer gradients, into 64 registers
+// (the alignment loops are fully unrolled; gradients are exact halves of integer differences).  Geometry is fp64 like the reference's Eigen::Vector3d / SE3 code.  Memory behaviour: ~400 scattered 4-B
 // taps for the warp and <= 10 x 81 for the alignment per candidate, all inside a 5.6 MB image / pyramid level -> cache resident,
 // latency-bound; one workgroup = one wave so that 220+ workgroups spread over the chip.
 #include "../../include/sdvgn.h"
@@ -73,6 +73,18 @@ __device__ __forceinline__ float interp_I(const float* __restrict__ mat, float x
     const float dx = x - ix, dy = y - iy, dxdy = dx * dy;
     const float* bp = mat + 3 * (ix + iy * width);
     return ((dxdy * bp[3 + 3 * width] + (dy - dxdy) * bp[3 * width]) + (dx - dxdy) * bp[3]) + (1 - dx - dy + dxdy) * bp[0];
+}
+
+// The 9x9 intensity window an alignment iteration reads (8x8 pixels x 4 bilinear taps), fetched as ONE batch of 81 independent
+// loads: the kernel is bound by memory round trips (one wave per SIMD at most), so the loads of an iteration must be in flight
+// together instead of row by row.
+__device__ __forceinline__ void load_window(const float* __restrict__ cur, int wl, int u_r, int v_r, float (&win)[9][9]) {
+    const float* base = cur + 3 * ((size_t)(v_r - 4) * wl + (u_r - 4));
+#pragma unroll
+    for (int yy = 0; yy < 9; ++yy)
+#pragma unroll
+        for (int xx = 0; xx < 9; ++xx) win[yy][xx] = base[3 * ((size_t)yy * wl + xx)];
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // grid = ceil(n / 64), block = 64.  Outputs per candidate: px0 (projection into the new frame), cell (-1: outside the 8-px border),
@@ -169,19 +181,49 @@ __global__ void __launch_bounds__(64) k_reproject(const RpConst* __restrict__ Cp
             const float prx = (float)px[0], pry = (float)px[1];
             const float scale = (float)(1 << lvl);
             const float* __restrict__ img = ref.dI;
-            for (int y = 0; y < 10; ++y) {
+            for (int y0 = 0; y0 < 10; y0 += 2) {   // two patch rows = 80 independent tap loads per memory round trip
+                float tap[2][10][4], fdx[2][10], fdy[2][10];
+                bool inside[2][10];
 #pragma unroll
-                for (int x = 0; x < 10; ++x) {
-                    const float ppx = (float)(x - 5) * scale, ppy = (float)(y - 5) * scale;
-                    const float qx = (a00 * ppx + a01 * ppy) + prx;
-                    const float qy = (a10 * ppx + a11 * ppy) + pry;
-                    unsigned char val = 0;
-                    if (!(qx < 0 || qy < 0 || qx >= w0 - 1 || qy >= h0 - 1)) val = (unsigned char)(int)interp_I(img, qx, qy, w0);
-                    s_pwb[y * 10 + x][lane] = val;
-                }
+                for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                    for (int x = 0; x < 10; ++x) {
+                        const float ppx = (float)(x - 5) * scale, ppy = (float)(y0 + yy - 5) * scale;
+                        const float qx = (a00 * ppx + a01 * ppy) + prx;
+                        const float qy = (a10 * ppx + a11 * ppy) + pry;
+                        inside[yy][x] = !(qx < 0 || qy < 0 || qx >= w0 - 1 || qy >= h0 - 1);
+                        const float sxq = inside[yy][x] ? qx : 0.0f, syq = inside[yy][x] ? qy : 0.0f;
+                        const int ix = (int)sxq, iy = (int)syq;
+                        fdx[yy][x] = sxq - ix; fdy[yy][x] = syq - iy;
+                        const float* bp = img + 3 * (ix + iy * w0);
+                        tap[yy][x][0] = bp[0]; tap[yy][x][1] = bp[3]; tap[yy][x][2] = bp[3 * w0]; tap[yy][x][3] = bp[3 + 3 * w0];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                    for (int x = 0; x < 10; ++x) {
+                        // getInterpolatedElement33(...)[0] (globalFuncs.h:51-65), same operation order as interp_I
+                        const float dx = fdx[yy][x], dy = fdy[yy][x], dxdy = dx * dy;
+                        const float val = ((dxdy * tap[yy][x][3] + (dy - dxdy) * tap[yy][x][2]) + (dx - dxdy) * tap[yy][x][1]) + (1 - dx - dy + dxdy) * tap[yy][x][0];
+                        s_pwb[(y0 + yy) * 10 + x][lane] = inside[yy][x] ? (unsigned char)(int)val : (unsigned char)0;
+                    }
             }
         }
 #define PWB(yy, xx) ((int)s_pwb[(yy) * 10 + (xx)][lane])   /* patch_with_border_[y][x]; patch_[y][x] = PWB(y+1, x+1) (:338-347) */
+        // One packed word per patch pixel, built once: intensity (8 bits) and the two integer central differences (+256, 10 bits
+        // each).  The alignment loops are fully unrolled, so these 64 words stay in registers and an iteration costs no LDS traffic
+        // (5 byte reads per pixel and iteration made the first version of this kernel LDS-issue-bound).
+        unsigned pk[64];
+#pragma unroll
+        for (int y = 0; y < 8; ++y)
+#pragma unroll
+            for (int x = 0; x < 8; ++x)
+                pk[y * 8 + x] = (unsigned)PWB(y + 1, x + 1) | ((unsigned)(PWB(y + 1, x + 2) - PWB(y + 1, x) + 256) << 8) |
+                                ((unsigned)(PWB(y + 2, x + 1) - PWB(y, x + 1) + 256) << 18);
+#define PK_I(k) ((int)(pk[k] & 255u))
+#define PK_DX(k) ((int)((pk[k] >> 8) & 1023u) - 256)
+#define PK_DY(k) ((int)((pk[k] >> 18) & 1023u) - 256)
         const int wl = C.w[lvl], hl = C.h[lvl];
         const float* __restrict__ cur = C.cur[lvl];
         const float aff0 = ref.affLL[0], aff1 = ref.affLL[1];
@@ -202,10 +244,11 @@ __global__ void __launch_bounds__(64) k_reproject(const RpConst* __restrict__ Cp
                 dir0 = (float)d0; dir1 = (float)d1;
             }
             float H0 = 0, H1 = 0, H2 = 0, H3 = 0;
+#pragma unroll
             for (int y = 0; y < 8; ++y)
 #pragma unroll
                 for (int x = 0; x < 8; ++x) {
-                    const float J0 = (float)(0.5 * (double)(dir0 * (float)(PWB(y + 1, x + 2) - PWB(y + 1, x)) + dir1 * (float)(PWB(y + 2, x + 1) - PWB(y, x + 1))));
+                    const float J0 = (float)(0.5 * (double)(dir0 * (float)PK_DX(y * 8 + x) + dir1 * (float)PK_DY(y * 8 + x)));
                     H0 += J0 * J0; H1 += J0 * 1.0f; H2 += 1.0f * J0; H3 += 1.0f * 1.0f;
                 }
             const float hdet = H0 * H3 - H1 * H2;
@@ -221,13 +264,15 @@ __global__ void __launch_bounds__(64) k_reproject(const RpConst* __restrict__ Cp
                 const float wBL = (float)((1.0 - (double)sx) * (double)sy);
                 const float wBR = sx * sy;
                 float Jr0 = 0, Jr1 = 0;
-                for (int y = 0; y < 8; ++y) {
-                    const float* it = cur + 3 * ((size_t)(v_r + y - 4) * wl + u_r - 4);
+                float win[9][9];
+                load_window(cur, wl, u_r, v_r, win);
 #pragma unroll
-                    for (int x = 0; x < 8; ++x, it += 3) {
-                        const float sp = ((wTL * it[0] + wTR * it[3]) + wBL * it[3 * wl]) + wBR * it[3 * wl + 3];
-                        const float res = (sp - (float)(aff0 * (float)PWB(y + 1, x + 1) + aff1)) + mean_diff;
-                        const float J0 = (float)(0.5 * (double)(dir0 * (float)(PWB(y + 1, x + 2) - PWB(y + 1, x)) + dir1 * (float)(PWB(y + 2, x + 1) - PWB(y, x + 1))));
+                for (int y = 0; y < 8; ++y) {
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) {
+                        const float sp = ((wTL * win[y][x] + wTR * win[y][x + 1]) + wBL * win[y + 1][x]) + wBR * win[y + 1][x + 1];
+                        const float res = (sp - (float)(aff0 * (float)PK_I(y * 8 + x) + aff1)) + mean_diff;
+                        const float J0 = (float)(0.5 * (double)(dir0 * (float)PK_DX(y * 8 + x) + dir1 * (float)PK_DY(y * 8 + x)));
                         Jr0 -= res * J0;
                         Jr1 -= res;
                     }
@@ -241,10 +286,11 @@ __global__ void __launch_bounds__(64) k_reproject(const RpConst* __restrict__ Cp
         } else {
             // CORNER -> align2D (:449-545)
             float H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
             for (int y = 0; y < 8; ++y)
 #pragma unroll
                 for (int x = 0; x < 8; ++x) {
-                    const float J[3] = {(float)(0.5 * (double)(PWB(y + 1, x + 2) - PWB(y + 1, x))), (float)(0.5 * (double)(PWB(y + 2, x + 1) - PWB(y, x + 1))), 1.0f};
+                    const float J[3] = {(float)(0.5 * (double)PK_DX(y * 8 + x)), (float)(0.5 * (double)PK_DY(y * 8 + x)), 1.0f};
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -262,14 +308,16 @@ __global__ void __launch_bounds__(64) k_reproject(const RpConst* __restrict__ Cp
                 const float wBL = (float)((1.0 - (double)sx) * (double)sy);
                 const float wBR = sx * sy;
                 float Jr0 = 0, Jr1 = 0, Jr2 = 0;
-                for (int y = 0; y < 8; ++y) {
-                    const float* it = cur + 3 * ((size_t)(v_r + y - 4) * wl + u_r - 4);
+                float win[9][9];
+                load_window(cur, wl, u_r, v_r, win);
 #pragma unroll
-                    for (int x = 0; x < 8; ++x, it += 3) {
-                        const float sp = ((wTL * it[0] + wTR * it[3]) + wBL * it[3 * wl]) + wBR * it[3 * wl + 3];
-                        const float res = (sp - (float)(aff0 * (float)PWB(y + 1, x + 1) + aff1)) + mean_diff;
-                        const float dxv = (float)(0.5 * (double)(PWB(y + 1, x + 2) - PWB(y + 1, x)));
-                        const float dyv = (float)(0.5 * (double)(PWB(y + 2, x + 1) - PWB(y, x + 1)));
+                for (int y = 0; y < 8; ++y) {
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) {
+                        const float sp = ((wTL * win[y][x] + wTR * win[y][x + 1]) + wBL * win[y + 1][x]) + wBR * win[y + 1][x + 1];
+                        const float res = (sp - (float)(aff0 * (float)PK_I(y * 8 + x) + aff1)) + mean_diff;
+                        const float dxv = (float)(0.5 * (double)PK_DX(y * 8 + x));
+                        const float dyv = (float)(0.5 * (double)PK_DY(y * 8 + x));
                         Jr0 -= res * dxv;
                         Jr1 -= res * dyv;
                         Jr2 -= res;
@@ -285,6 +333,9 @@ __global__ void __launch_bounds__(64) k_reproject(const RpConst* __restrict__ Cp
             }
         }
 #undef PWB
+#undef PK_I
+#undef PK_DX
+#undef PK_DY
         if (!nan_exit) { pxs[0] = (double)uu; pxs[1] = (double)vv; }   // `cur_px_estimate << u, v` (not reached on the NaN return)
         pxs[0] = pxs[0] * (1 << lvl); pxs[1] = pxs[1] * (1 << lvl);   // px_cur = px_scaled * (1<<search_level_)
         success = (converged && !nan_exit) ? 1 : 0;
