@@ -143,6 +143,21 @@ int sdvgn_tracker_struct_res_hb(sdvgn_tracker* t, int n, const float* u, const f
                                 double* b6, double* energy, int* num);
 int sdvgn_struct_trace_stride(void);
 
+/* ImmaturePoint::traceOn(frame, hostToFrame_KRKi, hostToFrame_Kt, hostToFrame_affine, HCalib)   ImmaturePoint.cpp:47-353,
+ * for ALL immature points of all key-frames in one launch -- the loop of FullSystem::traceNewCoarse (FullSystem.cpp:519-553).
+ * The frame traced on is the tracker's current new frame (set_new_image / set_new_pyr level 0 = fh->dI).
+ * set_points registers the per-point data that does not change between frames (ImmaturePoint.h:33-75: u, v, energyTH, gradH as
+ * row-major 2x2, color[8], weights[8], and the index of its host key-frame, < 16); call it when immature points are created or
+ * deleted.  trace_points runs the search: per host h the caller passes exactly what traceNewCoarse computes -- KRKi9[h] = K *
+ * hostToNew.rotationMatrix().cast<float>() * K.inverse() (row-major), Kt3[h] = K * hostToNew.translation().cast<float>(),
+ * aff2[h] = AffLight::fromToVecExposure(host, new).cast<float>() -- and the per-point state arrays, updated in place:
+ * idepth_min, idepth_max, quality, status (= lastTraceStatus, enum ImmaturePointStatus 0..5, ImmaturePoint.h:20-30),
+ * lastTraceUV (2 per point), lastTracePixelInterval.  Points with status IPS_OOB are left untouched (:49). */
+int sdvgn_tracker_trace_set_points(sdvgn_tracker* t, int n, const float* u, const float* v, const float* energyTH, const float* gradH4,
+                                   const float* color8, const float* weights8, const int* host_idx);
+int sdvgn_tracker_trace_points(sdvgn_tracker* t, int n_hosts, const float* KRKi9, const float* Kt3, const float* aff2, float* idepth_min,
+                               float* idepth_max, float* quality, int* status, float* lastTraceUV2, float* lastTracePixelInterval);
+
 /* ===================================================================================================
  * Reprojector -- the per-candidate work of class Reprojector (src/FullSystem/Reprojector.h:17-112); SURVEY.md 8f row 2
  * =================================================================================================== */

@@ -45,6 +45,8 @@ PROTOTYPES = [
     ("sdvgn_tracker_struct_pose", C.c_int, [vp, C.c_int, f32p, f32p, f32p, i32p, C.c_int, f64p, f64p, f64p, vp, vp]),
     ("sdvgn_tracker_struct_res_hb", C.c_int, [vp, C.c_int, f32p, f32p, f32p, i32p, C.c_int, f64p, f64p, f64p, f64p, f64p, vp, vp]),
     ("sdvgn_struct_trace_stride", C.c_int, []),
+    ("sdvgn_tracker_trace_set_points", C.c_int, [vp, C.c_int, f32p, f32p, f32p, f32p, f32p, f32p, i32p]),
+    ("sdvgn_tracker_trace_points", C.c_int, [vp, C.c_int, f32p, f32p, f32p, f32p, f32p, f32p, i32p, f32p, f32p]),
 ]
 
 _LIB = None
@@ -260,3 +262,23 @@ class CoarseTracker:
                                                  np.ascontiguousarray(worldToCur7, np.float64), H, b, C.cast(C.byref(e), vp),
                                                  C.cast(C.byref(n), vp)))
         return H.reshape(6, 6), b, e.value, n.value
+
+    # -- ImmaturePoint::traceOn for all immature points (ImmaturePoint.cpp:47-353; FullSystem::traceNewCoarse) ----------
+    def traceSetPoints(self, u, v, energyTH, gradH, color, weights, host_idx):
+        u, v, energyTH = (np.ascontiguousarray(x, np.float32) for x in (u, v, energyTH))
+        gradH = np.ascontiguousarray(gradH, np.float32).reshape(-1)
+        color = np.ascontiguousarray(color, np.float32).reshape(-1)
+        weights = np.ascontiguousarray(weights, np.float32).reshape(-1)
+        self._trace_n = len(u)
+        check(self.L.sdvgn_tracker_trace_set_points(self.h_, len(u), u, v, energyTH, gradH, color, weights, np.ascontiguousarray(host_idx, np.int32)))
+
+    def tracePoints(self, KRKi, Kt, aff, idepth_min, idepth_max, quality, status, lastTraceUV=None, interval=None):
+        n = self._trace_n
+        KRKi = np.ascontiguousarray(KRKi, np.float32).reshape(-1, 9)
+        st = dict(idepth_min=np.array(idepth_min, np.float32), idepth_max=np.array(idepth_max, np.float32), quality=np.array(quality, np.float32),
+                  status=np.array(status, np.int32), lastTraceUV=np.zeros((n, 2), np.float32) if lastTraceUV is None else np.array(lastTraceUV, np.float32),
+                  interval=np.zeros(n, np.float32) if interval is None else np.array(interval, np.float32))
+        check(self.L.sdvgn_tracker_trace_points(self.h_, KRKi.shape[0], KRKi.reshape(-1), np.ascontiguousarray(Kt, np.float32).reshape(-1),
+                                                np.ascontiguousarray(aff, np.float32).reshape(-1), st["idepth_min"], st["idepth_max"], st["quality"],
+                                                st["status"], st["lastTraceUV"].reshape(-1), st["interval"]))
+        return st

@@ -27,6 +27,7 @@ using namespace sdvgn;
 namespace sdvgn {
 #include "tracker_track_kernel.inc"
 #include "tracker_struct_pose.inc"
+#include "tracker_trace_points.inc"
 }
 
 struct sdvgn_tracker {
@@ -73,6 +74,11 @@ struct sdvgn_tracker {
 
     // side outputs of the last track() call
     std::vector<double> trace;
+
+    // ImmaturePoint::traceOn (tracker_trace_points.inc): static per-point data resident on the device, dynamic state in pinned memory
+    int tp_n = 0, tp_cap = 0;
+    float* tp_static_dev = nullptr;     // u | v | energyTH | gradH(4) | color(8) | weights(8) | host_idx : 23 words per point
+    void* tp_state_host = nullptr;      // pinned: idepth_min | idepth_max | quality | status | lastTraceUV(2) | interval : 7 words per point
 
     // structPoseEstimation (tracker_struct_pose.inc): packed input staging and the result block, both pinned host memory
     void* sp_stage_host = nullptr;   // pinned, read by the kernel directly
@@ -295,6 +301,7 @@ void sdvgn_tracker_destroy(sdvgn_tracker* t) {
     hipFree(t->out_dev); hipHostFree(t->out_host); hipFree(t->terms_dev); hipFree(t->status_dev);
     hipHostFree(t->track_host);
     hipHostFree(t->sp_stage_host); hipHostFree(t->sp_io_host);
+    hipFree(t->tp_static_dev); hipHostFree(t->tp_state_host);
     if (t->own_stream) hipStreamDestroy(t->stream);
     delete t;
 }
@@ -586,3 +593,68 @@ int sdvgn_tracker_struct_res_hb(sdvgn_tracker* t, int n, const float* u, const f
 }
 
 int sdvgn_struct_trace_stride(void) { return kStructTraceStride; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// ImmaturePoint::traceOn for all immature points (first part)
+// ---------------------------------------------------------------------------------------------------------------
+int sdvgn_tracker_trace_set_points(sdvgn_tracker* t, int n, const float* u, const float* v, const float* energyTH, const float* gradH4,
+                                   const float* color8, const float* weights8, const int* host_idx) {
+    if (!t || n < 0) return SDVGN_E_ARG;
+    if (n > 0 && (!u || !v || !energyTH || !gradH4 || !color8 || !weights8 || !host_idx)) return SDVGN_E_ARG;
+    for (int i = 0; i < n; ++i) if (host_idx[i] < 0 || host_idx[i] >= kTraceMaxHosts) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    const size_t np = ((size_t)n + 63) & ~(size_t)63;
+    if ((int)np > t->tp_cap) {
+        HIPCHK(hipStreamSynchronize(t->stream));
+        hipFree(t->tp_static_dev); hipHostFree(t->tp_state_host);
+        t->tp_static_dev = nullptr; t->tp_state_host = nullptr; t->tp_cap = 0;
+        const size_t cap = np + np / 2 + 1024;
+        HIPCHK(hipMalloc((void**)&t->tp_static_dev, sizeof(float) * 24 * cap));
+        HIPCHK(hipHostMalloc(&t->tp_state_host, sizeof(float) * 8 * cap));
+        t->tp_cap = (int)cap;
+    }
+    t->tp_n = n;
+    if (n == 0) return SDVGN_OK;
+    const size_t cap = t->tp_cap;
+    std::vector<float> st(24 * cap, 0.f);
+    float* su = st.data(), *sv = su + cap, *se = sv + cap, *sg = se + cap, *sc = sg + 4 * cap, *sw = sc + 8 * cap;
+    int* sh = (int*)(sw + 8 * cap);
+    std::memcpy(su, u, 4 * (size_t)n); std::memcpy(sv, v, 4 * (size_t)n); std::memcpy(se, energyTH, 4 * (size_t)n);
+    std::memcpy(sg, gradH4, 16 * (size_t)n); std::memcpy(sc, color8, 32 * (size_t)n); std::memcpy(sw, weights8, 32 * (size_t)n);
+    std::memcpy(sh, host_idx, 4 * (size_t)n);
+    HIPCHK(hipMemcpyAsync(t->tp_static_dev, st.data(), sizeof(float) * 24 * cap, hipMemcpyHostToDevice, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    return SDVGN_OK;
+}
+
+int sdvgn_tracker_trace_points(sdvgn_tracker* t, int n_hosts, const float* KRKi9, const float* Kt3, const float* aff2, float* idepth_min,
+                               float* idepth_max, float* quality, int* status, float* lastTraceUV2, float* lastTracePixelInterval) {
+    if (!t || n_hosts < 1 || n_hosts > kTraceMaxHosts || !KRKi9 || !Kt3 || !aff2) return SDVGN_E_ARG;
+    if (!t->haveNew) return SDVGN_E_STATE;
+    const int n = t->tp_n;
+    if (n == 0) return SDVGN_OK;
+    if (!idepth_min || !idepth_max || !quality || !status || !lastTraceUV2 || !lastTracePixelInterval) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    TraceConst C;
+    C.n = n; C.w = t->w[0]; C.h = t->h[0]; C.dI = t->pyr_dev[0];
+    std::memset(C.KRKi, 0, sizeof(C.KRKi)); std::memset(C.Kt, 0, sizeof(C.Kt)); std::memset(C.aff, 0, sizeof(C.aff));
+    std::memcpy(C.KRKi, KRKi9, sizeof(float) * 9 * n_hosts);
+    std::memcpy(C.Kt, Kt3, sizeof(float) * 3 * n_hosts);
+    std::memcpy(C.aff, aff2, sizeof(float) * 2 * n_hosts);
+    const size_t cap = t->tp_cap;
+    float* hs = (float*)t->tp_state_host;
+    float* hmin = hs, *hmax = hs + cap, *hq = hs + 2 * cap;
+    int* hst = (int*)(hs + 3 * cap);
+    float* huv = hs + 4 * cap, *hiv = hs + 6 * cap;
+    std::memcpy(hmin, idepth_min, 4 * (size_t)n); std::memcpy(hmax, idepth_max, 4 * (size_t)n); std::memcpy(hq, quality, 4 * (size_t)n);
+    std::memcpy(hst, status, 4 * (size_t)n); std::memcpy(huv, lastTraceUV2, 8 * (size_t)n); std::memcpy(hiv, lastTracePixelInterval, 4 * (size_t)n);
+    const float* sd = t->tp_static_dev;
+    // the dynamic state (28 B per point) is read and written in place in pinned host memory by the kernel: no copy engine
+    k_trace_points<<<(n + 63) / 64, 64, 0, t->stream>>>(C, sd, sd + cap, sd + 2 * cap, (const float4*)(sd + 3 * cap), (const float4*)(sd + 7 * cap),
+                                                      (const float4*)(sd + 15 * cap), (const int*)(sd + 23 * cap), hmin, hmax, hq, hst, (float2*)huv, hiv);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(t->stream));
+    std::memcpy(idepth_min, hmin, 4 * (size_t)n); std::memcpy(idepth_max, hmax, 4 * (size_t)n); std::memcpy(quality, hq, 4 * (size_t)n);
+    std::memcpy(status, hst, 4 * (size_t)n); std::memcpy(lastTraceUV2, huv, 8 * (size_t)n); std::memcpy(lastTracePixelInterval, hiv, 4 * (size_t)n);
+    return SDVGN_OK;
+}

@@ -397,3 +397,59 @@ def make_reproject_problem(W, levels=3, seed=0, pose_err=(0.01, 0.001), edgelet_
     P.type = (rng.random(int(sel.sum())) < edgelet_frac).astype(np.int32)      # 0 = CORNER, 1 = EDGELET (HessianBlocks.h:401)
     P.n = int(sel.sum())
     return P
+
+
+# =====================================================================================================
+# ImmaturePoint::traceOn: the window's points re-used as immature points of key-frames
+# 0..nF-2, traced on the last frame.
+# =====================================================================================================
+class TraceProblem:
+    pass
+
+
+IPS_GOOD, IPS_OOB, IPS_OUTLIER, IPS_SKIPPED, IPS_BADCONDITION, IPS_UNINITIALIZED = range(6)   # ImmaturePoint.h:20-30
+
+
+def make_trace_problem(W, target=None, pose_err=(0.0, 0.0), seed=0):
+    """Immature points = the points of key-frames != target, with the fields the ImmaturePoint constructor computes
+    (ImmaturePoint.cpp:8-35): color, weights, gradH, energyTH; initial state idepth_min = 0, idepth_max = NaN, quality = 10000,
+    status UNINITIALIZED.  Per-host KRKi / Kt / aff as FullSystem::traceNewCoarse builds them (FullSystem.cpp:525-538)."""
+    rng = np.random.default_rng(seed + 15000)
+    P = TraceProblem()
+    tgt = W.nF - 1 if target is None else target
+    P.w, P.h, P.target = W.w, W.h, tgt
+    fx, fy, cx, cy = (np.float32(W.calib[k]) for k in ("fx", "fy", "cx", "cy"))
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float32)
+    Ki = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    sel = W.host != tgt
+    P.n = int(sel.sum())
+    P.u, P.v = W.u[sel].copy(), W.v[sel].copy()
+    P.host_idx = W.host[sel].astype(np.int32)
+    P.color, P.weights = W.color[sel].copy(), W.weights[sel].copy()
+    P.true_idepth = W.idepth[sel].copy()
+    gradH = np.zeros((P.n, 4), np.float32)
+    for i in range(P.n):
+        I = W.pyr0[P.host_idx[i]]
+        g = np.zeros((2, 2), np.float32)
+        for dx, dy in PATTERN8:
+            gv = I[int(P.v[i]) + dy, int(P.u[i]) + dx, 1:3]
+            g = (g + np.outer(gv, gv).astype(np.float32)).astype(np.float32)
+        gradH[i] = g.reshape(-1)
+    P.gradH = gradH
+    P.energyTH = np.full(P.n, 8 * 12 * 12, np.float32)       # patternNum * setting_outlierTH * overallEnergyTHWeight^2
+    P.idepth_min = np.zeros(P.n, np.float32)
+    P.idepth_max = np.full(P.n, np.nan, np.float32)
+    P.quality = np.full(P.n, 10000, np.float32)
+    P.status = np.full(P.n, IPS_UNINITIALIZED, np.int32)
+    w2c_t = _se3_mul_np(se3_exp_np(np.concatenate([rng.normal(0, pose_err[0], 3), rng.normal(0, pose_err[1], 3)])), W.gt_worldToCam[tgt])
+    P.KRKi = np.zeros((W.nF, 9), np.float32)
+    P.Kt = np.zeros((W.nF, 3), np.float32)
+    P.aff = np.tile(np.array([1.0, 0.0], np.float32), (W.nF, 1))
+    for hk in range(W.nF):
+        hostToNew = _se3_mul_np(w2c_t, _se3_inv_np(W.gt_worldToCam[hk]))
+        R = quat_to_R(hostToNew[:4]).astype(np.float32)
+        P.KRKi[hk] = ((K @ R).astype(np.float32) @ Ki).astype(np.float32).reshape(-1)
+        P.Kt[hk] = (K @ hostToNew[4:].astype(np.float32)).astype(np.float32)
+    P.image = W.images[tgt]
+    P.dI = W.pyr0[tgt]
+    return P
