@@ -286,6 +286,33 @@ def reproject_extras(W, G, local, want_cpu):
     return out
 
 
+def trace_extras(W, local, want_cpu):
+    """SURVEY 8f-4 at the named shape: the 14 000 points of seven key-frames as immature points, traced on the eighth frame
+    (ImmaturePoint::traceOn for all of them = the loop of FullSystem::traceNewCoarse), first (uninitialised) pass."""
+    from sdv_loam_amd import api, synthetic as syn
+    P = syn.make_trace_problem(W, seed=0)
+    T = api.CoarseTracker(P.w, P.h, 4, max_points=64, device=local)
+    T.makeK(**W.calib)
+    T.set_new_image(P.image, 1.0)
+    T.traceSetPoints(P.u, P.v, P.energyTH, P.gradH, P.color, P.weights, P.host_idx)
+    a = (P.KRKi, P.Kt, P.aff, P.idepth_min, P.idepth_max, P.quality, P.status)
+    for _ in range(3):
+        st = T.tracePoints(*a)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        st = T.tracePoints(*a)
+    ms = 1e3 * (time.perf_counter() - t0) / 20
+    out = dict(points=int(P.n), good=int((st["status"] == 0).sum()), call_ms=ms, points_per_s=P.n / (ms * 1e-3))
+    if want_cpu:
+        from oracle.trace import trace_on
+        t0 = time.perf_counter()
+        trace_on(P, P.dI, P.idepth_min, P.idepth_max, P.quality, P.status)
+        dt = time.perf_counter() - t0
+        out["cpu_ms_1thread"] = 1e3 * dt
+        out["cpu_us_per_point"] = 1e6 * dt / P.n
+    return out
+
+
 def main():
     args = parse()
     if args.pmc_child:
@@ -353,6 +380,7 @@ def main():
         out["tracker"] = tracker_extras(torch, local, args.batch, oracle, not args.no_cpu)
     if rank == 0 and not args.quick:
         out["reprojector"] = reproject_extras(W, G, local, not args.no_cpu)
+        out["trace_points"] = trace_extras(W, local, not args.no_cpu)
     if rank == 0 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_backend(W)
     if rank == 0:

@@ -105,11 +105,24 @@ def reproject_golden():
     np.savez_compressed(os.path.join(HERE, "reproject_small.npz"), **out)
 
 
+def trace_golden():
+    from oracle.trace import trace_on
+    W = syn.make_window(w=200, h=96, nF=3, pts_per_kf=80, seed=13, calib=dict(fx=150., fy=152., cx=99.5, cy=47.5))
+    P = syn.make_trace_problem(W, seed=13, pose_err=(0.01, 0.001))
+    P.aff[:, 0] = np.float32(0.95); P.aff[:, 1] = np.float32(2.0)
+    st = trace_on(P, P.dI, P.idepth_min, P.idepth_max, P.quality, P.status)
+    st2 = trace_on(P, P.dI, st["idepth_min"], st["idepth_max"], st["quality"], st["status"])     # finite-interval branches
+    np.savez_compressed(os.path.join(HERE, "trace_small.npz"), w=P.w, h=P.h, I=P.image, u=P.u, v=P.v, energyTH=P.energyTH, gradH=P.gradH,
+                        color=P.color, weights=P.weights, host_idx=P.host_idx, KRKi=P.KRKi, Kt=P.Kt, aff=P.aff,
+                        **{"s1_" + k: v for k, v in st.items()}, **{"s2_" + k: v for k, v in st2.items()})
+
+
 if __name__ == "__main__":
     tracker_golden()
     backend_golden()
     struct_pose_golden()
     reproject_golden()
+    trace_golden()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

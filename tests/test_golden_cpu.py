@@ -61,3 +61,30 @@ def test_reproject_oracle_matches_golden(orc):
     assert np.array_equal(px0, g["px0"]) and np.array_equal(cell, g["cell"]) and np.array_equal(q, g["quality"])
     ok, pm, lvl = O.find_match(*a, g["ref_idx"], g["type"], px0)
     assert np.array_equal(ok, g["success"]) and np.array_equal(lvl, g["level"]) and np.array_equal(pm[ok], g["px"][g["success"]])
+
+
+def _trace_problem_from_golden():
+    import os
+    from golden_util import HERE
+    from sdv_loam_amd import synthetic as syn
+    g = np.load(os.path.join(HERE, "trace_small.npz"))
+
+    class P:
+        pass
+    for k in ("u", "v", "energyTH", "gradH", "color", "weights", "host_idx", "KRKi", "Kt", "aff"):
+        setattr(P, k, g[k])
+    P.w, P.h, P.image = int(g["w"]), int(g["h"]), g["I"]
+    P.dI = syn.pyramid_numpy(g["I"], 1)[0]
+    n = len(P.u)
+    init = dict(idepth_min=np.zeros(n, np.float32), idepth_max=np.full(n, np.nan, np.float32), quality=np.full(n, 10000, np.float32),
+                status=np.full(n, 5, np.int32))
+    return g, P, init
+
+
+def test_trace_oracle_matches_golden(orc):
+    from oracle.trace import trace_on
+    g, P, init = _trace_problem_from_golden()
+    s1 = trace_on(P, P.dI, init["idepth_min"], init["idepth_max"], init["quality"], init["status"])
+    s2 = trace_on(P, P.dI, s1["idepth_min"], s1["idepth_max"], s1["quality"], s1["status"])
+    for k in s1:
+        assert np.array_equal(s1[k], g["s1_" + k], equal_nan=True) and np.array_equal(s2[k], g["s2_" + k], equal_nan=True), k

@@ -82,3 +82,17 @@ def test_reproject_gpu_matches_golden(sdvgn_lib):
     assert np.array_equal(r["success"][cand], g["success"][cand]) and np.array_equal(r["level"][cand], g["level"][cand])
     good = cand & g["success"]
     assert good.sum() > 20 and np.array_equal(r["px"][good], g["px"][good])
+
+
+def test_trace_gpu_matches_golden(sdvgn_lib):
+    from sdv_loam_amd import api
+    from test_golden_cpu import _trace_problem_from_golden
+    g, P, init = _trace_problem_from_golden()
+    G = api.CoarseTracker(P.w, P.h, 2, max_points=64)
+    G.makeK(150., 152., 99.5, 47.5)
+    G.set_new_image(P.image, 1.0)
+    G.traceSetPoints(P.u, P.v, P.energyTH, P.gradH, P.color, P.weights, P.host_idx)
+    s1 = G.tracePoints(P.KRKi, P.Kt, P.aff, init["idepth_min"], init["idepth_max"], init["quality"], init["status"])
+    s2 = G.tracePoints(P.KRKi, P.Kt, P.aff, s1["idepth_min"], s1["idepth_max"], s1["quality"], s1["status"])
+    for k in s1:
+        assert np.array_equal(s1[k], g["s1_" + k], equal_nan=True) and np.array_equal(s2[k], g["s2_" + k], equal_nan=True), k
