@@ -313,6 +313,33 @@ def trace_extras(W, local, want_cpu):
     return out
 
 
+def immature_extras(W, G, want_cpu):
+    """SURVEY 8f-4: FullSystem::optimizeImmaturePoint for the window's 16 000 points treated as activation candidates (inverse-depth
+    interval +-10-20 % around the truth), one launch on the back-end handle that already holds the frames."""
+    rng = np.random.default_rng(3)
+    lo = rng.uniform(0.02, 0.2, W.nP).astype(np.float32)
+    hi = rng.uniform(0.02, 0.2, W.nP).astype(np.float32)
+    a = (W.host, W.u, W.v, (W.idepth * (1 - lo)).astype(np.float32), (W.idepth * (1 + hi)).astype(np.float32), np.full(W.nP, 8 * 144, np.float32),
+         W.color, W.weights, W.isFromSensor)
+    G.load(W)
+    for _ in range(3):
+        r = G.optimizeImmature(*a)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        r = G.optimizeImmature(*a)
+    ms = 1e3 * (time.perf_counter() - t0) / 20
+    out = dict(points=int(W.nP), activated=int((r[0] == 1).sum()), call_ms=ms, points_per_s=W.nP / (ms * 1e-3))
+    if want_cpu:
+        from oracle.backend import OracleEF
+        O = OracleEF(W.w, W.h).load(W)
+        t0 = time.perf_counter()
+        O.optimizeImmature(*a)
+        dt = time.perf_counter() - t0
+        out["cpu_ms_1thread"] = 1e3 * dt
+        out["cpu_us_per_point"] = 1e6 * dt / W.nP
+    return out
+
+
 def main():
     args = parse()
     if args.pmc_child:
@@ -381,6 +408,7 @@ def main():
     if rank == 0 and not args.quick:
         out["reprojector"] = reproject_extras(W, G, local, not args.no_cpu)
         out["trace_points"] = trace_extras(W, local, not args.no_cpu)
+        out["optimize_immature"] = immature_extras(W, G, not args.no_cpu)
     if rank == 0 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_backend(W)
     if rank == 0:

@@ -269,6 +269,20 @@ int sdvgn_ef_optimize(sdvgn_ef* ef, int mnumOptIts, int flags /* bit0: run exact
 /* state after optimize: CalibHessian::value_scaled, FrameHessian::state (nF x 10), PointHessian::idepth (nP) */
 int sdvgn_ef_get_state(sdvgn_ef* ef, double* value_scaled4, double* state10, float* idepth);
 
+/* FullSystem::optimizeImmaturePoint(ImmaturePoint*, int minObs, ImmaturePointTemporaryResidual*)   FullSystemOptPoint.cpp:18-185,
+ * with ImmaturePoint::linearizeResidual (ImmaturePoint.cpp:410-477), for n immature points in one launch (the loop of
+ * activatePointsMT_Reductor, FullSystem.cpp:555-566).  Uses the window loaded on the handle: calibration, frame images and the
+ * frames' current states (PRE_RTll / PRE_tTll / PRE_aff_mode of FrameFramePrecalc, HessianBlocks.cpp:169-195).
+ * Per point: host index, u, v, idepth_min, idepth_max, energyTH, color[8], weights[8], isFromSensor.  Outputs:
+ *   result[i]   0 = the reference returns 0 (not well constrained, :57-63,:83-90), -1 = it returns (PointHessian*)-1
+ *               (NaN idepth / fewer than minObs inlier residuals / NaN energyTH, :125-143), 1 = activate
+ *   idepth[i]   inverse depth for setIdepth / setIdepthZero (:150-159) when result is 1 (NaN otherwise)
+ *   res_state[i*nF + t]  ResState of the temporary residual towards frame t (0 IN, 1 OOB, 2 OUTLIER; -1 for t == host): the
+ *               caller creates PointFrameResiduals for the IN ones (:163-181). */
+int sdvgn_ef_optimize_immature(sdvgn_ef* e, int n, const int* host, const float* u, const float* v, const float* idepth_min,
+                               const float* idepth_max, const float* energyTH, const float* color8, const float* weights8,
+                               const unsigned char* isFromSensor, int minObs, int* result, float* idepth, int* res_state);
+
 /* parity / read-back hooks */
 int sdvgn_ef_dim(sdvgn_ef* ef);
 int sdvgn_ef_get_system(sdvgn_ef* ef, double* HA, double* bA, double* Hsc, double* bsc, double* HFinal, double* bFinal);

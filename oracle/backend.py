@@ -40,6 +40,7 @@ def _L():
         L.orc_ef_get_points.argtypes = [vp, f32p]
         L.orc_ef_get_frame_steps.argtypes = [vp, f64p, f64p]
         L.orc_ef_get_top_acc.argtypes = [vp, f32p]
+        L.orc_ef_optimize_immature.argtypes = [vp, C.c_int, i32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, u8p, C.c_int, i32p, f32p, i32p]
         L.orc_ef_get_precalc.argtypes = [vp, C.c_int, C.c_int, f32p]
         L.orc_ef_get_adjoints.argtypes = [vp, f64p, f64p]
         L.orc_ef_res_in_A.argtypes = [vp]
@@ -151,6 +152,17 @@ class OracleEF:
         c4 = np.zeros(4)
         self.L.orc_ef_get_frame_steps(self.h_, s, c4)
         return s.reshape(self.nF, 6), c4
+
+    def optimizeImmature(self, host, u, v, idepth_min, idepth_max, energyTH, color, weights, isFromSensor, minObs=1):
+        host = np.ascontiguousarray(host, np.int32)
+        n = len(host)
+        f = lambda a: np.ascontiguousarray(a, np.float32).reshape(-1)   # noqa: E731
+        result = np.zeros(n, np.int32)
+        idepth = np.zeros(n, np.float32)
+        rs = np.zeros((n, self.nF), np.int32)
+        self.L.orc_ef_optimize_immature(self.h_, n, host, f(u), f(v), f(idepth_min), f(idepth_max), f(energyTH), f(color), f(weights),
+                                        np.ascontiguousarray(isFromSensor, np.uint8), minObs, result, idepth, rs.reshape(-1))
+        return result, idepth, rs
 
     def top_acc(self):
         out = np.zeros((self.nF * self.nF, 13, 13), np.float32)

@@ -950,6 +950,111 @@ static int optimize(EF* E, int mnumOptIts, double* trace, int trace_stride, int 
 }  // namespace orcb
 
 using namespace orcb;
+// ---- 8f-4 (part 2): ImmaturePoint::linearizeResidual (ImmaturePoint.cpp:410-477) and FullSystem::optimizeImmaturePoint
+// (FullSystemOptPoint.cpp:18-185).  The tail of optimizeImmaturePoint that allocates the PointHessian / PointFrameResidual objects
+// stays with the caller; this returns what it needs: result code (0 = "return 0" not well-constrained, -1 = the (PointHessian*)-1
+// outlier code, 1 = activate), the optimised inverse depth and the per-target residual states.
+struct ImmRes { int state_state, state_NewState; double state_energy, state_NewEnergy; int target; };
+struct ImmPt { int host; float u, v, idepth_min, idepth_max, energyTH; float color[8], weights[8]; bool isFromSensor; };
+static const float setting_minIdepthH_act = 100;           // settings.cpp:41
+static const int setting_GNItsOnPointActivation = 3;       // settings.cpp:133
+static const float setting_huberTH_imm = 6;                // settings.cpp:101
+
+static double imm_linearize_residual(const EF* E, const ImmPt& pt, float outlierTHSlack, ImmRes* tmp, float& Hdd, float& bd, float idepth) {
+    if (tmp->state_state == 1 /*OOB*/) { tmp->state_NewState = 1; return tmp->state_energy; }
+    const Precalc& pc = E->precalc[(size_t)pt.host * E->nF + tmp->target];
+    float energyLeft = 0;
+    const float* dIl = E->frames[tmp->target].dI.data();
+    const float* R = pc.PRE_RTll;
+    const float* t = pc.PRE_tTll;
+    const float affLL[2] = {pc.PRE_aff_mode[0], pc.PRE_aff_mode[1]};
+    for (int idx = 0; idx < patternNum; idx++) {
+        const int dx = patternP[idx][0], dy = patternP[idx][1];
+        // projectPoint (ResidualProjections.h:32-59)
+        const float KliP[3] = {(pt.u + dx - E->cxl) * E->fxli, (pt.v + dy - E->cyl) * E->fyli, 1};
+        const float ptp[3] = {((R[0] * KliP[0] + R[1] * KliP[1]) + R[2] * KliP[2]) + t[0] * idepth,
+                              ((R[3] * KliP[0] + R[4] * KliP[1]) + R[5] * KliP[2]) + t[1] * idepth,
+                              ((R[6] * KliP[0] + R[7] * KliP[1]) + R[8] * KliP[2]) + t[2] * idepth};
+        const float drescale = 1.0f / ptp[2];
+        bool ok = drescale > 0;
+        float u = 0, v = 0, Ku = 0, Kv = 0;
+        if (ok) {
+            u = ptp[0] * drescale;
+            v = ptp[1] * drescale;
+            Ku = u * E->fxl + E->cxl;
+            Kv = v * E->fyl + E->cyl;
+            ok = Ku > 1.1f && Kv > 1.1f && Ku < E->wM3G && Kv < E->hM3G;
+        }
+        if (!ok) { tmp->state_NewState = 1; return tmp->state_energy; }
+        float hit[3];
+        interp33(dIl, Ku, Kv, E->w, hit);
+        if (!std::isfinite(hit[0])) { tmp->state_NewState = 1; return tmp->state_energy; }
+        const float residual = hit[0] - (affLL[0] * pt.color[idx] + affLL[1]);
+        float hw = fabsf(residual) < setting_huberTH_imm ? 1 : setting_huberTH_imm / fabsf(residual);
+        energyLeft += pt.weights[idx] * pt.weights[idx] * hw * residual * residual * (2 - hw);
+        const float dxInterp = hit[1] * E->fxl, dyInterp = hit[2] * E->fyl;
+        const float d_idepth = (dxInterp * drescale * (t[0] - t[2] * u) + dyInterp * drescale * (t[1] - t[2] * v)) * SCALE_IDEPTH;   // derive_idepth
+        hw *= pt.weights[idx] * pt.weights[idx];
+        Hdd += (hw * d_idepth) * d_idepth;
+        bd += (hw * residual) * d_idepth;
+    }
+    if (energyLeft > pt.energyTH * outlierTHSlack) { energyLeft = pt.energyTH * outlierTHSlack; tmp->state_NewState = 2 /*OUTLIER*/; }
+    else tmp->state_NewState = 0 /*IN*/;
+    tmp->state_NewEnergy = energyLeft;
+    return energyLeft;
+}
+
+static int imm_optimize(const EF* E, const ImmPt& pt, int minObs, ImmRes* res, float* idepth_out) {
+    int nres = 0;
+    for (int f = 0; f < E->nF; ++f)
+        if (f != pt.host) {
+            res[nres].state_NewEnergy = res[nres].state_energy = 0;
+            res[nres].state_NewState = 2;
+            res[nres].state_state = 0;
+            res[nres].target = f;
+            nres++;
+        }
+    float lastEnergy = 0, lastHdd = 0, lastbd = 0;
+    float currentIdepth = (pt.idepth_max + pt.idepth_min) * 0.5f;
+    const float trueDepth = currentIdepth;
+    if (!pt.isFromSensor) {
+        for (int i = 0; i < nres; i++) {
+            lastEnergy += imm_linearize_residual(E, pt, 1000, res + i, lastHdd, lastbd, currentIdepth);
+            res[i].state_state = res[i].state_NewState;
+            res[i].state_energy = res[i].state_NewEnergy;
+        }
+        if (!std::isfinite(lastEnergy) || lastHdd < setting_minIdepthH_act) return 0;
+        float lambda = 0.1f;
+        for (int iteration = 0; iteration < setting_GNItsOnPointActivation; iteration++) {
+            float H = lastHdd;
+            H *= 1 + lambda;
+            const float step = (float)((1.0 / H) * lastbd);
+            const float newIdepth = currentIdepth - step;
+            float newHdd = 0, newbd = 0, newEnergy = 0;
+            for (int i = 0; i < nres; i++) newEnergy += imm_linearize_residual(E, pt, 1, res + i, newHdd, newbd, newIdepth);
+            if (!std::isfinite(lastEnergy) || newHdd < setting_minIdepthH_act) return 0;
+            if (newEnergy < lastEnergy) {
+                currentIdepth = newIdepth;
+                lastHdd = newHdd;
+                lastbd = newbd;
+                lastEnergy = newEnergy;
+                for (int i = 0; i < nres; i++) { res[i].state_state = res[i].state_NewState; res[i].state_energy = res[i].state_NewEnergy; }
+                lambda *= 0.5f;
+            } else {
+                lambda *= 5;
+            }
+            if (fabsf(step) < 0.0001 * currentIdepth) break;
+        }
+    }
+    if (!std::isfinite(currentIdepth)) return -1;
+    int numGoodRes = 0;
+    for (int i = 0; i < nres; i++) if (res[i].state_state == 0) numGoodRes++;
+    if (numGoodRes < minObs) return -1;
+    if (!std::isfinite(pt.energyTH)) return -1;            // `new PointHessian(point)` copies energyTH (:139-140)
+    *idepth_out = pt.isFromSensor ? trueDepth : currentIdepth;
+    return 1;
+}
+
 extern "C" {
 
 void* orc_ef_create(int w, int h) {
@@ -1136,5 +1241,26 @@ void orc_ef_get_state(void* e, double* value_scaled4, double* state10, float* id
     for (int i = 0; i < 4; ++i) value_scaled4[i] = E->value_scaled[i];
     for (int h = 0; h < E->nF; ++h) for (int i = 0; i < 10; ++i) state10[10 * h + i] = E->frames[h].state[i];
     for (size_t i = 0; i < E->points.size(); ++i) idepth[i] = E->points[i].idepth;
+}
+
+// optimizeImmaturePoint for n points against the frames / precalc currently set on the handle (orc_ef_set_precalc first).
+// res_state[n][nF]: state_state of the residual towards frame t (-1 for t == host); result[n]: 0 / -1 / 1; idepth[n] valid if 1.
+void orc_ef_optimize_immature(void* e, int n, const int* host, const float* u, const float* v, const float* idepth_min, const float* idepth_max,
+                              const float* energyTH, const float* color8, const float* weights8, const uint8_t* isFromSensor, int minObs,
+                              int* result, float* idepth, int* res_state) {
+    const EF* E = (const EF*)e;
+    std::vector<ImmRes> res(E->nF);
+    for (int i = 0; i < n; ++i) {
+        ImmPt pt;
+        pt.host = host[i]; pt.u = u[i]; pt.v = v[i]; pt.idepth_min = idepth_min[i]; pt.idepth_max = idepth_max[i]; pt.energyTH = energyTH[i];
+        for (int k = 0; k < 8; ++k) { pt.color[k] = color8[8 * i + k]; pt.weights[k] = weights8[8 * i + k]; }
+        pt.isFromSensor = isFromSensor[i] != 0;
+        float id = NAN;
+        result[i] = imm_optimize(E, pt, minObs, res.data(), &id);
+        idepth[i] = id;
+        for (int t = 0; t < E->nF; ++t) res_state[(size_t)i * E->nF + t] = -1;
+        int k = 0;
+        for (int t = 0; t < E->nF; ++t) if (t != pt.host) res_state[(size_t)i * E->nF + t] = res[k++].state_state;
+    }
 }
 }

@@ -34,6 +34,7 @@ PROTOTYPES = [
     ("sdvgn_ef_get_residual_state", C.c_int, [vp, vp, vp, vp, vp, vp]),
     ("sdvgn_ef_get_points", C.c_int, [vp, f32p]),
     ("sdvgn_ef_get_top_acc", C.c_int, [vp, f64p, vp]),
+    ("sdvgn_ef_optimize_immature", C.c_int, [vp, C.c_int, i32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, u8p, C.c_int, i32p, f32p, i32p]),
     ("sdvgn_ef_accumulators_dev", C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int)]),
     ("sdvgn_ef_accumulate", C.c_int, [vp]),
     ("sdvgn_ef_finish_solve", C.c_int, [vp, C.c_int, C.c_double, vp]),
@@ -176,6 +177,18 @@ class EnergyFunctional:
         out = np.zeros((self.nP, 9), np.float32)
         self._check(self.L.sdvgn_ef_get_points(self.h_, out.reshape(-1)))
         return out
+
+    def optimizeImmature(self, host, u, v, idepth_min, idepth_max, energyTH, color, weights, isFromSensor, minObs=1):
+        """FullSystem::optimizeImmaturePoint for n points (FullSystemOptPoint.cpp:18-185): (result, idepth, res_state[n][nF])."""
+        host = np.ascontiguousarray(host, np.int32)
+        n = len(host)
+        f = lambda a: np.ascontiguousarray(a, np.float32).reshape(-1)   # noqa: E731
+        result = np.zeros(n, np.int32)
+        idepth = np.zeros(n, np.float32)
+        rs = np.zeros((n, self.nF), np.int32)
+        self._check(self.L.sdvgn_ef_optimize_immature(self.h_, n, host, f(u), f(v), f(idepth_min), f(idepth_max), f(energyTH), f(color), f(weights),
+                                                      np.ascontiguousarray(isFromSensor, np.uint8), minObs, result, idepth, rs.reshape(-1)))
+        return result, idepth, rs
 
     def top_acc(self):
         out = np.zeros((self.nF * self.nF, 11, 11))

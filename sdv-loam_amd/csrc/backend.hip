@@ -98,6 +98,10 @@ struct sdvgn_ef {
     double* energy_partial = nullptr;
     float *top_partial = nullptr, *sc_partial = nullptr;
     int* nres_partial = nullptr;
+    ImmPrecalc* imm_pc_dev = nullptr;       // optimizeImmaturePoint: PRE_RTll / PRE_tTll / PRE_aff_mode per (host,target)
+    ImmPrecalc* imm_pc_host = nullptr;      // pinned
+    void* imm_stage = nullptr;              // pinned candidate / result staging, grown on demand
+    size_t imm_stage_bytes = 0;
     unsigned short* sc_off_dev = nullptr;   // packed upper-triangle index (53x53) -> offset inside the 10 SC tiles
     double* acc_dev = nullptr;    // packed: top [nF*nF][256] | sc [nF][2560] | resInA
     double* acc_host = nullptr;   // pinned; the reduce kernels write it DIRECTLY (zero-copy) when no all-reduce is installed
@@ -582,6 +586,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->sc_partial, (size_t)SDVGN_MAX_FRAMES * kMaxChunks * kScP);
     bad |= dev_alloc(&e->nres_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks);
     bad |= dev_alloc(&e->sc_off_dev, (size_t)kScE);
+    bad |= dev_alloc(&e->imm_pc_dev, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES);
     const size_t accmax = (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kTopE + (size_t)SDVGN_MAX_FRAMES * kScE + 1;
     bad |= dev_alloc(&e->acc_dev, accmax);
     bad |= dev_alloc(&e->xc_dev, 4) | dev_alloc(&e->xAd_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6);
@@ -590,6 +595,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     HIPCHK(hipHostMalloc(&e->precalc_host, 2 * sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
     HIPCHK(hipHostMalloc(&e->acc_host, sizeof(double) * accmax));
     HIPCHK(hipHostMalloc(&e->stats_host, sizeof(double) * 4));
+    HIPCHK(hipHostMalloc((void**)&e->imm_pc_host, sizeof(ImmPrecalc) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
     HIPCHK(hipHostMalloc(&e->x_host, 2 * sizeof(float) * (4 + SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6)));
     HIPCHK(hipEventCreateWithFlags(&e->ev_top, hipEventDisableTiming));
     {   // packed upper triangle of the live 53x53 SC Gram -> offset inside its ten 16x16 tiles (k_ef_sc_gram's layout)
@@ -622,11 +628,13 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->rstate, e->rstate_new, e->rmatcher, e->renergy, e->renergy_new, e->renergy_wo, e->rres_toZero, e->J, e->JpJd, e->pHddA,
                     e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->images, e->img_stage,
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
-                    e->xc_dev, e->xAd_dev, e->stats_dev, e->stats_partial, e->sc_off_dev};
+                    e->xc_dev, e->xAd_dev, e->stats_dev, e->stats_partial, e->sc_off_dev, e->imm_pc_dev};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->precalc_host) hipHostFree(e->precalc_host);
     if (e->acc_host) hipHostFree(e->acc_host);
     if (e->stats_host) hipHostFree(e->stats_host);
+    if (e->imm_pc_host) hipHostFree(e->imm_pc_host);
+    if (e->imm_stage) hipHostFree(e->imm_stage);
     if (e->x_host) hipHostFree(e->x_host);
     if (e->ev_top) hipEventDestroy(e->ev_top);
     if (e->own_stream) hipStreamDestroy(e->stream);
@@ -1257,6 +1265,63 @@ int sdvgn_ef_get_points(sdvgn_ef* e, float* out9) {
         for (int k = 0; k < 4; ++k) o[2 + k] = c[(size_t)k * nP + i];
         o[6] = d[i]; o[7] = f[i]; o[8] = g[i];
     }
+    return SDVGN_OK;
+}
+
+// FullSystem::optimizeImmaturePoint (FullSystemOptPoint.cpp:18-185) for n immature points against the window currently loaded
+// (frames, images, calibration and frame states as set by set_frames / set_frame_states).
+int sdvgn_ef_optimize_immature(sdvgn_ef* e, int n, const int* host, const float* u, const float* v, const float* idepth_min,
+                               const float* idepth_max, const float* energyTH, const float* color8, const float* weights8,
+                               const unsigned char* isFromSensor, int minObs, int* result, float* idepth, int* res_state) {
+    if (!e || e->host_only || e->nF < 2 || n < 0) return e && !e->host_only && n >= 0 ? SDVGN_E_STATE : SDVGN_E_ARG;
+    if (n == 0) return SDVGN_OK;
+    if (!host || !u || !v || !idepth_min || !idepth_max || !energyTH || !color8 || !weights8 || !isFromSensor || !result || !idepth || !res_state)
+        return SDVGN_E_ARG;
+    const int nF = e->nF;
+    for (int i = 0; i < n; ++i) if (host[i] < 0 || host[i] >= nF) return SDVGN_E_ARG;
+    EF_DEVICE(e);
+    // FrameFramePrecalc::set (HessianBlocks.cpp:169-195), the three fields linearizeResidual reads
+    for (int h = 0; h < nF; ++h)
+        for (int t = 0; t < nF; ++t) {
+            ImmPrecalc& P = e->imm_pc_host[h * nF + t];
+            const FrameH& hf = e->frames[h];
+            const FrameH& tf = e->frames[t];
+            const gn::Pose l = gn::compose(tf.PRE_worldToCam, hf.PRE_camToWorld);
+            double R[9];
+            gn::rotation_matrix(l.q, R);
+            for (int k = 0; k < 9; ++k) P.R[k] = (float)R[k];
+            for (int k = 0; k < 3; ++k) P.t[k] = (float)l.t[k];
+            double ab[2];
+            gn::aff_from_to(hf.ab_exposure, tf.ab_exposure, hf.state_scaled[6], hf.state_scaled[7], tf.state_scaled[6], tf.state_scaled[7], ab);
+            P.aff[0] = (float)ab[0]; P.aff[1] = (float)ab[1];
+        }
+    HIPCHK(hipMemcpyAsync(e->imm_pc_dev, e->imm_pc_host, sizeof(ImmPrecalc) * nF * nF, hipMemcpyHostToDevice, e->stream));
+    // candidates in / results out through pinned memory the kernel accesses directly
+    const size_t np = ((size_t)n + 63) & ~(size_t)63;
+    const size_t bytes = np * (4 * 6 + 32 + 32 + 4 + 4 + 4 + 4 * (size_t)nF);
+    if (bytes > e->imm_stage_bytes) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->imm_stage) hipHostFree(e->imm_stage);
+        e->imm_stage = nullptr; e->imm_stage_bytes = 0;
+        HIPCHK(hipHostMalloc(&e->imm_stage, bytes * 2));
+        e->imm_stage_bytes = bytes * 2;
+    }
+    float* base = (float*)e->imm_stage;
+    int* s_host = (int*)base;
+    float* s_u = base + np, *s_v = base + 2 * np, *s_min = base + 3 * np, *s_max = base + 4 * np, *s_eth = base + 5 * np;
+    float* s_col = base + 6 * np, *s_wts = base + 14 * np;
+    int* s_res = (int*)(base + 22 * np);
+    float* s_id = base + 23 * np;
+    int* s_rs = (int*)(base + 24 * np);
+    unsigned char* s_sens = (unsigned char*)(base + 24 * np + (size_t)nF * np);
+    std::memcpy(s_host, host, 4 * (size_t)n); std::memcpy(s_u, u, 4 * (size_t)n); std::memcpy(s_v, v, 4 * (size_t)n);
+    std::memcpy(s_min, idepth_min, 4 * (size_t)n); std::memcpy(s_max, idepth_max, 4 * (size_t)n); std::memcpy(s_eth, energyTH, 4 * (size_t)n);
+    std::memcpy(s_col, color8, 32 * (size_t)n); std::memcpy(s_wts, weights8, 32 * (size_t)n); std::memcpy(s_sens, isFromSensor, (size_t)n);
+    k_ef_optimize_immature<<<(n + 63) / 64, 64, 0, e->stream>>>(e->C, e->images, e->imm_pc_dev, n, minObs, s_host, s_u, s_v, s_min, s_max, s_eth,
+                                                              (const float4*)s_col, (const float4*)s_wts, s_sens, s_res, s_id, s_rs);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    std::memcpy(result, s_res, 4 * (size_t)n); std::memcpy(idepth, s_id, 4 * (size_t)n); std::memcpy(res_state, s_rs, 4 * (size_t)n * nF);
     return SDVGN_OK;
 }
 

@@ -320,6 +320,157 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, con
     if (threadIdx.x == 0) energy_partial[(size_t)pair * gridDim.x + chunk] = s_e[0] + s_e[1];
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// SURVEY 8f-4 (part 2): FullSystem::optimizeImmaturePoint (FullSystemOptPoint.cpp:18-185) with
+// ImmaturePoint::linearizeResidual (ImmaturePoint.cpp:410-477), one lane = one immature point.  The lane runs the reference's
+// loops in the reference's order (float accumulation of Hdd / bd across residuals and pattern pixels, including the partial
+// contributions an out-of-bounds pattern pixel leaves behind), so result codes, inverse depths and residual states are
+// bit-identical to the CPU restatement.  Per (pass, target) the 8 pattern projections are computed first and their 96 taps
+// loaded as one batch.
+// ------------------------------------------------------------------------------------------------------------
+struct ImmPrecalc {   // FrameFramePrecalc fields linearizeResidual reads: PRE_RTll, PRE_tTll, PRE_aff_mode, per (host,target)
+    float R[9], t[3], aff[2], pad[2];
+};
+
+struct ImmLaneRes { int state_state, state_NewState; double state_energy, state_NewEnergy; };
+
+__device__ __forceinline__ double imm_linearize_residual(const EFConst& C, const float* __restrict__ img, const ImmPrecalc& pc, float pu, float pv,
+                                                         const float* col, const float* wts, float energyTH, float outlierTHSlack, ImmLaneRes& tmp,
+                                                         float& Hdd, float& bd, float idepth) {
+    if (tmp.state_state == RS_OOB) { tmp.state_NewState = RS_OOB; return tmp.state_energy; }
+    const int pat[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};
+    float us[8], vs[8], dres[8], fx8[8], fy8[8], tp[8][12];
+    bool ok[8];
+    const float* bp8[8];
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) {   // projectPoint (ResidualProjections.h:32-59)
+        const float k0 = (pu + pat[idx][0] - C.cxl) * C.fxli, k1 = (pv + pat[idx][1] - C.cyl) * C.fyli;
+        const float p0 = ((pc.R[0] * k0 + pc.R[1] * k1) + pc.R[2] * 1.0f) + pc.t[0] * idepth;
+        const float p1 = ((pc.R[3] * k0 + pc.R[4] * k1) + pc.R[5] * 1.0f) + pc.t[1] * idepth;
+        const float p2 = ((pc.R[6] * k0 + pc.R[7] * k1) + pc.R[8] * 1.0f) + pc.t[2] * idepth;
+        const float drescale = 1.0f / p2;
+        dres[idx] = drescale;
+        bool good = drescale > 0;
+        const float u = p0 * drescale, v = p1 * drescale;
+        const float Ku = u * C.fxl + C.cxl, Kv = v * C.fyl + C.cyl;
+        good = good && (Ku > 1.1f && Kv > 1.1f && Ku < C.wM3G && Kv < C.hM3G);
+        us[idx] = u; vs[idx] = v; ok[idx] = good;
+        const float x = good ? Ku : 2.0f, y = good ? Kv : 2.0f;
+        const int ix = (int)x, iy = (int)y;
+        fx8[idx] = x - ix; fy8[idx] = y - iy;
+        bp8[idx] = img + 3 * (ix + iy * C.w);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) {
+        const float* bq = bp8[idx] + 3 * C.w;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { tp[idx][k] = bp8[idx][k]; tp[idx][6 + k] = bq[k]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float energyLeft = 0;
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) {
+        if (!ok[idx]) { tmp.state_NewState = RS_OOB; return tmp.state_energy; }
+        const float dx = fx8[idx], dy = fy8[idx], dxdy = dx * dy;
+        const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+        const float* q = tp[idx];
+        const float h0 = ((w11 * q[9] + w01 * q[6]) + w10 * q[3]) + w00 * q[0];
+        const float h1 = ((w11 * q[10] + w01 * q[7]) + w10 * q[4]) + w00 * q[1];
+        const float h2 = ((w11 * q[11] + w01 * q[8]) + w10 * q[5]) + w00 * q[2];
+        if (!isfinite(h0)) { tmp.state_NewState = RS_OOB; return tmp.state_energy; }
+        const float residual = h0 - (pc.aff[0] * col[idx] + pc.aff[1]);
+        float hw = fabsf(residual) < C.huberTH ? 1.0f : C.huberTH / fabsf(residual);
+        energyLeft += wts[idx] * wts[idx] * hw * residual * residual * (2 - hw);
+        const float dxInterp = h1 * C.fxl, dyInterp = h2 * C.fyl;
+        const float d_idepth = (dxInterp * dres[idx] * (pc.t[0] - pc.t[2] * us[idx]) + dyInterp * dres[idx] * (pc.t[1] - pc.t[2] * vs[idx])) * SDVGN_SCALE_IDEPTH;
+        hw *= wts[idx] * wts[idx];
+        Hdd += (hw * d_idepth) * d_idepth;
+        bd += (hw * residual) * d_idepth;
+    }
+    if (energyLeft > energyTH * outlierTHSlack) { energyLeft = energyTH * outlierTHSlack; tmp.state_NewState = RS_OUTLIER; }
+    else tmp.state_NewState = RS_IN;
+    tmp.state_NewEnergy = energyLeft;
+    return energyLeft;
+}
+
+__global__ void __launch_bounds__(64) k_ef_optimize_immature(EFConst C, const float* __restrict__ images, const ImmPrecalc* __restrict__ precalc, int n,
+                                                             int minObs, const int* __restrict__ host, const float* __restrict__ u, const float* __restrict__ v,
+                                                             const float* __restrict__ idepth_min, const float* __restrict__ idepth_max,
+                                                             const float* __restrict__ energyTH, const float4* __restrict__ color,
+                                                             const float4* __restrict__ weights, const unsigned char* __restrict__ isFromSensor,
+                                                             int* __restrict__ result, float* __restrict__ idepth_out, int* __restrict__ res_state) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const int nF = C.nF, hst = host[i];
+    const float pu = u[i], pv = v[i], eTH = energyTH[i];
+    const float4 c0 = color[2 * i], c1 = color[2 * i + 1], w0 = weights[2 * i], w1 = weights[2 * i + 1];
+    const float col[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float wts[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    const bool fromSensor = isFromSensor[i] != 0;
+    const size_t imgStride = (size_t)C.w * C.h * 3;
+    ImmLaneRes res[kMaxFrames];
+#pragma unroll
+    for (int t = 0; t < kMaxFrames; ++t) { res[t].state_NewEnergy = res[t].state_energy = 0; res[t].state_NewState = RS_OUTLIER; res[t].state_state = RS_IN; }
+    float lastEnergy = 0, lastHdd = 0, lastbd = 0;
+    float currentIdepth = (idepth_max[i] + idepth_min[i]) * 0.5f;
+    const float trueDepth = currentIdepth;
+    int code = 1;
+    if (!fromSensor) {
+#pragma unroll
+        for (int t = 0; t < kMaxFrames; ++t) {
+            if (t < nF && t != hst) {
+                lastEnergy = (float)((double)lastEnergy + imm_linearize_residual(C, images + t * imgStride, precalc[hst * nF + t], pu, pv, col, wts, eTH, 1000.f,
+                                                                                 res[t], lastHdd, lastbd, currentIdepth));
+                res[t].state_state = res[t].state_NewState;
+                res[t].state_energy = res[t].state_NewEnergy;
+            }
+        }
+        if (!isfinite(lastEnergy) || lastHdd < 100.f) code = 0;       // setting_minIdepthH_act (settings.cpp:41)
+        float lambda = 0.1f;
+        for (int iteration = 0; code == 1 && iteration < 3; iteration++) {   // setting_GNItsOnPointActivation (settings.cpp:133)
+            float H = lastHdd;
+            H *= 1 + lambda;
+            const float step = (float)((1.0 / (double)H) * (double)lastbd);
+            const float newIdepth = currentIdepth - step;
+            float newHdd = 0, newbd = 0, newEnergy = 0;
+#pragma unroll
+            for (int t = 0; t < kMaxFrames; ++t)
+                if (t < nF && t != hst)
+                    newEnergy = (float)((double)newEnergy + imm_linearize_residual(C, images + t * imgStride, precalc[hst * nF + t], pu, pv, col, wts, eTH, 1.f,
+                                                                                   res[t], newHdd, newbd, newIdepth));
+            if (!isfinite(lastEnergy) || newHdd < 100.f) { code = 0; break; }
+            if (newEnergy < lastEnergy) {
+                currentIdepth = newIdepth;
+                lastHdd = newHdd;
+                lastbd = newbd;
+                lastEnergy = newEnergy;
+#pragma unroll
+                for (int t = 0; t < kMaxFrames; ++t) { res[t].state_state = res[t].state_NewState; res[t].state_energy = res[t].state_NewEnergy; }
+                lambda *= 0.5f;
+            } else {
+                lambda *= 5;
+            }
+            if ((double)fabsf(step) < 0.0001 * (double)currentIdepth) break;
+        }
+    }
+    if (code == 1) {
+        if (!isfinite(currentIdepth)) code = -1;
+        else {
+            int numGoodRes = 0;
+#pragma unroll
+            for (int t = 0; t < kMaxFrames; ++t) if (t < nF && t != hst && res[t].state_state == RS_IN) numGoodRes++;
+            if (numGoodRes < minObs) code = -1;
+            else if (!isfinite(eTH)) code = -1;
+        }
+    }
+    result[i] = code;
+    idepth_out[i] = code == 1 ? (fromSensor ? trueDepth : currentIdepth) : NAN;
+#pragma unroll
+    for (int t = 0; t < kMaxFrames; ++t)
+        if (t < nF) res_state[(size_t)i * nF + t] = (t == hst) ? -1 : res[t].state_state;
+}
+
 // applyRes(true): one thread per slot
 __global__ void __launch_bounds__(256) k_ef_apply(int nF, int nP, EFArrays A, const PrecalcDev* __restrict__ precalc,
                                                   const int* __restrict__ phost) {

@@ -1,0 +1,75 @@
+"""GPU parity of sdvgn_ef_optimize_immature (FullSystem::optimizeImmaturePoint + ImmaturePoint::linearizeResidual)
+against the CPU oracle, through the C ABI: result codes, inverse depths and residual states bit-identical."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CAL = dict(fx=250., fy=252., cx=159.5, cy=99.5)
+
+
+def _pair(seed, **kw):
+    from oracle.backend import OracleEF
+    from sdv_loam_amd import backend_api, synthetic as syn
+    W = syn.make_window(w=320, h=200, nF=4, pts_per_kf=250, seed=seed, calib=CAL, **kw)
+    return W, backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W), OracleEF(W.w, W.h).load(W)
+
+
+def _args(W, seed, rel=0.2):
+    rng = np.random.default_rng(seed)
+    lo = rng.uniform(0.1 * rel, rel, W.nP).astype(np.float32)
+    hi = rng.uniform(0.1 * rel, rel, W.nP).astype(np.float32)
+    imin, imax = (W.idepth * (1 - lo)).astype(np.float32), (W.idepth * (1 + hi)).astype(np.float32)
+    eth = np.full(W.nP, 8 * 144, np.float32)
+    return imin, imax, eth
+
+
+def _same(a, b):
+    assert np.array_equal(a[0], b[0])
+    assert np.array_equal(a[1], b[1], equal_nan=True)
+    assert np.array_equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("seed,rel", [(2, 0.2), (3, 0.05), (4, 0.6)])
+def test_immature_parity(orc, seed, rel):
+    W, G, O = _pair(seed)
+    imin, imax, eth = _args(W, seed, rel)
+    a = (W.host, W.u, W.v, imin, imax, eth, W.color, W.weights, W.isFromSensor)
+    rg, ro = G.optimizeImmature(*a), O.optimizeImmature(*a)
+    _same(rg, ro)
+    assert (ro[0] == 1).sum() > 0.3 * W.nP
+
+
+def test_immature_parity_branches(orc):
+    W, G, O = _pair(5)
+    imin, imax, eth = _args(W, 5)
+    wts = W.weights.copy()
+    wts[:40] = 0                                       # Hdd = 0 -> return 0
+    eth[40:80] = np.nan                                # NaN threshold -> -1 at the PointHessian check
+    imin[80:160] *= 3; imax[80:160] *= 3               # wrong depth: OUTLIER / OOB residuals
+    u = W.u.copy()
+    u[160:200] = 3.0                                   # pattern pixel projects out of the image -> OOB with partial Hdd / bd sums
+    sensor = W.isFromSensor.copy()
+    sensor[200:260] = 1
+    for minObs in (1, 2, W.nF - 1, W.nF):
+        a = (W.host, u, W.v, imin, imax, eth, W.color, wts, sensor, minObs)
+        rg, ro = G.optimizeImmature(*a), O.optimizeImmature(*a)
+        _same(rg, ro)
+    assert set(np.unique(ro[0])) <= {-1, 0} and (ro[0] == -1).sum() > 0   # minObs = nF can never be met
+    a = (W.host, u, W.v, imin, imax, eth, W.color, wts, sensor, 1)
+    ro = O.optimizeImmature(*a)
+    assert set(np.unique(ro[0])) == {-1, 0, 1} and set(np.unique(ro[2])) >= {-1, 0, 1}
+
+
+def test_immature_follows_frame_state_updates(orc):
+    """After an optimize() the frames' states changed: the precalc the kernel uses must be the current one."""
+    W, G, O = _pair(6)
+    G.optimize(3)
+    O.optimize(3)
+    imin, imax, eth = _args(W, 6)
+    a = (W.host, W.u, W.v, imin, imax, eth, W.color, W.weights, W.isFromSensor)
+    _same(G.optimizeImmature(*a), O.optimizeImmature(*a))
+    with pytest.raises(RuntimeError):
+        bad = W.host.copy()
+        bad[0] = 9
+        G.optimizeImmature(bad, *a[1:])
