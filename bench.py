@@ -375,6 +375,18 @@ def main():
     dt = max_over_ranks(time.perf_counter() - t0, world)
     value = (world if scaling == "weak" else 1) * K / dt
 
+    # ---- the same K loop bodies with the reference's literal re-linearisation after every rejected step (A/B; results identical) ----
+    value_relin = None
+    if world == 1 and hasattr(runner, "load"):
+        runner.load(W)
+        runner.optimize(Wm, want_trace=False, fixed_its=True, relinearize_on_reject=True)
+        runner.load(W)
+        barrier_sync(world)
+        t1 = time.perf_counter()
+        runner.optimize(K, want_trace=False, fixed_its=True, relinearize_on_reject=True)
+        barrier_sync(world)
+        value_relin = K / (time.perf_counter() - t1)
+
     # ---- dominant kernel: k_ef_linearize, HIP events on the library's stream -----------------------------------
     for _ in range(5):
         G.linearizeAll(want_energy=False)
@@ -397,6 +409,7 @@ def main():
                    "parallelism": parallelism},
         "roofline": roof,
         "kernel_ms": {"linearizeAll": ms_lin, "accumulate(point+top+sc+reduce)": ms_acc},
+        "value_with_literal_relinearize_on_reject": value_relin,
     }
     if rank == 0 and world == 1 and not args.quick:
         traffic, how = measure_traffic()

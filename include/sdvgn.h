@@ -264,7 +264,9 @@ int sdvgn_ef_set_frame_states(sdvgn_ef* ef, const double* state10);
  * reject (loadSateBackup, re-linearise, lambda*100), break on a tiny step.  One loop body = one "Gauss-Newton
  * iteration" of BASELINE.json's metric.  trace rows: {iteration, lambda, accepted, E, E_L, E_M, canbreak, x[4+6nF]}.
  * Returns the number of iterations run (>= 0) or an error (< 0). */
-int sdvgn_ef_optimize(sdvgn_ef* ef, int mnumOptIts, int flags /* bit0: run exactly mnumOptIts bodies (bench) */,
+int sdvgn_ef_optimize(sdvgn_ef* ef, int mnumOptIts, int flags /* bit0: run exactly mnumOptIts bodies (bench); bit1: re-linearise after a
+                      rejected step literally like FullSystemOptimize.cpp:446-449 instead of switching back to the kept state_New* set
+                      (same results, bit for bit -- tests/test_backend_gpu.py) */,
                       double* trace, int trace_stride, int trace_cap);
 /* state after optimize: CalibHessian::value_scaled, FrameHessian::state (nF x 10), PointHessian::idepth (nP) */
 int sdvgn_ef_get_state(sdvgn_ef* ef, double* value_scaled4, double* state10, float* idepth);

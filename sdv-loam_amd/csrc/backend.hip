@@ -86,6 +86,11 @@ struct sdvgn_ef {
     uint8_t* psensor = nullptr;
     uint8_t* rflags = nullptr;
     int8_t *rstate = nullptr, *rstate_new = nullptr;
+    // second set of the three state_New* planes: the optimize loop linearises a trial step into the other set and swaps on accept,
+    // so that a rejected step needs no re-linearisation (the reference's is a bit-exact recomputation of what the set still holds)
+    int8_t* rstate_new2 = nullptr;
+    float *renergy_new2 = nullptr, *renergy_wo2 = nullptr;
+    int new_cur = 0;   // which set holds the current state_New* values
     float2* rmatcher = nullptr;
     float *renergy = nullptr, *renergy_new = nullptr, *renergy_wo = nullptr, *rres_toZero = nullptr, *J = nullptr, *JpJd = nullptr;
     float *pHddA = nullptr, *pbdA = nullptr, *pHcdA = nullptr, *pHddL = nullptr, *pbdL = nullptr, *pHcdL = nullptr, *pHdi = nullptr,
@@ -153,12 +158,22 @@ static void m3f_mul(const float* A, const float* B, float* C) {
         for (int j = 0; j < 3; ++j) C[i * 3 + j] = (A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j]) + A[i * 3 + 2] * B[6 + j];
 }
 
+// point the kernels' state_New* planes at set `write` (0/1) and the read-only "previous state_NewEnergy" at set `prev`
+static void ef_select_new_set(sdvgn_ef* e, int write, int prev) {
+    EFArrays& A = e->A;
+    A.rstate_new = write ? e->rstate_new2 : e->rstate_new;
+    A.renergy_new = write ? e->renergy_new2 : e->renergy_new;
+    A.renergy_wo = write ? e->renergy_wo2 : e->renergy_wo;
+    A.renergy_new_prev = prev ? e->renergy_new2 : e->renergy_new;
+}
+
 static void ef_fill_arrays(sdvgn_ef* e) {
     EFArrays& A = e->A;
     A.pu = e->pu; A.pv = e->pv; A.pidz = e->pidz; A.pid = e->pid; A.pcolor = e->pcolor; A.pweights = e->pweights;
     A.ppriorF = e->ppriorF; A.pdeltaF = e->pdeltaF; A.psensor = e->psensor;
     A.rflags = e->rflags; A.rstate = e->rstate; A.rstate_new = e->rstate_new; A.rmatcher = e->rmatcher;
     A.renergy = e->renergy; A.renergy_new = e->renergy_new; A.renergy_wo = e->renergy_wo; A.rres_toZero = e->rres_toZero;
+    A.renergy_new_prev = e->renergy_new; e->new_cur = 0;
     A.J = e->J; A.JpJd = e->JpJd;
     A.pHddA = e->pHddA; A.pbdA = e->pbdA; A.pHcdA = e->pHcdA; A.pHddL = e->pHddL; A.pbdL = e->pbdL; A.pHcdL = e->pHcdL;
     A.pHdi = e->pHdi; A.pbdSum = e->pbdSum; A.pHcd = e->pHcd; A.pstep = e->pstep;
@@ -575,6 +590,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->ppriorF, mp) | dev_alloc(&e->pdeltaF, mp) | dev_alloc(&e->pcolor, 2 * mp) | dev_alloc(&e->pweights, 2 * mp) | dev_alloc(&e->psensor, mp);
     bad |= dev_alloc(&e->rflags, slots) | dev_alloc(&e->rstate, slots) | dev_alloc(&e->rstate_new, slots) | dev_alloc(&e->rmatcher, slots);
     bad |= dev_alloc(&e->renergy, slots) | dev_alloc(&e->renergy_new, slots) | dev_alloc(&e->renergy_wo, slots) | dev_alloc(&e->rres_toZero, 2 * slots);
+    bad |= dev_alloc(&e->rstate_new2, slots) | dev_alloc(&e->renergy_new2, slots) | dev_alloc(&e->renergy_wo2, slots);
     bad |= dev_alloc(&e->J, 2 * (size_t)kJPlanes * slots) | dev_alloc(&e->JpJd, 6 * slots);
     bad |= dev_alloc(&e->pHddA, mp) | dev_alloc(&e->pbdA, mp) | dev_alloc(&e->pHcdA, 4 * mp) | dev_alloc(&e->pHddL, mp) | dev_alloc(&e->pbdL, mp) | dev_alloc(&e->pHcdL, 4 * mp);
     bad |= dev_alloc(&e->pHdi, mp) | dev_alloc(&e->pbdSum, mp) | dev_alloc(&e->pHcd, 4 * mp) | dev_alloc(&e->pstep, mp);
@@ -628,7 +644,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->rstate, e->rstate_new, e->rmatcher, e->renergy, e->renergy_new, e->renergy_wo, e->rres_toZero, e->J, e->JpJd, e->pHddA,
                     e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->images, e->img_stage,
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
-                    e->xc_dev, e->xAd_dev, e->stats_dev, e->stats_partial, e->sc_off_dev, e->imm_pc_dev};
+                    e->xc_dev, e->xAd_dev, e->stats_dev, e->stats_partial, e->sc_off_dev, e->imm_pc_dev, e->rstate_new2, e->renergy_new2, e->renergy_wo2};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->precalc_host) hipHostFree(e->precalc_host);
     if (e->acc_host) hipHostFree(e->acc_host);
@@ -786,6 +802,11 @@ int sdvgn_ef_set_residuals(sdvgn_ef* e, int nR, const int* point, const int* tar
     HIPCHK(hipMemsetAsync(e->renergy, 0, 4 * slots, s));
     HIPCHK(hipMemsetAsync(e->renergy_new, 0, 4 * slots, s));
     HIPCHK(hipMemsetAsync(e->renergy_wo, 0, 4 * slots, s));
+    HIPCHK(hipMemsetAsync(e->rstate_new2, RS_OUTLIER, slots, s));
+    HIPCHK(hipMemsetAsync(e->renergy_new2, 0, 4 * slots, s));
+    HIPCHK(hipMemsetAsync(e->renergy_wo2, 0, 4 * slots, s));
+    e->new_cur = 0;
+    ef_select_new_set(e, 0, 0);
     HIPCHK(hipMemsetAsync(e->rres_toZero, 0, 8 * slots, s));
     HIPCHK(hipMemsetAsync(e->J, 0, sizeof(float) * 2 * kJPlanes * slots, s));
     HIPCHK(hipMemsetAsync(e->JpJd, 0, sizeof(float) * 6 * slots, s));
@@ -1101,6 +1122,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     const int nF = e->nF, n = CPARS + 6 * nF;
     if (nF < 2) return 0;
     const bool fixed_its = (flags & 1) != 0;   // benchmark mode: exactly mnumOptIts loop bodies, no early break
+    const bool relinearize_on_reject = (flags & 2) != 0;   // run the reference's redundant re-linearisation literally (A/B timing, tests)
     if (!fixed_its && nF < 3) mnumOptIts = 100;
     if (!fixed_its && nF < 4) mnumOptIts = 75;
     const size_t slots = (size_t)nF * e->nP;
@@ -1139,6 +1161,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         if ((rc = ef_upload_precalc(e))) return rc;                                       // setPrecalcValues + setDeltaF
         g_pt.stop(PT_PRECALC);
         double newEnergy, newEnergyL, sID, sNID;
+        ef_select_new_set(e, 1 - e->new_cur, e->new_cur);                                 // trial linearisation goes to the other set
         if ((rc = linearize_and_stats(e, &newEnergy, &newEnergyL, &sID, &sNID))) return rc;
         g_pt.stop(PT_LIN);
         const double newEnergyM = calc_M_energy(e);
@@ -1154,6 +1177,8 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         it = iteration + 1;
         g_pt.start();
         if (accept) {
+            e->new_cur = 1 - e->new_cur;                                                  // the trial set becomes the current one
+            ef_select_new_set(e, e->new_cur, e->new_cur);
             if ((rc = sdvgn_ef_apply_res(e))) return rc;
             lastEnergy = newEnergy; lastEnergyL = newEnergyL; lastEnergyM = newEnergyM;
             lambda *= 0.25;
@@ -1162,8 +1187,15 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             for (FrameH& f : e->frames) frame_set_state(f, f.state_backup);
             if ((rc = sdvgn_ef_point_step(e, 2, 0.f))) return rc;
             if ((rc = ef_upload_precalc(e))) return rc;
-            if ((rc = linearize_and_stats(e, &lastEnergy, &lastEnergyL, nullptr, nullptr))) return rc;
-            lastEnergyM = calc_M_energy(e);
+            // The reference re-linearises here (`lastEnergy = linearizeAll(false)`, FullSystemOptimize.cpp:446-449).  With the state
+            // restored exactly, that is a bit-for-bit recomputation of the previous accepted linearisation: its energies are the
+            // lastEnergy* values still held, its state_New* planes are the current set (untouched by the trial), and the J it would
+            // write into the not-owned buffer is overwritten by the next linearise before anything reads it.  So: switch back.
+            ef_select_new_set(e, e->new_cur, e->new_cur);
+            if (relinearize_on_reject) {
+                if ((rc = linearize_and_stats(e, &lastEnergy, &lastEnergyL, nullptr, nullptr))) return rc;
+                lastEnergyM = calc_M_energy(e);
+            }
             lambda *= 1e2;
         }
         g_pt.stop(PT_APPLY);
@@ -1232,9 +1264,9 @@ int sdvgn_ef_get_residual_state(sdvgn_ef* e, int* state_state, int* state_new, f
     std::vector<uint8_t> fl(slots);
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(st.data(), e->rstate, slots, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(sn.data(), e->rstate_new, slots, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(en.data(), e->renergy_new, 4 * slots, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ew.data(), e->renergy_wo, 4 * slots, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sn.data(), e->A.rstate_new, slots, hipMemcpyDeviceToHost));      // the current set (see new_cur)
+    HIPCHK(hipMemcpy(en.data(), e->A.renergy_new, 4 * slots, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ew.data(), e->A.renergy_wo, 4 * slots, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(fl.data(), e->rflags, slots, hipMemcpyDeviceToHost));
     for (int i = 0; i < e->nR; ++i) {
         const size_t s = e->r_slot[i];

@@ -69,6 +69,7 @@ struct EFArrays {
     uint8_t* rflags; int8_t* rstate; int8_t* rstate_new;
     const float2* rmatcher;
     float* renergy; float* renergy_new; float* renergy_wo;
+    const float* renergy_new_prev;   // state_NewEnergy as the previous linearisation left it (== renergy_new unless a trial set is written)
     float* rres_toZero;      // [2][slots]
     float* J;                // [2 buffers][24][slots]
     float* JpJd;             // [6][slots]
@@ -289,6 +290,7 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, con
         A.renergy_wo[s] = -1.0f;
         if (L.oob) {
             A.rstate_new[s] = RS_OOB;
+            A.renergy_new[s] = A.renergy_new_prev[s];   // state_NewEnergy is left untouched by the reference's early return (:118-119)
             my_e = (double)L.e_prev;   // `return state_energy`
         } else {
             // the reference's sequential loop over the 8 pattern pixels, `break` at the first failing one (:160-176)

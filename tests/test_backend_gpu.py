@@ -171,6 +171,27 @@ def test_optimize_loop_parity(api, orc, seed):
     assert rel_err(ig, io) < 1e-6
 
 
+@pytest.mark.parametrize("seed", [2, 3, 4])
+def test_kept_state_equals_relinearize_on_reject(api, orc, seed):
+    """A rejected step switches back to the kept state_New* set instead of re-linearising (FullSystemOptimize.cpp:446-449): both
+    variants must be bit-identical in every traced quantity, in the final state and in the per-residual state_New* planes."""
+    from sdv_loam_amd import synthetic as syn
+    W = syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=seed, calib=dict(fx=400., fy=410., cx=319.5, cy=119.5))
+    A = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+    B = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+    ta = A.optimize(8, fixed_its=True)
+    tb = B.optimize(8, fixed_its=True, relinearize_on_reject=True)
+    assert (ta[:, 2] == 0).any()                                              # the reject branch was taken
+    assert np.array_equal(ta, tb)
+    for x, y in zip(A.state(), B.state()):
+        assert np.array_equal(x, y)
+    sa, sb = A.residual_state(), B.residual_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    xa, xb = A.solveSystemF(3, 0.1), B.solveSystemF(3, 0.1)                   # and the next solve sees the same system
+    assert np.array_equal(xa, xb)
+
+
 def test_sharded_path_single_rank_nccl(api, orc, window):
     """cfg4 plumbing on one GPU: external torch buffers, torch stream, and the all-reduce callback going through a
     1-rank RCCL process group -- must give exactly the single-GPU result."""
