@@ -213,6 +213,21 @@ def tracker_extras(torch, local, batch, oracle, want_cpu):
         _, sp_tr, _ = G.structPoseEstimation(SP.init_curToWorld7, *sp_args)
     out["struct_pose_call_ms"] = 1e3 * (time.perf_counter() - t0) / 50
     out["struct_pose_lm_iterations"] = len(sp_tr)
+    # (ii-d) setCoarseTrackingRef: reference template on the device from 14 000 splat tuples (row a3), vs the oracle
+    rng_cd = np.random.default_rng(4)
+    cd = (rng_cd.integers(0, P.w, 14000).astype(np.int32), rng_cd.integers(0, P.h, 14000).astype(np.int32),
+          rng_cd.uniform(0.02, 0.5, 14000).astype(np.float32), rng_cd.uniform(0.3, 3.0, 14000).astype(np.float32))
+    GT = api.CoarseTracker(P.w, P.h, P.levels, max_points=P.w * P.h, max_batch=2, device=local)
+    GT.makeK(**P.calib)
+    GT.set_new_image(P.image, 1.0)
+    for _ in range(3):
+        GT.makeCoarseDepth(*cd)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        GT.makeCoarseDepth(*cd)
+    out["make_coarse_depth_ms"] = 1e3 * (time.perf_counter() - t0) / 20
+    out["make_coarse_depth_template_points_lvl0"] = int(GT.n[0])
+    del GT
     # (iii) batched roofline run of the fused tracker kernel
     poses = np.stack([oracle.se3_mul(oracle.se3_exp(syn.perturbation(1000 + i)), P.gt_pose) for i in range(batch)])
     affs = np.tile([0.02, 2.0], (batch, 1))
@@ -246,6 +261,10 @@ def tracker_extras(torch, local, batch, oracle, want_cpu):
         for _ in range(50):
             O.structPoseEstimation(SP.init_curToWorld7, *sp_args)
         out["cpu_struct_pose_call_ms_1thread"] = 1e3 * (time.perf_counter() - t0) / 50
+        t0 = time.perf_counter()
+        for _ in range(5):
+            O.makeCoarseDepth(*cd)
+        out["cpu_make_coarse_depth_ms_1thread"] = 1e3 * (time.perf_counter() - t0) / 5
     return out
 
 

@@ -62,9 +62,24 @@ int sdvgn_tracker_get_K(sdvgn_tracker* t, int lvl, float fxfycxcy[4], float Ki9[
 
 /* Result of CoarseTracker::makeCoarseDepthL0 / makeCoarseDepthForFirstFrame (CoarseTracker.cpp:108-425):
  * the compacted reference template pc_u, pc_v, pc_idepth, pc_color [pc_n[lvl]] of one level
- * (CoarseTracker.h:87-91).  The splat/dilate itself stays on the host. */
+ * (CoarseTracker.h:87-91), for callers that build it themselves; sdvgn_tracker_make_coarse_depth builds it on the device. */
 int sdvgn_tracker_set_ref(sdvgn_tracker* t, int lvl, int n, const float* pc_u, const float* pc_v,
                           const float* pc_idepth, const float* pc_color);
+/* CoarseTracker::makeCoarseDepthL0(frameHessians) (CoarseTracker.cpp:258-425) and makeCoarseDepthForFirstFrame (:108-256) -- the body
+ * of setCoarseTrackingRef / setCTRefForFirstFrame (:636-660) -- on the device: builds pc_u / pc_v / pc_idepth / pc_color of every
+ * level (what sdvgn_tracker_set_ref uploads otherwise) from the tuples the reference splats, in the reference's order:
+ *   makeCoarseDepthL0:            per point either (int)u, (int)v, idepth (:268-277) or (int)(centerProjectedTo + 0.5f), centerProjectedTo[2]
+ *                                 (:284-292), weight = sqrtf(1e-3 / (efPoint->HdiF + 1e-12))
+ *   makeCoarseDepthForFirstFrame: (int)(u + 0.5f), (int)(v + 0.5f), idepth, same weight (:114-125)
+ * ref_pyr_dev: lastRef->dIp[lvl] as device pointers (AoS {I,dx,dy}), e.g. another tracker handle's pyramid; NULL = this handle's
+ * current new frame.  The tracker must have been created with max_points >= the number of template points (the reference
+ * allocates w*h per level).  Raster order and every value are identical to the reference's loop; one documented deviation: the
+ * dilation's out-of-range neighbour reads at the first / last processed pixel (undefined behaviour, :339-342) count as "no value". */
+int sdvgn_tracker_make_coarse_depth(sdvgn_tracker* t, int n, const int* u, const int* v, const float* new_idepth, const float* weight,
+                                    const float* const* ref_pyr_dev);
+/* read back the reference template of a level (parity hook); returns pc_n[lvl]; with u == NULL only the count */
+int sdvgn_tracker_get_ref(sdvgn_tracker* t, int lvl, float* u, float* v, float* idepth, float* color);
+
 /* lastRef->ab_exposure and lastRef_aff_g2l set in setCoarseTrackingRef / setCTRefForFirstFrame
  * (CoarseTracker.cpp:636-660) */
 int sdvgn_tracker_set_ref_frame(sdvgn_tracker* t, float ab_exposure, double aff_a, double aff_b);

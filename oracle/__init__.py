@@ -56,6 +56,10 @@ def lib():
     L.orc_track.argtypes = [C.c_void_p, f64p, f64p, C.c_int, f64p, f64p, f64p, C.c_void_p, C.c_int, C.c_void_p]
     L.orc_track.restype = C.c_int
     L.orc_trace_stride.restype = C.c_int
+    L.orc_tracker_make_coarse_depth.argtypes = [C.c_void_p, C.c_int, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"),
+                                                np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"), f32p, f32p]
+    L.orc_tracker_get_ref.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_tracker_get_ref.restype = C.c_int
     i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
     L.orc_struct_trace_stride.restype = C.c_int
     L.orc_struct_pose.argtypes = [C.c_void_p, C.c_int, f32p, f32p, f32p, i32p, f64p, f64p, f64p, C.c_void_p, C.c_void_p]
@@ -176,6 +180,18 @@ class OracleTracker:
 
     def set_ref_frame(self, exposure=1.0, a=0.0, b=0.0):
         self.L.orc_tracker_set_ref_frame(self.h_, exposure, a, b)
+
+    def makeCoarseDepth(self, u, v, new_idepth, weight):
+        """makeCoarseDepthL0 / makeCoarseDepthForFirstFrame from their splat tuples; lastRef->dIp = the current new-frame pyramid."""
+        u, v = (np.ascontiguousarray(x, np.int32) for x in (u, v))
+        self.L.orc_tracker_make_coarse_depth(self.h_, len(u), u, v, np.ascontiguousarray(new_idepth, np.float32),
+                                             np.ascontiguousarray(weight, np.float32))
+
+    def get_ref(self, lvl):
+        n = self.L.orc_tracker_get_ref(self.h_, lvl, None, None, None, None)
+        out = [np.zeros(n, np.float32) for _ in range(4)]
+        self.L.orc_tracker_get_ref(self.h_, lvl, *[a.ctypes.data_as(C.c_void_p) for a in out])
+        return dict(u=out[0], v=out[1], idepth=out[2], color=out[3])
 
     def set_new_image(self, color, exposure=1.0):
         self.L.orc_tracker_set_new_image(self.h_, np.ascontiguousarray(color, np.float32).reshape(-1), exposure)

@@ -642,6 +642,69 @@ static int struct_pose_estimation(const Tracker* T, int n, const float* u, const
     return its;
 }
 
+// ---- a3 / 8f-4: makeCoarseDepthL0 and makeCoarseDepthForFirstFrame (CoarseTracker.cpp:108-256, 258-425) --------------------
+// Both functions are: splat (u, v, new_idepth, weight) tuples into the level-0 idepth / weightSums maps in point order, sum the
+// maps down the pyramid, dilate (diagonal neighbours on levels 0-1, 4-neighbours above), normalise and collect the reference
+// template pc_u / pc_v / pc_idepth / pc_color in raster order.  They differ only in WHICH tuples are splat (:266-293 vs :114-125),
+// which stays with the caller.  Deviation: the dilation loops read one element before / after the maps at the first / last
+// processed pixel (i-1-wl = -1 at i = wl on levels 0-1; i+1+wl = w*h at i = wh-1), undefined behaviour in the reference -- here
+// (and in the HIP kernels) an out-of-range neighbour counts as "no value".
+static void make_coarse_depth(Tracker* T, int n, const int* pu, const int* pv, const float* new_idepth, const float* weight) {
+    const int L = T->levels;
+    std::vector<std::vector<float>> idepth(L), wsum(L), wbak(L);
+    for (int l = 0; l < L; ++l) { idepth[l].assign((size_t)T->w[l] * T->h[l], 0.f); wsum[l].assign((size_t)T->w[l] * T->h[l], 0.f); }
+    for (int i = 0; i < n; ++i) {
+        const size_t k = (size_t)pu[i] + (size_t)T->w[0] * pv[i];
+        idepth[0][k] += new_idepth[i] * weight[i];
+        wsum[0][k] += weight[i];
+    }
+    for (int lvl = 1; lvl < L; lvl++) {
+        const int wl = T->w[lvl], hl = T->h[lvl], wlm1 = T->w[lvl - 1];
+        for (int y = 0; y < hl; y++)
+            for (int x = 0; x < wl; x++) {
+                const int b = 2 * x + 2 * y * wlm1;
+                idepth[lvl][x + y * wl] = idepth[lvl - 1][b] + idepth[lvl - 1][b + 1] + idepth[lvl - 1][b + wlm1] + idepth[lvl - 1][b + wlm1 + 1];
+                wsum[lvl][x + y * wl] = wsum[lvl - 1][b] + wsum[lvl - 1][b + 1] + wsum[lvl - 1][b + wlm1] + wsum[lvl - 1][b + wlm1 + 1];
+            }
+    }
+    for (int lvl = 0; lvl < L; lvl++) {
+        const int wl = T->w[lvl], total = T->w[lvl] * T->h[lvl], wh = total - wl;
+        wbak[lvl] = wsum[lvl];
+        const std::vector<float>& bak = wbak[lvl];
+        std::vector<float>& id = idepth[lvl];
+        const int off[2][4] = {{1 + wl, -1 - wl, wl - 1, -wl + 1}, {1, -1, wl, -wl}};
+        const int* o = off[lvl < 2 ? 0 : 1];
+        for (int i = wl; i < wh; i++) {
+            if (bak[i] <= 0) {
+                float sum = 0, num = 0, numn = 0;
+                for (int q = 0; q < 4; ++q) {
+                    const int j = i + o[q];
+                    if (j >= 0 && j < total && bak[j] > 0) { sum += id[j]; num += bak[j]; numn++; }
+                }
+                if (numn > 0) { id[i] = sum / numn; wsum[lvl][i] = num / numn; }
+            }
+        }
+    }
+    for (int lvl = 0; lvl < L; lvl++) {
+        const int wl = T->w[lvl], hl = T->h[lvl];
+        const float* dIRef = T->dIp[lvl].data();
+        T->pc_u[lvl].clear(); T->pc_v[lvl].clear(); T->pc_idepth[lvl].clear(); T->pc_color[lvl].clear();
+        for (int y = 2; y < hl - 2; y++)
+            for (int x = 2; x < wl - 2; x++) {
+                const int i = x + y * wl;
+                if (wsum[lvl][i] > 0) {
+                    idepth[lvl][i] /= wsum[lvl][i];
+                    const float c = dIRef[3 * i];
+                    if (!std::isfinite(c) || !(idepth[lvl][i] > 0)) { idepth[lvl][i] = -1; continue; }
+                    T->pc_u[lvl].push_back((float)x); T->pc_v[lvl].push_back((float)y);
+                    T->pc_idepth[lvl].push_back(idepth[lvl][i]); T->pc_color[lvl].push_back(c);
+                } else idepth[lvl][i] = -1;
+                wsum[lvl][i] = 1;
+            }
+        T->pc_n[lvl] = (int)T->pc_u[lvl].size();
+    }
+}
+
 extern "C" {
 
 int orc_trace_stride() { return kTraceStride; }
@@ -670,6 +733,16 @@ void orc_tracker_set_ref(void* h, int lvl, int n, const float* u, const float* v
     T->pc_n[lvl] = n;
     T->pc_u[lvl].assign(u, u + n); T->pc_v[lvl].assign(v, v + n);
     T->pc_idepth[lvl].assign(idepth, idepth + n); T->pc_color[lvl].assign(color, color + n);
+}
+// reference template from splat tuples; the reference frame's pyramid (lastRef->dIp) is the one set with set_new_image / set_new_pyr
+void orc_tracker_make_coarse_depth(void* h, int n, const int* u, const int* v, const float* new_idepth, const float* weight) {
+    make_coarse_depth((Tracker*)h, n, u, v, new_idepth, weight);
+}
+int orc_tracker_get_ref(void* h, int lvl, float* u, float* v, float* idepth, float* color) {
+    Tracker* T = (Tracker*)h;
+    const int n = T->pc_n[lvl];
+    if (u) for (int i = 0; i < n; ++i) { u[i] = T->pc_u[lvl][i]; v[i] = T->pc_v[lvl][i]; idepth[i] = T->pc_idepth[lvl][i]; color[i] = T->pc_color[lvl][i]; }
+    return n;
 }
 void orc_tracker_set_ref_frame(void* h, float exposure, double a, double b) {
     Tracker* T = (Tracker*)h; T->ref_exposure = exposure; T->ref_a = a; T->ref_b = b;

@@ -29,6 +29,8 @@ PROTOTYPES = [
     ("sdvgn_tracker_get_K", C.c_int, [vp, C.c_int, f32p, f32p]),
     ("sdvgn_tracker_set_ref", C.c_int, [vp, C.c_int, C.c_int, f32p, f32p, f32p, f32p]),
     ("sdvgn_tracker_set_ref_frame", C.c_int, [vp, C.c_float, C.c_double, C.c_double]),
+    ("sdvgn_tracker_make_coarse_depth", C.c_int, [vp, C.c_int, i32p, i32p, f32p, f32p, vp]),
+    ("sdvgn_tracker_get_ref", C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
     ("sdvgn_tracker_set_new_image", C.c_int, [vp, f32p, C.c_float]),
     ("sdvgn_tracker_set_new_image_dev", C.c_int, [vp, vp, C.c_float]),
     ("sdvgn_tracker_set_new_pyr", C.c_int, [vp, C.c_int, f32p, C.c_float]),
@@ -147,6 +149,23 @@ class CoarseTracker:
 
     def set_ref_frame(self, exposure=1.0, a=0.0, b=0.0):
         check(self.L.sdvgn_tracker_set_ref_frame(self.h_, exposure, a, b))
+
+    def makeCoarseDepth(self, u, v, new_idepth, weight, ref_pyr_dev=None):
+        """makeCoarseDepthL0 / makeCoarseDepthForFirstFrame from their splat tuples (CoarseTracker.cpp:108-425)."""
+        u, v = (np.ascontiguousarray(x, np.int32) for x in (u, v))
+        arr = None
+        if ref_pyr_dev is not None:
+            arr = (vp * len(ref_pyr_dev))(*ref_pyr_dev)
+        check(self.L.sdvgn_tracker_make_coarse_depth(self.h_, len(u), u, v, np.ascontiguousarray(new_idepth, np.float32),
+                                                     np.ascontiguousarray(weight, np.float32), arr))
+        for l in range(self.levels):
+            self.n[l] = self.L.sdvgn_tracker_get_ref(self.h_, l, None, None, None, None)
+
+    def get_ref(self, lvl):
+        n = check(self.L.sdvgn_tracker_get_ref(self.h_, lvl, None, None, None, None))
+        out = [np.zeros(n, np.float32) for _ in range(4)]
+        check(self.L.sdvgn_tracker_get_ref(self.h_, lvl, *[a.ctypes.data_as(vp) for a in out]))
+        return dict(u=out[0], v=out[1], idepth=out[2], color=out[3])
 
     def set_new_image(self, color, exposure=1.0):
         color = np.ascontiguousarray(color, np.float32).reshape(-1)

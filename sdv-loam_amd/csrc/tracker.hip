@@ -28,6 +28,7 @@ namespace sdvgn {
 #include "tracker_track_kernel.inc"
 #include "tracker_struct_pose.inc"
 #include "tracker_trace_points.inc"
+#include "tracker_coarse_depth.inc"
 }
 
 struct sdvgn_tracker {
@@ -79,6 +80,15 @@ struct sdvgn_tracker {
     int tp_n = 0, tp_cap = 0;
     float* tp_static_dev = nullptr;     // u | v | energyTH | gradH(4) | color(8) | weights(8) | host_idx : 23 words per point
     void* tp_state_host = nullptr;      // pinned: idepth_min | idepth_max | quality | status | lastTraceUV(2) | interval : 7 words per point
+
+    // makeCoarseDepthL0 (tracker_coarse_depth.inc): per-level maps, row bookkeeping, host-side ordered pre-accumulation
+    float* cd_maps = nullptr;            // idepth | wsum | wdil for all levels
+    int* cd_rows = nullptr;              // rowcount | rowoff
+    int* cd_n_host = nullptr;            // pinned: pc_n per level, written by k_cd_scan
+    void* cd_stage = nullptr;            // pinned: unique pixels (pix | val | wgt), read by k_cd_scatter directly
+    int cd_stage_cap = 0;
+    std::vector<int> cd_slot, cd_stamp;  // dense pixel -> slot map with a generation stamp (no per-call clearing)
+    int cd_gen = 0;
 
     // structPoseEstimation (tracker_struct_pose.inc): packed input staging and the result block, both pinned host memory
     void* sp_stage_host = nullptr;   // pinned, read by the kernel directly
@@ -302,6 +312,7 @@ void sdvgn_tracker_destroy(sdvgn_tracker* t) {
     hipHostFree(t->track_host);
     hipHostFree(t->sp_stage_host); hipHostFree(t->sp_io_host);
     hipFree(t->tp_static_dev); hipHostFree(t->tp_state_host);
+    hipFree(t->cd_maps); hipFree(t->cd_rows); hipHostFree(t->cd_n_host); hipHostFree(t->cd_stage);
     if (t->own_stream) hipStreamDestroy(t->stream);
     delete t;
 }
@@ -607,6 +618,7 @@ int sdvgn_tracker_trace_set_points(sdvgn_tracker* t, int n, const float* u, cons
     if ((int)np > t->tp_cap) {
         HIPCHK(hipStreamSynchronize(t->stream));
         hipFree(t->tp_static_dev); hipHostFree(t->tp_state_host);
+    hipFree(t->cd_maps); hipFree(t->cd_rows); hipHostFree(t->cd_n_host); hipHostFree(t->cd_stage);
         t->tp_static_dev = nullptr; t->tp_state_host = nullptr; t->tp_cap = 0;
         const size_t cap = np + np / 2 + 1024;
         HIPCHK(hipMalloc((void**)&t->tp_static_dev, sizeof(float) * 24 * cap));
@@ -657,4 +669,92 @@ int sdvgn_tracker_trace_points(sdvgn_tracker* t, int n_hosts, const float* KRKi9
     std::memcpy(idepth_min, hmin, 4 * (size_t)n); std::memcpy(idepth_max, hmax, 4 * (size_t)n); std::memcpy(quality, hq, 4 * (size_t)n);
     std::memcpy(status, hst, 4 * (size_t)n); std::memcpy(lastTraceUV2, huv, 8 * (size_t)n); std::memcpy(lastTracePixelInterval, hiv, 4 * (size_t)n);
     return SDVGN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// makeCoarseDepthL0 / makeCoarseDepthForFirstFrame: reference template on the device
+// ---------------------------------------------------------------------------------------------------------------
+int sdvgn_tracker_make_coarse_depth(sdvgn_tracker* t, int n, const int* u, const int* v, const float* new_idepth, const float* weight,
+                                    const float* const* ref_pyr_dev) {
+    if (!t || n < 0 || (n > 0 && (!u || !v || !new_idepth || !weight))) return SDVGN_E_ARG;
+    if (!ref_pyr_dev && !t->haveNew) return SDVGN_E_STATE;
+    const int L = t->levels, w0 = t->w[0], h0 = t->h[0];
+    for (int i = 0; i < n; ++i) if (u[i] < 0 || u[i] >= w0 || v[i] < 0 || v[i] >= h0) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    size_t npix = 0, nrows = 0;
+    for (int l = 0; l < L; ++l) { npix += (size_t)t->w[l] * t->h[l]; nrows += t->h[l]; }
+    if (!t->cd_maps) {
+        HIPCHK(hipMalloc((void**)&t->cd_maps, sizeof(float) * 3 * npix));
+        HIPCHK(hipMalloc((void**)&t->cd_rows, sizeof(int) * 2 * nrows));
+        HIPCHK(hipHostMalloc((void**)&t->cd_n_host, sizeof(int) * SDVGN_MAX_LEVELS));
+        t->cd_slot.assign((size_t)w0 * h0, 0);
+        t->cd_stamp.assign((size_t)w0 * h0, 0);
+    }
+    if (n > t->cd_stage_cap) {
+        HIPCHK(hipStreamSynchronize(t->stream));
+        hipHostFree(t->cd_stage);
+        t->cd_stage = nullptr; t->cd_stage_cap = 0;
+        const int cap = n + n / 2 + 1024;
+        HIPCHK(hipHostMalloc(&t->cd_stage, (size_t)cap * 12));
+        t->cd_stage_cap = cap;
+    }
+    // splat in tuple order (:266-293): tuples that hit one pixel are summed here, sequentially, exactly like `idepth[0][k] += ...`
+    int* s_pix = (int*)t->cd_stage;
+    float* s_val = (float*)(s_pix + t->cd_stage_cap);
+    float* s_wgt = s_val + t->cd_stage_cap;
+    int nu = 0;
+    const int gen = ++t->cd_gen;
+    for (int i = 0; i < n; ++i) {
+        const int k = u[i] + w0 * v[i];
+        if (t->cd_stamp[k] != gen) { t->cd_stamp[k] = gen; t->cd_slot[k] = nu; s_pix[nu] = k; s_val[nu] = 0.0f; s_wgt[nu] = 0.0f; ++nu; }
+        const int sl = t->cd_slot[k];
+        s_val[sl] += new_idepth[i] * weight[i];
+        s_wgt[sl] += weight[i];
+    }
+    CdLevels C;
+    C.levels = L;
+    {
+        float* p = t->cd_maps;
+        int r = 0;
+        for (int l = 0; l < L; ++l) {
+            const size_t np = (size_t)t->w[l] * t->h[l];
+            C.w[l] = t->w[l]; C.h[l] = t->h[l];
+            C.idepth[l] = p; C.wsum[l] = p + np; C.wdil[l] = p + 2 * np;
+            p += 3 * np;
+            C.ref[l] = ref_pyr_dev ? ref_pyr_dev[l] : t->pyr_dev[l];
+            if (!C.ref[l]) return SDVGN_E_ARG;
+            C.pc[l] = t->pc_dev[l];
+            C.row0[l] = r; r += t->h[l];
+        }
+    }
+    int* rowcount = t->cd_rows;
+    int* rowoff = t->cd_rows + nrows;
+    HIPCHK(hipMemsetAsync(C.idepth[0], 0, sizeof(float) * 2 * (size_t)w0 * h0, t->stream));   // idepth[0] and wsum[0] are adjacent
+    if (nu) k_cd_scatter<<<(nu + 255) / 256, 256, 0, t->stream>>>(nu, s_pix, s_val, s_wgt, C.idepth[0], C.wsum[0]);
+    for (int l = 1; l < L; ++l)
+        k_cd_pyr<<<(t->w[l] * t->h[l] + 255) / 256, 256, 0, t->stream>>>(t->w[l], t->h[l], t->w[l - 1], C.idepth[l - 1], C.wsum[l - 1], C.idepth[l], C.wsum[l]);
+    k_cd_dilate<<<dim3((w0 * h0 + 255) / 256, L), 256, 0, t->stream>>>(C);
+    k_cd_count<<<dim3(h0, L), 256, 0, t->stream>>>(C, rowcount);
+    k_cd_scan<<<L, 256, 0, t->stream>>>(C, rowcount, rowoff, t->cd_n_host);
+    k_cd_emit<<<dim3(h0, L), 256, 0, t->stream>>>(C, rowoff, t->max_points);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(t->stream));
+    for (int l = 0; l < L; ++l) {
+        if (t->cd_n_host[l] > t->max_points) { t->pc_n[l] = 0; return SDVGN_E_ARG; }   // create the tracker with max_points = w*h like the reference (:49-55)
+        t->pc_n[l] = t->cd_n_host[l];
+    }
+    return SDVGN_OK;
+}
+
+int sdvgn_tracker_get_ref(sdvgn_tracker* t, int lvl, float* u, float* v, float* idepth, float* color) {
+    if (!t || lvl < 0 || lvl >= t->levels) return SDVGN_E_ARG;
+    const int n = t->pc_n[lvl];
+    if (!u) return n;
+    if (!v || !idepth || !color) return SDVGN_E_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    std::vector<float4> p(n);
+    HIPCHK(hipStreamSynchronize(t->stream));
+    if (n) HIPCHK(hipMemcpy(p.data(), t->pc_dev[lvl], sizeof(float4) * n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) { u[i] = p[i].x; v[i] = p[i].y; idepth[i] = p[i].z; color[i] = p[i].w; }
+    return n;
 }
