@@ -227,6 +227,19 @@ def tracker_extras(torch, local, batch, oracle, want_cpu):
         GT.makeCoarseDepth(*cd)
     out["make_coarse_depth_ms"] = 1e3 * (time.perf_counter() - t0) / 20
     out["make_coarse_depth_template_points_lvl0"] = int(GT.n[0])
+    # (ii-e) the same tracker calls on that dense template (what the reference really tracks with: tens of thousands of points per level)
+    GT.set_ref_frame(1.0, 0.0, 0.0)
+    dense_pose = oracle.se3_exp(np.array([0.02, -0.01, 0.03, 0.002, -0.001, 0.0015]))
+    GT.trackNewestCoarse(dense_pose, (0.0, 0.0), 3)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        GT.trackNewestCoarse(dense_pose, (0.0, 0.0), 3)
+    out["dense_template_track_call_host_driven_ms"] = 1e3 * (time.perf_counter() - t0) / 10
+    GT.trackBatch(dense_pose[None], np.zeros((1, 2)), 3)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        GT.trackBatch(dense_pose[None], np.zeros((1, 2)), 3)
+    out["dense_template_track_call_device_resident_ms"] = 1e3 * (time.perf_counter() - t0) / 10
     del GT
     # (iii) batched roofline run of the fused tracker kernel
     poses = np.stack([oracle.se3_mul(oracle.se3_exp(syn.perturbation(1000 + i)), P.gt_pose) for i in range(batch)])
@@ -265,6 +278,11 @@ def tracker_extras(torch, local, batch, oracle, want_cpu):
         for _ in range(5):
             O.makeCoarseDepth(*cd)
         out["cpu_make_coarse_depth_ms_1thread"] = 1e3 * (time.perf_counter() - t0) / 5
+        O.set_ref_frame(1.0, 0.0, 0.0)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            O.trackNewestCoarse(dense_pose, (0.0, 0.0), 3)
+        out["cpu_dense_template_track_call_ms_1thread"] = 1e3 * (time.perf_counter() - t0) / 3
     return out
 
 

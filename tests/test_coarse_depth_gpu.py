@@ -78,6 +78,32 @@ def test_tracking_on_the_device_built_template(orc):
     assert oko and e1 < 0.3 * e0
 
 
+def test_large_template_feeds_calc_res_and_gs(orc):
+    """KITTI-sized template (64 k points on level 0, far more than the 2000-point bench configuration): calcRes / calcGSSSE on the
+    device-built template agree with the oracle on every level, on both the host-driven and the device-resident path."""
+    from common import rel_err
+    from sdv_loam_amd import synthetic as syn
+    w, h, L = 1241, 376, 4
+    G, O, img = _pair(orc, w, h, L, 7, syn.KITTI00)
+    t = _tuples(w, h, 14000, 7)
+    for T in (G, O):
+        T.makeCoarseDepth(*t)
+        T.set_ref_frame(1.0, 0.0, 0.0)
+    pose = orc.se3_exp(np.array([0.02, -0.01, 0.03, 0.002, -0.001, 0.0015]))
+    for l in range(L):
+        rg, Hg, bg = G.resAndGS(l, pose, 0.01, 1.0, 20.0)
+        ro = O.calcRes(l, pose, 0.01, 1.0, 20.0)
+        Ho, bo = O.calcGS(l, 0.01, 1.0)
+        assert rg[1] == ro[1] and rel_err(rg[0], ro[0]) < 1e-5
+        assert rel_err(Hg, Ho) < 1e-5 and rel_err(bg, bo) < 1e-5
+    okg, pg, *_ = G.trackNewestCoarse(pose, (0.0, 0.0), 3)
+    okb, pb, *_ = G.trackBatch(pose[None], np.zeros((1, 2)), 3)
+    oko, po, *_ = O.trackNewestCoarse(pose, (0.0, 0.0), 3)
+    assert okg == oko == bool(okb[0])
+    d = lambda p: orc.se3_log(orc.se3_mul(p, orc.se3_inverse(pose)))   # noqa: E731
+    assert rel_err(d(pg), d(po)) < 1e-4 and rel_err(d(pb[0]), d(po)) < 1e-4
+
+
 def test_errors(orc):
     from sdv_loam_amd import api, synthetic as syn
     G = api.CoarseTracker(160, 120, 3, max_points=500)
