@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=2048, help="LM trials per launch for the batched tracker roofline run")
+    ap.add_argument("--batch", type=int, default=4096, help="LM trials per launch for the batched tracker roofline run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--quick", action="store_true", help="skip the tracker extras and the PMC traffic passes")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -436,6 +436,22 @@ def main():
                 note="%d residuals x %d B algorithmic = %.1f MB per launch; %.4f ms per launch (HIP events around "
                      "k_ef_linearize alone, on the library stream)" % (W.nR, LINEARIZE_BYTES_PER_RES, alg / 1e6, ms_lin))
     ms_acc = event_ms(torch, ext, lambda: G.accumulate(), 50)
+    # what a plain streaming copy reaches on this box (1 GiB read + 1 GiB written), for reading `frac` against the achievable rate
+    try:
+        src = torch.empty(1 << 28, dtype=torch.float32, device=torch.device("cuda", local))
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        roof["hbm_copy_measured_GBps"] = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+    except Exception:  # noqa: BLE001
+        roof["hbm_copy_measured_GBps"] = None
 
     out = {
         "metric": "Gauss-Newton iters/sec (KITTI res, 8 KF x 2000 pts)",
