@@ -92,11 +92,18 @@ class ShardedEnergyFunctional:
         if world > 1 or force_collective:
             acc_ptr, stats_ptr = self.acc.data_ptr(), self.stats.data_ptr()
 
+            via_host = dist.get_backend(self.group) == "gloo"   # test rigs without RCCL peers (e.g. two ranks sharing one GPU)
+
             def _allreduce(user, buf, count):
                 assert buf in (acc_ptr, stats_ptr)
                 t = self.acc[:count] if buf == acc_ptr else self.stats[:count]
                 with torch.cuda.stream(self.stream):
-                    dist.all_reduce(t, group=self.group)
+                    if via_host:
+                        h = t.cpu()                      # synchronises this stream: the accumulate kernels are done
+                        dist.all_reduce(h, group=self.group)
+                        t.copy_(h)
+                    else:
+                        dist.all_reduce(t, group=self.group)
                 self.n_allreduce += 1
 
             self._cb = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)(_allreduce)

@@ -1,0 +1,61 @@
+"""The sharded back end (BASELINE.json configs[3]) with world_size 2 on ONE GPU: two processes, each with its own library handle
+and stream on cuda:0, each linearising / accumulating only its host-frame shard on the device, packed accumulators and linearize
+statistics all-reduced through torch.distributed (gloo, staged through the host because two ranks cannot form an RCCL clique on one
+device).  Must reproduce the single-process optimize() -- same accept/reject trace, same final state."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CAL = dict(fx=400., fy=410., cx=319.5, cy=119.5)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from sdv_loam_amd import parallel, synthetic as syn
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    W = syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=2, calib=CAL)
+    S = parallel.ShardedEnergyFunctional(W, rank, world, 0)
+    tr = S.optimize(6, want_trace=True)
+    vs, st, idp = S.ef.state()
+    # every rank holds the full frame / calibration state; point inverse depths only for its own hosts
+    lo, hi = parallel.shard_hosts(W.nF, world)[rank]
+    mine = (W.host >= lo) & (W.host < hi)
+    q.put((rank, np.asarray(tr), vs, st, idp[mine], np.nonzero(mine)[0], S.n_allreduce))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_one_gpu_reproduce_single_process(sdvgn_lib):
+    import torch.multiprocessing as mp
+    from sdv_loam_amd import backend_api, synthetic as syn
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda r: r[0])
+    W = syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=2, calib=CAL)
+    G = backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+    tr = G.optimize(6)
+    vs, st, idp = G.state()
+    for rank, trr, vsr, str_, idr, idx, ncoll in res:
+        assert len(trr) == len(tr) and np.array_equal(trr[:, :3], tr[:, :3])            # iteration, lambda, accepted
+        assert np.allclose(trr[:, 3:6], tr[:, 3:6], rtol=1e-9, atol=1e-9)                # energies (sums in another grouping)
+        assert np.allclose(trr[:, 7:], tr[:, 7:], rtol=1e-6, atol=1e-12)                 # increments
+        assert np.allclose(vsr, vs, rtol=1e-10) and np.allclose(str_, st, rtol=1e-7, atol=1e-12)
+        assert np.allclose(idr, idp[idx], rtol=1e-6)
+        assert ncoll >= 2 * len(tr)                                                      # >= one accumulator + one statistics all-reduce per iteration
+    assert np.array_equal(res[0][1], res[1][1])                                          # both ranks took bitwise the same path
