@@ -2,6 +2,8 @@
 
 Tolerances: per-point terms and integer counters bit-exact; E rel 1e-5 (float tree sum vs sequential float sum);
 H, b rel 1e-5; pose increments rel 1e-4 (BASELINE.json north_star)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -197,3 +199,26 @@ def test_full_size_configs(api, orc, cfg):
         db = orc.se3_log(orc.se3_mul(pb[i], orc.se3_inverse(start)))
         assert rel_err(db, do) < 1e-4
     assert np.array_equal(pb[0], pb[1]) and np.array_equal(pb[1], pb[2])   # deterministic across workgroups
+
+
+@pytest.mark.parametrize("B", [6, 64, 260])
+def test_res_and_gs_batch_matches_single_calls(orc, B):
+    """sdvgn_tracker_res_and_gs_batch (B pose hypotheses in one launch): every
+    hypothesis' {Vec6, H, b} equals the single-call result (different partial-sum grouping: rel 1e-5, counters exact)."""
+    import torch
+    from sdv_loam_amd import api, synthetic as syn
+    P = small_problem(seed=12, n=700)
+    G = load_problem(api.CoarseTracker(P.w, P.h, P.levels, max_points=4096, max_batch=512), P)
+    poses = np.stack([orc.se3_mul(orc.se3_exp(syn.perturbation(100 + i, 0.03, 0.004)), P.gt_pose) for i in range(B)])
+    affs = np.stack([[0.01 * (i % 5), 0.5 * (i % 3)] for i in range(B)]).astype(np.float64)
+    out = torch.zeros((B, 80), dtype=torch.float64, device="cuda")
+    for lvl in (0, P.levels - 1):
+        G.resAndGSBatch(lvl, poses, affs, 20.0, out_dev_ptr=C.c_void_p(out.data_ptr()))
+        ext = torch.cuda.ExternalStream(G.stream())
+        ext.synchronize()
+        got = out.cpu().numpy()
+        for i in range(0, B, max(1, B // 16)):
+            r, H, b = G.resAndGS(lvl, poses[i], affs[i, 0], affs[i, 1], 20.0)
+            assert got[i, 1] == r[1] and got[i, 78] >= 0                      # counters exact
+            assert rel_err(got[i, 0], r[0]) < 1e-5 and rel_err(got[i, 2:6], r[2:6]) < 1e-5
+            assert rel_err(got[i, 6:70].reshape(8, 8), H) < 1e-5 and rel_err(got[i, 70:78], b) < 1e-5
