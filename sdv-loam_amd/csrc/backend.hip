@@ -114,7 +114,10 @@ struct sdvgn_ef {
     float *xc_dev = nullptr, *xAd_dev = nullptr;
     float* x_host = nullptr;      // pinned, 2 slots used alternately: xc(4) + xAd(nF*nF*6)
     int x_slot = 0;
-    hipEvent_t ev_top = nullptr;  // split accumulate: the top accumulators have landed in acc_host
+    hipEvent_t ev_top = nullptr;  // (unused by the flag path; kept for the event fallback)
+    int* flags_host = nullptr;    // pinned: [0] top accumulators done, [1] all accumulators done, [2] linearize statistics done
+    unsigned* done_ctr = nullptr; // device: workgroup counters for the multi-workgroup publishers (2)
+    int seq_top = 0, seq_acc = 0, seq_stats = 0;
     bool split_pending = false;   // the SC part of acc_host is still in flight on the stream
     bool acc_in_host = false;     // the last accumulate wrote acc_host directly (acc_dev not updated)
     double* stats_dev = nullptr;   // {linearize energy, L-energy point part, sum step^2, sum |idepth_backup|}
@@ -535,7 +538,7 @@ __global__ void __launch_bounds__(256) k_ef_point_stats(EFConst C, EFArrays A, c
 // out[0] = sum energy partials, out[1] = sum L partials (nL may be 0), out[2], out[3] = sums of the two halves of the
 // resubstitute partials (step^2, |idepth_backup|): one launch instead of four tiny ones
 __global__ void k_ef_sum_stats(const double* __restrict__ pe, int nE, const double* __restrict__ pl, int nL,
-                               const double* __restrict__ ps, int nS, double* __restrict__ out) {
+                               const double* __restrict__ ps, int nS, double* __restrict__ out, volatile int* done_flag, int done_seq) {
     __shared__ double s[4][256];
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     for (int i = threadIdx.x; i < nE; i += 256) a0 += pe[i];
@@ -548,6 +551,10 @@ __global__ void k_ef_sum_stats(const double* __restrict__ pe, int nE, const doub
         __syncthreads();
     }
     if (threadIdx.x < 4) out[threadIdx.x] = s[threadIdx.x][0];
+    if (done_flag) {   // single workgroup: publish after the four stores (waitflag.hpp)
+        __syncthreads();
+        if (threadIdx.x == 0) { __threadfence_system(); *done_flag = done_seq; }
+    }
 }
 
 static int lin_chunks_for_np(const sdvgn_ef* e) {   // k_ef_linearize: 128 residuals per workgroup
@@ -611,6 +618,10 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     HIPCHK(hipHostMalloc(&e->precalc_host, 2 * sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
     HIPCHK(hipHostMalloc(&e->acc_host, sizeof(double) * accmax));
     HIPCHK(hipHostMalloc(&e->stats_host, sizeof(double) * 4));
+    HIPCHK(hipHostMalloc((void**)&e->flags_host, 64));
+    e->flags_host[0] = e->flags_host[1] = e->flags_host[2] = 0;
+    HIPCHK(hipMalloc((void**)&e->done_ctr, 2 * sizeof(unsigned)));
+    HIPCHK(hipMemset(e->done_ctr, 0, 2 * sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void**)&e->imm_pc_host, sizeof(ImmPrecalc) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
     HIPCHK(hipHostMalloc(&e->x_host, 2 * sizeof(float) * (4 + SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6)));
     HIPCHK(hipEventCreateWithFlags(&e->ev_top, hipEventDisableTiming));
@@ -649,6 +660,8 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
     if (e->precalc_host) hipHostFree(e->precalc_host);
     if (e->acc_host) hipHostFree(e->acc_host);
     if (e->stats_host) hipHostFree(e->stats_host);
+    if (e->flags_host) hipHostFree(e->flags_host);
+    if (e->done_ctr) hipFree(e->done_ctr);
     if (e->imm_pc_host) hipHostFree(e->imm_pc_host);
     if (e->imm_stage) hipHostFree(e->imm_stage);
     if (e->x_host) hipHostFree(e->x_host);
@@ -903,12 +916,12 @@ static int ef_accumulate(sdvgn_ef* e, bool split) {
         // engine in the path -- a small D2H memcpy costs 10-20 us of fixed latency, more than the 154 kB take over PCIe
         k_ef_top_gram<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->top_partial, e->nres_partial);
         k_ef_acc_reduce<<<(ntop + 255) / 256, 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks, e->nres_partial,
-                                                                   e->sc_off_dev, e->acc_host, 0, ntop, 0);
-        HIPCHK(hipEventRecord(e->ev_top, e->stream));
+                                                                   e->sc_off_dev, e->acc_host, 0, ntop, 0, e->done_ctr, e->flags_host, ++e->seq_top);
         k_ef_point<<<(e->nP + 63) / 64, 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev);
         k_ef_sc_gram<<<dim3(sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, sc_ppb);
         k_ef_acc_reduce<<<(nsc + 255) / 256 + 1, 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks, e->nres_partial,
-                                                                      e->sc_off_dev, e->acc_host, ntop, ntop + nsc, 1);
+                                                                      e->sc_off_dev, e->acc_host, ntop, ntop + nsc, 1, e->done_ctr + 1, e->flags_host + 1,
+                                                                      ++e->seq_acc);
         e->split_pending = true;
         e->acc_in_host = true;
     } else {
@@ -917,7 +930,7 @@ static int ef_accumulate(sdvgn_ef* e, bool split) {
         k_ef_top_gram<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->top_partial, e->nres_partial);
         k_ef_sc_gram<<<dim3(sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, sc_ppb);
         k_ef_acc_reduce<<<(ntop + nsc + 255) / 256 + 1, 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks,
-                                                                             e->nres_partial, e->sc_off_dev, e->acc_dev, 0, ntop + nsc, 1);
+                                                                             e->nres_partial, e->sc_off_dev, e->acc_dev, 0, ntop + nsc, 1, nullptr, nullptr, 0);
     }
     HIPCHK(hipGetLastError());
     return SDVGN_OK;
@@ -964,7 +977,7 @@ static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, d
     stitch_top(e, acc);
     g_pt.stop(PT_STITCH_TOP);
     if (e->split_pending) {   // the SC accumulators were still being produced while the top part was stitched
-        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(wait_flag(e->flags_host + 1, e->seq_acc, e->stream));
         e->split_pending = false;
         g_pt.stop(PT_D2H);
     }
@@ -1008,9 +1021,7 @@ int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
     const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
     g_pt.start();
     if (e->split_pending) {
-        hipError_t q;
-        while ((q = hipEventQuery(e->ev_top)) == hipErrorNotReady) {}   // spin: hipEventSynchronize costs ~20 us of wake-up latency
-        if (q != hipSuccess) return -(int)q;
+        HIPCHK(wait_flag(e->flags_host, e->seq_top, e->stream));   // the top accumulators are in acc_host (waitflag.hpp)
     } else {
         HIPCHK(hipMemcpyAsync(e->acc_host, e->acc_dev, sizeof(double) * acc_count(e), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -1098,14 +1109,17 @@ static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* 
     }
     const int nS = (e->nP + 63) / 64;
     // without an all-reduce the four sums go straight into pinned host memory (no copy engine, see ef_accumulate)
+    const bool flagged = e->allreduce == nullptr;
     k_ef_sum_stats<<<1, 256, 0, e->stream>>>(e->energy_partial, chunks * pairs, e->stats_partial, nL, e->stats_partial + (e->nP / 64 + 2), nS,
-                                             e->allreduce ? e->stats_dev : e->stats_host);
+                                             e->allreduce ? e->stats_dev : e->stats_host, flagged ? e->flags_host + 2 : nullptr, flagged ? ++e->seq_stats : 0);
     HIPCHK(hipGetLastError());
     if (e->allreduce) {
         e->allreduce(e->allreduce_user, e->stats_dev, 4);   // ranks hold disjoint host-frame shards
         HIPCHK(hipMemcpyAsync(e->stats_host, e->stats_dev, 4 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    } else {
+        HIPCHK(wait_flag(e->flags_host + 2, e->seq_stats, e->stream));
     }
-    HIPCHK(hipStreamSynchronize(e->stream));
     *energy = e->stats_host[0];
     double En = 0;   // calcLEnergyF_MT: frame + calib priors on the host, point part from the device
     for (const FrameH& f : e->frames) for (int i = 0; i < 6; ++i) En += f.delta_prior[i] * f.prior[i] * f.delta_prior[i];

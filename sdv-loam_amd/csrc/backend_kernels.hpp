@@ -28,6 +28,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "waitflag.hpp"
+
 namespace sdvgn {
 
 constexpr int kMaxFrames = 8;
@@ -793,7 +795,8 @@ __device__ __forceinline__ double sum_chunks_f64(const float* __restrict__ base,
 __global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__ top_partial, int pairs, int top_chunks,
                                                        const float* __restrict__ sc_partial, int nF, int sc_chunks,
                                                        const int* __restrict__ nres_partial, const unsigned short* __restrict__ sc_off,
-                                                       double* __restrict__ out, int e_begin, int e_end, int do_nres) {
+                                                       double* __restrict__ out, int e_begin, int e_end, int do_nres,
+                                                       unsigned* __restrict__ done_ctr, volatile int* done_flag, int done_seq) {
     const int ntop = pairs * 121, nsc = nF * 1431;
     if (do_nres && blockIdx.x == gridDim.x - 1) {   // resInA: integer sum, order-free
         __shared__ int part[4];
@@ -803,17 +806,25 @@ __global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__
         for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
         if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
         __syncthreads();
-        if (threadIdx.x == 0) out[ntop + nsc] = (double)(part[0] + part[1] + part[2] + part[3]);
+        if (threadIdx.x == 0) {
+            out[ntop + nsc] = (double)(part[0] + part[1] + part[2] + part[3]);
+            if (done_flag) publish_when_all_done(done_ctr, gridDim.x, done_flag, done_seq);
+        }
         return;
     }
     const int e = e_begin + blockIdx.x * blockDim.x + threadIdx.x;   // outputs [e_begin, e_end) of the packed buffer
-    if (e >= e_end) return;
-    if (e < ntop) {
-        const int g = e / 121, k = e - g * 121, r = k / 11, c = k - r * 11;
-        out[e] = sum_chunks_f64<256>(top_partial + (size_t)g * top_chunks * 256 + r * 16 + c, top_chunks);
-    } else if (e < ntop + nsc) {
-        const int q = e - ntop, g = q / 1431, k = q - g * 1431;
-        out[e] = sum_chunks_f64<2560>(sc_partial + (size_t)g * sc_chunks * 2560 + sc_off[k], sc_chunks);
+    if (e < e_end) {
+        if (e < ntop) {
+            const int g = e / 121, k = e - g * 121, r = k / 11, c = k - r * 11;
+            out[e] = sum_chunks_f64<256>(top_partial + (size_t)g * top_chunks * 256 + r * 16 + c, top_chunks);
+        } else if (e < ntop + nsc) {
+            const int q = e - ntop, g = q / 1431, k = q - g * 1431;
+            out[e] = sum_chunks_f64<2560>(sc_partial + (size_t)g * sc_chunks * 2560 + sc_off[k], sc_chunks);
+        }
+    }
+    if (done_flag) {   // completion signal for the host (waitflag.hpp): all workgroups of this launch have stored their outputs
+        __syncthreads();
+        if (threadIdx.x == 0) publish_when_all_done(done_ctr, gridDim.x, done_flag, done_seq);
     }
 }
 

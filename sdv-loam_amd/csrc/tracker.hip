@@ -9,6 +9,7 @@
 #include "../../include/sdvgn.h"
 #include "gnmath.hpp"
 #include "tracker_kernels.hpp"
+#include "waitflag.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -68,6 +69,8 @@ struct sdvgn_tracker {
     float* partial_dev = nullptr;
     double* out_dev = nullptr;
     double* out_host = nullptr;          // pinned
+    int* flag_host = nullptr;            // pinned completion flag of the host-driven trial (waitflag.hpp)
+    int flag_seq = 0;
     float* terms_dev = nullptr;
     int* status_dev = nullptr;
     int terms_lvl = -1;
@@ -168,7 +171,8 @@ static int launch_res_gs(sdvgn_tracker* t, int lvl, int B, const double* pose7, 
         k_res_gs<false><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], t->pyr_dev[lvl], params, t->partial_dev,
                                                        nullptr, nullptr);
     }
-    k_finalize<<<B, 128, 0, t->stream>>>(t->partial_dev, chunks, out_dev);
+    if (zero_copy && B == 1) k_finalize<<<B, 128, 0, t->stream>>>(t->partial_dev, chunks, out_dev, t->flag_host, ++t->flag_seq);
+    else k_finalize<<<B, 128, 0, t->stream>>>(t->partial_dev, chunks, out_dev);
     HIPCHK(hipGetLastError());
     return SDVGN_OK;
 }
@@ -178,7 +182,8 @@ static int res_gs_sync(sdvgn_tracker* t, int lvl, const double* pose7, double a,
     const double aff[2] = {a, b};
     int rc = launch_res_gs(t, lvl, 1, pose7, aff, cutoffTH, write_terms, t->out_host, /*zero_copy=*/true);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(t->stream));
+    HIPCHK(wait_flag(t->flag_host, t->flag_seq, t->stream));
+    if (write_terms) HIPCHK(hipStreamSynchronize(t->stream));   // the per-point parity planes are read back by a later call
     if (out6) std::memcpy(out6, t->out_host, 6 * sizeof(double));
     if (H) std::memcpy(H, t->out_host + 6, 64 * sizeof(double));
     if (bv) std::memcpy(bv, t->out_host + 70, 8 * sizeof(double));
@@ -294,6 +299,8 @@ int sdvgn_tracker_create(sdvgn_tracker** out, int device, int w0, int h0, int le
     HIPCHK(hipMalloc(&t->partial_dev, sizeof(float) * kNRed * (size_t)t->max_chunks * max_batch));
     HIPCHK(hipMalloc(&t->out_dev, sizeof(double) * kOutStride * max_batch));
     HIPCHK(hipHostMalloc(&t->out_host, sizeof(double) * kOutStride * max_batch));
+    HIPCHK(hipHostMalloc((void**)&t->flag_host, 64));
+    *t->flag_host = 0;
     HIPCHK(hipMalloc(&t->terms_dev, sizeof(float) * 8 * (size_t)max_points));
     HIPCHK(hipMalloc(&t->status_dev, sizeof(int) * (size_t)max_points));
     HIPCHK(hipHostMalloc(&t->track_host, sizeof(TrackState) * max_batch));
@@ -308,7 +315,7 @@ void sdvgn_tracker_destroy(sdvgn_tracker* t) {
     hipStreamSynchronize(t->stream);
     for (int l = 0; l < t->levels; ++l) { hipFree(t->pc_dev[l]); hipFree(t->pyr_dev[l]); if (t->pyr_half_dev[l]) hipFree(t->pyr_half_dev[l]); }
     hipFree(t->img_stage_dev); hipFree(t->params_dev); hipHostFree(t->params_host); hipFree(t->partial_dev);
-    hipFree(t->out_dev); hipHostFree(t->out_host); hipFree(t->terms_dev); hipFree(t->status_dev);
+    hipFree(t->out_dev); hipHostFree(t->out_host); hipHostFree(t->flag_host); hipFree(t->terms_dev); hipFree(t->status_dev);
     hipHostFree(t->track_host);
     hipHostFree(t->sp_stage_host); hipHostFree(t->sp_io_host);
     hipFree(t->tp_static_dev); hipHostFree(t->tp_state_host);

@@ -316,7 +316,8 @@ __device__ __forceinline__ void finalize_outputs(const double* S, int tid, doubl
 
 // Deterministic fp64 combine of the partial rows + the tail of calcGSSSE (:468-483) and calcRes (:625-633).
 // grid = B, block = 128.  out: [B][kOutStride] doubles.
-static __global__ void __launch_bounds__(128) k_finalize(const float* __restrict__ partial, int chunks, double* __restrict__ out) {
+static __global__ void __launch_bounds__(128) k_finalize(const float* __restrict__ partial, int chunks, double* __restrict__ out,
+                                                         volatile int* done_flag = nullptr, int done_seq = 0) {
     __shared__ double S[kNRed];
     const int b = blockIdx.x;
     if (threadIdx.x < kNRed) {
@@ -327,6 +328,10 @@ static __global__ void __launch_bounds__(128) k_finalize(const float* __restrict
     }
     __syncthreads();
     finalize_outputs(S, threadIdx.x, out + (size_t)b * kOutStride);
+    if (done_flag) {   // single-hypothesis host-driven trial: publish completion to the spinning host (waitflag.hpp)
+        __syncthreads();
+        if (threadIdx.x == 0) { __threadfence_system(); *done_flag = done_seq; }
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------
