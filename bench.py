@@ -45,12 +45,20 @@ def dist_setup():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # SDVGN_BENCH_SHARE_GPU=1 (test rigs only): all ranks use cuda:0 and talk through gloo -- lets the N > 1 code path of this file
+    # run on a one-GPU box (two ranks cannot form an RCCL clique on one device).  The driver's runs use nccl = RCCL.
+    share = os.environ.get("SDVGN_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     return rank, local, world
 
 
@@ -67,7 +75,7 @@ def max_over_ranks(x, world):
     if world == 1:
         return x
     import torch.distributed as dist
-    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
