@@ -9,6 +9,9 @@
 //           independent of the number of points ("tiny; keep on host").
 #include "../../include/sdvgn.h"
 #include "backend_kernels.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: the library is resolved at run time (dlopen), so libsdvgn has no link-time RCCL dependency
 #include "gnmath.hpp"
 #include "tracker_kernels.hpp"
 
@@ -115,6 +118,7 @@ struct sdvgn_ef {
     float* x_host = nullptr;      // pinned, 2 slots used alternately: xc(4) + xAd(nF*nF*6)
     int x_slot = 0;
     hipEvent_t ev_top = nullptr;  // (unused by the flag path; kept for the event fallback)
+    ncclComm_t rccl_comm = nullptr;   // cfg4 with the collectives issued by the library itself (sdvgn_ef_init_rccl)
     int* flags_host = nullptr;    // pinned: [0] top accumulators done, [1] all accumulators done, [2] linearize statistics done
     unsigned* done_ctr = nullptr; // device: workgroup counters for the multi-workgroup publishers (2)
     int seq_top = 0, seq_acc = 0, seq_stats = 0;
@@ -557,6 +561,15 @@ __global__ void k_ef_sum_stats(const double* __restrict__ pe, int nE, const doub
     }
 }
 
+// device buffer -> pinned host buffer + completion flag (waitflag.hpp): the read-back after an all-reduce without the copy engine
+__global__ void __launch_bounds__(256) k_ef_copy_publish(const double* __restrict__ src, double* __restrict__ dst, int n, unsigned* __restrict__ ctr,
+                                                         volatile int* flag, int seq) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) publish_when_all_done(ctr, gridDim.x, flag, seq);
+}
+
 static int lin_chunks_for_np(const sdvgn_ef* e) {   // k_ef_linearize: 128 residuals per workgroup
     int mx = 1;
     for (int h = 0; h < e->nF; ++h) mx = std::max(mx, e->hostP0[h + 1] - e->hostP0[h]);
@@ -566,6 +579,42 @@ static int chunks_for_np(const sdvgn_ef* e) {
     int mx = 1;
     for (int h = 0; h < e->nF; ++h) mx = std::max(mx, e->hostP0[h + 1] - e->hostP0[h]);
     return std::min(kMaxChunks, (mx + 255) / 256);
+}
+
+// ---- RCCL, resolved at run time ---------------------------------------------------------------------------------
+// PyTorch-ROCm ships its own librccl.so; when it is already in the process (torch.distributed "nccl") the SAME instance must be
+// used, so RTLD_NOLOAD is tried first, then the normal search path (/opt/rocm/lib).
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    bool ok = false;
+};
+static RcclApi& rccl_api() {
+    static RcclApi api;
+    if (api.lib || api.ok) return api;
+    const char* names[] = {"librccl.so", "librccl.so.1"};
+    for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!api.lib) return api;
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+    api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+    api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy;
+    return api;
+}
+static inline bool ef_sharded(const sdvgn_ef* e) { return e->allreduce != nullptr || e->rccl_comm != nullptr; }
+// sum `count` doubles at buf_dev over all ranks, ordered on the library stream
+static int ef_allreduce(sdvgn_ef* e, double* buf_dev, int count) {
+    if (e->rccl_comm) {
+        const ncclResult_t r = rccl_api().AllReduce(buf_dev, buf_dev, (size_t)count, ncclDouble, ncclSum, e->rccl_comm, e->stream);
+        return r == ncclSuccess ? SDVGN_OK : SDVGN_E_STATE;
+    }
+    if (e->allreduce) e->allreduce(e->allreduce_user, buf_dev, count);
+    return SDVGN_OK;
 }
 
 extern "C" {
@@ -651,6 +700,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
     if (!e->own_stats) e->stats_dev = nullptr;
     hipSetDevice(e->device);
     hipStreamSynchronize(e->stream);
+    if (e->rccl_comm) { rccl_api().CommDestroy(e->rccl_comm); e->rccl_comm = nullptr; }
     void* ptrs[] = {e->pu, e->pv, e->pidz, e->pid, e->pidepth_backup, e->ppriorF, e->pdeltaF, e->pcolor, e->pweights, e->psensor, e->rflags,
                     e->rstate, e->rstate_new, e->rmatcher, e->renergy, e->renergy_new, e->renergy_wo, e->rres_toZero, e->J, e->JpJd, e->pHddA,
                     e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->images, e->img_stage,
@@ -961,6 +1011,30 @@ int sdvgn_ef_set_allreduce(sdvgn_ef* e, void (*fn)(void*, double*, int), void* u
     return SDVGN_OK;
 }
 
+int sdvgn_rccl_unique_id(unsigned char* out128) {
+    if (!out128) return SDVGN_E_ARG;
+    RcclApi& api = rccl_api();
+    if (!api.ok) return SDVGN_E_STATE;
+    ncclUniqueId id;
+    if (api.GetUniqueId(&id) != ncclSuccess) return SDVGN_E_STATE;
+    std::memcpy(out128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_init_rccl(sdvgn_ef* e, const unsigned char* id128, int rank, int world) {
+    if (!e || e->host_only || !id128 || world < 1 || rank < 0 || rank >= world) return SDVGN_E_ARG;
+    RcclApi& api = rccl_api();
+    if (!api.ok) return SDVGN_E_STATE;
+    EF_DEVICE(e);
+    if (e->rccl_comm) { api.CommDestroy(e->rccl_comm); e->rccl_comm = nullptr; }
+    ncclUniqueId id;
+    std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    if (api.CommInitRank(&comm, world, id, rank) != ncclSuccess) return SDVGN_E_STATE;   // collective: every rank calls it
+    e->rccl_comm = comm;
+    return SDVGN_OK;
+}
+
 int sdvgn_ef_accumulator_count(sdvgn_ef* e) { return e ? (int)acc_count(e) : SDVGN_E_ARG; }
 
 int sdvgn_ef_accumulators_dev(sdvgn_ef* e, double** buf, int* count) {
@@ -1023,8 +1097,11 @@ int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
     if (e->split_pending) {
         HIPCHK(wait_flag(e->flags_host, e->seq_top, e->stream));   // the top accumulators are in acc_host (waitflag.hpp)
     } else {
-        HIPCHK(hipMemcpyAsync(e->acc_host, e->acc_dev, sizeof(double) * acc_count(e), hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
+        const int na = (int)acc_count(e);   // sharded / generic path: the (all-reduced) device buffer comes back through a copy kernel
+        k_ef_copy_publish<<<(na + 255) / 256, 256, 0, e->stream>>>(e->acc_dev, e->acc_host, na, e->done_ctr + 1, e->flags_host + 1, ++e->seq_acc);
+        HIPCHK(hipGetLastError());
+        HIPCHK(wait_flag(e->flags_host + 1, e->seq_acc, e->stream));
+        e->acc_in_host = false;
     }
     g_pt.stop(PT_D2H);
     int rc = ef_stitch_solve_host(e, e->acc_host, iteration, lambda, x_out);
@@ -1062,10 +1139,10 @@ int sdvgn_ef_solve_system(sdvgn_ef* e, int iteration, double lambda, double* x_o
     if (!e || e->host_only || !e->havePrecalc) return SDVGN_E_STATE;
     EF_DEVICE(e);
     g_pt.start();
-    int rc = ef_accumulate(e, /*split=*/e->allreduce == nullptr);
+    int rc = ef_accumulate(e, /*split=*/!ef_sharded(e));
     g_pt.stop(PT_ACCUM);
     if (rc) return rc;
-    if (e->allreduce) e->allreduce(e->allreduce_user, e->acc_dev, (int)acc_count(e));   // cfg4: one all-reduce per GN iteration
+    if (ef_sharded(e) && (rc = ef_allreduce(e, e->acc_dev, (int)acc_count(e)))) return rc;   // cfg4: one all-reduce per GN iteration
     return sdvgn_ef_finish_solve(e, iteration, lambda, x_out);
 }
 
@@ -1109,14 +1186,15 @@ static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* 
     }
     const int nS = (e->nP + 63) / 64;
     // without an all-reduce the four sums go straight into pinned host memory (no copy engine, see ef_accumulate)
-    const bool flagged = e->allreduce == nullptr;
+    const bool flagged = !ef_sharded(e);
     k_ef_sum_stats<<<1, 256, 0, e->stream>>>(e->energy_partial, chunks * pairs, e->stats_partial, nL, e->stats_partial + (e->nP / 64 + 2), nS,
-                                             e->allreduce ? e->stats_dev : e->stats_host, flagged ? e->flags_host + 2 : nullptr, flagged ? ++e->seq_stats : 0);
+                                             flagged ? e->stats_host : e->stats_dev, flagged ? e->flags_host + 2 : nullptr, flagged ? ++e->seq_stats : 0);
     HIPCHK(hipGetLastError());
-    if (e->allreduce) {
-        e->allreduce(e->allreduce_user, e->stats_dev, 4);   // ranks hold disjoint host-frame shards
-        HIPCHK(hipMemcpyAsync(e->stats_host, e->stats_dev, 4 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
+    if (!flagged) {
+        { const int rca = ef_allreduce(e, e->stats_dev, 4); if (rca) return rca; }   // ranks hold disjoint host-frame shards
+        k_ef_copy_publish<<<1, 256, 0, e->stream>>>(e->stats_dev, e->stats_host, 4, e->done_ctr, e->flags_host + 2, ++e->seq_stats);
+        HIPCHK(hipGetLastError());
+        HIPCHK(wait_flag(e->flags_host + 2, e->seq_stats, e->stream));
     } else {
         HIPCHK(wait_flag(e->flags_host + 2, e->seq_stats, e->stream));
     }

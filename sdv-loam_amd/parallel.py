@@ -17,6 +17,11 @@ SC_E = SC_N * (SC_N + 1) // 2   # its upper triangle, row-major (1431)
 MAX_FRAMES = 8
 
 
+def direct_rccl_disabled():
+    import os
+    return os.environ.get("SDVGN_NO_DIRECT_RCCL") == "1"
+
+
 def shard_hosts(nF, world):
     """Contiguous host-frame ranges, as even as possible: rank r owns [lo[r], hi[r])."""
     base, extra = divmod(nF, world)
@@ -89,7 +94,23 @@ class ShardedEnergyFunctional:
         self.ef.load(W)
         self._cb = None
         self.n_allreduce = 0
-        if world > 1 or force_collective:
+        self.direct_rccl = False
+        if (world > 1 or force_collective) and dist.get_backend(self.group) == "nccl" and not direct_rccl_disabled():
+            # preferred: the library issues ncclAllReduce itself on its stream (no callback / Python in the iteration).  Rank 0's id
+            # travels through the existing process group; any failure falls back to the callback path below.
+            try:
+                ident = [None]
+                if rank == 0:
+                    buf = (C.c_ubyte * 128)()
+                    self.ef._check(L.sdvgn_rccl_unique_id(buf))
+                    ident = [bytes(buf)]
+                dist.broadcast_object_list(ident, src=0, group=self.group)
+                idbuf = (C.c_ubyte * 128).from_buffer_copy(ident[0])
+                self.ef._check(L.sdvgn_ef_init_rccl(self.ef.h_, idbuf, rank, world))
+                self.direct_rccl = True
+            except Exception:  # noqa: BLE001
+                self.direct_rccl = False
+        if (world > 1 or force_collective) and not self.direct_rccl:
             acc_ptr, stats_ptr = self.acc.data_ptr(), self.stats.data_ptr()
 
             via_host = dist.get_backend(self.group) == "gloo"   # test rigs without RCCL peers (e.g. two ranks sharing one GPU)

@@ -192,21 +192,29 @@ def test_kept_state_equals_relinearize_on_reject(api, orc, seed):
     assert np.array_equal(xa, xb)
 
 
-def test_sharded_path_single_rank_nccl(api, orc, window):
-    """cfg4 plumbing on one GPU: external torch buffers, torch stream, and the all-reduce callback going through a
-    1-rank RCCL process group -- must give exactly the single-GPU result."""
+@pytest.mark.parametrize("direct", [True, False])
+def test_sharded_path_single_rank_nccl(api, orc, window, direct, monkeypatch):
+    """cfg4 plumbing on one GPU: external torch buffers, torch stream, and the collectives of a 1-rank RCCL group -- issued either by
+    the library itself (ncclAllReduce resolved from the librccl.so torch loaded; direct=True) or through the torch.distributed
+    callback (direct=False) -- must give exactly the single-GPU result."""
     import torch
     import torch.distributed as dist
     from sdv_loam_amd.parallel import ShardedEnergyFunctional
+    if not direct:
+        monkeypatch.setenv("SDVGN_NO_DIRECT_RCCL", "1")
     if not dist.is_initialized():
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29733", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29733 + int(direct)), rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
     try:
         S = ShardedEnergyFunctional(window, 0, 1, 0, force_collective=True)
+        assert S.direct_rccl == direct
         ts = S.optimize(6, want_trace=True)
-        assert S.n_allreduce >= 2 * len(ts)
+        if not direct:
+            assert S.n_allreduce >= 2 * len(ts)
         G = api.EnergyFunctional(window.w, window.h, max_points=window.nP).load(window)
         tg = G.optimize(6)
         assert np.array_equal(ts, tg)
         assert np.array_equal(S.ef.state()[2], G.state()[2])
+        del S
     finally:
         dist.destroy_process_group()
