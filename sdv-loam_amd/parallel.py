@@ -98,18 +98,19 @@ class ShardedEnergyFunctional:
         if (world > 1 or force_collective) and dist.get_backend(self.group) == "nccl" and not direct_rccl_disabled():
             # preferred: the library issues ncclAllReduce itself on its stream (no callback / Python in the iteration).  Rank 0's id
             # travels through the existing process group; any failure falls back to the callback path below.
-            try:
-                ident = [None]
-                if rank == 0:
-                    buf = (C.c_ubyte * 128)()
-                    self.ef._check(L.sdvgn_rccl_unique_id(buf))
+            ident = [None]
+            if rank == 0:
+                buf = (C.c_ubyte * 128)()
+                if L.sdvgn_rccl_unique_id(buf) == 0:
                     ident = [bytes(buf)]
-                dist.broadcast_object_list(ident, src=0, group=self.group)
+            dist.broadcast_object_list(ident, src=0, group=self.group)      # always executed by every rank (None = no RCCL: all fall back)
+            if ident[0] is not None:
                 idbuf = (C.c_ubyte * 128).from_buffer_copy(ident[0])
-                self.ef._check(L.sdvgn_ef_init_rccl(self.ef.h_, idbuf, rank, world))
-                self.direct_rccl = True
-            except Exception:  # noqa: BLE001
-                self.direct_rccl = False
+                self.direct_rccl = L.sdvgn_ef_init_rccl(self.ef.h_, idbuf, rank, world) == 0   # collective (ncclCommInitRank)
+                if world > 1:   # agree on the outcome: one failing rank sends everybody to the callback path
+                    okt = torch.tensor([1 if self.direct_rccl else 0], device="cuda")
+                    dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=self.group)
+                    self.direct_rccl = bool(okt.item())
         if (world > 1 or force_collective) and not self.direct_rccl:
             acc_ptr, stats_ptr = self.acc.data_ptr(), self.stats.data_ptr()
 
