@@ -328,7 +328,8 @@ int sdvgn_ef_set_allreduce(sdvgn_ef* ef, void (*fn)(void* user, double* buf_dev,
 /* The same collectives issued by the library itself through RCCL (ncclAllReduce on the handle's stream, in place, ncclDouble /
  * ncclSum) -- no callback, no Python in the iteration.  librccl.so is resolved at run time (the instance already loaded by
  * torch.distributed when there is one).  Rank 0 obtains a 128-byte id with sdvgn_rccl_unique_id and distributes it by any means;
- * every rank then calls sdvgn_ef_init_rccl (collective, like ncclCommInitRank).  Takes precedence over set_allreduce. */
+ * every rank then calls sdvgn_ef_init_rccl (collective, like ncclCommInitRank).  Takes precedence over set_allreduce;
+ * id128 == NULL drops the communicator again. */
 int sdvgn_rccl_unique_id(unsigned char* out128);
 int sdvgn_ef_init_rccl(sdvgn_ef* ef, const unsigned char* id128, int rank, int world);
 /* restrict this rank's work to host frames [h0,h1) (cfg4: frames sharded across GPUs); default all. */

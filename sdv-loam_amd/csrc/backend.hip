@@ -1022,7 +1022,12 @@ int sdvgn_rccl_unique_id(unsigned char* out128) {
 }
 
 int sdvgn_ef_init_rccl(sdvgn_ef* e, const unsigned char* id128, int rank, int world) {
-    if (!e || e->host_only || !id128 || world < 1 || rank < 0 || rank >= world) return SDVGN_E_ARG;
+    if (e && !e->host_only && !id128) {   // id128 == NULL: drop the communicator, back to the callback / single-GPU behaviour
+        EF_DEVICE(e);
+        if (e->rccl_comm) { hipStreamSynchronize(e->stream); rccl_api().CommDestroy(e->rccl_comm); e->rccl_comm = nullptr; }
+        return SDVGN_OK;
+    }
+    if (!e || e->host_only || world < 1 || rank < 0 || rank >= world) return SDVGN_E_ARG;
     RcclApi& api = rccl_api();
     if (!api.ok) return SDVGN_E_STATE;
     EF_DEVICE(e);

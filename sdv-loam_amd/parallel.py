@@ -111,6 +111,8 @@ class ShardedEnergyFunctional:
                     okt = torch.tensor([1 if self.direct_rccl else 0], device="cuda")
                     dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=self.group)
                     self.direct_rccl = bool(okt.item())
+                if not self.direct_rccl:
+                    L.sdvgn_ef_init_rccl(self.ef.h_, None, 0, 0)          # drop a communicator this rank may have got
         if (world > 1 or force_collective) and not self.direct_rccl:
             acc_ptr, stats_ptr = self.acc.data_ptr(), self.stats.data_ptr()
 
