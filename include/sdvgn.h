@@ -134,6 +134,10 @@ int sdvgn_tracker_get_trace(sdvgn_tracker* t, double* rows, int cap);
 int sdvgn_tracker_res_and_gs_batch(sdvgn_tracker* t, int lvl, int B, const double* pose7, const double* aff,
                                    float cutoffTH, double* out_dev);
 void* sdvgn_tracker_stream(sdvgn_tracker* t);
+/* Device pointer of level `lvl` of the current new-frame pyramid (dIp[lvl], AoS {I,dx,dy}, (w0>>lvl)*(h0>>lvl)*3 floats), NULL if none
+ * was set.  For handing the image to the other handles without a copy: sdvgn_reproj_set_cur_level(.., dIp_aos3_dev),
+ * sdvgn_tracker_make_coarse_depth(.., ref_pyr_dev).  Valid until the next set_new_image / set_new_pyr / destroy of this handle. */
+const float* sdvgn_tracker_pyr_dev(sdvgn_tracker* t, int lvl);
 
 /* CoarseTracker::structPoseEstimation(SE3& curToWorld, overlap_pts)   CoarseTracker.cpp:949-1004, called right after
  * trackNewestCoarse on every frame (FullSystem.cpp:483-489); with calculateRes (:840-872), calculateWeight (:874-889),
@@ -285,6 +289,9 @@ int sdvgn_ef_optimize(sdvgn_ef* ef, int mnumOptIts, int flags /* bit0: run exact
                       double* trace, int trace_stride, int trace_cap);
 /* state after optimize: CalibHessian::value_scaled, FrameHessian::state (nF x 10), PointHessian::idepth (nP) */
 int sdvgn_ef_get_state(sdvgn_ef* ef, double* value_scaled4, double* state10, float* idepth);
+/* Device pointer of key-frame idx's level-0 image (dI, AoS {I,dx,dy}) held by the window, for sdvgn_reproj_set_frame(.., dI_aos3_dev);
+ * NULL if idx is out of range or the handle is host-only.  Valid until that frame's image is replaced or the handle is destroyed. */
+const float* sdvgn_ef_frame_image_dev(sdvgn_ef* ef, int idx);
 
 /* FullSystem::optimizeImmaturePoint(ImmaturePoint*, int minObs, ImmaturePointTemporaryResidual*)   FullSystemOptPoint.cpp:18-185,
  * with ImmaturePoint::linearizeResidual (ImmaturePoint.cpp:410-477), for n immature points in one launch (the loop of

@@ -44,6 +44,7 @@ PROTOTYPES = [
     ("sdvgn_tracker_get_trace", C.c_int, [vp, vp, C.c_int]),
     ("sdvgn_tracker_res_and_gs_batch", C.c_int, [vp, C.c_int, C.c_int, f64p, f64p, C.c_float, vp]),
     ("sdvgn_tracker_stream", vp, [vp]),
+    ("sdvgn_tracker_pyr_dev", vp, [vp, C.c_int]),
     ("sdvgn_tracker_struct_pose", C.c_int, [vp, C.c_int, f32p, f32p, f32p, i32p, C.c_int, f64p, f64p, f64p, vp, vp]),
     ("sdvgn_tracker_struct_res_hb", C.c_int, [vp, C.c_int, f32p, f32p, f32p, i32p, C.c_int, f64p, f64p, f64p, f64p, f64p, vp, vp]),
     ("sdvgn_struct_trace_stride", C.c_int, []),
@@ -251,6 +252,13 @@ class CoarseTracker:
 
     def stream(self):
         return self.L.sdvgn_tracker_stream(self.h_)
+
+    def pyr_dev(self, lvl):
+        """Device pointer (ctypes c_void_p) of level `lvl` of the current new-frame pyramid, for zero-copy hand-over."""
+        p = self.L.sdvgn_tracker_pyr_dev(self.h_, lvl)
+        if not p:
+            raise RuntimeError("no new-frame pyramid on this tracker (level %d)" % lvl)
+        return vp(p)
 
     # -- structPoseEstimation (CoarseTracker.cpp:840-1007) ----------------------------------------------
     @staticmethod

@@ -34,6 +34,7 @@ PROTOTYPES = [
     ("sdvgn_ef_get_residual_state", C.c_int, [vp, vp, vp, vp, vp, vp]),
     ("sdvgn_ef_get_points", C.c_int, [vp, f32p]),
     ("sdvgn_ef_get_top_acc", C.c_int, [vp, f64p, vp]),
+    ("sdvgn_ef_frame_image_dev", vp, [vp, C.c_int]),
     ("sdvgn_rccl_unique_id", C.c_int, [vp]),
     ("sdvgn_ef_init_rccl", C.c_int, [vp, vp, C.c_int, C.c_int]),
     ("sdvgn_ef_optimize_immature", C.c_int, [vp, C.c_int, i32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, u8p, C.c_int, i32p, f32p, i32p]),
@@ -191,6 +192,13 @@ class EnergyFunctional:
         self._check(self.L.sdvgn_ef_optimize_immature(self.h_, n, host, f(u), f(v), f(idepth_min), f(idepth_max), f(energyTH), f(color), f(weights),
                                                       np.ascontiguousarray(isFromSensor, np.uint8), minObs, result, idepth, rs.reshape(-1)))
         return result, idepth, rs
+
+    def frame_image_dev(self, idx):
+        """Device pointer (ctypes c_void_p) of key-frame idx's level-0 {I,dx,dy} image held by the window."""
+        p = self.L.sdvgn_ef_frame_image_dev(self.h_, idx)
+        if not p:
+            raise RuntimeError("no device image for frame %d" % idx)
+        return vp(p)
 
     def top_acc(self):
         out = np.zeros((self.nF * self.nF, 11, 11))

@@ -721,6 +721,11 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
 }
 
 void* sdvgn_ef_stream(sdvgn_ef* e) { return e ? (void*)e->stream : nullptr; }
+const float* sdvgn_ef_frame_image_dev(sdvgn_ef* e, int idx) {
+    if (!e || e->host_only || idx < 0 || idx >= e->nF || !e->images) return nullptr;
+    if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) return nullptr;   // uploads / pyramid kernels done
+    return e->images + (size_t)idx * e->C.w * e->C.h * 3;
+}
 
 int sdvgn_ef_set_calib(sdvgn_ef* e, const double vs[4], const double vmz[4]) {
     if (!e || !vs || !vmz) return SDVGN_E_ARG;

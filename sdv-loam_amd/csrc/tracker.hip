@@ -325,6 +325,12 @@ void sdvgn_tracker_destroy(sdvgn_tracker* t) {
 }
 
 void* sdvgn_tracker_stream(sdvgn_tracker* t) { return t ? (void*)t->stream : nullptr; }
+const float* sdvgn_tracker_pyr_dev(sdvgn_tracker* t, int lvl) {
+    if (!t || lvl < 0 || lvl >= t->levels || !t->haveNew) return nullptr;
+    // the consumer runs on another handle's stream: make sure the pyramid kernels of this handle have finished
+    if (hipSetDevice(t->device) != hipSuccess || hipStreamSynchronize(t->stream) != hipSuccess) return nullptr;
+    return t->pyr_dev[lvl];
+}
 
 int sdvgn_tracker_set_settings(sdvgn_tracker* t, float huberTH, float coarseCutoffTH, float affA, float affB) {
     if (!t) return SDVGN_E_ARG;
