@@ -482,6 +482,10 @@ int sdvgn_reproj_match(sdvgn_reproj* r, int n, const float* u, const float* v, c
         nframes = std::max(nframes, std::max(host_idx[i], ref_idx[i]) + 1);
     }
     HIPCHK(hipSetDevice(r->device));
+    {   // hipGetLastError() below must report THIS launch: drop an error some earlier, unrelated runtime call left behind
+        const hipError_t stale = hipGetLastError();
+        if (stale != hipSuccess && getenv("SDVGN_PROFILE")) fprintf(stderr, "[sdvgn] stale HIP error %d (%s) cleared in sdvgn_reproj_match\n", (int)stale, hipGetErrorString(stale));
+    }
     RpConst& C = *r->C_host;
     C.levels = r->levels; C.nframes = nframes;
     for (int l = 0; l < r->levels; ++l) { C.w[l] = r->w[l]; C.h[l] = r->h[l]; }

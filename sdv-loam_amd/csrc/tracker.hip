@@ -313,14 +313,21 @@ void sdvgn_tracker_destroy(sdvgn_tracker* t) {
     if (!t) return;
     hipSetDevice(t->device);
     hipStreamSynchronize(t->stream);
-    for (int l = 0; l < t->levels; ++l) { hipFree(t->pc_dev[l]); hipFree(t->pyr_dev[l]); if (t->pyr_half_dev[l]) hipFree(t->pyr_half_dev[l]); }
-    hipFree(t->img_stage_dev); hipFree(t->params_dev); hipHostFree(t->params_host); hipFree(t->partial_dev);
-    hipFree(t->out_dev); hipHostFree(t->out_host); hipHostFree(t->flag_host); hipFree(t->terms_dev); hipFree(t->status_dev);
-    hipHostFree(t->track_host);
-    hipHostFree(t->sp_stage_host); hipHostFree(t->sp_io_host);
-    hipFree(t->tp_static_dev); hipHostFree(t->tp_state_host);
-    hipFree(t->cd_maps); hipFree(t->cd_rows); hipHostFree(t->cd_n_host); hipHostFree(t->cd_stage);
-    if (t->own_stream) hipStreamDestroy(t->stream);
+    const bool dbg = getenv("SDVGN_PROFILE") != nullptr;
+    auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && dbg) fprintf(stderr, "[sdvgn] tracker destroy: %s -> %d (%s)\n", what, (int)e, hipGetErrorString(e)); };
+#define DFREE(p) chk(hipFree(p), "hipFree(" #p ")")
+#define HFREE(p) chk(hipHostFree(p), "hipHostFree(" #p ")")
+    for (int l = 0; l < t->levels; ++l) { DFREE(t->pc_dev[l]); DFREE(t->pyr_dev[l]); if (t->pyr_half_dev[l]) DFREE(t->pyr_half_dev[l]); }
+    DFREE(t->img_stage_dev); DFREE(t->params_dev); HFREE(t->params_host); DFREE(t->partial_dev);
+    DFREE(t->out_dev); HFREE(t->out_host); HFREE(t->flag_host); DFREE(t->terms_dev); DFREE(t->status_dev);
+    HFREE(t->track_host);
+    HFREE(t->sp_stage_host); HFREE(t->sp_io_host);
+    DFREE(t->tp_static_dev); HFREE(t->tp_state_host);
+    DFREE(t->cd_maps); DFREE(t->cd_rows); HFREE(t->cd_n_host); HFREE(t->cd_stage);
+#undef DFREE
+#undef HFREE
+    if (t->own_stream) chk(hipStreamDestroy(t->stream), "hipStreamDestroy");
+    (void)hipGetLastError();   // a failed free must not surface as the "last error" of some later, unrelated launch
     delete t;
 }
 
@@ -631,7 +638,6 @@ int sdvgn_tracker_trace_set_points(sdvgn_tracker* t, int n, const float* u, cons
     if ((int)np > t->tp_cap) {
         HIPCHK(hipStreamSynchronize(t->stream));
         hipFree(t->tp_static_dev); hipHostFree(t->tp_state_host);
-    hipFree(t->cd_maps); hipFree(t->cd_rows); hipHostFree(t->cd_n_host); hipHostFree(t->cd_stage);
         t->tp_static_dev = nullptr; t->tp_state_host = nullptr; t->tp_cap = 0;
         const size_t cap = np + np / 2 + 1024;
         HIPCHK(hipMalloc((void**)&t->tp_static_dev, sizeof(float) * 24 * cap));

@@ -118,3 +118,25 @@ def test_errors(orc):
     bad[0][0] = 160
     with pytest.raises(RuntimeError):
         G.makeCoarseDepth(*bad)
+
+
+def test_template_survives_other_lazy_buffers(orc):
+    """Regression: growing the immature-point buffers (trace_set_points) once freed the coarse-depth maps of the same handle; the
+    template must be rebuildable -- and identical -- after the other lazily allocated features of the tracker were used."""
+    from sdv_loam_amd import synthetic as syn
+    w, h, L = 320, 200, 3
+    G, O, _ = _pair(orc, w, h, L, 12, dict(fx=250., fy=252., cx=159.5, cy=99.5))
+    t = _tuples(w, h, 900, 12)
+    G.makeCoarseDepth(*t)
+    O.makeCoarseDepth(*t)
+    W = syn.make_window(w=w, h=h, nF=3, pts_per_kf=200, seed=12, calib=dict(fx=250., fy=252., cx=159.5, cy=99.5))
+    TP = syn.make_trace_problem(W, seed=12)
+    for grow in (1, 3):                                    # second round re-allocates the trace buffers
+        rep = lambda a: np.concatenate([a] * grow)         # noqa: E731
+        G.traceSetPoints(rep(TP.u), rep(TP.v), rep(TP.energyTH), rep(TP.gradH), rep(TP.color), rep(TP.weights), rep(TP.host_idx))
+        G.tracePoints(TP.KRKi, TP.Kt, TP.aff, rep(TP.idepth_min), rep(TP.idepth_max), rep(TP.quality), rep(TP.status))
+        G.makeCoarseDepth(*t)
+        for l in range(L):
+            g, o = G.get_ref(l), O.get_ref(l)
+            for k in ("u", "v", "idepth", "color"):
+                assert np.array_equal(g[k], o[k]), (grow, l, k)
