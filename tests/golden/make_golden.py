@@ -117,12 +117,48 @@ def trace_golden():
                         **{"s1_" + k: v for k, v in st.items()}, **{"s2_" + k: v for k, v in st2.items()})
 
 
+def coarse_depth_golden():
+    w, h, L = 96, 64, 3
+    img = syn.make_image(w, h, seed=17)
+    rng = np.random.default_rng(17)
+    n = 220
+    u = rng.integers(0, w, n).astype(np.int32); v = rng.integers(0, h, n).astype(np.int32)
+    u[:40] = u[40:80]; v[:40] = v[40:80]; u[80:100] = u[:20]; v[80:100] = v[:20]          # double and triple hits
+    idp = rng.uniform(0.02, 0.5, n).astype(np.float32)
+    wt = np.sqrt(1e-3 / (rng.uniform(1e-6, 1e-2, n) + 1e-12)).astype(np.float32)
+    O = oracle.OracleTracker(w, h, L)
+    O.makeK(60., 60., w / 2 - 0.5, h / 2 - 0.5)
+    O.set_new_image(img, 1.0)
+    O.makeCoarseDepth(u, v, idp, wt)
+    out = dict(w=w, h=h, levels=L, I=img, u=u, v=v, idepth=idp, weight=wt)
+    for l in range(L):
+        r = O.get_ref(l)
+        for k in r:
+            out["pc%d_%s" % (l, k)] = r[k]
+    np.savez_compressed(os.path.join(HERE, "coarse_depth_small.npz"), **out)
+
+
+def immature_golden():
+    W = syn.make_window(w=200, h=96, nF=3, pts_per_kf=60, seed=4, calib=dict(fx=150., fy=152., cx=99.5, cy=47.5))
+    E = OracleEF(W.w, W.h).load(W)
+    rng = np.random.default_rng(19)
+    lo = rng.uniform(0.02, 0.3, W.nP).astype(np.float32); hi = rng.uniform(0.02, 0.3, W.nP).astype(np.float32)
+    imin, imax = (W.idepth * (1 - lo)).astype(np.float32), (W.idepth * (1 + hi)).astype(np.float32)
+    imin[:10] *= 3; imax[:10] *= 3
+    eth = np.full(W.nP, 8 * 144, np.float32); eth[10:15] = np.nan
+    res, idp, rs = E.optimizeImmature(W.host, W.u, W.v, imin, imax, eth, W.color, W.weights, W.isFromSensor, 2)
+    np.savez_compressed(os.path.join(HERE, "immature_small.npz"), idepth_min=imin, idepth_max=imax, energyTH=eth, minObs=2, result=res,
+                        idepth=idp, res_state=rs)      # the window itself is backend_small.npz (same generator call)
+
+
 if __name__ == "__main__":
     tracker_golden()
     backend_golden()
     struct_pose_golden()
     reproject_golden()
     trace_golden()
+    coarse_depth_golden()
+    immature_golden()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -88,3 +88,40 @@ def test_trace_oracle_matches_golden(orc):
     s2 = trace_on(P, P.dI, s1["idepth_min"], s1["idepth_max"], s1["quality"], s1["status"])
     for k in s1:
         assert np.array_equal(s1[k], g["s1_" + k], equal_nan=True) and np.array_equal(s2[k], g["s2_" + k], equal_nan=True), k
+
+
+def _coarse_depth_golden():
+    import os
+    from golden_util import HERE
+    return np.load(os.path.join(HERE, "coarse_depth_small.npz"))
+
+
+def _check_template(T, g):
+    T.makeK(60., 60., int(g["w"]) / 2 - 0.5, int(g["h"]) / 2 - 0.5)
+    T.set_new_image(g["I"], 1.0)
+    T.makeCoarseDepth(g["u"], g["v"], g["idepth"], g["weight"])
+    for l in range(int(g["levels"])):
+        r = T.get_ref(l)
+        for k in r:
+            assert np.array_equal(r[k], g["pc%d_%s" % (l, k)]), (l, k)
+
+
+def test_coarse_depth_oracle_matches_golden(orc):
+    g = _coarse_depth_golden()
+    _check_template(orc.OracleTracker(int(g["w"]), int(g["h"]), int(g["levels"])), g)
+
+
+def _immature_golden():
+    import os
+    from golden_util import HERE, load_window
+    W, _ = load_window()
+    g = np.load(os.path.join(HERE, "immature_small.npz"))
+    args = (W.host, W.u, W.v, g["idepth_min"], g["idepth_max"], g["energyTH"], W.color, W.weights, W.isFromSensor, int(g["minObs"]))
+    return W, g, args
+
+
+def test_immature_oracle_matches_golden(orc):
+    from oracle.backend import OracleEF
+    W, g, args = _immature_golden()
+    r = OracleEF(W.w, W.h).load(W).optimizeImmature(*args)
+    assert np.array_equal(r[0], g["result"]) and np.array_equal(r[1], g["idepth"], equal_nan=True) and np.array_equal(r[2], g["res_state"])

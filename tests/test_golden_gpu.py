@@ -96,3 +96,18 @@ def test_trace_gpu_matches_golden(sdvgn_lib):
     s2 = G.tracePoints(P.KRKi, P.Kt, P.aff, s1["idepth_min"], s1["idepth_max"], s1["quality"], s1["status"])
     for k in s1:
         assert np.array_equal(s1[k], g["s1_" + k], equal_nan=True) and np.array_equal(s2[k], g["s2_" + k], equal_nan=True), k
+
+
+def test_coarse_depth_gpu_matches_golden(sdvgn_lib):
+    from sdv_loam_amd import api
+    from test_golden_cpu import _check_template, _coarse_depth_golden
+    g = _coarse_depth_golden()
+    _check_template(api.CoarseTracker(int(g["w"]), int(g["h"]), int(g["levels"]), max_points=int(g["w"]) * int(g["h"])), g)
+
+
+def test_immature_gpu_matches_golden(sdvgn_lib):
+    from sdv_loam_amd import backend_api
+    from test_golden_cpu import _immature_golden
+    W, g, args = _immature_golden()
+    r = backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W).optimizeImmature(*args)
+    assert np.array_equal(r[0], g["result"]) and np.array_equal(r[1], g["idepth"], equal_nan=True) and np.array_equal(r[2], g["res_state"])
