@@ -282,6 +282,8 @@ static void stitch_sc(sdvgn_ef* e, const double* Gall /*[nF][10][256]*/) {
     H.assign((size_t)n * n, 0); b.assign(n, 0);
     const double sT[6] = {kScaleXiTrans, kScaleXiTrans, kScaleXiTrans, kScaleXiRot, kScaleXiRot, kScaleXiRot};  // adTarget = diag
     std::vector<double> G(64 * 64), Ah((size_t)6 * nf6), B((size_t)6 * nf6);
+    double sT48[6 * SDVGN_MAX_FRAMES];
+    for (int q = 0; q < nf6; ++q) sT48[q] = sT[q % 6];
     for (int h = 0; h < nF; ++h) {
         const double* gp = Gall + (size_t)h * kScE;   // packed upper triangle of the 53x53 Gram
         {
@@ -311,19 +313,18 @@ static void stitch_sc(sdvgn_ef* e, const double* Gall /*[nF][10][256]*/) {
                 for (int q = 0; q < nf6; ++q) s += B[(size_t)r * nf6 + q] * Ah[(size_t)c * nf6 + q];
                 H[(size_t)(iIdx + r) * n + iIdx + c] += s;
             }
-        for (int k = 0; k < nF; ++k) {
-            const int kIdx = CPARS + k * 6;
-            for (int r = 0; r < 6; ++r)
-                for (int c = 0; c < 6; ++c) {
-                    const double v = B[(size_t)r * nf6 + 6 * k + c];
-                    H[(size_t)(iIdx + r) * n + kIdx + c] += v * sT[c];       // AH_ij D_jk AT^T summed over j
-                    H[(size_t)(kIdx + c) * n + iIdx + r] += sT[c] * v;       // AT D_kj AH_ij^T summed over j (D symmetric)
-                }
-            for (int j = 0; j < nF; ++j) {
-                const int jIdx = CPARS + j * 6;
-                for (int r = 0; r < 6; ++r)
-                    for (int c = 0; c < 6; ++c) H[(size_t)(jIdx + r) * n + kIdx + c] += sT[r] * G[(size_t)(6 * j + r) * 64 + 6 * k + c] * sT[c];
-            }
+        // the three frame-block terms, written as contiguous 6nF-wide row updates (element-wise: vectorisable without reassociation)
+        for (int r = 0; r < 6; ++r) {
+            double* hrow = &H[(size_t)(iIdx + r) * n + CPARS];
+            const double* brow = &B[(size_t)r * nf6];
+            for (int q = 0; q < nf6; ++q) hrow[q] += brow[q] * sT48[q];              // AH_ij D_jk AT^T summed over j
+            for (int q = 0; q < nf6; ++q) H[(size_t)(CPARS + q) * n + iIdx + r] += sT48[q] * brow[q];   // its transpose (D symmetric)
+        }
+        for (int row = 0; row < nf6; ++row) {                                         // AT D_jk AT^T
+            double* hrow = &H[(size_t)(CPARS + row) * n + CPARS];
+            const double* grow = &G[(size_t)row * 64];
+            const double sr = sT48[row];
+            for (int q = 0; q < nf6; ++q) hrow[q] += sr * grow[q] * sT48[q];
         }
         // E (6nF x 4), EB (6nF)
         for (int j = 0; j < nF; ++j) {
@@ -1055,6 +1056,55 @@ int sdvgn_ef_accumulators_dev(sdvgn_ef* e, double** buf, int* count) {
 
 // host part of solveSystemF on an accumulator buffer (own or all-reduced): stitch, HM/bM, damped preconditioned LDLT,
 // null-space projection.  Pure host code -- also the entry point of the CPU (gloo) test of the multi-GPU logic.
+// Host LDL^T with Eigen's pivot order (largest remaining ORIGINAL diagonal first, see tracker_track_kernel.inc) in right-looking
+// form: every inner loop is an element-wise row update (no floating-point reduction), which the compiler may vectorise without
+// -ffast-math; the left-looking gn::ldlt_solve_inplace spends its time in scalar dot products at n = 52.  Full symmetric storage,
+// A (n x n, row-major) and b are overwritten; b returns x.  Same solution as the left-looking form up to rounding order.
+static void ldlt_solve_rl(int n, double* A, double* b) {
+    constexpr int MAXN = CPARS + 6 * SDVGN_MAX_FRAMES;
+    int perm[MAXN];
+    double d0[MAXN], colk[MAXN];
+    for (int i = 0; i < n; ++i) d0[i] = std::fabs(A[(size_t)i * n + i]);
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        double big = d0[k];
+        for (int i = k + 1; i < n; ++i) if (d0[i] > big) { big = d0[i]; p = i; }
+        perm[k] = p;
+        if (p != k) {   // symmetric swap of rows and columns k <-> p
+            std::swap(d0[k], d0[p]);
+            double* rk = A + (size_t)k * n; double* rp = A + (size_t)p * n;
+            for (int c = 0; c < n; ++c) std::swap(rk[c], rp[c]);
+            for (int r = 0; r < n; ++r) std::swap(A[(size_t)r * n + k], A[(size_t)r * n + p]);
+            std::swap(b[k], b[p]);
+        }
+        const double d = A[(size_t)k * n + k];
+        if (std::fabs(d) > 0.0) {
+            const double* rowk = A + (size_t)k * n;
+            for (int r = k + 1; r < n; ++r) colk[r] = A[(size_t)r * n + k] / d;           // L[r][k]
+            for (int r = k + 1; r < n; ++r) {
+                double* rr = A + (size_t)r * n;
+                const double l = colk[r];
+                for (int c = k + 1; c < n; ++c) rr[c] -= l * rowk[c];                      // trailing update, contiguous in c
+                rr[k] = l;
+            }
+        }
+    }
+    for (int k = 0; k < n; ++k) {           // forward substitution, column-oriented (AXPY)
+        const double yk = b[k];
+        for (int r = k + 1; r < n; ++r) b[r] -= A[(size_t)r * n + k] * yk;
+    }
+    for (int i = 0; i < n; ++i) {
+        const double d = A[(size_t)i * n + i];
+        b[i] = (std::fabs(d) > 5.562684646268003e-309) ? b[i] / d : 0.0;   // Eigen's LDLT solve tolerance (1/DBL_MAX)
+    }
+    for (int k = n - 1; k >= 0; --k) {      // backward substitution with L^T
+        double s = b[k];
+        for (int r = k + 1; r < n; ++r) s -= A[(size_t)r * n + k] * b[r];
+        b[k] = s;
+    }
+    for (int k = n - 1; k >= 0; --k) if (perm[k] != k) std::swap(b[k], b[perm[k]]);
+}
+
 static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, double lambda, double* x_out) {
     const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
     g_pt.start();
@@ -1085,7 +1135,7 @@ static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, d
         }
         xs[i] = sv[i] * e->bFinal[i];
     }
-    gn::ldlt_solve_inplace<CPARS + 6 * SDVGN_MAX_FRAMES>(n, Hs.data(), n, xs.data());
+    ldlt_solve_rl(n, Hs.data(), xs.data());
     e->lastX.resize(n);
     for (int i = 0; i < n; ++i) e->lastX[i] = sv[i] * xs[i];
     if (iteration >= 2) orthogonalize_x(e, e->lastX);   // SOLVER_ORTHOGONALIZE_X_LATER
