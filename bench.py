@@ -419,6 +419,9 @@ def main():
     barrier_sync(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)
     value = (world if scaling == "weak" else 1) * K / dt
+    it_us = (runner.ef if hasattr(runner, "ef") else runner).iteration_times_us()     # per loop body, this rank
+    iter_stats = dict(median_us=float(np.median(it_us)), p10_us=float(np.percentile(it_us, 10)), p90_us=float(np.percentile(it_us, 90)),
+                      n=int(len(it_us))) if len(it_us) else None
 
     # ---- the same K loop bodies with the reference's literal re-linearisation after every rejected step (A/B; results identical) ----
     value_relin = None
@@ -471,6 +474,7 @@ def main():
         "roofline": roof,
         "kernel_ms": {"linearizeAll": ms_lin, "accumulate(point+top+sc+reduce)": ms_acc},
         "value_with_literal_relinearize_on_reject": value_relin,
+        "iteration_us": iter_stats,
     }
     if rank == 0 and world == 1 and not args.quick:
         traffic, how = measure_traffic()

@@ -289,6 +289,8 @@ int sdvgn_ef_optimize(sdvgn_ef* ef, int mnumOptIts, int flags /* bit0: run exact
                       double* trace, int trace_stride, int trace_cap);
 /* state after optimize: CalibHessian::value_scaled, FrameHessian::state (nF x 10), PointHessian::idepth (nP) */
 int sdvgn_ef_get_state(sdvgn_ef* ef, double* value_scaled4, double* state10, float* idepth);
+/* wall time (microseconds, host steady_clock) of every loop body of the last sdvgn_ef_optimize call; returns their number */
+int sdvgn_ef_get_iteration_times(sdvgn_ef* ef, double* us, int cap);
 /* Device pointer of key-frame idx's level-0 image (dI, AoS {I,dx,dy}) held by the window, for sdvgn_reproj_set_frame(.., dI_aos3_dev);
  * NULL if idx is out of range or the handle is host-only.  Valid until that frame's image is replaced or the handle is destroyed. */
 const float* sdvgn_ef_frame_image_dev(sdvgn_ef* ef, int idx);

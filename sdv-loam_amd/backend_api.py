@@ -34,6 +34,7 @@ PROTOTYPES = [
     ("sdvgn_ef_get_residual_state", C.c_int, [vp, vp, vp, vp, vp, vp]),
     ("sdvgn_ef_get_points", C.c_int, [vp, f32p]),
     ("sdvgn_ef_get_top_acc", C.c_int, [vp, f64p, vp]),
+    ("sdvgn_ef_get_iteration_times", C.c_int, [vp, vp, C.c_int]),
     ("sdvgn_ef_frame_image_dev", vp, [vp, C.c_int]),
     ("sdvgn_rccl_unique_id", C.c_int, [vp]),
     ("sdvgn_ef_init_rccl", C.c_int, [vp, vp, C.c_int, C.c_int]),
@@ -214,6 +215,12 @@ class EnergyFunctional:
         trace = np.zeros((cap, stride))
         n = self._check(self.L.sdvgn_ef_optimize(self.h_, its, (1 if fixed_its else 0) | (2 if relinearize_on_reject else 0), trace.ctypes.data_as(vp) if want_trace else None, stride, cap))
         return trace[:n]
+
+    def iteration_times_us(self):
+        n = self.L.sdvgn_ef_get_iteration_times(self.h_, None, 0)
+        out = np.zeros(max(n, 1))
+        self.L.sdvgn_ef_get_iteration_times(self.h_, out.ctypes.data_as(vp), n)
+        return out[:n]
 
     def state(self):
         vs = np.zeros(4)

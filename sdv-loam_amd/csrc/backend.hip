@@ -94,6 +94,7 @@ struct sdvgn_ef {
     int8_t* rstate_new2 = nullptr;
     float *renergy_new2 = nullptr, *renergy_wo2 = nullptr;
     int new_cur = 0;   // which set holds the current state_New* values
+    std::vector<double> iter_us;   // wall time of every loop body of the last sdvgn_ef_optimize call (microseconds)
     float2* rmatcher = nullptr;
     float *renergy = nullptr, *renergy_new = nullptr, *renergy_wo = nullptr, *rres_toZero = nullptr, *J = nullptr, *JpJd = nullptr;
     float *pHddA = nullptr, *pbdA = nullptr, *pHcdA = nullptr, *pHddL = nullptr, *pbdL = nullptr, *pHcdL = nullptr, *pHdi = nullptr,
@@ -1289,7 +1290,9 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     const float stepsize = 1, thOpt = 1.2f;
     std::vector<double> x(n);
     int it = 0;
+    e->iter_us.clear();
     for (int iteration = 0; iteration < mnumOptIts; iteration++) {
+        const auto t_iter = std::chrono::steady_clock::now();
         for (int i = 0; i < 4; ++i) e->value_backup[i] = e->value[i];                     // backupState
         for (FrameH& f : e->frames) for (int i = 0; i < 10; ++i) f.state_backup[i] = f.state[i];
         if ((rc = sdvgn_ef_solve_system(e, iteration, lambda, x.data()))) return rc;   // its resubstitute also backs up the idepths
@@ -1351,6 +1354,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             lambda *= 1e2;
         }
         g_pt.stop(PT_APPLY);
+        e->iter_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_iter).count());
         if (!fixed_its && canbreak && iteration >= 1) break;
     }
     if (g_pt.on) {
@@ -1359,6 +1363,13 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         for (int k = 0; k < PT_N; ++k) { g_pt.acc[k] = 0; g_pt.cnt[k] = 0; }
     }
     return it;
+}
+
+int sdvgn_ef_get_iteration_times(sdvgn_ef* e, double* us, int cap) {
+    if (!e) return SDVGN_E_ARG;
+    const int n = (int)e->iter_us.size();
+    if (us) for (int i = 0; i < n && i < cap; ++i) us[i] = e->iter_us[i];
+    return n;
 }
 
 int sdvgn_ef_get_state(sdvgn_ef* e, double* value_scaled4, double* state10, float* idepth) {
