@@ -423,6 +423,19 @@ def main():
     iter_stats = dict(median_us=float(np.median(it_us)), p10_us=float(np.percentile(it_us, 10)), p90_us=float(np.percentile(it_us, 90)),
                       n=int(len(it_us))) if len(it_us) else None
 
+    # ---- N > 1 only: the same K loop bodies as N independent replicas (every rank optimises its own copy of the full window, no
+    # collective) -- the weak-scaling view next to the strong-scaling headline that configs[3] asks for ----
+    replicas_value = None
+    if world > 1 and runner is not G:
+        G.load(W)
+        G.optimize(Wm, want_trace=False, fixed_its=True)
+        G.load(W)
+        barrier_sync(world)
+        t2 = time.perf_counter()
+        G.optimize(K, want_trace=False, fixed_its=True)
+        barrier_sync(world)
+        replicas_value = world * K / max_over_ranks(time.perf_counter() - t2, world)
+
     # ---- the same K loop bodies with the reference's literal re-linearisation after every rejected step (A/B; results identical) ----
     value_relin = None
     if world == 1 and hasattr(runner, "load"):
@@ -475,6 +488,7 @@ def main():
         "kernel_ms": {"linearizeAll": ms_lin, "accumulate(point+top+sc+reduce)": ms_acc},
         "value_with_literal_relinearize_on_reject": value_relin,
         "iteration_us": iter_stats,
+        "replicas_value_weak_scaling": replicas_value,
     }
     if rank == 0 and world == 1 and not args.quick:
         traffic, how = measure_traffic()
