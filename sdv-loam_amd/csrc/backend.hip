@@ -115,9 +115,7 @@ struct sdvgn_ef {
     double* acc_dev = nullptr;    // packed: top [nF*nF][256] | sc [nF][2560] | resInA
     double* acc_host = nullptr;   // pinned; the reduce kernels write it DIRECTLY (zero-copy) when no all-reduce is installed
     double* stats_host = nullptr; // pinned, 4 doubles: same for k_ef_sum_stats
-    float *xc_dev = nullptr, *xAd_dev = nullptr;
-    float* x_host = nullptr;      // pinned, 2 slots used alternately: xc(4) + xAd(nF*nF*6)
-    int x_slot = 0;
+    float fuse_step_fac = -1.0f;   // set by sdvgn_ef_optimize: k_ef_resubstitute also applies the point step
     hipEvent_t ev_top = nullptr;  // (unused by the flag path; kept for the event fallback)
     ncclComm_t rccl_comm = nullptr;   // cfg4 with the collectives issued by the library itself (sdvgn_ef_init_rccl)
     int* flags_host = nullptr;    // pinned: [0] top accumulators done, [1] all accumulators done, [2] linearize statistics done
@@ -408,6 +406,10 @@ static void orthogonalize_x(sdvgn_ef* e, std::vector<double>& x) {
     for (int i = 0; i < n; ++i) { double a = 0; for (int j = 0; j < k; ++j) a += N[(size_t)i * k + j] * tP[j] + Npi[(size_t)i * k + j] * tN[j]; x[i] -= 0.5 * a; }
 }
 
+__global__ void __launch_bounds__(1024) k_ef_precalc_in(const unsigned long long* __restrict__ src_pinned, unsigned long long* __restrict__ dst, int n8) {
+    for (int i = threadIdx.x; i < n8; i += 1024) dst[i] = src_pinned[i];
+}
+
 static int ef_upload_precalc(sdvgn_ef* e) {
     const int nF = e->nF;
     const EFConst& C = e->C;
@@ -458,8 +460,14 @@ static int ef_upload_precalc(sdvgn_ef* e) {
         }
     for (FrameH& f : e->frames)
         for (int i = 0; i < 6; ++i) { f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i]; }
-    if (!e->host_only)
-        HIPCHK(hipMemcpyAsync(e->precalc_dev, pch, sizeof(PrecalcDev) * nF * nF, hipMemcpyHostToDevice, e->stream));
+    if (!e->host_only) {
+        // the table goes host -> device inside a one-workgroup kernel that reads the pinned staging half directly (one PCIe
+        // round trip, ~3 us on the stream; a hipMemcpyAsync of the same 10 kB costs a ~8 us blit kernel plus its launch)
+        static_assert(sizeof(PrecalcDev) % 8 == 0, "PrecalcDev is copied as 8-byte words");
+        const int n8 = (int)(sizeof(PrecalcDev) * nF * nF / 8);
+        k_ef_precalc_in<<<1, 1024, 0, e->stream>>>((const unsigned long long*)pch, (unsigned long long*)e->precalc_dev, n8);
+        HIPCHK(hipGetLastError());
+    }
     e->havePrecalc = true;
     return 0;
 }
@@ -663,7 +671,6 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->imm_pc_dev, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES);
     const size_t accmax = (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kTopE + (size_t)SDVGN_MAX_FRAMES * kScE + 1;
     bad |= dev_alloc(&e->acc_dev, accmax);
-    bad |= dev_alloc(&e->xc_dev, 4) | dev_alloc(&e->xAd_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6);
     bad |= dev_alloc(&e->stats_dev, 4) | dev_alloc(&e->stats_partial, 3 * (mp / 64 + 2));
     if (bad) { sdvgn_ef_destroy(e); return -(int)hipErrorOutOfMemory; }
     HIPCHK(hipHostMalloc(&e->precalc_host, 2 * sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
@@ -674,7 +681,6 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     HIPCHK(hipMalloc((void**)&e->done_ctr, 2 * sizeof(unsigned)));
     HIPCHK(hipMemset(e->done_ctr, 0, 2 * sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void**)&e->imm_pc_host, sizeof(ImmPrecalc) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
-    HIPCHK(hipHostMalloc(&e->x_host, 2 * sizeof(float) * (4 + SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6)));
     HIPCHK(hipEventCreateWithFlags(&e->ev_top, hipEventDisableTiming));
     {   // packed upper triangle of the live 53x53 SC Gram -> offset inside its ten 16x16 tiles (k_ef_sc_gram's layout)
         unsigned short off[kScE];
@@ -707,7 +713,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->rstate, e->rstate_new, e->rmatcher, e->renergy, e->renergy_new, e->renergy_wo, e->rres_toZero, e->J, e->JpJd, e->pHddA,
                     e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->images, e->img_stage,
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
-                    e->xc_dev, e->xAd_dev, e->stats_dev, e->stats_partial, e->sc_off_dev, e->imm_pc_dev, e->rstate_new2, e->renergy_new2, e->renergy_wo2};
+                    e->stats_dev, e->stats_partial, e->sc_off_dev, e->imm_pc_dev, e->rstate_new2, e->renergy_new2, e->renergy_wo2};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->precalc_host) hipHostFree(e->precalc_host);
     if (e->acc_host) hipHostFree(e->acc_host);
@@ -716,7 +722,6 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
     if (e->done_ctr) hipFree(e->done_ctr);
     if (e->imm_pc_host) hipHostFree(e->imm_pc_host);
     if (e->imm_stage) hipHostFree(e->imm_stage);
-    if (e->x_host) hipHostFree(e->x_host);
     if (e->ev_top) hipEventDestroy(e->ev_top);
     if (e->own_stream) hipStreamDestroy(e->stream);
     delete e;
@@ -1168,15 +1173,12 @@ int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
     int rc = ef_stitch_solve_host(e, e->acc_host, iteration, lambda, x_out);
     g_pt.start();
     if (rc) return rc;
-    // resubstituteF_MT (:221-247): xc, xAd[nF*h + t]
-    // two pinned slots used alternately: the copies below are still in flight when this function returns, and at least one
-    // stream synchronisation (the statistics read-back of the next linearize) happens before a slot comes round again
-    e->x_slot ^= 1;
-    float* xc = e->x_host + (size_t)e->x_slot * (4 + SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 6);
-    float* xAd = xc + 4;
+    // resubstituteF_MT (:221-247): xc, xAd[nF*h + t] -- handed to the kernel by value (kernel-argument segment, no H2D copy)
+    ResubX X;
+    std::memset(&X, 0, sizeof(X));
     std::vector<float> xF(n);
     for (int i = 0; i < n; ++i) xF[i] = (float)e->lastX[i];
-    for (int i = 0; i < 4; ++i) xc[i] = xF[i];
+    for (int i = 0; i < 4; ++i) X.xc[i] = xF[i];
     for (int h = 0; h < nF; ++h)
         for (int t = 0; t < nF; ++t) {
             const float* AH = &e->adHostF[(size_t)(h + nF * t) * 36];
@@ -1184,14 +1186,14 @@ int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
             for (int c = 0; c < 6; ++c) {
                 float a = 0, b = 0;
                 for (int q = 0; q < 6; ++q) { a += xF[CPARS + 6 * h + q] * AH[q * 6 + c]; b += xF[CPARS + 6 * t + q] * AT[q * 6 + c]; }
-                xAd[(size_t)(nF * h + t) * 6 + c] = a + b;
+                X.xAd[(size_t)(nF * h + t) * 6 + c] = a + b;
             }
         }
-    HIPCHK(hipMemcpyAsync(e->xc_dev, xc, sizeof(float) * 4, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->xAd_dev, xAd, sizeof(float) * pairs * 6, hipMemcpyHostToDevice, e->stream));
-    k_ef_resubstitute<<<(e->nP + 63) / 64, 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->xc_dev, e->xAd_dev,
-                                                             e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2));
+    const float step_fac = e->fuse_step_fac;   // >= 0 inside sdvgn_ef_optimize: doStepFromBackup for the points rides along
+    k_ef_resubstitute<<<(e->nP + 63) / 64, 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, X, e->pidepth_backup,
+                                                             e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid, e->pidz, e->pdeltaF);
     HIPCHK(hipGetLastError());
+    if (step_fac >= 0.0f) e->deltaF_nonzero = false;
     g_pt.stop(PT_RESUB);
     return SDVGN_OK;
 }
@@ -1295,7 +1297,10 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         const auto t_iter = std::chrono::steady_clock::now();
         for (int i = 0; i < 4; ++i) e->value_backup[i] = e->value[i];                     // backupState
         for (FrameH& f : e->frames) for (int i = 0; i < 10; ++i) f.state_backup[i] = f.state[i];
-        if ((rc = sdvgn_ef_solve_system(e, iteration, lambda, x.data()))) return rc;   // its resubstitute also backs up the idepths
+        e->fuse_step_fac = stepsize;   // resubstitute also backs up the idepths and applies doStepFromBackup's point part
+        rc = sdvgn_ef_solve_system(e, iteration, lambda, x.data());
+        e->fuse_step_fac = -1.0f;
+        if (rc) return rc;
         // doStepFromBackup
         g_pt.start();
         double v[4];
@@ -1311,8 +1316,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             for (int i = 0; i < 3; ++i) sumT += (float)(x[CPARS + 6 * h + i] * x[CPARS + 6 * h + i]);
             for (int i = 3; i < 6; ++i) sumR += (float)(x[CPARS + 6 * h + i] * x[CPARS + 6 * h + i]);
         }
-        if ((rc = sdvgn_ef_point_step(e, 1, stepsize))) return rc;
-        g_pt.stop(PT_STEP);
+        g_pt.stop(PT_STEP);   // the point step (idepth = backup + stepsize * step) ran inside k_ef_resubstitute
         if ((rc = ef_upload_precalc(e))) return rc;                                       // setPrecalcValues + setDeltaF
         g_pt.stop(PT_PRECALC);
         double newEnergy, newEnergyL, sID, sNID;

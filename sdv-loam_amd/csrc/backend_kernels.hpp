@@ -843,11 +843,23 @@ __global__ void __launch_bounds__(256) k_ef_gram_reduce(const float* __restrict_
 // residual in target t, wave 0 subtracts the 8 terms in ascending target order.  Also does backupState for the point
 // (idepth_backup = idepth, FullSystemOptimize.cpp:300-305) and the per-block partial sums of step^2 and |idepth_backup|
 // that doStepFromBackup needs (:236-249).  xAd: [nF(host)][nF(target)][6] floats (index nF*h + t), xc: 4 floats.
+// The solution (xc and the nF*nF adjoint-transformed frame steps) travels in the kernel-argument segment: no H2D copy, the
+// values sit in scalar registers / the scalar cache.  step_fac >= 0 additionally performs doStepFromBackup for the point
+// (idepth = idepth_zero = backup + step_fac * step, FullSystemOptimize.cpp:236-249) -- the optimize loop always does both.
+struct ResubX { float xc[4]; float xAd[kMaxFrames * kMaxFrames * 6]; };
+
 __global__ void __launch_bounds__(512) k_ef_resubstitute(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
-                                                         const int* __restrict__ phost, const float* __restrict__ xc,
-                                                         const float* __restrict__ xAd, float* __restrict__ backup,
-                                                         double* __restrict__ stats_partial) {
+                                                         const int* __restrict__ phost, const ResubX X, float* __restrict__ backup,
+                                                         double* __restrict__ stats_partial, float step_fac,
+                                                         float* __restrict__ pid_w, float* __restrict__ pidz_w, float* __restrict__ pdeltaF_w) {
     __shared__ float part[kMaxFrames][2][64];
+    __shared__ float sx[4 + kMaxFrames * kMaxFrames * 6];
+    // one pass over the argument block into LDS (the per-lane host index below would otherwise turn every use into a
+    // vector load from the kernel-argument segment)
+    if (threadIdx.x < 4 + kMaxFrames * kMaxFrames * 6) sx[threadIdx.x] = reinterpret_cast<const float*>(&X)[threadIdx.x];
+    __syncthreads();
+    const float* xc = sx;
+    const float* xAd = sx + 4;
     const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
     const int p = blockIdx.x * 64 + lane;
     const size_t slots = (size_t)C.nF * C.nP;
@@ -886,6 +898,12 @@ __global__ void __launch_bounds__(512) k_ef_resubstitute(EFConst C, EFArrays A, 
         A.pstep[p] = step;
         const float idb = A.pid[p] * (1.0f / SDVGN_SCALE_IDEPTH);
         backup[p] = idb;
+        if (step_fac >= 0.0f) {
+            const float v = idb + step_fac * step;
+            pid_w[p] = SDVGN_SCALE_IDEPTH * v;
+            pidz_w[p] = SDVGN_SCALE_IDEPTH * v;
+            pdeltaF_w[p] = v - v;
+        }
         s2 = (double)(step * step);
         sa = (double)fabsf(idb);
     }
