@@ -291,6 +291,9 @@ int sdvgn_ef_optimize(sdvgn_ef* ef, int mnumOptIts, int flags /* bit0: run exact
 int sdvgn_ef_get_state(sdvgn_ef* ef, double* value_scaled4, double* state10, float* idepth);
 /* wall time (microseconds, host steady_clock) of every loop body of the last sdvgn_ef_optimize call; returns their number */
 int sdvgn_ef_get_iteration_times(sdvgn_ef* ef, double* us, int cap);
+/* Diagnostics (SDVGN_PROFILE=1 in the environment when the library is loaded): prints the accumulated host wall time per phase
+ * of the solve / optimize path to stderr, divided by `per`, and clears the counters.  Returns 1 if a report was printed, else 0. */
+int sdvgn_debug_phase_report(int per);
 /* Device pointer of key-frame idx's level-0 image (dI, AoS {I,dx,dy}) held by the window, for sdvgn_reproj_set_frame(.., dI_aos3_dev);
  * NULL if idx is out of range or the handle is host-only.  Valid until that frame's image is replaced or the handle is destroyed. */
 const float* sdvgn_ef_frame_image_dev(sdvgn_ef* ef, int idx);

@@ -26,6 +26,8 @@ def _L():
         L.orc_ef_set_residuals.argtypes = [vp, C.c_int, i32p, i32p, i32p, u8p, f64p, u8p, u8p]
         L.orc_ef_set_marg_prior.argtypes = [vp, f64p, f64p]
         L.orc_ef_set_nullspaces.argtypes = [vp, C.c_int, f64p]
+        L.orc_ef_set_threads.argtypes = [vp, C.c_int]
+        L.orc_ef_set_threads.restype = None
         L.orc_ef_set_precalc.argtypes = [vp]
         L.orc_ef_set_adjoints.argtypes = [vp]
         L.orc_ef_linearize_all.argtypes = [vp]
@@ -182,6 +184,11 @@ class OracleEF:
 
     def resInA(self):
         return self.L.orc_ef_res_in_A(self.h_)
+
+    def set_threads(self, n):
+        """n > 1: the reference's multiThreading=true paths (IndexThreadReduce, NUM_THREADS=6 in the reference) -- timing baseline
+        and tolerance-level results; 1 (default) is the reference's default and the parity configuration."""
+        self.L.orc_ef_set_threads(self.h_, int(n))
 
     def optimize(self, its=6, cap=128):
         stride = 7 + self.dim

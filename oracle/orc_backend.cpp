@@ -17,6 +17,8 @@
 // "parity unpinned"; pinned by analytic known-answer tests in tests/test_oracle_backend.py.
 // Float32 / float64 usage, operand order and the 1k/1M tiered accumulation follow the reference.
 #include "orc_math.hpp"
+#include <omp.h>
+
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -192,6 +194,7 @@ struct Residual {
 
 struct EF {
     int w, h, nF;
+    int nThreads = 1;   // 1 = the reference's default (multiThreading = false); > 1 = its IndexThreadReduce paths, see solve_system
     // CalibHessian
     double value_scaled[4], value_minus_value_zero[4], value[4], value_zero[4], value_backup[4];
     float fxl, fyl, cxl, cyl, fxli, fyli, cxli, cyli;
@@ -533,7 +536,10 @@ static void add_AMBt(std::vector<double>& H, int n, int r0, int c0, const double
 }
 
 // ---- b4: stitchDoubleInternal(tid=-1) + tail of stitchDoubleMT ------------------------------------------
-static void stitch_top(EF* E, std::vector<AccumulatorApprox>& acc, std::vector<double>& H, std::vector<double>& b, bool usePrior) {
+// `extra`: the accumulators of worker threads 1..T-1 (stitchDoubleMT sums the finished per-thread matrices in double,
+// AccumulatedTopHessian.h:70-98); empty in the single-thread configuration.
+static void stitch_top(EF* E, std::vector<AccumulatorApprox>& acc, std::vector<double>& H, std::vector<double>& b, bool usePrior,
+                       std::vector<std::vector<AccumulatorApprox>>* extra = nullptr) {
     const int nF = E->nF, n = CPARS + 6 * nF;
     H.assign((size_t)n * n, 0); b.assign(n, 0);
     for (int k = 0; k < nF * nF; ++k) {
@@ -544,6 +550,12 @@ static void stitch_top(EF* E, std::vector<AccumulatorApprox>& acc, std::vector<d
         acc[aidx].finish();
         if (acc[aidx].num != 0)
             for (int r = 0; r < 13; ++r) for (int c = 0; c < 13; ++c) accH[r * 13 + c] += (double)acc[aidx].H[r][c];
+        if (extra)
+            for (auto& ex : *extra) {
+                ex[aidx].finish();
+                if (ex[aidx].num == 0) continue;
+                for (int r = 0; r < 13; ++r) for (int c = 0; c < 13; ++c) accH[r * 13 + c] += (double)ex[aidx].H[r][c];
+            }
         const double* AH = &E->adHost[(size_t)aidx * 36];
         const double* AT = &E->adTarget[(size_t)aidx * 36];
         const double* A66 = &accH[CPARS * 13 + CPARS];
@@ -635,7 +647,7 @@ static void add_AMBt6(std::vector<double>& H, int n, int r0, int c0, const doubl
     add_AMBt(H, n, r0, c0, A, M8, 8, B);
 }
 
-static void stitch_sc(EF* E, SCAcc& S, std::vector<double>& H, std::vector<double>& b) {
+static void stitch_sc(EF* E, SCAcc& S, std::vector<double>& H, std::vector<double>& b, std::vector<SCAcc>* extra = nullptr) {
     const int nF = S.nF, n = CPARS + 6 * nF, nframes2 = nF * nF;
     H.assign((size_t)n * n, 0); b.assign(n, 0);
     for (int k = 0; k < nframes2; ++k) {
@@ -645,6 +657,12 @@ static void stitch_sc(EF* E, SCAcc& S, std::vector<double>& H, std::vector<doubl
         double Hpc[8 * CPARS], bp[8];
         for (int q = 0; q < 8 * CPARS; ++q) Hpc[q] = (double)S.accE[ijIdx].A1m[q];
         for (int q = 0; q < 8; ++q) bp[q] = (double)S.accEB[ijIdx].A1m[q];
+        if (extra)
+            for (SCAcc& X : *extra) {   // AccumulatedSCHessian.cpp:80-90 (tid loop)
+                X.accE[ijIdx].finish(); X.accEB[ijIdx].finish();
+                for (int q = 0; q < 8 * CPARS; ++q) Hpc[q] += (double)X.accE[ijIdx].A1m[q];
+                for (int q = 0; q < 8; ++q) bp[q] += (double)X.accEB[ijIdx].A1m[q];
+            }
         const double* AH = &E->adHost[(size_t)ijIdx * 36];
         const double* AT = &E->adTarget[(size_t)ijIdx * 36];
         for (int r = 0; r < 6; ++r) {
@@ -665,6 +683,11 @@ static void stitch_sc(EF* E, SCAcc& S, std::vector<double>& H, std::vector<doubl
             std::memset(accDM, 0, sizeof(accDM));
             S.accD[ijkIdx].finish();
             if (S.accD[ijkIdx].num != 0) for (int q = 0; q < 64; ++q) accDM[q] += (double)S.accD[ijkIdx].A1m[q];
+            if (extra)
+                for (SCAcc& X : *extra) {
+                    X.accD[ijkIdx].finish();
+                    if (X.accD[ijkIdx].num != 0) for (int q = 0; q < 64; ++q) accDM[q] += (double)X.accD[ijkIdx].A1m[q];
+                }
             const double* AHk = &E->adHost[(size_t)ikIdx * 36];
             const double* ATk = &E->adTarget[(size_t)ikIdx * 36];
             add_AMBt6(H, n, iIdx, iIdx, AH, accDM, AHk);
@@ -678,6 +701,14 @@ static void stitch_sc(EF* E, SCAcc& S, std::vector<double>& H, std::vector<doubl
         for (int c = 0; c < CPARS; ++c) H[(size_t)r * n + c] += (double)S.accHcc.A1m[r * CPARS + c];
         b[r] += (double)S.accbc.A1m[r];
     }
+    if (extra)
+        for (SCAcc& X : *extra) {
+            X.accHcc.finish(); X.accbc.finish();
+            for (int r = 0; r < CPARS; ++r) {
+                for (int c = 0; c < CPARS; ++c) H[(size_t)r * n + c] += (double)X.accHcc.A1m[r * CPARS + c];
+                b[r] += (double)X.accbc.A1m[r];
+            }
+        }
     for (int h = 0; h < nF; ++h) {
         const int hIdx = CPARS + h * 6;
         for (int i = 0; i < CPARS; ++i) for (int j = 0; j < 6; ++j) H[(size_t)i * n + hIdx + j] = H[(size_t)(hIdx + j) * n + i];
@@ -752,6 +783,10 @@ static void solve_system(EF* E, int iteration, double lambda) {
     E->accA.resize((size_t)nF * nF);
     for (auto& a : E->accA) a.initialize();
     E->resInA = 0;
+    const int T = E->nThreads, nPts = (int)E->points.size();
+    SCAcc S;
+    S.setZero(nF);
+    if (T <= 1) {
     for (Point& p : E->points) add_point_top(E, E->accA, p, 0, E->resInA);
     stitch_top(E, E->accA, E->HA, E->bA, true);
     // accumulateLF_MT: result discarded, but it (re)sets p->*_accLF
@@ -760,10 +795,42 @@ static void solve_system(EF* E, int iteration, double lambda) {
     E->resInL = 0;
     for (Point& p : E->points) add_point_top(E, E->accL, p, 1, E->resInL);
     // accumulateSCF_MT
-    SCAcc S;
-    S.setZero(nF);
     for (Point& p : E->points) add_point_sc(E, S, p, true);
     stitch_sc(E, S, E->Hsc, E->bsc);
+    } else {
+        // multiThreading = true (settings.cpp:164 off by default): the *_MT calls hand blocks of 50 points to the IndexThreadReduce
+        // workers, each with its own accumulator set (EnergyFunctional.cpp:158-219); here the blocks go to the T workers round-robin
+        // (static schedule) so that a run is reproducible.  Timing baseline only -- sums differ from T = 1 in the last float bits.
+        std::vector<std::vector<AccumulatorApprox>> exA(T - 1, std::vector<AccumulatorApprox>((size_t)nF * nF)), accLT(T, std::vector<AccumulatorApprox>((size_t)nF * nF));
+        for (auto& v : exA) for (auto& a : v) a.initialize();
+        for (auto& v : accLT) for (auto& a : v) a.initialize();
+        std::vector<SCAcc> exS(T - 1);
+        for (SCAcc& X : exS) X.setZero(nF);
+        std::vector<int> nA(T, 0), nL(T, 0);
+#pragma omp parallel num_threads(T)
+        {
+            const int tid = omp_get_thread_num();
+            std::vector<AccumulatorApprox>& mineA = tid == 0 ? E->accA : exA[tid - 1];
+#pragma omp for schedule(static, 50)
+            for (int i = 0; i < nPts; ++i) add_point_top(E, mineA, E->points[i], 0, nA[tid]);
+#pragma omp for schedule(static, 50)
+            for (int i = 0; i < nPts; ++i) add_point_top(E, accLT[tid], E->points[i], 1, nL[tid]);
+            SCAcc& mineS = tid == 0 ? S : exS[tid - 1];
+#pragma omp for schedule(static, 50)
+            for (int i = 0; i < nPts; ++i) add_point_sc(E, mineS, E->points[i], true);
+        }
+        for (int t = 0; t < T; ++t) E->resInA += nA[t];
+        stitch_top(E, E->accA, E->HA, E->bA, true, &exA);
+        stitch_sc(E, S, E->Hsc, E->bsc, &exS);
+        // fold the workers' (finished) accumulators into set 0 so that the getters below see the totals
+        for (auto& v : exA) for (int k = 0; k < nF * nF; ++k) for (int r = 0; r < 13; ++r) for (int c = 0; c < 13; ++c) E->accA[k].H[r][c] += v[k].H[r][c];
+        for (SCAcc& X : exS) {
+            for (int k = 0; k < nF * nF; ++k) { for (int q = 0; q < 32; ++q) S.accE[k].A1m[q] += X.accE[k].A1m[q]; for (int q = 0; q < 8; ++q) S.accEB[k].A1m[q] += X.accEB[k].A1m[q]; }
+            for (int k = 0; k < nF * nF * nF; ++k) for (int q = 0; q < 64; ++q) S.accD[k].A1m[q] += X.accD[k].A1m[q];
+            for (int q = 0; q < 16; ++q) S.accHcc.A1m[q] += X.accHcc.A1m[q];
+            for (int q = 0; q < 4; ++q) S.accbc.A1m[q] += X.accbc.A1m[q];
+        }
+    }
     {
         E->scE.assign((size_t)nF * nF * 32, 0); E->scEB.assign((size_t)nF * nF * 8, 0); E->scD.assign((size_t)nF * nF * nF * 64, 0);
         for (int k = 0; k < nF * nF; ++k) { std::memcpy(&E->scE[(size_t)k * 32], S.accE[k].A1m, 32 * 4); std::memcpy(&E->scEB[(size_t)k * 8], S.accEB[k].A1m, 8 * 4); }
@@ -805,7 +872,9 @@ static void solve_system(EF* E, int iteration, double lambda) {
             }
         }
     }
-    for (Point& p : E->points) {
+#pragma omp parallel for schedule(static) num_threads(T) if (T > 1)
+    for (int pi = 0; pi < nPts; ++pi) {
+        Point& p = E->points[pi];
         int ngoodres = 0;
         for (int ri = p.r0; ri < p.r1; ++ri) if (E->res[ri].isActive) ngoodres++;
         if (ngoodres == 0) { p.step = 0; continue; }
@@ -868,7 +937,24 @@ static double calc_M_energy(EF* E) {
 }
 static double linearize_all(EF* E) {
     double s = 0;
-    for (Residual& r : E->res) if (!r.isLinearized) s += linearize(E, r);
+    const int T = E->nThreads;
+    if (T <= 1) {
+        for (Residual& r : E->res) if (!r.isLinearized) s += linearize(E, r);
+        return s;
+    }
+    // linearizeAll_Reductor over T contiguous blocks (treadReduce.reduce(.., 0, n, 0), FullSystemOptimize.cpp:120-129); per-worker
+    // energies added in worker order
+    const int nR = (int)E->res.size();
+    std::vector<double> part(T, 0.0);
+#pragma omp parallel num_threads(T)
+    {
+        const int tid = omp_get_thread_num();
+        double a = 0;
+#pragma omp for schedule(static)
+        for (int i = 0; i < nR; ++i) if (!E->res[i].isLinearized) a += linearize(E, E->res[i]);
+        part[tid] = a;
+    }
+    for (int t = 0; t < T; ++t) s += part[t];
     return s;
 }
 
@@ -1233,6 +1319,7 @@ void orc_ef_get_sc_acc(void* e, float* accE, float* accEB, float* accD, float* H
     std::memcpy(accE, E->scE.data(), 4 * E->scE.size()); std::memcpy(accEB, E->scEB.data(), 4 * E->scEB.size());
     std::memcpy(accD, E->scD.data(), 4 * E->scD.size()); std::memcpy(Hcc, E->scHcc.data(), 64); std::memcpy(bc, E->scbc.data(), 16);
 }
+void orc_ef_set_threads(void* e, int n) { ((EF*)e)->nThreads = n < 1 ? 1 : n; }
 int orc_ef_optimize(void* e, int its, double* trace, int stride, int cap) { return optimize((EF*)e, its, trace, stride, cap); }
 double orc_ef_calc_L_energy(void* e) { return calc_L_energy((EF*)e); }
 double orc_ef_calc_M_energy(void* e) { return calc_M_energy((EF*)e); }

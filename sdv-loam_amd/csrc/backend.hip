@@ -80,6 +80,8 @@ struct sdvgn_ef {
     double cPrior[4];
     std::vector<double> HM, bM;
     std::vector<std::vector<double>> nullspaces;
+    std::vector<double> ns_N, ns_Npi;   // normalised null-space basis and its pseudo-inverse (orthogonalize_x), cached
+    bool ns_dirty = true;
     std::vector<double> HA, bA, Hsc, bsc, HFinal, bFinal, lastX;
     int resInA = 0;
     // device
@@ -144,8 +146,8 @@ struct PhaseTimer {   // SDVGN_PROFILE=1: host wall time per phase of the optimi
     void stop(int k) { if (on) { auto t1 = std::chrono::steady_clock::now(); acc[k] += std::chrono::duration<double, std::micro>(t1 - t0).count(); cnt[k]++; t0 = t1; } }
 };
 static PhaseTimer g_pt;
-enum { PT_ACCUM = 0, PT_D2H, PT_STITCH_TOP, PT_STITCH_SC, PT_SOLVE, PT_RESUB, PT_STEP, PT_PRECALC, PT_LIN, PT_APPLY, PT_N };
-static const char* kPtNames[PT_N] = {"accumulate(launch)", "acc D2H+sync", "stitch_top", "stitch_sc", "HM+LDLT", "xAd+H2D+resub+sync", "state step", "precalc upload", "linearize+stats+sync", "apply/restore"};
+enum { PT_ACCUM = 0, PT_D2H, PT_STITCH_TOP, PT_STITCH_SC, PT_SOLVE, PT_RESUB, PT_STEP, PT_PRECALC, PT_LIN, PT_APPLY, PT_PREP, PT_N };
+static const char* kPtNames[PT_N] = {"accumulate(launch)", "acc D2H+sync", "stitch_top", "stitch_sc", "LDLT+orthogonalize", "xAd+resub launch", "state step", "precalc upload", "linearize+stats+sync", "apply/restore", "HFinal+scale"};
 
 static size_t acc_count(const sdvgn_ef* e) { return (size_t)e->nF * e->nF * kTopE + (size_t)e->nF * kScE + 1; }
 
@@ -280,7 +282,7 @@ static void stitch_sc(sdvgn_ef* e, const double* Gall /*[nF][10][256]*/) {
     std::vector<double>& b = e->bsc;
     H.assign((size_t)n * n, 0); b.assign(n, 0);
     const double sT[6] = {kScaleXiTrans, kScaleXiTrans, kScaleXiTrans, kScaleXiRot, kScaleXiRot, kScaleXiRot};  // adTarget = diag
-    std::vector<double> G(64 * 64), Ah((size_t)6 * nf6), B((size_t)6 * nf6);
+    double G[64 * 64], Ah[6 * 6 * SDVGN_MAX_FRAMES], B[6 * 6 * SDVGN_MAX_FRAMES];
     double sT48[6 * SDVGN_MAX_FRAMES];
     for (int q = 0; q < nf6; ++q) sT48[q] = sT[q % 6];
     for (int h = 0; h < nF; ++h) {
@@ -296,7 +298,7 @@ static void stitch_sc(sdvgn_ef* e, const double* Gall /*[nF][10][256]*/) {
             for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Ah[(size_t)r * nf6 + 6 * j + c] = AH[r * 6 + c];
         }
         // B = A_h * D (D = G[0:nf6, 0:nf6]); inner loop contiguous over c so that it vectorises
-        std::fill(B.begin(), B.end(), 0.0);
+        std::fill(B, B + (size_t)6 * nf6, 0.0);
         for (int r = 0; r < 6; ++r)
             for (int q = 0; q < nf6; ++q) {
                 const double a = Ah[(size_t)r * nf6 + q];
@@ -386,6 +388,13 @@ static void svd_jacobi(int m, int k, std::vector<double>& A, std::vector<double>
 static void orthogonalize_x(sdvgn_ef* e, std::vector<double>& x) {
     const int n = (int)x.size(), k = (int)e->nullspaces.size();
     if (k == 0) return;
+    if (!e->ns_dirty && e->ns_N.size() == (size_t)n * k) {   // N and its pseudo-inverse only change with sdvgn_ef_set_nullspaces
+        const std::vector<double>&N = e->ns_N, &Npi = e->ns_Npi;
+        std::vector<double> tN(k, 0), tP(k, 0);
+        for (int j = 0; j < k; ++j) { double a = 0, c = 0; for (int i = 0; i < n; ++i) { a += N[(size_t)i * k + j] * x[i]; c += Npi[(size_t)i * k + j] * x[i]; } tN[j] = a; tP[j] = c; }
+        for (int i = 0; i < n; ++i) { double a = 0; for (int j = 0; j < k; ++j) a += N[(size_t)i * k + j] * tP[j] + Npi[(size_t)i * k + j] * tN[j]; x[i] -= 0.5 * a; }
+        return;
+    }
     std::vector<double> N((size_t)n * k), U, s, V;
     for (int j = 0; j < k; ++j) {
         double nn = 0;
@@ -404,6 +413,7 @@ static void orthogonalize_x(sdvgn_ef* e, std::vector<double>& x) {
         for (int j = 0; j < k; ++j) { double a = 0; for (int q = 0; q < k; ++q) a += U[(size_t)i * k + q] * s[q] * V[(size_t)j * k + q]; Npi[(size_t)i * k + j] = a; }
     for (int j = 0; j < k; ++j) { double a = 0, c = 0; for (int i = 0; i < n; ++i) { a += N[(size_t)i * k + j] * x[i]; c += Npi[(size_t)i * k + j] * x[i]; } tN[j] = a; tP[j] = c; }
     for (int i = 0; i < n; ++i) { double a = 0; for (int j = 0; j < k; ++j) a += N[(size_t)i * k + j] * tP[j] + Npi[(size_t)i * k + j] * tN[j]; x[i] -= 0.5 * a; }
+    e->ns_N = N; e->ns_Npi = Npi; e->ns_dirty = false;
 }
 
 __global__ void __launch_bounds__(1024) k_ef_precalc_in(const unsigned long long* __restrict__ src_pinned, unsigned long long* __restrict__ dst, int n8) {
@@ -902,6 +912,7 @@ int sdvgn_ef_set_nullspaces(sdvgn_ef* e, int k, const double* v) {
     if (!e || k < 0 || (k > 0 && !v) || e->nF < 1) return SDVGN_E_ARG;
     const int n = CPARS + 6 * e->nF;
     e->nullspaces.clear();
+    e->ns_dirty = true;
     for (int j = 0; j < k; ++j) e->nullspaces.emplace_back(v + (size_t)j * n, v + (size_t)(j + 1) * n);
     return SDVGN_OK;
 }
@@ -1141,6 +1152,7 @@ static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, d
         }
         xs[i] = sv[i] * e->bFinal[i];
     }
+    g_pt.stop(PT_PREP);
     ldlt_solve_rl(n, Hs.data(), xs.data());
     e->lastX.resize(n);
     for (int i = 0; i < n; ++i) e->lastX[i] = sv[i] * xs[i];
@@ -1158,7 +1170,7 @@ int sdvgn_ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, do
 int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_out) {
     if (!e || e->host_only || !e->havePrecalc) return SDVGN_E_STATE;
     EF_DEVICE(e);
-    const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
+    const int nF = e->nF, n = CPARS + 6 * nF;
     g_pt.start();
     if (e->split_pending) {
         HIPCHK(wait_flag(e->flags_host, e->seq_top, e->stream));   // the top accumulators are in acc_host (waitflag.hpp)
@@ -1361,12 +1373,16 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         e->iter_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_iter).count());
         if (!fixed_its && canbreak && iteration >= 1) break;
     }
-    if (g_pt.on) {
-        fprintf(stderr, "[sdvgn profile] %d iterations\n", it);
-        for (int k = 0; k < PT_N; ++k) if (g_pt.cnt[k]) fprintf(stderr, "  %-24s %8.1f us/iter  (%ld calls, %.1f us each)\n", kPtNames[k], g_pt.acc[k] / it, g_pt.cnt[k], g_pt.acc[k] / g_pt.cnt[k]);
-        for (int k = 0; k < PT_N; ++k) { g_pt.acc[k] = 0; g_pt.cnt[k] = 0; }
-    }
+    if (g_pt.on) sdvgn_debug_phase_report(it);
     return it;
+}
+
+int sdvgn_debug_phase_report(int per) {
+    if (!g_pt.on || per < 1) return 0;
+    fprintf(stderr, "[sdvgn profile] %d iterations\n", per);
+    for (int k = 0; k < PT_N; ++k) if (g_pt.cnt[k]) fprintf(stderr, "  %-24s %8.1f us/iter  (%ld calls, %.1f us each)\n", kPtNames[k], g_pt.acc[k] / per, g_pt.cnt[k], g_pt.acc[k] / g_pt.cnt[k]);
+    for (int k = 0; k < PT_N; ++k) { g_pt.acc[k] = 0; g_pt.cnt[k] = 0; }
+    return 1;
 }
 
 int sdvgn_ef_get_iteration_times(sdvgn_ef* e, double* us, int cap) {

@@ -157,3 +157,23 @@ def test_system_symmetry_lambda_and_orthogonalize(orc, ef, small_window):
     x2 = ef.system()["x"]
     Q, _ = np.linalg.qr(ns.T)
     assert rel_err(x2, s["x"] - Q @ (Q.T @ s["x"])) < 1e-9
+
+
+def test_threaded_mode_matches_single_thread(orc):
+    """oracle multi-thread timing mode (the reference's multiThreading=true IndexThreadReduce paths): per-worker accumulators summed
+    in double at the stitch -> same accept/reject sequence, energies and increments to float-summation-order accuracy."""
+    from oracle.backend import OracleEF
+    from sdv_loam_amd import synthetic as syn
+    W = syn.make_window(w=320, h=160, nF=5, pts_per_kf=150, seed=11, calib=dict(fx=200., fy=205., cx=159.5, cy=79.5))
+    out = {}
+    for T in (1, 3):
+        O = OracleEF(W.w, W.h).load(W)
+        O.set_threads(T)
+        tr = O.optimize(5)
+        out[T] = (tr, O.system()["HFinal"], O.state())
+    a, b = out[1][0], out[3][0]
+    assert len(a) == len(b) and (a[:, 2] == b[:, 2]).all()                                   # accept / reject sequence
+    assert np.abs(a[:, 3] - b[:, 3]).max() <= 1e-5 * np.abs(a[:, 3]).max()                    # energies
+    assert np.abs(a[:, 7:] - b[:, 7:]).max() <= 1e-4 * np.abs(a[:, 7:]).max()                 # increments (north_star tolerance)
+    Ha, Hb = out[1][1], out[3][1]
+    assert np.linalg.norm(Ha - Hb) <= 1e-5 * np.linalg.norm(Ha)
