@@ -23,6 +23,4 @@ t0 = time.perf_counter()
 for _ in range(N): L.sdvgn_ef_stitch_solve_host(h, acc, 3, 0.1, xp)
 dt = time.perf_counter() - t0
 print("stitch+solve %.1f us/call" % (1e6 * dt / N), "x checksum", float(np.sum(x)))
-L.sdvgn_debug_phase_report.restype = C.c_int
-L.sdvgn_debug_phase_report.argtypes = [C.c_int]
 L.sdvgn_debug_phase_report(N + 200)

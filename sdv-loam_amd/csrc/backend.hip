@@ -276,83 +276,91 @@ static void stitch_top(sdvgn_ef* e, const double* G /*[nF*nF][256]*/) {
 // G_h is the 64x64 Gram of host h (upper 16x16 tiles); features 6t+i (JpJdF of target t), 48-51 Hcd, 52 bdSum.
 // Uses A_h = [AH_h0 | ... | AH_h,nF-1] (6 x 6nF) so that all  AH D AH^T / AH D AT^T / AT D AH^T  terms of one host come
 // from B = A_h * D_h (6 x 6nF) instead of nF^2 separate 6x6x6 products.
-static void stitch_sc(sdvgn_ef* e, const double* Gall /*[nF][10][256]*/) {
+// Works on the packed upper triangles directly (no 64x64 unpack): D_h symmetric, so  B = A_h D_h  is assembled from each packed
+// row q as an AXPY over the columns c >= q plus, by symmetry, a sum over c > q into column q (two accumulator sets).  The terms
+// that do not involve AH -- diag(sT) D_h diag(sT) -- are summed over the hosts in packed form and applied once; the AH D AT^T row
+// blocks go to R and enter as R + R^T at the end.
+static void stitch_sc(sdvgn_ef* e, const double* Gall /*[nF][1431]*/) {
     const int nF = e->nF, n = CPARS + 6 * nF, nf6 = 6 * nF;
     std::vector<double>& H = e->Hsc;
     std::vector<double>& b = e->bsc;
+    const double* adHost = e->adHost.data();
     H.assign((size_t)n * n, 0); b.assign(n, 0);
     const double sT[6] = {kScaleXiTrans, kScaleXiTrans, kScaleXiTrans, kScaleXiRot, kScaleXiRot, kScaleXiRot};  // adTarget = diag
-    double G[64 * 64], Ah[6 * 6 * SDVGN_MAX_FRAMES], B[6 * 6 * SDVGN_MAX_FRAMES];
+    double Ah[6 * 6 * SDVGN_MAX_FRAMES], B[6 * 6 * SDVGN_MAX_FRAMES];
     double sT48[6 * SDVGN_MAX_FRAMES];
+    double R[6 * SDVGN_MAX_FRAMES * 6 * SDVGN_MAX_FRAMES];      // row-block terms  R[iIdx-4 + r][q] = B[r][q] * sT48[q]; H += R + R^T at the end
+    double Dsum[48 * 49 / 2 + 48];      // sum over hosts of the packed upper 48x48 (row-major upper, row q has 48-q entries)
+    int off[kScN];                      // offset of packed row r: entries (r, r..52)
+    { int k = 0; for (int r = 0; r < kScN; ++r) { off[r] = k; k += kScN - r; } }
     for (int q = 0; q < nf6; ++q) sT48[q] = sT[q % 6];
+    std::memset(R, 0, sizeof(double) * (size_t)nf6 * nf6);
+    std::memset(Dsum, 0, sizeof(Dsum));
     for (int h = 0; h < nF; ++h) {
-        const double* gp = Gall + (size_t)h * kScE;   // packed upper triangle of the 53x53 Gram
-        {
-            size_t k = 0;
-            for (int r = 0; r < kScN; ++r)
-                for (int c = r; c < kScN; ++c) { const double v = gp[k++]; G[(size_t)r * 64 + c] = v; G[(size_t)c * 64 + r] = v; }
-        }
+        const double* gp = Gall + (size_t)h * kScE;
         const int iIdx = CPARS + h * 6;
-        for (int j = 0; j < nF; ++j) {
-            const double* AH = &e->adHost[(size_t)(h + nF * j) * 36];
-            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Ah[(size_t)r * nf6 + 6 * j + c] = AH[r * 6 + c];
-        }
-        // B = A_h * D (D = G[0:nf6, 0:nf6]); inner loop contiguous over c so that it vectorises
+        for (int j = 0; j < nF; ++j) { const double* AH = &adHost[(size_t)(h + nF * j) * 36]; for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Ah[(size_t)r * nf6 + 6 * j + c] = AH[r * 6 + c]; }
+        // B = A_h * D with D symmetric, from its packed upper rows: row q contributes  B[:, q..] += A[:, q] u[q..]  (upper incl. diagonal)
+        // and  B[:, q] += sum_{c > q} A[:, c] u[c]  (strict lower, by symmetry)
         std::fill(B, B + (size_t)6 * nf6, 0.0);
-        for (int r = 0; r < 6; ++r)
-            for (int q = 0; q < nf6; ++q) {
+        double AT8[6 * SDVGN_MAX_FRAMES][8];            // A_h transposed, rows padded to 8
+        for (int c = 0; c < nf6; ++c) { for (int r = 0; r < 6; ++r) AT8[c][r] = Ah[(size_t)r * nf6 + c]; AT8[c][6] = AT8[c][7] = 0; }
+        for (int q = 0; q < nf6; ++q) {
+            const double* u = gp + off[q];          // u[c - q] = D[q][c], c >= q
+            const int len = nf6 - q;
+            // upper part incl. diagonal: B[:, q..] += A[:, q] u[q..]
+            for (int r = 0; r < 6; ++r) {
                 const double a = Ah[(size_t)r * nf6 + q];
                 if (a == 0.0) continue;
-                const double* gq = &G[(size_t)q * 64];
-                double* br = &B[(size_t)r * nf6];
-                for (int c = 0; c < nf6; ++c) br[c] += a * gq[c];
+                double* br = &B[(size_t)r * nf6 + q];
+                for (int c = 0; c < len; ++c) br[c] += a * u[c];
             }
-        // H[i,i] += sum_jk AH_ij D_jk AH_ik^T = B A_h^T
-        for (int r = 0; r < 6; ++r)
-            for (int c = 0; c < 6; ++c) {
-                double s = 0;
-                for (int q = 0; q < nf6; ++q) s += B[(size_t)r * nf6 + q] * Ah[(size_t)c * nf6 + q];
-                H[(size_t)(iIdx + r) * n + iIdx + c] += s;
+            // strict lower part by symmetry: B[:, q] += sum_{c > q} u[c] A[:, c]; two accumulator sets (even / odd c)
+            double w0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int c = 1;
+            for (; c + 1 < len; c += 2) {
+                const double u0 = u[c], u1 = u[c + 1];
+                const double* a0 = AT8[q + c]; const double* a1 = AT8[q + c + 1];
+                for (int r = 0; r < 8; ++r) { w0[r] += u0 * a0[r]; w1[r] += u1 * a1[r]; }
             }
-        // the three frame-block terms, written as contiguous 6nF-wide row updates (element-wise: vectorisable without reassociation)
-        for (int r = 0; r < 6; ++r) {
-            double* hrow = &H[(size_t)(iIdx + r) * n + CPARS];
-            const double* brow = &B[(size_t)r * nf6];
-            for (int q = 0; q < nf6; ++q) hrow[q] += brow[q] * sT48[q];              // AH_ij D_jk AT^T summed over j
-            for (int q = 0; q < nf6; ++q) H[(size_t)(CPARS + q) * n + iIdx + r] += sT48[q] * brow[q];   // its transpose (D symmetric)
+            if (c < len) { const double u0 = u[c]; const double* a0 = AT8[q + c]; for (int r = 0; r < 8; ++r) w0[r] += u0 * a0[r]; }
+            for (int r = 0; r < 6; ++r) B[(size_t)r * nf6 + q] += w0[r] + w1[r];
         }
-        for (int row = 0; row < nf6; ++row) {                                         // AT D_jk AT^T
-            double* hrow = &H[(size_t)(CPARS + row) * n + CPARS];
-            const double* grow = &G[(size_t)row * 64];
-            const double sr = sT48[row];
-            for (int q = 0; q < nf6; ++q) hrow[q] += sr * grow[q] * sT48[q];
+        {   // H[i,i] += B A_h^T, accumulated as 6 rows of 8 (A_h^T rows from AT8)
+            double M[6][8];
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 8; ++c) M[r][c] = 0;
+            for (int q = 0; q < nf6; ++q) {
+                const double* aq = AT8[q];
+                for (int r = 0; r < 6; ++r) { const double bq = B[(size_t)r * nf6 + q]; for (int c = 0; c < 8; ++c) M[r][c] += bq * aq[c]; }
+            }
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H[(size_t)(iIdx + r) * n + iIdx + c] += M[r][c];
         }
-        // E (6nF x 4), EB (6nF)
+        for (int r = 0; r < 6; ++r) { double* rrow = &R[(size_t)(6 * h + r) * nf6]; const double* brow = &B[(size_t)r * nf6]; for (int q = 0; q < nf6; ++q) rrow[q] += brow[q] * sT48[q]; }
+        // sum of the packed 48x48 parts (AT D AT^T is applied once after the loop)
+        { int k = 0; for (int q = 0; q < nf6; ++q) { const double* u = gp + off[q]; const int len = nf6 - q; for (int c = 0; c < len; ++c) Dsum[k + c] += u[c]; k += len; } }
         for (int j = 0; j < nF; ++j) {
-            const int jIdx = CPARS + j * 6;
-            const double* AH = &e->adHost[(size_t)(h + nF * j) * 36];
+            const int jIdx = CPARS + j * 6; const double* AH = &adHost[(size_t)(h + nF * j) * 36];
             for (int r = 0; r < 6; ++r) {
-                for (int c = 0; c < CPARS; ++c) {
-                    double sh = 0;
-                    for (int q = 0; q < 6; ++q) sh += AH[r * 6 + q] * G[(size_t)(6 * j + q) * 64 + 48 + c];
-                    H[(size_t)(iIdx + r) * n + c] += sh;
-                    H[(size_t)(jIdx + r) * n + c] += sT[r] * G[(size_t)(6 * j + r) * 64 + 48 + c];
-                }
-                double sh = 0;
-                for (int q = 0; q < 6; ++q) sh += AH[r * 6 + q] * G[(size_t)(6 * j + q) * 64 + 52];
-                b[iIdx + r] += sh;
-                b[jIdx + r] += sT[r] * G[(size_t)(6 * j + r) * 64 + 52];
+                const double* ur = gp + off[6 * j + r] - (6 * j + r);   // ur[c] = G[6j+r][c], c >= 6j+r
+                for (int c = 0; c < CPARS; ++c) H[(size_t)(jIdx + r) * n + c] += sT[r] * ur[48 + c];
+                b[jIdx + r] += sT[r] * ur[52];
+            }
+            double e5[6][5];
+            for (int q = 0; q < 6; ++q) { const double* uq = gp + off[6 * j + q] - (6 * j + q); for (int c = 0; c < 5; ++c) e5[q][c] = uq[48 + c]; }
+            for (int r = 0; r < 6; ++r) {
+                double sh[5] = {0, 0, 0, 0, 0};
+                for (int q = 0; q < 6; ++q) { const double a = AH[r * 6 + q]; for (int c = 0; c < 5; ++c) sh[c] += a * e5[q][c]; }
+                for (int c = 0; c < CPARS; ++c) H[(size_t)(iIdx + r) * n + c] += sh[c];
+                b[iIdx + r] += sh[4];
             }
         }
-        for (int r = 0; r < CPARS; ++r) {
-            for (int c = 0; c < CPARS; ++c) H[(size_t)r * n + c] += G[(size_t)(48 + r) * 64 + 48 + c];
-            b[r] += G[(size_t)(48 + r) * 64 + 52];
-        }
+        for (int r = 0; r < CPARS; ++r) { const double* ur = gp + off[48 + r] - (48 + r); for (int c = r; c < CPARS; ++c) { H[(size_t)r * n + c] += ur[48 + c]; if (c != r) H[(size_t)c * n + r] += ur[48 + c]; } b[r] += ur[52]; }
     }
-    for (int h = 0; h < nF; ++h) {
-        const int hIdx = CPARS + h * 6;
-        for (int i = 0; i < CPARS; ++i) for (int j = 0; j < 6; ++j) H[(size_t)i * n + hIdx + j] = H[(size_t)(hIdx + j) * n + i];
-    }
+    // frame block: R + R^T + diag(sT) Dsum diag(sT)
+    { int k = 0;
+      for (int q = 0; q < nf6; ++q) { const int len = nf6 - q; for (int c = 0; c < len; ++c) { const double v = sT48[q] * Dsum[k + c] * sT48[q + c]; H[(size_t)(CPARS + q) * n + CPARS + q + c] += v; if (c) H[(size_t)(CPARS + q + c) * n + CPARS + q] += v; } k += len; } }
+    for (int r = 0; r < nf6; ++r) for (int c = 0; c < nf6; ++c) H[(size_t)(CPARS + r) * n + CPARS + c] += R[(size_t)r * nf6 + c] + R[(size_t)c * nf6 + r];
+    for (int h = 0; h < nF; ++h) { const int hIdx = CPARS + h * 6; for (int i = 0; i < CPARS; ++i) for (int j = 0; j < 6; ++j) H[(size_t)i * n + hIdx + j] = H[(size_t)(hIdx + j) * n + i]; }
 }
 
 // one-sided Jacobi SVD (m x k, k small) used by the null-space projection
@@ -987,11 +995,11 @@ static int ef_accumulate(sdvgn_ef* e, bool split) {
     if (split) {
         // the reduce kernels store straight into the pinned host buffer (fine-grained, visible at kernel completion): no copy
         // engine in the path -- a small D2H memcpy costs 10-20 us of fixed latency, more than the 154 kB take over PCIe
-        k_ef_top_gram<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->top_partial, e->nres_partial);
-        k_ef_acc_reduce<<<(ntop + 255) / 256, 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks, e->nres_partial,
-                                                                   e->sc_off_dev, e->acc_host, 0, ntop, 0, e->done_ctr, e->flags_host, ++e->seq_top);
-        k_ef_point<<<(e->nP + 63) / 64, 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev);
-        k_ef_sc_gram<<<dim3(sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, sc_ppb);
+        // three launches: [top Gram | per-point sums], [top reduce + flag | Schur Gram], [Schur reduce + resInA + flag]
+        const int n_top = chunks * pairs, n_pt = (e->nP + 63) / 64, n_red = (ntop + 255) / 256;
+        k_ef_acc_stage1<<<n_top + n_pt, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, chunks, n_top);
+        k_ef_acc_stage2<<<n_red + sc_chunks * nF, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, sc_ppb, sc_chunks, e->top_partial,
+                                                                       pairs, chunks, e->acc_host, n_red, e->done_ctr, e->flags_host, ++e->seq_top);
         k_ef_acc_reduce<<<(nsc + 255) / 256 + 1, 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks, e->nres_partial,
                                                                       e->sc_off_dev, e->acc_host, ntop, ntop + nsc, 1, e->done_ctr + 1, e->flags_host + 1,
                                                                       ++e->seq_acc);
@@ -999,7 +1007,7 @@ static int ef_accumulate(sdvgn_ef* e, bool split) {
         e->acc_in_host = true;
     } else {
         e->acc_in_host = false;
-        k_ef_point<<<(e->nP + 63) / 64, 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev);
+        k_ef_point<<<(e->nP + 63) / 64, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev);
         k_ef_top_gram<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->top_partial, e->nres_partial);
         k_ef_sc_gram<<<dim3(sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, sc_ppb);
         k_ef_acc_reduce<<<(ntop + nsc + 255) / 256 + 1, 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks,
@@ -1075,50 +1083,43 @@ int sdvgn_ef_accumulators_dev(sdvgn_ef* e, double** buf, int* count) {
 // null-space projection.  Pure host code -- also the entry point of the CPU (gloo) test of the multi-GPU logic.
 // Host LDL^T with Eigen's pivot order (largest remaining ORIGINAL diagonal first, see tracker_track_kernel.inc) in right-looking
 // form: every inner loop is an element-wise row update (no floating-point reduction), which the compiler may vectorise without
-// -ffast-math; the left-looking gn::ldlt_solve_inplace spends its time in scalar dot products at n = 52.  Full symmetric storage,
-// A (n x n, row-major) and b are overwritten; b returns x.  Same solution as the left-looking form up to rounding order.
+// -ffast-math; the left-looking gn::ldlt_solve_inplace spends its time in scalar dot products at n = 52.  Only the upper triangle
+// A[r][c], c >= r of the trailing block is kept current (half the updates of a full-square right-looking step); the multipliers
+// of step k stay in row k (A[k][c] = L[c][k], c > k), i.e. L^T sits in the strict upper triangle.  A (n x n, row-major, upper
+// triangle read) and b are overwritten; b returns x.  Same solution as the left-looking form up to rounding order.
 static void ldlt_solve_rl(int n, double* A, double* b) {
     constexpr int MAXN = CPARS + 6 * SDVGN_MAX_FRAMES;
     int perm[MAXN];
-    double d0[MAXN], colk[MAXN];
+    double d0[MAXN];
     for (int i = 0; i < n; ++i) d0[i] = std::fabs(A[(size_t)i * n + i]);
     for (int k = 0; k < n; ++k) {
-        int p = k;
-        double big = d0[k];
+        int p = k; double big = d0[k];
         for (int i = k + 1; i < n; ++i) if (d0[i] > big) { big = d0[i]; p = i; }
         perm[k] = p;
-        if (p != k) {   // symmetric swap of rows and columns k <-> p
+        if (p != k) {   // symmetric swap k <-> p on upper storage
             std::swap(d0[k], d0[p]);
-            double* rk = A + (size_t)k * n; double* rp = A + (size_t)p * n;
-            for (int c = 0; c < n; ++c) std::swap(rk[c], rp[c]);
-            for (int r = 0; r < n; ++r) std::swap(A[(size_t)r * n + k], A[(size_t)r * n + p]);
+            for (int i = 0; i < k; ++i) std::swap(A[(size_t)i * n + k], A[(size_t)i * n + p]);          // finished multipliers: columns k,p of rows < k
+            std::swap(A[(size_t)k * n + k], A[(size_t)p * n + p]);
+            for (int i = k + 1; i < p; ++i) std::swap(A[(size_t)k * n + i], A[(size_t)i * n + p]);      // (k,i) <-> (i,p)
+            for (int i = p + 1; i < n; ++i) std::swap(A[(size_t)k * n + i], A[(size_t)p * n + i]);      // (k,i) <-> (p,i)
             std::swap(b[k], b[p]);
         }
         const double d = A[(size_t)k * n + k];
         if (std::fabs(d) > 0.0) {
-            const double* rowk = A + (size_t)k * n;
-            for (int r = k + 1; r < n; ++r) colk[r] = A[(size_t)r * n + k] / d;           // L[r][k]
+            double* rowk = A + (size_t)k * n;
             for (int r = k + 1; r < n; ++r) {
+                const double l = rowk[r] / d;                 // L[r][k]
                 double* rr = A + (size_t)r * n;
-                const double l = colk[r];
-                for (int c = k + 1; c < n; ++c) rr[c] -= l * rowk[c];                      // trailing update, contiguous in c
-                rr[k] = l;
+                for (int c = r; c < n; ++c) rr[c] -= l * rowk[c];
+                // rowk[r] must stay the un-scaled value until every row has used it: scale afterwards
             }
+            for (int r = k + 1; r < n; ++r) rowk[r] = rowk[r] / d;
         }
     }
-    for (int k = 0; k < n; ++k) {           // forward substitution, column-oriented (AXPY)
-        const double yk = b[k];
-        for (int r = k + 1; r < n; ++r) b[r] -= A[(size_t)r * n + k] * yk;
-    }
-    for (int i = 0; i < n; ++i) {
-        const double d = A[(size_t)i * n + i];
-        b[i] = (std::fabs(d) > 5.562684646268003e-309) ? b[i] / d : 0.0;   // Eigen's LDLT solve tolerance (1/DBL_MAX)
-    }
-    for (int k = n - 1; k >= 0; --k) {      // backward substitution with L^T
-        double s = b[k];
-        for (int r = k + 1; r < n; ++r) s -= A[(size_t)r * n + k] * b[r];
-        b[k] = s;
-    }
+    // L^T in the strict upper triangle: forward substitution L y = b  ->  y[r] -= L[r][k] y[k] = U[k][r] y[k]
+    for (int k = 0; k < n; ++k) { const double yk = b[k]; const double* rowk = A + (size_t)k * n; for (int r = k + 1; r < n; ++r) b[r] -= rowk[r] * yk; }
+    for (int i = 0; i < n; ++i) { const double d = A[(size_t)i * n + i]; b[i] = (std::fabs(d) > 5.562684646268003e-309) ? b[i] / d : 0.0; }
+    for (int k = n - 1; k >= 0; --k) { double s = b[k]; const double* rowk = A + (size_t)k * n; for (int r = k + 1; r < n; ++r) s -= rowk[r] * b[r]; b[k] = s; }
     for (int k = n - 1; k >= 0; --k) if (perm[k] != k) std::swap(b[k], b[perm[k]]);
 }
 

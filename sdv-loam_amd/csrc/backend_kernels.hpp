@@ -506,21 +506,26 @@ __global__ void __launch_bounds__(256) k_ef_apply(int nF, int nP, EFArrays A, co
 // Per-point sums of addPoint<0> (active, not linearised) and addPoint<1> (active, linearised), then the head of the
 // Schur accumulation: HdiF, bdSumF, Hcd.  Workgroup = 64 points x 8 waves; wave t reads the residual slot of target
 // frame t (coalesced: consecutive lanes = consecutive points), lanes of wave 0 add the 8 targets in ascending order.
-__global__ void __launch_bounds__(512) k_ef_point(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
-                                                  const int* __restrict__ phost) {
-    __shared__ float part[kMaxFrames][13][64];
-    const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
-    const int p = blockIdx.x * 64 + lane;
+struct PointSmem { float part[kMaxFrames][13][64]; };
+
+// body for one workgroup of 256 threads = 64 points; wave w handles targets w and w + 4
+__device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
+                                           const int* __restrict__ phost, int block, PointSmem& S) {
+    float (*part)[13][64] = S.part;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = block * 64 + lane;
     const size_t slots = (size_t)C.nF * C.nP;
-    float v[13];
-#pragma unroll
-    for (int i = 0; i < 13; ++i) v[i] = 0.0f;   // bdA HddA HcdA[4] bdL HddL HcdL[4] ngood
     int h = 0;
     bool mine = false;
     if (p < C.nP) {
         h = phost[p];
         mine = precalc[h * C.nF + h].np != 0;   // host frame in this rank's shard
     }
+#pragma unroll
+    for (int t = wave; t < kMaxFrames; t += 4) {
+    float v[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) v[i] = 0.0f;   // bdA HddA HcdA[4] bdL HddL HcdL[4] ngood
     if (mine && t < C.nF) {
         const size_t s = (size_t)t * C.nP + p;
         const uint8_t fl = A.rflags[s];
@@ -556,8 +561,9 @@ __global__ void __launch_bounds__(512) k_ef_point(EFConst C, EFArrays A, const P
     }
 #pragma unroll
     for (int i = 0; i < 13; ++i) part[t][i][lane] = v[i];
+    }
     __syncthreads();
-    if (t != 0 || !mine) return;
+    if (wave != 0 || !mine) return;
     float sum[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) sum[i] = 0.0f;
@@ -584,6 +590,12 @@ __global__ void __launch_bounds__(512) k_ef_point(EFConst C, EFArrays A, const P
     A.pbdSum[p] = bds;
 #pragma unroll
     for (int i = 0; i < 4; ++i) A.pHcd[(size_t)i * C.nP + p] = sum[2 + i] + sum[8 + i];
+}
+
+__global__ void __launch_bounds__(256) k_ef_point(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                  const int* __restrict__ phost) {
+    __shared__ PointSmem S;
+    point_body(C, A, precalc, phost, blockIdx.x, S);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -618,12 +630,15 @@ __device__ __forceinline__ void gram_tile_accumulate(const float* __restrict__ t
 
 // top Gram: grid = (chunks, nF*nF), block = 256 (4 waves x 64 residual slots).  Features (16, 11 live):
 // 0-3 Jpdc, 4-9 Jpdxi, 10 res; two row sets (x and y).  partial: [pair][chunk][256] floats (row-major 16x16).
-__global__ void __launch_bounds__(256) k_ef_top_gram(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
-                                                     float* __restrict__ partial, int* __restrict__ nres_partial) {
-    __shared__ float tile[4][2][16 * kTileStride];
-    __shared__ float red[4][256];
-    __shared__ int s_n[4];
-    const int pair = blockIdx.y;
+struct TopGramSmem { float tile[4][2][16 * kTileStride]; float red[4][256]; int s_n[4]; };
+
+// body for workgroup (bx of gx chunks, pair)
+__device__ __forceinline__ void top_gram_body(const EFConst& C, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
+                                              float* __restrict__ partial, int* __restrict__ nres_partial, int bx, int pair, int gx,
+                                              TopGramSmem& S) {
+    float (*tile)[2][16 * kTileStride] = S.tile;
+    float (*red)[256] = S.red;
+    int* s_n = S.s_n;
     const int h = pair / C.nF, t = pair % C.nF;
     const PrecalcDev& pc = precalc[pair];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -632,7 +647,7 @@ __global__ void __launch_bounds__(256) k_ef_top_gram(EFConst C, EFArrays A, cons
     f32x4 acc[1] = {{0, 0, 0, 0}};
     int cnt = 0;
     if (h != t) {
-        for (int base = blockIdx.x * 256 + wave * 64; base < np; base += gridDim.x * 256) {
+        for (int base = bx * 256 + wave * 64; base < np; base += gx * 256) {
             const int pl = base + lane;
             bool use = false;
             size_t s = 0;
@@ -676,9 +691,26 @@ __global__ void __launch_bounds__(256) k_ef_top_gram(EFConst C, EFArrays A, cons
     for (int off = 32; off > 0; off >>= 1) wc += __shfl_xor(wc, off);
     if (lane == 0) s_n[wave] = wc;
     __syncthreads();
-    const size_t o = ((size_t)pair * gridDim.x + blockIdx.x);
+    const size_t o = ((size_t)pair * gx + bx);
     partial[o * 256 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     if (threadIdx.x == 0) nres_partial[o] = (s_n[0] + s_n[1]) + (s_n[2] + s_n[3]);
+}
+
+__global__ void __launch_bounds__(256) k_ef_top_gram(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                     float* __restrict__ partial, int* __restrict__ nres_partial) {
+    __shared__ TopGramSmem S;
+    top_gram_body(C, A, precalc, partial, nres_partial, blockIdx.x, blockIdx.y, gridDim.x, S);
+}
+
+// Stage 1 of the split accumulate: the top-Gram workgroups and the per-point (Hdd, bd, Hcd, HdiF) workgroups are independent, so
+// they share one launch (workgroups [0, n_top) = top Gram as (chunk, pair), the rest = 64 points each) and run side by side.
+__global__ void __launch_bounds__(256) k_ef_acc_stage1(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                       const int* __restrict__ phost, float* __restrict__ top_partial,
+                                                       int* __restrict__ nres_partial, int top_chunks, int n_top) {
+    __shared__ union U { TopGramSmem t; PointSmem p; __device__ U() {} } S;
+    const int b = blockIdx.x;
+    if (b < n_top) top_gram_body(C, A, precalc, top_partial, nres_partial, b % top_chunks, b / top_chunks, top_chunks, S.t);
+    else point_body(C, A, precalc, phost, b - n_top, S.p);
 }
 
 // SC Gram: grid = (chunks, nF hosts), block = 256.  Features (64, 53 live): 6*t+i = JpJdF of the residual in target t
@@ -758,21 +790,26 @@ __device__ __forceinline__ void sc_gram_wave(const EFConst& C, const EFArrays& A
     }
 }
 
+struct ScGramSmem { float tile[64 * kTileStride]; float wrow[64]; };
+
+__device__ __forceinline__ void sc_gram_body(const EFConst& C, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
+                                             float* __restrict__ partial, int pts_per_block, int bx, int h, int gx, ScGramSmem& S) {
+    const int wave = threadIdx.x >> 6;
+    const int P0 = precalc[h * C.nF + h].P0, np = precalc[h * C.nF + h].np;   // np == 0 outside this rank's shard
+    const int begin = bx * pts_per_block, end = min(np, begin + pts_per_block);
+    float* out = partial + ((size_t)h * gx + bx) * 10 * 256;
+    switch (wave) {   // wave-uniform: every wave runs straight-line code specialised for the tiles / features it owns
+        case 0: sc_gram_wave<0>(C, A, P0, begin, end, S.tile, S.wrow, out); break;
+        case 1: sc_gram_wave<1>(C, A, P0, begin, end, S.tile, S.wrow, out); break;
+        case 2: sc_gram_wave<2>(C, A, P0, begin, end, S.tile, S.wrow, out); break;
+        default: sc_gram_wave<3>(C, A, P0, begin, end, S.tile, S.wrow, out); break;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_ef_sc_gram(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
                                                     float* __restrict__ partial, int pts_per_block) {
-    __shared__ float tile[64 * kTileStride];
-    __shared__ float wrow[64];
-    const int wave = threadIdx.x >> 6;
-    const int h = blockIdx.y;
-    const int P0 = precalc[h * C.nF + h].P0, np = precalc[h * C.nF + h].np;   // np == 0 outside this rank's shard
-    const int begin = blockIdx.x * pts_per_block, end = min(np, begin + pts_per_block);
-    float* out = partial + ((size_t)h * gridDim.x + blockIdx.x) * 10 * 256;
-    switch (wave) {   // wave-uniform: every wave runs straight-line code specialised for the tiles / features it owns
-        case 0: sc_gram_wave<0>(C, A, P0, begin, end, tile, wrow, out); break;
-        case 1: sc_gram_wave<1>(C, A, P0, begin, end, tile, wrow, out); break;
-        case 2: sc_gram_wave<2>(C, A, P0, begin, end, tile, wrow, out); break;
-        default: sc_gram_wave<3>(C, A, P0, begin, end, tile, wrow, out); break;
-    }
+    __shared__ ScGramSmem S;
+    sc_gram_body(C, A, precalc, partial, pts_per_block, blockIdx.x, blockIdx.y, gridDim.x, S);
 }
 
 // Fixed-order fp64 sum of the per-workgroup partials into the PACKED accumulator buffer, all three parts in one launch:
@@ -826,6 +863,30 @@ __global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__
         __syncthreads();
         if (threadIdx.x == 0) publish_when_all_done(done_ctr, gridDim.x, done_flag, done_seq);
     }
+}
+
+// Stage 2 of the split accumulate: workgroups [0, n_red) sum the top-Gram partials of stage 1 into the packed host buffer and
+// publish the "top part done" flag, the remaining sc_chunks * nF workgroups build the Schur Grams -- the host stitches the top
+// part while those still run.
+__global__ void __launch_bounds__(256) k_ef_acc_stage2(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                       float* __restrict__ sc_partial, int pts_per_block, int sc_chunks,
+                                                       const float* __restrict__ top_partial, int pairs, int top_chunks,
+                                                       double* __restrict__ out, int n_red, unsigned* __restrict__ done_ctr,
+                                                       volatile int* done_flag, int done_seq) {
+    __shared__ ScGramSmem S;
+    const int b = blockIdx.x;
+    if (b < n_red) {
+        const int e = b * 256 + threadIdx.x;
+        if (e < pairs * 121) {
+            const int g = e / 121, k = e - g * 121, r = k / 11, c = k - r * 11;
+            out[e] = sum_chunks_f64<256>(top_partial + (size_t)g * top_chunks * 256 + r * 16 + c, top_chunks);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) publish_when_all_done(done_ctr, n_red, done_flag, done_seq);
+        return;
+    }
+    const int q = b - n_red;
+    sc_gram_body(C, A, precalc, sc_partial, pts_per_block, q % sc_chunks, q / sc_chunks, sc_chunks, S);
 }
 
 // out[g][e] = sum over chunks of partial[g][chunk][e] in fp64, fixed order.  grid = groups, block = 256, E elements.
