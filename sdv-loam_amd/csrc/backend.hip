@@ -1007,8 +1007,8 @@ static int ef_accumulate(sdvgn_ef* e, bool split) {
         e->acc_in_host = true;
     } else {
         e->acc_in_host = false;
-        k_ef_point<<<(e->nP + 63) / 64, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev);
-        k_ef_top_gram<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->top_partial, e->nres_partial);
+        const int n_top = chunks * pairs, n_pt = (e->nP + 63) / 64;
+        k_ef_acc_stage1<<<n_top + n_pt, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, chunks, n_top);
         k_ef_sc_gram<<<dim3(sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, sc_ppb);
         k_ef_acc_reduce<<<(ntop + nsc + 255) / 256 + 1, 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks,
                                                                              e->nres_partial, e->sc_off_dev, e->acc_dev, 0, ntop + nsc, 1, nullptr, nullptr, 0);
@@ -1127,6 +1127,11 @@ static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, d
     const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
     g_pt.start();
     stitch_top(e, acc);
+    // bM_top = bM + HM * delta (needs no accumulator: done before waiting for the Schur part)
+    std::vector<double> d(n), bM_top(n);
+    for (int i = 0; i < CPARS; ++i) d[i] = (double)e->C.cDeltaF[i];
+    for (int h = 0; h < nF; ++h) for (int i = 0; i < 6; ++i) d[CPARS + 6 * h + i] = e->frames[h].delta[i];
+    for (int i = 0; i < n; ++i) { double a = 0; for (int j = 0; j < n; ++j) a += e->HM[(size_t)i * n + j] * d[j]; bM_top[i] = e->bM[i] + a; }
     g_pt.stop(PT_STITCH_TOP);
     if (e->split_pending) {   // the SC accumulators were still being produced while the top part was stitched
         HIPCHK(wait_flag(e->flags_host + 1, e->seq_acc, e->stream));
@@ -1136,11 +1141,7 @@ static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, d
     e->resInA = (int)acc[acc_count(e) - 1];
     stitch_sc(e, acc + (size_t)pairs * kTopE);
     g_pt.stop(PT_STITCH_SC);
-    // bM_top = bM + HM * delta ; HFinal = HA + HM - Hsc ; bFinal = bA + bM_top - bsc   (EnergyFunctional.cpp:668-699)
-    std::vector<double> d(n), bM_top(n);
-    for (int i = 0; i < CPARS; ++i) d[i] = (double)e->C.cDeltaF[i];
-    for (int h = 0; h < nF; ++h) for (int i = 0; i < 6; ++i) d[CPARS + 6 * h + i] = e->frames[h].delta[i];
-    for (int i = 0; i < n; ++i) { double a = 0; for (int j = 0; j < n; ++j) a += e->HM[(size_t)i * n + j] * d[j]; bM_top[i] = e->bM[i] + a; }
+    // HFinal = HA + HM - Hsc ; bFinal = bA + bM_top - bsc   (EnergyFunctional.cpp:668-699)
     e->HFinal.resize((size_t)n * n); e->bFinal.resize(n);
     for (size_t i = 0; i < (size_t)n * n; ++i) e->HFinal[i] = e->HA[i] + e->HM[i] - e->Hsc[i];
     for (int i = 0; i < n; ++i) e->bFinal[i] = e->bA[i] + bM_top[i] - e->bsc[i];

@@ -4,11 +4,14 @@
 //                        projectPoint (both overloads)             src/FullSystem/ResidualProjections.h:20-59
 //   k_ef_apply       b1  PointFrameResidual::applyRes(true)        src/FullSystem/Residuals.cpp:252-275
 //                        EFResidual::takeDataF                     src/OptimizationBackend/EnergyFunctionalStructs.cpp:15-25
-//   k_ef_point       b2  per-point part of addPoint<0>/<1>         src/OptimizationBackend/AccumulatedTopHessian.cpp:26-110
+//   point_body       b2  per-point part of addPoint<0>/<1>         src/OptimizationBackend/AccumulatedTopHessian.cpp:26-110
 //                    b7  head of AccumulatedSCHessianSSE::addPoint src/OptimizationBackend/AccumulatedSCHessian.cpp:10-37
-//   k_ef_top_gram    b2  acc[h,t].update/updateTopRight/BotRight   AccumulatedTopHessian.cpp:68-82 (AccumulatorApprox, b3)
-//   k_ef_sc_gram     b7  accD / accE / accEB / accHcc / accbc      AccumulatedSCHessian.cpp:39-61
-//   k_ef_gram_reduce     fixed-order fp64 sum of the per-workgroup partial Gram tiles
+//   top_gram_body    b2  acc[h,t].update/updateTopRight/BotRight   AccumulatedTopHessian.cpp:68-82 (AccumulatorApprox, b3)
+//   sc_gram_body     b7  accD / accE / accEB / accHcc / accbc      AccumulatedSCHessian.cpp:39-61
+//   k_ef_acc_stage1      launch 1 of an accumulate: top_gram_body workgroups | point_body workgroups (independent, side by side)
+//   k_ef_acc_stage2      launch 2: fp64 reduce of the top partials (+ "top done" flag) | sc_gram_body workgroups
+//   k_ef_sc_gram         sc_gram_body alone (sharded path, where one combined reduce follows)
+//   k_ef_acc_reduce      fixed-order fp64 sum of the per-workgroup partial Gram tiles into the packed accumulator buffer
 //   k_ef_resubstitute b6 EnergyFunctional::resubstituteFPt         src/OptimizationBackend/EnergyFunctional.cpp:250-282
 //   k_ef_step            doStepFromBackup / loadSateBackup on the per-point idepths  FullSystemOptimize.cpp:165-262
 //
@@ -475,32 +478,42 @@ __global__ void __launch_bounds__(64) k_ef_optimize_immature(EFConst C, const fl
         if (t < nF) res_state[(size_t)i * nF + t] = (t == hst) ? -1 : res[t].state_state;
 }
 
-// applyRes(true): one thread per slot
+// applyRes(true): one thread per slot.  All per-slot inputs are loaded up front (independent loads, one round trip) and the J
+// planes of the buffer the flip would select right behind the flags, so that the kernel is two memory round trips deep instead
+// of six; which values are used is decided afterwards.
 __global__ void __launch_bounds__(256) k_ef_apply(int nF, int nP, EFArrays A, const PrecalcDev* __restrict__ precalc,
                                                   const int* __restrict__ phost) {
     const size_t slots = (size_t)nF * nP;
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= slots) return;
     const int hh = phost[s % nP];
-    if (precalc[hh * nF + hh].np == 0) return;   // host frame not in this rank's shard
     uint8_t fl = A.rflags[s];
-    if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED)) return;
-    if (A.rstate[s] == RS_OOB) return;
+    const int st = A.rstate[s];
     const int sn = A.rstate_new[s];
+    const float en = A.renergy_new[s];
+    __builtin_amdgcn_sched_barrier(0);
+    const int np_h = precalc[hh * nF + hh].np;
+    const int buf = (fl & RF_SEL) ? 0 : 1;              // the buffer the residual's freshly linearised J sits in
+    const float* Je = A.J + (size_t)buf * kJPlanes * slots + s;
+    float jx[6], jy[6];
+    const float d0 = Je[22 * slots], d1 = Je[23 * slots];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { jx[i] = Je[(2 + i) * slots]; jy[i] = Je[(8 + i) * slots]; }
+    __builtin_amdgcn_sched_barrier(0);
+    if (np_h == 0) return;   // host frame not in this rank's shard
+    if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED)) return;
+    if (st == RS_OOB) return;
     if (sn == RS_IN) {
         fl |= RF_ACTIVE;
         fl ^= RF_SEL;                                   // takeDataF: swap J with the residual's freshly linearised J
-        const int buf = (fl & RF_SEL) ? 1 : 0;
-        const float* Je = A.J + (size_t)buf * kJPlanes * slots + s;
-        const float d0 = Je[22 * slots], d1 = Je[23 * slots];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) A.JpJd[(size_t)i * slots + s] = Je[(2 + i) * slots] * d0 + Je[(8 + i) * slots] * d1;
+        for (int i = 0; i < 6; ++i) A.JpJd[(size_t)i * slots + s] = jx[i] * d0 + jy[i] * d1;
     } else {
         fl &= (uint8_t)~RF_ACTIVE;
     }
     A.rflags[s] = fl;
     A.rstate[s] = (int8_t)sn;
-    A.renergy[s] = A.renergy_new[s];
+    A.renergy[s] = en;
 }
 
 // Per-point sums of addPoint<0> (active, not linearised) and addPoint<1> (active, linearised), then the head of the
@@ -590,12 +603,6 @@ __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, 
     A.pbdSum[p] = bds;
 #pragma unroll
     for (int i = 0; i < 4; ++i) A.pHcd[(size_t)i * C.nP + p] = sum[2 + i] + sum[8 + i];
-}
-
-__global__ void __launch_bounds__(256) k_ef_point(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
-                                                  const int* __restrict__ phost) {
-    __shared__ PointSmem S;
-    point_body(C, A, precalc, phost, blockIdx.x, S);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -696,12 +703,6 @@ __device__ __forceinline__ void top_gram_body(const EFConst& C, const EFArrays& 
     if (threadIdx.x == 0) nres_partial[o] = (s_n[0] + s_n[1]) + (s_n[2] + s_n[3]);
 }
 
-__global__ void __launch_bounds__(256) k_ef_top_gram(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
-                                                     float* __restrict__ partial, int* __restrict__ nres_partial) {
-    __shared__ TopGramSmem S;
-    top_gram_body(C, A, precalc, partial, nres_partial, blockIdx.x, blockIdx.y, gridDim.x, S);
-}
-
 // Stage 1 of the split accumulate: the top-Gram workgroups and the per-point (Hdd, bd, Hcd, HdiF) workgroups are independent, so
 // they share one launch (workgroups [0, n_top) = top Gram as (chunk, pair), the rest = 64 points each) and run side by side.
 __global__ void __launch_bounds__(256) k_ef_acc_stage1(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
@@ -747,11 +748,11 @@ __device__ __forceinline__ void sc_gram_wave(const EFConst& C, const EFArrays& A
             float v = 0.0f;
             if (f < 48) {
                 const int t = f / 6, i = f - 6 * t;
-                if (in && t < C.nF) {
-                    const size_t s = (size_t)t * C.nP + p;
-                    const uint8_t fl = A.rflags[s];
-                    if ((fl & RF_EXISTS) && (fl & RF_ACTIVE)) v = A.JpJd[(size_t)i * slots + s];
-                }
+                const bool ok = in && t < C.nF;
+                const size_t s = ok ? (size_t)t * C.nP + p : 0;   // flag and value loaded side by side (one round trip), selected afterwards
+                const uint8_t fl = A.rflags[s];
+                const float jv = A.JpJd[(size_t)i * slots + s];
+                if (ok && (fl & RF_EXISTS) && (fl & RF_ACTIVE)) v = jv;
             } else if (f < 52) {
                 if (in) v = A.pHcd[(size_t)(f - 48) * C.nP + p];
             } else if (f == 52) {
@@ -915,28 +916,43 @@ __global__ void __launch_bounds__(512) k_ef_resubstitute(EFConst C, EFArrays A, 
                                                          float* __restrict__ pid_w, float* __restrict__ pidz_w, float* __restrict__ pdeltaF_w) {
     __shared__ float part[kMaxFrames][2][64];
     __shared__ float sx[4 + kMaxFrames * kMaxFrames * 6];
-    // one pass over the argument block into LDS (the per-lane host index below would otherwise turn every use into a
-    // vector load from the kernel-argument segment)
-    if (threadIdx.x < 4 + kMaxFrames * kMaxFrames * 6) sx[threadIdx.x] = reinterpret_cast<const float*>(&X)[threadIdx.x];
-    __syncthreads();
-    const float* xc = sx;
-    const float* xAd = sx + 4;
     const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
     const int p = blockIdx.x * 64 + lane;
     const size_t slots = (size_t)C.nF * C.nP;
-    int h = 0;
-    bool mine = false;
-    if (p < C.nP) { h = phost[p]; mine = precalc[h * C.nF + h].np != 0; }
+    const bool inP = p < C.nP;
+    const bool slot_ok = inP && t < C.nF;
+    // every global input of this thread up front (independent loads; all slots / points have storage behind them), the
+    // dependent decisions afterwards: two memory round trips instead of five
+    const size_t s = slot_ok ? (size_t)t * C.nP + p : 0;
+    const int h = inP ? phost[p] : 0;
+    const uint8_t fl = A.rflags[s];
+    float jp[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) jp[i] = A.JpJd[(size_t)i * slots + s];
+    float bsum = 0, hca[4] = {0, 0, 0, 0}, hdi = 0, pidv = 0;
+    uint8_t sens = 0;
+    if (t == 0 && inP) {
+        bsum = A.pbdSum[p];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hca[i] = A.pHcdA[(size_t)i * C.nP + p];
+        hdi = A.pHdi[p]; pidv = A.pid[p]; sens = A.psensor[p];
+    }
+    // one pass over the argument block into LDS (the per-lane host index below would otherwise turn every use into a
+    // vector load from the kernel-argument segment)
+    if (threadIdx.x < 4 + kMaxFrames * kMaxFrames * 6) sx[threadIdx.x] = reinterpret_cast<const float*>(&X)[threadIdx.x];
+    __builtin_amdgcn_sched_barrier(0);
+    const bool mine = inP && precalc[h * C.nF + h].np != 0;
+    __syncthreads();
+    const float* xc = sx;
+    const float* xAd = sx + 4;
     float dotv = 0.0f, good = 0.0f;
     if (mine && t < C.nF) {
-        const size_t s = (size_t)t * C.nP + p;
-        const uint8_t fl = A.rflags[s];
         if ((fl & RF_EXISTS) && (fl & RF_ACTIVE)) {
             good = 1.0f;
             const float* xa = xAd + (size_t)(C.nF * h + t) * 6;
             float sum = 0;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) sum += xa[i] * A.JpJd[(size_t)i * slots + s];
+            for (int i = 0; i < 6; ++i) sum += xa[i] * jp[i];
             dotv = sum;
         }
     }
@@ -945,19 +961,19 @@ __global__ void __launch_bounds__(512) k_ef_resubstitute(EFConst C, EFArrays A, 
     if (t != 0) return;
     double s2 = 0, sa = 0;
     if (mine) {
-        float b = A.pbdSum[p];
+        float b = bsum;
         float dot = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dot += xc[i] * A.pHcdA[(size_t)i * C.nP + p];
+        for (int i = 0; i < 4; ++i) dot += xc[i] * hca[i];
         b -= dot;
         float ngood = 0;
         for (int tt = 0; tt < C.nF; ++tt) {
             if (part[tt][1][lane] != 0.0f) { b -= part[tt][0][lane]; ngood += 1.0f; }
         }
         float step = 0.0f;
-        if (ngood > 0 && !A.psensor[p]) step = -b * A.pHdi[p];
+        if (ngood > 0 && !sens) step = -b * hdi;
         A.pstep[p] = step;
-        const float idb = A.pid[p] * (1.0f / SDVGN_SCALE_IDEPTH);
+        const float idb = pidv * (1.0f / SDVGN_SCALE_IDEPTH);
         backup[p] = idb;
         if (step_fac >= 0.0f) {
             const float v = idb + step_fac * step;
