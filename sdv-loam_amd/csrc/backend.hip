@@ -118,6 +118,10 @@ struct sdvgn_ef {
     double* acc_host = nullptr;   // pinned; the reduce kernels write it DIRECTLY (zero-copy) when no all-reduce is installed
     double* stats_host = nullptr; // pinned, 4 doubles: same for k_ef_sum_stats
     float fuse_step_fac = -1.0f;   // set by sdvgn_ef_optimize: k_ef_resubstitute also applies the point step
+    // second copies of the planes a trial step overwrites (point idepths, precalc table): the optimize loop writes the trial values
+    // into them and swaps the pointers, so that loadSateBackup after a rejected step is a pointer swap back, not two launches
+    float *pid_alt = nullptr, *pidz_alt = nullptr, *pdeltaF_alt = nullptr;
+    PrecalcDev* precalc_alt = nullptr;
     hipEvent_t ev_top = nullptr;  // (unused by the flag path; kept for the event fallback)
     ncclComm_t rccl_comm = nullptr;   // cfg4 with the collectives issued by the library itself (sdvgn_ef_init_rccl)
     int* flags_host = nullptr;    // pinned: [0] top accumulators done, [1] all accumulators done, [2] linearize statistics done
@@ -428,7 +432,13 @@ __global__ void __launch_bounds__(1024) k_ef_precalc_in(const unsigned long long
     for (int i = threadIdx.x; i < n8; i += 1024) dst[i] = src_pinned[i];
 }
 
-static int ef_upload_precalc(sdvgn_ef* e) {
+static void ef_refresh_frame_deltas(sdvgn_ef* e) {   // the host-side part of setDeltaF: FrameHessian delta / delta_prior
+    for (FrameH& f : e->frames)
+        for (int i = 0; i < 6; ++i) { f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i]; }
+}
+
+// setPrecalcValues + setDeltaF for the current frame states; the table goes to `dst` (default: the table the kernels read)
+static int ef_upload_precalc(sdvgn_ef* e, PrecalcDev* dst = nullptr) {
     const int nF = e->nF;
     const EFConst& C = e->C;
     const float K[9] = {C.fxl, 0, C.cxl, 0, C.fyl, C.cyl, 0, 0, 1};
@@ -476,14 +486,13 @@ static int ef_upload_precalc(sdvgn_ef* e) {
             P.np = e->hostP0.empty() ? 0 : e->hostP0[h + 1] - e->hostP0[h];
             if (h < e->h0 || h >= e->h1) P.np = 0;   // not this rank's shard
         }
-    for (FrameH& f : e->frames)
-        for (int i = 0; i < 6; ++i) { f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i]; }
+    ef_refresh_frame_deltas(e);
     if (!e->host_only) {
         // the table goes host -> device inside a one-workgroup kernel that reads the pinned staging half directly (one PCIe
         // round trip, ~3 us on the stream; a hipMemcpyAsync of the same 10 kB costs a ~8 us blit kernel plus its launch)
         static_assert(sizeof(PrecalcDev) % 8 == 0, "PrecalcDev is copied as 8-byte words");
         const int n8 = (int)(sizeof(PrecalcDev) * nF * nF / 8);
-        k_ef_precalc_in<<<1, 1024, 0, e->stream>>>((const unsigned long long*)pch, (unsigned long long*)e->precalc_dev, n8);
+        k_ef_precalc_in<<<1, 1024, 0, e->stream>>>((const unsigned long long*)pch, (unsigned long long*)(dst ? dst : e->precalc_dev), n8);
         HIPCHK(hipGetLastError());
     }
     e->havePrecalc = true;
@@ -680,7 +689,8 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->pHdi, mp) | dev_alloc(&e->pbdSum, mp) | dev_alloc(&e->pHcd, 4 * mp) | dev_alloc(&e->pstep, mp);
     bad |= dev_alloc(&e->images, (size_t)SDVGN_MAX_FRAMES * w * h * 3) | dev_alloc(&e->img_stage, (size_t)w * h);
     bad |= dev_alloc(&e->phost_dev, mp) | dev_alloc(&e->hostP0_dev, SDVGN_MAX_FRAMES + 1);
-    bad |= dev_alloc(&e->precalc_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES);
+    bad |= dev_alloc(&e->precalc_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES) | dev_alloc(&e->precalc_alt, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES);
+    bad |= dev_alloc(&e->pid_alt, mp) | dev_alloc(&e->pidz_alt, mp) | dev_alloc(&e->pdeltaF_alt, mp);
     bad |= dev_alloc(&e->energy_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * 2);
     bad |= dev_alloc(&e->top_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * kTopP);
     bad |= dev_alloc(&e->sc_partial, (size_t)SDVGN_MAX_FRAMES * kMaxChunks * kScP);
@@ -731,7 +741,8 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->rstate, e->rstate_new, e->rmatcher, e->renergy, e->renergy_new, e->renergy_wo, e->rres_toZero, e->J, e->JpJd, e->pHddA,
                     e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->images, e->img_stage,
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
-                    e->stats_dev, e->stats_partial, e->sc_off_dev, e->imm_pc_dev, e->rstate_new2, e->renergy_new2, e->renergy_wo2};
+                    e->stats_dev, e->stats_partial, e->sc_off_dev, e->imm_pc_dev, e->rstate_new2, e->renergy_new2, e->renergy_wo2,
+                    e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->precalc_alt};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->precalc_host) hipHostFree(e->precalc_host);
     if (e->acc_host) hipHostFree(e->acc_host);
@@ -849,6 +860,10 @@ int sdvgn_ef_set_points(sdvgn_ef* e, int nP, const int* host, const float* u, co
     HIPCHK(hipMemcpyAsync(e->pv, v, 4 * nP, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(e->pid, ids.data(), 4 * nP, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(e->pidz, idz.data(), 4 * nP, hipMemcpyHostToDevice, s));
+    // the trial copies start identical (points outside this rank's shard are never rewritten and must read the same from both)
+    HIPCHK(hipMemcpyAsync(e->pid_alt, ids.data(), 4 * nP, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->pidz_alt, idz.data(), 4 * nP, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->pdeltaF_alt, delta.data(), 4 * nP, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(e->pcolor, color8, 32 * (size_t)nP, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(e->pweights, weights8, 32 * (size_t)nP, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(e->ppriorF, prior.data(), 4 * nP, hipMemcpyHostToDevice, s));
@@ -1123,6 +1138,11 @@ static void ldlt_solve_rl(int n, double* A, double* b) {
     for (int k = n - 1; k >= 0; --k) if (perm[k] != k) std::swap(b[k], b[perm[k]]);
 }
 
+static void ef_swap_point_copies(sdvgn_ef* e) {
+    std::swap(e->pid, e->pid_alt); std::swap(e->pidz, e->pidz_alt); std::swap(e->pdeltaF, e->pdeltaF_alt);
+    e->A.pid = e->pid; e->A.pidz = e->pidz; e->A.pdeltaF = e->pdeltaF;
+}
+
 static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, double lambda, double* x_out) {
     const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
     g_pt.start();
@@ -1205,9 +1225,12 @@ int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
         }
     const float step_fac = e->fuse_step_fac;   // >= 0 inside sdvgn_ef_optimize: doStepFromBackup for the points rides along
     k_ef_resubstitute<<<(e->nP + 63) / 64, 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, X, e->pidepth_backup,
-                                                             e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid, e->pidz, e->pdeltaF);
+                                                             e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt, e->pdeltaF_alt);
     HIPCHK(hipGetLastError());
-    if (step_fac >= 0.0f) e->deltaF_nonzero = false;
+    if (step_fac >= 0.0f) {   // the stepped idepths are in the second copies: make them the ones every later launch reads
+        ef_swap_point_copies(e);
+        e->deltaF_nonzero = false;
+    }
     g_pt.stop(PT_RESUB);
     return SDVGN_OK;
 }
@@ -1311,6 +1334,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         const auto t_iter = std::chrono::steady_clock::now();
         for (int i = 0; i < 4; ++i) e->value_backup[i] = e->value[i];                     // backupState
         for (FrameH& f : e->frames) for (int i = 0; i < 10; ++i) f.state_backup[i] = f.state[i];
+        const bool zero_differs = e->deltaF_nonzero;   // idepth != idepth_zero before this trial (only possible right after a load)
         e->fuse_step_fac = stepsize;   // resubstitute also backs up the idepths and applies doStepFromBackup's point part
         rc = sdvgn_ef_solve_system(e, iteration, lambda, x.data());
         e->fuse_step_fac = -1.0f;
@@ -1331,7 +1355,8 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             for (int i = 3; i < 6; ++i) sumR += (float)(x[CPARS + 6 * h + i] * x[CPARS + 6 * h + i]);
         }
         g_pt.stop(PT_STEP);   // the point step (idepth = backup + stepsize * step) ran inside k_ef_resubstitute
-        if ((rc = ef_upload_precalc(e))) return rc;                                       // setPrecalcValues + setDeltaF
+        if ((rc = ef_upload_precalc(e, e->precalc_alt))) return rc;                       // setPrecalcValues + setDeltaF, into the second table
+        std::swap(e->precalc_dev, e->precalc_alt);
         g_pt.stop(PT_PRECALC);
         double newEnergy, newEnergyL, sID, sNID;
         ef_select_new_set(e, 1 - e->new_cur, e->new_cur);                                 // trial linearisation goes to the other set
@@ -1356,10 +1381,16 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             lastEnergy = newEnergy; lastEnergyL = newEnergyL; lastEnergyM = newEnergyM;
             lambda *= 0.25;
         } else {
-            calib_set_value(e, e->value_backup);                                          // loadSateBackup
+            // loadSateBackup: the idepths and the precalc table of the backed-up state are still in the copies the trial did not
+            // write -- swap back (no launch); the host-side frame / calib values are recomputed from the backup
+            calib_set_value(e, e->value_backup);
             for (FrameH& f : e->frames) frame_set_state(f, f.state_backup);
-            if ((rc = sdvgn_ef_point_step(e, 2, 0.f))) return rc;
-            if ((rc = ef_upload_precalc(e))) return rc;
+            ef_refresh_frame_deltas(e);
+            ef_swap_point_copies(e);
+            std::swap(e->precalc_dev, e->precalc_alt);
+            // the reference also sets idepth_zero = idepth_backup here (FullSystemOptimize.cpp:276-277); the swapped-back copies
+            // already satisfy that unless the window was loaded with idepth != idepth_zero and its very first step is rejected
+            if (zero_differs && (rc = sdvgn_ef_point_step(e, 2, 0.f))) return rc;
             // The reference re-linearises here (`lastEnergy = linearizeAll(false)`, FullSystemOptimize.cpp:446-449).  With the state
             // restored exactly, that is a bit-for-bit recomputation of the previous accepted linearisation: its energies are the
             // lastEnergy* values still held, its state_New* planes are the current set (untouched by the trial), and the J it would
