@@ -460,6 +460,17 @@ def main():
         barrier_sync(world)
         value_relin = K / (time.perf_counter() - t1)
 
+    # ---- opt-in flag bit2: bodies that follow a rejected step re-use the stitched system (bit-identical results; extra key only) ----
+    value_reuse = None
+    if world == 1:
+        G.load(W)
+        G.optimize(Wm, want_trace=False, fixed_its=True, reuse_after_reject=True)
+        G.load(W)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        G.optimize(K, want_trace=False, fixed_its=True, reuse_after_reject=True)
+        value_reuse = K / (time.perf_counter() - t1)
+
     # ---- the cpu_baseline protocol on the device: optimize(6) on a freshly loaded window, load untimed, the optimize calls timed
     # one by one (each includes its initial linearizeAll + applyRes like FullSystem::optimize).  A long run on ONE window ends up in
     # the converged regime where most steps are rejected; this one has the accept-heavy mix of the first iterations of a key-frame.
@@ -518,6 +529,7 @@ def main():
         "kernel_ms": {"linearizeAll": ms_lin, "accumulate(point+top+sc+reduce)": ms_acc},
         "value_with_literal_relinearize_on_reject": value_relin,
         "accepted_fraction": accepted_fraction,
+        "value_with_system_reuse_after_rejected_steps": value_reuse,
         "value_fresh_windows_6_bodies": fresh,
         "iteration_us": iter_stats,
         "replicas_value_weak_scaling": replicas_value,

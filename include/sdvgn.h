@@ -285,7 +285,9 @@ int sdvgn_ef_set_frame_states(sdvgn_ef* ef, const double* state10);
  * Returns the number of iterations run (>= 0) or an error (< 0). */
 int sdvgn_ef_optimize(sdvgn_ef* ef, int mnumOptIts, int flags /* bit0: run exactly mnumOptIts bodies (bench); bit1: re-linearise after a
                       rejected step literally like FullSystemOptimize.cpp:446-449 instead of switching back to the kept state_New* set
-                      (same results, bit for bit -- tests/test_backend_gpu.py) */,
+                      (same results, bit for bit -- tests/test_backend_gpu.py); bit2 (opt-in): the body that follows a rejected step
+                      works on the state its predecessor's normal equations were built on, so it re-uses the stitched HA/bA/Hsc/bsc and the
+                      per-point Schur terms (only lambda changed) instead of accumulating again -- same trace and final state, bit for bit */,
                       double* trace, int trace_stride, int trace_cap);
 /* state after optimize: CalibHessian::value_scaled, FrameHessian::state (nF x 10), PointHessian::idepth (nP) */
 int sdvgn_ef_get_state(sdvgn_ef* ef, double* value_scaled4, double* state10, float* idepth);

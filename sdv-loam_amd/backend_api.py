@@ -211,10 +211,11 @@ class EnergyFunctional:
     def stream(self):
         return self.L.sdvgn_ef_stream(self.h_)
 
-    def optimize(self, its=6, cap=128, want_trace=True, fixed_its=False, relinearize_on_reject=False):
+    def optimize(self, its=6, cap=128, want_trace=True, fixed_its=False, relinearize_on_reject=False, reuse_after_reject=False):
         stride = 7 + self.dim
         trace = np.zeros((cap, stride))
-        n = self._check(self.L.sdvgn_ef_optimize(self.h_, its, (1 if fixed_its else 0) | (2 if relinearize_on_reject else 0), trace.ctypes.data_as(vp) if want_trace else None, stride, cap))
+        flags = (1 if fixed_its else 0) | (2 if relinearize_on_reject else 0) | (4 if reuse_after_reject else 0)
+        n = self._check(self.L.sdvgn_ef_optimize(self.h_, its, flags, trace.ctypes.data_as(vp) if want_trace else None, stride, cap))
         return trace[:n]
 
     def iteration_times_us(self):

@@ -118,6 +118,8 @@ struct sdvgn_ef {
     double* acc_host = nullptr;   // pinned; the reduce kernels write it DIRECTLY (zero-copy) when no all-reduce is installed
     double* stats_host = nullptr; // pinned, 4 doubles: same for k_ef_sum_stats
     float fuse_step_fac = -1.0f;   // set by sdvgn_ef_optimize: k_ef_resubstitute also applies the point step
+    bool reuse_system = false;     // set by sdvgn_ef_optimize (flags bit2) for the solve that follows a rejected step: HA/bA/Hsc/bsc and
+                                   // the per-point Schur terms on the device are those of the identical state one body earlier
     // second copies of the planes a trial step overwrites (point idepths, precalc table): the optimize loop writes the trial values
     // into them and swaps the pointers, so that loadSateBackup after a rejected step is a pointer swap back, not two launches
     float *pid_alt = nullptr, *pidz_alt = nullptr, *pdeltaF_alt = nullptr;
@@ -1146,7 +1148,8 @@ static void ef_swap_point_copies(sdvgn_ef* e) {
 static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, double lambda, double* x_out) {
     const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
     g_pt.start();
-    stitch_top(e, acc);
+    const bool reuse = e->reuse_system && (int)e->HA.size() == n * n && (int)e->Hsc.size() == n * n;
+    if (!reuse) stitch_top(e, acc);
     // bM_top = bM + HM * delta (needs no accumulator: done before waiting for the Schur part)
     std::vector<double> d(n), bM_top(n);
     for (int i = 0; i < CPARS; ++i) d[i] = (double)e->C.cDeltaF[i];
@@ -1158,8 +1161,10 @@ static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, d
         e->split_pending = false;
         g_pt.stop(PT_D2H);
     }
-    e->resInA = (int)acc[acc_count(e) - 1];
-    stitch_sc(e, acc + (size_t)pairs * kTopE);
+    if (!reuse) {
+        e->resInA = (int)acc[acc_count(e) - 1];
+        stitch_sc(e, acc + (size_t)pairs * kTopE);
+    }
     g_pt.stop(PT_STITCH_SC);
     // HFinal = HA + HM - Hsc ; bFinal = bA + bM_top - bsc   (EnergyFunctional.cpp:668-699)
     e->HFinal.resize((size_t)n * n); e->bFinal.resize(n);
@@ -1194,7 +1199,9 @@ int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
     EF_DEVICE(e);
     const int nF = e->nF, n = CPARS + 6 * nF;
     g_pt.start();
-    if (e->split_pending) {
+    if (e->reuse_system) {
+        // nothing to fetch
+    } else if (e->split_pending) {
         HIPCHK(wait_flag(e->flags_host, e->seq_top, e->stream));   // the top accumulators are in acc_host (waitflag.hpp)
     } else {
         const int na = (int)acc_count(e);   // sharded / generic path: the (all-reduced) device buffer comes back through a copy kernel
@@ -1238,6 +1245,7 @@ int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
 int sdvgn_ef_solve_system(sdvgn_ef* e, int iteration, double lambda, double* x_out) {
     if (!e || e->host_only || !e->havePrecalc) return SDVGN_E_STATE;
     EF_DEVICE(e);
+    if (e->reuse_system) return sdvgn_ef_finish_solve(e, iteration, lambda, x_out);
     g_pt.start();
     int rc = ef_accumulate(e, /*split=*/!ef_sharded(e));
     g_pt.stop(PT_ACCUM);
@@ -1315,6 +1323,8 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     if (nF < 2) return 0;
     const bool fixed_its = (flags & 1) != 0;   // benchmark mode: exactly mnumOptIts loop bodies, no early break
     const bool relinearize_on_reject = (flags & 2) != 0;   // run the reference's redundant re-linearisation literally (A/B timing, tests)
+    const bool reuse_after_reject = (flags & 4) != 0;      // opt-in: the solve after a rejected step reuses the stitched system (see header)
+    bool prev_rejected_clean = false;
     if (!fixed_its && nF < 3) mnumOptIts = 100;
     if (!fixed_its && nF < 4) mnumOptIts = 75;
     const size_t slots = (size_t)nF * e->nP;
@@ -1336,8 +1346,10 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         for (FrameH& f : e->frames) for (int i = 0; i < 10; ++i) f.state_backup[i] = f.state[i];
         const bool zero_differs = e->deltaF_nonzero;   // idepth != idepth_zero before this trial (only possible right after a load)
         e->fuse_step_fac = stepsize;   // resubstitute also backs up the idepths and applies doStepFromBackup's point part
+        e->reuse_system = reuse_after_reject && prev_rejected_clean;
         rc = sdvgn_ef_solve_system(e, iteration, lambda, x.data());
         e->fuse_step_fac = -1.0f;
+        e->reuse_system = false;
         if (rc) return rc;
         // doStepFromBackup
         g_pt.start();
@@ -1380,6 +1392,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             if ((rc = sdvgn_ef_apply_res(e))) return rc;
             lastEnergy = newEnergy; lastEnergyL = newEnergyL; lastEnergyM = newEnergyM;
             lambda *= 0.25;
+            prev_rejected_clean = false;
         } else {
             // loadSateBackup: the idepths and the precalc table of the backed-up state are still in the copies the trial did not
             // write -- swap back (no launch); the host-side frame / calib values are recomputed from the backup
@@ -1401,6 +1414,8 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
                 lastEnergyM = calc_M_energy(e);
             }
             lambda *= 1e2;
+            // the restored state is the one this body's system was built on, bit for bit (unless idepth_zero just changed, above)
+            prev_rejected_clean = !zero_differs;
         }
         g_pt.stop(PT_APPLY);
         e->iter_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_iter).count());

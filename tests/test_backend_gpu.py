@@ -192,6 +192,30 @@ def test_kept_state_equals_relinearize_on_reject(api, orc, seed):
     assert np.array_equal(xa, xb)
 
 
+@pytest.mark.parametrize("seed", [2, 3, 4])
+def test_reuse_after_reject_is_bit_identical(api, orc, seed):
+    """flags bit2: the body after a rejected step re-uses the stitched system of its predecessor (same state, only lambda changed)
+    instead of accumulating and stitching again -- trace, final state and per-residual planes must not change by a bit, also with
+    several rejected steps in a row and with an accepted step in between."""
+    from sdv_loam_amd import synthetic as syn
+    W = syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=seed, calib=dict(fx=400., fy=410., cx=319.5, cy=119.5))
+    A = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+    B = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+    ta = A.optimize(12, fixed_its=True)
+    tb = B.optimize(12, fixed_its=True, reuse_after_reject=True)
+    rej = ta[:, 2] == 0
+    assert rej.any() and (rej[:-1] & rej[1:]).any()                           # consecutive rejected steps: the reuse path ran
+    assert np.array_equal(ta, tb)
+    for x, y in zip(A.state(), B.state()):
+        assert np.array_equal(x, y)
+    sa, sb = A.residual_state(), B.residual_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(A.points(), B.points())
+    xa, xb = A.solveSystemF(3, 0.1), B.solveSystemF(3, 0.1)
+    assert np.array_equal(xa, xb)
+
+
 @pytest.mark.parametrize("direct", [True, False])
 def test_sharded_path_single_rank_nccl(api, orc, window, direct, monkeypatch):
     """cfg4 plumbing on one GPU: external torch buffers, torch stream, and the collectives of a 1-rank RCCL group -- issued either by
