@@ -92,9 +92,9 @@ def event_ms(torch, stream, fn, reps):
 
 
 # ------------------------------------------------------------------------------------------------------------
-def backend_setup(device):
+def backend_setup(device, **window_kw):
     from sdv_loam_amd import backend_api, synthetic as syn
-    W = syn.make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=syn.KITTI00)
+    W = syn.make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=syn.KITTI00, **window_kw)
     G = backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP, device=device).load(W)
     return W, G
 
@@ -488,6 +488,32 @@ def main():
         fresh = dict(value=its / tt, unit="GN iters/s", accepted_fraction=acc / its,
                      note="20 x [load (untimed) + optimize(6 bodies) timed]; includes each call's initial linearizeAll + applyRes")
         G.load(W)
+        if not args.quick:
+            # the same protocol on a window that starts further from its optimum (50x larger pose / 17x larger inverse-depth
+            # perturbation), where about half of the first six steps are accepted -- device and 1-thread oracle side by side
+            W2, G2 = backend_setup(local, state_sigma=1e-2, idepth_sigma=0.05)
+            tt, its, acc = 0.0, 0, 0.0
+            for _ in range(20):
+                G2.load(W2)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                tr6 = G2.optimize(6, want_trace=True, fixed_its=True)
+                tt += time.perf_counter() - t1
+                its += len(tr6)
+                acc += float(tr6[:, 2].sum())
+            fresh["perturbed_window"] = dict(value=its / tt, accepted_fraction=acc / its,
+                                             note="state_sigma 1e-2, idepth_sigma 0.05; same protocol")
+            if not args.no_cpu:
+                from oracle.backend import OracleEF
+                O2 = OracleEF(W2.w, W2.h)
+                tt, its = 0.0, 0
+                while tt < 3.0:
+                    O2.load(W2)
+                    t1 = time.perf_counter()
+                    its += len(O2.optimize(6))
+                    tt += time.perf_counter() - t1
+                fresh["perturbed_window"]["cpu_oracle_1_thread"] = its / tt
+            del G2
 
     # ---- dominant kernel: k_ef_linearize, HIP events on the library's stream -----------------------------------
     for _ in range(5):

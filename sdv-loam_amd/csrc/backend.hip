@@ -124,6 +124,9 @@ struct sdvgn_ef {
     // into them and swaps the pointers, so that loadSateBackup after a rejected step is a pointer swap back, not two launches
     float *pid_alt = nullptr, *pidz_alt = nullptr, *pdeltaF_alt = nullptr;
     PrecalcDev* precalc_alt = nullptr;
+    const PrecalcDev* precalc_staged = nullptr;   // pinned half the last ef_upload_precalc filled
+    bool in_optimize_loop = false;                // finish_solve then also does doStepFromBackup's host part before its launch
+    float step_sumT = 0, step_sumR = 0;
     hipEvent_t ev_top = nullptr;  // (unused by the flag path; kept for the event fallback)
     ncclComm_t rccl_comm = nullptr;   // cfg4 with the collectives issued by the library itself (sdvgn_ef_init_rccl)
     int* flags_host = nullptr;    // pinned: [0] top accumulators done, [1] all accumulators done, [2] linearize statistics done
@@ -440,7 +443,8 @@ static void ef_refresh_frame_deltas(sdvgn_ef* e) {   // the host-side part of se
 }
 
 // setPrecalcValues + setDeltaF for the current frame states; the table goes to `dst` (default: the table the kernels read)
-static int ef_upload_precalc(sdvgn_ef* e, PrecalcDev* dst = nullptr) {
+// stage_only: only fill the pinned staging half (e->precalc_staged); the caller's next kernel carries the copy
+static int ef_upload_precalc(sdvgn_ef* e, PrecalcDev* dst = nullptr, bool stage_only = false) {
     const int nF = e->nF;
     const EFConst& C = e->C;
     const float K[9] = {C.fxl, 0, C.cxl, 0, C.fyl, C.cyl, 0, 0, 1};
@@ -489,7 +493,8 @@ static int ef_upload_precalc(sdvgn_ef* e, PrecalcDev* dst = nullptr) {
             if (h < e->h0 || h >= e->h1) P.np = 0;   // not this rank's shard
         }
     ef_refresh_frame_deltas(e);
-    if (!e->host_only) {
+    e->precalc_staged = pch;
+    if (!e->host_only && !stage_only) {
         // the table goes host -> device inside a one-workgroup kernel that reads the pinned staging half directly (one PCIe
         // round trip, ~3 us on the stream; a hipMemcpyAsync of the same 10 kB costs a ~8 us blit kernel plus its launch)
         static_assert(sizeof(PrecalcDev) % 8 == 0, "PrecalcDev is copied as 8-byte words");
@@ -1194,6 +1199,30 @@ int sdvgn_ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, do
     return ef_stitch_solve_host(e, acc, iteration, lambda, x_out);
 }
 
+static void calib_set_value(sdvgn_ef* e, const double* v);
+
+// doStepFromBackup, host part (FullSystemOptimize.cpp:212-235): calib and frame states from the backup and lastX, then the precalc
+// table of the stepped state into the pinned staging half
+static int ef_step_from_backup_host(sdvgn_ef* e, float stepsize) {
+    const int nF = e->nF;
+    const std::vector<double>& x = e->lastX;
+    double v[4];
+    for (int i = 0; i < 4; ++i) v[i] = e->value_backup[i] + stepsize * (-x[i]);
+    calib_set_value(e, v);
+    float sumT = 0, sumR = 0;
+    for (int h = 0; h < nF; ++h) {
+        FrameH& f = e->frames[h];
+        double st[10];
+        for (int i = 0; i < 6; ++i) st[i] = f.state_backup[i] + (double)stepsize * (-x[CPARS + 6 * h + i]);
+        for (int i = 6; i < 10; ++i) st[i] = f.state_backup[i];
+        frame_set_state(f, st);
+        for (int i = 0; i < 3; ++i) sumT += (float)(x[CPARS + 6 * h + i] * x[CPARS + 6 * h + i]);
+        for (int i = 3; i < 6; ++i) sumR += (float)(x[CPARS + 6 * h + i] * x[CPARS + 6 * h + i]);
+    }
+    e->step_sumT = sumT; e->step_sumR = sumR;
+    return ef_upload_precalc(e, nullptr, /*stage_only=*/true);                        // setPrecalcValues + setDeltaF
+}
+
 int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_out) {
     if (!e || e->host_only || !e->havePrecalc) return SDVGN_E_STATE;
     EF_DEVICE(e);
@@ -1231,13 +1260,28 @@ int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
             }
         }
     const float step_fac = e->fuse_step_fac;   // >= 0 inside sdvgn_ef_optimize: doStepFromBackup for the points rides along
-    k_ef_resubstitute<<<(e->nP + 63) / 64, 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, X, e->pidepth_backup,
-                                                             e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt, e->pdeltaF_alt);
+    const EFConst C_solve = e->C;              // the calib the system was built with (the host step below moves e->C on)
+    const unsigned long long* pc_src = nullptr;
+    int pc_n8 = 0;
+    g_pt.stop(PT_RESUB);
+    if (e->in_optimize_loop) {
+        // host part of doStepFromBackup first, so that the table of the stepped state rides in this launch (one extra workgroup
+        // copies it from the pinned staging half into the second device table) instead of in a launch of its own
+        if ((rc = ef_step_from_backup_host(e, step_fac))) return rc;
+        pc_src = (const unsigned long long*)e->precalc_staged;
+        pc_n8 = (int)(sizeof(PrecalcDev) * nF * nF / 8);
+        g_pt.stop(PT_PRECALC);
+    }
+    const int nblk = (e->nP + 63) / 64;
+    k_ef_resubstitute<<<nblk + (pc_src ? 1 : 0), 512, 0, e->stream>>>(C_solve, e->A, e->precalc_dev, e->phost_dev, X, e->pidepth_backup,
+                                                                       e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt,
+                                                                       e->pdeltaF_alt, nblk, pc_src, (unsigned long long*)e->precalc_alt, pc_n8);
     HIPCHK(hipGetLastError());
     if (step_fac >= 0.0f) {   // the stepped idepths are in the second copies: make them the ones every later launch reads
         ef_swap_point_copies(e);
         e->deltaF_nonzero = false;
     }
+    if (pc_src) std::swap(e->precalc_dev, e->precalc_alt);
     g_pt.stop(PT_RESUB);
     return SDVGN_OK;
 }
@@ -1347,29 +1391,16 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         const bool zero_differs = e->deltaF_nonzero;   // idepth != idepth_zero before this trial (only possible right after a load)
         e->fuse_step_fac = stepsize;   // resubstitute also backs up the idepths and applies doStepFromBackup's point part
         e->reuse_system = reuse_after_reject && prev_rejected_clean;
+        e->in_optimize_loop = true;
         rc = sdvgn_ef_solve_system(e, iteration, lambda, x.data());
+        e->in_optimize_loop = false;
         e->fuse_step_fac = -1.0f;
         e->reuse_system = false;
         if (rc) return rc;
-        // doStepFromBackup
+        // doStepFromBackup ran inside the solve: host part (calib / frame states / precalc table) before the resubstitute launch,
+        // point part and the table copy inside it
+        float sumT = e->step_sumT, sumR = e->step_sumR;
         g_pt.start();
-        double v[4];
-        for (int i = 0; i < 4; ++i) v[i] = e->value_backup[i] + stepsize * (-x[i]);
-        calib_set_value(e, v);
-        float sumT = 0, sumR = 0;
-        for (int h = 0; h < nF; ++h) {
-            FrameH& f = e->frames[h];
-            double st[10];
-            for (int i = 0; i < 6; ++i) st[i] = f.state_backup[i] + (double)stepsize * (-x[CPARS + 6 * h + i]);
-            for (int i = 6; i < 10; ++i) st[i] = f.state_backup[i];
-            frame_set_state(f, st);
-            for (int i = 0; i < 3; ++i) sumT += (float)(x[CPARS + 6 * h + i] * x[CPARS + 6 * h + i]);
-            for (int i = 3; i < 6; ++i) sumR += (float)(x[CPARS + 6 * h + i] * x[CPARS + 6 * h + i]);
-        }
-        g_pt.stop(PT_STEP);   // the point step (idepth = backup + stepsize * step) ran inside k_ef_resubstitute
-        if ((rc = ef_upload_precalc(e, e->precalc_alt))) return rc;                       // setPrecalcValues + setDeltaF, into the second table
-        std::swap(e->precalc_dev, e->precalc_alt);
-        g_pt.stop(PT_PRECALC);
         double newEnergy, newEnergyL, sID, sNID;
         ef_select_new_set(e, 1 - e->new_cur, e->new_cur);                                 // trial linearisation goes to the other set
         if ((rc = linearize_and_stats(e, &newEnergy, &newEnergyL, &sID, &sNID))) return rc;

@@ -913,7 +913,13 @@ struct ResubX { float xc[4]; float xAd[kMaxFrames * kMaxFrames * 6]; };
 __global__ void __launch_bounds__(512) k_ef_resubstitute(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
                                                          const int* __restrict__ phost, const ResubX X, float* __restrict__ backup,
                                                          double* __restrict__ stats_partial, float step_fac,
-                                                         float* __restrict__ pid_w, float* __restrict__ pidz_w, float* __restrict__ pdeltaF_w) {
+                                                         float* __restrict__ pid_w, float* __restrict__ pidz_w, float* __restrict__ pdeltaF_w,
+                                                         int n_point_blocks, const unsigned long long* __restrict__ pc_src_pinned,
+                                                         unsigned long long* __restrict__ pc_dst, int pc_n8) {
+    if ((int)blockIdx.x >= n_point_blocks) {   // extra workgroup: precalc table of the stepped state, pinned host -> second device table
+        for (int i = threadIdx.x; i < pc_n8; i += blockDim.x) pc_dst[i] = pc_src_pinned[i];
+        return;
+    }
     __shared__ float part[kMaxFrames][2][64];
     __shared__ float sx[4 + kMaxFrames * kMaxFrames * 6];
     const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
@@ -985,7 +991,7 @@ __global__ void __launch_bounds__(512) k_ef_resubstitute(EFConst C, EFArrays A, 
         sa = (double)fabsf(idb);
     }
     s2 = wave_sum_double(s2); sa = wave_sum_double(sa);
-    if (lane == 63) { stats_partial[blockIdx.x] = s2; stats_partial[gridDim.x + blockIdx.x] = sa; }
+    if (lane == 63) { stats_partial[blockIdx.x] = s2; stats_partial[n_point_blocks + blockIdx.x] = sa; }
 }
 
 }  // namespace sdvgn
