@@ -1440,7 +1440,9 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             // lastEnergy* values still held, its state_New* planes are the current set (untouched by the trial), and the J it would
             // write into the not-owned buffer is overwritten by the next linearise before anything reads it.  So: switch back.
             ef_select_new_set(e, e->new_cur, e->new_cur);
-            if (relinearize_on_reject) {
+            // Exception: if the restore just moved idepth_zero (zero_differs), the linearisation point of the centre projection and
+            // deltaF changed, so the kept energies do not describe the restored state -- re-linearise like the reference.
+            if (relinearize_on_reject || zero_differs) {
                 if ((rc = linearize_and_stats(e, &lastEnergy, &lastEnergyL, nullptr, nullptr))) return rc;
                 lastEnergyM = calc_M_energy(e);
             }

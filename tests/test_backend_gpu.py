@@ -171,6 +171,36 @@ def test_optimize_loop_parity(api, orc, seed):
     assert rel_err(ig, io) < 1e-6
 
 
+@pytest.mark.parametrize("seed", [3, 5])
+def test_first_step_rejected_with_idepth_zero_offset(api, orc, seed):
+    """Window loaded with idepth != idepth_zero whose very first step is rejected: the reference's loadSateBackup then also moves
+    idepth_zero to the backed-up idepth (FullSystemOptimize.cpp:276-277) -- the one restore the pointer swap alone does not
+    reproduce.  Trace, final state and the next solve must follow the oracle, and the three loop variants must stay bit-identical."""
+    from sdv_loam_amd import synthetic as syn
+    W = syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=seed, calib=dict(fx=400., fy=410., cx=319.5, cy=119.5))
+    W.idepth_zero = (W.idepth + np.random.default_rng(1).normal(0, 2e-4, W.nP)).astype(np.float32)
+    G, O = pair(api, orc, W)
+    tg, to = G.optimize(6), O.optimize(6)
+    assert to[0, 2] == 0                                                      # first step rejected
+    assert len(tg) == len(to) and np.array_equal(tg[:, [0, 1, 2, 6]], to[:, [0, 1, 2, 6]])
+    assert np.allclose(tg[:, 3:6], to[:, 3:6], rtol=1e-5, atol=1e-6)
+    for i in range(len(to)):
+        assert rel_err(tg[i, 7:], to[i, 7:]) < 1e-4
+    assert rel_err(G.state()[2], O.state()[2]) < 1e-6
+    xg = G.solveSystemF(3, 0.1)                                               # idepth_zero / deltaF after the loop feed this solve
+    O.solveSystemF(3, 0.1)
+    assert rel_err(xg, O.system()["x"]) < 1e-4
+    ref = None
+    for kw in (dict(), dict(relinearize_on_reject=True), dict(reuse_after_reject=True)):
+        B = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+        out = (B.optimize(6, **kw), B.state()[2], B.points(), B.solveSystemF(3, 0.1))
+        if ref is None:
+            ref = out
+        else:
+            for a, b in zip(ref, out):
+                assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("seed", [2, 3, 4])
 def test_kept_state_equals_relinearize_on_reject(api, orc, seed):
     """A rejected step switches back to the kept state_New* set instead of re-linearising (FullSystemOptimize.cpp:446-449): both
