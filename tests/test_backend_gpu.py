@@ -152,6 +152,39 @@ def test_full_size_cfg3(api, orc):
     assert rel_err(Hd @ x, s["bFinal"]) < 1e-6
 
 
+def test_full_size_shard_linearity(api):
+    """Size-independent property at BASELINE.json's full size (configs[2]/[3]): the packed accumulator buffer is a sum over residuals
+    and a host-frame shard only touches its own (host, target) tiles and host Schur tiles, so the buffers of disjoint shards add up
+    to the unsharded buffer EXACTLY (every entry has exactly one non-zero contributor; resInA adds as integers).  Shardings 8 = 4+4,
+    3+5 and 8 x 1 (the one-key-frame-per-GPU layout of configs[3])."""
+    import torch
+    from sdv_loam_amd import synthetic as syn
+    W = syn.make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=syn.KITTI00)
+
+    def fetch(h0, h1):
+        G = api.EnergyFunctional(W.w, W.h, max_points=W.nP)
+        acc = torch.zeros(8 * 8 * 121 + 8 * 1431 + 1, dtype=torch.float64, device="cuda")      # capacity for nF = 8
+        stats = torch.zeros(4, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        G._check(G.L.sdvgn_ef_set_external_buffers(G.h_, acc.data_ptr(), acc.numel(), stats.data_ptr()))
+        G.set_host_range(h0, h1)
+        G.load(W)
+        G.linearizeAll(); G.applyRes()
+        G.accumulate()                                  # the packed buffer lands in `acc` (library stream)
+        torch.cuda.synchronize()
+        out = acc.cpu().numpy().copy()
+        G.close()
+        return out
+
+    full = fetch(0, 8)
+    assert full[-1] > 50000 and np.abs(full).max() > 0                         # resInA: active residuals of the window
+    for cuts in ((0, 4, 8), (0, 3, 8), tuple(range(9))):
+        parts = [fetch(a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert np.array_equal(sum(parts), full), cuts
+        nz = sum((p != 0).astype(int) for p in parts)
+        assert nz.max() <= 1 or np.array_equal(np.flatnonzero(nz > 1), [len(full) - 1])   # only resInA is shared
+
+
 @pytest.mark.parametrize("seed", [2, 3])
 def test_optimize_loop_parity(api, orc, seed):
     """Whole FullSystem::optimize loop (b8): same accept/reject sequence, lambda schedule, x per iteration and final state."""
