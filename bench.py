@@ -91,6 +91,18 @@ def event_ms(torch, stream, fn, reps):
     return float(np.median([a.elapsed_time(b) for a, b in evs]))
 
 
+def event_avg_ms(torch, stream, fn, reps):
+    """average duration of fn() in ms over `reps` back-to-back calls bracketed by ONE pair of HIP events on `stream`: launch
+    duration incl. the gap to the next launch, without the per-launch event packets of event_ms()."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(stream)
+    for _ in range(reps):
+        fn()
+    b.record(stream)
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
 # ------------------------------------------------------------------------------------------------------------
 def backend_setup(device, **window_kw):
     from sdv_loam_amd import backend_api, synthetic as syn
@@ -519,13 +531,15 @@ def main():
     for _ in range(5):
         G.linearizeAll(want_energy=False)
     torch.cuda.synchronize()
-    ms_lin = event_ms(torch, ext, lambda: G.linearizeAll(want_energy=False), 50)
+    ms_lin_each = event_ms(torch, ext, lambda: G.linearizeAll(want_energy=False), 50)
+    ms_lin = event_avg_ms(torch, ext, lambda: G.linearizeAll(want_energy=False), 50)
     alg = W.nR * LINEARIZE_BYTES_PER_RES
     achieved = alg / (ms_lin * 1e-3) / 1e9
     roof = dict(bound="hbm", kernel="k_ef_linearize", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                 traffic=None,
-                note="%d residuals x %d B algorithmic = %.1f MB per launch; %.4f ms per launch (HIP events around "
-                     "k_ef_linearize alone, on the library stream)" % (W.nR, LINEARIZE_BYTES_PER_RES, alg / 1e6, ms_lin))
+                note="%d residuals x %d B algorithmic = %.1f MB per launch; %.4f ms average launch duration (one pair of HIP events "
+                     "around 50 back-to-back launches of k_ef_linearize alone on the library stream; an event pair around each "
+                     "single launch reads %.4f ms, rocprofv3's kernel time is in profiles/)" % (W.nR, LINEARIZE_BYTES_PER_RES, alg / 1e6, ms_lin, ms_lin_each))
     ms_acc = event_ms(torch, ext, lambda: G.accumulate(), 50)
     # what a plain streaming copy reaches on this box (1 GiB read + 1 GiB written), for reading `frac` against the achievable rate
     try:
