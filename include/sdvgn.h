@@ -296,6 +296,9 @@ int sdvgn_ef_get_iteration_times(sdvgn_ef* ef, double* us, int cap);
 /* Diagnostics (SDVGN_PROFILE=1 in the environment when the library is loaded): prints the accumulated host wall time per phase
  * of the solve / optimize path to stderr, divided by `per`, and clears the counters.  Returns 1 if a report was printed, else 0. */
 int sdvgn_debug_phase_report(int per);
+/* Diagnostics (SDVGN_DEBUG_FLAGS bit5 = 32 set when the handle is created): wall_clock64() stamps (10 ns) of k_ef_linearize's stages
+ * from the last launch, [workgroup][wave][8] 64-bit words (tools/exp_linearize_stages.py).  Returns the number of words copied, 0 if the diagnostics are off. */
+int sdvgn_debug_read_stamps(sdvgn_ef* ef, unsigned long long* out, int cap_words);
 /* Device pointer of key-frame idx's level-0 image (dI, AoS {I,dx,dy}) held by the window, for sdvgn_reproj_set_frame(.., dI_aos3_dev);
  * NULL if idx is out of range or the handle is host-only.  Valid until that frame's image is replaced or the handle is destroyed. */
 const float* sdvgn_ef_frame_image_dev(sdvgn_ef* ef, int idx);

@@ -36,6 +36,7 @@ PROTOTYPES = [
     ("sdvgn_ef_get_top_acc", C.c_int, [vp, f64p, vp]),
     ("sdvgn_ef_get_iteration_times", C.c_int, [vp, vp, C.c_int]),
     ("sdvgn_debug_phase_report", C.c_int, [C.c_int]),
+    ("sdvgn_debug_read_stamps", C.c_int, [vp, vp, C.c_int]),
     ("sdvgn_ef_frame_image_dev", vp, [vp, C.c_int]),
     ("sdvgn_rccl_unique_id", C.c_int, [vp]),
     ("sdvgn_ef_init_rccl", C.c_int, [vp, vp, C.c_int, C.c_int]),

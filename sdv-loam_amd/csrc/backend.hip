@@ -124,6 +124,7 @@ struct sdvgn_ef {
     // into them and swaps the pointers, so that loadSateBackup after a rejected step is a pointer swap back, not two launches
     float *pid_alt = nullptr, *pidz_alt = nullptr, *pdeltaF_alt = nullptr;
     PrecalcDev* precalc_alt = nullptr;
+    unsigned long long* dbg_stamps = nullptr;     // SDVGN_DEBUG_FLAGS bit5 only (kDbgStampWords words)
     const PrecalcDev* precalc_staged = nullptr;   // pinned half the last ef_upload_precalc filled
     bool in_optimize_loop = false;                // finish_solve then also does doStepFromBackup's host part before its launch
     float step_sumT = 0, step_sumR = 0;
@@ -158,6 +159,7 @@ static PhaseTimer g_pt;
 enum { PT_ACCUM = 0, PT_D2H, PT_STITCH_TOP, PT_STITCH_SC, PT_SOLVE, PT_RESUB, PT_STEP, PT_PRECALC, PT_LIN, PT_APPLY, PT_PREP, PT_N };
 static const char* kPtNames[PT_N] = {"accumulate(launch)", "acc D2H+sync", "stitch_top", "stitch_sc", "LDLT+orthogonalize", "xAd+resub launch", "state step", "precalc upload", "linearize+stats+sync", "apply/restore", "HFinal+scale"};
 
+constexpr size_t kDbgStampWords = (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 2 * kMaxChunks * 4 * 8;
 static size_t acc_count(const sdvgn_ef* e) { return (size_t)e->nF * e->nF * kTopE + (size_t)e->nF * kScE + 1; }
 
 static void frame_set_state(FrameH& f, const double* state) {  // FrameHessian::setState, HessianBlocks.h:131-143
@@ -195,6 +197,7 @@ static void ef_fill_arrays(sdvgn_ef* e) {
     A.pHddA = e->pHddA; A.pbdA = e->pbdA; A.pHcdA = e->pHcdA; A.pHddL = e->pHddL; A.pbdL = e->pbdL; A.pHcdL = e->pHcdL;
     A.pHdi = e->pHdi; A.pbdSum = e->pbdSum; A.pHcd = e->pHcd; A.pstep = e->pstep;
     A.images = e->images;
+    A.dbg_stamps = e->dbg_stamps;
 }
 
 static void ef_update_const(sdvgn_ef* e) {  // CalibHessian float views, HessianBlocks.h:302-330
@@ -619,6 +622,14 @@ static int lin_chunks_for_np(const sdvgn_ef* e) {   // k_ef_linearize: 128 resid
     for (int h = 0; h < e->nF; ++h) mx = std::max(mx, e->hostP0[h + 1] - e->hostP0[h]);
     return std::min(2 * kMaxChunks, (mx + 127) / 128);
 }
+// launches PointFrameResidual::linearize over the window; returns the number of energy partials written (128-residual granularity)
+static int ef_launch_linearize(sdvgn_ef* e) {
+    const int pairs = e->nF * e->nF;
+    const int chunks = lin_chunks_for_np(e);
+    if ((e->C.debug_flags & 32) && e->dbg_stamps) k_ef_linearize<true><<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
+    else k_ef_linearize<false><<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
+    return chunks * pairs;
+}
 static int chunks_for_np(const sdvgn_ef* e) {
     int mx = 1;
     for (int h = 0; h < e->nF; ++h) mx = std::max(mx, e->hostP0[h + 1] - e->hostP0[h]);
@@ -698,6 +709,10 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->phost_dev, mp) | dev_alloc(&e->hostP0_dev, SDVGN_MAX_FRAMES + 1);
     bad |= dev_alloc(&e->precalc_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES) | dev_alloc(&e->precalc_alt, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES);
     bad |= dev_alloc(&e->pid_alt, mp) | dev_alloc(&e->pidz_alt, mp) | dev_alloc(&e->pdeltaF_alt, mp);
+    if (getenv("SDVGN_DEBUG_FLAGS") && (atoi(getenv("SDVGN_DEBUG_FLAGS")) & 32)) {
+        bad |= dev_alloc(&e->dbg_stamps, kDbgStampWords);
+        if (!bad) hipMemset(e->dbg_stamps, 0, sizeof(unsigned long long) * kDbgStampWords);
+    }
     bad |= dev_alloc(&e->energy_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * 2);
     bad |= dev_alloc(&e->top_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * kTopP);
     bad |= dev_alloc(&e->sc_partial, (size_t)SDVGN_MAX_FRAMES * kMaxChunks * kScP);
@@ -749,7 +764,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->images, e->img_stage,
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
                     e->stats_dev, e->stats_partial, e->sc_off_dev, e->imm_pc_dev, e->rstate_new2, e->renergy_new2, e->renergy_wo2,
-                    e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->precalc_alt};
+                    e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->precalc_alt, e->dbg_stamps};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->precalc_host) hipHostFree(e->precalc_host);
     if (e->acc_host) hipHostFree(e->acc_host);
@@ -982,11 +997,9 @@ int sdvgn_ef_set_precalc(sdvgn_ef* e) {
 int sdvgn_ef_linearize_all(sdvgn_ef* e, double* energy_out) {
     if (!e || e->host_only || !e->havePrecalc || e->nR < 0) return SDVGN_E_STATE;
     EF_DEVICE(e);
-    const int pairs = e->nF * e->nF;
-    const int chunks = lin_chunks_for_np(e);
-    k_ef_linearize<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
+    const int n_partials = ef_launch_linearize(e);
     double* edst = e->stats_dev;
-    if (energy_out) k_ef_sum_energy<<<1, 256, 0, e->stream>>>(e->energy_partial, chunks * pairs, edst);   // NULL: leave the per-workgroup partials
+    if (energy_out) k_ef_sum_energy<<<1, 256, 0, e->stream>>>(e->energy_partial, n_partials, edst);   // NULL: leave the per-workgroup partials
     HIPCHK(hipGetLastError());
     if (energy_out) {
         HIPCHK(hipMemcpyAsync(e->acc_host, edst, sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -1328,9 +1341,7 @@ static double calc_M_energy(sdvgn_ef* e) {   // EnergyFunctional::calcMEnergyF
 // launches linearizeAll + the point statistics; returns {energy, L-energy, sum step^2, sum |idepth_backup|} after ONE sync
 static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* sumID, double* sumNID) {
     if (!e->havePrecalc) return SDVGN_E_STATE;
-    const int pairs = e->nF * e->nF;
-    const int chunks = lin_chunks_for_np(e);
-    k_ef_linearize<<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
+    const int n_partials = ef_launch_linearize(e);
     int nL = 0;
     if (e->deltaF_nonzero || e->has_linearized) {
         nL = (e->nP + 255) / 256;
@@ -1339,7 +1350,7 @@ static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* 
     const int nS = (e->nP + 63) / 64;
     // without an all-reduce the four sums go straight into pinned host memory (no copy engine, see ef_accumulate)
     const bool flagged = !ef_sharded(e);
-    k_ef_sum_stats<<<1, 256, 0, e->stream>>>(e->energy_partial, chunks * pairs, e->stats_partial, nL, e->stats_partial + (e->nP / 64 + 2), nS,
+    k_ef_sum_stats<<<1, 256, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, e->stats_partial + (e->nP / 64 + 2), nS,
                                              flagged ? e->stats_host : e->stats_dev, flagged ? e->flags_host + 2 : nullptr, flagged ? ++e->seq_stats : 0);
     HIPCHK(hipGetLastError());
     if (!flagged) {
@@ -1456,6 +1467,14 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     }
     if (g_pt.on) sdvgn_debug_phase_report(it);
     return it;
+}
+
+int sdvgn_debug_read_stamps(sdvgn_ef* e, unsigned long long* out, int cap_words) {
+    if (!e || !out || !e->dbg_stamps) return 0;
+    if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) return SDVGN_E_NODEVICE;
+    const int n = std::min<int>(cap_words, (int)kDbgStampWords);
+    if (hipMemcpy(out, e->dbg_stamps, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost) != hipSuccess) return SDVGN_E_NODEVICE;
+    return n;
 }
 
 int sdvgn_debug_phase_report(int per) {

@@ -61,7 +61,8 @@ struct EFConst {
     float wM3G, hM3G;
     float cDeltaF[4];
     float huberTH, outlierTHSumComponent;
-    int debug_flags;   // profiling experiments only, never set by the product path: bit1 skip the J stores, bit2 disable the XCD mapping
+    int debug_flags;   // profiling experiments only, never set by the product path: bit1 skip the J stores, bit2 disable the XCD mapping,
+                       // bit5 stage stamps of k_ef_linearize into EFArrays::dbg_stamps (tools/exp_linearize_stages.py)
 };
 
 struct EFArrays {
@@ -85,6 +86,8 @@ struct EFArrays {
     float* pstep;
     // images
     const float* images;     // [nF][w*h*3]
+    // diagnostics (SDVGN_DEBUG_FLAGS bit5): wall_clock64() stamps of k_ef_linearize's stages, [workgroup][wave][8]; NULL otherwise
+    unsigned long long* dbg_stamps;
 };
 
 // 64-lane double sum (for the energy), result valid in lane 63
@@ -115,9 +118,13 @@ struct LinLane {
     uint8_t fl;
 };
 
-template <int ROLE>
+// STAMPS: diagnostics instantiation only (tools/exp_linearize_stages.py); the product instantiation carries none of it
+#define LIN_STAMP(k) do { if (STAMPS) { if ((threadIdx.x & 63) == 0) stamps[k] = wall_clock64(); } } while (0)
+
+template <int ROLE, bool STAMPS>
 __device__ __forceinline__ void lin_phase1(const EFConst& C, const EFArrays& A, const PrecalcDev& pc, int t, int p, size_t s, size_t slots,
-                                           LinLane& L) {
+                                           LinLane& L, unsigned long long* stamps) {
+    LIN_STAMP(0);
     // Round trip 1: every per-slot / per-point input of this lane in one batch of independent loads (the dense table has storage
     // behind every slot, so the loads need no flag test); the flag-dependent work starts after them.  The sched_barriers pin the
     // order [loads | pattern projection | 16 tap loads | centre projection + Jacobian row | tap consumption]: without them the
@@ -130,6 +137,8 @@ __device__ __forceinline__ void lin_phase1(const EFConst& C, const EFArrays& A, 
     const float2 m = A.rmatcher[s];
     L.e_prev = (ROLE == 0) ? A.renergy[s] : 0.0f;
     __builtin_amdgcn_sched_barrier(0);
+    if (STAMPS) { const float dep = pu + (float)fl + m.x + c4.x + w4.x + ids; if (dep == 1.2345e30f) stamps[7] = 1; }   // the stamp below waits for the loads
+    LIN_STAMP(1);
     L.fl = fl;
     L.todo = (fl & RF_EXISTS) && !(fl & RF_LINEARIZED);
     bool oob = (st == RS_OOB) || !(fl & RF_MATCHER);
@@ -156,6 +165,7 @@ __device__ __forceinline__ void lin_phase1(const EFConst& C, const EFArrays& A, 
         bp4[k] = img + 3 * (ix + iy * C.w);
     }
     __builtin_amdgcn_sched_barrier(0);
+    LIN_STAMP(2);
     // Round trip 2: 4 x (2 rows x 24 B) tap loads back to back
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -164,6 +174,7 @@ __device__ __forceinline__ void lin_phase1(const EFConst& C, const EFArrays& A, 
         for (int q = 0; q < 6; ++q) { tp[k][q] = bp4[k][q]; tp[k][6 + q] = bq[q]; }
     }
     __builtin_amdgcn_sched_barrier(0);
+    LIN_STAMP(7);   // all 16 tap loads have been issued
 
     // centre projection (both roles) and this role's row of the geometric Jacobian (Residuals.cpp:93-155), while the taps fly
     float Ku = 0, Kv = 0, u = 0, v = 0, drescale = 0, new_idepth = 0, KliP0 = 0, KliP1 = 0;
@@ -215,6 +226,9 @@ __device__ __forceinline__ void lin_phase1(const EFConst& C, const EFArrays& A, 
     L.energyLeft = hwm * (res0 * res0 + res1 * res1) * (2 - hwm);
     if (hwm < 1) hwm = sqrtf(hwm);
     __builtin_amdgcn_sched_barrier(0);
+    LIN_STAMP(3);
+    if (STAMPS) { float dep = 0; for (int k = 0; k < 4; ++k) dep += tp[k][0] + tp[k][11]; if (dep == 1.2345e30f) stamps[6] = 1; }
+    LIN_STAMP(4);
 
     // consume the taps: per-pixel terms of the reference's pattern loop (:157-194); summed later in pixel order by role 0
     const float col[4] = {c4.x, c4.y, c4.z, c4.w};
@@ -239,6 +253,7 @@ __device__ __forceinline__ void lin_phase1(const EFConst& C, const EFArrays& A, 
         L.wj[k] = hw * hw * (h1 * h1 + h2 * h2);
         if (inb[k] && isfinite(g0)) L.ok |= 1u << k;
     }
+    LIN_STAMP(5);
     // this role's row of the new Jacobian goes to the buffer the EnergyFunctional side does NOT own
     L.wrote = L.todo && !oob;
     if (L.wrote && (!(C.debug_flags & 2) || hwm != hwm)) {
@@ -253,6 +268,7 @@ __device__ __forceinline__ void lin_phase1(const EFConst& C, const EFArrays& A, 
     }
 }
 
+template <bool STAMPS>
 __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
                                                        double* __restrict__ energy_partial) {
     __shared__ double s_e[2];
@@ -280,9 +296,11 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, con
     L.todo = false; L.oob = true; L.wrote = false; L.ok = 0; L.energyLeft = 0; L.e_prev = 0; L.fl = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { L.e[k] = 0; L.wj[k] = 0; }
+    unsigned long long* stamps = nullptr;
+    if (STAMPS) stamps = A.dbg_stamps + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
     if (active) {
-        if (role == 0) lin_phase1<0>(C, A, pc, t, p, s, slots, L);
-        else lin_phase1<1>(C, A, pc, t, p, s, slots, L);
+        if (role == 0) lin_phase1<0, STAMPS>(C, A, pc, t, p, s, slots, L, stamps);
+        else lin_phase1<1, STAMPS>(C, A, pc, t, p, s, slots, L, stamps);
     }
     if (role == 1) {
 #pragma unroll
@@ -325,6 +343,8 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, con
     }
     __syncthreads();
     if (threadIdx.x == 0) energy_partial[(size_t)pair * gridDim.x + chunk] = s_e[0] + s_e[1];
+    if (STAMPS) __builtin_amdgcn_s_waitcnt(0);   // all of this wave's stores have been acknowledged
+    LIN_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------------------------
