@@ -53,3 +53,10 @@ for x in range(8):
     b = wg[:, 0].min()
     s_rel, e_rel = (wg[:, 0] - b) * tick_us, (wg[:, 6] - b) * tick_us
     print("%3d %7d %11.2f %11.2f %11.2f %11.2f %11.2f" % (x, len(wg), np.median(s_rel), np.percentile(s_rel, 90), s_rel.max(), np.median(e_rel), e_rel.max()))
+
+# where do the slowest waves spend their time?
+slow = tot >= np.percentile(tot, 90)
+fast = tot <= np.percentile(tot, 10)
+print("\nmean stage durations (us): slowest 10 %% of the waves (total %.2f) | fastest 10 %% (total %.2f)" % (tot[slow].mean(), tot[fast].mean()))
+for k in range(7):
+    print("  %-20s -> %-20s %6.2f | %6.2f" % (names[k], names[k + 1], d[slow, k].mean(), d[fast, k].mean()))
