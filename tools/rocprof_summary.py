@@ -59,6 +59,25 @@ def main():
                 d.get("scratch_size"), d.get("workgroup_x"), "(%s,%s)" % (d.get("grid_x"), d.get("grid_y"))))
     except sqlite3.Error as e:
         print("# kernels view unavailable: %s" % e)
+    # the roofline kernel by launch context: bench.py times it in back-to-back launches (the previous launch of the same kernel started
+    # < 25 us earlier), the optimize loop launches it between other kernels
+    try:
+        rows = cur.execute("select start, duration from kernels where name like '%k_ef_linearize%' order by start").fetchall()
+        if len(rows) > 2:
+            st = [r[0] for r in rows]
+            du = [r[1] / 1000.0 for r in rows]
+            b2b = [du[i] for i in range(1, len(du)) if st[i] - st[i - 1] < 25000]
+            loop = [du[i] for i in range(1, len(du)) if st[i] - st[i - 1] >= 25000] + du[:1]
+
+            def stats(v):
+                v = sorted(v)
+                return "n=%d avg=%.2f median=%.2f p10=%.2f p90=%.2f us" % (len(v), sum(v) / len(v), v[len(v) // 2], v[len(v) // 10], v[(9 * len(v)) // 10]) if v else "n=0"
+            print()
+            print("# k_ef_linearize by launch context")
+            print("#   back-to-back launches (what bench.py's roofline line times): %s" % stats(b2b))
+            print("#   launches inside the optimize loop / API sequences:             %s" % stats(loop))
+    except sqlite3.Error as e:
+        print("# per-dispatch durations unavailable: %s" % e)
 
 
 if __name__ == "__main__":
