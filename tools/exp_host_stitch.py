@@ -1,5 +1,7 @@
-import sys, time, ctypes as C, numpy as np
-sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__file__), "..", ".."))
+"""Host-only microbenchmark of the fp64 stitch + solve (sdvgn_ef_stitch_solve_host on a host-only handle, no GPU needed).
+SDVGN_PROFILE=1 prints the per-phase split (sdvgn_debug_phase_report)."""
+import os, sys, time, ctypes as C, numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from sdv_loam_amd import api, parallel, synthetic as syn
 W = syn.make_window(w=320, h=160, nF=8, pts_per_kf=200, seed=7, calib=dict(fx=200., fy=205., cx=159.5, cy=79.5))
 L = api.load_library()
