@@ -289,6 +289,28 @@ int sdvgn_ef_optimize(sdvgn_ef* ef, int mnumOptIts, int flags /* bit0: run exact
                       works on the state its predecessor's normal equations were built on, so it re-uses the stitched HA/bA/Hsc/bsc and the
                       per-point Schur terms (only lambda changed) instead of accumulating again -- same trace and final state, bit for bit */,
                       double* trace, int trace_stride, int trace_cap);
+/* ---- key-frame cycle around optimize: marginalisation (SURVEY 8 row b2 mode 2, EnergyFunctional.cpp:434-597) -------------------------
+ * void EFResidual::fixLinearizationF(EnergyFunctional*)   EnergyFunctionalStructs.cpp:45-55, for every ACTIVE residual of the points with
+ * mask[p] != 0 (FullSystem::flagPointsForRemoval calls it after re-linearising + applying those residuals, FullSystem.cpp:771-783 --
+ * here: sdvgn_ef_linearize_all + sdvgn_ef_apply_res): res_toZeroF = resF - (Jpdxi . adHTdeltaF + Jpdc . cDeltaF + Jpdd * deltaF),
+ * isLinearized = true. */
+int sdvgn_ef_fix_linearization(sdvgn_ef* ef, const unsigned char* mask /* [nP] */);
+/* void EnergyFunctional::marginalizePointsF()  EnergyFunctional.cpp:514-576 (+ dropPointsF :578-597) under the reference's
+ * setting_solverMode (SOLVER_ORTHOGONALIZE_X_LATER: no null-space branch): for the points with marg[p] != 0 (stateFlag == PS_MARGINALIZE)
+ * priorF *= setting_idepthFixPriorMargFac, AccumulatedTopHessianSSE::addPoint<2> + AccumulatedSCHessianSSE::addPoint(p, false) on the
+ * device, stitch without priors, HM += setting_margWeightFac * (M - Msc), bM likewise.  Those points and the ones with drop[p] != 0
+ * (PS_DROP; drop may be NULL) then leave the window (their residual slots cease to exist).  Single-GPU entry point. */
+int sdvgn_ef_marginalize_points(sdvgn_ef* ef, const unsigned char* marg /* [nP] */, const unsigned char* drop /* [nP] or NULL */);
+/* EnergyFunctional::HM, bM as they stand ((4+6nF)^2 and 4+6nF doubles; zeros if none was set). */
+int sdvgn_ef_get_marg_prior(sdvgn_ef* ef, double* HM, double* bM);
+/* void EnergyFunctional::marginalizeFrame(EFFrame*)  EnergyFunctional.cpp:434-512, the algebra on HM / bM: frame idx is moved to the end,
+ * its prior added (:468-469), the Schur complement taken on the preconditioned system (:471-493).  Host-only and pure: outputs are
+ * (4+6(nF-1))^2 and 4+6(nF-1) doubles; the caller rebuilds the window without the frame (sdvgn_ef_set_frames ...) and installs them with
+ * sdvgn_ef_set_marg_prior, like the reference re-indexes its frames (:495-511). */
+int sdvgn_ef_marginalize_frame(sdvgn_ef* ef, int idx, double* HM_out, double* bM_out);
+/* EFResidual::res_toZeroF (nR x 2) and isLinearized (nR), in the order of sdvgn_ef_set_residuals (tests). */
+int sdvgn_ef_get_res_toZero(sdvgn_ef* ef, float* res_toZero2, unsigned char* isLinearized);
+
 /* state after optimize: CalibHessian::value_scaled, FrameHessian::state (nF x 10), PointHessian::idepth (nP) */
 int sdvgn_ef_get_state(sdvgn_ef* ef, double* value_scaled4, double* state10, float* idepth);
 /* wall time (microseconds, host steady_clock) of every loop body of the last sdvgn_ef_optimize call; returns their number */

@@ -26,6 +26,20 @@ def _L():
         L.orc_ef_set_residuals.argtypes = [vp, C.c_int, i32p, i32p, i32p, u8p, f64p, u8p, u8p]
         L.orc_ef_set_marg_prior.argtypes = [vp, f64p, f64p]
         L.orc_ef_set_nullspaces.argtypes = [vp, C.c_int, f64p]
+        L.orc_ef_fix_linearization.argtypes = [vp, u8p]
+        L.orc_ef_fix_linearization.restype = None
+        L.orc_ef_marginalize_points.argtypes = [vp, u8p, u8p]
+        L.orc_ef_marginalize_points.restype = None
+        L.orc_ef_marginalize_frame.argtypes = [vp, C.c_int, f64p, f64p]
+        L.orc_ef_marginalize_frame.restype = None
+        L.orc_ef_get_marg_prior.argtypes = [vp, f64p, f64p]
+        L.orc_ef_get_marg_prior.restype = None
+        L.orc_ef_get_res_toZero.argtypes = [vp, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), u8p]
+        L.orc_ef_get_res_toZero.restype = None
+        L.orc_ef_get_adHTdeltaF.argtypes = [vp, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")]
+        L.orc_ef_get_adHTdeltaF.restype = None
+        L.orc_ef_get_frame_prior.argtypes = [vp, C.c_int, f64p, f64p]
+        L.orc_ef_get_frame_prior.restype = None
         L.orc_ef_set_threads.argtypes = [vp, C.c_int]
         L.orc_ef_set_threads.restype = None
         L.orc_ef_set_precalc.argtypes = [vp]
@@ -184,6 +198,43 @@ class OracleEF:
 
     def resInA(self):
         return self.L.orc_ef_res_in_A(self.h_)
+
+    # ---- marginalisation (EnergyFunctionalStructs.cpp:45-55, EnergyFunctional.cpp:434-576) ----
+    def fixLinearization(self, mask):
+        self.L.orc_ef_fix_linearization(self.h_, np.ascontiguousarray(mask, np.uint8))
+
+    def marginalizePoints(self, marg, drop=None):
+        marg = np.ascontiguousarray(marg, np.uint8)
+        drop = np.zeros_like(marg) if drop is None else np.ascontiguousarray(drop, np.uint8)
+        self.L.orc_ef_marginalize_points(self.h_, marg, drop)
+
+    def marginalizeFrame(self, idx):
+        n = self.dim - 6
+        HM, bM = np.zeros((n, n)), np.zeros(n)
+        self.L.orc_ef_marginalize_frame(self.h_, int(idx), HM.reshape(-1), bM)
+        return HM, bM
+
+    def marg_prior(self):
+        n = self.dim
+        HM, bM = np.zeros((n, n)), np.zeros(n)
+        self.L.orc_ef_get_marg_prior(self.h_, HM.reshape(-1), bM)
+        return HM, bM
+
+    def res_toZero(self):
+        out = np.zeros((self.nR, 2), np.float32)
+        lin = np.zeros(self.nR, np.uint8)
+        self.L.orc_ef_get_res_toZero(self.h_, out.reshape(-1), lin)
+        return out, lin
+
+    def adHTdeltaF(self):
+        out = np.zeros((self.nF * self.nF, 6), np.float32)
+        self.L.orc_ef_get_adHTdeltaF(self.h_, out.reshape(-1))
+        return out
+
+    def frame_prior(self, idx):
+        pr, dp = np.zeros(6), np.zeros(6)
+        self.L.orc_ef_get_frame_prior(self.h_, int(idx), pr, dp)
+        return pr, dp
 
     def set_threads(self, n):
         """n > 1: the reference's multiThreading=true paths (IndexThreadReduce, NUM_THREADS=6 in the reference) -- timing baseline

@@ -194,6 +194,7 @@ struct Residual {
 
 struct EF {
     int w, h, nF;
+    int resInM = 0;
     int nThreads = 1;   // 1 = the reference's default (multiThreading = false); > 1 = its IndexThreadReduce paths, see solve_system
     // CalibHessian
     double value_scaled[4], value_minus_value_zero[4], value[4], value_zero[4], value_backup[4];
@@ -488,11 +489,13 @@ static void add_point_top(EF* E, std::vector<AccumulatorApprox>& acc, Point& p, 
         Residual& r = E->res[ri];
         if (mode == 0) { if (r.isLinearized || !r.isActive) continue; }
         if (mode == 1) { if (!r.isLinearized || !r.isActive) continue; }
+        if (mode == 2) { if (!r.isActive) continue; }   // marginalise: all active residuals (the reference asserts isLinearized, :40)
         const RawJ& rJ = r.Jef;
         const int htIDX = r.host + r.target * E->nF;
         const float* dp = &E->adHTdeltaF[(size_t)htIDX * 6];
         float resApprox[2];
         if (mode == 0) { resApprox[0] = rJ.resF[0]; resApprox[1] = rJ.resF[1]; }
+        else if (mode == 2) { resApprox[0] = r.res_toZeroF[0]; resApprox[1] = r.res_toZeroF[1]; }   // :61-62
         else {
             float dx = 0, dy = 0;
             for (int i = 0; i < 6; ++i) { dx += rJ.Jpdxi[0][i] * dp[i]; dy += rJ.Jpdxi[1][i] * dp[i]; }
@@ -514,6 +517,7 @@ static void add_point_top(EF* E, std::vector<AccumulatorApprox>& acc, Point& p, 
     }
     if (mode == 0) { p.Hdd_accAF = Hdd_acc; p.bd_accAF = bd_acc; for (int i = 0; i < 4; ++i) p.Hcd_accAF[i] = Hcd_acc[i]; }
     else { p.Hdd_accLF = Hdd_acc; p.bd_accLF = bd_acc; for (int i = 0; i < 4; ++i) p.Hcd_accLF[i] = Hcd_acc[i]; }
+    if (mode == 2) { p.Hdd_accAF = 0; p.bd_accAF = 0; for (int i = 0; i < 4; ++i) p.Hcd_accAF[i] = 0; }   // :105-110
 }
 
 static inline double* blk(std::vector<double>& H, int n, int r, int c) { return &H[(size_t)r * n + c]; }
@@ -1033,6 +1037,109 @@ static int optimize(EF* E, int mnumOptIts, double* trace, int trace_stride, int 
     return it;
 }
 
+// ---- EFResidual::fixLinearizationF (EnergyFunctionalStructs.cpp:45-55) for the active residuals of the flagged points -------------
+static void fix_linearization(EF* E, const uint8_t* mask) {
+    for (size_t pi = 0; pi < E->points.size(); ++pi) {
+        if (!mask[pi]) continue;
+        Point& p = E->points[pi];
+        for (int ri = p.r0; ri < p.r1; ++ri) {
+            Residual& r = E->res[ri];
+            if (!r.isActive) continue;
+            const float* dp = &E->adHTdeltaF[(size_t)(r.host + E->nF * r.target) * 6];
+            float dx = 0, dy = 0, cx = 0, cy = 0;
+            for (int i = 0; i < 6; ++i) { dx += r.Jef.Jpdxi[0][i] * dp[i]; dy += r.Jef.Jpdxi[1][i] * dp[i]; }
+            for (int i = 0; i < 4; ++i) { cx += r.Jef.Jpdc[0][i] * E->cDeltaF[i]; cy += r.Jef.Jpdc[1][i] * E->cDeltaF[i]; }
+            const float Jp_delta_x = dx + cx + r.Jef.Jpdd[0] * p.deltaF;
+            const float Jp_delta_y = dy + cy + r.Jef.Jpdd[1] * p.deltaF;
+            r.res_toZeroF[0] = r.Jef.resF[0] - Jp_delta_x;
+            r.res_toZeroF[1] = r.Jef.resF[1] - Jp_delta_y;
+            r.isLinearized = true;
+        }
+    }
+}
+
+// ---- EnergyFunctional::marginalizePointsF (EnergyFunctional.cpp:514-576), setting_solverMode = SOLVER_ORTHOGONALIZE_X_LATER (no
+// ORTHOGONALIZE_POINTMARG / _FULL branch).  marg[p]: stateFlag == PS_MARGINALIZE; drop[p]: PS_DROP (dropPointsF, :578-597).  Removed
+// points keep their slots but all their residuals become inactive + linearised, which takes them out of every later loop.
+static const float setting_idepthFixPriorMargFac = 600 * 600;   // settings.cpp:22
+static const float setting_margWeightFac = 0.5f * 0.5f;         // settings.cpp:71
+static void marginalize_points(EF* E, const uint8_t* marg, const uint8_t* drop) {
+    const int nF = E->nF, n = CPARS + 6 * nF;
+    std::vector<AccumulatorApprox> acc((size_t)nF * nF);
+    for (auto& a : acc) a.initialize();
+    SCAcc S;
+    S.setZero(nF);
+    int nres = 0;
+    for (size_t pi = 0; pi < E->points.size(); ++pi) {
+        if (!marg[pi]) continue;
+        Point& p = E->points[pi];
+        p.priorF *= setting_idepthFixPriorMargFac;
+        add_point_top(E, acc, p, 2, nres);
+        add_point_sc(E, S, p, false);
+    }
+    std::vector<double> M, Mb, Msc, Mbsc;
+    stitch_top(E, acc, M, Mb, false);
+    stitch_sc(E, S, Msc, Mbsc);
+    E->resInM += nres;
+    if ((int)E->HM.size() != n * n) { E->HM.assign((size_t)n * n, 0); E->bM.assign(n, 0); }
+    for (size_t i = 0; i < (size_t)n * n; ++i) E->HM[i] += (double)setting_margWeightFac * (M[i] - Msc[i]);
+    for (int i = 0; i < n; ++i) E->bM[i] += (double)setting_margWeightFac * (Mb[i] - Mbsc[i]);
+    for (size_t pi = 0; pi < E->points.size(); ++pi) {
+        if (!marg[pi] && !(drop && drop[pi])) continue;
+        Point& p = E->points[pi];
+        for (int ri = p.r0; ri < p.r1; ++ri) { E->res[ri].isActive = false; E->res[ri].isLinearized = true; }
+    }
+}
+
+// ---- EnergyFunctional::marginalizeFrame (EnergyFunctional.cpp:434-512), the algebra on HM / bM: frame idx goes to the end, its prior is
+// added, the Schur complement on the (preconditioned) last 6x6 block is taken.  Outputs are (n-6) x (n-6) and n-6.
+static void inverse6(const double* A, double* Ainv) {   // Gauss-Jordan with partial pivoting (stands in for Eigen's Mat66::inverse)
+    double a[6][12];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { a[i][j] = A[i * 6 + j]; a[i][6 + j] = (i == j); }
+    for (int c = 0; c < 6; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 6; ++r) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (piv != c) for (int j = 0; j < 12; ++j) std::swap(a[c][j], a[piv][j]);
+        const double d = a[c][c];
+        for (int j = 0; j < 12; ++j) a[c][j] /= d;
+        for (int r = 0; r < 6; ++r) if (r != c) { const double f = a[r][c]; if (f != 0) for (int j = 0; j < 12; ++j) a[r][j] -= f * a[c][j]; }
+    }
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Ainv[i * 6 + j] = a[i][6 + j];
+}
+static void marginalize_frame(const EF* E, int idx, double* HM_out, double* bM_out) {
+    const int nF = E->nF, odim = CPARS + 6 * nF, ndim = odim - 6;
+    std::vector<double> H = E->HM, b = E->bM;
+    if ((int)H.size() != odim * odim) { H.assign((size_t)odim * odim, 0); b.assign(odim, 0); }
+    // permutation: frame idx to the end (:446-466)
+    std::vector<int> perm;
+    for (int i = 0; i < odim; ++i) if (i < CPARS + 6 * idx || i >= CPARS + 6 * idx + 6) perm.push_back(i);
+    for (int i = 0; i < 6; ++i) perm.push_back(CPARS + 6 * idx + i);
+    std::vector<double> Hp((size_t)odim * odim), bp(odim);
+    for (int i = 0; i < odim; ++i) { bp[i] = b[perm[i]]; for (int j = 0; j < odim; ++j) Hp[(size_t)i * odim + j] = H[(size_t)perm[i] * odim + perm[j]]; }
+    const Frame& f = E->frames[idx];
+    for (int i = 0; i < 6; ++i) { Hp[(size_t)(ndim + i) * odim + ndim + i] += f.prior[i]; bp[ndim + i] += f.prior[i] * f.delta_prior[i]; }   // :468-469
+    std::vector<double> SVec(odim), SVecI(odim);
+    for (int i = 0; i < odim; ++i) { SVec[i] = std::sqrt(std::fabs(Hp[(size_t)i * odim + i]) + 10); SVecI[i] = 1.0 / SVec[i]; }
+    std::vector<double> Hs((size_t)odim * odim), bs(odim);
+    for (int i = 0; i < odim; ++i) { bs[i] = SVecI[i] * bp[i]; for (int j = 0; j < odim; ++j) Hs[(size_t)i * odim + j] = SVecI[i] * Hp[(size_t)i * odim + j] * SVecI[j]; }
+    double hp[36], hpi[36];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) hp[i * 6 + j] = Hs[(size_t)(ndim + i) * odim + ndim + j];
+    for (int i = 0; i < 36; ++i) hp[i] = 0.5f * (hp[i] + hp[i]);          // `hpi = 0.5f*(hpi+hpi)` :478 (a no-op kept as written)
+    inverse6(hp, hpi);
+    for (int i = 0; i < 36; ++i) hpi[i] = 0.5f * (hpi[i] + hpi[i]);
+    // bli = bottomLeft^T * hpi  (ndim x 6); H_tl -= bli * bottomLeft ; b_head -= bli * b_tail
+    std::vector<double> bli((size_t)ndim * 6);
+    for (int r = 0; r < ndim; ++r) for (int c = 0; c < 6; ++c) { double a = 0; for (int k = 0; k < 6; ++k) a += Hs[(size_t)(ndim + k) * odim + r] * hpi[k * 6 + c]; bli[(size_t)r * 6 + c] = a; }
+    for (int r = 0; r < ndim; ++r) {
+        for (int c = 0; c < ndim; ++c) { double a = 0; for (int k = 0; k < 6; ++k) a += bli[(size_t)r * 6 + k] * Hs[(size_t)(ndim + k) * odim + c]; Hs[(size_t)r * odim + c] -= a; }
+        double a = 0; for (int k = 0; k < 6; ++k) a += bli[(size_t)r * 6 + k] * bs[ndim + k];
+        bs[r] -= a;
+    }
+    // unscale, symmetrise (:489-493)
+    for (int i = 0; i < odim; ++i) { bs[i] = SVec[i] * bs[i]; for (int j = 0; j < odim; ++j) Hs[(size_t)i * odim + j] = SVec[i] * Hs[(size_t)i * odim + j] * SVec[j]; }
+    for (int r = 0; r < ndim; ++r) { bM_out[r] = bs[r]; for (int c = 0; c < ndim; ++c) HM_out[(size_t)r * ndim + c] = 0.5 * (Hs[(size_t)r * odim + c] + Hs[(size_t)c * odim + r]); }
+}
+
 }  // namespace orcb
 
 using namespace orcb;
@@ -1318,6 +1425,23 @@ void orc_ef_get_sc_acc(void* e, float* accE, float* accEB, float* accD, float* H
     EF* E = (EF*)e;
     std::memcpy(accE, E->scE.data(), 4 * E->scE.size()); std::memcpy(accEB, E->scEB.data(), 4 * E->scEB.size());
     std::memcpy(accD, E->scD.data(), 4 * E->scD.size()); std::memcpy(Hcc, E->scHcc.data(), 64); std::memcpy(bc, E->scbc.data(), 16);
+}
+void orc_ef_fix_linearization(void* e, const uint8_t* mask) { fix_linearization((EF*)e, mask); }
+void orc_ef_marginalize_points(void* e, const uint8_t* marg, const uint8_t* drop) { marginalize_points((EF*)e, marg, drop); }
+void orc_ef_marginalize_frame(void* e, int idx, double* HM_out, double* bM_out) { marginalize_frame((const EF*)e, idx, HM_out, bM_out); }
+void orc_ef_get_marg_prior(void* e, double* HM, double* bM) {
+    EF* E = (EF*)e; const int n = CPARS + 6 * E->nF;
+    for (size_t i = 0; i < (size_t)n * n; ++i) HM[i] = E->HM[i];
+    for (int i = 0; i < n; ++i) bM[i] = E->bM[i];
+}
+void orc_ef_get_res_toZero(void* e, float* out2, uint8_t* isLinearized) {
+    EF* E = (EF*)e;
+    for (size_t i = 0; i < E->res.size(); ++i) { out2[2 * i] = E->res[i].res_toZeroF[0]; out2[2 * i + 1] = E->res[i].res_toZeroF[1]; isLinearized[i] = E->res[i].isLinearized; }
+}
+void orc_ef_get_adHTdeltaF(void* e, float* out) { EF* E = (EF*)e; for (size_t i = 0; i < E->adHTdeltaF.size(); ++i) out[i] = E->adHTdeltaF[i]; }
+void orc_ef_get_frame_prior(void* e, int idx, double* prior6, double* delta_prior6) {
+    const Frame& f = ((EF*)e)->frames[idx];
+    for (int i = 0; i < 6; ++i) { prior6[i] = f.prior[i]; delta_prior6[i] = f.delta_prior[i]; }
 }
 void orc_ef_set_threads(void* e, int n) { ((EF*)e)->nThreads = n < 1 ? 1 : n; }
 int orc_ef_optimize(void* e, int its, double* trace, int stride, int cap) { return optimize((EF*)e, its, trace, stride, cap); }

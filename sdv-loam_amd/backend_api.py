@@ -36,6 +36,11 @@ PROTOTYPES = [
     ("sdvgn_ef_get_top_acc", C.c_int, [vp, f64p, vp]),
     ("sdvgn_ef_get_iteration_times", C.c_int, [vp, vp, C.c_int]),
     ("sdvgn_debug_phase_report", C.c_int, [C.c_int]),
+    ("sdvgn_ef_fix_linearization", C.c_int, [vp, vp]),
+    ("sdvgn_ef_marginalize_points", C.c_int, [vp, vp, vp]),
+    ("sdvgn_ef_get_marg_prior", C.c_int, [vp, vp, vp]),
+    ("sdvgn_ef_marginalize_frame", C.c_int, [vp, C.c_int, vp, vp]),
+    ("sdvgn_ef_get_res_toZero", C.c_int, [vp, vp, vp]),
     ("sdvgn_debug_read_stamps", C.c_int, [vp, vp, C.c_int]),
     ("sdvgn_ef_frame_image_dev", vp, [vp, C.c_int]),
     ("sdvgn_rccl_unique_id", C.c_int, [vp]),
@@ -218,6 +223,34 @@ class EnergyFunctional:
         flags = (1 if fixed_its else 0) | (2 if relinearize_on_reject else 0) | (4 if reuse_after_reject else 0)
         n = self._check(self.L.sdvgn_ef_optimize(self.h_, its, flags, trace.ctypes.data_as(vp) if want_trace else None, stride, cap))
         return trace[:n]
+
+    # ---- marginalisation (the key-frame cycle around optimize) ----
+    def fixLinearization(self, mask):
+        m = np.ascontiguousarray(mask, np.uint8)
+        self._check(self.L.sdvgn_ef_fix_linearization(self.h_, m.ctypes.data_as(vp)))
+
+    def marginalizePoints(self, marg, drop=None):
+        m = np.ascontiguousarray(marg, np.uint8)
+        d = None if drop is None else np.ascontiguousarray(drop, np.uint8)
+        self._check(self.L.sdvgn_ef_marginalize_points(self.h_, m.ctypes.data_as(vp), None if d is None else d.ctypes.data_as(vp)))
+
+    def marg_prior(self):
+        n = self.dim
+        HM, bM = np.zeros((n, n)), np.zeros(n)
+        self._check(self.L.sdvgn_ef_get_marg_prior(self.h_, HM.ctypes.data_as(vp), bM.ctypes.data_as(vp)))
+        return HM, bM
+
+    def marginalizeFrame(self, idx):
+        n = self.dim - 6
+        HM, bM = np.zeros((n, n)), np.zeros(n)
+        self._check(self.L.sdvgn_ef_marginalize_frame(self.h_, int(idx), HM.ctypes.data_as(vp), bM.ctypes.data_as(vp)))
+        return HM, bM
+
+    def res_toZero(self):
+        out = np.zeros((self.nR, 2), np.float32)
+        lin = np.zeros(self.nR, np.uint8)
+        self._check(self.L.sdvgn_ef_get_res_toZero(self.h_, out.ctypes.data_as(vp), lin.ctypes.data_as(vp)))
+        return out, lin
 
     def iteration_times_us(self):
         n = self.L.sdvgn_ef_get_iteration_times(self.h_, None, 0)

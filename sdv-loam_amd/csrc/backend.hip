@@ -125,6 +125,8 @@ struct sdvgn_ef {
     float *pid_alt = nullptr, *pidz_alt = nullptr, *pdeltaF_alt = nullptr;
     PrecalcDev* precalc_alt = nullptr;
     unsigned long long* dbg_stamps = nullptr;     // SDVGN_DEBUG_FLAGS bit5 only (kDbgStampWords words)
+    uint8_t *marg_mask_dev = nullptr, *drop_mask_dev = nullptr;   // point masks of fixLinearization / marginalizePointsF
+    int resInM = 0;
     const PrecalcDev* precalc_staged = nullptr;   // pinned half the last ef_upload_precalc filled
     bool in_optimize_loop = false;                // finish_solve then also does doStepFromBackup's host part before its launch
     float step_sumT = 0, step_sumR = 0;
@@ -213,7 +215,7 @@ static void ef_update_const(sdvgn_ef* e) {  // CalibHessian float views, Hessian
 }
 
 // ---------------- host stitch: top (AccumulatedTopHessian.cpp:181-242 + .h:100-113) --------------------------
-static void stitch_top(sdvgn_ef* e, const double* G /*[nF*nF][256]*/) {
+static void stitch_top(sdvgn_ef* e, const double* G /*[nF*nF][256]*/, bool use_prior = true) {
     const int nF = e->nF, n = CPARS + 6 * nF;
     std::vector<double>& H = e->HA;
     std::vector<double>& b = e->bA;
@@ -266,13 +268,15 @@ static void stitch_top(sdvgn_ef* e, const double* G /*[nF*nF][256]*/) {
             b[i] += g[i * 16 + 10];
         }
     }
-    // priors (usePrior)
+    // priors (usePrior; marginalizePointsF stitches without them, EnergyFunctional.cpp:545)
+    if (use_prior) {
     for (int i = 0; i < CPARS; ++i) { H[(size_t)i * n + i] += e->cPrior[i]; b[i] += e->cPrior[i] * (double)e->C.cDeltaF[i]; }
     for (int h = 0; h < nF; ++h)
         for (int i = 0; i < 6; ++i) {
             H[(size_t)(CPARS + h * 6 + i) * n + CPARS + h * 6 + i] += e->frames[h].prior[i];
             b[CPARS + h * 6 + i] += e->frames[h].prior[i] * e->frames[h].delta_prior[i];
         }
+    }
     for (int h = 0; h < nF; ++h) {
         const int hIdx = CPARS + h * 6;
         for (int i = 0; i < CPARS; ++i) for (int j = 0; j < 6; ++j) H[(size_t)i * n + hIdx + j] = H[(size_t)(hIdx + j) * n + i];
@@ -709,6 +713,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->phost_dev, mp) | dev_alloc(&e->hostP0_dev, SDVGN_MAX_FRAMES + 1);
     bad |= dev_alloc(&e->precalc_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES) | dev_alloc(&e->precalc_alt, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES);
     bad |= dev_alloc(&e->pid_alt, mp) | dev_alloc(&e->pidz_alt, mp) | dev_alloc(&e->pdeltaF_alt, mp);
+    bad |= dev_alloc(&e->marg_mask_dev, mp) | dev_alloc(&e->drop_mask_dev, mp);
     if (getenv("SDVGN_DEBUG_FLAGS") && (atoi(getenv("SDVGN_DEBUG_FLAGS")) & 32)) {
         bad |= dev_alloc(&e->dbg_stamps, kDbgStampWords);
         if (!bad) hipMemset(e->dbg_stamps, 0, sizeof(unsigned long long) * kDbgStampWords);
@@ -764,7 +769,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->images, e->img_stage,
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
                     e->stats_dev, e->stats_partial, e->sc_off_dev, e->imm_pc_dev, e->rstate_new2, e->renergy_new2, e->renergy_wo2,
-                    e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->precalc_alt, e->dbg_stamps};
+                    e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->precalc_alt, e->dbg_stamps, e->marg_mask_dev, e->drop_mask_dev};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->precalc_host) hipHostFree(e->precalc_host);
     if (e->acc_host) hipHostFree(e->acc_host);
@@ -1467,6 +1472,130 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     }
     if (g_pt.on) sdvgn_debug_phase_report(it);
     return it;
+}
+
+// ---- marginalisation: EFResidual::fixLinearizationF, EnergyFunctional::marginalizePointsF / dropPointsF / marginalizeFrame ----------
+int sdvgn_ef_fix_linearization(sdvgn_ef* e, const unsigned char* mask) {
+    if (!e || !mask || e->nP < 1) return SDVGN_E_ARG;
+    if (!e->havePrecalc || !e->haveAdjoints) return SDVGN_E_STATE;
+    EF_DEVICE(e);
+    HIPCHK(hipMemcpyAsync(e->marg_mask_dev, mask, e->nP, hipMemcpyHostToDevice, e->stream));
+    const size_t slots = (size_t)e->nF * e->nP;
+    k_ef_fix_linearization<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->marg_mask_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));   // `mask` may be freed by the caller
+    e->has_linearized = true;
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_marginalize_points(sdvgn_ef* e, const unsigned char* marg, const unsigned char* drop) {
+    if (!e || !marg || e->nP < 1) return SDVGN_E_ARG;
+    if (!e->havePrecalc || !e->haveAdjoints) return SDVGN_E_STATE;
+    if (ef_sharded(e)) return SDVGN_E_STATE;   // single-GPU entry point (the key-frame cycle around optimize), not part of cfg4
+    EF_DEVICE(e);
+    const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF, chunks = chunks_for_np(e);
+    HIPCHK(hipMemcpyAsync(e->marg_mask_dev, marg, e->nP, hipMemcpyHostToDevice, e->stream));
+    if (drop) HIPCHK(hipMemcpyAsync(e->drop_mask_dev, drop, e->nP, hipMemcpyHostToDevice, e->stream));
+    int mx = 1;
+    for (int h = 0; h < nF; ++h) mx = std::max(mx, e->hostP0[h + 1] - e->hostP0[h]);
+    const int sc_chunks = std::min(kMaxChunks, (mx + 127) / 128);
+    const int sc_ppb = ((mx + sc_chunks - 1) / sc_chunks + 63) / 64 * 64;
+    const int ntop = pairs * kTopE, nsc = nF * kScE, n_top = chunks * pairs, n_pt = (e->nP + 63) / 64;
+    // addPoint<2> + AccumulatedSCHessian::addPoint(p, false) over the flagged points (priorF *= setting_idepthFixPriorMargFac inside)
+    k_ef_marg_stage1<<<n_top + n_pt, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, chunks, n_top,
+                                                          e->marg_mask_dev, e->ppriorF);
+    k_ef_marg_sc_gram<<<dim3(sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, sc_ppb, e->marg_mask_dev);
+    k_ef_acc_reduce<<<(ntop + nsc + 255) / 256 + 1, 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks, e->nres_partial,
+                                                                         e->sc_off_dev, e->acc_dev, 0, ntop + nsc, 1, nullptr, nullptr, 0);
+    k_ef_remove_points<<<(unsigned)(((size_t)nF * e->nP + 255) / 256), 256, 0, e->stream>>>(nF, e->nP, e->rflags, e->marg_mask_dev, drop ? e->drop_mask_dev : nullptr);
+    HIPCHK(hipGetLastError());
+    const int na = (int)acc_count(e);
+    HIPCHK(hipMemcpyAsync(e->acc_host, e->acc_dev, sizeof(double) * na, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->acc_in_host = false;
+    // stitchDouble(M, Mb, usePrior = false), SC stitch, HM += margWeightFac * (M - Msc), bM likewise (:545-566); the null-space
+    // branches are off under setting_solverMode = SOLVER_ORTHOGONALIZE_X_LATER
+    stitch_top(e, e->acc_host, /*use_prior=*/false);
+    stitch_sc(e, e->acc_host + (size_t)pairs * kTopE);
+    e->resInM += (int)e->acc_host[na - 1];
+    if ((int)e->HM.size() != n * n) { e->HM.assign((size_t)n * n, 0); e->bM.assign(n, 0); }
+    const double wfac = (double)(0.5f * 0.5f);   // setting_margWeightFac, settings.cpp:71
+    for (size_t i = 0; i < (size_t)n * n; ++i) e->HM[i] += wfac * (e->HA[i] - e->Hsc[i]);
+    for (int i = 0; i < n; ++i) e->bM[i] += wfac * (e->bA[i] - e->bsc[i]);
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_get_marg_prior(sdvgn_ef* e, double* HM, double* bM) {
+    if (!e || !HM || !bM || e->nF < 1) return SDVGN_E_ARG;
+    const int n = CPARS + 6 * e->nF;
+    if ((int)e->HM.size() != n * n) { std::memset(HM, 0, sizeof(double) * n * n); std::memset(bM, 0, sizeof(double) * n); return SDVGN_OK; }
+    std::memcpy(HM, e->HM.data(), sizeof(double) * n * n);
+    std::memcpy(bM, e->bM.data(), sizeof(double) * n);
+    return SDVGN_OK;
+}
+
+static void inverse6(const double* A, double* Ainv) {   // Gauss-Jordan with partial pivoting (Mat66::inverse, EnergyFunctional.cpp:479)
+    double a[6][12];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { a[i][j] = A[i * 6 + j]; a[i][6 + j] = (i == j); }
+    for (int c = 0; c < 6; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 6; ++r) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (piv != c) for (int j = 0; j < 12; ++j) std::swap(a[c][j], a[piv][j]);
+        const double d = a[c][c];
+        for (int j = 0; j < 12; ++j) a[c][j] /= d;
+        for (int r = 0; r < 6; ++r) if (r != c) { const double f = a[r][c]; if (f != 0) for (int j = 0; j < 12; ++j) a[r][j] -= f * a[c][j]; }
+    }
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Ainv[i * 6 + j] = a[i][6 + j];
+}
+
+// EnergyFunctional::marginalizeFrame (:434-512), the algebra on HM / bM only: frame idx moves to the end, its prior is added, the
+// Schur complement on the preconditioned last 6x6 block is taken.  Pure host function of the handle's HM, bM and frame prior; the
+// caller rebuilds the window without that frame and installs the outputs with sdvgn_ef_set_marg_prior.
+int sdvgn_ef_marginalize_frame(sdvgn_ef* e, int idx, double* HM_out, double* bM_out) {
+    if (!e || !HM_out || !bM_out || idx < 0 || idx >= e->nF || e->nF < 2) return SDVGN_E_ARG;
+    const int nF = e->nF, odim = CPARS + 6 * nF, ndim = odim - 6;
+    std::vector<double> H = e->HM, b = e->bM;
+    if ((int)H.size() != odim * odim) { H.assign((size_t)odim * odim, 0); b.assign(odim, 0); }
+    std::vector<int> perm;
+    for (int i = 0; i < odim; ++i) if (i < CPARS + 6 * idx || i >= CPARS + 6 * idx + 6) perm.push_back(i);
+    for (int i = 0; i < 6; ++i) perm.push_back(CPARS + 6 * idx + i);
+    std::vector<double> Hp((size_t)odim * odim), bp(odim);
+    for (int i = 0; i < odim; ++i) { bp[i] = b[perm[i]]; for (int j = 0; j < odim; ++j) Hp[(size_t)i * odim + j] = H[(size_t)perm[i] * odim + perm[j]]; }
+    const FrameH& f = e->frames[idx];
+    for (int i = 0; i < 6; ++i) { Hp[(size_t)(ndim + i) * odim + ndim + i] += f.prior[i]; bp[ndim + i] += f.prior[i] * f.delta_prior[i]; }
+    std::vector<double> SVec(odim), SVecI(odim), Hs((size_t)odim * odim), bs(odim);
+    for (int i = 0; i < odim; ++i) { SVec[i] = std::sqrt(std::fabs(Hp[(size_t)i * odim + i]) + 10); SVecI[i] = 1.0 / SVec[i]; }
+    for (int i = 0; i < odim; ++i) { bs[i] = SVecI[i] * bp[i]; for (int j = 0; j < odim; ++j) Hs[(size_t)i * odim + j] = SVecI[i] * Hp[(size_t)i * odim + j] * SVecI[j]; }
+    double hp[36], hpi[36];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) hp[i * 6 + j] = Hs[(size_t)(ndim + i) * odim + ndim + j];
+    inverse6(hp, hpi);   // the reference's two `0.5f*(hpi+hpi)` statements (:478,480) are identities
+    std::vector<double> bli((size_t)ndim * 6);
+    for (int r = 0; r < ndim; ++r) for (int c = 0; c < 6; ++c) { double a = 0; for (int k = 0; k < 6; ++k) a += Hs[(size_t)(ndim + k) * odim + r] * hpi[k * 6 + c]; bli[(size_t)r * 6 + c] = a; }
+    for (int r = 0; r < ndim; ++r) {
+        for (int c = 0; c < ndim; ++c) { double a = 0; for (int k = 0; k < 6; ++k) a += bli[(size_t)r * 6 + k] * Hs[(size_t)(ndim + k) * odim + c]; Hs[(size_t)r * odim + c] -= a; }
+        double a = 0; for (int k = 0; k < 6; ++k) a += bli[(size_t)r * 6 + k] * bs[ndim + k];
+        bs[r] -= a;
+    }
+    for (int i = 0; i < odim; ++i) { bs[i] = SVec[i] * bs[i]; for (int j = 0; j < odim; ++j) Hs[(size_t)i * odim + j] = SVec[i] * Hs[(size_t)i * odim + j] * SVec[j]; }
+    for (int r = 0; r < ndim; ++r) { bM_out[r] = bs[r]; for (int c = 0; c < ndim; ++c) HM_out[(size_t)r * ndim + c] = 0.5 * (Hs[(size_t)r * odim + c] + Hs[(size_t)c * odim + r]); }
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_get_res_toZero(sdvgn_ef* e, float* res_toZero2, unsigned char* isLinearized) {
+    if (!e || !res_toZero2 || !isLinearized || e->host_only) return SDVGN_E_ARG;
+    EF_DEVICE(e);
+    const size_t slots = (size_t)e->nF * e->nP;
+    std::vector<float> r2z(2 * slots);
+    std::vector<uint8_t> fl(slots);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(r2z.data(), e->rres_toZero, sizeof(float) * 2 * slots, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(fl.data(), e->rflags, slots, hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->nR; ++i) {
+        const size_t s = (size_t)e->r_slot[i];
+        res_toZero2[2 * i] = r2z[s]; res_toZero2[2 * i + 1] = r2z[slots + s];
+        isLinearized[i] = (fl[s] & RF_LINEARIZED) ? 1 : 0;
+    }
+    return SDVGN_OK;
 }
 
 int sdvgn_debug_read_stamps(sdvgn_ef* e, unsigned long long* out, int cap_words) {

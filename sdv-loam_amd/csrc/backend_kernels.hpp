@@ -541,9 +541,15 @@ __global__ void __launch_bounds__(256) k_ef_apply(int nF, int nP, EFArrays A, co
 // frame t (coalesced: consecutive lanes = consecutive points), lanes of wave 0 add the 8 targets in ascending order.
 struct PointSmem { float part[kMaxFrames][13][64]; };
 
-// body for one workgroup of 256 threads = 64 points; wave w handles targets w and w + 4
+// body for one workgroup of 256 threads = 64 points; wave w handles targets w and w + 4.
+// MODE 0: solveSystemF (addPoint<0> and <1> + accumulateSCF head, shiftPriorToZero = true).
+// MODE 2: marginalizePointsF (EnergyFunctional.cpp:514-549) for the points with mask[p] != 0: priorF *= setting_idepthFixPriorMargFac,
+//         addPoint<2> (all active residuals, resApprox = res_toZeroF; sums go to the L fields, the A fields are zeroed,
+//         AccumulatedTopHessian.cpp:61-62,99-110) + SC head with shiftPriorToZero = false; other points are left untouched.
+template <int MODE = 0>
 __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
-                                           const int* __restrict__ phost, int block, PointSmem& S) {
+                                           const int* __restrict__ phost, int block, PointSmem& S,
+                                           const uint8_t* __restrict__ mask = nullptr, float* __restrict__ prior_w = nullptr) {
     float (*part)[13][64] = S.part;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = block * 64 + lane;
@@ -553,6 +559,7 @@ __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, 
     if (p < C.nP) {
         h = phost[p];
         mine = precalc[h * C.nF + h].np != 0;   // host frame in this rank's shard
+        if (MODE == 2) mine = mine && mask[p] != 0;
     }
 #pragma unroll
     for (int t = wave; t < kMaxFrames; t += 4) {
@@ -569,7 +576,13 @@ __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, 
             float c0[4], c1[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { c0[i] = Je[(14 + i) * slots]; c1[i] = Je[(18 + i) * slots]; }
-            if (!(fl & RF_LINEARIZED)) {
+            if (MODE == 2) {
+                const float r0 = A.rres_toZero[s], r1 = A.rres_toZero[slots + s];
+                v[6] = r0 * d0 + r1 * d1;
+                v[7] = d0 * d0 + d1 * d1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[8 + i] = c0[i] * d0 + c1[i] * d1;
+            } else if (!(fl & RF_LINEARIZED)) {
                 const float r0 = Je[0], r1 = Je[slots];
                 v[0] = r0 * d0 + r1 * d1;
                 v[1] = d0 * d0 + d1 * d1;
@@ -614,12 +627,13 @@ __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, 
         for (int i = 0; i < 4; ++i) A.pHcd[(size_t)i * C.nP + p] = 0;
         return;
     }
-    const float prior = A.ppriorF[p];
+    float prior = A.ppriorF[p];
+    if (MODE == 2) { prior *= 600.0f * 600.0f; prior_w[p] = prior; }   // setting_idepthFixPriorMargFac, EnergyFunctional.cpp:527
     float H = HddA + HddL + prior;
     if (H < 1e-10) H = 1e-10;
     A.pHdi[p] = (float)(1.0 / H);
     float bds = bdA + bdL;
-    bds += prior * A.pdeltaF[p];  // shiftPriorToZero == true in accumulateSCF_MT
+    if (MODE != 2) bds += prior * A.pdeltaF[p];  // shiftPriorToZero == true in accumulateSCF_MT, false in marginalizePointsF
     A.pbdSum[p] = bds;
 #pragma unroll
     for (int i = 0; i < 4; ++i) A.pHcd[(size_t)i * C.nP + p] = sum[2 + i] + sum[8 + i];
@@ -659,10 +673,12 @@ __device__ __forceinline__ void gram_tile_accumulate(const float* __restrict__ t
 // 0-3 Jpdc, 4-9 Jpdxi, 10 res; two row sets (x and y).  partial: [pair][chunk][256] floats (row-major 16x16).
 struct TopGramSmem { float tile[4][2][16 * kTileStride]; float red[4][256]; int s_n[4]; };
 
-// body for workgroup (bx of gx chunks, pair)
+// body for workgroup (bx of gx chunks, pair).  MODE 0: addPoint<0>; MODE 2: addPoint<2> over the points with mask[p] != 0 (all
+// active residuals, residual feature = res_toZeroF).
+template <int MODE = 0>
 __device__ __forceinline__ void top_gram_body(const EFConst& C, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
                                               float* __restrict__ partial, int* __restrict__ nres_partial, int bx, int pair, int gx,
-                                              TopGramSmem& S) {
+                                              TopGramSmem& S, const uint8_t* __restrict__ mask = nullptr) {
     float (*tile)[2][16 * kTileStride] = S.tile;
     float (*red)[256] = S.red;
     int* s_n = S.s_n;
@@ -682,7 +698,8 @@ __device__ __forceinline__ void top_gram_body(const EFConst& C, const EFArrays& 
             if (pl < np) {
                 s = (size_t)t * C.nP + (P0 + pl);
                 fl = A.rflags[s];
-                use = (fl & RF_EXISTS) && (fl & RF_ACTIVE) && !(fl & RF_LINEARIZED);
+                if (MODE == 2) use = (fl & RF_EXISTS) && (fl & RF_ACTIVE) && mask[P0 + pl] != 0;
+                else use = (fl & RF_EXISTS) && (fl & RF_ACTIVE) && !(fl & RF_LINEARIZED);
             }
             const float* Je = A.J + (size_t)((fl & RF_SEL) ? 1 : 0) * kJPlanes * slots + s;
             float* tx = tile[wave][0];
@@ -698,8 +715,13 @@ __device__ __forceinline__ void top_gram_body(const EFConst& C, const EFArrays& 
                 tx[(4 + i) * kTileStride + lane] = use ? Je[(2 + i) * slots] : 0.0f;
                 ty[(4 + i) * kTileStride + lane] = use ? Je[(8 + i) * slots] : 0.0f;
             }
-            tx[10 * kTileStride + lane] = use ? Je[0] : 0.0f;
-            ty[10 * kTileStride + lane] = use ? Je[slots] : 0.0f;
+            if (MODE == 2) {
+                tx[10 * kTileStride + lane] = use ? A.rres_toZero[s] : 0.0f;
+                ty[10 * kTileStride + lane] = use ? A.rres_toZero[slots + s] : 0.0f;
+            } else {
+                tx[10 * kTileStride + lane] = use ? Je[0] : 0.0f;
+                ty[10 * kTileStride + lane] = use ? Je[slots] : 0.0f;
+            }
 #pragma unroll
             for (int i = 11; i < 16; ++i) { tx[i * kTileStride + lane] = 0.0f; ty[i * kTileStride + lane] = 0.0f; }
             cnt += use ? 1 : 0;
@@ -746,9 +768,9 @@ template <int A> struct ScTile {   // a-th upper tile of the 4x4 tile grid, row-
 };
 
 // body of k_ef_sc_gram for one wave; WAVE is a compile-time constant so that feature / tile indices fold
-template <int WAVE>
+template <int WAVE, int MODE = 0>
 __device__ __forceinline__ void sc_gram_wave(const EFConst& C, const EFArrays& A, int P0, int begin, int end, float* tile, float* wrow,
-                                             float* __restrict__ out) {
+                                             float* __restrict__ out, const uint8_t* __restrict__ mask = nullptr) {
     const int lane = threadIdx.x & 63;
     const size_t slots = (size_t)C.nF * C.nP;
     constexpr int NQ = (WAVE + 8 < 10) ? 3 : 2;   // tiles WAVE, WAVE+4, WAVE+8 (< 10)
@@ -780,7 +802,7 @@ __device__ __forceinline__ void sc_gram_wave(const EFConst& C, const EFArrays& A
             }
             stage[j] = v;
         }
-        if (WAVE == 3) stage_w = (in && !A.psensor[p]) ? A.pHdi[p] : 0.0f;
+        if (WAVE == 3) stage_w = (in && !A.psensor[p] && (MODE != 2 || mask[p] != 0)) ? A.pHdi[p] : 0.0f;
     };
     if (begin < end) fetch(begin);
     for (int base = begin; base < end; base += 64) {
@@ -813,17 +835,19 @@ __device__ __forceinline__ void sc_gram_wave(const EFConst& C, const EFArrays& A
 
 struct ScGramSmem { float tile[64 * kTileStride]; float wrow[64]; };
 
+template <int MODE = 0>
 __device__ __forceinline__ void sc_gram_body(const EFConst& C, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
-                                             float* __restrict__ partial, int pts_per_block, int bx, int h, int gx, ScGramSmem& S) {
+                                             float* __restrict__ partial, int pts_per_block, int bx, int h, int gx, ScGramSmem& S,
+                                             const uint8_t* __restrict__ mask = nullptr) {
     const int wave = threadIdx.x >> 6;
     const int P0 = precalc[h * C.nF + h].P0, np = precalc[h * C.nF + h].np;   // np == 0 outside this rank's shard
     const int begin = bx * pts_per_block, end = min(np, begin + pts_per_block);
     float* out = partial + ((size_t)h * gx + bx) * 10 * 256;
     switch (wave) {   // wave-uniform: every wave runs straight-line code specialised for the tiles / features it owns
-        case 0: sc_gram_wave<0>(C, A, P0, begin, end, S.tile, S.wrow, out); break;
-        case 1: sc_gram_wave<1>(C, A, P0, begin, end, S.tile, S.wrow, out); break;
-        case 2: sc_gram_wave<2>(C, A, P0, begin, end, S.tile, S.wrow, out); break;
-        default: sc_gram_wave<3>(C, A, P0, begin, end, S.tile, S.wrow, out); break;
+        case 0: sc_gram_wave<0, MODE>(C, A, P0, begin, end, S.tile, S.wrow, out, mask); break;
+        case 1: sc_gram_wave<1, MODE>(C, A, P0, begin, end, S.tile, S.wrow, out, mask); break;
+        case 2: sc_gram_wave<2, MODE>(C, A, P0, begin, end, S.tile, S.wrow, out, mask); break;
+        default: sc_gram_wave<3, MODE>(C, A, P0, begin, end, S.tile, S.wrow, out, mask); break;
     }
 }
 
@@ -831,6 +855,58 @@ __global__ void __launch_bounds__(256) k_ef_sc_gram(EFConst C, EFArrays A, const
                                                     float* __restrict__ partial, int pts_per_block) {
     __shared__ ScGramSmem S;
     sc_gram_body(C, A, precalc, partial, pts_per_block, blockIdx.x, blockIdx.y, gridDim.x, S);
+}
+
+// ---- marginalizePointsF (EnergyFunctional.cpp:514-549): the same three bodies in MODE 2 over the points flagged by `mask` ----
+__global__ void __launch_bounds__(256) k_ef_marg_stage1(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                        const int* __restrict__ phost, float* __restrict__ top_partial,
+                                                        int* __restrict__ nres_partial, int top_chunks, int n_top,
+                                                        const uint8_t* __restrict__ mask, float* __restrict__ prior_w) {
+    __shared__ union U { TopGramSmem t; PointSmem p; __device__ U() {} } S;
+    const int b = blockIdx.x;
+    if (b < n_top) top_gram_body<2>(C, A, precalc, top_partial, nres_partial, b % top_chunks, b / top_chunks, top_chunks, S.t, mask);
+    else point_body<2>(C, A, precalc, phost, b - n_top, S.p, mask, prior_w);
+}
+__global__ void __launch_bounds__(256) k_ef_marg_sc_gram(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                         float* __restrict__ partial, int pts_per_block, const uint8_t* __restrict__ mask) {
+    __shared__ ScGramSmem S;
+    sc_gram_body<2>(C, A, precalc, partial, pts_per_block, blockIdx.x, blockIdx.y, gridDim.x, S, mask);
+}
+
+// EFResidual::fixLinearizationF (EnergyFunctionalStructs.cpp:45-55) for the active residuals of the flagged points: one thread per slot.
+// res_toZeroF = resF - (Jpdxi . adHTdeltaF + Jpdc . cDeltaF + Jpdd * deltaF), isLinearized = true.
+__global__ void __launch_bounds__(256) k_ef_fix_linearization(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                              const int* __restrict__ phost, const uint8_t* __restrict__ mask) {
+    const size_t slots = (size_t)C.nF * C.nP;
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= slots) return;
+    const int p = (int)(s % C.nP), t = (int)(s / C.nP);
+    if (!mask[p]) return;
+    const int h = phost[p];
+    const PrecalcDev& pc = precalc[h * C.nF + t];
+    if (precalc[h * C.nF + h].np == 0) return;   // host frame not in this rank's shard
+    uint8_t fl = A.rflags[s];
+    if (!(fl & RF_EXISTS) || !(fl & RF_ACTIVE)) return;
+    const float* Je = A.J + (size_t)((fl & RF_SEL) ? 1 : 0) * kJPlanes * slots + s;
+    const float dd = A.pdeltaF[p];
+    float dx = 0, dy = 0, cx = 0, cy = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { dx += Je[(2 + i) * slots] * pc.dp[i]; dy += Je[(8 + i) * slots] * pc.dp[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { cx += Je[(14 + i) * slots] * C.cDeltaF[i]; cy += Je[(18 + i) * slots] * C.cDeltaF[i]; }
+    const float jx = dx + cx + Je[22 * slots] * dd, jy = dy + cy + Je[23 * slots] * dd;
+    A.rres_toZero[s] = Je[0] - jx;
+    A.rres_toZero[slots + s] = Je[slots] - jy;
+    A.rflags[s] = fl | RF_LINEARIZED;
+}
+
+// removePoint / dropPointsF for the flagged points: their residual slots cease to exist
+__global__ void __launch_bounds__(256) k_ef_remove_points(int nF, int nP, uint8_t* __restrict__ rflags, const uint8_t* __restrict__ marg,
+                                                          const uint8_t* __restrict__ drop) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= (size_t)nF * nP) return;
+    const int p = (int)(s % nP);
+    if (marg[p] || (drop && drop[p])) rflags[s] = 0;
 }
 
 // Fixed-order fp64 sum of the per-workgroup partials into the PACKED accumulator buffer, all three parts in one launch:

@@ -1,0 +1,83 @@
+"""GPU parity for the marginalisation step (SURVEY 8 row b2 mode 2): sdvgn_ef_fix_linearization, sdvgn_ef_marginalize_points,
+sdvgn_ef_marginalize_frame against the CPU oracle (EnergyFunctionalStructs.cpp:45-55, EnergyFunctional.cpp:434-597)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def api(sdvgn_lib):
+    from sdv_loam_amd import backend_api
+    return backend_api
+
+
+def make(api, orc, W):
+    from oracle.backend import OracleEF
+    G = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+    O = OracleEF(W.w, W.h).load(W)
+    G.linearizeAll(); G.applyRes()
+    O.linearizeAll(); O.applyRes()
+    return G, O
+
+
+@pytest.mark.parametrize("cfg", [dict(w=320, h=160, nF=5, pts_per_kf=120, seed=4, calib=dict(fx=200., fy=205., cx=159.5, cy=79.5)),
+                                 dict(w=640, h=240, nF=8, pts_per_kf=300, seed=9, calib=dict(fx=400., fy=410., cx=319.5, cy=119.5)),
+                                 dict(w=320, h=160, nF=3, pts_per_kf=70, seed=2, calib=dict(fx=200., fy=205., cx=159.5, cy=79.5))])
+def test_fix_linearization_and_marginalize_points(api, orc, cfg):
+    from sdv_loam_amd import synthetic as syn
+    W = syn.make_window(**cfg)
+    W.idepth_zero = (W.idepth + np.random.default_rng(5).normal(0, 2e-4, W.nP)).astype(np.float32)   # deltaF != 0
+    G, O = make(api, orc, W)
+    rng = np.random.default_rng(1)
+    marg = (rng.random(W.nP) < 0.2).astype(np.uint8)
+    drop = ((rng.random(W.nP) < 0.1) & (marg == 0)).astype(np.uint8)
+    G.fixLinearization(marg); O.fixLinearization(marg)
+    rg, lg = G.res_toZero(); ro, lo = O.res_toZero()
+    assert np.array_equal(lg, lo) and lo.sum() > 20
+    assert np.array_equal(rg, ro)                                  # per-residual float arithmetic in the oracle's order: bit-exact
+    H0, b0 = O.marg_prior()
+    G.marginalizePoints(marg, drop); O.marginalizePoints(marg, drop)
+    Hg, bg = G.marg_prior(); Ho, bo = O.marg_prior()
+    assert np.linalg.norm(Ho - H0) > 0
+    assert rel_err(Hg - H0, Ho - H0) < 1e-5 and rel_err(bg - b0, bo - b0) < 1e-5      # what the step added
+    assert rel_err(Hg, Ho) < 1e-6 and rel_err(bg, bo) < 1e-6
+    # the window goes on without those points: same system, same solution
+    xg = G.solveSystemF(0, 0.1); O.solveSystemF(0, 0.1)
+    so = O.system()
+    assert rel_err(G.system()["HFinal"], so["HFinal"]) < 1e-5
+    assert rel_err(xg, so["x"]) < 1e-4
+    tg, to = G.optimize(4), O.optimize(4)
+    assert len(tg) == len(to) and np.array_equal(tg[:, [0, 1, 2, 6]], to[:, [0, 1, 2, 6]])
+
+
+def test_marginalize_points_nothing_flagged_is_a_no_op(api, orc):
+    from sdv_loam_amd import synthetic as syn
+    W = syn.make_window(w=320, h=160, nF=4, pts_per_kf=100, seed=3, calib=dict(fx=200., fy=205., cx=159.5, cy=79.5))
+    G, O = make(api, orc, W)
+    H0, b0 = G.marg_prior()
+    x0 = G.solveSystemF(0, 0.1)
+    G.marginalizePoints(np.zeros(W.nP, np.uint8))
+    H1, b1 = G.marg_prior()
+    assert np.array_equal(H0, H1) and np.array_equal(b0, b1)
+    assert np.array_equal(G.solveSystemF(0, 0.1), x0)
+
+
+def test_marginalize_frame(api, orc):
+    from sdv_loam_amd import synthetic as syn
+    W = syn.make_window(w=320, h=160, nF=5, pts_per_kf=120, seed=4, calib=dict(fx=200., fy=205., cx=159.5, cy=79.5))
+    G, O = make(api, orc, W)
+    m = (np.random.default_rng(2).random(W.nP) < 0.3).astype(np.uint8)
+    for X in (G, O):
+        X.fixLinearization(m); X.marginalizePoints(m)
+    for idx in range(W.nF):
+        Hg, bg = G.marginalizeFrame(idx)
+        Ho, bo = O.marginalizeFrame(idx)
+        assert Hg.shape == (G.dim - 6, G.dim - 6)
+        assert rel_err(Hg, Ho) < 1e-6 and rel_err(bg, bo) < 1e-6
+        assert np.array_equal(Hg, Hg.T)
