@@ -151,6 +151,27 @@ def immature_golden():
                         idepth=idp, res_state=rs)      # the window itself is backend_small.npz (same generator call)
 
 
+def marginalize_golden():
+    """fixLinearizationF + marginalizePointsF + marginalizeFrame on the backend_small window (same generator call), deltaF != 0."""
+    W = syn.make_window(w=200, h=96, nF=3, pts_per_kf=60, seed=4, calib=dict(fx=150., fy=152., cx=99.5, cy=47.5))
+    idz = (W.idepth + np.random.default_rng(23).normal(0, 2e-4, W.nP)).astype(np.float32)
+    W.idepth_zero = idz
+    E = OracleEF(W.w, W.h).load(W)
+    E.linearizeAll(); E.applyRes()
+    rng = np.random.default_rng(29)
+    marg = (rng.random(W.nP) < 0.25).astype(np.uint8)
+    drop = ((rng.random(W.nP) < 0.1) & (marg == 0)).astype(np.uint8)
+    E.fixLinearization(marg)
+    r2z, lin = E.res_toZero()
+    E.marginalizePoints(marg, drop)
+    HM, bM = E.marg_prior()
+    frames = [E.marginalizeFrame(i) for i in range(W.nF)]
+    E.solveSystemF(0, 0.1)
+    np.savez_compressed(os.path.join(HERE, "marginalize_small.npz"), idepth_zero=idz, marg=marg, drop=drop, res_toZero=r2z, isLinearized=lin,
+                        HM=HM, bM=bM, HM_frame=np.stack([f[0] for f in frames]), bM_frame=np.stack([f[1] for f in frames]),
+                        x_after=E.system()["x"], resInA_after=np.array(E.resInA()))
+
+
 if __name__ == "__main__":
     tracker_golden()
     backend_golden()
@@ -159,6 +180,7 @@ if __name__ == "__main__":
     trace_golden()
     coarse_depth_golden()
     immature_golden()
+    marginalize_golden()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

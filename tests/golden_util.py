@@ -59,3 +59,7 @@ def load_reproject():
         T.set_cur(g["cur_pose7"], syn.pyramid_numpy(g["cur_I"], levels), 1.0, 0.02, 1.0)
         return T
     return g, setup
+
+
+def load_marginalize():
+    return np.load(os.path.join(HERE, "marginalize_small.npz"))

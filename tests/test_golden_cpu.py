@@ -1,7 +1,7 @@
 """The oracle reproduces the committed golden vectors (regression pin; CPU only)."""
 import numpy as np
 
-from golden_util import load_tracker, load_window, setup_tracker
+from golden_util import load_marginalize, load_tracker, load_window, setup_tracker
 
 
 def test_tracker_oracle_matches_golden(orc):
@@ -125,3 +125,23 @@ def test_immature_oracle_matches_golden(orc):
     W, g, args = _immature_golden()
     r = OracleEF(W.w, W.h).load(W).optimizeImmature(*args)
     assert np.array_equal(r[0], g["result"]) and np.array_equal(r[1], g["idepth"], equal_nan=True) and np.array_equal(r[2], g["res_state"])
+
+
+def test_marginalize_oracle_matches_golden(orc):
+    from oracle.backend import OracleEF
+    W, _ = load_window()
+    g = load_marginalize()
+    W.idepth_zero = g["idepth_zero"]
+    E = OracleEF(W.w, W.h).load(W)
+    E.linearizeAll(); E.applyRes()
+    E.fixLinearization(g["marg"])
+    r2z, lin = E.res_toZero()
+    assert np.array_equal(r2z, g["res_toZero"]) and np.array_equal(lin, g["isLinearized"])
+    E.marginalizePoints(g["marg"], g["drop"])
+    HM, bM = E.marg_prior()
+    assert np.allclose(HM, g["HM"], rtol=1e-10, atol=1e-300) and np.allclose(bM, g["bM"], rtol=1e-10, atol=1e-300)
+    for i in range(W.nF):
+        Hf, bf = E.marginalizeFrame(i)
+        assert np.allclose(Hf, g["HM_frame"][i], rtol=1e-9, atol=1e-12) and np.allclose(bf, g["bM_frame"][i], rtol=1e-9, atol=1e-12)
+    E.solveSystemF(0, 0.1)
+    assert E.resInA() == int(g["resInA_after"]) and np.allclose(E.system()["x"], g["x_after"], rtol=1e-9, atol=1e-14)

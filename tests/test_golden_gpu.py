@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from common import rel_err
-from golden_util import load_tracker, load_window, setup_tracker
+from golden_util import load_marginalize, load_tracker, load_window, setup_tracker
 
 pytestmark = pytest.mark.gpu
 
@@ -111,3 +111,22 @@ def test_immature_gpu_matches_golden(sdvgn_lib):
     W, g, args = _immature_golden()
     r = backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W).optimizeImmature(*args)
     assert np.array_equal(r[0], g["result"]) and np.array_equal(r[1], g["idepth"], equal_nan=True) and np.array_equal(r[2], g["res_state"])
+
+
+def test_marginalize_gpu_matches_golden(sdvgn_lib):
+    from sdv_loam_amd import backend_api
+    W, _ = load_window()
+    g = load_marginalize()
+    W.idepth_zero = g["idepth_zero"]
+    E = backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+    E.linearizeAll(); E.applyRes()
+    E.fixLinearization(g["marg"])
+    r2z, lin = E.res_toZero()
+    assert np.array_equal(lin, g["isLinearized"]) and np.array_equal(r2z, g["res_toZero"])
+    E.marginalizePoints(g["marg"], g["drop"])
+    HM, bM = E.marg_prior()
+    assert rel_err(HM, g["HM"]) < 1e-6 and rel_err(bM, g["bM"]) < 1e-6
+    for i in range(W.nF):
+        Hf, bf = E.marginalizeFrame(i)
+        assert rel_err(Hf, g["HM_frame"][i]) < 1e-6 and rel_err(bf, g["bM_frame"][i]) < 1e-6
+    assert rel_err(E.solveSystemF(0, 0.1), g["x_after"]) < 1e-4
