@@ -295,6 +295,9 @@ int sdvgn_ef_optimize(sdvgn_ef* ef, int mnumOptIts, int flags /* bit0: run exact
  * here: sdvgn_ef_linearize_all + sdvgn_ef_apply_res): res_toZeroF = resF - (Jpdxi . adHTdeltaF + Jpdc . cDeltaF + Jpdd * deltaF),
  * isLinearized = true. */
 int sdvgn_ef_fix_linearization(sdvgn_ef* ef, const unsigned char* mask /* [nP] */);
+/* PointFrameResidual::resetOOB (Residuals.h:70-76: state_NewEnergy = state_energy = 0, state_NewState = OUTLIER, state_state = IN) for the
+ * non-linearised residuals of the points with mask[p] != 0 (NULL: all points, the head of FullSystem::optimize :353-364). */
+int sdvgn_ef_reset_oob(sdvgn_ef* ef, const unsigned char* mask /* [nP] or NULL */);
 /* void EnergyFunctional::marginalizePointsF()  EnergyFunctional.cpp:514-576 (+ dropPointsF :578-597) under the reference's
  * setting_solverMode (SOLVER_ORTHOGONALIZE_X_LATER: no null-space branch): for the points with marg[p] != 0 (stateFlag == PS_MARGINALIZE)
  * priorF *= setting_idepthFixPriorMargFac, AccumulatedTopHessianSSE::addPoint<2> + AccumulatedSCHessianSSE::addPoint(p, false) on the

@@ -28,6 +28,8 @@ def _L():
         L.orc_ef_set_nullspaces.argtypes = [vp, C.c_int, f64p]
         L.orc_ef_fix_linearization.argtypes = [vp, u8p]
         L.orc_ef_fix_linearization.restype = None
+        L.orc_ef_reset_oob.argtypes = [vp, vp]
+        L.orc_ef_reset_oob.restype = None
         L.orc_ef_marginalize_points.argtypes = [vp, u8p, u8p]
         L.orc_ef_marginalize_points.restype = None
         L.orc_ef_marginalize_frame.argtypes = [vp, C.c_int, f64p, f64p]
@@ -202,6 +204,9 @@ class OracleEF:
     # ---- marginalisation (EnergyFunctionalStructs.cpp:45-55, EnergyFunctional.cpp:434-576) ----
     def fixLinearization(self, mask):
         self.L.orc_ef_fix_linearization(self.h_, np.ascontiguousarray(mask, np.uint8))
+
+    def resetOOB(self, mask=None):
+        self.L.orc_ef_reset_oob(self.h_, None if mask is None else np.ascontiguousarray(mask, np.uint8).ctypes.data_as(vp))
 
     def marginalizePoints(self, marg, drop=None):
         marg = np.ascontiguousarray(marg, np.uint8)

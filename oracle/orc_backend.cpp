@@ -1427,6 +1427,14 @@ void orc_ef_get_sc_acc(void* e, float* accE, float* accEB, float* accD, float* H
     std::memcpy(accD, E->scD.data(), 4 * E->scD.size()); std::memcpy(Hcc, E->scHcc.data(), 64); std::memcpy(bc, E->scbc.data(), 16);
 }
 void orc_ef_fix_linearization(void* e, const uint8_t* mask) { fix_linearization((EF*)e, mask); }
+void orc_ef_reset_oob(void* e, const uint8_t* mask) {   // PointFrameResidual::resetOOB (Residuals.h:70-76) for the flagged points (NULL: all)
+    EF* E = (EF*)e;
+    for (Residual& r : E->res) {
+        if (mask && !mask[r.point]) continue;
+        if (r.isLinearized) continue;
+        r.state_NewEnergy = r.state_energy = 0; r.state_NewState = OUTLIER; r.state_state = IN;
+    }
+}
 void orc_ef_marginalize_points(void* e, const uint8_t* marg, const uint8_t* drop) { marginalize_points((EF*)e, marg, drop); }
 void orc_ef_marginalize_frame(void* e, int idx, double* HM_out, double* bM_out) { marginalize_frame((const EF*)e, idx, HM_out, bM_out); }
 void orc_ef_get_marg_prior(void* e, double* HM, double* bM) {

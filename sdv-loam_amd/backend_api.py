@@ -37,6 +37,7 @@ PROTOTYPES = [
     ("sdvgn_ef_get_iteration_times", C.c_int, [vp, vp, C.c_int]),
     ("sdvgn_debug_phase_report", C.c_int, [C.c_int]),
     ("sdvgn_ef_fix_linearization", C.c_int, [vp, vp]),
+    ("sdvgn_ef_reset_oob", C.c_int, [vp, vp]),
     ("sdvgn_ef_marginalize_points", C.c_int, [vp, vp, vp]),
     ("sdvgn_ef_get_marg_prior", C.c_int, [vp, vp, vp]),
     ("sdvgn_ef_marginalize_frame", C.c_int, [vp, C.c_int, vp, vp]),
@@ -228,6 +229,10 @@ class EnergyFunctional:
     def fixLinearization(self, mask):
         m = np.ascontiguousarray(mask, np.uint8)
         self._check(self.L.sdvgn_ef_fix_linearization(self.h_, m.ctypes.data_as(vp)))
+
+    def resetOOB(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self._check(self.L.sdvgn_ef_reset_oob(self.h_, None if m is None else m.ctypes.data_as(vp)))
 
     def marginalizePoints(self, marg, drop=None):
         m = np.ascontiguousarray(marg, np.uint8)

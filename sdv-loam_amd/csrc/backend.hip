@@ -545,9 +545,10 @@ __global__ void k_ef_point_step(int nP, int mode, float fac, float* __restrict__
 
 
 // PointFrameResidual::resetOOB for every non-linearised residual (start of FullSystem::optimize, :353-364)
-__global__ void k_ef_reset_oob(size_t slots, EFArrays A) {
+__global__ void k_ef_reset_oob(size_t slots, EFArrays A, const uint8_t* __restrict__ mask = nullptr, int nP = 1) {
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= slots) return;
+    if (mask && !mask[s % nP]) return;
     const uint8_t fl = A.rflags[s];
     if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED)) return;
     A.renergy[s] = 0; A.renergy_new[s] = 0;
@@ -1475,6 +1476,17 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
 }
 
 // ---- marginalisation: EFResidual::fixLinearizationF, EnergyFunctional::marginalizePointsF / dropPointsF / marginalizeFrame ----------
+int sdvgn_ef_reset_oob(sdvgn_ef* e, const unsigned char* mask) {
+    if (!e || e->nP < 1) return SDVGN_E_ARG;
+    EF_DEVICE(e);
+    const size_t slots = (size_t)e->nF * e->nP;
+    if (mask) HIPCHK(hipMemcpyAsync(e->marg_mask_dev, mask, e->nP, hipMemcpyHostToDevice, e->stream));
+    k_ef_reset_oob<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(slots, e->A, mask ? e->marg_mask_dev : nullptr, e->nP);
+    HIPCHK(hipGetLastError());
+    if (mask) HIPCHK(hipStreamSynchronize(e->stream));
+    return SDVGN_OK;
+}
+
 int sdvgn_ef_fix_linearization(sdvgn_ef* e, const unsigned char* mask) {
     if (!e || !mask || e->nP < 1) return SDVGN_E_ARG;
     if (!e->havePrecalc || !e->haveAdjoints) return SDVGN_E_STATE;
