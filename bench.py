@@ -408,6 +408,44 @@ def immature_extras(W, G, want_cpu):
     return out
 
 
+def marginalize_extras(torch, W, G, want_cpu):
+    """SURVEY 8 row b2 mode 2: the marginalisation step of a key-frame on the cfg3 window -- 10 % of the points leave (resetOOB +
+    fixLinearizationF + marginalizePointsF; the window is reloaded, untimed, before every repetition because the points are removed),
+    and marginalizeFrame (host algebra)."""
+    rng = np.random.default_rng(11)
+    mask = (rng.random(W.nP) < 0.10).astype(np.uint8)
+    tt, reps = 0.0, 8
+    for k in range(reps + 1):
+        G.load(W)
+        G.linearizeAll(want_energy=False); G.applyRes()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        G.resetOOB(mask)
+        G.linearizeAll(want_energy=False); G.applyRes()
+        G.fixLinearization(mask)
+        G.marginalizePoints(mask)
+        dt = time.perf_counter() - t0
+        if k:
+            tt += dt
+    t0 = time.perf_counter()
+    for _ in range(50):
+        G.marginalizeFrame(3)
+    out = dict(points_leaving=int(mask.sum()), flag_fix_marginalize_points_ms=1e3 * tt / reps, marginalize_frame_ms=1e3 * (time.perf_counter() - t0) / 50)
+    if want_cpu:
+        from oracle.backend import OracleEF
+        O = OracleEF(W.w, W.h).load(W)
+        O.linearizeAll(); O.applyRes()
+        t0 = time.perf_counter()
+        O.resetOOB(mask)
+        O.linearizeAll(); O.applyRes()
+        O.fixLinearization(mask)
+        O.marginalizePoints(mask)
+        out["cpu_ms_1thread"] = 1e3 * (time.perf_counter() - t0)
+        out["cpu_note"] = "the oracle re-linearises the whole window like the device path (the reference touches only the departing points)"
+    G.load(W)
+    return out
+
+
 def main():
     args = parse()
     if args.pmc_child:
@@ -585,6 +623,7 @@ def main():
         out["reprojector"] = reproject_extras(W, G, local, not args.no_cpu)
         out["trace_points"] = trace_extras(W, local, not args.no_cpu)
         out["optimize_immature"] = immature_extras(W, G, not args.no_cpu)
+        out["marginalize"] = marginalize_extras(torch, W, G, not args.no_cpu)
     if rank == 0 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_backend(W)
     if rank == 0:
