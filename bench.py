@@ -122,19 +122,22 @@ def cpu_baseline_backend(W, budget_s=12.0):
         O.set_threads(threads)
         O.optimize(2)                      # warm-up
         # time only the optimize calls (loading is setup)
-        its, tt = 0, 0.0
+        its, tt, per_body = 0, 0.0, []
         while tt < budget:
             O.load(W)
             O.set_threads(threads)
             t1 = time.perf_counter()
             tr = O.optimize(6)
-            tt += time.perf_counter() - t1
+            dt1 = time.perf_counter() - t1
+            tt += dt1
             its += len(tr)
-        return its, tt
+            per_body.append(1e3 * dt1 / max(len(tr), 1))
+        return its, tt, per_body
 
-    its, tt = run(1, budget_s * 0.5)
-    its6, tt6 = run(6, budget_s * 0.25)
+    its, tt, pb = run(1, budget_s * 0.5)
+    its6, tt6, _ = run(6, budget_s * 0.25)
     return dict(value=its / tt, unit="GN iters/s", cores=1, kind="port",
+                ms_per_body=dict(median=float(np.median(pb)), p10=float(np.percentile(pb, 10)), p90=float(np.percentile(pb, 90)), calls=len(pb)),
                 sample="%d optimize-loop bodies (8 KF x 2000 pts, 112000 residuals) in %.1f s on 1 host thread; "
                        "host has %d logical CPUs" % (its, tt, os.cpu_count()),
                 threads6=dict(value=its6 / tt6, unit="GN iters/s", cores=6,
