@@ -127,7 +127,7 @@ def cpu_baseline_backend(W, budget_s=12.0):
             O.load(W)
             O.set_threads(threads)
             t1 = time.perf_counter()
-            tr = O.optimize(6)
+            tr = O.optimize(6, fixed_its=True)      # exactly 6 bodies per call, like the device's fresh-window protocol
             dt1 = time.perf_counter() - t1
             tt += dt1
             its += len(tr)
@@ -563,7 +563,7 @@ def main():
                 while tt < 3.0:
                     O2.load(W2)
                     t1 = time.perf_counter()
-                    its += len(O2.optimize(6))
+                    its += len(O2.optimize(6, fixed_its=True))
                     tt += time.perf_counter() - t1
                 fresh["perturbed_window"]["cpu_oracle_1_thread"] = its / tt
             del G2

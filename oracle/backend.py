@@ -42,6 +42,8 @@ def _L():
         L.orc_ef_get_adHTdeltaF.restype = None
         L.orc_ef_get_frame_prior.argtypes = [vp, C.c_int, f64p, f64p]
         L.orc_ef_get_frame_prior.restype = None
+        L.orc_ef_set_fixed_its.argtypes = [vp, C.c_int]
+        L.orc_ef_set_fixed_its.restype = None
         L.orc_ef_set_threads.argtypes = [vp, C.c_int]
         L.orc_ef_set_threads.restype = None
         L.orc_ef_set_precalc.argtypes = [vp]
@@ -246,7 +248,9 @@ class OracleEF:
         and tolerance-level results; 1 (default) is the reference's default and the parity configuration."""
         self.L.orc_ef_set_threads(self.h_, int(n))
 
-    def optimize(self, its=6, cap=128):
+    def optimize(self, its=6, cap=128, fixed_its=False):
+        """fixed_its: exactly `its` loop bodies (bench; like flags bit0 of sdvgn_ef_optimize)."""
+        self.L.orc_ef_set_fixed_its(self.h_, 1 if fixed_its else 0)
         stride = 7 + self.dim
         trace = np.zeros((cap, stride))
         n = self.L.orc_ef_optimize(self.h_, its, trace.ctypes.data_as(vp), stride, cap)

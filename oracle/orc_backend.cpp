@@ -195,6 +195,7 @@ struct Residual {
 struct EF {
     int w, h, nF;
     int resInM = 0;
+    bool fixedIts = false;   // bench only: run exactly mnumOptIts loop bodies (no early break, no nF-dependent iteration count), like flags bit0 of sdvgn_ef_optimize
     int nThreads = 1;   // 1 = the reference's default (multiThreading = false); > 1 = its IndexThreadReduce paths, see solve_system
     // CalibHessian
     double value_scaled[4], value_minus_value_zero[4], value[4], value_zero[4], value_backup[4];
@@ -967,8 +968,8 @@ static double linearize_all(EF* E) {
 static int optimize(EF* E, int mnumOptIts, double* trace, int trace_stride, int trace_cap) {
     const int nF = E->nF, n = CPARS + 6 * nF;
     if (nF < 2) return 0;
-    if (nF < 3) mnumOptIts = 100;
-    if (nF < 4) mnumOptIts = 75;
+    if (!E->fixedIts && nF < 3) mnumOptIts = 100;
+    if (!E->fixedIts && nF < 4) mnumOptIts = 75;
     for (Residual& r : E->res) if (!r.isLinearized) { r.state_NewEnergy = r.state_energy = 0; r.state_NewState = OUTLIER; r.state_state = IN; }  // resetOOB
     double lastEnergy = linearize_all(E);
     double lastEnergyL = calc_L_energy(E), lastEnergyM = calc_M_energy(E);
@@ -1032,7 +1033,7 @@ static int optimize(EF* E, int mnumOptIts, double* trace, int trace_stride, int 
             lastEnergyL = calc_L_energy(E); lastEnergyM = calc_M_energy(E);
             lambda *= 1e2;
         }
-        if (canbreak && iteration >= 1) break;   // setting_minOptIterations = 1
+        if (!E->fixedIts && canbreak && iteration >= 1) break;   // setting_minOptIterations = 1
     }
     return it;
 }
@@ -1451,6 +1452,7 @@ void orc_ef_get_frame_prior(void* e, int idx, double* prior6, double* delta_prio
     const Frame& f = ((EF*)e)->frames[idx];
     for (int i = 0; i < 6; ++i) { prior6[i] = f.prior[i]; delta_prior6[i] = f.delta_prior[i]; }
 }
+void orc_ef_set_fixed_its(void* e, int on) { ((EF*)e)->fixedIts = on != 0; }
 void orc_ef_set_threads(void* e, int n) { ((EF*)e)->nThreads = n < 1 ? 1 : n; }
 int orc_ef_optimize(void* e, int its, double* trace, int stride, int cap) { return optimize((EF*)e, its, trace, stride, cap); }
 double orc_ef_calc_L_energy(void* e) { return calc_L_energy((EF*)e); }
