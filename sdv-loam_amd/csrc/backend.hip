@@ -215,7 +215,16 @@ static void ef_update_const(sdvgn_ef* e) {  // CalibHessian float views, Hessian
 }
 
 // ---------------- host stitch: top (AccumulatedTopHessian.cpp:181-242 + .h:100-113) --------------------------
-static void stitch_top(sdvgn_ef* e, const double* G /*[nF*nF][256]*/, bool use_prior = true) {
+// Host fp64 algebra of the solve (stitches, LDLT): compiled for FMA and allowed to contract -- it is tolerance-checked double-precision
+// glue, not part of the bit-exact float paths (those are built with -ffp-contract=off and stay that way).
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#define SDVGN_HOST_FMA __attribute__((target("avx2,fma")))
+#else
+#define SDVGN_HOST_FMA
+#endif
+
+SDVGN_HOST_FMA static void stitch_top(sdvgn_ef* e, const double* G /*[nF*nF][256]*/, bool use_prior = true) {
+#pragma clang fp contract(fast)
     const int nF = e->nF, n = CPARS + 6 * nF;
     std::vector<double>& H = e->HA;
     std::vector<double>& b = e->bA;
@@ -296,7 +305,8 @@ static void stitch_top(sdvgn_ef* e, const double* G /*[nF*nF][256]*/, bool use_p
 // row q as an AXPY over the columns c >= q plus, by symmetry, a sum over c > q into column q (two accumulator sets).  The terms
 // that do not involve AH -- diag(sT) D_h diag(sT) -- are summed over the hosts in packed form and applied once; the AH D AT^T row
 // blocks go to R and enter as R + R^T at the end.
-static void stitch_sc(sdvgn_ef* e, const double* Gall /*[nF][1431]*/) {
+SDVGN_HOST_FMA static void stitch_sc(sdvgn_ef* e, const double* Gall /*[nF][1431]*/) {
+#pragma clang fp contract(fast)
     const int nF = e->nF, n = CPARS + 6 * nF, nf6 = 6 * nF;
     std::vector<double>& H = e->Hsc;
     std::vector<double>& b = e->bsc;
@@ -1128,7 +1138,8 @@ int sdvgn_ef_accumulators_dev(sdvgn_ef* e, double** buf, int* count) {
 // A[r][c], c >= r of the trailing block is kept current (half the updates of a full-square right-looking step); the multipliers
 // of step k stay in row k (A[k][c] = L[c][k], c > k), i.e. L^T sits in the strict upper triangle.  A (n x n, row-major, upper
 // triangle read) and b are overwritten; b returns x.  Same solution as the left-looking form up to rounding order.
-static void ldlt_solve_rl(int n, double* A, double* b) {
+SDVGN_HOST_FMA static void ldlt_solve_rl(int n, double* A, double* b) {
+#pragma clang fp contract(fast)
     constexpr int MAXN = CPARS + 6 * SDVGN_MAX_FRAMES;
     int perm[MAXN];
     double d0[MAXN];
