@@ -1043,9 +1043,9 @@ static int ef_accumulate(sdvgn_ef* e, bool split) {
     // one 64-point tile per Schur-Gram workgroup: the workgroup is a chain of dependent round trips (flags + JpJdF -> LDS -> MFMA), and
     // with the top reduce running beside it in stage 2 a second tile per workgroup costs more than the extra partial tiles (measured
     // 64 / 128 / 192 points per workgroup: 99.9 / 101.0 / 105.3 us per loop body)
-    // (the serial three-launch path of the sharded configuration keeps 128: 22.0 vs 23.3 us there)
-    const int sc_pts = split ? 64 : 128;
-    const int sc_chunks = std::min(kMaxChunks, (mx + sc_pts - 1) / sc_pts);
+    // (the serial three-launch path of the sharded configuration would prefer 128 -- 22.0 vs 23.3 us -- but uses the same chunking so
+    // that a sharded run reproduces the single-GPU run bit for bit, tests/test_backend_gpu.py::test_sharded_path_single_rank_nccl)
+    const int sc_chunks = std::min(kMaxChunks, (mx + 63) / 64);
     const int sc_ppb = ((mx + sc_chunks - 1) / sc_chunks + 63) / 64 * 64;
     const int ntop = pairs * kTopE, nsc = nF * kScE;
     if (split) {
