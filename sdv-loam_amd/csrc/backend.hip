@@ -1056,7 +1056,7 @@ static int ef_accumulate(sdvgn_ef* e, bool split) {
         k_ef_acc_stage1<<<n_top + n_pt, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, chunks, n_top);
         k_ef_acc_stage2<<<n_red + sc_chunks * nF, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, sc_ppb, sc_chunks, e->top_partial,
                                                                        pairs, chunks, e->acc_host, n_red, e->done_ctr, e->flags_host, ++e->seq_top);
-        k_ef_acc_reduce<<<(nsc + 255) / 256 + 1, 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks, e->nres_partial,
+        k_ef_acc_reduce<<<acc_reduce_grid(ntop, ntop + nsc, ntop, nsc, 1), 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks, e->nres_partial,
                                                                       e->sc_off_dev, e->acc_host, ntop, ntop + nsc, 1, e->done_ctr + 1, e->flags_host + 1,
                                                                       ++e->seq_acc);
         e->split_pending = true;
@@ -1066,7 +1066,7 @@ static int ef_accumulate(sdvgn_ef* e, bool split) {
         const int n_top = chunks * pairs, n_pt = (e->nP + 63) / 64;
         k_ef_acc_stage1<<<n_top + n_pt, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, chunks, n_top);
         k_ef_sc_gram<<<dim3(sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, sc_ppb);
-        k_ef_acc_reduce<<<(ntop + nsc + 255) / 256 + 1, 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks,
+        k_ef_acc_reduce<<<acc_reduce_grid(0, ntop + nsc, ntop, nsc, 1), 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks,
                                                                              e->nres_partial, e->sc_off_dev, e->acc_dev, 0, ntop + nsc, 1, nullptr, nullptr, 0);
     }
     HIPCHK(hipGetLastError());
@@ -1533,7 +1533,7 @@ int sdvgn_ef_marginalize_points(sdvgn_ef* e, const unsigned char* marg, const un
     k_ef_marg_stage1<<<n_top + n_pt, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, chunks, n_top,
                                                           e->marg_mask_dev, e->ppriorF);
     k_ef_marg_sc_gram<<<dim3(sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, sc_ppb, e->marg_mask_dev);
-    k_ef_acc_reduce<<<(ntop + nsc + 255) / 256 + 1, 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks, e->nres_partial,
+    k_ef_acc_reduce<<<acc_reduce_grid(0, ntop + nsc, ntop, nsc, 1), 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks, e->nres_partial,
                                                                          e->sc_off_dev, e->acc_dev, 0, ntop + nsc, 1, nullptr, nullptr, 0);
     k_ef_remove_points<<<(unsigned)(((size_t)nF * e->nP + 255) / 256), 256, 0, e->stream>>>(nF, e->nP, e->rflags, e->marg_mask_dev, drop ? e->drop_mask_dev : nullptr);
     HIPCHK(hipGetLastError());

@@ -913,18 +913,24 @@ __global__ void __launch_bounds__(256) k_ef_remove_points(int nF, int nP, uint8_
 // top Gram [pairs][121] (the live 11x11), SC Gram [nF][1431] (upper triangle of the live 53x53), resInA.
 // The partial loads of one output are issued in batches of 8 independent loads (one memory round trip per batch instead of
 // one per chunk); the packed-triangle -> tile offset comes from a table built once on the host (sc_off[1431]).
-// grid = ceil((e_end - e_begin) / 256) (+ 1 if do_nres: the last workgroup sums the integer residual counters).
-template <int STRIDE>
+// grid = acc_reduce_grid(...) (the last workgroup sums the integer residual counters if do_nres).
+template <int STRIDE, int BATCH = 8>
 __device__ __forceinline__ double sum_chunks_f64(const float* __restrict__ base, int chunks) {
     double s = 0;
-    for (int c0 = 0; c0 < chunks; c0 += 8) {
-        float v[8];
+    for (int c0 = 0; c0 < chunks; c0 += BATCH) {   // BATCH independent loads per memory round trip; the sum order is c = 0, 1, 2, ...
+        float v[BATCH];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (c0 + j < chunks) ? base[(size_t)(c0 + j) * STRIDE] : 0.0f;
+        for (int j = 0; j < BATCH; ++j) v[j] = (c0 + j < chunks) ? base[(size_t)(c0 + j) * STRIDE] : 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += (double)v[j];   // + 0.0 for the absent chunks is exact
+        for (int j = 0; j < BATCH; ++j) s += (double)v[j];   // + 0.0 for the absent chunks is exact
     }
     return s;
+}
+// grid of k_ef_acc_reduce for the output range [e_begin, e_end): one thread per top output, four per Schur output, + the resInA workgroup
+static inline int acc_reduce_grid(int e_begin, int e_end, int ntop, int nsc, int do_nres) {
+    const int n_top = std::max(0, std::min(e_end, ntop) - std::min(e_begin, ntop));
+    const int n_sc = std::max(0, std::min(e_end, ntop + nsc) - std::max(e_begin, ntop));
+    return (n_top + 255) / 256 + (4 * n_sc + 255) / 256 + (do_nres ? 1 : 0);
 }
 __global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__ top_partial, int pairs, int top_chunks,
                                                        const float* __restrict__ sc_partial, int nF, int sc_chunks,
@@ -946,15 +952,31 @@ __global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__
         }
         return;
     }
-    const int e = e_begin + blockIdx.x * blockDim.x + threadIdx.x;   // outputs [e_begin, e_end) of the packed buffer
-    if (e < e_end) {
-        if (e < ntop) {
+    // outputs [e_begin, e_end) of the packed buffer.  Workgroups [0, nb_top) take the top outputs of the range one per thread; the
+    // following workgroups take the Schur outputs FOUR lanes per output: lane part p sums chunks [p*q, (p+1)*q) in order, q =
+    // ceil(sc_chunks / 4), and the four partial sums are combined as (p0 + p1) + (p2 + p3) -- a fixed order, the same on every path.
+    const int top_lo = min(e_begin, ntop), top_hi = min(e_end, ntop);
+    const int nb_top = (top_hi - top_lo + 255) / 256;
+    if ((int)blockIdx.x < nb_top) {
+        const int e = top_lo + blockIdx.x * 256 + threadIdx.x;
+        if (e < top_hi) {
             const int g = e / 121, k = e - g * 121, r = k / 11, c = k - r * 11;
             out[e] = sum_chunks_f64<256>(top_partial + (size_t)g * top_chunks * 256 + r * 16 + c, top_chunks);
-        } else if (e < ntop + nsc) {
-            const int q = e - ntop, g = q / 1431, k = q - g * 1431;
-            out[e] = sum_chunks_f64<2560>(sc_partial + (size_t)g * sc_chunks * 2560 + sc_off[k], sc_chunks);
         }
+    } else {
+        const int sc_lo = max(e_begin, ntop), sc_hi = min(e_end, ntop + nsc);
+        const int v = (blockIdx.x - nb_top) * 256 + threadIdx.x;
+        const int e = sc_lo + (v >> 2), part = v & 3;
+        const int per = (sc_chunks + 3) >> 2;
+        double s = 0;
+        if (e < sc_hi) {
+            const int q = e - ntop, g = q / 1431, k = q - g * 1431;
+            const int c_lo = part * per, c_n = max(0, min(sc_chunks, c_lo + per) - c_lo);
+            s = sum_chunks_f64<2560>(sc_partial + ((size_t)g * sc_chunks + c_lo) * 2560 + sc_off[k], c_n);
+        }
+        s += __shfl_down(s, 1);     // parts 0+1 in lane 4i, 2+3 in lane 4i+2
+        s += __shfl_down(s, 2);     // (0+1) + (2+3) in lane 4i
+        if (e < sc_hi && part == 0) out[e] = s;
     }
     if (done_flag) {   // completion signal for the host (waitflag.hpp): all workgroups of this launch have stored their outputs
         __syncthreads();
