@@ -619,15 +619,16 @@ def main():
         traffic, how = measure_traffic()
         roof["traffic"] = traffic
         roof["traffic_note"] = how
-    if rank == 0 and not args.quick:
+    # the per-row extras and the CPU baseline are N = 1 material: at N > 1 the other ranks would only wait for rank 0 at the final barrier
+    if rank == 0 and world == 1 and not args.quick:
         import oracle
         out["tracker"] = tracker_extras(torch, local, args.batch, oracle, not args.no_cpu)
-    if rank == 0 and not args.quick:
+    if rank == 0 and world == 1 and not args.quick:
         out["reprojector"] = reproject_extras(W, G, local, not args.no_cpu)
         out["trace_points"] = trace_extras(W, local, not args.no_cpu)
         out["optimize_immature"] = immature_extras(W, G, not args.no_cpu)
         out["marginalize"] = marginalize_extras(torch, W, G, not args.no_cpu)
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_backend(W)
     if rank == 0:
         print(json.dumps(out))
