@@ -237,6 +237,15 @@ int sdvgn_ef_set_calib(sdvgn_ef* ef, const double value_scaled[4], const double 
  * (unscaled), frameID (0 => initial pose prior, HessianBlocks.h:220-232), ab_exposure, frameEnergyTH. */
 int sdvgn_ef_set_frames(sdvgn_ef* ef, int nF, const double* evalPT7, const double* state10, const double* state_zero10,
                         const int* frameID, const float* ab_exposure, const float* frameEnergyTH);
+/* A new frame set INVALIDATES the window tables: points and residuals must be set again (sdvgn_ef_set_points / _set_residuals;
+ * entry points that need them return SDVGN_E_STATE until then), and the marginalisation prior HM, bM is reset to zero -- a caller that
+ * carries a prior over re-installs it with sdvgn_ef_set_marg_prior.
+ *
+ * FrameHessian::frameEnergyTH of all nF frames as the last linearizeAll left them: FullSystem::setNewFrameEnergyTH
+ * (FullSystemOptimize.cpp:63-97) runs inside every linearizeAll (:122) -- here inside sdvgn_ef_linearize_all, every linearisation
+ * of sdvgn_ef_optimize and sdvgn_ef_optimize_finish -- and rewrites the NEWEST frame's threshold from the 70th percentile of
+ * state_NewEnergyWithOutlier over the active residuals that target it (device-side exact selection, k_ef_select_th). */
+int sdvgn_ef_get_frame_energy_th(sdvgn_ef* ef, float* frameEnergyTH /* [nF] */);
 /* FrameHessian::dI (level-0 AoS {I,dx,dy}, w*h*3 floats) of frame idx; _raw builds it on the GPU from the float
  * image like FrameHessian::makeImages (HessianBlocks.cpp:107-167). */
 int sdvgn_ef_set_frame_image(sdvgn_ef* ef, int idx, const float* dI_aos3);
@@ -289,6 +298,19 @@ int sdvgn_ef_optimize(sdvgn_ef* ef, int mnumOptIts, int flags /* bit0: run exact
                       works on the state its predecessor's normal equations were built on, so it re-uses the stitched HA/bA/Hsc/bsc and the
                       per-point Schur terms (only lambda changed) instead of accumulating again -- same trace and final state, bit for bit */,
                       double* trace, int trace_stride, int trace_cap);
+/* trace rows (continued): if trace_stride > 7 + (4+6nF), column 7 + (4+6nF) holds the newest frame's frameEnergyTH as the trial
+ * linearizeAll of that iteration left it.
+ *
+ * Tail of FullSystem::optimize, FullSystemOptimize.cpp:460-470: frameHessians.back()->setEvalPT(PRE_worldToCam, state with only the
+ * affine part kept), ef->setAdjointsF, setPrecalcValues, lastEnergy = linearizeAll(true) -- i.e. linearize + applyRes(true) for every
+ * active residual, the isNew bookkeeping of its point (:34-47), setNewFrameEnergyTH, and the toRemove list (:136-155): residuals
+ * that are not active afterwards are dropped (their slots cease to exist on the device as well).
+ * lastEnergy_out = lastEnergy[0]; relbs_max[nP]: per point the largest relBS over its surviving residuals (caller:
+ * maxRelBaseline = max(maxRelBaseline, relbs_max[p])); ngood_inc[nP]: numGoodResiduals increments; removed[nR] (order of
+ * sdvgn_ef_set_residuals): 1 = the residual is in toRemove.  Any output may be NULL.  The caller reads the new linearisation point back
+ * with sdvgn_ef_get_state / its own FrameHessian (evalPT = PRE_worldToCam of the newest frame) and the states with
+ * sdvgn_ef_get_residual_state (lastResiduals bookkeeping, :128-134). */
+int sdvgn_ef_optimize_finish(sdvgn_ef* ef, double* lastEnergy_out, float* relbs_max, int* ngood_inc, unsigned char* removed);
 /* ---- key-frame cycle around optimize: marginalisation (SURVEY 8 row b2 mode 2, EnergyFunctional.cpp:434-597) -------------------------
  * void EFResidual::fixLinearizationF(EnergyFunctional*)   EnergyFunctionalStructs.cpp:45-55, for every ACTIVE residual of the points with
  * mask[p] != 0 (FullSystem::flagPointsForRemoval calls it after re-linearising + applying those residuals, FullSystem.cpp:771-783 --
@@ -365,7 +387,9 @@ int sdvgn_ef_accumulator_count(sdvgn_ef* ef);
  * collective: fn(user, buf_dev, count) must sum buf_dev[0..count) over all ranks in stream order (RCCL all-reduce).
  * With a callback registered, sdvgn_ef_solve_system / sdvgn_ef_optimize all-reduce the packed accumulators (once per
  * GN iteration) and the 4 energy/step statistics (once per linearizeAll). */
-int sdvgn_ef_set_external_buffers(sdvgn_ef* ef, double* acc_dev, int acc_capacity, double* stats4_dev);
+int sdvgn_ef_set_external_buffers(sdvgn_ef* ef, double* acc_dev, int acc_capacity, double* stats_dev, int stats_capacity);
+/* stats_dev: 4 + max_points doubles -- {energy, L-energy, sum step^2, sum |idepth|} followed by this rank's candidates of
+ * setNewFrameEnergyTH's quantile (energy + 1 per point, 0 = none); ONE all-reduce per linearizeAll carries both. */
 int sdvgn_ef_set_allreduce(sdvgn_ef* ef, void (*fn)(void* user, double* buf_dev, int count), void* user);
 /* The same collectives issued by the library itself through RCCL (ncclAllReduce on the handle's stream, in place, ncclDouble /
  * ncclSum) -- no callback, no Python in the iteration.  librccl.so is resolved at run time (the instance already loaded by

@@ -73,6 +73,12 @@ def _L():
         L.orc_ef_calc_M_energy.argtypes = [vp]
         L.orc_ef_calc_M_energy.restype = C.c_double
         L.orc_ef_get_state.argtypes = [vp, f64p, f64p, f32p]
+        L.orc_ef_optimize_finish.argtypes = [vp, f32p, i32p, u8p]
+        L.orc_ef_optimize_finish.restype = C.c_double
+        L.orc_ef_get_frame_energy_th.argtypes = [vp, f32p]
+        L.orc_ef_get_frame_energy_th.restype = None
+        L.orc_ef_get_evalPT.argtypes = [vp, C.c_int, f64p, f64p]
+        L.orc_ef_get_evalPT.restype = None
         _bound = True
     return L
 
@@ -251,10 +257,29 @@ class OracleEF:
     def optimize(self, its=6, cap=128, fixed_its=False):
         """fixed_its: exactly `its` loop bodies (bench; like flags bit0 of sdvgn_ef_optimize)."""
         self.L.orc_ef_set_fixed_its(self.h_, 1 if fixed_its else 0)
-        stride = 7 + self.dim
+        stride = 8 + self.dim   # ..., x[dim], frameEnergyTH of the newest frame after the trial linearizeAll
         trace = np.zeros((cap, stride))
         n = self.L.orc_ef_optimize(self.h_, its, trace.ctypes.data_as(vp), stride, cap)
         return trace[:n]
+
+    def optimize_finish(self):
+        """Tail of FullSystem::optimize (FullSystemOptimize.cpp:460-470): setEvalPT on the newest frame, adjoints, precalc,
+        linearizeAll(true).  Returns (lastEnergy[0], relbs_max[nP], ngood_inc[nP], removed[nR])."""
+        rb = np.zeros(self.nP, np.float32)
+        ng = np.zeros(self.nP, np.int32)
+        rm = np.zeros(self.nR, np.uint8)
+        e = self.L.orc_ef_optimize_finish(self.h_, rb, ng, rm)
+        return e, rb, ng, rm
+
+    def frame_energy_th(self):
+        th = np.zeros(self.nF, np.float32)
+        self.L.orc_ef_get_frame_energy_th(self.h_, th)
+        return th
+
+    def evalPT(self, idx):
+        p, z = np.zeros(7), np.zeros(10)
+        self.L.orc_ef_get_evalPT(self.h_, int(idx), p, z)
+        return p, z
 
     def calcLEnergy(self):
         return self.L.orc_ef_calc_L_energy(self.h_)

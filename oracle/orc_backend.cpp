@@ -33,6 +33,9 @@ static const float SCALE_XI_ROT = 1.0f, SCALE_XI_TRANS = 0.5f, SCALE_F = 50.0f, 
 static const float setting_idepthFixPrior = 50 * 50, setting_initialRotPrior = 1e11, setting_initialTransPrior = 1e10,
                    setting_initialCalibHessian = 5e9, setting_outlierTHSumComponent = 50 * 50, setting_huberTH = 6;
 static const int patternNum = 8;
+// settings.cpp:108-111
+static const float setting_frameEnergyTHConstWeight = 0.5f, setting_frameEnergyTHN = 0.7f, setting_frameEnergyTHFacMedian = 1.5f,
+                   setting_overallEnergyTHWeight = 1;
 static const int patternP[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};  // settings.cpp:250
 
 enum ResState { IN = 0, OOB = 1, OUTLIER = 2 };
@@ -189,6 +192,7 @@ struct Residual {
     float res_toZeroF[2];
     float JpJdF[8];
     bool isLinearized, isActive;
+    bool dropped;   // removed by the tail of optimize (linearizeAll(true)'s toRemove list)
     float centerProjectedTo[3];
 };
 
@@ -940,7 +944,34 @@ static double calc_M_energy(EF* E) {
     for (int i = 0; i < n; ++i) { double a = 2 * E->bM[i]; for (int j = 0; j < n; ++j) a += E->HM[(size_t)i * n + j] * d[j]; s += d[i] * a; }
     return s;
 }
+// FullSystem::setNewFrameEnergyTH (FullSystemOptimize.cpp:63-97): after every linearizeAll the outlier threshold of the NEWEST
+// key-frame becomes a function of the 70th percentile of state_NewEnergyWithOutlier over the active (= non-linearised) residuals
+// that target it; the next linearize classifies IN / OUTLIER with it (Residuals.cpp:212-214).
+static void set_new_frame_energy_th(EF* E) {
+    std::vector<float> allResVec;                      // FullSystem.h:299, a vector<float>: the double energies are narrowed on push_back
+    allResVec.reserve(E->res.size());
+    const int newFrame = E->nF - 1;                    // frameHessians.back()
+    for (const Residual& r : E->res)
+        if (!r.isLinearized && r.state_NewEnergyWithOutlier >= 0 && r.target == newFrame) allResVec.push_back((float)r.state_NewEnergyWithOutlier);
+    Frame& nf = E->frames[newFrame];
+    if (allResVec.size() == 0) { nf.frameEnergyTH = 12 * 12 * patternNum; return; }
+    const int nthIdx = setting_frameEnergyTHN * allResVec.size();   // float * size_t -> float product, truncated (:85)
+    std::nth_element(allResVec.begin(), allResVec.begin() + nthIdx, allResVec.end());
+    const float nthElement = sqrtf(allResVec[nthIdx]);
+    nf.frameEnergyTH = nthElement * setting_frameEnergyTHFacMedian;
+    nf.frameEnergyTH = 26.0f * setting_frameEnergyTHConstWeight + nf.frameEnergyTH * (1 - setting_frameEnergyTHConstWeight);
+    nf.frameEnergyTH = nf.frameEnergyTH * nf.frameEnergyTH;
+    nf.frameEnergyTH *= setting_overallEnergyTHWeight * setting_overallEnergyTHWeight;
+}
+
+static double linearize_all_energy(EF* E);
+// FullSystem::linearizeAll(false) (FullSystemOptimize.cpp:99-123): the reductor over activeResiduals, then setNewFrameEnergyTH
 static double linearize_all(EF* E) {
+    const double s = linearize_all_energy(E);
+    set_new_frame_energy_th(E);
+    return s;
+}
+static double linearize_all_energy(EF* E) {
     double s = 0;
     const int T = E->nThreads;
     if (T <= 1) {
@@ -1014,6 +1045,7 @@ static int optimize(EF* E, int mnumOptIts, double* trace, int trace_stride, int 
             double* tr = trace + (size_t)iteration * trace_stride;
             tr[0] = iteration; tr[1] = lambda; tr[2] = accept; tr[3] = newEnergy; tr[4] = newEnergyL; tr[5] = newEnergyM; tr[6] = canbreak;
             for (int i = 0; i < n && 7 + i < trace_stride; ++i) tr[7 + i] = E->lastX[i];
+            if (7 + n < trace_stride) tr[7 + n] = E->frames[nF - 1].frameEnergyTH;   // as set by the trial linearizeAll
         }
         it = iteration + 1;
         if (accept) {
@@ -1036,6 +1068,49 @@ static int optimize(EF* E, int mnumOptIts, double* trace, int trace_stride, int 
         if (!E->fixedIts && canbreak && iteration >= 1) break;   // setting_minOptIterations = 1
     }
     return it;
+}
+
+// ---- tail of FullSystem::optimize (FullSystemOptimize.cpp:460-470): the newest frame's linearisation point moves to its optimised
+// pose (setEvalPT with a zero state except the affine part), adjoints / precalc are rebuilt, then linearizeAll(true):
+// linearize + applyRes(true) per active residual, the isNew bookkeeping of its point (:34-47; isNew is never cleared by the reference),
+// setNewFrameEnergyTH, and every residual that is not active afterwards is dropped (:136-155).
+// relbs_max[nP]: max over the point's surviving residuals of relBS (caller: maxRelBaseline = max(maxRelBaseline, relbs_max));
+// ngood_inc[nP]: numGoodResiduals increments; removed[nR] (input order): 1 = in toRemove.  Returns lastEnergy[0].
+static double optimize_finish(EF* E, float* relbs_max, int* ngood_inc, uint8_t* removed) {
+    Frame& nf = E->frames[E->nF - 1];
+    double newStateZero[10] = {0, 0, 0, 0, 0, 0, nf.state[6], nf.state[7], 0, 0};
+    nf.evalPT = nf.PRE_worldToCam;                      // setEvalPT (HessianBlocks.h:170-176): evalPT, setState, setStateZero
+    frame_set_state(nf, newStateZero);
+    for (int i = 0; i < 10; ++i) nf.state_zero[i] = newStateZero[i];
+    set_adjoints(E);
+    set_precalc(E); set_delta(E);
+    double lastEnergyP = 0;
+    for (size_t pi = 0; pi < E->points.size(); ++pi) { if (relbs_max) relbs_max[pi] = 0; if (ngood_inc) ngood_inc[pi] = 0; }
+    for (size_t ri = 0; ri < E->res.size(); ++ri) {
+        Residual& r = E->res[ri];
+        if (removed) removed[ri] = 0;
+        if (r.isLinearized) continue;                   // not in activeResiduals
+        lastEnergyP += linearize(E, r);
+        apply_res(r);
+        if (r.isActive) {
+            const Point& p = E->points[r.point];
+            const Precalc& pc = E->precalc[(size_t)r.host * E->nF + r.target];
+            float v3[3] = {p.u, p.v, 1}, inf[3];
+            mat3f_vec(pc.PRE_KRKiTll, v3, inf);                                  // projected point assuming infinite depth
+            const float ptp[3] = {inf[0] + pc.PRE_KtTll[0] * p.idepth_scaled, inf[1] + pc.PRE_KtTll[1] * p.idepth_scaled,
+                                  inf[2] + pc.PRE_KtTll[2] * p.idepth_scaled};   // with real depth
+            const float dx = inf[0] / inf[2] - ptp[0] / ptp[2], dy = inf[1] / inf[2] - ptp[1] / ptp[2];
+            const float relBS = 0.01 * sqrtf(dx * dx + dy * dy);                 // 0.01 (double) * float norm -> float
+            if (relbs_max && relBS > relbs_max[r.point]) relbs_max[r.point] = relBS;
+            if (ngood_inc) ngood_inc[r.point]++;
+        } else if (removed) removed[ri] = 1;
+    }
+    set_new_frame_energy_th(E);
+    for (size_t ri = 0; ri < E->res.size(); ++ri) {     // ef->dropResidual + deleteOut: the residual no longer exists
+        Residual& r = E->res[ri];
+        if (!r.isLinearized && !r.isActive) { r.isLinearized = true; r.dropped = true; }
+    }
+    return lastEnergyP;
 }
 
 // ---- EFResidual::fixLinearizationF (EnergyFunctionalStructs.cpp:45-55) for the active residuals of the flagged points -------------
@@ -1345,11 +1420,14 @@ void orc_ef_set_nullspaces(void* e, int k, const double* ns) {
 }
 void orc_ef_set_precalc(void* e) { set_precalc((EF*)e); set_delta((EF*)e); }
 void orc_ef_set_adjoints(void* e) { set_adjoints((EF*)e); }
-double orc_ef_linearize_all(void* e) {
-    EF* E = (EF*)e;
-    double s = 0;
-    for (Residual& r : E->res) if (!r.isLinearized) s += linearize(E, r);
-    return s;
+double orc_ef_linearize_all(void* e) { return linearize_all((EF*)e); }   // FullSystem::linearizeAll(false), incl. setNewFrameEnergyTH
+double orc_ef_optimize_finish(void* e, float* relbs_max, int* ngood_inc, uint8_t* removed) { return optimize_finish((EF*)e, relbs_max, ngood_inc, removed); }
+void orc_ef_get_frame_energy_th(void* e, float* th) { EF* E = (EF*)e; for (int i = 0; i < E->nF; ++i) th[i] = E->frames[i].frameEnergyTH; }
+void orc_ef_get_evalPT(void* e, int idx, double* q4t3, double* state_zero10) {
+    const Frame& f = ((EF*)e)->frames[idx];
+    for (int i = 0; i < 4; ++i) q4t3[i] = f.evalPT.q[i];
+    for (int i = 0; i < 3; ++i) q4t3[4 + i] = f.evalPT.t[i];
+    for (int i = 0; i < 10; ++i) state_zero10[i] = f.state_zero[i];
 }
 void orc_ef_apply_res(void* e) { for (Residual& r : ((EF*)e)->res) if (!r.isLinearized) apply_res(r); }
 void orc_ef_solve_system(void* e, int iteration, double lambda) { solve_system((EF*)e, iteration, lambda); }

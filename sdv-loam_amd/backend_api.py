@@ -53,7 +53,9 @@ PROTOTYPES = [
     ("sdvgn_ef_set_host_range", C.c_int, [vp, C.c_int, C.c_int]),
     ("sdvgn_ef_stitch_solve_host", C.c_int, [vp, f64p, C.c_int, C.c_double, vp]),
     ("sdvgn_ef_accumulator_count", C.c_int, [vp]),
-    ("sdvgn_ef_set_external_buffers", C.c_int, [vp, vp, C.c_int, vp]),
+    ("sdvgn_ef_set_external_buffers", C.c_int, [vp, vp, C.c_int, vp, C.c_int]),
+    ("sdvgn_ef_get_frame_energy_th", C.c_int, [vp, f32p]),
+    ("sdvgn_ef_optimize_finish", C.c_int, [vp, vp, vp, vp, vp]),
     ("sdvgn_ef_set_allreduce", C.c_int, [vp, vp, vp]),
     ("sdvgn_ef_optimize", C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
     ("sdvgn_ef_get_state", C.c_int, [vp, vp, vp, vp]),
@@ -219,11 +221,25 @@ class EnergyFunctional:
         return self.L.sdvgn_ef_stream(self.h_)
 
     def optimize(self, its=6, cap=128, want_trace=True, fixed_its=False, relinearize_on_reject=False, reuse_after_reject=False):
-        stride = 7 + self.dim
+        stride = 8 + self.dim   # ..., x[dim], frameEnergyTH of the newest frame after the trial linearizeAll
         trace = np.zeros((cap, stride))
         flags = (1 if fixed_its else 0) | (2 if relinearize_on_reject else 0) | (4 if reuse_after_reject else 0)
         n = self._check(self.L.sdvgn_ef_optimize(self.h_, its, flags, trace.ctypes.data_as(vp) if want_trace else None, stride, cap))
         return trace[:n]
+
+    def optimize_finish(self):
+        """Tail of FullSystem::optimize (FullSystemOptimize.cpp:460-470): (lastEnergy[0], relbs_max[nP], ngood_inc[nP], removed[nR])."""
+        e = C.c_double(0)
+        rb = np.zeros(self.nP, np.float32)
+        ng = np.zeros(self.nP, np.int32)
+        rm = np.zeros(max(self.nR, 1), np.uint8)
+        self._check(self.L.sdvgn_ef_optimize_finish(self.h_, C.byref(e), rb.ctypes.data_as(vp), ng.ctypes.data_as(vp), rm.ctypes.data_as(vp)))
+        return e.value, rb, ng, rm[:self.nR]
+
+    def frame_energy_th(self):
+        th = np.zeros(self.nF, np.float32)
+        self._check(self.L.sdvgn_ef_get_frame_energy_th(self.h_, th))
+        return th
 
     # ---- marginalisation (the key-frame cycle around optimize) ----
     def fixLinearization(self, mask):

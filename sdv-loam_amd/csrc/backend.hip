@@ -68,7 +68,8 @@ struct sdvgn_ef {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int nF = 0, nP = 0, nR = 0;
-    int h0 = 0, h1 = SDVGN_MAX_FRAMES;   // host-frame shard of this rank
+    int h0 = 0, h1 = SDVGN_MAX_FRAMES;   // host-frame shard of this rank (only meaningful when shard_set)
+    bool shard_set = false;              // sdvgn_ef_set_host_range was called; otherwise the shard is always [0, nF)
     // calib
     double value_scaled[4] = {0, 0, 0, 0}, value_minus_value_zero[4] = {0, 0, 0, 0};
     double value[4] = {0, 0, 0, 0}, value_zero[4] = {0, 0, 0, 0}, value_backup[4] = {0, 0, 0, 0};
@@ -96,6 +97,12 @@ struct sdvgn_ef {
     int8_t* rstate_new2 = nullptr;
     float *renergy_new2 = nullptr, *renergy_wo2 = nullptr;
     int new_cur = 0;   // which set holds the current state_New* values
+    void* fin_dev = nullptr;       // outputs of sdvgn_ef_optimize_finish (relbs_max, ngood_inc, removed), grown on demand
+    size_t fin_bytes = 0;
+    float* th_dev = nullptr;       // frameEnergyTH [2 sets][SDVGN_MAX_FRAMES]: one per state_New* set (setNewFrameEnergyTH after every linearizeAll)
+    float* th_log = nullptr;       // pinned ring: threshold of the newest frame after each linearizeAll of the last optimize call (trace, tests)
+    int th_log_n = 0;
+    size_t stats_cap = 0;          // doubles behind stats_dev: 4 statistics + max_points quantile candidates (sharded path)
     std::vector<double> iter_us;   // wall time of every loop body of the last sdvgn_ef_optimize call (microseconds)
     float2* rmatcher = nullptr;
     float *renergy = nullptr, *renergy_new = nullptr, *renergy_wo = nullptr, *rres_toZero = nullptr, *J = nullptr, *JpJd = nullptr;
@@ -179,14 +186,20 @@ static void m3f_mul(const float* A, const float* B, float* C) {
         for (int j = 0; j < 3; ++j) C[i * 3 + j] = (A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j]) + A[i * 3 + 2] * B[6 + j];
 }
 
-// point the kernels' state_New* planes at set `write` (0/1) and the read-only "previous state_NewEnergy" at set `prev`
-static void ef_select_new_set(sdvgn_ef* e, int write, int prev) {
+// point the kernels' state_New* planes at set `write` (0/1) and the read-only "previous state_NewEnergy" at set `prev`;
+// the thresholds the next linearise classifies with come from set `th_read` (default: prev), the ones its setNewFrameEnergyTH
+// produces go to set `write`
+static void ef_select_new_set(sdvgn_ef* e, int write, int prev, int th_read = -1) {
     EFArrays& A = e->A;
     A.rstate_new = write ? e->rstate_new2 : e->rstate_new;
     A.renergy_new = write ? e->renergy_new2 : e->renergy_new;
     A.renergy_wo = write ? e->renergy_wo2 : e->renergy_wo;
     A.renergy_new_prev = prev ? e->renergy_new2 : e->renergy_new;
+    if (th_read < 0) th_read = prev;
+    A.frameTH_r = e->th_dev + (size_t)th_read * SDVGN_MAX_FRAMES;
+    A.frameTH_w = e->th_dev + (size_t)write * SDVGN_MAX_FRAMES;
 }
+constexpr int kThLog = 1024;
 
 static void ef_fill_arrays(sdvgn_ef* e) {
     EFArrays& A = e->A;
@@ -195,6 +208,7 @@ static void ef_fill_arrays(sdvgn_ef* e) {
     A.rflags = e->rflags; A.rstate = e->rstate; A.rstate_new = e->rstate_new; A.rmatcher = e->rmatcher;
     A.renergy = e->renergy; A.renergy_new = e->renergy_new; A.renergy_wo = e->renergy_wo; A.rres_toZero = e->rres_toZero;
     A.renergy_new_prev = e->renergy_new; e->new_cur = 0;
+    A.frameTH_r = e->th_dev; A.frameTH_w = e->th_dev;
     A.J = e->J; A.JpJd = e->JpJd;
     A.pHddA = e->pHddA; A.pbdA = e->pbdA; A.pHcdA = e->pHcdA; A.pHddL = e->pHddL; A.pbdL = e->pbdL; A.pHcdL = e->pHcdL;
     A.pHdi = e->pHdi; A.pbdSum = e->pbdSum; A.pHcd = e->pHcd; A.pstep = e->pstep;
@@ -494,7 +508,7 @@ static int ef_upload_precalc(sdvgn_ef* e, PrecalcDev* dst = nullptr, bool stage_
                             target.state_scaled[7], ab);
             P.aff0 = (float)ab[0]; P.aff1 = (float)ab[1];
             P.b0 = (float)(host.state_zero[7] * kScaleB);
-            P.frameEnergyTH = std::max<float>(host.frameEnergyTH, target.frameEnergyTH);
+            P.unused_th = 0;
             // setDeltaF: adHTdeltaF[h + t*nF]
             const float* AHf = &e->adHostF[(size_t)(h + t * nF) * 36];
             const float* ATf = &e->adTargetF[(size_t)(h + t * nF) * 36];
@@ -507,7 +521,7 @@ static int ef_upload_precalc(sdvgn_ef* e, PrecalcDev* dst = nullptr, bool stage_
             }
             P.P0 = e->hostP0.empty() ? 0 : e->hostP0[h];
             P.np = e->hostP0.empty() ? 0 : e->hostP0[h + 1] - e->hostP0[h];
-            if (h < e->h0 || h >= e->h1) P.np = 0;   // not this rank's shard
+            if (e->shard_set && (h < e->h0 || h >= e->h1)) P.np = 0;   // not this rank's shard
         }
     ef_refresh_frame_deltas(e);
     e->precalc_staged = pch;
@@ -618,6 +632,7 @@ __global__ void k_ef_sum_stats(const double* __restrict__ pe, int nE, const doub
     }
     if (threadIdx.x < 4) out[threadIdx.x] = s[threadIdx.x][0];
     if (done_flag) {   // single workgroup: publish after the four stores (waitflag.hpp)
+        __threadfence_system();   // every storing thread orders its result stores before the flag (waitflag.hpp)
         __syncthreads();
         if (threadIdx.x == 0) { __threadfence_system(); *done_flag = done_seq; }
     }
@@ -628,6 +643,7 @@ __global__ void __launch_bounds__(256) k_ef_copy_publish(const double* __restric
                                                          volatile int* flag, int seq) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = src[i];
+    __threadfence_system();   // every storing thread orders its result stores before the flag (waitflag.hpp)
     __syncthreads();
     if (threadIdx.x == 0) publish_when_all_done(ctr, gridDim.x, flag, seq);
 }
@@ -687,6 +703,18 @@ static int ef_allreduce(sdvgn_ef* e, double* buf_dev, int count) {
     return SDVGN_OK;
 }
 
+// FullSystem::setNewFrameEnergyTH for the linearisation just launched (its state_NewEnergyWithOutlier plane is A.renergy_wo):
+// the new threshold set goes to A.frameTH_w.  Single rank: one launch, nothing to wait for (the next linearise follows on the stream).
+// Sharded: the candidates of all ranks arrive through stats_dev[4 ..] (see linearize_and_stats).
+static void ef_launch_select_th(sdvgn_ef* e, bool from_reduced) {
+    float* log_slot = e->th_log ? e->th_log + (e->th_log_n++ % kThLog) : nullptr;
+    if (from_reduced)
+        k_ef_select_th<1><<<1, kSelLanes, 0, e->stream>>>(e->nF, e->nP, nullptr, nullptr, e->stats_dev + 4, nullptr, nullptr, e->A.frameTH_r, e->A.frameTH_w, log_slot);
+    else
+        k_ef_select_th<0><<<1, kSelLanes, 0, e->stream>>>(e->nF, e->nP, e->rflags, e->A.renergy_wo, nullptr, e->phost_dev, e->precalc_dev, e->A.frameTH_r,
+                                                          e->A.frameTH_w, log_slot);
+}
+
 extern "C" {
 
 int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, void* stream) {
@@ -737,12 +765,15 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->imm_pc_dev, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES);
     const size_t accmax = (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kTopE + (size_t)SDVGN_MAX_FRAMES * kScE + 1;
     bad |= dev_alloc(&e->acc_dev, accmax);
-    bad |= dev_alloc(&e->stats_dev, 4) | dev_alloc(&e->stats_partial, 3 * (mp / 64 + 2));
+    e->stats_cap = 4 + mp;
+    bad |= dev_alloc(&e->stats_dev, e->stats_cap) | dev_alloc(&e->stats_partial, 3 * (mp / 64 + 2));
+    bad |= dev_alloc(&e->th_dev, 2 * SDVGN_MAX_FRAMES);
     if (bad) { sdvgn_ef_destroy(e); return -(int)hipErrorOutOfMemory; }
     HIPCHK(hipHostMalloc(&e->precalc_host, 2 * sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
     HIPCHK(hipHostMalloc(&e->acc_host, sizeof(double) * accmax));
     HIPCHK(hipHostMalloc(&e->stats_host, sizeof(double) * 4));
     HIPCHK(hipHostMalloc((void**)&e->flags_host, 64));
+    HIPCHK(hipHostMalloc((void**)&e->th_log, sizeof(float) * kThLog));
     e->flags_host[0] = e->flags_host[1] = e->flags_host[2] = 0;
     HIPCHK(hipMalloc((void**)&e->done_ctr, 2 * sizeof(unsigned)));
     HIPCHK(hipMemset(e->done_ctr, 0, 2 * sizeof(unsigned)));
@@ -780,12 +811,13 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->images, e->img_stage,
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
                     e->stats_dev, e->stats_partial, e->sc_off_dev, e->imm_pc_dev, e->rstate_new2, e->renergy_new2, e->renergy_wo2,
-                    e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->precalc_alt, e->dbg_stamps, e->marg_mask_dev, e->drop_mask_dev};
+                    e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->precalc_alt, e->dbg_stamps, e->marg_mask_dev, e->drop_mask_dev, e->th_dev, e->fin_dev};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->precalc_host) hipHostFree(e->precalc_host);
     if (e->acc_host) hipHostFree(e->acc_host);
     if (e->stats_host) hipHostFree(e->stats_host);
     if (e->flags_host) hipHostFree(e->flags_host);
+    if (e->th_log) hipHostFree(e->th_log);
     if (e->done_ctr) hipFree(e->done_ctr);
     if (e->imm_pc_host) hipHostFree(e->imm_pc_host);
     if (e->imm_stage) hipHostFree(e->imm_stage);
@@ -829,11 +861,35 @@ int sdvgn_ef_set_frames(sdvgn_ef* e, int nF, const double* evalPT7, const double
         if (f.frameID == 0) { for (int k = 0; k < 3; ++k) f.prior[k] = kInitialTransPrior; for (int k = 3; k < 6; ++k) f.prior[k] = kInitialRotPrior; }
     }
     const int n = CPARS + 6 * nF;
+    // the marginalisation prior belongs to a window layout: a new frame set starts without one (documented in sdvgn.h; the caller
+    // re-installs the prior it carried over with sdvgn_ef_set_marg_prior)
     e->HM.assign((size_t)n * n, 0); e->bM.assign(n, 0);
-    e->h1 = std::min(e->h1, nF);
-    if (e->h0 == 0 && e->h1 >= nF) e->h1 = nF;
+    // the point / residual tables are laid out for the previous frame count (slot = target*nP + p, hostP0[nF+1]): invalidate them,
+    // so that nothing can run on a stale layout before sdvgn_ef_set_points / _set_residuals are called again
+    e->nP = 0; e->nR = -1;
+    e->hostP0.clear(); e->phost.clear(); e->r_slot.clear();
+    if (!e->host_only) {
+        float th[2 * SDVGN_MAX_FRAMES] = {0};
+        for (int i = 0; i < nF; ++i) th[i] = th[SDVGN_MAX_FRAMES + i] = frameEnergyTH[i];
+        HIPCHK(hipSetDevice(e->device));
+        HIPCHK(hipMemcpyAsync(e->th_dev, th, sizeof(th), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        e->new_cur = 0;
+        ef_select_new_set(e, 0, 0);
+    }
     ef_update_const(e);
     e->havePrecalc = e->haveAdjoints = false;
+    return SDVGN_OK;
+}
+
+// FrameHessian::frameEnergyTH of every frame as the last linearizeAll left it (setNewFrameEnergyTH moves the newest frame's)
+int sdvgn_ef_get_frame_energy_th(sdvgn_ef* e, float* th) {
+    if (!e || !th || e->nF < 1) return SDVGN_E_ARG;
+    if (e->host_only) { for (int i = 0; i < e->nF; ++i) th[i] = e->frames[i].frameEnergyTH; return SDVGN_OK; }
+    EF_DEVICE(e);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(th, e->th_dev + (size_t)e->new_cur * SDVGN_MAX_FRAMES, sizeof(float) * e->nF, hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->nF; ++i) e->frames[i].frameEnergyTH = th[i];
     return SDVGN_OK;
 }
 
@@ -847,6 +903,7 @@ int sdvgn_ef_set_frame_states(sdvgn_ef* e, const double* state10) {
 int sdvgn_ef_set_host_range(sdvgn_ef* e, int h0, int h1) {
     if (!e || h0 < 0 || h1 < h0 || h1 > SDVGN_MAX_FRAMES) return SDVGN_E_ARG;
     e->h0 = h0; e->h1 = h1;
+    e->shard_set = !(h0 == 0 && h1 == SDVGN_MAX_FRAMES);   // [0, SDVGN_MAX_FRAMES) = "everything", whatever nF becomes
     e->havePrecalc = false;
     return SDVGN_OK;
 }
@@ -883,7 +940,11 @@ int sdvgn_ef_set_points(sdvgn_ef* e, int nP, const int* host, const float* u, co
         if (host[i] < 0 || host[i] >= e->nF || (i > 0 && host[i] < host[i - 1])) return SDVGN_E_ARG;  // grouped by host, ascending
         e->hostP0[host[i] + 1]++;
     }
-    for (int h = 0; h < e->nF; ++h) e->hostP0[h + 1] += e->hostP0[h];
+    for (int h = 0; h < e->nF; ++h) {
+        // the per-pair kernels cover kMaxChunks * 256 points of one host frame (k_ef_linearize: 2 * kMaxChunks chunks of 128)
+        if (e->hostP0[h + 1] > kMaxChunks * 256) { e->hostP0.clear(); e->phost.clear(); e->nP = 0; return SDVGN_E_ARG; }
+        e->hostP0[h + 1] += e->hostP0[h];
+    }
     e->nP = nP;
     std::vector<float> prior(nP), delta(nP), ids(nP), idz(nP);
     bool any_delta = false;
@@ -1011,11 +1072,16 @@ int sdvgn_ef_set_precalc(sdvgn_ef* e) {
 }
 
 int sdvgn_ef_linearize_all(sdvgn_ef* e, double* energy_out) {
-    if (!e || e->host_only || !e->havePrecalc || e->nR < 0) return SDVGN_E_STATE;
+    if (!e || e->host_only || !e->havePrecalc || e->nR < 0 || e->nP < 1) return SDVGN_E_STATE;
     EF_DEVICE(e);
     const int n_partials = ef_launch_linearize(e);
     double* edst = e->stats_dev;
     if (energy_out) k_ef_sum_energy<<<1, 256, 0, e->stream>>>(e->energy_partial, n_partials, edst);   // NULL: leave the per-workgroup partials
+    if (ef_sharded(e)) {   // setNewFrameEnergyTH needs the candidates of every rank: one all-reduce of [4 unused | nP candidates]
+        k_ef_pack_th_candidates<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->nF, e->nP, e->rflags, e->A.renergy_wo, e->phost_dev, e->precalc_dev, e->stats_dev + 4);
+        { const int rca = ef_allreduce(e, e->stats_dev, 4 + e->nP); if (rca) return rca; }
+        ef_launch_select_th(e, true);
+    } else ef_launch_select_th(e, false);
     HIPCHK(hipGetLastError());
     if (energy_out) {
         HIPCHK(hipMemcpyAsync(e->acc_host, edst, sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -1074,15 +1140,15 @@ static int ef_accumulate(sdvgn_ef* e, bool split) {
 }
 
 int sdvgn_ef_accumulate(sdvgn_ef* e) {
-    if (!e || e->host_only || !e->havePrecalc) return SDVGN_E_STATE;
+    if (!e || e->host_only || !e->havePrecalc || e->nP < 1) return SDVGN_E_STATE;
     EF_DEVICE(e);
     return ef_accumulate(e, false);
 }
 
-int sdvgn_ef_set_external_buffers(sdvgn_ef* e, double* acc_dev, int acc_capacity, double* stats_dev) {
+int sdvgn_ef_set_external_buffers(sdvgn_ef* e, double* acc_dev, int acc_capacity, double* stats_dev, int stats_capacity) {
     if (!e || e->host_only || !acc_dev || !stats_dev) return SDVGN_E_ARG;
     const size_t accmax = (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kTopE + (size_t)SDVGN_MAX_FRAMES * kScE + 1;
-    if ((size_t)acc_capacity < accmax) return SDVGN_E_ARG;
+    if ((size_t)acc_capacity < accmax || (size_t)stats_capacity < 4 + (size_t)e->max_points) return SDVGN_E_ARG;
     EF_DEVICE(e);
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->own_acc) hipFree(e->acc_dev);
@@ -1259,7 +1325,7 @@ static int ef_step_from_backup_host(sdvgn_ef* e, float stepsize) {
 }
 
 int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_out) {
-    if (!e || e->host_only || !e->havePrecalc) return SDVGN_E_STATE;
+    if (!e || e->host_only || !e->havePrecalc || e->nP < 1) return SDVGN_E_STATE;
     EF_DEVICE(e);
     const int nF = e->nF, n = CPARS + 6 * nF;
     g_pt.start();
@@ -1322,7 +1388,7 @@ int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_o
 }
 
 int sdvgn_ef_solve_system(sdvgn_ef* e, int iteration, double lambda, double* x_out) {
-    if (!e || e->host_only || !e->havePrecalc) return SDVGN_E_STATE;
+    if (!e || e->host_only || !e->havePrecalc || e->nP < 1) return SDVGN_E_STATE;
     EF_DEVICE(e);
     if (e->reuse_system) return sdvgn_ef_finish_solve(e, iteration, lambda, x_out);
     g_pt.start();
@@ -1376,11 +1442,17 @@ static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* 
                                              flagged ? e->stats_host : e->stats_dev, flagged ? e->flags_host + 2 : nullptr, flagged ? ++e->seq_stats : 0);
     HIPCHK(hipGetLastError());
     if (!flagged) {
-        { const int rca = ef_allreduce(e, e->stats_dev, 4); if (rca) return rca; }   // ranks hold disjoint host-frame shards
+        // ranks hold disjoint host-frame shards: ONE all-reduce carries the four sums and the candidates of setNewFrameEnergyTH's quantile
+        k_ef_pack_th_candidates<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->nF, e->nP, e->rflags, e->A.renergy_wo, e->phost_dev, e->precalc_dev, e->stats_dev + 4);
+        { const int rca = ef_allreduce(e, e->stats_dev, 4 + e->nP); if (rca) return rca; }
         k_ef_copy_publish<<<1, 256, 0, e->stream>>>(e->stats_dev, e->stats_host, 4, e->done_ctr, e->flags_host + 2, ++e->seq_stats);
+        ef_launch_select_th(e, true);
         HIPCHK(hipGetLastError());
         HIPCHK(wait_flag(e->flags_host + 2, e->seq_stats, e->stream));
     } else {
+        // setNewFrameEnergyTH: queued behind the statistics; only the NEXT linearise needs it, the host does not wait for it
+        ef_launch_select_th(e, false);
+        HIPCHK(hipGetLastError());
         HIPCHK(wait_flag(e->flags_host + 2, e->seq_stats, e->stream));
     }
     *energy = e->stats_host[0];
@@ -1409,6 +1481,8 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     if (!e->havePrecalc && (rc = ef_upload_precalc(e))) return rc;
     k_ef_reset_oob<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(slots, e->A);
     double lastEnergy, lastEnergyL, lastEnergyM;
+    e->th_log_n = 0;
+    ef_select_new_set(e, e->new_cur, e->new_cur);
     if ((rc = linearize_and_stats(e, &lastEnergy, &lastEnergyL, nullptr, nullptr))) return rc;
     lastEnergyM = calc_M_energy(e);
     if ((rc = sdvgn_ef_apply_res(e))) return rc;
@@ -1417,6 +1491,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     std::vector<double> x(n);
     int it = 0;
     e->iter_us.clear();
+    std::vector<int> th_idx;   // th_log slot of every trial linearisation (trace only)
     for (int iteration = 0; iteration < mnumOptIts; iteration++) {
         const auto t_iter = std::chrono::steady_clock::now();
         for (int i = 0; i < 4; ++i) e->value_backup[i] = e->value[i];                     // backupState
@@ -1436,6 +1511,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         g_pt.start();
         double newEnergy, newEnergyL, sID, sNID;
         ef_select_new_set(e, 1 - e->new_cur, e->new_cur);                                 // trial linearisation goes to the other set
+        th_idx.push_back(e->th_log_n % kThLog);
         if ((rc = linearize_and_stats(e, &newEnergy, &newEnergyL, &sID, &sNID))) return rc;
         g_pt.stop(PT_LIN);
         const double newEnergyM = calc_M_energy(e);
@@ -1472,13 +1548,25 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             // restored exactly, that is a bit-for-bit recomputation of the previous accepted linearisation: its energies are the
             // lastEnergy* values still held, its state_New* planes are the current set (untouched by the trial), and the J it would
             // write into the not-owned buffer is overwritten by the next linearise before anything reads it.  So: switch back.
-            ef_select_new_set(e, e->new_cur, e->new_cur);
+            // Two things do depend on that re-linearisation and are reproduced: (1) it classifies IN / OUTLIER under the threshold the
+            // TRIAL's linearizeAll just set (setNewFrameEnergyTH, FullSystemOptimize.cpp:122) -- k_ef_reclassify repeats that decision
+            // on the kept set; (2) its own setNewFrameEnergyTH recomputes the quantile of the same energies, i.e. restores the
+            // threshold of the last accepted linearisation -- which is the kept set's threshold array.
             // Exception: if the restore just moved idepth_zero (zero_differs), the linearisation point of the centre projection and
             // deltaF changed, so the kept energies do not describe the restored state -- re-linearise like the reference.
+            const int trial = 1 - e->new_cur;
             if (relinearize_on_reject || zero_differs) {
+                ef_select_new_set(e, e->new_cur, e->new_cur, /*th_read=*/trial);
                 if ((rc = linearize_and_stats(e, &lastEnergy, &lastEnergyL, nullptr, nullptr))) return rc;
                 lastEnergyM = calc_M_energy(e);
+            } else {
+                ef_select_new_set(e, e->new_cur, e->new_cur);
+                const int P0l = e->hostP0[nF - 1], npl = e->hostP0[nF] - P0l, nthr = e->nP + npl * (nF - 1);
+                k_ef_reclassify<<<(nthr + 255) / 256, 256, 0, e->stream>>>(nF, e->nP, P0l, npl, e->rflags, e->A.renergy_wo, e->A.rstate_new, e->A.renergy_new,
+                                                                           e->phost_dev, e->precalc_dev, e->th_dev + (size_t)trial * SDVGN_MAX_FRAMES);
+                HIPCHK(hipGetLastError());
             }
+            ef_select_new_set(e, e->new_cur, e->new_cur);
             lambda *= 1e2;
             // the restored state is the one this body's system was built on, bit for bit (unless idepth_zero just changed, above)
             prev_rejected_clean = !zero_differs;
@@ -1488,7 +1576,58 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         if (!fixed_its && canbreak && iteration >= 1) break;
     }
     if (g_pt.on) sdvgn_debug_phase_report(it);
+    if (trace && 7 + n < trace_stride) {   // frameEnergyTH of the newest frame as each trial linearizeAll left it
+        HIPCHK(hipStreamSynchronize(e->stream));
+        for (int i = 0; i < it && i < trace_cap; ++i) trace[(size_t)i * trace_stride + 7 + n] = e->th_log[th_idx[i]];
+    }
     return it;
+}
+
+// Tail of FullSystem::optimize (FullSystemOptimize.cpp:460-470): setEvalPT on the newest frame (its optimised pose becomes the
+// linearisation point, state = zero except the affine part), setAdjointsF, setPrecalcValues, linearizeAll(true) = linearize +
+// applyRes(true) per active residual + the isNew bookkeeping of the points (:34-47) + setNewFrameEnergyTH + the toRemove list
+// (:136-155: every residual that is not active afterwards is dropped; its slot ceases to exist here as well).
+int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_max, int* ngood_inc, unsigned char* removed) {
+    if (!e || e->host_only || e->nP < 1 || e->nR < 0 || e->nF < 1) return SDVGN_E_STATE;
+    EF_DEVICE(e);
+    const int nF = e->nF;
+    FrameH& nf = e->frames[nF - 1];
+    const double newStateZero[10] = {0, 0, 0, 0, 0, 0, nf.state[6], nf.state[7], 0, 0};
+    nf.evalPT = nf.PRE_worldToCam;
+    frame_set_state(nf, newStateZero);
+    for (int i = 0; i < 10; ++i) nf.state_zero[i] = newStateZero[i];
+    int rc;
+    if ((rc = sdvgn_ef_set_adjoints(e))) return rc;
+    if ((rc = ef_upload_precalc(e))) return rc;
+    ef_select_new_set(e, e->new_cur, e->new_cur);
+    double energy = 0, EL = 0;
+    if ((rc = linearize_and_stats(e, &energy, &EL, nullptr, nullptr))) return rc;
+    if ((rc = sdvgn_ef_apply_res(e))) return rc;
+    const size_t slots = (size_t)nF * e->nP, need = slots + 8 * (size_t)e->nP;
+    if (need > e->fin_bytes) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->fin_dev) hipFree(e->fin_dev);
+        e->fin_dev = nullptr; e->fin_bytes = 0;
+        HIPCHK(hipMalloc(&e->fin_dev, need));
+        e->fin_bytes = need;
+    }
+    float* relbs_dev = (float*)e->fin_dev;
+    int* ngood_dev = (int*)e->fin_dev + e->nP;
+    uint8_t* removed_dev = (uint8_t*)e->fin_dev + 8 * (size_t)e->nP;
+    k_ef_finish_points<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, relbs_dev, ngood_dev, removed_dev);
+    HIPCHK(hipGetLastError());
+    std::vector<uint8_t> rm(slots);
+    std::vector<float> rb(e->nP);
+    std::vector<int> ng(e->nP);
+    HIPCHK(hipMemcpyAsync(rb.data(), relbs_dev, 4 * (size_t)e->nP, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(ng.data(), ngood_dev, 4 * (size_t)e->nP, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(rm.data(), removed_dev, slots, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (lastEnergy_out) *lastEnergy_out = energy;
+    if (relbs_max) std::memcpy(relbs_max, rb.data(), 4 * (size_t)e->nP);
+    if (ngood_inc) std::memcpy(ngood_inc, ng.data(), 4 * (size_t)e->nP);
+    if (removed) for (int i = 0; i < e->nR; ++i) removed[i] = rm[(size_t)e->r_slot[i]];
+    return SDVGN_OK;
 }
 
 // ---- marginalisation: EFResidual::fixLinearizationF, EnergyFunctional::marginalizePointsF / dropPointsF / marginalizeFrame ----------
@@ -1711,7 +1850,7 @@ int sdvgn_ef_get_residual_state(sdvgn_ef* e, int* state_state, int* state_new, f
     for (int i = 0; i < e->nR; ++i) {
         const size_t s = e->r_slot[i];
         if (state_state) state_state[i] = st[s];
-        if (state_new) state_new[i] = sn[s];
+        if (state_new) state_new[i] = sn[s] & RS_MASK;   // (bit RS_WJLOW rides in the same plane)
         if (energy_new) energy_new[i] = en[s];
         if (energy_wo) energy_wo[i] = ew[s];
         if (isActive) isActive[i] = (fl[s] & RF_ACTIVE) ? 1 : 0;

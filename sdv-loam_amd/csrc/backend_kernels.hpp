@@ -40,6 +40,9 @@ constexpr int kJPlanes = 24;   // resF(2) Jpdxi[0](6) Jpdxi[1](6) Jpdc[0](4) Jpd
 constexpr int kTileStride = 66;
 
 enum : int { RS_IN = 0, RS_OOB = 1, RS_OUTLIER = 2 };
+// bit kept next to state_NewState in its plane: the linearisation found wJI2_sum < 2 (Residuals.cpp:212), which k_ef_reclassify needs
+// to repeat the IN / OUTLIER decision under another threshold; consumers of the state mask with RS_MASK
+enum : int { RS_WJLOW = 16, RS_MASK = 3 };
 enum : uint8_t { RF_EXISTS = 1, RF_MATCHER = 2, RF_LINEARIZED = 4, RF_ACTIVE = 8, RF_SEL = 16 };
 
 #define SDVGN_SCALE_F 50.0f
@@ -49,7 +52,7 @@ enum : uint8_t { RF_EXISTS = 1, RF_MATCHER = 2, RF_LINEARIZED = 4, RF_ACTIVE = 8
 struct PrecalcDev {  // FrameFramePrecalc fields linearize reads (HessianBlocks.h:51-79), one per (host,target)
     float KRKi[9], Kt[3], R0[9], t0[3];
     float aff0, aff1, b0;
-    float frameEnergyTH;  // max(host->frameEnergyTH, target->frameEnergyTH)
+    float unused_th;      // (thresholds live in EFArrays::frameTH_r: they change after every linearizeAll)
     float dp[6];          // adHTdeltaF[h + t*nF]  (EnergyFunctional.cpp:140-141)
     int P0, np;           // point range of the host frame
     int pad[2];
@@ -86,6 +89,10 @@ struct EFArrays {
     float* pstep;
     // images
     const float* images;     // [nF][w*h*3]
+    // frameEnergyTH per frame [nF]: the set k_ef_linearize classifies with / the set k_ef_select_th writes (one per state_New* set,
+    // because FullSystem::setNewFrameEnergyTH moves the newest frame's threshold after EVERY linearizeAll, FullSystemOptimize.cpp:63-97,122)
+    const float* frameTH_r;
+    float* frameTH_w;
     // diagnostics (SDVGN_DEBUG_FLAGS bit5): wall_clock64() stamps of k_ef_linearize's stages, [workgroup][wave][8]; NULL otherwise
     unsigned long long* dbg_stamps;
 };
@@ -284,6 +291,8 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, con
     }
     const int h = pair / C.nF, t = pair % C.nF;
     const PrecalcDev pc = precalc[pair];
+    const float thH = A.frameTH_r[h], thT = A.frameTH_r[t];
+    const float frameTH = thH < thT ? thT : thH;   // std::max<float>(host->frameEnergyTH, target->frameEnergyTH), Residuals.cpp:212
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int role = wave & 1, grp = wave >> 1;
@@ -331,7 +340,8 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, con
                 }
             }
             A.renergy_wo[s] = energyLeft2;
-            if (energyLeft2 > pc.frameEnergyTH || wJI2_sum < 2) { energyLeft2 = pc.frameEnergyTH; A.rstate_new[s] = RS_OUTLIER; }
+            const bool wjlow = wJI2_sum < 2;
+            if (energyLeft2 > frameTH || wjlow) { energyLeft2 = frameTH; A.rstate_new[s] = (int8_t)(RS_OUTLIER | (wjlow ? RS_WJLOW : 0)); }
             else A.rstate_new[s] = RS_IN;
             A.renergy_new[s] = energyLeft2;
             my_e = (double)L.energyLeft;
@@ -523,7 +533,7 @@ __global__ void __launch_bounds__(256) k_ef_apply(int nF, int nP, EFArrays A, co
     if (np_h == 0) return;   // host frame not in this rank's shard
     if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED)) return;
     if (st == RS_OOB) return;
-    if (sn == RS_IN) {
+    if ((sn & RS_MASK) == RS_IN) {
         fl |= RF_ACTIVE;
         fl ^= RF_SEL;                                   // takeDataF: swap J with the residual's freshly linearised J
 #pragma unroll
@@ -532,7 +542,7 @@ __global__ void __launch_bounds__(256) k_ef_apply(int nF, int nP, EFArrays A, co
         fl &= (uint8_t)~RF_ACTIVE;
     }
     A.rflags[s] = fl;
-    A.rstate[s] = (int8_t)sn;
+    A.rstate[s] = (int8_t)(sn & RS_MASK);
     A.renergy[s] = en;
 }
 
@@ -979,6 +989,7 @@ __global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__
         if (e < sc_hi && part == 0) out[e] = s;
     }
     if (done_flag) {   // completion signal for the host (waitflag.hpp): all workgroups of this launch have stored their outputs
+        __threadfence_system();   // every storing thread orders its result stores before the flag (waitflag.hpp)
         __syncthreads();
         if (threadIdx.x == 0) publish_when_all_done(done_ctr, gridDim.x, done_flag, done_seq);
     }
@@ -1000,6 +1011,7 @@ __global__ void __launch_bounds__(256) k_ef_acc_stage2(EFConst C, EFArrays A, co
             const int g = e / 121, k = e - g * 121, r = k / 11, c = k - r * 11;
             out[e] = sum_chunks_f64<256>(top_partial + (size_t)g * top_chunks * 256 + r * 16 + c, top_chunks);
         }
+        __threadfence_system();   // every storing thread orders its result stores before the flag (waitflag.hpp)
         __syncthreads();
         if (threadIdx.x == 0) publish_when_all_done(done_ctr, n_red, done_flag, done_seq);
         return;
@@ -1110,6 +1122,181 @@ __global__ void __launch_bounds__(512) k_ef_resubstitute(EFConst C, EFArrays A, 
     }
     s2 = wave_sum_double(s2); sa = wave_sum_double(sa);
     if (lane == 63) { stats_partial[blockIdx.x] = s2; stats_partial[n_point_blocks + blockIdx.x] = sa; }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// FullSystem::setNewFrameEnergyTH (FullSystemOptimize.cpp:63-97), run by the reference at the end of EVERY linearizeAll (:122):
+//   allResVec = state_NewEnergyWithOutlier of the active (non-linearised) residuals with target == newest frame and value >= 0
+//   nth = allResVec[(int)(0.7f * size)] after nth_element ; TH = ((26*0.5 + 1.5*sqrt(nth)*0.5))^2 ; empty -> 12*12*8
+// The k-th smallest of <= nP non-negative floats is found EXACTLY by a radix descent on the float bit pattern (monotone for
+// non-negative floats): two bits per step, each step one block-wide count of keys below three candidate prefixes.  One workgroup
+// of 1024 lanes, keys in registers (16 per lane up to 16384 points, the rest re-read from memory), no atomics: deterministic.
+// SRC 0: candidates from the state_NewEnergyWithOutlier plane of the newest target (slots (nF-1)*nP + p) and the slot flags.
+// SRC 1: candidates from a double buffer cand[p] = energy + 1 (0 = no candidate), the sum over the ranks of a sharded window.
+// th_out[0..nF-2] = th_prev[0..nF-2]; th_out[nF-1] = new threshold; *log_slot (pinned, may be NULL) = new threshold.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kSelLanes = 1024, kSelVPT = 16;
+template <int SRC>
+__device__ __forceinline__ unsigned sel_key(int p, int nF, int nP, const uint8_t* __restrict__ rflags, const float* __restrict__ wo,
+                                             const double* __restrict__ cand, const int* __restrict__ phost, const PrecalcDev* __restrict__ precalc) {
+    if (p >= nP) return 0xFFFFFFFFu;
+    float v;
+    if (SRC == 0) {
+        const size_t s = (size_t)(nF - 1) * nP + p;
+        const uint8_t fl = rflags[s];
+        v = wo[s];
+        if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED)) return 0xFFFFFFFFu;
+        const int h = phost[p];
+        if (precalc[h * nF + h].np == 0) return 0xFFFFFFFFu;   // host frame not in this rank's shard (planes not written here)
+    } else {
+        const double c = cand[p];
+        if (!(c > 0.5)) return 0xFFFFFFFFu;
+        v = (float)(c - 1.0);
+    }
+    if (!(v >= 0.0f)) return 0xFFFFFFFFu;     // -1 (OOB) and NaN are not candidates (`state_NewEnergyWithOutlier >= 0`)
+    return __float_as_uint(v) & 0x7FFFFFFFu;  // -0.0f counts as 0
+}
+
+template <int SRC>
+__global__ void __launch_bounds__(kSelLanes) k_ef_select_th(int nF, int nP, const uint8_t* __restrict__ rflags, const float* __restrict__ wo,
+                                                            const double* __restrict__ cand, const int* __restrict__ phost,
+                                                            const PrecalcDev* __restrict__ precalc, const float* __restrict__ th_prev,
+                                                            float* __restrict__ th_out, float* __restrict__ log_slot) {
+    __shared__ unsigned long long s_cnt[2][kSelLanes / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned key[kSelVPT];
+#pragma unroll
+    for (int i = 0; i < kSelVPT; ++i) key[i] = sel_key<SRC>(tid + i * kSelLanes, nF, nP, rflags, wo, cand, phost, precalc);
+    const int p_tail = kSelLanes * kSelVPT;
+    // packed block-wide count of keys below c1 / c2 / c3 (21-bit fields; <= 2^20 candidates)
+    auto count3 = [&](unsigned c1, unsigned c2, unsigned c3, int buf) -> unsigned long long {
+        unsigned long long a = 0;
+#pragma unroll
+        for (int i = 0; i < kSelVPT; ++i) {
+            const unsigned k = key[i];
+            a += (unsigned long long)(k < c1) | ((unsigned long long)(k < c2) << 21) | ((unsigned long long)(k < c3) << 42);
+        }
+        for (int p = p_tail + tid; p < nP; p += kSelLanes) {
+            const unsigned k = sel_key<SRC>(p, nF, nP, rflags, wo, cand, phost, precalc);
+            a += (unsigned long long)(k < c1) | ((unsigned long long)(k < c2) << 21) | ((unsigned long long)(k < c3) << 42);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+        if (lane == 0) s_cnt[buf][wave] = a;
+        __syncthreads();
+        unsigned long long t = 0;
+#pragma unroll
+        for (int w = 0; w < kSelLanes / 64; ++w) t += s_cnt[buf][w];
+        return t;
+    };
+    // number of candidates = keys below 0x80000000
+    const unsigned long long c0 = count3(0x80000000u, 0u, 0u, 0);
+    const int N = (int)(c0 & 0x1FFFFFu);
+    float th;
+    if (N == 0) {
+        th = 12 * 12 * 8;
+    } else {
+        const int kth = (int)(0.7f * (float)N);   // setting_frameEnergyTHN * allResVec.size(): float product, truncated
+        unsigned ans = 0;
+        int buf = 1;
+        // bits 30..1 two at a time, then bit 0: the largest prefix with count(key < prefix) <= kth is the kth smallest key
+        for (int b = 29; b >= -1; b -= 2) {
+            const unsigned lo = (b >= 0) ? (1u << b) : 0u, hi = 1u << (b + 1);
+            const unsigned c1 = ans | lo, c2 = ans | hi, c3 = ans | hi | lo;
+            const unsigned long long c = count3(c1, c2, c3, buf);
+            buf ^= 1;
+            const int n1 = (int)(c & 0x1FFFFFu), n2 = (int)((c >> 21) & 0x1FFFFFu), n3 = (int)((c >> 42) & 0x1FFFFFu);
+            if (n3 <= kth) ans = c3;
+            else if (n2 <= kth) ans = c2;
+            else if (b >= 0 && n1 <= kth) ans = c1;
+        }
+        const float nthElement = sqrtf(__uint_as_float(ans));
+        th = nthElement * 1.5f;                       // setting_frameEnergyTHFacMedian
+        th = 26.0f * 0.5f + th * (1 - 0.5f);          // setting_frameEnergyTHConstWeight
+        th = th * th;
+        th *= 1.0f * 1.0f;                            // setting_overallEnergyTHWeight^2
+    }
+    if (tid < nF - 1) th_out[tid] = th_prev[tid];
+    if (tid == 0) {
+        th_out[nF - 1] = th;
+        if (log_slot) *log_slot = th;
+    }
+}
+
+// sharded windows: this rank's candidates of the quantile above as doubles (energy + 1, 0 = none), summed over the ranks by the
+// same all-reduce that carries the four linearize statistics
+__global__ void __launch_bounds__(256) k_ef_pack_th_candidates(int nF, int nP, const uint8_t* __restrict__ rflags, const float* __restrict__ wo,
+                                                               const int* __restrict__ phost, const PrecalcDev* __restrict__ precalc,
+                                                               double* __restrict__ cand) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= nP) return;
+    const unsigned k = sel_key<0>(p, nF, nP, rflags, wo, nullptr, phost, precalc);
+    cand[p] = (k == 0xFFFFFFFFu) ? 0.0 : (double)__uint_as_float(k) + 1.0;
+}
+
+// After a REJECTED step the reference re-linearises the restored state (FullSystemOptimize.cpp:446-449).  Everything that
+// re-linearisation computes is what the kept state_New* set already holds, EXCEPT the IN / OUTLIER classification and the clamped
+// state_NewEnergy: those are taken under the threshold the trial's linearizeAll just set (th), not the one the kept set was built
+// with.  This kernel repeats exactly that decision (Residuals.cpp:210-222) for the residuals that involve the newest frame (the
+// only threshold that moves): lanes [0, nP) = target == newest, then np_last x (nF-1) lanes = host == newest.
+__global__ void __launch_bounds__(256) k_ef_reclassify(int nF, int nP, int P0_last, int np_last, const uint8_t* __restrict__ rflags,
+                                                       const float* __restrict__ wo, int8_t* __restrict__ rstate_new, float* __restrict__ renergy_new,
+                                                       const int* __restrict__ phost, const PrecalcDev* __restrict__ precalc, const float* __restrict__ th) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int p, t;
+    if (i < nP) { p = i; t = nF - 1; }
+    else { const int j = i - nP; if (j >= np_last * (nF - 1)) return; t = j / np_last; p = P0_last + j % np_last; }
+    const int h = phost[p];
+    if (h == t || precalc[h * nF + h].np == 0) return;
+    const size_t s = (size_t)t * nP + p;
+    const uint8_t fl = rflags[s];
+    const int sn = rstate_new[s];
+    const float e = wo[s];
+    if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED) || (sn & RS_MASK) == RS_OOB) return;
+    const float a = th[h], b = th[t];
+    const float frameTH = a < b ? b : a;
+    const bool wjlow = (sn & RS_WJLOW) != 0;
+    if (e > frameTH || wjlow) { renergy_new[s] = frameTH; rstate_new[s] = (int8_t)(RS_OUTLIER | (wjlow ? RS_WJLOW : 0)); }
+    else { renergy_new[s] = e; rstate_new[s] = RS_IN; }
+}
+
+// linearizeAll(true)'s per-residual epilogue (FullSystemOptimize.cpp:32-52, 136-155) after linearize + applyRes: one lane per point.
+// For every residual of the point that was in activeResiduals (exists, not linearised): still active -> relBS (the relative baseline,
+// 0.01 * pixel distance between the projections at infinite and at real depth) feeds the point's maxRelBaseline, numGoodResiduals++;
+// not active -> toRemove: the slot ceases to exist.
+__global__ void __launch_bounds__(256) k_ef_finish_points(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc, const int* __restrict__ phost,
+                                                          float* __restrict__ relbs_max, int* __restrict__ ngood_inc, uint8_t* __restrict__ removed) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= C.nP) return;
+    const int h = phost[p];
+    const bool mine = precalc[h * C.nF + h].np != 0;
+    const float pu = A.pu[p], pv = A.pv[p], ids = A.pid[p];
+    float mx = 0.0f;
+    int ng = 0;
+    for (int t = 0; t < C.nF; ++t) {
+        const size_t s = (size_t)t * C.nP + p;
+        uint8_t rm = 0;
+        const uint8_t fl = A.rflags[s];
+        if (mine && (fl & RF_EXISTS) && !(fl & RF_LINEARIZED)) {
+            if (fl & RF_ACTIVE) {
+                const PrecalcDev& pc = precalc[h * C.nF + t];
+                const float i0 = (pc.KRKi[0] * pu + pc.KRKi[1] * pv) + pc.KRKi[2] * 1.0f;
+                const float i1 = (pc.KRKi[3] * pu + pc.KRKi[4] * pv) + pc.KRKi[5] * 1.0f;
+                const float i2 = (pc.KRKi[6] * pu + pc.KRKi[7] * pv) + pc.KRKi[8] * 1.0f;
+                const float q0 = i0 + pc.Kt[0] * ids, q1 = i1 + pc.Kt[1] * ids, q2 = i2 + pc.Kt[2] * ids;
+                const float dx = i0 / i2 - q0 / q2, dy = i1 / i2 - q1 / q2;
+                const float relBS = (float)(0.01 * (double)sqrtf(dx * dx + dy * dy));
+                if (relBS > mx) mx = relBS;
+                ng++;
+            } else {
+                rm = 1;
+                A.rflags[s] = 0;
+            }
+        }
+        removed[s] = rm;
+    }
+    relbs_max[p] = mx;
+    ngood_inc[p] = ng;
 }
 
 }  // namespace sdvgn

@@ -6,12 +6,13 @@
 // Multi-workgroup kernels use a device counter: every workgroup fences and increments it, the one that sees it complete publishes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <chrono>
 
 namespace sdvgn {
 
-// call by ONE thread of a workgroup after the workgroup's results are written (and a __syncthreads()); nblocks = workgroups that
-// will call this for the same (counter, seq).  The counter must be 0 before the launch; the publisher resets it.
+// call by ONE thread of a workgroup after the workgroup's results are written, fenced by EVERY storing thread
+// (__threadfence_system()) and a __syncthreads(); nblocks = workgroups that will call this for the same (counter, seq).  The counter must be 0 before the launch; the publisher resets it.
 __device__ __forceinline__ void publish_when_all_done(unsigned* counter, unsigned nblocks, volatile int* flag, int seq) {
     __threadfence_system();
     const unsigned prev = atomicAdd(counter, 1u);
@@ -33,6 +34,7 @@ static inline hipError_t wait_flag(volatile int* flag, int seq, hipStream_t stre
             return *flag == seq ? hipSuccess : hipErrorUnknown;
         }
     }
+    std::atomic_thread_fence(std::memory_order_acquire);   // the result reads that follow must not be satisfied before the flag read
     return hipSuccess;
 }
 

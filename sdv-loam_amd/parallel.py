@@ -85,10 +85,11 @@ class ShardedEnergyFunctional:
         self.ef = EnergyFunctional(W.w, W.h, max_points=W.nP, device=device, stream=self.stream.cuda_stream)
         with torch.cuda.stream(self.stream):
             self.acc = torch.zeros(acc_capacity(), dtype=torch.float64, device="cuda")
-            self.stats = torch.zeros(4, dtype=torch.float64, device="cuda")
+            self.stats = torch.zeros(4 + W.nP, dtype=torch.float64, device="cuda")   # 4 statistics + the quantile candidates
         self.stream.synchronize()
         L = self.ef.L
-        self.ef._check(L.sdvgn_ef_set_external_buffers(self.ef.h_, self.acc.data_ptr(), self.acc.numel(), self.stats.data_ptr()))
+        self.ef._check(L.sdvgn_ef_set_external_buffers(self.ef.h_, self.acc.data_ptr(), self.acc.numel(), self.stats.data_ptr(), self.stats.numel()))
+        self.max_points = W.nP
         self.lo, self.hi = shard_hosts(W.nF, world)[rank]
         self.ef.set_host_range(self.lo, self.hi)
         self.ef.load(W)
@@ -134,6 +135,11 @@ class ShardedEnergyFunctional:
             self.ef._check(L.sdvgn_ef_set_allreduce(self.ef.h_, C.cast(self._cb, C.c_void_p), None))
 
     def reload(self, W):
+        if W.nP > self.max_points:
+            raise ValueError("window has %d points, the handle was created for %d" % (W.nP, self.max_points))
+        # the shard follows the window: a different nF re-partitions the host frames
+        self.lo, self.hi = shard_hosts(W.nF, self.world)[self.rank]
+        self.ef.set_host_range(self.lo, self.hi)
         self.ef.load(W)
 
     def optimize(self, its, fixed_its=False, want_trace=False):

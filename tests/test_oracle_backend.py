@@ -177,3 +177,77 @@ def test_threaded_mode_matches_single_thread(orc):
     assert np.abs(a[:, 7:] - b[:, 7:]).max() <= 1e-4 * np.abs(a[:, 7:]).max()                 # increments (north_star tolerance)
     Ha, Hb = out[1][1], out[3][1]
     assert np.linalg.norm(Ha - Hb) <= 1e-5 * np.linalg.norm(Ha)
+
+
+def _th_mirror(energy_wo, target, lin, nF):
+    """numpy mirror of FullSystem::setNewFrameEnergyTH (FullSystemOptimize.cpp:63-97), float32 like the reference."""
+    v = energy_wo[(target == nF - 1) & (lin == 0) & (energy_wo >= 0)].astype(np.float32)
+    if v.size == 0:
+        return np.float32(12 * 12 * 8)
+    k = int(np.float32(0.7) * np.float32(v.size))
+    nth = np.sqrt(np.partition(v, k)[k], dtype=np.float32)
+    th = nth * np.float32(1.5)
+    th = np.float32(26.0) * np.float32(0.5) + th * np.float32(0.5)
+    return np.float32(th * th)
+
+
+def test_set_new_frame_energy_th(orc, small_window):
+    """linearizeAll ends with setNewFrameEnergyTH: the newest frame's threshold is the numpy-partition quantile formula, the other
+    frames keep theirs, and the NEXT linearise classifies IN / OUTLIER with max(host TH, target TH) (Residuals.cpp:212-214)."""
+    import copy
+    from oracle.backend import OracleEF
+    W = copy.copy(small_window)
+    W.frameEnergyTH = np.array([150, 170, 190, 512], np.float32)   # older frames below the newest's: its threshold decides (max of the two)
+    E = OracleEF(W.w, W.h).load(W)
+    th0 = E.frame_energy_th()
+    assert np.array_equal(th0, W.frameEnergyTH)
+    E.linearizeAll()
+    st = E.residual_state()
+    th1 = E.frame_energy_th()
+    want = _th_mirror(st["energy_with_outlier"], W.r_target, W.r_isLinearized, W.nF)
+    assert th1[-1] == want and np.array_equal(th1[:-1], th0[:-1]) and th1[-1] != 512.0
+    # same state again: same energies -> same quantile, but the classification now uses the new threshold
+    E.linearizeAll()
+    st2 = E.residual_state()
+    assert E.frame_energy_th()[-1] == want
+    assert np.array_equal(st2["energy_with_outlier"], st["energy_with_outlier"])
+    h = W.host[W.r_point]
+    thr = np.maximum(th1[h], th1[W.r_target]).astype(np.float64)
+    live = st2["new_state"] != 1
+    over = st2["energy_with_outlier"] > thr
+    assert np.all(st2["new_state"][live & over] == 2) and np.all(st2["new_energy"][live & over] == thr[live & over])
+    assert np.all(st2["new_energy"][live & (st2["new_state"] == 0)] == st2["energy_with_outlier"][live & (st2["new_state"] == 0)])
+    moved = (st2["new_state"] != st["new_state"]).sum()
+    assert moved > 0      # the window is built so that the threshold matters
+    # no candidate at all -> 12*12*patternNum
+    W2 = copy.copy(W)
+    W2.r_hasMatcher = W.r_hasMatcher.copy(); W2.r_hasMatcher[W.r_target == W.nF - 1] = 0     # -> OOB, energy -1
+    E2 = OracleEF(W2.w, W2.h).load(W2)
+    E2.linearizeAll()
+    assert E2.frame_energy_th()[-1] == 12 * 12 * 8
+
+
+def test_optimize_trace_carries_threshold_and_finish(orc, small_window):
+    import copy
+    from oracle.backend import OracleEF
+    W = copy.copy(small_window)
+    W.frameEnergyTH = np.array([150, 170, 190, 300], np.float32)
+    E = OracleEF(W.w, W.h).load(W)
+    tr = E.optimize(6)
+    n = E.dim
+    assert tr.shape[1] == 8 + n and np.all(tr[:, 7 + n] > 0) and len(set(tr[:, 7 + n])) > 1
+    st_before = E.state()[1]
+    e, rb, ng, rm = E.optimize_finish()
+    assert np.isfinite(e) and e > 0
+    p7, z = E.evalPT(W.nF - 1)
+    # setEvalPT: the state is zero except the affine part, which is kept; state_zero == state
+    st = E.state()[1]
+    assert np.all(st[-1, :6] == 0) and np.array_equal(st[-1, 6:8], st_before[-1, 6:8]) and np.array_equal(z, st[-1])
+    rs = E.residual_state()
+    # toRemove == not active after applyRes(true); surviving residuals are counted per point
+    assert np.array_equal(rm.astype(bool), rs["active"] == 0)
+    cnt = np.bincount(W.r_point[rs["active"] == 1], minlength=W.nP)
+    assert np.array_equal(cnt, ng)
+    assert np.all(rb[ng > 0] > 0) and np.all(rb[ng == 0] == 0)
+    want = _th_mirror(rs["energy_with_outlier"], W.r_target, W.r_isLinearized, W.nF)
+    assert E.frame_energy_th()[-1] == want
