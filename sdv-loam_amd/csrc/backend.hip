@@ -616,15 +616,17 @@ __global__ void __launch_bounds__(256) k_ef_point_stats(EFConst C, EFArrays A, c
     if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 // out[0] = sum energy partials, out[1] = sum L partials (nL may be 0), out[2], out[3] = sums of the two halves of the
-// resubstitute partials (step^2, |idepth_backup|): one launch instead of four tiny ones
-__global__ void k_ef_sum_stats(const double* __restrict__ pe, int nE, const double* __restrict__ pl, int nL,
-                               const double* __restrict__ ps, int nS, double* __restrict__ out, volatile int* done_flag, int done_seq) {
-    __shared__ double s[4][256];
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    for (int i = threadIdx.x; i < nE; i += 256) a0 += pe[i];
-    for (int i = threadIdx.x; i < nL; i += 256) a1 += pl[i];
-    for (int i = threadIdx.x; i < nS; i += 256) { a2 += ps[i]; a3 += ps[nS + i]; }
-    s[0][threadIdx.x] = a0; s[1][threadIdx.x] = a1; s[2][threadIdx.x] = a2; s[3][threadIdx.x] = a3;
+// resubstitute partials (step^2, |idepth_backup|): one workgroup instead of four tiny launches
+__device__ __forceinline__ void sum_stats_body(const double* __restrict__ pe, int nE, const double* __restrict__ pl, int nL,
+                                               const double* __restrict__ ps, int nS, double* __restrict__ out, volatile int* done_flag, int done_seq,
+                                               double (*s)[256]) {
+    if (threadIdx.x < 256) {
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int i = threadIdx.x; i < nE; i += 256) a0 += pe[i];
+        for (int i = threadIdx.x; i < nL; i += 256) a1 += pl[i];
+        for (int i = threadIdx.x; i < nS; i += 256) { a2 += ps[i]; a3 += ps[nS + i]; }
+        s[0][threadIdx.x] = a0; s[1][threadIdx.x] = a1; s[2][threadIdx.x] = a2; s[3][threadIdx.x] = a3;
+    }
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (threadIdx.x < o) for (int q = 0; q < 4; ++q) s[q][threadIdx.x] += s[q][threadIdx.x + o];
@@ -632,10 +634,24 @@ __global__ void k_ef_sum_stats(const double* __restrict__ pe, int nE, const doub
     }
     if (threadIdx.x < 4) out[threadIdx.x] = s[threadIdx.x][0];
     if (done_flag) {   // single workgroup: publish after the four stores (waitflag.hpp)
-        __threadfence_system();   // every storing thread orders its result stores before the flag (waitflag.hpp)
         __syncthreads();
         if (threadIdx.x == 0) { __threadfence_system(); *done_flag = done_seq; }
     }
+}
+__global__ void __launch_bounds__(256) k_ef_sum_stats(const double* __restrict__ pe, int nE, const double* __restrict__ pl, int nL,
+                                                      const double* __restrict__ ps, int nS, double* __restrict__ out, volatile int* done_flag, int done_seq) {
+    __shared__ double s[4][256];
+    sum_stats_body(pe, nE, pl, nL, ps, nS, out, done_flag, done_seq, s);
+}
+// single-rank tail of a linearizeAll in ONE launch: workgroup 0 = the four statistics (+ flag for the host), workgroup 1 =
+// FullSystem::setNewFrameEnergyTH (k_ef_select_th's body) -- they are independent and run side by side on two CUs
+struct SelArgs { int nF, nP, own0, own1; const uint8_t* rflags; const float* wo; const float* th_prev; float* th_out; float* log_slot; };
+__global__ void __launch_bounds__(kSelLanes) k_ef_stats_select(const double* __restrict__ pe, int nE, const double* __restrict__ pl, int nL,
+                                                                const double* __restrict__ ps, int nS, double* __restrict__ out, volatile int* done_flag,
+                                                                int done_seq, SelArgs a) {
+    __shared__ union U { double s[4][256]; SelectSmem sel; __device__ U() {} } S;
+    if (blockIdx.x == 0) sum_stats_body(pe, nE, pl, nL, ps, nS, out, done_flag, done_seq, S.s);
+    else select_th_body<0>(a.nF, a.nP, a.own0, a.own1, a.rflags, a.wo, nullptr, a.th_prev, a.th_out, a.log_slot, S.sel);
 }
 
 // device buffer -> pinned host buffer + completion flag (waitflag.hpp): the read-back after an all-reduce without the copy engine
@@ -643,7 +659,6 @@ __global__ void __launch_bounds__(256) k_ef_copy_publish(const double* __restric
                                                          volatile int* flag, int seq) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = src[i];
-    __threadfence_system();   // every storing thread orders its result stores before the flag (waitflag.hpp)
     __syncthreads();
     if (threadIdx.x == 0) publish_when_all_done(ctr, gridDim.x, flag, seq);
 }
@@ -706,13 +721,24 @@ static int ef_allreduce(sdvgn_ef* e, double* buf_dev, int count) {
 // FullSystem::setNewFrameEnergyTH for the linearisation just launched (its state_NewEnergyWithOutlier plane is A.renergy_wo):
 // the new threshold set goes to A.frameTH_w.  Single rank: one launch, nothing to wait for (the next linearise follows on the stream).
 // Sharded: the candidates of all ranks arrive through stats_dev[4 ..] (see linearize_and_stats).
+static void ef_owned_points(const sdvgn_ef* e, int& own0, int& own1) {   // point range hosted by this rank's key-frames
+    const int h0 = e->shard_set ? std::min(e->h0, e->nF) : 0, h1 = e->shard_set ? std::min(e->h1, e->nF) : e->nF;
+    own0 = e->hostP0.empty() ? 0 : e->hostP0[h0];
+    own1 = e->hostP0.empty() ? 0 : e->hostP0[std::max(h0, h1)];
+}
 static void ef_launch_select_th(sdvgn_ef* e, bool from_reduced) {
     float* log_slot = e->th_log ? e->th_log + (e->th_log_n++ % kThLog) : nullptr;
+    int own0, own1;
+    ef_owned_points(e, own0, own1);
     if (from_reduced)
-        k_ef_select_th<1><<<1, kSelLanes, 0, e->stream>>>(e->nF, e->nP, nullptr, nullptr, e->stats_dev + 4, nullptr, nullptr, e->A.frameTH_r, e->A.frameTH_w, log_slot);
+        k_ef_select_th<1><<<1, kSelLanes, 0, e->stream>>>(e->nF, e->nP, 0, e->nP, nullptr, nullptr, e->stats_dev + 4, e->A.frameTH_r, e->A.frameTH_w, log_slot);
     else
-        k_ef_select_th<0><<<1, kSelLanes, 0, e->stream>>>(e->nF, e->nP, e->rflags, e->A.renergy_wo, nullptr, e->phost_dev, e->precalc_dev, e->A.frameTH_r,
-                                                          e->A.frameTH_w, log_slot);
+        k_ef_select_th<0><<<1, kSelLanes, 0, e->stream>>>(e->nF, e->nP, own0, own1, e->rflags, e->A.renergy_wo, nullptr, e->A.frameTH_r, e->A.frameTH_w, log_slot);
+}
+static void ef_launch_pack_th(sdvgn_ef* e) {
+    int own0, own1;
+    ef_owned_points(e, own0, own1);
+    k_ef_pack_th_candidates<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->nF, e->nP, own0, own1, e->rflags, e->A.renergy_wo, e->stats_dev + 4);
 }
 
 extern "C" {
@@ -1078,7 +1104,7 @@ int sdvgn_ef_linearize_all(sdvgn_ef* e, double* energy_out) {
     double* edst = e->stats_dev;
     if (energy_out) k_ef_sum_energy<<<1, 256, 0, e->stream>>>(e->energy_partial, n_partials, edst);   // NULL: leave the per-workgroup partials
     if (ef_sharded(e)) {   // setNewFrameEnergyTH needs the candidates of every rank: one all-reduce of [4 unused | nP candidates]
-        k_ef_pack_th_candidates<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->nF, e->nP, e->rflags, e->A.renergy_wo, e->phost_dev, e->precalc_dev, e->stats_dev + 4);
+        ef_launch_pack_th(e);
         { const int rca = ef_allreduce(e, e->stats_dev, 4 + e->nP); if (rca) return rca; }
         ef_launch_select_th(e, true);
     } else ef_launch_select_th(e, false);
@@ -1438,20 +1464,25 @@ static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* 
     const int nS = (e->nP + 63) / 64;
     // without an all-reduce the four sums go straight into pinned host memory (no copy engine, see ef_accumulate)
     const bool flagged = !ef_sharded(e);
-    k_ef_sum_stats<<<1, 256, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, e->stats_partial + (e->nP / 64 + 2), nS,
-                                             flagged ? e->stats_host : e->stats_dev, flagged ? e->flags_host + 2 : nullptr, flagged ? ++e->seq_stats : 0);
-    HIPCHK(hipGetLastError());
+    const double* ps = e->stats_partial + (e->nP / 64 + 2);
     if (!flagged) {
+        k_ef_sum_stats<<<1, 256, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_dev, nullptr, 0);
         // ranks hold disjoint host-frame shards: ONE all-reduce carries the four sums and the candidates of setNewFrameEnergyTH's quantile
-        k_ef_pack_th_candidates<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->nF, e->nP, e->rflags, e->A.renergy_wo, e->phost_dev, e->precalc_dev, e->stats_dev + 4);
+        ef_launch_pack_th(e);
         { const int rca = ef_allreduce(e, e->stats_dev, 4 + e->nP); if (rca) return rca; }
         k_ef_copy_publish<<<1, 256, 0, e->stream>>>(e->stats_dev, e->stats_host, 4, e->done_ctr, e->flags_host + 2, ++e->seq_stats);
         ef_launch_select_th(e, true);
         HIPCHK(hipGetLastError());
         HIPCHK(wait_flag(e->flags_host + 2, e->seq_stats, e->stream));
     } else {
-        // setNewFrameEnergyTH: queued behind the statistics; only the NEXT linearise needs it, the host does not wait for it
-        ef_launch_select_th(e, false);
+        // statistics (host waits for their flag) and setNewFrameEnergyTH (only the NEXT linearise needs it) side by side in one launch
+        SelArgs a;
+        a.nF = e->nF; a.nP = e->nP;
+        ef_owned_points(e, a.own0, a.own1);
+        a.rflags = e->rflags; a.wo = e->A.renergy_wo; a.th_prev = e->A.frameTH_r; a.th_out = e->A.frameTH_w;
+        a.log_slot = e->th_log ? e->th_log + (e->th_log_n++ % kThLog) : nullptr;
+        k_ef_stats_select<<<2, kSelLanes, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host, e->flags_host + 2,
+                                                          ++e->seq_stats, a);
         HIPCHK(hipGetLastError());
         HIPCHK(wait_flag(e->flags_host + 2, e->seq_stats, e->stream));
     }

@@ -989,7 +989,6 @@ __global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__
         if (e < sc_hi && part == 0) out[e] = s;
     }
     if (done_flag) {   // completion signal for the host (waitflag.hpp): all workgroups of this launch have stored their outputs
-        __threadfence_system();   // every storing thread orders its result stores before the flag (waitflag.hpp)
         __syncthreads();
         if (threadIdx.x == 0) publish_when_all_done(done_ctr, gridDim.x, done_flag, done_seq);
     }
@@ -1011,7 +1010,6 @@ __global__ void __launch_bounds__(256) k_ef_acc_stage2(EFConst C, EFArrays A, co
             const int g = e / 121, k = e - g * 121, r = k / 11, c = k - r * 11;
             out[e] = sum_chunks_f64<256>(top_partial + (size_t)g * top_chunks * 256 + r * 16 + c, top_chunks);
         }
-        __threadfence_system();   // every storing thread orders its result stores before the flag (waitflag.hpp)
         __syncthreads();
         if (threadIdx.x == 0) publish_when_all_done(done_ctr, n_red, done_flag, done_seq);
         return;
@@ -1136,18 +1134,32 @@ __global__ void __launch_bounds__(512) k_ef_resubstitute(EFConst C, EFArrays A, 
 // th_out[0..nF-2] = th_prev[0..nF-2]; th_out[nF-1] = new threshold; *log_slot (pinned, may be NULL) = new threshold.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kSelLanes = 1024, kSelVPT = 16;
+// 64-lane integer sum with DPP moves (no LDS crossbar); result valid in lane 63
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dpp_move_u32(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false); }
+__device__ __forceinline__ unsigned wave_sum_dpp_u32(unsigned v) {
+    v += dpp_move_u32<0x111, 0xF>(v);   // row_shr:1
+    v += dpp_move_u32<0x112, 0xF>(v);   // row_shr:2
+    v += dpp_move_u32<0x114, 0xF>(v);   // row_shr:4
+    v += dpp_move_u32<0x118, 0xF>(v);   // row_shr:8  -> lane 15 of every row holds the row sum
+    v += dpp_move_u32<0x142, 0xA>(v);   // row_bcast:15 into rows 1,3
+    v += dpp_move_u32<0x143, 0xC>(v);   // row_bcast:31 into rows 2,3 -> lane 63 holds the wave sum
+    return v;
+}
+// inclusive 64-lane prefix sum with DPP moves
+__device__ __forceinline__ unsigned wave_scan_dpp_u32(unsigned v) { return wave_sum_dpp_u32(v); }   // the sum IS built as an inclusive scan
+struct SelectSmem { unsigned hist[2 * kSelLanes]; unsigned wsum[kSelLanes / 64]; unsigned sel[2]; };
+// own0/own1: the point range [own0, own1) hosted by this rank's key-frames (the planes of other points are not written here)
 template <int SRC>
-__device__ __forceinline__ unsigned sel_key(int p, int nF, int nP, const uint8_t* __restrict__ rflags, const float* __restrict__ wo,
-                                             const double* __restrict__ cand, const int* __restrict__ phost, const PrecalcDev* __restrict__ precalc) {
+__device__ __forceinline__ unsigned sel_key(int p, int nF, int nP, int own0, int own1, const uint8_t* __restrict__ rflags,
+                                             const float* __restrict__ wo, const double* __restrict__ cand) {
     if (p >= nP) return 0xFFFFFFFFu;
     float v;
     if (SRC == 0) {
         const size_t s = (size_t)(nF - 1) * nP + p;
         const uint8_t fl = rflags[s];
         v = wo[s];
-        if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED)) return 0xFFFFFFFFu;
-        const int h = phost[p];
-        if (precalc[h * nF + h].np == 0) return 0xFFFFFFFFu;   // host frame not in this rank's shard (planes not written here)
+        if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED) || p < own0 || p >= own1) return 0xFFFFFFFFu;
     } else {
         const double c = cand[p];
         if (!(c > 0.5)) return 0xFFFFFFFFu;
@@ -1157,60 +1169,82 @@ __device__ __forceinline__ unsigned sel_key(int p, int nF, int nP, const uint8_t
     return __float_as_uint(v) & 0x7FFFFFFFu;  // -0.0f counts as 0
 }
 
+// body for one workgroup of kSelLanes lanes
 template <int SRC>
-__global__ void __launch_bounds__(kSelLanes) k_ef_select_th(int nF, int nP, const uint8_t* __restrict__ rflags, const float* __restrict__ wo,
-                                                            const double* __restrict__ cand, const int* __restrict__ phost,
-                                                            const PrecalcDev* __restrict__ precalc, const float* __restrict__ th_prev,
-                                                            float* __restrict__ th_out, float* __restrict__ log_slot) {
-    __shared__ unsigned long long s_cnt[2][kSelLanes / 64];
+__device__ __forceinline__ void select_th_body(int nF, int nP, int own0, int own1, const uint8_t* __restrict__ rflags, const float* __restrict__ wo,
+                                               const double* __restrict__ cand, const float* __restrict__ th_prev, float* __restrict__ th_out,
+                                               float* __restrict__ log_slot, SelectSmem& S) {
+    unsigned* s_hist = S.hist; unsigned* s_wsum = S.wsum; unsigned* s_sel = S.sel;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned key[kSelVPT];
-#pragma unroll
-    for (int i = 0; i < kSelVPT; ++i) key[i] = sel_key<SRC>(tid + i * kSelLanes, nF, nP, rflags, wo, cand, phost, precalc);
-    const int p_tail = kSelLanes * kSelVPT;
-    // packed block-wide count of keys below c1 / c2 / c3 (21-bit fields; <= 2^20 candidates)
-    auto count3 = [&](unsigned c1, unsigned c2, unsigned c3, int buf) -> unsigned long long {
-        unsigned long long a = 0;
+    {   // all loads of this lane in ONE batch (clamped addresses), the candidate tests afterwards: one memory round trip, not 16
+        uint8_t fl[kSelVPT];
+        float v[kSelVPT];
+        double c[kSelVPT];
 #pragma unroll
         for (int i = 0; i < kSelVPT; ++i) {
-            const unsigned k = key[i];
-            a += (unsigned long long)(k < c1) | ((unsigned long long)(k < c2) << 21) | ((unsigned long long)(k < c3) << 42);
+            const int p = min(tid + i * kSelLanes, nP - 1);
+            if (SRC == 0) { const size_t s = (size_t)(nF - 1) * nP + p; fl[i] = rflags[s]; v[i] = wo[s]; }
+            else c[i] = cand[p];
         }
-        for (int p = p_tail + tid; p < nP; p += kSelLanes) {
-            const unsigned k = sel_key<SRC>(p, nF, nP, rflags, wo, cand, phost, precalc);
-            a += (unsigned long long)(k < c1) | ((unsigned long long)(k < c2) << 21) | ((unsigned long long)(k < c3) << 42);
-        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-        if (lane == 0) s_cnt[buf][wave] = a;
+        for (int i = 0; i < kSelVPT; ++i) {
+            const int p = tid + i * kSelLanes;
+            bool ok = p < nP;
+            float e;
+            if (SRC == 0) { ok = ok && (fl[i] & RF_EXISTS) && !(fl[i] & RF_LINEARIZED) && p >= own0 && p < own1; e = v[i]; }
+            else { ok = ok && c[i] > 0.5; e = (float)(c[i] - 1.0); }
+            ok = ok && e >= 0.0f;
+            key[i] = ok ? (__float_as_uint(e) & 0x7FFFFFFFu) : 0xFFFFFFFFu;
+        }
+    }
+    const int p_tail = kSelLanes * kSelVPT;
+    // MSB-first radix select with LDS histograms, 11 + 11 + 9 bits: per pass every key that still matches the prefix adds 1 to its
+    // digit's bin (integer LDS atomics: order-free, deterministic), a block scan finds the bin holding rank k.  (A compare-and-count
+    // descent, 2 bits per step, costs 16384 keys x 3 compares x 17 steps on ONE CU's vector units: measured 26 us; this: ~5 us.)
+    unsigned prefix = 0, pmask = 0x80000000u;   // valid keys have bit 31 clear; 0xFFFFFFFF never matches
+    int N = 0, kth = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = pass == 0 ? 20 : (pass == 1 ? 9 : 0);
+        const int nb = pass == 2 ? 512 : 2048;
+        s_hist[tid] = 0; s_hist[tid + kSelLanes] = 0;
         __syncthreads();
-        unsigned long long t = 0;
 #pragma unroll
-        for (int w = 0; w < kSelLanes / 64; ++w) t += s_cnt[buf][w];
-        return t;
-    };
-    // number of candidates = keys below 0x80000000
-    const unsigned long long c0 = count3(0x80000000u, 0u, 0u, 0);
-    const int N = (int)(c0 & 0x1FFFFFu);
+        for (int i = 0; i < kSelVPT; ++i)
+            if ((key[i] & pmask) == prefix) atomicAdd(&s_hist[(key[i] >> shift) & (nb - 1)], 1u);
+        for (int p0 = p_tail; p0 < nP; p0 += kSelLanes) {   // windows beyond 16384 points: re-read (uniform trip count)
+            const unsigned k = sel_key<SRC>(p0 + tid, nF, nP, own0, own1, rflags, wo, cand);
+            if ((k & pmask) == prefix) atomicAdd(&s_hist[(k >> shift) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        // lane t owns bins 2t, 2t+1: exclusive block scan of the pair sums
+        const unsigned c0 = s_hist[2 * tid], c1 = s_hist[2 * tid + 1];
+        const unsigned incl = wave_scan_dpp_u32(c0 + c1);
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        unsigned before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kSelLanes / 64; ++w) { const unsigned t = s_wsum[w]; if (w < wave) before += t; total += t; }
+        if (pass == 0) { N = (int)total; kth = (int)(0.7f * (float)N); }   // setting_frameEnergyTHN * allResVec.size(): float product, truncated
+        if (N == 0) break;
+        const unsigned excl = before + incl - (c0 + c1);
+        if ((unsigned)kth >= excl && (unsigned)kth < excl + c0 + c1) {     // exactly one lane
+            const bool second = (unsigned)kth >= excl + c0;
+            s_sel[0] = 2 * tid + (second ? 1 : 0);
+            s_sel[1] = excl + (second ? c0 : 0);
+        }
+        __syncthreads();
+        prefix |= s_sel[0] << shift;
+        kth -= (int)s_sel[1];
+        pmask |= (unsigned)(nb - 1) << shift;
+    }
     float th;
     if (N == 0) {
         th = 12 * 12 * 8;
     } else {
-        const int kth = (int)(0.7f * (float)N);   // setting_frameEnergyTHN * allResVec.size(): float product, truncated
-        unsigned ans = 0;
-        int buf = 1;
-        // bits 30..1 two at a time, then bit 0: the largest prefix with count(key < prefix) <= kth is the kth smallest key
-        for (int b = 29; b >= -1; b -= 2) {
-            const unsigned lo = (b >= 0) ? (1u << b) : 0u, hi = 1u << (b + 1);
-            const unsigned c1 = ans | lo, c2 = ans | hi, c3 = ans | hi | lo;
-            const unsigned long long c = count3(c1, c2, c3, buf);
-            buf ^= 1;
-            const int n1 = (int)(c & 0x1FFFFFu), n2 = (int)((c >> 21) & 0x1FFFFFu), n3 = (int)((c >> 42) & 0x1FFFFFu);
-            if (n3 <= kth) ans = c3;
-            else if (n2 <= kth) ans = c2;
-            else if (b >= 0 && n1 <= kth) ans = c1;
-        }
-        const float nthElement = sqrtf(__uint_as_float(ans));
+        const float nthElement = sqrtf(__uint_as_float(prefix));
         th = nthElement * 1.5f;                       // setting_frameEnergyTHFacMedian
         th = 26.0f * 0.5f + th * (1 - 0.5f);          // setting_frameEnergyTHConstWeight
         th = th * th;
@@ -1223,14 +1257,21 @@ __global__ void __launch_bounds__(kSelLanes) k_ef_select_th(int nF, int nP, cons
     }
 }
 
+template <int SRC>
+__global__ void __launch_bounds__(kSelLanes) k_ef_select_th(int nF, int nP, int own0, int own1, const uint8_t* __restrict__ rflags,
+                                                            const float* __restrict__ wo, const double* __restrict__ cand,
+                                                            const float* __restrict__ th_prev, float* __restrict__ th_out, float* __restrict__ log_slot) {
+    __shared__ SelectSmem S;
+    select_th_body<SRC>(nF, nP, own0, own1, rflags, wo, cand, th_prev, th_out, log_slot, S);
+}
+
 // sharded windows: this rank's candidates of the quantile above as doubles (energy + 1, 0 = none), summed over the ranks by the
 // same all-reduce that carries the four linearize statistics
-__global__ void __launch_bounds__(256) k_ef_pack_th_candidates(int nF, int nP, const uint8_t* __restrict__ rflags, const float* __restrict__ wo,
-                                                               const int* __restrict__ phost, const PrecalcDev* __restrict__ precalc,
-                                                               double* __restrict__ cand) {
+__global__ void __launch_bounds__(256) k_ef_pack_th_candidates(int nF, int nP, int own0, int own1, const uint8_t* __restrict__ rflags,
+                                                               const float* __restrict__ wo, double* __restrict__ cand) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= nP) return;
-    const unsigned k = sel_key<0>(p, nF, nP, rflags, wo, nullptr, phost, precalc);
+    const unsigned k = sel_key<0>(p, nF, nP, own0, own1, rflags, wo, nullptr);
     cand[p] = (k == 0xFFFFFFFFu) ? 0.0 : (double)__uint_as_float(k) + 1.0;
 }
 

@@ -329,7 +329,6 @@ static __global__ void __launch_bounds__(128) k_finalize(const float* __restrict
     __syncthreads();
     finalize_outputs(S, threadIdx.x, out + (size_t)b * kOutStride);
     if (done_flag) {   // single-hypothesis host-driven trial: publish completion to the spinning host (waitflag.hpp)
-        __threadfence_system();   // every storing thread orders its result stores before the flag (waitflag.hpp)
         __syncthreads();
         if (threadIdx.x == 0) { __threadfence_system(); *done_flag = done_seq; }
     }

@@ -11,8 +11,13 @@
 
 namespace sdvgn {
 
-// call by ONE thread of a workgroup after the workgroup's results are written, fenced by EVERY storing thread
-// (__threadfence_system()) and a __syncthreads(); nblocks = workgroups that will call this for the same (counter, seq).  The counter must be 0 before the launch; the publisher resets it.
+// call by ONE thread of a workgroup after the workgroup's results are written and a __syncthreads(); nblocks = workgroups that
+// will call this for the same (counter, seq).
+// Ordering: __syncthreads() is `fence release(workgroup); s_barrier; fence acquire(workgroup)`, so every result store of the
+// workgroup happens-before the publishing thread's system-scope release fence below, and release fences are cumulative in the
+// AMDGPU memory model: the flag store cannot become visible to the host before those stores.  (A system-scope fence in EVERY storing
+// thread was tried for belt and braces: each one is an L2 write-back, +10 us on k_ef_acc_reduce -- profiles/r02_notes.txt.)
+// The host side pairs it with an acquire fence after the spin (wait_flag).  The counter must be 0 before the launch; the publisher resets it.
 __device__ __forceinline__ void publish_when_all_done(unsigned* counter, unsigned nblocks, volatile int* flag, int seq) {
     __threadfence_system();
     const unsigned prev = atomicAdd(counter, 1u);
