@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types only: the library is resolved at run time (dlopen), so libsdvgn has no link-time RCCL dependency
 #include "gnmath.hpp"
+#include "backend_solve.inc"
 #include "tracker_kernels.hpp"
 
 #include <algorithm>
@@ -97,6 +98,22 @@ struct sdvgn_ef {
     int8_t* rstate_new2 = nullptr;
     float *renergy_new2 = nullptr, *renergy_wo2 = nullptr;
     int new_cur = 0;   // which set holds the current state_New* values
+    // device-resident small solve (backend_solve.inc)
+    SolveWindow* win_dev = nullptr;        // per-window constants of the solve (adjoints, priors, HM/bM, null-space basis, evalPT ...)
+    SolveWindow* win_host = nullptr;       // pinned staging copy
+    bool win_dirty = true;
+    SolveState* sstate_dev = nullptr;      // [2]: calib value + frame states, the current set and the trial set of the optimize loop
+    SolveState* sstate_host = nullptr;     // pinned staging
+    CalibDev* calib_dev = nullptr;         // [2]: CalibHessian float views of the two state sets
+    CalibDev* calib_host = nullptr;        // pinned staging
+    int st_cur = 0;                        // which of the two sets holds the current state
+    bool state_dirty = true;               // the host mirror changed outside the loop: upload before the next device solve
+    ResubX* rx_dev = nullptr;              // xc, xAd of the last solve (k_ef_resubstitute reads them)
+    SolveSys* sys_dev = nullptr;           // HA, bA, Hsc, bsc, HFinal, bFinal of the last solve
+    SolveOut* sol_host = nullptr;          // pinned: x, step statistics, resInA, status
+    unsigned* solve_ctr = nullptr;         // arrival counter of k_ef_reduce_solve
+    int seq_solve = 0;                     // flags_host[3]
+    bool sys_on_device = false, sys_fetched = false, sys_valid = false;
     void* fin_dev = nullptr;       // outputs of sdvgn_ef_optimize_finish (relbs_max, ngood_inc, removed), grown on demand
     size_t fin_bytes = 0;
     float* th_dev = nullptr;       // frameEnergyTH [2 sets][SDVGN_MAX_FRAMES]: one per state_New* set (setNewFrameEnergyTH after every linearizeAll)
@@ -166,7 +183,7 @@ struct PhaseTimer {   // SDVGN_PROFILE=1: host wall time per phase of the optimi
 };
 static PhaseTimer g_pt;
 enum { PT_ACCUM = 0, PT_D2H, PT_STITCH_TOP, PT_STITCH_SC, PT_SOLVE, PT_RESUB, PT_STEP, PT_PRECALC, PT_LIN, PT_APPLY, PT_PREP, PT_N };
-static const char* kPtNames[PT_N] = {"accumulate(launch)", "acc D2H+sync", "stitch_top", "stitch_sc", "LDLT+orthogonalize", "xAd+resub launch", "state step", "precalc upload", "linearize+stats+sync", "apply/restore", "HFinal+scale"};
+static const char* kPtNames[PT_N] = {"launches (acc..solve..resub..linearize..stats)", "wait for x (solve flag)", "-", "-", "-", "-", "host mirror of the step", "-", "wait for the statistics", "decision + apply/restore", "-"};
 
 constexpr size_t kDbgStampWords = (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * 2 * kMaxChunks * 4 * 8;
 static size_t acc_count(const sdvgn_ef* e) { return (size_t)e->nF * e->nF * kTopE + (size_t)e->nF * kScE + 1; }
@@ -432,18 +449,12 @@ static void svd_jacobi(int m, int k, std::vector<double>& A, std::vector<double>
     }
 }
 
-// EnergyFunctional::orthogonalize(&x, 0)  EnergyFunctional.cpp:615-648
-static void orthogonalize_x(sdvgn_ef* e, std::vector<double>& x) {
-    const int n = (int)x.size(), k = (int)e->nullspaces.size();
-    if (k == 0) return;
-    if (!e->ns_dirty && e->ns_N.size() == (size_t)n * k) {   // N and its pseudo-inverse only change with sdvgn_ef_set_nullspaces
-        const std::vector<double>&N = e->ns_N, &Npi = e->ns_Npi;
-        std::vector<double> tN(k, 0), tP(k, 0);
-        for (int j = 0; j < k; ++j) { double a = 0, c = 0; for (int i = 0; i < n; ++i) { a += N[(size_t)i * k + j] * x[i]; c += Npi[(size_t)i * k + j] * x[i]; } tN[j] = a; tP[j] = c; }
-        for (int i = 0; i < n; ++i) { double a = 0; for (int j = 0; j < k; ++j) a += N[(size_t)i * k + j] * tP[j] + Npi[(size_t)i * k + j] * tN[j]; x[i] -= 0.5 * a; }
-        return;
-    }
-    std::vector<double> N((size_t)n * k), U, s, V;
+// EnergyFunctional::orthogonalize(&x, 0)  EnergyFunctional.cpp:615-648.  The normalised null-space basis N and its pseudo-inverse
+// Npi (via SVD, singular values below setting_solverModeDelta * max cut) only change with sdvgn_ef_set_nullspaces: computed once.
+static void ef_prepare_nullspace(sdvgn_ef* e, int n) {
+    const int k = (int)e->nullspaces.size();
+    if (!e->ns_dirty && e->ns_N.size() == (size_t)n * k) return;
+    std::vector<double> N((size_t)n * k), U, sv, V;
     for (int j = 0; j < k; ++j) {
         double nn = 0;
         for (int i = 0; i < n; ++i) nn += e->nullspaces[j][i] * e->nullspaces[j][i];
@@ -451,17 +462,74 @@ static void orthogonalize_x(sdvgn_ef* e, std::vector<double>& x) {
         for (int i = 0; i < n; ++i) N[(size_t)i * k + j] = e->nullspaces[j][i] / nn;
     }
     U = N;
-    svd_jacobi(n, k, U, s, V);
+    svd_jacobi(n, k, U, sv, V);
     double maxSv = 0;
-    for (double v : s) maxSv = std::max(maxSv, v);
-    for (double& v : s) v = (v > 1e-5 * maxSv) ? 1.0 / v : 0;   // setting_solverModeDelta
-    // Npi = U S V^T ; y = 0.5 (N Npi^T + Npi N^T) x
-    std::vector<double> Npi((size_t)n * k, 0), tN(k, 0), tP(k, 0);
+    for (double v : sv) maxSv = std::max(maxSv, v);
+    for (double& v : sv) v = (v > 1e-5 * maxSv) ? 1.0 / v : 0;   // setting_solverModeDelta
+    std::vector<double> Npi((size_t)n * k, 0);                    // Npi = U S V^T
     for (int i = 0; i < n; ++i)
-        for (int j = 0; j < k; ++j) { double a = 0; for (int q = 0; q < k; ++q) a += U[(size_t)i * k + q] * s[q] * V[(size_t)j * k + q]; Npi[(size_t)i * k + j] = a; }
+        for (int j = 0; j < k; ++j) { double a = 0; for (int q = 0; q < k; ++q) a += U[(size_t)i * k + q] * sv[q] * V[(size_t)j * k + q]; Npi[(size_t)i * k + j] = a; }
+    e->ns_N = N; e->ns_Npi = Npi; e->ns_dirty = false;
+}
+static void orthogonalize_x(sdvgn_ef* e, std::vector<double>& x) {     // y = x - 0.5 (N Npi^T + Npi N^T) x
+    const int n = (int)x.size(), k = (int)e->nullspaces.size();
+    if (k == 0) return;
+    ef_prepare_nullspace(e, n);
+    const std::vector<double>&N = e->ns_N, &Npi = e->ns_Npi;
+    std::vector<double> tN(k, 0), tP(k, 0);
     for (int j = 0; j < k; ++j) { double a = 0, c = 0; for (int i = 0; i < n; ++i) { a += N[(size_t)i * k + j] * x[i]; c += Npi[(size_t)i * k + j] * x[i]; } tN[j] = a; tP[j] = c; }
     for (int i = 0; i < n; ++i) { double a = 0; for (int j = 0; j < k; ++j) a += N[(size_t)i * k + j] * tP[j] + Npi[(size_t)i * k + j] * tN[j]; x[i] -= 0.5 * a; }
-    e->ns_N = N; e->ns_Npi = Npi; e->ns_dirty = false;
+}
+
+// ---- device-resident solve: the window constants and the state set the solve kernel reads (backend_solve.inc) -------------------
+static int ef_sync_window(sdvgn_ef* e) {
+    if (!e->win_dirty) return 0;
+    const int nF = e->nF, n = CPARS + 6 * nF, k = (int)e->nullspaces.size();
+    if (k > kMaxNs) return SDVGN_E_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));     // the staging copy may still feed an earlier upload
+    SolveWindow& W = *e->win_host;
+    std::memset(&W, 0, sizeof(W));
+    W.nF = nF; W.n = n; W.ns_k = k;
+    if (e->haveAdjoints) {
+        std::memcpy(W.adHost, e->adHost.data(), sizeof(double) * (size_t)nF * nF * 36);
+        std::memcpy(W.adHostF, e->adHostF.data(), sizeof(float) * (size_t)nF * nF * 36);
+        std::memcpy(W.adTargetF, e->adTargetF.data(), sizeof(float) * (size_t)nF * nF * 36);
+    }
+    for (int i = 0; i < 4; ++i) { W.cPrior[i] = e->cPrior[i]; W.value_zero[i] = e->value_zero[i]; }
+    for (int h = 0; h < nF; ++h) {
+        const FrameH& f = e->frames[h];
+        gn::pose_store(f.evalPT, W.fr[h].evalPT);
+        for (int i = 0; i < 10; ++i) W.fr[h].state_zero[i] = f.state_zero[i];
+        for (int i = 0; i < 6; ++i) W.fr[h].prior[i] = f.prior[i];
+        W.fr[h].ab_exposure = f.ab_exposure; W.fr[h].frameID = f.frameID;
+    }
+    if ((int)e->HM.size() == n * n) { std::memcpy(W.HM, e->HM.data(), sizeof(double) * n * n); std::memcpy(W.bM, e->bM.data(), sizeof(double) * n); }
+    if (k > 0) {
+        ef_prepare_nullspace(e, n);
+        std::memcpy(W.nsN, e->ns_N.data(), sizeof(double) * (size_t)n * k);
+        std::memcpy(W.nsNpi, e->ns_Npi.data(), sizeof(double) * (size_t)n * k);
+    }
+    HIPCHK(hipMemcpyAsync(e->win_dev, e->win_host, sizeof(SolveWindow), hipMemcpyHostToDevice, e->stream));
+    e->win_dirty = false;
+    return 0;
+}
+static void ef_fill_calib(const sdvgn_ef* e, CalibDev& c) {
+    c.fxl = e->C.fxl; c.fyl = e->C.fyl; c.cxl = e->C.cxl; c.cyl = e->C.cyl; c.fxli = e->C.fxli; c.fyli = e->C.fyli;
+    for (int i = 0; i < 4; ++i) c.cDeltaF[i] = e->C.cDeltaF[i];
+    c.pad[0] = c.pad[1] = 0;
+}
+// host mirror (calib value, frame states) -> the current device state set
+static int ef_sync_state(sdvgn_ef* e) {
+    if (!e->state_dirty) return 0;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    SolveState& S = *e->sstate_host;
+    for (int i = 0; i < 4; ++i) S.value[i] = e->value[i];
+    for (int h = 0; h < e->nF; ++h) for (int i = 0; i < 10; ++i) S.state[h][i] = e->frames[h].state[i];
+    ef_fill_calib(e, *e->calib_host);
+    HIPCHK(hipMemcpyAsync(e->sstate_dev + e->st_cur, e->sstate_host, sizeof(SolveState), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->calib_dev + e->st_cur, e->calib_host, sizeof(CalibDev), hipMemcpyHostToDevice, e->stream));
+    e->state_dirty = false;
+    return 0;
 }
 
 __global__ void __launch_bounds__(1024) k_ef_precalc_in(const unsigned long long* __restrict__ src_pinned, unsigned long long* __restrict__ dst, int n8) {
@@ -582,8 +650,9 @@ __global__ void k_ef_reset_oob(size_t slots, EFArrays A, const uint8_t* __restri
 
 // per-block partial sums of calcLEnergyPt (EnergyFunctional.cpp:297-331); only launched when some residual is linearised
 // or some point has deltaF != 0 (otherwise the sum is exactly 0)
-__global__ void __launch_bounds__(256) k_ef_point_stats(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+__global__ void __launch_bounds__(256) k_ef_point_stats(EFConst Cin, EFArrays A, const PrecalcDev* __restrict__ precalc,
                                                        const int* __restrict__ phost, double* __restrict__ partial) {
+    const EFConst C = ef_const(Cin, A);
     __shared__ double sh[4];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     double e = 0;
@@ -794,13 +863,22 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     e->stats_cap = 4 + mp;
     bad |= dev_alloc(&e->stats_dev, e->stats_cap) | dev_alloc(&e->stats_partial, 3 * (mp / 64 + 2));
     bad |= dev_alloc(&e->th_dev, 2 * SDVGN_MAX_FRAMES);
+    bad |= dev_alloc(&e->win_dev, 1) | dev_alloc(&e->sstate_dev, 2) | dev_alloc(&e->calib_dev, 2) | dev_alloc(&e->rx_dev, 1) | dev_alloc(&e->sys_dev, 1);
+    bad |= dev_alloc(&e->solve_ctr, 1);
     if (bad) { sdvgn_ef_destroy(e); return -(int)hipErrorOutOfMemory; }
     HIPCHK(hipHostMalloc(&e->precalc_host, 2 * sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
     HIPCHK(hipHostMalloc(&e->acc_host, sizeof(double) * accmax));
     HIPCHK(hipHostMalloc(&e->stats_host, sizeof(double) * 4));
     HIPCHK(hipHostMalloc((void**)&e->flags_host, 64));
     HIPCHK(hipHostMalloc((void**)&e->th_log, sizeof(float) * kThLog));
-    e->flags_host[0] = e->flags_host[1] = e->flags_host[2] = 0;
+    HIPCHK(hipHostMalloc((void**)&e->win_host, sizeof(SolveWindow)));
+    HIPCHK(hipHostMalloc((void**)&e->sstate_host, sizeof(SolveState)));
+    HIPCHK(hipHostMalloc((void**)&e->calib_host, sizeof(CalibDev)));
+    HIPCHK(hipHostMalloc((void**)&e->sol_host, sizeof(SolveOut)));
+    std::memset(e->sol_host, 0, sizeof(SolveOut));
+    HIPCHK(hipMemset(e->solve_ctr, 0, sizeof(unsigned)));
+    HIPCHK(hipMemset(e->rx_dev, 0, sizeof(ResubX)));
+    e->flags_host[0] = e->flags_host[1] = e->flags_host[2] = e->flags_host[3] = 0;
     HIPCHK(hipMalloc((void**)&e->done_ctr, 2 * sizeof(unsigned)));
     HIPCHK(hipMemset(e->done_ctr, 0, 2 * sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void**)&e->imm_pc_host, sizeof(ImmPrecalc) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
@@ -837,13 +915,18 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->images, e->img_stage,
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
                     e->stats_dev, e->stats_partial, e->sc_off_dev, e->imm_pc_dev, e->rstate_new2, e->renergy_new2, e->renergy_wo2,
-                    e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->precalc_alt, e->dbg_stamps, e->marg_mask_dev, e->drop_mask_dev, e->th_dev, e->fin_dev};
+                    e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->precalc_alt, e->dbg_stamps, e->marg_mask_dev, e->drop_mask_dev, e->th_dev, e->fin_dev,
+                    e->win_dev, e->sstate_dev, e->calib_dev, e->rx_dev, e->sys_dev, e->solve_ctr};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->precalc_host) hipHostFree(e->precalc_host);
     if (e->acc_host) hipHostFree(e->acc_host);
     if (e->stats_host) hipHostFree(e->stats_host);
     if (e->flags_host) hipHostFree(e->flags_host);
     if (e->th_log) hipHostFree(e->th_log);
+    if (e->win_host) hipHostFree(e->win_host);
+    if (e->sstate_host) hipHostFree(e->sstate_host);
+    if (e->calib_host) hipHostFree(e->calib_host);
+    if (e->sol_host) hipHostFree(e->sol_host);
     if (e->done_ctr) hipFree(e->done_ctr);
     if (e->imm_pc_host) hipHostFree(e->imm_pc_host);
     if (e->imm_stage) hipHostFree(e->imm_stage);
@@ -868,6 +951,7 @@ int sdvgn_ef_set_calib(sdvgn_ef* e, const double vs[4], const double vmz[4]) {
     for (int i = 0; i < 4; ++i) e->value_zero[i] = e->value[i] - vmz[i];
     ef_update_const(e);
     e->havePrecalc = false;
+    e->win_dirty = e->state_dirty = true; e->sys_valid = false;
     return SDVGN_OK;
 }
 
@@ -894,6 +978,7 @@ int sdvgn_ef_set_frames(sdvgn_ef* e, int nF, const double* evalPT7, const double
     // so that nothing can run on a stale layout before sdvgn_ef_set_points / _set_residuals are called again
     e->nP = 0; e->nR = -1;
     e->hostP0.clear(); e->phost.clear(); e->r_slot.clear();
+    e->win_dirty = e->state_dirty = true; e->sys_valid = false;
     if (!e->host_only) {
         float th[2 * SDVGN_MAX_FRAMES] = {0};
         for (int i = 0; i < nF; ++i) th[i] = th[SDVGN_MAX_FRAMES + i] = frameEnergyTH[i];
@@ -923,6 +1008,7 @@ int sdvgn_ef_set_frame_states(sdvgn_ef* e, const double* state10) {
     if (!e || !state10) return SDVGN_E_ARG;
     for (int i = 0; i < e->nF; ++i) frame_set_state(e->frames[i], state10 + 10 * i);
     e->havePrecalc = false;
+    e->state_dirty = true; e->sys_valid = false;
     return SDVGN_OK;
 }
 
@@ -1053,6 +1139,7 @@ int sdvgn_ef_set_marg_prior(sdvgn_ef* e, const double* HM, const double* bM) {
     if (!e || !HM || !bM || e->nF < 1) return SDVGN_E_ARG;
     const int n = CPARS + 6 * e->nF;
     e->HM.assign(HM, HM + (size_t)n * n); e->bM.assign(bM, bM + n);
+    e->win_dirty = true; e->sys_valid = false;
     return SDVGN_OK;
 }
 
@@ -1060,7 +1147,7 @@ int sdvgn_ef_set_nullspaces(sdvgn_ef* e, int k, const double* v) {
     if (!e || k < 0 || (k > 0 && !v) || e->nF < 1) return SDVGN_E_ARG;
     const int n = CPARS + 6 * e->nF;
     e->nullspaces.clear();
-    e->ns_dirty = true;
+    e->ns_dirty = true; e->win_dirty = true;
     for (int j = 0; j < k; ++j) e->nullspaces.emplace_back(v + (size_t)j * n, v + (size_t)(j + 1) * n);
     return SDVGN_OK;
 }
@@ -1088,6 +1175,7 @@ int sdvgn_ef_set_adjoints(sdvgn_ef* e) {  // EnergyFunctional::setAdjointsF
     for (int i = 0; i < 4; ++i) e->cPrior[i] = kInitialCalibHessian;
     e->haveAdjoints = true;
     e->havePrecalc = false;
+    e->win_dirty = true; e->sys_valid = false;
     return SDVGN_OK;
 }
 
@@ -1126,41 +1214,33 @@ int sdvgn_ef_apply_res(sdvgn_ef* e) {
     return SDVGN_OK;
 }
 
-// split = true (single-GPU solve): the top Gram is reduced into acc_host first and ev_top recorded, so that the host can
-// stitch the top part while the point / SC-Gram kernels still run; the SC part + resInA follow on the stream (split_pending).
-static int ef_accumulate(sdvgn_ef* e, bool split) {
-    const int nF = e->nF, pairs = nF * nF, chunks = chunks_for_np(e);
+// The accumulate kernels of one solveSystemF: [top Gram | per-point sums], [Schur Gram]; their per-workgroup partial tiles are
+// reduced either by k_ef_acc_reduce (with_reduce: packed buffer in acc_dev, the form the all-reduce of a sharded window needs) or by
+// the caller's k_ef_reduce_solve, whose last workgroup continues with the solve.
+struct AccGeom { int pairs, chunks, sc_chunks, sc_ppb, ntop, nsc; };
+static AccGeom ef_acc_geom(const sdvgn_ef* e) {
+    AccGeom g;
+    const int nF = e->nF;
+    g.pairs = nF * nF; g.chunks = chunks_for_np(e);
     int mx = 1;
     for (int h = 0; h < nF; ++h) mx = std::max(mx, e->hostP0[h + 1] - e->hostP0[h]);
-    // one 64-point tile per Schur-Gram workgroup: the workgroup is a chain of dependent round trips (flags + JpJdF -> LDS -> MFMA), and
-    // with the top reduce running beside it in stage 2 a second tile per workgroup costs more than the extra partial tiles (measured
-    // 64 / 128 / 192 points per workgroup: 99.9 / 101.0 / 105.3 us per loop body)
-    // (the serial three-launch path of the sharded configuration would prefer 128 -- 22.0 vs 23.3 us -- but uses the same chunking so
-    // that a sharded run reproduces the single-GPU run bit for bit, tests/test_backend_gpu.py::test_sharded_path_single_rank_nccl)
-    const int sc_chunks = std::min(kMaxChunks, (mx + 63) / 64);
-    const int sc_ppb = ((mx + sc_chunks - 1) / sc_chunks + 63) / 64 * 64;
-    const int ntop = pairs * kTopE, nsc = nF * kScE;
-    if (split) {
-        // the reduce kernels store straight into the pinned host buffer (fine-grained, visible at kernel completion): no copy
-        // engine in the path -- a small D2H memcpy costs 10-20 us of fixed latency, more than the 154 kB take over PCIe
-        // three launches: [top Gram | per-point sums], [top reduce + flag | Schur Gram], [Schur reduce + resInA + flag]
-        const int n_top = chunks * pairs, n_pt = (e->nP + 63) / 64, n_red = (ntop + 255) / 256;
-        k_ef_acc_stage1<<<n_top + n_pt, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, chunks, n_top);
-        k_ef_acc_stage2<<<n_red + sc_chunks * nF, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, sc_ppb, sc_chunks, e->top_partial,
-                                                                       pairs, chunks, e->acc_host, n_red, e->done_ctr, e->flags_host, ++e->seq_top);
-        k_ef_acc_reduce<<<acc_reduce_grid(ntop, ntop + nsc, ntop, nsc, 1), 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks, e->nres_partial,
-                                                                      e->sc_off_dev, e->acc_host, ntop, ntop + nsc, 1, e->done_ctr + 1, e->flags_host + 1,
-                                                                      ++e->seq_acc);
-        e->split_pending = true;
-        e->acc_in_host = true;
-    } else {
-        e->acc_in_host = false;
-        const int n_top = chunks * pairs, n_pt = (e->nP + 63) / 64;
-        k_ef_acc_stage1<<<n_top + n_pt, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, chunks, n_top);
-        k_ef_sc_gram<<<dim3(sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, sc_ppb);
-        k_ef_acc_reduce<<<acc_reduce_grid(0, ntop + nsc, ntop, nsc, 1), 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks,
-                                                                             e->nres_partial, e->sc_off_dev, e->acc_dev, 0, ntop + nsc, 1, nullptr, nullptr, 0);
-    }
+    // one 64-point tile per Schur-Gram workgroup (a workgroup is a chain of dependent round trips: flags + JpJdF -> LDS -> MFMA;
+    // 64 / 128 / 192 points per workgroup measured 99.9 / 101.0 / 105.3 us per loop body in round 1); the same chunking on every path,
+    // so that a sharded run reproduces the single-GPU run bit for bit
+    g.sc_chunks = std::min(kMaxChunks, (mx + 63) / 64);
+    g.sc_ppb = ((mx + g.sc_chunks - 1) / g.sc_chunks + 63) / 64 * 64;
+    g.ntop = g.pairs * kTopE; g.nsc = nF * kScE;
+    return g;
+}
+static int ef_accumulate(sdvgn_ef* e, bool with_reduce) {
+    const AccGeom g = ef_acc_geom(e);
+    const int nF = e->nF, n_top = g.chunks * g.pairs, n_pt = (e->nP + 63) / 64;
+    k_ef_acc_stage1<<<n_top + n_pt, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, n_top);
+    k_ef_sc_gram<<<dim3(g.sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, g.sc_ppb);
+    if (with_reduce)
+        k_ef_acc_reduce<<<acc_reduce_grid(0, g.ntop + g.nsc, g.ntop, g.nsc, 1), 256, 0, e->stream>>>(e->top_partial, g.pairs, g.chunks, e->sc_partial, nF, g.sc_chunks,
+                                                                                     e->nres_partial, e->sc_off_dev, e->acc_dev, 0, g.ntop + g.nsc, 1, nullptr, nullptr, 0);
+    e->acc_in_host = false;
     HIPCHK(hipGetLastError());
     return SDVGN_OK;
 }
@@ -1168,7 +1248,7 @@ static int ef_accumulate(sdvgn_ef* e, bool split) {
 int sdvgn_ef_accumulate(sdvgn_ef* e) {
     if (!e || e->host_only || !e->havePrecalc || e->nP < 1) return SDVGN_E_STATE;
     EF_DEVICE(e);
-    return ef_accumulate(e, false);
+    return ef_accumulate(e, /*with_reduce=*/true);
 }
 
 int sdvgn_ef_set_external_buffers(sdvgn_ef* e, double* acc_dev, int acc_capacity, double* stats_dev, int stats_capacity) {
@@ -1277,27 +1357,18 @@ static void ef_swap_point_copies(sdvgn_ef* e) {
     e->A.pid = e->pid; e->A.pidz = e->pidz; e->A.pdeltaF = e->pdeltaF;
 }
 
+// host version of the small solve (stitch, HM/bM, damped preconditioned LDLT, null-space projection) on a caller-supplied packed
+// accumulator buffer: the entry point of host-only handles (CPU / gloo tests of the multi-GPU logic) and the reference the device
+// solve (backend_solve.inc) is tested against
 static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, double lambda, double* x_out) {
     const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF;
-    g_pt.start();
-    const bool reuse = e->reuse_system && (int)e->HA.size() == n * n && (int)e->Hsc.size() == n * n;
-    if (!reuse) stitch_top(e, acc);
-    // bM_top = bM + HM * delta (needs no accumulator: done before waiting for the Schur part)
+    stitch_top(e, acc);
     std::vector<double> d(n), bM_top(n);
     for (int i = 0; i < CPARS; ++i) d[i] = (double)e->C.cDeltaF[i];
     for (int h = 0; h < nF; ++h) for (int i = 0; i < 6; ++i) d[CPARS + 6 * h + i] = e->frames[h].delta[i];
     for (int i = 0; i < n; ++i) { double a = 0; for (int j = 0; j < n; ++j) a += e->HM[(size_t)i * n + j] * d[j]; bM_top[i] = e->bM[i] + a; }
-    g_pt.stop(PT_STITCH_TOP);
-    if (e->split_pending) {   // the SC accumulators were still being produced while the top part was stitched
-        HIPCHK(wait_flag(e->flags_host + 1, e->seq_acc, e->stream));
-        e->split_pending = false;
-        g_pt.stop(PT_D2H);
-    }
-    if (!reuse) {
-        e->resInA = (int)acc[acc_count(e) - 1];
-        stitch_sc(e, acc + (size_t)pairs * kTopE);
-    }
-    g_pt.stop(PT_STITCH_SC);
+    e->resInA = (int)acc[acc_count(e) - 1];
+    stitch_sc(e, acc + (size_t)pairs * kTopE);
     // HFinal = HA + HM - Hsc ; bFinal = bA + bM_top - bsc   (EnergyFunctional.cpp:668-699)
     e->HFinal.resize((size_t)n * n); e->bFinal.resize(n);
     for (size_t i = 0; i < (size_t)n * n; ++i) e->HFinal[i] = e->HA[i] + e->HM[i] - e->Hsc[i];
@@ -1311,118 +1382,87 @@ static int ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, d
         }
         xs[i] = sv[i] * e->bFinal[i];
     }
-    g_pt.stop(PT_PREP);
     ldlt_solve_rl(n, Hs.data(), xs.data());
     e->lastX.resize(n);
     for (int i = 0; i < n; ++i) e->lastX[i] = sv[i] * xs[i];
     if (iteration >= 2) orthogonalize_x(e, e->lastX);   // SOLVER_ORTHOGONALIZE_X_LATER
     if (x_out) std::memcpy(x_out, e->lastX.data(), sizeof(double) * n);
-    g_pt.stop(PT_SOLVE);
+    e->sys_on_device = false;
     return SDVGN_OK;
 }
 
 int sdvgn_ef_stitch_solve_host(sdvgn_ef* e, const double* acc, int iteration, double lambda, double* x_out) {
     if (!e || !acc || !e->haveAdjoints || !e->havePrecalc) return SDVGN_E_STATE;
+    ef_refresh_frame_deltas(e);
     return ef_stitch_solve_host(e, acc, iteration, lambda, x_out);
 }
 
 static void calib_set_value(sdvgn_ef* e, const double* v);
 
-// doStepFromBackup, host part (FullSystemOptimize.cpp:212-235): calib and frame states from the backup and lastX, then the precalc
-// table of the stepped state into the pinned staging half
-static int ef_step_from_backup_host(sdvgn_ef* e, float stepsize) {
+// ---- the device-resident solve ------------------------------------------------------------------------------------------------------
+static void ef_fill_solve_io(sdvgn_ef* e, SolveIO& io, int iteration, double lambda, bool do_step, float stepsize, bool reuse) {
+    io.acc = e->acc_dev; io.W = e->win_dev;
+    io.cur = e->sstate_dev + e->st_cur; io.trial = e->sstate_dev + (1 - e->st_cur);
+    io.calib_cur = e->calib_dev + e->st_cur; io.calib_trial = e->calib_dev + (1 - e->st_cur);
+    io.pc_cur = e->precalc_dev; io.pc_trial = e->precalc_alt;
+    io.rx = e->rx_dev; io.sys = e->sys_dev; io.out = e->sol_host;
+    io.done_flag = e->flags_host + 3; io.done_seq = ++e->seq_solve;
+    io.lambda = lambda; io.iteration = iteration; io.do_step = do_step ? 1 : 0; io.reuse = reuse ? 1 : 0; io.stepsize = stepsize;
+}
+// solveSystemF on the device, all launches asynchronous: accumulate (unless the stitched system of the previous body is re-used),
+// reduce + stitch + LDL^T + null-space projection (+ the calib / frame part of doStepFromBackup and the precalc table of the stepped
+// state when do_step), then resubstituteF (+ the point part of doStepFromBackup when step_fac >= 0).  x reaches the host through
+// pinned memory; ef_wait_solve fetches it.
+static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_step, float step_fac, bool reuse, bool accumulated) {
+    int rc;
+    if ((rc = ef_sync_window(e)) || (rc = ef_sync_state(e))) return rc;
     const int nF = e->nF;
-    const std::vector<double>& x = e->lastX;
-    double v[4];
-    for (int i = 0; i < 4; ++i) v[i] = e->value_backup[i] + stepsize * (-x[i]);
-    calib_set_value(e, v);
-    float sumT = 0, sumR = 0;
-    for (int h = 0; h < nF; ++h) {
-        FrameH& f = e->frames[h];
-        double st[10];
-        for (int i = 0; i < 6; ++i) st[i] = f.state_backup[i] + (double)stepsize * (-x[CPARS + 6 * h + i]);
-        for (int i = 6; i < 10; ++i) st[i] = f.state_backup[i];
-        frame_set_state(f, st);
-        for (int i = 0; i < 3; ++i) sumT += (float)(x[CPARS + 6 * h + i] * x[CPARS + 6 * h + i]);
-        for (int i = 3; i < 6; ++i) sumR += (float)(x[CPARS + 6 * h + i] * x[CPARS + 6 * h + i]);
+    SolveIO io;
+    ef_fill_solve_io(e, io, iteration, lambda, do_step, do_step ? step_fac : 0.0f, reuse);
+    if (reuse) {
+        k_ef_solve<<<1, kSolveLanes, 0, e->stream>>>(io);
+    } else if (ef_sharded(e) || accumulated) {
+        // sharded window: the packed buffer of every rank is summed first (ONE all-reduce per GN iteration), then every rank solves
+        if (!accumulated && (rc = ef_accumulate(e, /*with_reduce=*/true))) return rc;
+        if (!accumulated && (rc = ef_allreduce(e, e->acc_dev, (int)acc_count(e)))) return rc;
+        k_ef_solve<<<1, kSolveLanes, 0, e->stream>>>(io);
+    } else {
+        if ((rc = ef_accumulate(e, /*with_reduce=*/false))) return rc;
+        const AccGeom g = ef_acc_geom(e);
+        k_ef_reduce_solve<<<reduce_solve_grid(g.pairs, nF), kSolveLanes, 0, e->stream>>>(e->top_partial, g.pairs, g.chunks, e->sc_partial, nF, g.sc_chunks,
+                                                                                         e->nres_partial, e->sc_off_dev, e->acc_dev, e->solve_ctr, io);
     }
-    e->step_sumT = sumT; e->step_sumR = sumR;
-    return ef_upload_precalc(e, nullptr, /*stage_only=*/true);                        // setPrecalcValues + setDeltaF
+    HIPCHK(hipGetLastError());
+    const int nblk = (e->nP + 63) / 64;
+    k_ef_resubstitute<<<nblk, 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->rx_dev, e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2),
+                                                   step_fac, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, nblk, nullptr, nullptr, 0);
+    HIPCHK(hipGetLastError());
+    e->sys_on_device = true; e->sys_fetched = false; e->sys_valid = true;
+    return SDVGN_OK;
+}
+static int ef_wait_solve(sdvgn_ef* e, double* x_out) {
+    HIPCHK(wait_flag(e->flags_host + 3, e->seq_solve, e->stream));
+    const int n = CPARS + 6 * e->nF;
+    e->lastX.assign(e->sol_host->x, e->sol_host->x + n);
+    e->resInA = e->sol_host->resInA;
+    if (x_out) std::memcpy(x_out, e->lastX.data(), sizeof(double) * n);
+    return e->sol_host->status ? SDVGN_E_STATE : SDVGN_OK;
 }
 
 int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_out) {
     if (!e || e->host_only || !e->havePrecalc || e->nP < 1) return SDVGN_E_STATE;
     EF_DEVICE(e);
-    const int nF = e->nF, n = CPARS + 6 * nF;
-    g_pt.start();
-    if (e->reuse_system) {
-        // nothing to fetch
-    } else if (e->split_pending) {
-        HIPCHK(wait_flag(e->flags_host, e->seq_top, e->stream));   // the top accumulators are in acc_host (waitflag.hpp)
-    } else {
-        const int na = (int)acc_count(e);   // sharded / generic path: the (all-reduced) device buffer comes back through a copy kernel
-        k_ef_copy_publish<<<(na + 255) / 256, 256, 0, e->stream>>>(e->acc_dev, e->acc_host, na, e->done_ctr + 1, e->flags_host + 1, ++e->seq_acc);
-        HIPCHK(hipGetLastError());
-        HIPCHK(wait_flag(e->flags_host + 1, e->seq_acc, e->stream));
-        e->acc_in_host = false;
-    }
-    g_pt.stop(PT_D2H);
-    int rc = ef_stitch_solve_host(e, e->acc_host, iteration, lambda, x_out);
-    g_pt.start();
+    int rc = ef_launch_solve(e, iteration, lambda, /*do_step=*/false, -1.0f, /*reuse=*/false, /*accumulated=*/true);
     if (rc) return rc;
-    // resubstituteF_MT (:221-247): xc, xAd[nF*h + t] -- handed to the kernel by value (kernel-argument segment, no H2D copy)
-    ResubX X;
-    std::memset(&X, 0, sizeof(X));
-    std::vector<float> xF(n);
-    for (int i = 0; i < n; ++i) xF[i] = (float)e->lastX[i];
-    for (int i = 0; i < 4; ++i) X.xc[i] = xF[i];
-    for (int h = 0; h < nF; ++h)
-        for (int t = 0; t < nF; ++t) {
-            const float* AH = &e->adHostF[(size_t)(h + nF * t) * 36];
-            const float* AT = &e->adTargetF[(size_t)(h + nF * t) * 36];
-            for (int c = 0; c < 6; ++c) {
-                float a = 0, b = 0;
-                for (int q = 0; q < 6; ++q) { a += xF[CPARS + 6 * h + q] * AH[q * 6 + c]; b += xF[CPARS + 6 * t + q] * AT[q * 6 + c]; }
-                X.xAd[(size_t)(nF * h + t) * 6 + c] = a + b;
-            }
-        }
-    const float step_fac = e->fuse_step_fac;   // >= 0 inside sdvgn_ef_optimize: doStepFromBackup for the points rides along
-    const EFConst C_solve = e->C;              // the calib the system was built with (the host step below moves e->C on)
-    const unsigned long long* pc_src = nullptr;
-    int pc_n8 = 0;
-    g_pt.stop(PT_RESUB);
-    if (e->in_optimize_loop) {
-        // host part of doStepFromBackup first, so that the table of the stepped state rides in this launch (one extra workgroup
-        // copies it from the pinned staging half into the second device table) instead of in a launch of its own
-        if ((rc = ef_step_from_backup_host(e, step_fac))) return rc;
-        pc_src = (const unsigned long long*)e->precalc_staged;
-        pc_n8 = (int)(sizeof(PrecalcDev) * nF * nF / 8);
-        g_pt.stop(PT_PRECALC);
-    }
-    const int nblk = (e->nP + 63) / 64;
-    k_ef_resubstitute<<<nblk + (pc_src ? 1 : 0), 512, 0, e->stream>>>(C_solve, e->A, e->precalc_dev, e->phost_dev, X, e->pidepth_backup,
-                                                                       e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt,
-                                                                       e->pdeltaF_alt, nblk, pc_src, (unsigned long long*)e->precalc_alt, pc_n8);
-    HIPCHK(hipGetLastError());
-    if (step_fac >= 0.0f) {   // the stepped idepths are in the second copies: make them the ones every later launch reads
-        ef_swap_point_copies(e);
-        e->deltaF_nonzero = false;
-    }
-    if (pc_src) std::swap(e->precalc_dev, e->precalc_alt);
-    g_pt.stop(PT_RESUB);
-    return SDVGN_OK;
+    return ef_wait_solve(e, x_out);
 }
 
 int sdvgn_ef_solve_system(sdvgn_ef* e, int iteration, double lambda, double* x_out) {
     if (!e || e->host_only || !e->havePrecalc || e->nP < 1) return SDVGN_E_STATE;
     EF_DEVICE(e);
-    if (e->reuse_system) return sdvgn_ef_finish_solve(e, iteration, lambda, x_out);
-    g_pt.start();
-    int rc = ef_accumulate(e, /*split=*/!ef_sharded(e));
-    g_pt.stop(PT_ACCUM);
+    int rc = ef_launch_solve(e, iteration, lambda, /*do_step=*/false, -1.0f, /*reuse=*/false, /*accumulated=*/false);
     if (rc) return rc;
-    if (ef_sharded(e) && (rc = ef_allreduce(e, e->acc_dev, (int)acc_count(e)))) return rc;   // cfg4: one all-reduce per GN iteration
-    return sdvgn_ef_finish_solve(e, iteration, lambda, x_out);
+    return ef_wait_solve(e, x_out);
 }
 
 int sdvgn_ef_point_step(sdvgn_ef* e, int mode, float stepfacD) {
@@ -1452,8 +1492,9 @@ static double calc_M_energy(sdvgn_ef* e) {   // EnergyFunctional::calcMEnergyF
     for (int i = 0; i < n; ++i) { double a = 2 * e->bM[i]; for (int j = 0; j < n; ++j) a += e->HM[(size_t)i * n + j] * d[j]; s += d[i] * a; }
     return s;
 }
-// launches linearizeAll + the point statistics; returns {energy, L-energy, sum step^2, sum |idepth_backup|} after ONE sync
-static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* sumID, double* sumNID) {
+// linearizeAll + the point statistics + setNewFrameEnergyTH, in two halves: the launches (asynchronous) and the wait for the four
+// sums {energy, L-energy point part, sum step^2, sum |idepth_backup|}
+static int linearize_launch(sdvgn_ef* e) {
     if (!e->havePrecalc) return SDVGN_E_STATE;
     const int n_partials = ef_launch_linearize(e);
     int nL = 0;
@@ -1462,20 +1503,17 @@ static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* 
         k_ef_point_stats<<<nL, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->stats_partial);
     }
     const int nS = (e->nP + 63) / 64;
-    // without an all-reduce the four sums go straight into pinned host memory (no copy engine, see ef_accumulate)
-    const bool flagged = !ef_sharded(e);
     const double* ps = e->stats_partial + (e->nP / 64 + 2);
-    if (!flagged) {
+    if (ef_sharded(e)) {
         k_ef_sum_stats<<<1, 256, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_dev, nullptr, 0);
         // ranks hold disjoint host-frame shards: ONE all-reduce carries the four sums and the candidates of setNewFrameEnergyTH's quantile
         ef_launch_pack_th(e);
         { const int rca = ef_allreduce(e, e->stats_dev, 4 + e->nP); if (rca) return rca; }
         k_ef_copy_publish<<<1, 256, 0, e->stream>>>(e->stats_dev, e->stats_host, 4, e->done_ctr, e->flags_host + 2, ++e->seq_stats);
         ef_launch_select_th(e, true);
-        HIPCHK(hipGetLastError());
-        HIPCHK(wait_flag(e->flags_host + 2, e->seq_stats, e->stream));
     } else {
-        // statistics (host waits for their flag) and setNewFrameEnergyTH (only the NEXT linearise needs it) side by side in one launch
+        // statistics (the host waits for their flag; pinned memory, no copy engine) and setNewFrameEnergyTH (only the NEXT linearise
+        // needs it) side by side in one launch
         SelArgs a;
         a.nF = e->nF; a.nP = e->nP;
         ef_owned_points(e, a.own0, a.own1);
@@ -1483,11 +1521,14 @@ static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* 
         a.log_slot = e->th_log ? e->th_log + (e->th_log_n++ % kThLog) : nullptr;
         k_ef_stats_select<<<2, kSelLanes, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host, e->flags_host + 2,
                                                           ++e->seq_stats, a);
-        HIPCHK(hipGetLastError());
-        HIPCHK(wait_flag(e->flags_host + 2, e->seq_stats, e->stream));
     }
+    HIPCHK(hipGetLastError());
+    return SDVGN_OK;
+}
+static int linearize_wait(sdvgn_ef* e, double* energy, double* EL, double* sumID, double* sumNID) {
+    HIPCHK(wait_flag(e->flags_host + 2, e->seq_stats, e->stream));
     *energy = e->stats_host[0];
-    double En = 0;   // calcLEnergyF_MT: frame + calib priors on the host, point part from the device
+    double En = 0;   // calcLEnergyF_MT: frame + calib priors on the host (of the host mirror's state), point part from the device
     for (const FrameH& f : e->frames) for (int i = 0; i < 6; ++i) En += f.delta_prior[i] * f.prior[i] * f.delta_prior[i];
     { float a = 0; for (int i = 0; i < 4; ++i) a += e->C.cDeltaF[i] * (float)e->cPrior[i] * e->C.cDeltaF[i]; En += a; }
     *EL = En + (double)(float)e->stats_host[1];
@@ -1495,7 +1536,15 @@ static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* 
     if (sumNID) *sumNID = e->stats_host[3];
     return SDVGN_OK;
 }
+static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* sumID, double* sumNID) {
+    const int rc = linearize_launch(e);
+    return rc ? rc : linearize_wait(e, energy, EL, sumID, sumNID);
+}
 
+// FullSystem::optimize, the loop (FullSystemOptimize.cpp:344-458).  The window's state lives on the device: per loop body the host
+// only launches -- accumulate, reduce + solve + step + precalc table (k_ef_reduce_solve), resubstitute + point step, linearize,
+// statistics + setNewFrameEnergyTH -- then mirrors the step from x (pinned memory) while the GPU still works, waits ONCE for the four
+// sums, takes the accept / reject decision and launches applyRes or the re-classification.
 int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int trace_stride, int trace_cap) {
     if (!e || !e->haveAdjoints || e->nP < 1) return SDVGN_E_STATE;
     EF_DEVICE(e);
@@ -1510,10 +1559,14 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     const size_t slots = (size_t)nF * e->nP;
     int rc;
     if (!e->havePrecalc && (rc = ef_upload_precalc(e))) return rc;
+    if ((rc = ef_sync_window(e)) || (rc = ef_sync_state(e))) return rc;
+    struct CalibGuard { sdvgn_ef* e; ~CalibGuard() { e->A.calib = nullptr; } } calib_guard{e};   // outside the loop the kernels take EFConst by value
+    e->A.calib = e->calib_dev + e->st_cur;
     k_ef_reset_oob<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(slots, e->A);
     double lastEnergy, lastEnergyL, lastEnergyM;
     e->th_log_n = 0;
     ef_select_new_set(e, e->new_cur, e->new_cur);
+    ef_refresh_frame_deltas(e);
     if ((rc = linearize_and_stats(e, &lastEnergy, &lastEnergyL, nullptr, nullptr))) return rc;
     lastEnergyM = calc_M_energy(e);
     if ((rc = sdvgn_ef_apply_res(e))) return rc;
@@ -1525,25 +1578,44 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     std::vector<int> th_idx;   // th_log slot of every trial linearisation (trace only)
     for (int iteration = 0; iteration < mnumOptIts; iteration++) {
         const auto t_iter = std::chrono::steady_clock::now();
+        g_pt.start();
         for (int i = 0; i < 4; ++i) e->value_backup[i] = e->value[i];                     // backupState
         for (FrameH& f : e->frames) for (int i = 0; i < 10; ++i) f.state_backup[i] = f.state[i];
         const bool zero_differs = e->deltaF_nonzero;   // idepth != idepth_zero before this trial (only possible right after a load)
-        e->fuse_step_fac = stepsize;   // resubstitute also backs up the idepths and applies doStepFromBackup's point part
-        e->reuse_system = reuse_after_reject && prev_rejected_clean;
-        e->in_optimize_loop = true;
-        rc = sdvgn_ef_solve_system(e, iteration, lambda, x.data());
-        e->in_optimize_loop = false;
-        e->fuse_step_fac = -1.0f;
-        e->reuse_system = false;
-        if (rc) return rc;
-        // doStepFromBackup ran inside the solve: host part (calib / frame states / precalc table) before the resubstitute launch,
-        // point part and the table copy inside it
-        float sumT = e->step_sumT, sumR = e->step_sumR;
-        g_pt.start();
-        double newEnergy, newEnergyL, sID, sNID;
+        // solveSystemF + doStepFromBackup, all on the device: the trial state (frame states, calib, precalc table, idepths) goes to the
+        // second copies; resubstitute also backs up the idepths and applies the point step
+        const bool reuse = reuse_after_reject && prev_rejected_clean && e->sys_valid;
+        if ((rc = ef_launch_solve(e, iteration, lambda, /*do_step=*/true, stepsize, reuse, /*accumulated=*/false))) return rc;
+        ef_swap_point_copies(e);                                                          // the stepped idepths are the ones every later launch reads
+        e->deltaF_nonzero = false;
+        std::swap(e->precalc_dev, e->precalc_alt);
+        const int st_trial = 1 - e->st_cur;
+        e->A.calib = e->calib_dev + st_trial;
         ef_select_new_set(e, 1 - e->new_cur, e->new_cur);                                 // trial linearisation goes to the other set
         th_idx.push_back(e->th_log_n % kThLog);
-        if ((rc = linearize_and_stats(e, &newEnergy, &newEnergyL, &sID, &sNID))) return rc;
+        if ((rc = linearize_launch(e))) return rc;
+        g_pt.stop(PT_ACCUM);
+        // x is in pinned memory as soon as the solve kernel is through: mirror doStepFromBackup on the host (FrameHessian::setState,
+        // CalibHessian::setValue -- the same double-precision operations the device performed) while the GPU linearises
+        if ((rc = ef_wait_solve(e, x.data()))) return rc;
+        g_pt.stop(PT_D2H);
+        {
+            double v[4];
+            for (int i = 0; i < 4; ++i) v[i] = e->value_backup[i] + stepsize * (-x[i]);
+            calib_set_value(e, v);
+            for (int h = 0; h < nF; ++h) {
+                FrameH& f = e->frames[h];
+                double st[10];
+                for (int i = 0; i < 6; ++i) st[i] = f.state_backup[i] + (double)stepsize * (-x[CPARS + 6 * h + i]);
+                for (int i = 6; i < 10; ++i) st[i] = f.state_backup[i];
+                frame_set_state(f, st);
+            }
+            ef_refresh_frame_deltas(e);
+        }
+        float sumT = e->sol_host->sumT, sumR = e->sol_host->sumR;
+        g_pt.stop(PT_STEP);
+        double newEnergy, newEnergyL, sID, sNID;
+        if ((rc = linearize_wait(e, &newEnergy, &newEnergyL, &sID, &sNID))) return rc;
         g_pt.stop(PT_LIN);
         const double newEnergyM = calc_M_energy(e);
         sumR /= nF; sumT /= nF;
@@ -1556,22 +1628,23 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             for (int i = 0; i < n && 7 + i < trace_stride; ++i) tr[7 + i] = x[i];
         }
         it = iteration + 1;
-        g_pt.start();
         if (accept) {
-            e->new_cur = 1 - e->new_cur;                                                  // the trial set becomes the current one
+            e->new_cur = 1 - e->new_cur;                                                  // the trial sets become the current ones
+            e->st_cur = st_trial;
             ef_select_new_set(e, e->new_cur, e->new_cur);
             if ((rc = sdvgn_ef_apply_res(e))) return rc;
             lastEnergy = newEnergy; lastEnergyL = newEnergyL; lastEnergyM = newEnergyM;
             lambda *= 0.25;
             prev_rejected_clean = false;
         } else {
-            // loadSateBackup: the idepths and the precalc table of the backed-up state are still in the copies the trial did not
-            // write -- swap back (no launch); the host-side frame / calib values are recomputed from the backup
+            // loadSateBackup: the idepths, the precalc table, the calib floats and the frame states of the backed-up state are still in
+            // the copies the trial did not write -- switch back (no launch); the host mirror is recomputed from the backup
             calib_set_value(e, e->value_backup);
             for (FrameH& f : e->frames) frame_set_state(f, f.state_backup);
             ef_refresh_frame_deltas(e);
             ef_swap_point_copies(e);
             std::swap(e->precalc_dev, e->precalc_alt);
+            e->A.calib = e->calib_dev + e->st_cur;
             // the reference also sets idepth_zero = idepth_backup here (FullSystemOptimize.cpp:276-277); the swapped-back copies
             // already satisfy that unless the window was loaded with idepth != idepth_zero and its very first step is rejected
             if (zero_differs && (rc = sdvgn_ef_point_step(e, 2, 0.f))) return rc;
@@ -1627,6 +1700,7 @@ int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_m
     nf.evalPT = nf.PRE_worldToCam;
     frame_set_state(nf, newStateZero);
     for (int i = 0; i < 10; ++i) nf.state_zero[i] = newStateZero[i];
+    e->win_dirty = e->state_dirty = true; e->sys_valid = false;   // evalPT / state / state_zero of the newest frame moved
     int rc;
     if ((rc = sdvgn_ef_set_adjoints(e))) return rc;
     if ((rc = ef_upload_precalc(e))) return rc;
@@ -1835,8 +1909,18 @@ int sdvgn_ef_get_state(sdvgn_ef* e, double* value_scaled4, double* state10, floa
 int sdvgn_ef_dim(sdvgn_ef* e) { return e ? CPARS + 6 * e->nF : SDVGN_E_ARG; }
 
 int sdvgn_ef_get_system(sdvgn_ef* e, double* HA, double* bA, double* Hsc, double* bsc, double* HFinal, double* bFinal) {
-    if (!e || e->HFinal.empty()) return SDVGN_E_STATE;
+    if (!e || (e->HFinal.empty() && !e->sys_on_device)) return SDVGN_E_STATE;
     const size_t n = CPARS + 6 * e->nF;
+    if (e->sys_on_device && !e->sys_fetched) {   // the last solve ran on the device: fetch its matrices once
+        EF_DEVICE(e);
+        std::vector<SolveSys> tmp(1);
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpy(tmp.data(), e->sys_dev, sizeof(SolveSys), hipMemcpyDeviceToHost));
+        e->HA.assign(tmp[0].HA, tmp[0].HA + n * n); e->bA.assign(tmp[0].bA, tmp[0].bA + n);
+        e->Hsc.assign(tmp[0].Hsc, tmp[0].Hsc + n * n); e->bsc.assign(tmp[0].bsc, tmp[0].bsc + n);
+        e->HFinal.assign(tmp[0].HFinal, tmp[0].HFinal + n * n); e->bFinal.assign(tmp[0].bFinal, tmp[0].bFinal + n);
+        e->sys_fetched = true;
+    }
     if (HA) std::memcpy(HA, e->HA.data(), 8 * n * n);
     if (bA) std::memcpy(bA, e->bA.data(), 8 * n);
     if (Hsc) std::memcpy(Hsc, e->Hsc.data(), 8 * n * n);

@@ -93,9 +93,25 @@ struct EFArrays {
     // because FullSystem::setNewFrameEnergyTH moves the newest frame's threshold after EVERY linearizeAll, FullSystemOptimize.cpp:63-97,122)
     const float* frameTH_r;
     float* frameTH_w;
+    // CalibHessian float views of the state the kernels work on, in device memory (written by the device-side step of the solve,
+    // backend_solve.inc); NULL: the values inside EFConst (host-driven entry points) are used
+    const struct CalibDev* calib;
     // diagnostics (SDVGN_DEBUG_FLAGS bit5): wall_clock64() stamps of k_ef_linearize's stages, [workgroup][wave][8]; NULL otherwise
     unsigned long long* dbg_stamps;
 };
+
+struct CalibDev { float fxl, fyl, cxl, cyl, fxli, fyli; float cDeltaF[4]; float pad[2]; };
+// the EFConst a kernel computes with: calibration floats from device memory when the window's state lives there
+__device__ __forceinline__ EFConst ef_const(const EFConst& Cin, const EFArrays& A) {
+    EFConst C = Cin;
+    if (A.calib) {
+        const CalibDev c = *A.calib;
+        C.fxl = c.fxl; C.fyl = c.fyl; C.cxl = c.cxl; C.cyl = c.cyl; C.fxli = c.fxli; C.fyli = c.fyli;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) C.cDeltaF[i] = c.cDeltaF[i];
+    }
+    return C;
+}
 
 // 64-lane double sum (for the energy), result valid in lane 63
 __device__ __forceinline__ double wave_sum_double(double v) {
@@ -276,8 +292,9 @@ __device__ __forceinline__ void lin_phase1(const EFConst& C, const EFArrays& A, 
 }
 
 template <bool STAMPS>
-__global__ void __launch_bounds__(256) k_ef_linearize(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+__global__ void __launch_bounds__(256) k_ef_linearize(EFConst Cin, EFArrays A, const PrecalcDev* __restrict__ precalc,
                                                        double* __restrict__ energy_partial) {
+    const EFConst C = ef_const(Cin, A);
     __shared__ double s_e[2];
     __shared__ float xch[2][9][64];
     int pair = blockIdx.y, chunk = blockIdx.x;
@@ -757,9 +774,10 @@ __device__ __forceinline__ void top_gram_body(const EFConst& C, const EFArrays& 
 
 // Stage 1 of the split accumulate: the top-Gram workgroups and the per-point (Hdd, bd, Hcd, HdiF) workgroups are independent, so
 // they share one launch (workgroups [0, n_top) = top Gram as (chunk, pair), the rest = 64 points each) and run side by side.
-__global__ void __launch_bounds__(256) k_ef_acc_stage1(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
+__global__ void __launch_bounds__(256) k_ef_acc_stage1(EFConst Cin, EFArrays A, const PrecalcDev* __restrict__ precalc,
                                                        const int* __restrict__ phost, float* __restrict__ top_partial,
                                                        int* __restrict__ nres_partial, int top_chunks, int n_top) {
+    const EFConst C = ef_const(Cin, A);
     __shared__ union U { TopGramSmem t; PointSmem p; __device__ U() {} } S;
     const int b = blockIdx.x;
     if (b < n_top) top_gram_body(C, A, precalc, top_partial, nres_partial, b % top_chunks, b / top_chunks, top_chunks, S.t);
@@ -994,6 +1012,18 @@ __global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__
     }
 }
 
+// one output of the packed accumulator buffer, summed exactly like k_ef_acc_reduce does it (same order on every path)
+__device__ __forceinline__ double reduce_top_output(const float* __restrict__ top_partial, int top_chunks, int e) {
+    const int g = e / 121, k = e - g * 121, r = k / 11, c = k - r * 11;
+    return sum_chunks_f64<256>(top_partial + (size_t)g * top_chunks * 256 + r * 16 + c, top_chunks);
+}
+__device__ __forceinline__ double reduce_sc_part(const float* __restrict__ sc_partial, int sc_chunks, const unsigned short* __restrict__ sc_off, int q, int part) {
+    const int g = q / 1431, k = q - g * 1431;
+    const int per = (sc_chunks + 3) >> 2;
+    const int c_lo = part * per, c_n = max(0, min(sc_chunks, c_lo + per) - c_lo);
+    return sum_chunks_f64<2560>(sc_partial + ((size_t)g * sc_chunks + c_lo) * 2560 + sc_off[k], c_n);
+}
+
 // Stage 2 of the split accumulate: workgroups [0, n_red) sum the top-Gram partials of stage 1 into the packed host buffer and
 // publish the "top part done" flag, the remaining sc_chunks * nF workgroups build the Schur Grams -- the host stitches the top
 // part while those still run.
@@ -1033,13 +1063,13 @@ __global__ void __launch_bounds__(256) k_ef_gram_reduce(const float* __restrict_
 // residual in target t, wave 0 subtracts the 8 terms in ascending target order.  Also does backupState for the point
 // (idepth_backup = idepth, FullSystemOptimize.cpp:300-305) and the per-block partial sums of step^2 and |idepth_backup|
 // that doStepFromBackup needs (:236-249).  xAd: [nF(host)][nF(target)][6] floats (index nF*h + t), xc: 4 floats.
-// The solution (xc and the nF*nF adjoint-transformed frame steps) travels in the kernel-argument segment: no H2D copy, the
-// values sit in scalar registers / the scalar cache.  step_fac >= 0 additionally performs doStepFromBackup for the point
+// The solution (xc and the nF*nF adjoint-transformed frame steps) is read from device memory, where the device-side solve
+// (backend_solve.inc) leaves it: the host need not have seen x when this kernel is launched.  step_fac >= 0 additionally performs doStepFromBackup for the point
 // (idepth = idepth_zero = backup + step_fac * step, FullSystemOptimize.cpp:236-249) -- the optimize loop always does both.
 struct ResubX { float xc[4]; float xAd[kMaxFrames * kMaxFrames * 6]; };
 
 __global__ void __launch_bounds__(512) k_ef_resubstitute(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
-                                                         const int* __restrict__ phost, const ResubX X, float* __restrict__ backup,
+                                                         const int* __restrict__ phost, const ResubX* __restrict__ Xp, float* __restrict__ backup,
                                                          double* __restrict__ stats_partial, float step_fac,
                                                          float* __restrict__ pid_w, float* __restrict__ pidz_w, float* __restrict__ pdeltaF_w,
                                                          int n_point_blocks, const unsigned long long* __restrict__ pc_src_pinned,
@@ -1073,7 +1103,7 @@ __global__ void __launch_bounds__(512) k_ef_resubstitute(EFConst C, EFArrays A, 
     }
     // one pass over the argument block into LDS (the per-lane host index below would otherwise turn every use into a
     // vector load from the kernel-argument segment)
-    if (threadIdx.x < 4 + kMaxFrames * kMaxFrames * 6) sx[threadIdx.x] = reinterpret_cast<const float*>(&X)[threadIdx.x];
+    if (threadIdx.x < 4 + kMaxFrames * kMaxFrames * 6) sx[threadIdx.x] = reinterpret_cast<const float*>(Xp)[threadIdx.x];
     __builtin_amdgcn_sched_barrier(0);
     const bool mine = inP && precalc[h * C.nF + h].np != 0;
     __syncthreads();
