@@ -281,6 +281,9 @@ int sdvgn_ef_apply_res(sdvgn_ef* ef);
  * (accumulateAF/LF/SCF, HM/bM, damped Jacobi-preconditioned LDLT, orthogonalize for iteration >= 2, resubstitute).
  * x_out[4+6nF] = lastX; frame/calib steps are -x, point steps stay on the device (sdvgn_ef_get_points). */
 int sdvgn_ef_solve_system(sdvgn_ef* ef, int iteration, double lambda, double* x_out);
+/* 1 if a pivot of the last device-side LDL^T was not positive / finite (x was set to 0: the caller's energy test rejects the step), else 0.
+ * The reference's `HFinalScaled.ldlt().solve()` (EnergyFunctional.cpp:743) has no failure path either. */
+int sdvgn_ef_get_solve_status(sdvgn_ef* ef);
 /* doStepFromBackup / backupState / loadSateBackup for the per-point idepths (FullSystemOptimize.cpp:165-321):
  * mode 0: backup = idepth; mode 1: idepth = idepth_zero = backup + stepfac*step; mode 2: idepth = idepth_zero = backup */
 int sdvgn_ef_point_step(sdvgn_ef* ef, int mode, float stepfacD);
@@ -343,6 +346,8 @@ int sdvgn_ef_get_iteration_times(sdvgn_ef* ef, double* us, int cap);
 /* Diagnostics (SDVGN_PROFILE=1 in the environment when the library is loaded): prints the accumulated host wall time per phase
  * of the solve / optimize path to stderr, divided by `per`, and clears the counters.  Returns 1 if a report was printed, else 0. */
 int sdvgn_debug_phase_report(int per);
+/* SDVGN_DEBUG_FLAGS bit 6: wall_clock64() (100 MHz) stamps of the phases of the last device-side small solve; returns the word count (16) */
+int sdvgn_debug_solve_stamps(sdvgn_ef* ef, unsigned long long* out16);
 /* Diagnostics (SDVGN_DEBUG_FLAGS bit5 = 32 set when the handle is created): wall_clock64() stamps (10 ns) of k_ef_linearize's stages
  * from the last launch, [workgroup][wave][8] 64-bit words (tools/exp_linearize_stages.py).  Returns the number of words copied, 0 if the diagnostics are off. */
 int sdvgn_debug_read_stamps(sdvgn_ef* ef, unsigned long long* out, int cap_words);

@@ -43,6 +43,8 @@ PROTOTYPES = [
     ("sdvgn_ef_marginalize_frame", C.c_int, [vp, C.c_int, vp, vp]),
     ("sdvgn_ef_get_res_toZero", C.c_int, [vp, vp, vp]),
     ("sdvgn_debug_read_stamps", C.c_int, [vp, vp, C.c_int]),
+    ("sdvgn_debug_solve_stamps", C.c_int, [vp, vp]),
+    ("sdvgn_ef_get_solve_status", C.c_int, [vp]),
     ("sdvgn_ef_frame_image_dev", vp, [vp, C.c_int]),
     ("sdvgn_rccl_unique_id", C.c_int, [vp]),
     ("sdvgn_ef_init_rccl", C.c_int, [vp, vp, C.c_int, C.c_int]),

@@ -111,7 +111,9 @@ struct sdvgn_ef {
     ResubX* rx_dev = nullptr;              // xc, xAd of the last solve (k_ef_resubstitute reads them)
     SolveSys* sys_dev = nullptr;           // HA, bA, Hsc, bsc, HFinal, bFinal of the last solve
     SolveOut* sol_host = nullptr;          // pinned: x, step statistics, resInA, status
-    unsigned* solve_ctr = nullptr;         // arrival counter of k_ef_reduce_solve
+    SolvePieces* pieces_dev = nullptr;     // [SDVGN_MAX_FRAMES]: per-host shares of HA / bA / Hsc / bsc
+    unsigned long long* solve_stamps = nullptr;   // pinned, 16 words: SDVGN_DEBUG_FLAGS bit6 only (phase stamps of the solve workgroup)
+    int solve_status = 0;                  // status of the last device solve: 1 = a pivot of the LDL^T was not positive / finite (x = 0)
     int seq_solve = 0;                     // flags_host[3]
     bool sys_on_device = false, sys_fetched = false, sys_valid = false;
     void* fin_dev = nullptr;       // outputs of sdvgn_ef_optimize_finish (relbs_max, ngood_inc, removed), grown on demand
@@ -496,6 +498,14 @@ static int ef_sync_window(sdvgn_ef* e) {
         std::memcpy(W.adTargetF, e->adTargetF.data(), sizeof(float) * (size_t)nF * nF * 36);
     }
     for (int i = 0; i < 4; ++i) { W.cPrior[i] = e->cPrior[i]; W.value_zero[i] = e->value_zero[i]; }
+    for (int h = 0; h < nF; ++h)
+        for (int t = 0; t < nF; ++t) {      // PRE_RTll_0 / PRE_tTll_0 (HessianBlocks.cpp:171-175), the same expressions as ef_upload_precalc
+            double R[9];
+            const gn::Pose l0 = gn::compose(e->frames[t].evalPT, gn::inverse(e->frames[h].evalPT));
+            gn::rotation_matrix(l0.q, R);
+            for (int i = 0; i < 9; ++i) W.l0[h * nF + t][i] = (float)R[i];
+            for (int i = 0; i < 3; ++i) W.l0[h * nF + t][9 + i] = (float)l0.t[i];
+        }
     for (int h = 0; h < nF; ++h) {
         const FrameH& f = e->frames[h];
         gn::pose_store(f.evalPT, W.fr[h].evalPT);
@@ -852,6 +862,10 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
         bad |= dev_alloc(&e->dbg_stamps, kDbgStampWords);
         if (!bad) hipMemset(e->dbg_stamps, 0, sizeof(unsigned long long) * kDbgStampWords);
     }
+    if (getenv("SDVGN_DEBUG_FLAGS") && (atoi(getenv("SDVGN_DEBUG_FLAGS")) & 64)) {
+        bad |= hipHostMalloc((void**)&e->solve_stamps, sizeof(unsigned long long) * 16) != hipSuccess;
+        if (!bad) std::memset(e->solve_stamps, 0, sizeof(unsigned long long) * 16);
+    }
     bad |= dev_alloc(&e->energy_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * 2);
     bad |= dev_alloc(&e->top_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * kTopP);
     bad |= dev_alloc(&e->sc_partial, (size_t)SDVGN_MAX_FRAMES * kMaxChunks * kScP);
@@ -864,7 +878,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->stats_dev, e->stats_cap) | dev_alloc(&e->stats_partial, 3 * (mp / 64 + 2));
     bad |= dev_alloc(&e->th_dev, 2 * SDVGN_MAX_FRAMES);
     bad |= dev_alloc(&e->win_dev, 1) | dev_alloc(&e->sstate_dev, 2) | dev_alloc(&e->calib_dev, 2) | dev_alloc(&e->rx_dev, 1) | dev_alloc(&e->sys_dev, 1);
-    bad |= dev_alloc(&e->solve_ctr, 1);
+    bad |= dev_alloc(&e->pieces_dev, SDVGN_MAX_FRAMES);
     if (bad) { sdvgn_ef_destroy(e); return -(int)hipErrorOutOfMemory; }
     HIPCHK(hipHostMalloc(&e->precalc_host, 2 * sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
     HIPCHK(hipHostMalloc(&e->acc_host, sizeof(double) * accmax));
@@ -876,7 +890,6 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     HIPCHK(hipHostMalloc((void**)&e->calib_host, sizeof(CalibDev)));
     HIPCHK(hipHostMalloc((void**)&e->sol_host, sizeof(SolveOut)));
     std::memset(e->sol_host, 0, sizeof(SolveOut));
-    HIPCHK(hipMemset(e->solve_ctr, 0, sizeof(unsigned)));
     HIPCHK(hipMemset(e->rx_dev, 0, sizeof(ResubX)));
     e->flags_host[0] = e->flags_host[1] = e->flags_host[2] = e->flags_host[3] = 0;
     HIPCHK(hipMalloc((void**)&e->done_ctr, 2 * sizeof(unsigned)));
@@ -916,7 +929,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
                     e->stats_dev, e->stats_partial, e->sc_off_dev, e->imm_pc_dev, e->rstate_new2, e->renergy_new2, e->renergy_wo2,
                     e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->precalc_alt, e->dbg_stamps, e->marg_mask_dev, e->drop_mask_dev, e->th_dev, e->fin_dev,
-                    e->win_dev, e->sstate_dev, e->calib_dev, e->rx_dev, e->sys_dev, e->solve_ctr};
+                    e->win_dev, e->sstate_dev, e->calib_dev, e->rx_dev, e->sys_dev, e->pieces_dev};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->precalc_host) hipHostFree(e->precalc_host);
     if (e->acc_host) hipHostFree(e->acc_host);
@@ -927,6 +940,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
     if (e->sstate_host) hipHostFree(e->sstate_host);
     if (e->calib_host) hipHostFree(e->calib_host);
     if (e->sol_host) hipHostFree(e->sol_host);
+    if (e->solve_stamps) hipHostFree(e->solve_stamps);
     if (e->done_ctr) hipFree(e->done_ctr);
     if (e->imm_pc_host) hipHostFree(e->imm_pc_host);
     if (e->imm_stage) hipHostFree(e->imm_stage);
@@ -1216,7 +1230,7 @@ int sdvgn_ef_apply_res(sdvgn_ef* e) {
 
 // The accumulate kernels of one solveSystemF: [top Gram | per-point sums], [Schur Gram]; their per-workgroup partial tiles are
 // reduced either by k_ef_acc_reduce (with_reduce: packed buffer in acc_dev, the form the all-reduce of a sharded window needs) or by
-// the caller's k_ef_reduce_solve, whose last workgroup continues with the solve.
+// left as partial tiles.
 struct AccGeom { int pairs, chunks, sc_chunks, sc_ppb, ntop, nsc; };
 static AccGeom ef_acc_geom(const sdvgn_ef* e) {
     AccGeom g;
@@ -1238,8 +1252,7 @@ static int ef_accumulate(sdvgn_ef* e, bool with_reduce) {
     k_ef_acc_stage1<<<n_top + n_pt, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, n_top);
     k_ef_sc_gram<<<dim3(g.sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, g.sc_ppb);
     if (with_reduce)
-        k_ef_acc_reduce<<<acc_reduce_grid(0, g.ntop + g.nsc, g.ntop, g.nsc, 1), 256, 0, e->stream>>>(e->top_partial, g.pairs, g.chunks, e->sc_partial, nF, g.sc_chunks,
-                                                                                     e->nres_partial, e->sc_off_dev, e->acc_dev, 0, g.ntop + g.nsc, 1, nullptr, nullptr, 0);
+        k_ef_acc_reduce<<<acc_reduce_grid(g.pairs, nF), 256, 0, e->stream>>>(e->top_partial, g.pairs, g.chunks, e->sc_partial, nF, g.sc_chunks, e->nres_partial, e->acc_dev);
     e->acc_in_host = false;
     HIPCHK(hipGetLastError());
     return SDVGN_OK;
@@ -1401,37 +1414,36 @@ static void calib_set_value(sdvgn_ef* e, const double* v);
 
 // ---- the device-resident solve ------------------------------------------------------------------------------------------------------
 static void ef_fill_solve_io(sdvgn_ef* e, SolveIO& io, int iteration, double lambda, bool do_step, float stepsize, bool reuse) {
-    io.acc = e->acc_dev; io.W = e->win_dev;
+    io.acc = e->acc_dev;
+    io.pieces = e->pieces_dev;
+    io.W = e->win_dev;
     io.cur = e->sstate_dev + e->st_cur; io.trial = e->sstate_dev + (1 - e->st_cur);
     io.calib_cur = e->calib_dev + e->st_cur; io.calib_trial = e->calib_dev + (1 - e->st_cur);
     io.pc_cur = e->precalc_dev; io.pc_trial = e->precalc_alt;
     io.rx = e->rx_dev; io.sys = e->sys_dev; io.out = e->sol_host;
     io.done_flag = e->flags_host + 3; io.done_seq = ++e->seq_solve;
     io.lambda = lambda; io.iteration = iteration; io.do_step = do_step ? 1 : 0; io.reuse = reuse ? 1 : 0; io.stepsize = stepsize;
+    io.stamps = e->solve_stamps;
 }
-// solveSystemF on the device, all launches asynchronous: accumulate (unless the stitched system of the previous body is re-used),
-// reduce + stitch + LDL^T + null-space projection (+ the calib / frame part of doStepFromBackup and the precalc table of the stepped
-// state when do_step), then resubstituteF (+ the point part of doStepFromBackup when step_fac >= 0).  x reaches the host through
-// pinned memory; ef_wait_solve fetches it.
+// solveSystemF on the device, all launches asynchronous: accumulate + reduce (unless the stitched system of the previous body is
+// re-used), per-host stitch, then the one-workgroup tail: LDL^T + null-space projection (+ the calib / frame part of doStepFromBackup
+// and the precalc table of the stepped state when do_step), then resubstituteF (+ the point part of doStepFromBackup when
+// step_fac >= 0).  x reaches the host through pinned memory; ef_wait_solve fetches it.
 static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_step, float step_fac, bool reuse, bool accumulated) {
     int rc;
     if ((rc = ef_sync_window(e)) || (rc = ef_sync_state(e))) return rc;
     const int nF = e->nF;
     SolveIO io;
     ef_fill_solve_io(e, io, iteration, lambda, do_step, do_step ? step_fac : 0.0f, reuse);
-    if (reuse) {
-        k_ef_solve<<<1, kSolveLanes, 0, e->stream>>>(io);
-    } else if (ef_sharded(e) || accumulated) {
-        // sharded window: the packed buffer of every rank is summed first (ONE all-reduce per GN iteration), then every rank solves
-        if (!accumulated && (rc = ef_accumulate(e, /*with_reduce=*/true))) return rc;
-        if (!accumulated && (rc = ef_allreduce(e, e->acc_dev, (int)acc_count(e)))) return rc;
-        k_ef_solve<<<1, kSolveLanes, 0, e->stream>>>(io);
-    } else {
-        if ((rc = ef_accumulate(e, /*with_reduce=*/false))) return rc;
-        const AccGeom g = ef_acc_geom(e);
-        k_ef_reduce_solve<<<reduce_solve_grid(g.pairs, nF), kSolveLanes, 0, e->stream>>>(e->top_partial, g.pairs, g.chunks, e->sc_partial, nF, g.sc_chunks,
-                                                                                         e->nres_partial, e->sc_off_dev, e->acc_dev, e->solve_ctr, io);
+    if (!reuse) {
+        if (!accumulated) {
+            if ((rc = ef_accumulate(e, /*with_reduce=*/true))) return rc;
+            // sharded window: the packed buffer of every rank is summed (ONE all-reduce per GN iteration), then every rank stitches and solves
+            if (ef_sharded(e) && (rc = ef_allreduce(e, e->acc_dev, (int)acc_count(e)))) return rc;
+        }
+        k_ef_stitch<<<nF, kSolveLanes, 0, e->stream>>>(io);
     }
+    k_ef_solve_tail<<<1, kSolveLanes, 0, e->stream>>>(io);
     HIPCHK(hipGetLastError());
     const int nblk = (e->nP + 63) / 64;
     k_ef_resubstitute<<<nblk, 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->rx_dev, e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2),
@@ -1446,7 +1458,10 @@ static int ef_wait_solve(sdvgn_ef* e, double* x_out) {
     e->lastX.assign(e->sol_host->x, e->sol_host->x + n);
     e->resInA = e->sol_host->resInA;
     if (x_out) std::memcpy(x_out, e->lastX.data(), sizeof(double) * n);
-    return e->sol_host->status ? SDVGN_E_STATE : SDVGN_OK;
+    // a non-positive / non-finite pivot is not an error of the call: like Eigen's ldlt().solve() on such a system the step is simply
+    // useless (here x = 0, the energy test rejects it and lambda grows); the condition can be queried (sdvgn_ef_get_solve_status)
+    e->solve_status = e->sol_host->status;
+    return SDVGN_OK;
 }
 
 int sdvgn_ef_finish_solve(sdvgn_ef* e, int iteration, double lambda, double* x_out) {
@@ -1777,8 +1792,7 @@ int sdvgn_ef_marginalize_points(sdvgn_ef* e, const unsigned char* marg, const un
     k_ef_marg_stage1<<<n_top + n_pt, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, chunks, n_top,
                                                           e->marg_mask_dev, e->ppriorF);
     k_ef_marg_sc_gram<<<dim3(sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, sc_ppb, e->marg_mask_dev);
-    k_ef_acc_reduce<<<acc_reduce_grid(0, ntop + nsc, ntop, nsc, 1), 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks, e->nres_partial,
-                                                                         e->sc_off_dev, e->acc_dev, 0, ntop + nsc, 1, nullptr, nullptr, 0);
+    k_ef_acc_reduce<<<acc_reduce_grid(pairs, nF), 256, 0, e->stream>>>(e->top_partial, pairs, chunks, e->sc_partial, nF, sc_chunks, e->nres_partial, e->acc_dev);
     k_ef_remove_points<<<(unsigned)(((size_t)nF * e->nP + 255) / 256), 256, 0, e->stream>>>(nF, e->nP, e->rflags, e->marg_mask_dev, drop ? e->drop_mask_dev : nullptr);
     HIPCHK(hipGetLastError());
     const int na = (int)acc_count(e);
@@ -1878,6 +1892,15 @@ int sdvgn_debug_read_stamps(sdvgn_ef* e, unsigned long long* out, int cap_words)
     return n;
 }
 
+int sdvgn_ef_get_solve_status(sdvgn_ef* e) { return e ? e->solve_status : SDVGN_E_ARG; }
+
+int sdvgn_debug_solve_stamps(sdvgn_ef* e, unsigned long long* out16) {
+    if (!e || !out16 || !e->solve_stamps) return 0;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return SDVGN_E_NODEVICE;
+    std::memcpy(out16, e->solve_stamps, sizeof(unsigned long long) * 16);
+    return 16;
+}
+
 int sdvgn_debug_phase_report(int per) {
     if (!g_pt.on || per < 1) return 0;
     fprintf(stderr, "[sdvgn profile] %d iterations\n", per);
@@ -1911,14 +1934,31 @@ int sdvgn_ef_dim(sdvgn_ef* e) { return e ? CPARS + 6 * e->nF : SDVGN_E_ARG; }
 int sdvgn_ef_get_system(sdvgn_ef* e, double* HA, double* bA, double* Hsc, double* bsc, double* HFinal, double* bFinal) {
     if (!e || (e->HFinal.empty() && !e->sys_on_device)) return SDVGN_E_STATE;
     const size_t n = CPARS + 6 * e->nF;
-    if (e->sys_on_device && !e->sys_fetched) {   // the last solve ran on the device: fetch its matrices once
+    if (e->sys_on_device && !e->sys_fetched) {   // the last solve ran on the device: fetch its system and sum the per-host shares once
         EF_DEVICE(e);
         std::vector<SolveSys> tmp(1);
+        std::vector<SolvePieces> pc(e->nF);
         HIPCHK(hipStreamSynchronize(e->stream));
         HIPCHK(hipMemcpy(tmp.data(), e->sys_dev, sizeof(SolveSys), hipMemcpyDeviceToHost));
-        e->HA.assign(tmp[0].HA, tmp[0].HA + n * n); e->bA.assign(tmp[0].bA, tmp[0].bA + n);
-        e->Hsc.assign(tmp[0].Hsc, tmp[0].Hsc + n * n); e->bsc.assign(tmp[0].bsc, tmp[0].bsc + n);
-        e->HFinal.assign(tmp[0].HFinal, tmp[0].HFinal + n * n); e->bFinal.assign(tmp[0].bFinal, tmp[0].bFinal + n);
+        HIPCHK(hipMemcpy(pc.data(), e->pieces_dev, sizeof(SolvePieces) * e->nF, hipMemcpyDeviceToHost));
+        e->HA.assign(n * n, 0); e->bA.assign(n, 0); e->Hsc.assign(n * n, 0); e->bsc.assign(n, 0);
+        e->HFinal.assign(n * n, 0); e->bFinal.assign(n, 0);
+        auto tri = [](size_t i, size_t j) { return i * (i + 1) / 2 + j; };    // packed lower triangle, the rhs as row n
+        for (size_t i = 0; i < n; ++i) {
+            for (size_t j = 0; j <= i; ++j) {
+                double ha = 0, hs = 0;
+                for (int h = 0; h < e->nF; ++h) { ha += pc[h].CA[tri(i, j)]; hs += pc[h].CS[tri(i, j)]; }
+                if (i == j) ha += i < CPARS ? e->cPrior[i] : e->frames[(i - CPARS) / 6].prior[(i - CPARS) % 6];
+                e->HA[i * n + j] = e->HA[j * n + i] = ha;
+                e->Hsc[i * n + j] = e->Hsc[j * n + i] = hs;
+                e->HFinal[i * n + j] = e->HFinal[j * n + i] = tmp[0].tri[tri(i, j)];
+            }
+            double ba = 0, bs = 0;
+            for (int h = 0; h < e->nF; ++h) { ba += pc[h].CA[tri(n, i)]; bs += pc[h].CS[tri(n, i)]; }
+            e->bA[i] = ba + tmp[0].bprior[i];
+            e->bsc[i] = bs;
+            e->bFinal[i] = tmp[0].tri[tri(n, i)];
+        }
         e->sys_fetched = true;
     }
     if (HA) std::memcpy(HA, e->HA.data(), 8 * n * n);

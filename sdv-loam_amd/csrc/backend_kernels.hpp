@@ -809,8 +809,11 @@ __device__ __forceinline__ void sc_gram_wave(const EFConst& C, const EFArrays& A
     float stage_w = 0.0f;
     auto fetch = [&](int base) {   // features WAVE*16 .. WAVE*16+15 of point base+lane
         const int pl = base + lane;
-        const bool in = pl < end;
+        bool in = pl < end;
         const int p = P0 + (in ? pl : 0);
+        // MODE 2: a point outside the mask has weight 0, and its Hcd / bdSum planes may never have been written (0 * NaN = NaN on the
+        // matrix cores): its whole feature row is zero
+        if (MODE == 2) in = in && mask[p] != 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             constexpr int f0 = WAVE * 16;
@@ -937,36 +940,71 @@ __global__ void __launch_bounds__(256) k_ef_remove_points(int nF, int nP, uint8_
     if (marg[p] || (drop && drop[p])) rflags[s] = 0;
 }
 
-// Fixed-order fp64 sum of the per-workgroup partials into the PACKED accumulator buffer, all three parts in one launch:
-// top Gram [pairs][121] (the live 11x11), SC Gram [nF][1431] (upper triangle of the live 53x53), resInA.
-// The partial loads of one output are issued in batches of 8 independent loads (one memory round trip per batch instead of
-// one per chunk); the packed-triangle -> tile offset comes from a table built once on the host (sc_off[1431]).
-// grid = acc_reduce_grid(...) (the last workgroup sums the integer residual counters if do_nres).
-template <int STRIDE, int BATCH = 8>
-__device__ __forceinline__ double sum_chunks_f64(const float* __restrict__ base, int chunks) {
-    double s = 0;
-    for (int c0 = 0; c0 < chunks; c0 += BATCH) {   // BATCH independent loads per memory round trip; the sum order is c = 0, 1, 2, ...
-        float v[BATCH];
+// Fixed-order fp64 sum of the per-workgroup partial Gram tiles into the PACKED accumulator buffer, all three parts in one launch and one
+// memory round trip: top Gram [pairs][121] (the live 11x11), SC Gram [nF][1431] (upper triangle of the live 53x53), resInA.
+// Every task sums four adjacent columns of one tile row with 16-byte buffer loads (the chunk stride in the SCALAR offset: one per-lane
+// offset register for all loads in flight), all loads first, then the running sums in chunk order:
+//   top: task = (pair, row r of 11, column group g of 3), chunks 0 .. top_chunks-1 in order
+//   SC : task = (host, tile A of 10, row r of 16, column group g of 4, part p of 4); part p sums chunks [p*per, (p+1)*per), per =
+//        ceil(sc_chunks / 4), and four neighbouring lanes combine (p0 + p1) + (p2 + p3) -- a fixed order, the same on every path.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int PM>
+__device__ __forceinline__ void sum4_chunks_f64(__amdgpu_buffer_rsrc_t rsrc, int voff, int chunk_bytes, int c0, int cn, int c_last, double* acc4) {
+    u32x4 v[PM];
 #pragma unroll
-        for (int j = 0; j < BATCH; ++j) v[j] = (c0 + j < chunks) ? base[(size_t)(c0 + j) * STRIDE] : 0.0f;
+    for (int j = 0; j < PM; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, min(c0 + j, c_last) * chunk_bytes, 0);
 #pragma unroll
-        for (int j = 0; j < BATCH; ++j) s += (double)v[j];   // + 0.0 for the absent chunks is exact
-    }
-    return s;
+    for (int j = 0; j < PM; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc4[i] += (j < cn) ? (double)__uint_as_float(v[j][i]) : 0.0;   // + 0.0 for the absent chunks is exact
 }
-// grid of k_ef_acc_reduce for the output range [e_begin, e_end): one thread per top output, four per Schur output, + the resInA workgroup
-static inline int acc_reduce_grid(int e_begin, int e_end, int ntop, int nsc, int do_nres) {
-    const int n_top = std::max(0, std::min(e_end, ntop) - std::min(e_begin, ntop));
-    const int n_sc = std::max(0, std::min(e_end, ntop + nsc) - std::max(e_begin, ntop));
-    return (n_top + 255) / 256 + (4 * n_sc + 255) / 256 + (do_nres ? 1 : 0);
-}
+__device__ __forceinline__ int sc_packed_index(int a, int b) { return a * 53 - (a * (a - 1)) / 2 + (b - a); }   // upper triangle, a <= b
+
+constexpr int kScTasksPerHost = 10 * 16 * 4 * 4;   // 2560
+static inline int acc_reduce_grid(int pairs, int nF) { return (nF * kScTasksPerHost) / 256 + (pairs * 33 + 255) / 256 + 1; }
 __global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__ top_partial, int pairs, int top_chunks,
                                                        const float* __restrict__ sc_partial, int nF, int sc_chunks,
-                                                       const int* __restrict__ nres_partial, const unsigned short* __restrict__ sc_off,
-                                                       double* __restrict__ out, int e_begin, int e_end, int do_nres,
-                                                       unsigned* __restrict__ done_ctr, volatile int* done_flag, int done_seq) {
+                                                       const int* __restrict__ nres_partial, double* __restrict__ out) {
     const int ntop = pairs * 121, nsc = nF * 1431;
-    if (do_nres && blockIdx.x == gridDim.x - 1) {   // resInA: integer sum, order-free
+    const int nb_sc = (nF * kScTasksPerHost) / 256, nb_top = (pairs * 33 + 255) / 256;
+    const int b = blockIdx.x;
+    if (b < nb_sc) {
+        const int u = b * 256 + threadIdx.x;
+        const int h = u / kScTasksPerHost, uu = u - h * kScTasksPerHost;      // wave-uniform: 2560 % 256 == 0
+        const int pq = uu & 3, g = (uu >> 2) & 3, r = (uu >> 4) & 15, A = uu >> 8;
+        const float* hb = sc_partial + (size_t)__builtin_amdgcn_readfirstlane(h) * sc_chunks * 2560;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hb), 0, sc_chunks * 10240, 0x00020000);
+        const int per = (sc_chunks + 3) >> 2;
+        const int c_lo = pq * per, c_n = max(0, min(sc_chunks, c_lo + per) - c_lo);
+        const int voff = 4 * (A * 256 + r * 16 + 4 * g);
+        double s4[4] = {0, 0, 0, 0};
+        if (per <= 8) sum4_chunks_f64<8>(rsrc, voff, 10240, c_lo, c_n, sc_chunks - 1, s4);
+        else sum4_chunks_f64<16>(rsrc, voff, 10240, c_lo, c_n, sc_chunks - 1, s4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s4[i] += __shfl_down(s4[i], 1); s4[i] += __shfl_down(s4[i], 2); }
+        if (pq == 0) {
+            const int ti = A < 4 ? 0 : (A < 7 ? 1 : (A < 9 ? 2 : 3)), tj = A < 4 ? A : (A < 7 ? A - 3 : (A < 9 ? A - 5 : 3));
+            const int a = ti * 16 + r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = tj * 16 + 4 * g + i;
+                if (a <= c && c < 53) out[(size_t)ntop + (size_t)h * 1431 + sc_packed_index(a, c)] = s4[i];
+            }
+        }
+    } else if (b < nb_sc + nb_top) {
+        const int u = (b - nb_sc) * 256 + threadIdx.x;
+        const bool on = u < pairs * 33;
+        const int uu = on ? u : 0;
+        const int pair = uu / 33, e = uu - pair * 33, r = e / 3, g = e - r * 3;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(top_partial), 0, pairs * top_chunks * 1024, 0x00020000);
+        const int voff = 4 * (pair * top_chunks * 256 + r * 16 + 4 * g);
+        double s4[4] = {0, 0, 0, 0};
+        for (int c0 = 0; c0 < top_chunks; c0 += 16) sum4_chunks_f64<16>(rsrc, voff, 1024, c0, on ? min(16, top_chunks - c0) : 0, top_chunks - 1, s4);
+        if (on) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int c = 4 * g + i; if (c < 11) out[(size_t)pair * 121 + r * 11 + c] = s4[i]; }
+        }
+    } else {   // resInA: integer sum, order-free
         __shared__ int part[4];
         int n = 0;
         for (int i = threadIdx.x; i < pairs * top_chunks; i += 256) n += nres_partial[i];
@@ -974,88 +1012,7 @@ __global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__
         for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
         if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            out[ntop + nsc] = (double)(part[0] + part[1] + part[2] + part[3]);
-            if (done_flag) publish_when_all_done(done_ctr, gridDim.x, done_flag, done_seq);
-        }
-        return;
-    }
-    // outputs [e_begin, e_end) of the packed buffer.  Workgroups [0, nb_top) take the top outputs of the range one per thread; the
-    // following workgroups take the Schur outputs FOUR lanes per output: lane part p sums chunks [p*q, (p+1)*q) in order, q =
-    // ceil(sc_chunks / 4), and the four partial sums are combined as (p0 + p1) + (p2 + p3) -- a fixed order, the same on every path.
-    const int top_lo = min(e_begin, ntop), top_hi = min(e_end, ntop);
-    const int nb_top = (top_hi - top_lo + 255) / 256;
-    if ((int)blockIdx.x < nb_top) {
-        const int e = top_lo + blockIdx.x * 256 + threadIdx.x;
-        if (e < top_hi) {
-            const int g = e / 121, k = e - g * 121, r = k / 11, c = k - r * 11;
-            out[e] = sum_chunks_f64<256>(top_partial + (size_t)g * top_chunks * 256 + r * 16 + c, top_chunks);
-        }
-    } else {
-        const int sc_lo = max(e_begin, ntop), sc_hi = min(e_end, ntop + nsc);
-        const int v = (blockIdx.x - nb_top) * 256 + threadIdx.x;
-        const int e = sc_lo + (v >> 2), part = v & 3;
-        const int per = (sc_chunks + 3) >> 2;
-        double s = 0;
-        if (e < sc_hi) {
-            const int q = e - ntop, g = q / 1431, k = q - g * 1431;
-            const int c_lo = part * per, c_n = max(0, min(sc_chunks, c_lo + per) - c_lo);
-            s = sum_chunks_f64<2560>(sc_partial + ((size_t)g * sc_chunks + c_lo) * 2560 + sc_off[k], c_n);
-        }
-        s += __shfl_down(s, 1);     // parts 0+1 in lane 4i, 2+3 in lane 4i+2
-        s += __shfl_down(s, 2);     // (0+1) + (2+3) in lane 4i
-        if (e < sc_hi && part == 0) out[e] = s;
-    }
-    if (done_flag) {   // completion signal for the host (waitflag.hpp): all workgroups of this launch have stored their outputs
-        __syncthreads();
-        if (threadIdx.x == 0) publish_when_all_done(done_ctr, gridDim.x, done_flag, done_seq);
-    }
-}
-
-// one output of the packed accumulator buffer, summed exactly like k_ef_acc_reduce does it (same order on every path)
-__device__ __forceinline__ double reduce_top_output(const float* __restrict__ top_partial, int top_chunks, int e) {
-    const int g = e / 121, k = e - g * 121, r = k / 11, c = k - r * 11;
-    return sum_chunks_f64<256>(top_partial + (size_t)g * top_chunks * 256 + r * 16 + c, top_chunks);
-}
-__device__ __forceinline__ double reduce_sc_part(const float* __restrict__ sc_partial, int sc_chunks, const unsigned short* __restrict__ sc_off, int q, int part) {
-    const int g = q / 1431, k = q - g * 1431;
-    const int per = (sc_chunks + 3) >> 2;
-    const int c_lo = part * per, c_n = max(0, min(sc_chunks, c_lo + per) - c_lo);
-    return sum_chunks_f64<2560>(sc_partial + ((size_t)g * sc_chunks + c_lo) * 2560 + sc_off[k], c_n);
-}
-
-// Stage 2 of the split accumulate: workgroups [0, n_red) sum the top-Gram partials of stage 1 into the packed host buffer and
-// publish the "top part done" flag, the remaining sc_chunks * nF workgroups build the Schur Grams -- the host stitches the top
-// part while those still run.
-__global__ void __launch_bounds__(256) k_ef_acc_stage2(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
-                                                       float* __restrict__ sc_partial, int pts_per_block, int sc_chunks,
-                                                       const float* __restrict__ top_partial, int pairs, int top_chunks,
-                                                       double* __restrict__ out, int n_red, unsigned* __restrict__ done_ctr,
-                                                       volatile int* done_flag, int done_seq) {
-    __shared__ ScGramSmem S;
-    const int b = blockIdx.x;
-    if (b < n_red) {
-        const int e = b * 256 + threadIdx.x;
-        if (e < pairs * 121) {
-            const int g = e / 121, k = e - g * 121, r = k / 11, c = k - r * 11;
-            out[e] = sum_chunks_f64<256>(top_partial + (size_t)g * top_chunks * 256 + r * 16 + c, top_chunks);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) publish_when_all_done(done_ctr, n_red, done_flag, done_seq);
-        return;
-    }
-    const int q = b - n_red;
-    sc_gram_body(C, A, precalc, sc_partial, pts_per_block, q % sc_chunks, q / sc_chunks, sc_chunks, S);
-}
-
-// out[g][e] = sum over chunks of partial[g][chunk][e] in fp64, fixed order.  grid = groups, block = 256, E elements.
-__global__ void __launch_bounds__(256) k_ef_gram_reduce(const float* __restrict__ partial, int chunks, int E,
-                                                        double* __restrict__ out) {
-    const int g = blockIdx.x;
-    for (int e = threadIdx.x; e < E; e += blockDim.x) {
-        double s = 0;
-        for (int c = 0; c < chunks; ++c) s += (double)partial[((size_t)g * chunks + c) * E + e];
-        out[(size_t)g * E + e] = s;
+        if (threadIdx.x == 0) out[ntop + nsc] = (double)(part[0] + part[1] + part[2] + part[3]);
     }
 }
 
