@@ -8,7 +8,9 @@ one step = one body of the FullSystem::optimize loop (FullSystemOptimize.cpp:395
 1241x376 window of 8 key-frames x 2000 points = 112 000 residuals:
     backupState -> solveSystemF (accumulate A/L/SC, stitch, (4+6*8)^2 LDLT, resubstitute) -> doStepFromBackup
     -> linearizeAll -> accept (applyRes) | reject (loadSateBackup + re-linearise)
-Window images, points and residual tables are resident in HBM before the timed region.
+Protocol: the K steps are ceil(K/6) FullSystem::optimize calls of 6 loop bodies (the reference's iteration count per key-frame), each
+on its own freshly loaded, perturbed window (mixed accepted / rejected steps) -- the protocol the cpu_baseline leg runs on the host.
+All windows (images, points, residual tables) are resident in HBM before the one timed region starts.
 Extra fields report the coarse tracker (configs[1]) and the roofline of the dominant kernel.
 Rank 0 prints ONE JSON line.
 """
@@ -138,8 +140,8 @@ def cpu_baseline_backend(W, budget_s=12.0):
     its6, tt6, _ = run(6, budget_s * 0.25)
     return dict(value=its / tt, unit="GN iters/s", cores=1, kind="port",
                 ms_per_body=dict(median=float(np.median(pb)), p10=float(np.percentile(pb, 10)), p90=float(np.percentile(pb, 90)), calls=len(pb)),
-                sample="%d optimize-loop bodies (8 KF x 2000 pts, 112000 residuals) in %.1f s on 1 host thread; "
-                       "host has %d logical CPUs" % (its, tt, os.cpu_count()),
+                sample="%d optimize-loop bodies (8 KF x 2000 pts, 112000 residuals; the headline's window and protocol: fresh window, "
+                       "optimize(6) timed, load untimed) in %.1f s on 1 host thread; host has %d logical CPUs" % (its, tt, os.cpu_count()),
                 threads6=dict(value=its6 / tt6, unit="GN iters/s", cores=6,
                               sample="%d loop bodies in %.1f s with 6 OpenMP workers on linearizeAll / accumulate / resubstitute "
                                      "(reference: multiThreading=true, NUM_THREADS=6)" % (its6, tt6)))
@@ -149,8 +151,7 @@ def pmc_child():
     """Body of the profiled child process: the window is loaded and k_ef_linearize is launched 20 times."""
     import torch  # noqa: F401
     W, G = backend_setup(0)
-    for _ in range(20):
-        G.linearizeAll(want_energy=False)
+    G.launch_linearize_only(20)
     torch.cuda.synchronize()
 
 
@@ -449,138 +450,127 @@ def marginalize_extras(torch, W, G, want_cpu):
     return out
 
 
+HEAD_KW = dict(state_sigma=3e-3, idepth_sigma=0.02)   # headline window: perturbed so that optimize(6) mixes accepted and rejected steps
+
+
+def run_protocol(runners, bodies, world, reload_with=None, **opt_kw):
+    """The fresh-window protocol: one FullSystem::optimize call (its initial linearizeAll + applyRes, then `nb` loop bodies) per resident
+    window, all inside ONE timed region (barrier + synchronize on both sides, max over ranks).  Returns (seconds, traces)."""
+    if reload_with is not None:
+        for r in runners:
+            (r.reload if hasattr(r, "reload") else r.load)(reload_with)
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    traces = []
+    for i, nb in enumerate(bodies):
+        traces.append(runners[i % len(runners)].optimize(nb, fixed_its=True, **opt_kw))
+    barrier_sync(world)
+    return max_over_ranks(time.perf_counter() - t0, world), traces
+
+
 def main():
     args = parse()
     if args.pmc_child:
         pmc_child()
         return
     import torch
+    from sdv_loam_amd import backend_api, synthetic as syn
     rank, local, world = dist_setup()
     K, Wm = args.steps, args.warmup
-    W, G = backend_setup(local)
+    W, G = backend_setup(local)                       # the unperturbed window: kernel timings, per-row extras, the soak
+    Wh = syn.make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=syn.KITTI00, **HEAD_KW)
     ext = torch.cuda.ExternalStream(G.stream(), device=torch.device("cuda", local))
+    n_calls = (K + 5) // 6
+    bodies = [6] * (n_calls - 1) + [K - 6 * (n_calls - 1)]
     parallelism, scaling = "single GPU", "strong"
-    runner = G
+    runners = None
     if world > 1:
-        # configs[3]: the SAME window, key-frames sharded by host frame across the ranks, one RCCL all-reduce of the packed
-        # accumulators per GN iteration (strong scaling: total work fixed).  Falls back to replicas if the collective path fails.
+        # configs[3]: every window sharded by host key-frame across the ranks, one RCCL all-reduce of the packed accumulators per GN
+        # iteration (strong scaling: total work fixed).  Falls back to replicas if the collective path fails.
         try:
             from sdv_loam_amd.parallel import ShardedEnergyFunctional, shard_hosts
-            runner = ShardedEnergyFunctional(W, rank, world, local)
-            runner.optimize(2, want_trace=False, fixed_its=True)      # first collectives happen here: fail early, fall back below
-            runner.reload(W)
-            parallelism = "host-keyframe shards %s + 1 all-reduce(154 kB fp64)/iteration over RCCL" % (shard_hosts(W.nF, world),)
+            runners = [ShardedEnergyFunctional(Wh, rank, world, local) for _ in range(min(n_calls, 16))]
+            runners[0].optimize(2, want_trace=False, fixed_its=True)      # first collectives happen here: fail early, fall back below
+            runners[0].reload(Wh)
+            parallelism = "host-keyframe shards %s + 1 all-reduce(154 kB fp64)/iteration over RCCL" % (shard_hosts(Wh.nF, world),)
         except Exception as ex:  # noqa: BLE001
-            runner = G
+            runners = None
             parallelism, scaling = "replicas x%d (sharded path unavailable: %r)" % (world, ex), "weak"
-
-    # ---- timed region: K optimize-loop bodies (+ the one initial linearizeAll/applyRes of the optimize call) ----
-    runner.optimize(Wm, want_trace=False, fixed_its=True)
-    (runner.reload if hasattr(runner, "reload") else runner.load)(W)
-    barrier_sync(world)
-    t0 = time.perf_counter()
-    tr_main = runner.optimize(K, want_trace=True, fixed_its=True, cap=K + 1) if runner is G else runner.optimize(K, want_trace=False, fixed_its=True)
-    barrier_sync(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world)
+    if runners is None:
+        # 80 MB per window: every window of the timed region is resident in HBM before it starts (288 GB would hold thousands)
+        runners = [backend_api.EnergyFunctional(Wh.w, Wh.h, max_points=Wh.nP, device=local).load(Wh) for _ in range(min(n_calls, 1024))]
+    # ---- warm-up: Wm bodies, then the windows are reloaded (untimed) -------------------------------------------------------------------
+    done = 0
+    while done < Wm:
+        nb = min(6, Wm - done)
+        runners[(done // 6) % len(runners)].optimize(nb, fixed_its=True, want_trace=False)
+        done += nb
+    # ---- timed region: K loop bodies = ceil(K / 6) optimize calls on fresh windows --------------------------------------------------------
+    dt, traces = run_protocol(runners, bodies, world, reload_with=Wh, want_trace=(world == 1))
     value = (world if scaling == "weak" else 1) * K / dt
-    accepted_fraction = float(np.mean(tr_main[:, 2])) if runner is G and len(tr_main) else None
-    it_us = (runner.ef if hasattr(runner, "ef") else runner).iteration_times_us()     # per loop body, this rank
+    single = world == 1
+    accepted_fraction = float(np.mean(np.concatenate([t[:, 2] for t in traces]))) if single else None
+    it_us = np.concatenate([(r.ef if hasattr(r, "ef") else r).iteration_times_us() for r in runners[:n_calls]])
     iter_stats = dict(median_us=float(np.median(it_us)), p10_us=float(np.percentile(it_us, 10)), p90_us=float(np.percentile(it_us, 90)),
                       n=int(len(it_us))) if len(it_us) else None
 
-    # ---- N > 1 only: the same K loop bodies as N independent replicas (every rank optimises its own copy of the full window, no
+    # ---- N > 1 only: the same protocol as N independent replicas (every rank optimises its own copies of the full window, no
     # collective) -- the weak-scaling view next to the strong-scaling headline that configs[3] asks for ----
     replicas_value = None
-    if world > 1 and runner is not G:
+    if world > 1 and scaling == "strong":
+        reps = [backend_api.EnergyFunctional(Wh.w, Wh.h, max_points=Wh.nP, device=local).load(Wh) for _ in range(min(n_calls, 16))]
+        reps[0].optimize(min(6, max(Wm, 1)), fixed_its=True, want_trace=False)
+        dt_r, _ = run_protocol(reps, bodies, world, reload_with=Wh, want_trace=False)
+        replicas_value = world * K / dt_r
+        del reps
+
+    value_relin = value_reuse = soak = other = lin_inloop = None
+    if single:
+        # ---- the same protocol with the reference's literal re-linearisation after every rejected step (A/B; results identical) ----
+        dt_l, _ = run_protocol(runners, bodies, world, reload_with=Wh, want_trace=False, relinearize_on_reject=True)
+        value_relin = K / dt_l
+        # ---- opt-in flag bit2: bodies that follow a rejected step re-use the stitched system (bit-identical results; extra key only) ----
+        dt_u, _ = run_protocol(runners, bodies, world, reload_with=Wh, want_trace=False, reuse_after_reject=True)
+        value_reuse = K / dt_u
+        # ---- k_ef_linearize inside the loop: a HIP event pair around every launch of the same protocol (own pass: the event packets
+        # cost ~2 us per body, so this pass is not the headline) ----
+        nl = min(len(runners), 8)
+        run_protocol(runners[:nl], [6] * nl, world, reload_with=Wh, want_trace=False, time_linearize=True)
+        lt = np.concatenate([r.linearize_times_ms() for r in runners[:nl]])
+        lin_inloop = dict(mean_ms=float(lt.mean()), median_ms=float(np.median(lt)), p90_ms=float(np.percentile(lt, 90)), launches=int(len(lt)))
+        # ---- one window, 60 bodies in ONE optimize call (the round-1 headline, kept as an extra: after a few accepted steps the window
+        # is converged and nearly every further step is rejected) ----
         G.load(W)
         G.optimize(Wm, want_trace=False, fixed_its=True)
         G.load(W)
-        barrier_sync(world)
-        t2 = time.perf_counter()
-        G.optimize(K, want_trace=False, fixed_its=True)
-        barrier_sync(world)
-        replicas_value = world * K / max_over_ranks(time.perf_counter() - t2, world)
-
-    # ---- the same K loop bodies with the reference's literal re-linearisation after every rejected step (A/B; results identical) ----
-    value_relin = None
-    if world == 1 and hasattr(runner, "load"):
-        runner.load(W)
-        runner.optimize(Wm, want_trace=False, fixed_its=True, relinearize_on_reject=True)
-        runner.load(W)
-        barrier_sync(world)
-        t1 = time.perf_counter()
-        runner.optimize(K, want_trace=False, fixed_its=True, relinearize_on_reject=True)
-        barrier_sync(world)
-        value_relin = K / (time.perf_counter() - t1)
-
-    # ---- opt-in flag bit2: bodies that follow a rejected step re-use the stitched system (bit-identical results; extra key only) ----
-    value_reuse = None
-    if world == 1:
-        G.load(W)
-        G.optimize(Wm, want_trace=False, fixed_its=True, reuse_after_reject=True)
-        G.load(W)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        G.optimize(K, want_trace=False, fixed_its=True, reuse_after_reject=True)
-        value_reuse = K / (time.perf_counter() - t1)
-
-    # ---- the cpu_baseline protocol on the device: optimize(6) on a freshly loaded window, load untimed, the optimize calls timed
-    # one by one (each includes its initial linearizeAll + applyRes like FullSystem::optimize).  A long run on ONE window ends up in
-    # the converged regime where most steps are rejected; this one has the accept-heavy mix of the first iterations of a key-frame.
-    fresh = None
-    if world == 1:
-        tt, its, acc = 0.0, 0, 0.0
-        for _ in range(20):
-            G.load(W)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            tr6 = G.optimize(6, want_trace=True, fixed_its=True)
-            tt += time.perf_counter() - t1
-            its += len(tr6)
-            acc += float(tr6[:, 2].sum())
-        fresh = dict(value=its / tt, unit="GN iters/s", accepted_fraction=acc / its,
-                     note="20 x [load (untimed) + optimize(6 bodies) timed]; includes each call's initial linearizeAll + applyRes")
+        tr_s = G.optimize(60, want_trace=True, fixed_its=True, cap=64)
+        soak = dict(value=60 / (time.perf_counter() - t1), bodies=60, accepted_fraction=float(np.mean(tr_s[:, 2])),
+                    note="unperturbed window, one optimize call of 60 bodies")
+        # ---- the protocol on two other windows: unperturbed (1 of 6 steps accepted) and perturbed far enough that all 6 are ----
+        other = {}
+        for name, kw in (("unperturbed", {}), ("all_steps_accepted", dict(state_sigma=1e-2, idepth_sigma=0.05))):
+            Wx = syn.make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=syn.KITTI00, **kw)
+            nx = min(len(runners), 8)
+            dtx, trx = run_protocol(runners[:nx], [6] * nx, world, reload_with=Wx, want_trace=True)
+            other[name] = dict(value=6 * nx / dtx, accepted_fraction=float(np.mean(np.concatenate([t[:, 2] for t in trx]))), window=kw)
         G.load(W)
-        if not args.quick:
-            # the same protocol on a window that starts further from its optimum (50x larger pose / 17x larger inverse-depth
-            # perturbation), where about half of the first six steps are accepted -- device and 1-thread oracle side by side
-            W2, G2 = backend_setup(local, state_sigma=1e-2, idepth_sigma=0.05)
-            tt, its, acc = 0.0, 0, 0.0
-            for _ in range(20):
-                G2.load(W2)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                tr6 = G2.optimize(6, want_trace=True, fixed_its=True)
-                tt += time.perf_counter() - t1
-                its += len(tr6)
-                acc += float(tr6[:, 2].sum())
-            fresh["perturbed_window"] = dict(value=its / tt, accepted_fraction=acc / its,
-                                             note="state_sigma 1e-2, idepth_sigma 0.05; same protocol")
-            if not args.no_cpu:
-                from oracle.backend import OracleEF
-                O2 = OracleEF(W2.w, W2.h)
-                tt, its = 0.0, 0
-                while tt < 3.0:
-                    O2.load(W2)
-                    t1 = time.perf_counter()
-                    its += len(O2.optimize(6, fixed_its=True))
-                    tt += time.perf_counter() - t1
-                fresh["perturbed_window"]["cpu_oracle_1_thread"] = its / tt
-            del G2
+    del runners
 
     # ---- dominant kernel: k_ef_linearize, HIP events on the library's stream -----------------------------------
-    for _ in range(5):
-        G.linearizeAll(want_energy=False)
+    G.launch_linearize_only(5)
     torch.cuda.synchronize()
-    ms_lin_each = event_ms(torch, ext, lambda: G.linearizeAll(want_energy=False), 50)
-    ms_lin = event_avg_ms(torch, ext, lambda: G.linearizeAll(want_energy=False), 50)
+    ms_lin_b2b = event_avg_ms(torch, ext, lambda: G.launch_linearize_only(1), 50)
     alg = W.nR * LINEARIZE_BYTES_PER_RES
+    ms_lin = lin_inloop["mean_ms"] if lin_inloop else ms_lin_b2b
     achieved = alg / (ms_lin * 1e-3) / 1e9
     roof = dict(bound="hbm", kernel="k_ef_linearize", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                traffic=None,
-                note="%d residuals x %d B algorithmic = %.1f MB per launch; %.4f ms average launch duration (one pair of HIP events "
-                     "around 50 back-to-back launches of k_ef_linearize alone on the library stream; an event pair around each "
-                     "single launch reads %.4f ms, rocprofv3's kernel time is in profiles/)" % (W.nR, LINEARIZE_BYTES_PER_RES, alg / 1e6, ms_lin, ms_lin_each))
+                traffic=None, in_loop=lin_inloop, back_to_back_ms=ms_lin_b2b,
+                note="%d residuals x %d B algorithmic = %.1f MB per launch; %.4f ms = mean duration of the launches INSIDE the optimize loop "
+                     "(HIP event pair around each launch on the library stream, fresh-window protocol, accumulate / solve kernels in between); "
+                     "back to back (one event pair around 50 launches of the kernel alone, images still in the L2s) %.4f ms; rocprofv3's "
+                     "kernel time is in profiles/" % (W.nR, LINEARIZE_BYTES_PER_RES, alg / 1e6, ms_lin, ms_lin_b2b))
     ms_acc = event_ms(torch, ext, lambda: G.accumulate(), 50)
     # what a plain streaming copy reaches on this box (1 GiB read + 1 GiB written), for reading `frac` against the achievable rate
     try:
@@ -604,15 +594,18 @@ def main():
         "value": value, "unit": "GN iters/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": 1e3 * dt / K,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[2]: KITTI-00 calib 1241x376, 8-keyframe window, 2000 points/KF, 112000 residuals; "
-                               "one step = one FullSystem::optimize loop body (solveSystemF + step + linearizeAll + accept/reject)",
-                   "parallelism": parallelism},
+                               "one step = one FullSystem::optimize loop body (solveSystemF + step + linearizeAll + accept/reject); "
+                               "protocol: ceil(K/6) optimize calls of 6 bodies, each on its own freshly loaded window resident in HBM "
+                               "(window perturbed: state_sigma 3e-3, idepth_sigma 0.02), every call incl. its initial linearizeAll + applyRes",
+                   "parallelism": parallelism, "windows": int(min(n_calls, 1024 if world == 1 else 16)), "optimize_calls": int(n_calls)},
         "roofline": roof,
-        "kernel_ms": {"linearizeAll": ms_lin, "accumulate(point+top+sc+reduce)": ms_acc},
-        "value_with_literal_relinearize_on_reject": value_relin,
         "accepted_fraction": accepted_fraction,
-        "value_with_system_reuse_after_rejected_steps": value_reuse,
-        "value_fresh_windows_6_bodies": fresh,
         "iteration_us": iter_stats,
+        "kernel_ms": {"k_ef_linearize_back_to_back": ms_lin_b2b, "accumulate(fused point+top+sc, reduce)": ms_acc},
+        "value_with_literal_relinearize_on_reject": value_relin,
+        "value_with_system_reuse_after_rejected_steps": value_reuse,
+        "one_window_soak": soak,
+        "other_windows_same_protocol": other,
         "replicas_value_weak_scaling": replicas_value,
     }
     if rank == 0 and world == 1 and not args.quick:
@@ -629,7 +622,7 @@ def main():
         out["optimize_immature"] = immature_extras(W, G, not args.no_cpu)
         out["marginalize"] = marginalize_extras(torch, W, G, not args.no_cpu)
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline_backend(W)
+        out["cpu_baseline"] = cpu_baseline_backend(Wh)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

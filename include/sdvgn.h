@@ -299,7 +299,8 @@ int sdvgn_ef_optimize(sdvgn_ef* ef, int mnumOptIts, int flags /* bit0: run exact
                       rejected step literally like FullSystemOptimize.cpp:446-449 instead of switching back to the kept state_New* set
                       (same results, bit for bit -- tests/test_backend_gpu.py); bit2 (opt-in): the body that follows a rejected step
                       works on the state its predecessor's normal equations were built on, so it re-uses the stitched HA/bA/Hsc/bsc and the
-                      per-point Schur terms (only lambda changed) instead of accumulating again -- same trace and final state, bit for bit */,
+                      per-point Schur terms (only lambda changed) instead of accumulating again -- same trace and final state, bit for bit;
+                      bit3 (measurement): a HIP event pair around every k_ef_linearize launch of the call, sdvgn_ef_get_linearize_times */,
                       double* trace, int trace_stride, int trace_cap);
 /* trace rows (continued): if trace_stride > 7 + (4+6nF), column 7 + (4+6nF) holds the newest frame's frameEnergyTH as the trial
  * linearizeAll of that iteration left it.
@@ -343,6 +344,11 @@ int sdvgn_ef_get_res_toZero(sdvgn_ef* ef, float* res_toZero2, unsigned char* isL
 int sdvgn_ef_get_state(sdvgn_ef* ef, double* value_scaled4, double* state10, float* idepth);
 /* wall time (microseconds, host steady_clock) of every loop body of the last sdvgn_ef_optimize call; returns their number */
 int sdvgn_ef_get_iteration_times(sdvgn_ef* ef, double* us, int cap);
+/* durations (milliseconds, HIP events on the library's stream) of the k_ef_linearize launches of the last sdvgn_ef_optimize call that ran
+ * with flags bit3, in launch order (the first is the call's initial linearizeAll); returns their number */
+int sdvgn_ef_get_linearize_times(sdvgn_ef* ef, float* ms, int cap);
+/* Diagnostics: k_ef_linearize alone, `reps` launches back to back on the library's stream (no statistics, no threshold select) */
+int sdvgn_debug_launch_linearize(sdvgn_ef* ef, int reps);
 /* Diagnostics (SDVGN_PROFILE=1 in the environment when the library is loaded): prints the accumulated host wall time per phase
  * of the solve / optimize path to stderr, divided by `per`, and clears the counters.  Returns 1 if a report was printed, else 0. */
 int sdvgn_debug_phase_report(int per);

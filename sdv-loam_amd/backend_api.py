@@ -44,6 +44,8 @@ PROTOTYPES = [
     ("sdvgn_ef_get_res_toZero", C.c_int, [vp, vp, vp]),
     ("sdvgn_debug_read_stamps", C.c_int, [vp, vp, C.c_int]),
     ("sdvgn_debug_solve_stamps", C.c_int, [vp, vp]),
+    ("sdvgn_ef_get_linearize_times", C.c_int, [vp, vp, C.c_int]),
+    ("sdvgn_debug_launch_linearize", C.c_int, [vp, C.c_int]),
     ("sdvgn_ef_get_solve_status", C.c_int, [vp]),
     ("sdvgn_ef_frame_image_dev", vp, [vp, C.c_int]),
     ("sdvgn_rccl_unique_id", C.c_int, [vp]),
@@ -222,12 +224,22 @@ class EnergyFunctional:
     def stream(self):
         return self.L.sdvgn_ef_stream(self.h_)
 
-    def optimize(self, its=6, cap=128, want_trace=True, fixed_its=False, relinearize_on_reject=False, reuse_after_reject=False):
+    def optimize(self, its=6, cap=128, want_trace=True, fixed_its=False, relinearize_on_reject=False, reuse_after_reject=False, time_linearize=False):
         stride = 8 + self.dim   # ..., x[dim], frameEnergyTH of the newest frame after the trial linearizeAll
         trace = np.zeros((cap, stride))
-        flags = (1 if fixed_its else 0) | (2 if relinearize_on_reject else 0) | (4 if reuse_after_reject else 0)
+        flags = (1 if fixed_its else 0) | (2 if relinearize_on_reject else 0) | (4 if reuse_after_reject else 0) | (8 if time_linearize else 0)
         n = self._check(self.L.sdvgn_ef_optimize(self.h_, its, flags, trace.ctypes.data_as(vp) if want_trace else None, stride, cap))
         return trace[:n]
+
+    def linearize_times_ms(self):
+        """durations of the k_ef_linearize launches of the last optimize(time_linearize=True) call (HIP events), in launch order"""
+        n = self.L.sdvgn_ef_get_linearize_times(self.h_, None, 0)
+        out = np.zeros(max(n, 1), np.float32)
+        self.L.sdvgn_ef_get_linearize_times(self.h_, out.ctypes.data_as(vp), n)
+        return out[:n]
+
+    def launch_linearize_only(self, reps=1):
+        self._check(self.L.sdvgn_debug_launch_linearize(self.h_, reps))
 
     def optimize_finish(self):
         """Tail of FullSystem::optimize (FullSystemOptimize.cpp:460-470): (lastEnergy[0], relbs_max[nP], ngood_inc[nP], removed[nR])."""

@@ -123,6 +123,10 @@ struct sdvgn_ef {
     int th_log_n = 0;
     size_t stats_cap = 0;          // doubles behind stats_dev: 4 statistics + max_points quantile candidates (sharded path)
     std::vector<double> iter_us;   // wall time of every loop body of the last sdvgn_ef_optimize call (microseconds)
+    bool time_lin = false;         // optimize flags bit3: HIP event pair around every k_ef_linearize launch of the call
+    std::vector<hipEvent_t> lin_events;
+    size_t lin_ev_used = 0;
+    std::vector<float> lin_ms;     // their durations (milliseconds), in launch order
     float2* rmatcher = nullptr;
     float *renergy = nullptr, *renergy_new = nullptr, *renergy_wo = nullptr, *rres_toZero = nullptr, *J = nullptr, *JpJd = nullptr;
     float *pHddA = nullptr, *pbdA = nullptr, *pHcdA = nullptr, *pHddL = nullptr, *pbdL = nullptr, *pHcdL = nullptr, *pHdi = nullptr,
@@ -751,8 +755,17 @@ static int lin_chunks_for_np(const sdvgn_ef* e) {   // k_ef_linearize: 128 resid
 static int ef_launch_linearize(sdvgn_ef* e) {
     const int pairs = e->nF * e->nF;
     const int chunks = lin_chunks_for_np(e);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (e->time_lin) {   // measurement mode (optimize flags bit3): one HIP event pair around this launch, read back after the loop
+        if (e->lin_ev_used + 2 > e->lin_events.size()) { e->lin_events.resize(e->lin_ev_used + 2, nullptr); }
+        for (int k = 0; k < 2; ++k) if (!e->lin_events[e->lin_ev_used + k]) hipEventCreate(&e->lin_events[e->lin_ev_used + k]);
+        ev0 = e->lin_events[e->lin_ev_used]; ev1 = e->lin_events[e->lin_ev_used + 1];
+        e->lin_ev_used += 2;
+        hipEventRecord(ev0, e->stream);
+    }
     if ((e->C.debug_flags & 32) && e->dbg_stamps) k_ef_linearize<true><<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
     else k_ef_linearize<false><<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
+    if (ev1) hipEventRecord(ev1, e->stream);
     return chunks * pairs;
 }
 static int chunks_for_np(const sdvgn_ef* e) {
@@ -940,6 +953,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
     if (e->sstate_host) hipHostFree(e->sstate_host);
     if (e->calib_host) hipHostFree(e->calib_host);
     if (e->sol_host) hipHostFree(e->sol_host);
+    for (hipEvent_t ev : e->lin_events) if (ev) hipEventDestroy(ev);
     if (e->solve_stamps) hipHostFree(e->solve_stamps);
     if (e->done_ctr) hipFree(e->done_ctr);
     if (e->imm_pc_host) hipHostFree(e->imm_pc_host);
@@ -1249,8 +1263,13 @@ static AccGeom ef_acc_geom(const sdvgn_ef* e) {
 static int ef_accumulate(sdvgn_ef* e, bool with_reduce) {
     const AccGeom g = ef_acc_geom(e);
     const int nF = e->nF, n_top = g.chunks * g.pairs, n_pt = (e->nP + 63) / 64;
-    k_ef_acc_stage1<<<n_top + n_pt, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, n_top);
-    k_ef_sc_gram<<<dim3(g.sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, g.sc_ppb);
+    if (g.sc_ppb == 64) {
+        const int n_sc = nF * g.sc_chunks;
+        k_ef_acc_fused<<<n_sc + n_top, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, e->sc_partial, g.sc_chunks, n_sc);
+    } else {
+        k_ef_acc_stage1<<<n_top + n_pt, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, n_top);
+        k_ef_sc_gram<<<dim3(g.sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, g.sc_ppb);
+    }
     if (with_reduce)
         k_ef_acc_reduce<<<acc_reduce_grid(g.pairs, nF), 256, 0, e->stream>>>(e->top_partial, g.pairs, g.chunks, e->sc_partial, nF, g.sc_chunks, e->nres_partial, e->acc_dev);
     e->acc_in_host = false;
@@ -1441,13 +1460,13 @@ static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_st
             // sharded window: the packed buffer of every rank is summed (ONE all-reduce per GN iteration), then every rank stitches and solves
             if (ef_sharded(e) && (rc = ef_allreduce(e, e->acc_dev, (int)acc_count(e)))) return rc;
         }
-        k_ef_stitch<<<nF, kSolveLanes, 0, e->stream>>>(io);
+        k_ef_stitch<<<nF + 1, kSolveLanes, 0, e->stream>>>(io);
     }
     k_ef_solve_tail<<<1, kSolveLanes, 0, e->stream>>>(io);
     HIPCHK(hipGetLastError());
     const int nblk = (e->nP + 63) / 64;
-    k_ef_resubstitute<<<nblk, 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->rx_dev, e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2),
-                                                   step_fac, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, nblk, nullptr, nullptr, 0);
+    k_ef_resubstitute_step<<<nblk + (do_step ? 1 : 0), 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->rx_dev, e->pidepth_backup,
+                                                                            e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, nblk, io);
     HIPCHK(hipGetLastError());
     e->sys_on_device = true; e->sys_fetched = false; e->sys_valid = true;
     return SDVGN_OK;
@@ -1568,6 +1587,9 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     const bool fixed_its = (flags & 1) != 0;   // benchmark mode: exactly mnumOptIts loop bodies, no early break
     const bool relinearize_on_reject = (flags & 2) != 0;   // run the reference's redundant re-linearisation literally (A/B timing, tests)
     const bool reuse_after_reject = (flags & 4) != 0;      // opt-in: the solve after a rejected step reuses the stitched system (see header)
+    e->time_lin = (flags & 8) != 0;                          // measurement: event pair around every k_ef_linearize launch
+    e->lin_ev_used = 0; e->lin_ms.clear();
+    struct TimeLinGuard { sdvgn_ef* e; ~TimeLinGuard() { e->time_lin = false; } } time_lin_guard{e};
     bool prev_rejected_clean = false;
     if (!fixed_its && nF < 3) mnumOptIts = 100;
     if (!fixed_its && nF < 4) mnumOptIts = 75;
@@ -1695,6 +1717,10 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         if (!fixed_its && canbreak && iteration >= 1) break;
     }
     if (g_pt.on) sdvgn_debug_phase_report(it);
+    if (e->time_lin) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        for (size_t k = 0; k + 1 < e->lin_ev_used; k += 2) { float ms = 0; hipEventElapsedTime(&ms, e->lin_events[k], e->lin_events[k + 1]); e->lin_ms.push_back(ms); }
+    }
     if (trace && 7 + n < trace_stride) {   // frameEnergyTH of the newest frame as each trial linearizeAll left it
         HIPCHK(hipStreamSynchronize(e->stream));
         for (int i = 0; i < it && i < trace_cap; ++i) trace[(size_t)i * trace_stride + 7 + n] = e->th_log[th_idx[i]];
@@ -1907,6 +1933,21 @@ int sdvgn_debug_phase_report(int per) {
     for (int k = 0; k < PT_N; ++k) if (g_pt.cnt[k]) fprintf(stderr, "  %-24s %8.1f us/iter  (%ld calls, %.1f us each)\n", kPtNames[k], g_pt.acc[k] / per, g_pt.cnt[k], g_pt.acc[k] / g_pt.cnt[k]);
     for (int k = 0; k < PT_N; ++k) { g_pt.acc[k] = 0; g_pt.cnt[k] = 0; }
     return 1;
+}
+
+int sdvgn_ef_get_linearize_times(sdvgn_ef* e, float* ms, int cap) {
+    if (!e) return SDVGN_E_ARG;
+    const int n = (int)e->lin_ms.size();
+    if (ms) for (int i = 0; i < n && i < cap; ++i) ms[i] = e->lin_ms[i];
+    return n;
+}
+
+int sdvgn_debug_launch_linearize(sdvgn_ef* e, int reps) {   // k_ef_linearize alone, `reps` launches back to back (no statistics, no threshold select)
+    if (!e || e->host_only || !e->havePrecalc || e->nP < 1) return SDVGN_E_STATE;
+    EF_DEVICE(e);
+    for (int i = 0; i < reps; ++i) ef_launch_linearize(e);
+    HIPCHK(hipGetLastError());
+    return SDVGN_OK;
 }
 
 int sdvgn_ef_get_iteration_times(sdvgn_ef* e, double* us, int cap) {

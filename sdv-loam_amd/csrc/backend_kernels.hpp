@@ -568,22 +568,22 @@ __global__ void __launch_bounds__(256) k_ef_apply(int nF, int nP, EFArrays A, co
 // frame t (coalesced: consecutive lanes = consecutive points), lanes of wave 0 add the 8 targets in ascending order.
 struct PointSmem { float part[kMaxFrames][13][64]; };
 
-// body for one workgroup of 256 threads = 64 points; wave w handles targets w and w + 4.
+// body for one workgroup of 256 threads = the points [p_base, p_base + p_count), p_count <= 64; wave w handles targets w and w + 4.
 // MODE 0: solveSystemF (addPoint<0> and <1> + accumulateSCF head, shiftPriorToZero = true).
 // MODE 2: marginalizePointsF (EnergyFunctional.cpp:514-549) for the points with mask[p] != 0: priorF *= setting_idepthFixPriorMargFac,
 //         addPoint<2> (all active residuals, resApprox = res_toZeroF; sums go to the L fields, the A fields are zeroed,
 //         AccumulatedTopHessian.cpp:61-62,99-110) + SC head with shiftPriorToZero = false; other points are left untouched.
 template <int MODE = 0>
 __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
-                                           const int* __restrict__ phost, int block, PointSmem& S,
+                                           const int* __restrict__ phost, int p_base, int p_count, PointSmem& S,
                                            const uint8_t* __restrict__ mask = nullptr, float* __restrict__ prior_w = nullptr) {
     float (*part)[13][64] = S.part;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int p = block * 64 + lane;
+    const int p = p_base + lane;
     const size_t slots = (size_t)C.nF * C.nP;
     int h = 0;
     bool mine = false;
-    if (p < C.nP) {
+    if (lane < p_count) {
         h = phost[p];
         mine = precalc[h * C.nF + h].np != 0;   // host frame in this rank's shard
         if (MODE == 2) mine = mine && mask[p] != 0;
@@ -781,7 +781,7 @@ __global__ void __launch_bounds__(256) k_ef_acc_stage1(EFConst Cin, EFArrays A, 
     __shared__ union U { TopGramSmem t; PointSmem p; __device__ U() {} } S;
     const int b = blockIdx.x;
     if (b < n_top) top_gram_body(C, A, precalc, top_partial, nres_partial, b % top_chunks, b / top_chunks, top_chunks, S.t);
-    else point_body(C, A, precalc, phost, b - n_top, S.p);
+    else point_body(C, A, precalc, phost, (b - n_top) * 64, min(64, C.nP - (b - n_top) * 64), S.p);
 }
 
 // SC Gram: grid = (chunks, nF hosts), block = 256.  Features (64, 53 live): 6*t+i = JpJdF of the residual in target t
@@ -888,6 +888,30 @@ __global__ void __launch_bounds__(256) k_ef_sc_gram(EFConst C, EFArrays A, const
     sc_gram_body(C, A, precalc, partial, pts_per_block, blockIdx.x, blockIdx.y, gridDim.x, S);
 }
 
+// The whole accumulate of solveSystemF in ONE launch (windows with <= 64 * kMaxChunks points per host frame): workgroups [0, n_sc) take
+// one 64-point tile of one host frame each -- first the per-point sums of that tile (point_body), then, behind a workgroup barrier, its
+// Schur Gram (sc_gram_body reads the Hcd / bdSum / HdiF this workgroup just wrote) -- and the remaining workgroups the top Grams.  The
+// two kinds are independent of each other, so the per-point launch + its kernel boundary leave the critical path of the loop body.
+__global__ void __launch_bounds__(256) k_ef_acc_fused(EFConst Cin, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                      const int* __restrict__ phost, float* __restrict__ top_partial,
+                                                      int* __restrict__ nres_partial, int top_chunks, float* __restrict__ sc_partial,
+                                                      int sc_chunks, int n_sc) {
+    const EFConst C = ef_const(Cin, A);
+    __shared__ union U { TopGramSmem t; PointSmem p; ScGramSmem s; __device__ U() {} } S;
+    const int b = blockIdx.x;
+    if (b < n_sc) {
+        const int h = b / sc_chunks, bx = b - h * sc_chunks;
+        const int P0 = precalc[h * C.nF + h].P0, np = precalc[h * C.nF + h].np;   // np == 0 outside this rank's shard
+        const int begin = bx * 64;
+        if (begin < np) point_body(C, A, precalc, phost, P0 + begin, min(64, np - begin), S.p);
+        __syncthreads();
+        sc_gram_body(C, A, precalc, sc_partial, 64, bx, h, sc_chunks, S.s);
+    } else {
+        const int q = b - n_sc;
+        top_gram_body(C, A, precalc, top_partial, nres_partial, q % top_chunks, q / top_chunks, top_chunks, S.t);
+    }
+}
+
 // ---- marginalizePointsF (EnergyFunctional.cpp:514-549): the same three bodies in MODE 2 over the points flagged by `mask` ----
 __global__ void __launch_bounds__(256) k_ef_marg_stage1(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
                                                         const int* __restrict__ phost, float* __restrict__ top_partial,
@@ -896,7 +920,7 @@ __global__ void __launch_bounds__(256) k_ef_marg_stage1(EFConst C, EFArrays A, c
     __shared__ union U { TopGramSmem t; PointSmem p; __device__ U() {} } S;
     const int b = blockIdx.x;
     if (b < n_top) top_gram_body<2>(C, A, precalc, top_partial, nres_partial, b % top_chunks, b / top_chunks, top_chunks, S.t, mask);
-    else point_body<2>(C, A, precalc, phost, b - n_top, S.p, mask, prior_w);
+    else point_body<2>(C, A, precalc, phost, (b - n_top) * 64, min(64, C.nP - (b - n_top) * 64), S.p, mask, prior_w);
 }
 __global__ void __launch_bounds__(256) k_ef_marg_sc_gram(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
                                                          float* __restrict__ partial, int pts_per_block, const uint8_t* __restrict__ mask) {
@@ -1025,16 +1049,13 @@ __global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__
 // (idepth = idepth_zero = backup + step_fac * step, FullSystemOptimize.cpp:236-249) -- the optimize loop always does both.
 struct ResubX { float xc[4]; float xAd[kMaxFrames * kMaxFrames * 6]; };
 
-__global__ void __launch_bounds__(512) k_ef_resubstitute(EFConst C, EFArrays A, const PrecalcDev* __restrict__ precalc,
-                                                         const int* __restrict__ phost, const ResubX* __restrict__ Xp, float* __restrict__ backup,
-                                                         double* __restrict__ stats_partial, float step_fac,
-                                                         float* __restrict__ pid_w, float* __restrict__ pidz_w, float* __restrict__ pdeltaF_w,
-                                                         int n_point_blocks, const unsigned long long* __restrict__ pc_src_pinned,
-                                                         unsigned long long* __restrict__ pc_dst, int pc_n8) {
-    if ((int)blockIdx.x >= n_point_blocks) {   // extra workgroup: precalc table of the stepped state, pinned host -> second device table
-        for (int i = threadIdx.x; i < pc_n8; i += blockDim.x) pc_dst[i] = pc_src_pinned[i];
-        return;
-    }
+// (body of one workgroup of 512 lanes; the kernel -- k_ef_resubstitute_step, backend_solve.inc -- adds one extra workgroup that performs the
+// calib / frame part of doStepFromBackup and writes the precalc table of the stepped state beside it)
+__device__ __forceinline__ void resubstitute_body(const EFConst& C, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
+                                                  const int* __restrict__ phost, const ResubX* __restrict__ Xp, float* __restrict__ backup,
+                                                  double* __restrict__ stats_partial, float step_fac,
+                                                  float* __restrict__ pid_w, float* __restrict__ pidz_w, float* __restrict__ pdeltaF_w,
+                                                  int n_point_blocks) {
     __shared__ float part[kMaxFrames][2][64];
     __shared__ float sx[4 + kMaxFrames * kMaxFrames * 6];
     const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
