@@ -55,6 +55,11 @@ int sdvgn_tracker_set_settings(sdvgn_tracker* t, float huberTH, float coarseCuto
  * 1 = fp16 pyramid, 2 = + fp16 Jacobian/residual operands, 3 = + fp16 accumulation.  Affects calc_gs / res_and_gs /
  * track (host-driven) only; calc_res (parity hook) and track_batch always run in fp32. */
 int sdvgn_tracker_set_precision(sdvgn_tracker* t, int mode);
+/* Arithmetic of the fused calcRes + calcGSSSE kernel (k_res_gs: calc_gs / res_and_gs / res_and_gs_batch / res_and_gs_multi / track, the
+ * host-driven paths): 0 = the reference's float arithmetic operation by operation (default; per-point terms bit-identical to the CPU path),
+ * 1 = tolerance mode: fused multiply-adds and reciprocal-based divisions (v_rcp_f32 + one Newton step).  BASELINE.json's contract for this
+ * path is 1e-4 relative on pose increments; mode 1 meets it (tests/test_tracker_gpu.py) with ~40 % fewer vector instructions per point. */
+int sdvgn_tracker_set_arith(sdvgn_tracker* t, int mode);
 
 /* CoarseTracker::makeK(CalibHessian*)   CoarseTracker.cpp:77-106  (level-0 fx,fy,cx,cy = HCalib->fxl()...) */
 int sdvgn_tracker_make_K(sdvgn_tracker* t, float fx, float fy, float cx, float cy);
@@ -133,6 +138,13 @@ int sdvgn_tracker_get_trace(sdvgn_tracker* t, double* rows, int cap);
  * (out_dev: B x 80 doubles = {out6[6], H88[64], b8[8], pad[2]}).  Used by bench.py for the roofline run. */
 int sdvgn_tracker_res_and_gs_batch(sdvgn_tracker* t, int lvl, int B, const double* pose7, const double* aff,
                                    float cutoffTH, double* out_dev);
+/* The same launch over B INDEPENDENT problems: problem b uses the reference template pc_dev[b] (sdvgn_tracker_ref_dev of any handle, level
+ * `lvl`) and the level image img_dev[b] (sdvgn_tracker_pyr_dev of any handle) -- many frames / agents in one launch.  All problems must
+ * have this handle's level geometry, intrinsics, exposure / affine reference and template point count. */
+int sdvgn_tracker_res_and_gs_multi(sdvgn_tracker* t, int lvl, int B, const void* const* pc_dev, const void* const* img_dev,
+                                   const double* pose7, const double* aff, float cutoffTH, double* out_dev);
+/* device pointer of the packed reference template {u,v,idepth,colour} of level `lvl` (float4 per point) */
+const void* sdvgn_tracker_ref_dev(sdvgn_tracker* t, int lvl);
 void* sdvgn_tracker_stream(sdvgn_tracker* t);
 /* Device pointer of level `lvl` of the current new-frame pyramid (dIp[lvl], AoS {I,dx,dy}, (w0>>lvl)*(h0>>lvl)*3 floats), NULL if none
  * was set.  For handing the image to the other handles without a copy: sdvgn_reproj_set_cur_level(.., dIp_aos3_dev),
@@ -265,6 +277,12 @@ int sdvgn_ef_set_residuals(sdvgn_ef* ef, int nR, const int* point, const int* ta
 /* EnergyFunctional::HM, bM (marginalisation prior) and lastNullspaces_pose + _scale (EnergyFunctional.h:96-119). */
 int sdvgn_ef_set_marg_prior(sdvgn_ef* ef, const double* HM, const double* bM);
 int sdvgn_ef_set_nullspaces(sdvgn_ef* ef, int k, const double* vectors);
+/* FullSystem::getNullspaces (FullSystemOptimize.cpp:548-588, called by FullSystem::solveSystem :504-513 before every solveSystemF) from the
+ * frames' linearisation points, with the per-frame columns of FrameHessian::setStateZero (HessianBlocks.cpp:57-76): installs the 6 pose + 1
+ * scale vectors that orthogonalize() projects out.  Host arithmetic (fp64, a dozen SE(3) exp / log per frame); call it after set_frames. */
+int sdvgn_ef_compute_nullspaces(sdvgn_ef* ef);
+/* the installed vectors, [k][4+6nF] row-major; returns k */
+int sdvgn_ef_get_nullspaces(sdvgn_ef* ef, double* out, int cap_vectors);
 
 /* FullSystem::setPrecalcValues (FrameFramePrecalc::set for every pair, HessianBlocks.cpp:169-195) +
  * EnergyFunctional::setDeltaF (EnergyFunctional.cpp:131-156). */

@@ -26,6 +26,8 @@ def _L():
         L.orc_ef_set_residuals.argtypes = [vp, C.c_int, i32p, i32p, i32p, u8p, f64p, u8p, u8p]
         L.orc_ef_set_marg_prior.argtypes = [vp, f64p, f64p]
         L.orc_ef_set_nullspaces.argtypes = [vp, C.c_int, f64p]
+        L.orc_ef_compute_nullspaces.argtypes = [vp, vp]
+        L.orc_ef_compute_nullspaces.restype = C.c_int
         L.orc_ef_fix_linearization.argtypes = [vp, u8p]
         L.orc_ef_fix_linearization.restype = None
         L.orc_ef_reset_oob.argtypes = [vp, vp]
@@ -120,6 +122,12 @@ class OracleEF:
         self.setAdjointsF()
         self.setPrecalcValues()
         return self
+
+    def compute_nullspaces(self):
+        """FullSystem::getNullspaces for the loaded frames: installs and returns the 6 pose + 1 scale vectors [7][4+6nF]."""
+        out = np.zeros((7, 4 + 6 * self.nF))
+        self.L.orc_ef_compute_nullspaces(self.h_, out.ctypes.data_as(C.c_void_p))
+        return out
 
     def setPrecalcValues(self):
         self.L.orc_ef_set_precalc(self.h_)

@@ -1413,6 +1413,43 @@ void orc_ef_set_marg_prior(void* e, const double* HM, const double* bM) {
     EF* E = (EF*)e; const int n = CPARS + 6 * E->nF;
     E->HM.assign(HM, HM + (size_t)n * n); E->bM.assign(bM, bM + n);
 }
+// FrameHessian::setStateZero, null-space columns (HessianBlocks.cpp:57-76) + FullSystem::getNullspaces (FullSystemOptimize.cpp:548-588):
+// lastNullspaces_pose (6) followed by lastNullspaces_scale (1), the set EnergyFunctional::orthogonalize projects out (:727-735)
+int orc_ef_compute_nullspaces(void* e, double* out) {
+    EF* E = (EF*)e; const int nF = E->nF, n = CPARS + 6 * nF;
+    E->nullspaces.assign(7, std::vector<double>(n, 0.0));
+    const float SCALE_XI_TRANS_INVERSE = 1.0f / SCALE_XI_TRANS, SCALE_XI_ROT_INVERSE = 1.0f / SCALE_XI_ROT;
+    for (int h = 0; h < nF; ++h) {
+        const SE3 T = E->frames[h].evalPT;                 // get_worldToCam_evalPT()
+        double pose[6][6], scale[6];
+        for (int i = 0; i < 6; ++i) {
+            double eps[6] = {0, 0, 0, 0, 0, 0}, meps[6] = {0, 0, 0, 0, 0, 0};
+            eps[i] = 1e-3; meps[i] = -1e-3;
+            const SE3 EepsP = se3_exp(eps), EepsM = se3_exp(meps);
+            const SE3 P = se3_mul(se3_mul(T, EepsP), se3_inverse(T));
+            const SE3 M = se3_mul(se3_mul(T, EepsM), se3_inverse(T));
+            double lp[6], lm[6];
+            se3_log(P, lp); se3_log(M, lm);
+            for (int r = 0; r < 6; ++r) pose[i][r] = (lp[r] - lm[r]) / (2e-3);
+        }
+        {
+            SE3 P = T, M = T;
+            for (int r = 0; r < 3; ++r) { P.t[r] *= 1.00001; M.t[r] /= 1.00001; }
+            P = se3_mul(P, se3_inverse(T)); M = se3_mul(M, se3_inverse(T));
+            double lp[6], lm[6];
+            se3_log(P, lp); se3_log(M, lm);
+            for (int r = 0; r < 6; ++r) scale[r] = (lp[r] - lm[r]) / (2e-3);
+        }
+        for (int i = 0; i < 7; ++i)
+            for (int r = 0; r < 6; ++r) {
+                double v = i < 6 ? pose[i][r] : scale[r];
+                v *= r < 3 ? SCALE_XI_TRANS_INVERSE : SCALE_XI_ROT_INVERSE;
+                E->nullspaces[i][CPARS + 6 * h + r] = v;
+            }
+    }
+    if (out) for (int j = 0; j < 7; ++j) std::memcpy(out + (size_t)j * n, E->nullspaces[j].data(), sizeof(double) * n);
+    return 7;
+}
 void orc_ef_set_nullspaces(void* e, int k, const double* ns) {
     EF* E = (EF*)e; const int n = CPARS + 6 * E->nF;
     E->nullspaces.clear();

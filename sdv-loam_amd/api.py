@@ -25,6 +25,9 @@ PROTOTYPES = [
     ("sdvgn_tracker_destroy", None, [vp]),
     ("sdvgn_tracker_set_settings", C.c_int, [vp, C.c_float, C.c_float, C.c_float, C.c_float]),
     ("sdvgn_tracker_set_precision", C.c_int, [vp, C.c_int]),
+    ("sdvgn_tracker_set_arith", C.c_int, [vp, C.c_int]),
+    ("sdvgn_tracker_res_and_gs_multi", C.c_int, [vp, C.c_int, C.c_int, vp, vp, f64p, f64p, C.c_float, vp]),
+    ("sdvgn_tracker_ref_dev", vp, [vp, C.c_int]),
     ("sdvgn_tracker_make_K", C.c_int, [vp, C.c_float, C.c_float, C.c_float, C.c_float]),
     ("sdvgn_tracker_get_K", C.c_int, [vp, C.c_int, f32p, f32p]),
     ("sdvgn_tracker_set_ref", C.c_int, [vp, C.c_int, C.c_int, f32p, f32p, f32p, f32p]),
@@ -130,6 +133,21 @@ class CoarseTracker:
     # -- configuration ------------------------------------------------------------------------------
     def set_settings(self, huber=6.0, cutoff=20.0, aff_a=0.0, aff_b=0.0):
         check(self.L.sdvgn_tracker_set_settings(self.h_, huber, cutoff, aff_a, aff_b))
+
+    def set_arith(self, mode):
+        check(self.L.sdvgn_tracker_set_arith(self.h_, mode))
+
+    def ref_dev(self, lvl):
+        return self.L.sdvgn_tracker_ref_dev(self.h_, lvl)
+
+    def resAndGSMulti(self, lvl, pc_ptrs, img_ptrs, poses7, affs, cutoff, out_dev_ptr=None):
+        """B independent problems in one launch: problem b = (template pc_ptrs[b], level image img_ptrs[b], pose b)."""
+        poses = np.ascontiguousarray(np.array(poses7, np.float64).reshape(-1, 7))
+        affs = np.ascontiguousarray(np.array(affs, np.float64).reshape(-1, 2))
+        B = poses.shape[0]
+        pa = (C.c_void_p * B)(*pc_ptrs)
+        ia = (C.c_void_p * B)(*img_ptrs)
+        check(self.L.sdvgn_tracker_res_and_gs_multi(self.h_, lvl, B, pa, ia, poses.reshape(-1), affs.reshape(-1), cutoff, out_dev_ptr))
 
     def set_precision(self, mode):
         check(self.L.sdvgn_tracker_set_precision(self.h_, mode))

@@ -21,6 +21,8 @@ PROTOTYPES = [
     ("sdvgn_ef_set_residuals", C.c_int, [vp, C.c_int, i32p, i32p, i32p, u8p, f64p, u8p, u8p]),
     ("sdvgn_ef_set_marg_prior", C.c_int, [vp, f64p, f64p]),
     ("sdvgn_ef_set_nullspaces", C.c_int, [vp, C.c_int, f64p]),
+    ("sdvgn_ef_compute_nullspaces", C.c_int, [vp]),
+    ("sdvgn_ef_get_nullspaces", C.c_int, [vp, vp, C.c_int]),
     ("sdvgn_ef_set_precalc", C.c_int, [vp]),
     ("sdvgn_ef_set_adjoints", C.c_int, [vp]),
     ("sdvgn_ef_linearize_all", C.c_int, [vp, vp]),
@@ -125,6 +127,14 @@ class EnergyFunctional:
 
     def set_marg_prior(self, HM, bM):
         self._check(self.L.sdvgn_ef_set_marg_prior(self.h_, np.ascontiguousarray(HM, np.float64).reshape(-1), np.ascontiguousarray(bM, np.float64)))
+
+    def compute_nullspaces(self):
+        """FullSystem::getNullspaces from the loaded frames (7 vectors); returns them [7][4+6nF]."""
+        self._check(self.L.sdvgn_ef_compute_nullspaces(self.h_))
+        k = self.L.sdvgn_ef_get_nullspaces(self.h_, None, 0)
+        out = np.zeros((k, 4 + 6 * self.nF))
+        self.L.sdvgn_ef_get_nullspaces(self.h_, out.ctypes.data_as(vp), k)
+        return out
 
     def set_nullspaces(self, ns):
         ns = np.ascontiguousarray(ns, np.float64)

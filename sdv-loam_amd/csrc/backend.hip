@@ -1180,6 +1180,41 @@ int sdvgn_ef_set_nullspaces(sdvgn_ef* e, int k, const double* v) {
     return SDVGN_OK;
 }
 
+// FullSystem::getNullspaces (FullSystemOptimize.cpp:548-588) from the per-frame null-space columns FrameHessian::setStateZero computes
+// by central differences around the linearisation point (HessianBlocks.cpp:57-76): 6 pose directions + 1 scale direction, the vectors
+// solveSystemF's orthogonalize(&x, 0) projects out (lastNullspaces_pose + lastNullspaces_scale, EnergyFunctional.cpp:727-735).
+int sdvgn_ef_compute_nullspaces(sdvgn_ef* e) {
+    if (!e || e->nF < 1) return SDVGN_E_STATE;
+    const int nF = e->nF, n = CPARS + 6 * nF;
+    e->nullspaces.assign(7, std::vector<double>(n, 0.0));
+    const double sInv[6] = {1.0f / kScaleXiTrans, 1.0f / kScaleXiTrans, 1.0f / kScaleXiTrans, 1.0f / kScaleXiRot, 1.0f / kScaleXiRot, 1.0f / kScaleXiRot};
+    for (int h = 0; h < nF; ++h) {
+        const gn::Pose T = e->frames[h].evalPT, Ti = gn::inverse(T);
+        for (int i = 0; i < 6; ++i) {
+            double ep[6] = {0, 0, 0, 0, 0, 0}, em[6] = {0, 0, 0, 0, 0, 0}, lp[6], lm[6];
+            ep[i] = 1e-3; em[i] = -1e-3;
+            gn::log_se3(gn::compose(gn::compose(T, gn::exp_se3(ep)), Ti), lp);
+            gn::log_se3(gn::compose(gn::compose(T, gn::exp_se3(em)), Ti), lm);
+            for (int r = 0; r < 6; ++r) e->nullspaces[i][CPARS + 6 * h + r] = (lp[r] - lm[r]) / (2e-3) * sInv[r];
+        }
+        gn::Pose P = T, M = T;
+        for (int r = 0; r < 3; ++r) { P.t[r] *= 1.00001; M.t[r] /= 1.00001; }
+        double lp[6], lm[6];
+        gn::log_se3(gn::compose(P, Ti), lp);
+        gn::log_se3(gn::compose(M, Ti), lm);
+        for (int r = 0; r < 6; ++r) e->nullspaces[6][CPARS + 6 * h + r] = (lp[r] - lm[r]) / (2e-3) * sInv[r];
+    }
+    e->ns_dirty = true; e->win_dirty = true;
+    return SDVGN_OK;
+}
+
+int sdvgn_ef_get_nullspaces(sdvgn_ef* e, double* out, int cap_vectors) {
+    if (!e) return SDVGN_E_ARG;
+    const int k = (int)e->nullspaces.size(), n = CPARS + 6 * e->nF;
+    if (out) for (int j = 0; j < k && j < cap_vectors; ++j) std::memcpy(out + (size_t)j * n, e->nullspaces[j].data(), sizeof(double) * n);
+    return k;
+}
+
 int sdvgn_ef_set_adjoints(sdvgn_ef* e) {  // EnergyFunctional::setAdjointsF
     if (!e || e->nF < 1) return SDVGN_E_STATE;
     const int nF = e->nF;

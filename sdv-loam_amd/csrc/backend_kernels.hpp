@@ -298,13 +298,17 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst Cin, EFArrays A, c
     __shared__ double s_e[2];
     __shared__ float xch[2][9][64];
     int pair = blockIdx.y, chunk = blockIdx.x;
-    if (C.nF == 8 && !(C.debug_flags & 4)) {
-        // XCD-aware mapping: workgroups go round-robin to the 8 XCDs by linear id, so id % 8 is the XCD.  Let XCD x linearise
-        // every residual whose TARGET is frame x: its 4 MB L2 then only ever gathers from one 5.6 MB image instead of all 8
-        // (measured: -17 % kernel time, HBM-side fetch 88 -> 43 MB per launch; profiles/r01_linearize_experiments.txt).
+    const int n_wg = gridDim.x * gridDim.y;
+    if ((n_wg & 7) == 0 && !(C.debug_flags & 4)) {
+        // XCD-aware mapping: workgroups go round-robin to the 8 XCDs by linear id, so id % 8 is the XCD.  The work items are ordered
+        // TARGET-major (target, host, chunk) and XCD x takes the x-th eighth of that order: with 8 key-frames XCD x linearises every
+        // residual whose target is frame x, with 5-7 key-frames an XCD sees at most two targets -- its 4 MB L2 then gathers from one or
+        // two 5.6 MB images instead of all of them (measured at nF = 8: -17 % kernel time, HBM-side fetch 88 -> 43 MB per launch;
+        // profiles/r01_linearize_experiments.txt).
         const int id = blockIdx.x + gridDim.x * blockIdx.y;
-        const int tt = id % 8, rest = id / 8;
-        pair = (rest / gridDim.x) * C.nF + tt; chunk = rest % gridDim.x;
+        const int item = (id & 7) * (n_wg >> 3) + (id >> 3);
+        const int tt = item / (C.nF * (int)gridDim.x), rest = item - tt * C.nF * (int)gridDim.x;
+        pair = (rest / (int)gridDim.x) * C.nF + tt; chunk = rest % (int)gridDim.x;
     }
     const int h = pair / C.nF, t = pair % C.nF;
     const PrecalcDev pc = precalc[pair];

@@ -104,6 +104,33 @@ GN_HD Pose exp_se3(const double* a) {
 }
 
 
+// log of a rigid transform -> twist [upsilon | omega]  (Sophus SE3::log se3.hpp:560-585, SO3::logAndTheta so3.hpp:491-531)
+GN_HD void log_se3(const Pose& T, double* out) {
+    const double sq = T.q[0] * T.q[0] + T.q[1] * T.q[1] + T.q[2] * T.q[2];
+    const double nrm = sqrt(sq), w = T.q[3];
+    double k;                                    // omega = k * vec(q), theta = k * |vec(q)|
+    if (nrm < 1e-10) k = 2.0 / w - 2.0 * sq / (w * w * w);
+    else if (fabs(w) < 1e-10) k = (w > 0 ? M_PI : -M_PI) / nrm;
+    else k = 2.0 * atan(nrm / w) / nrm;
+    const double th = k * nrm;
+    const double om[3] = {k * T.q[0], k * T.q[1], k * T.q[2]};
+    const double W[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+    double W2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int q = 0; q < 3; ++q) s += W[i * 3 + q] * W[q * 3 + j];
+            W2[i * 3 + j] = s;
+        }
+    const double c = fabs(th) < 1e-10 ? 1.0 / 12.0 : (1.0 - th / (2.0 * tan(th / 2.0))) / (th * th);
+    for (int i = 0; i < 3; ++i) {
+        double s = 0;
+        for (int j = 0; j < 3; ++j) s += (((i == j) ? 1.0 : 0.0) - 0.5 * W[i * 3 + j] + c * W2[i * 3 + j]) * T.t[j];   // V^-1 t
+        out[i] = s;
+    }
+    out[3] = om[0]; out[4] = om[1]; out[5] = om[2];
+}
+
 // inverse of a rigid transform (Sophus SE3::inverse, se3.hpp:169-173)
 GN_HD Pose inverse(const Pose& A) {
     Pose R;

@@ -59,6 +59,8 @@ struct sdvgn_tracker {
     __half* pyr_half_dev[SDVGN_MAX_LEVELS] = {};  // precision study only: fp16 {I,dx,dy,0}, built lazily
     bool half_valid = false;
     int precision = PREC_F32;
+    int arith = 0;                    // 0: the reference's arithmetic (default); 1: tolerance mode (FMA + rcp divisions), sdvgn_tracker_set_arith
+    ProblemPtrs* ptrs_dev = nullptr;  // per-problem template / image pointers of sdvgn_tracker_res_and_gs_multi (max_batch entries)
     float* img_stage_dev = nullptr;         // level-0 float image staging
     float new_exposure = 1.f;
     bool haveNew = false;
@@ -138,7 +140,7 @@ static void fill_params(const sdvgn_tracker* t, int lvl, const double* pose7, do
 // buffer and k_finalize stores its 640 B of results straight into pinned host memory -- no copy engine in the loop (a small
 // hipMemcpyAsync costs 10-20 us of fixed latency each way, the PCIe transfers themselves well under 1 us).
 static int launch_res_gs(sdvgn_tracker* t, int lvl, int B, const double* pose7, const double* aff, float cutoffTH,
-                         bool write_terms, double* out_dev, bool zero_copy = false) {
+                         bool write_terms, double* out_dev, bool zero_copy = false, const ProblemPtrs* ptrs = nullptr) {
     if (!t->haveK || !t->haveNew) return SDVGN_E_STATE;
     if (lvl < 0 || lvl >= t->levels || B < 1 || B > t->max_batch) return SDVGN_E_ARG;
     if (write_terms && B != 1) return SDVGN_E_ARG;
@@ -164,12 +166,12 @@ static int launch_res_gs(sdvgn_tracker* t, int lvl, int B, const double* pose7, 
         else if (t->precision == PREC_H_OPER) k_res_gs<false, PREC_H_OPER><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], himg, params, t->partial_dev, nullptr, nullptr);
         else k_res_gs<false, PREC_H_ACC><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], himg, params, t->partial_dev, nullptr, nullptr);
     } else if (write_terms) {
-        k_res_gs<true><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], t->pyr_dev[lvl], params, t->partial_dev,
-                                                      t->terms_dev, t->status_dev);
+        if (t->arith == 0) k_res_gs<true><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], t->pyr_dev[lvl], params, t->partial_dev, t->terms_dev, t->status_dev);
+        else k_res_gs<true, PREC_F32, 1><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], t->pyr_dev[lvl], params, t->partial_dev, t->terms_dev, t->status_dev);
         t->terms_lvl = lvl;
     } else {
-        k_res_gs<false><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], t->pyr_dev[lvl], params, t->partial_dev,
-                                                       nullptr, nullptr);
+        if (t->arith == 0) k_res_gs<false><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], t->pyr_dev[lvl], params, t->partial_dev, nullptr, nullptr, ptrs);
+        else k_res_gs<false, PREC_F32, 1><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], t->pyr_dev[lvl], params, t->partial_dev, nullptr, nullptr, ptrs);
     }
     if (zero_copy && B == 1) k_finalize<<<B, 128, 0, t->stream>>>(t->partial_dev, chunks, out_dev, t->flag_host, ++t->flag_seq);
     else k_finalize<<<B, 128, 0, t->stream>>>(t->partial_dev, chunks, out_dev);
@@ -318,7 +320,7 @@ void sdvgn_tracker_destroy(sdvgn_tracker* t) {
 #define DFREE(p) chk(hipFree(p), "hipFree(" #p ")")
 #define HFREE(p) chk(hipHostFree(p), "hipHostFree(" #p ")")
     for (int l = 0; l < t->levels; ++l) { DFREE(t->pc_dev[l]); DFREE(t->pyr_dev[l]); if (t->pyr_half_dev[l]) DFREE(t->pyr_half_dev[l]); }
-    DFREE(t->img_stage_dev); DFREE(t->params_dev); HFREE(t->params_host); DFREE(t->partial_dev);
+    DFREE(t->img_stage_dev); DFREE(t->params_dev); DFREE(t->ptrs_dev); HFREE(t->params_host); DFREE(t->partial_dev);
     DFREE(t->out_dev); HFREE(t->out_host); HFREE(t->flag_host); DFREE(t->terms_dev); DFREE(t->status_dev);
     HFREE(t->track_host);
     HFREE(t->sp_stage_host); HFREE(t->sp_io_host);
@@ -342,6 +344,12 @@ const float* sdvgn_tracker_pyr_dev(sdvgn_tracker* t, int lvl) {
 int sdvgn_tracker_set_settings(sdvgn_tracker* t, float huberTH, float coarseCutoffTH, float affA, float affB) {
     if (!t) return SDVGN_E_ARG;
     t->huberTH = huberTH; t->coarseCutoffTH = coarseCutoffTH; t->affineOptModeA = affA; t->affineOptModeB = affB;
+    return SDVGN_OK;
+}
+
+int sdvgn_tracker_set_arith(sdvgn_tracker* t, int mode) {
+    if (!t || mode < 0 || mode > 1) return SDVGN_E_ARG;
+    t->arith = mode;
     return SDVGN_OK;
 }
 
@@ -468,6 +476,25 @@ int sdvgn_tracker_res_and_gs_batch(sdvgn_tracker* t, int lvl, int B, const doubl
     if (!t || !pose7 || !aff) return SDVGN_E_ARG;
     HIPCHK(hipSetDevice(t->device));
     return launch_res_gs(t, lvl, B, pose7, aff, cutoffTH, false, out_dev ? out_dev : t->out_dev);
+}
+
+int sdvgn_tracker_res_and_gs_multi(sdvgn_tracker* t, int lvl, int B, const void* const* pc_dev, const void* const* img_dev, const double* pose7,
+                                   const double* aff, float cutoffTH, double* out_dev) {
+    if (!t || !pose7 || !aff || !pc_dev || !img_dev || B < 1 || B > t->max_batch) return SDVGN_E_ARG;
+    if (t->precision != PREC_F32) return SDVGN_E_STATE;
+    HIPCHK(hipSetDevice(t->device));
+    if (!t->ptrs_dev) HIPCHK(hipMalloc(&t->ptrs_dev, sizeof(ProblemPtrs) * t->max_batch));
+    std::vector<ProblemPtrs> hp(B);
+    for (int b = 0; b < B; ++b) { hp[b].pc = (const float4*)pc_dev[b]; hp[b].img = (const float*)img_dev[b]; if (!hp[b].pc || !hp[b].img) return SDVGN_E_ARG; }
+    HIPCHK(hipMemcpyAsync(t->ptrs_dev, hp.data(), sizeof(ProblemPtrs) * B, hipMemcpyHostToDevice, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));   // hp goes out of scope
+    return launch_res_gs(t, lvl, B, pose7, aff, cutoffTH, false, out_dev ? out_dev : t->out_dev, false, t->ptrs_dev);
+}
+
+const void* sdvgn_tracker_ref_dev(sdvgn_tracker* t, int lvl) {
+    if (!t || lvl < 0 || lvl >= t->levels) return nullptr;
+    if (hipSetDevice(t->device) != hipSuccess || hipStreamSynchronize(t->stream) != hipSuccess) return nullptr;
+    return t->pc_dev[lvl];
 }
 
 int sdvgn_tracker_get_point_terms(sdvgn_tracker* t, int lvl, float* terms, int* status) {

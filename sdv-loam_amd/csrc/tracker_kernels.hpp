@@ -190,6 +190,89 @@ __device__ __forceinline__ void point_features(const LevelParams& P, const float
     }
 }
 
+// Tolerance-mode arithmetic (sdvgn_tracker_set_arith(1)): the same formulas with fused multiply-adds (contraction allowed inside this
+// function only) and divisions as v_rcp_f32 + one Newton step (~1e-7 relative).  BASELINE.json's contract for this path is 1e-4 relative
+// on pose increments, not bit-exact per-point floats; the exact build above stays the default and the parity reference.  About 40 % fewer
+// VALU instructions per point (the fused kernel is VALU-bound in the batched run).
+__device__ __forceinline__ float fast_div(float a, float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+    return a * r;
+}
+template <bool WRITE_TERMS>
+__device__ __forceinline__ void point_features_fast(const LevelParams& P, const float* __restrict__ img, float4 pc, int i, bool valid,
+                                                    float* f, float& w, float* __restrict__ terms, int* __restrict__ status) {
+#pragma clang fp contract(fast)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) f[k] = 0.0f;
+    w = 0.0f;
+    if (!valid) return;
+    const float x = pc.x, y = pc.y, id = pc.z, refColor = pc.w;
+    const float p0 = P.RKi[0] * x + P.RKi[1] * y + P.RKi[2] + P.t[0] * id;
+    const float p1 = P.RKi[3] * x + P.RKi[4] * y + P.RKi[5] + P.t[1] * id;
+    const float p2 = P.RKi[6] * x + P.RKi[7] * y + P.RKi[8] + P.t[2] * id;
+    const float ip2 = fast_div(1.0f, p2);
+    const float u = p0 * ip2, v = p1 * ip2;
+    const float Ku = P.fx * u + P.cx, Kv = P.fy * v + P.cy;
+    const float new_idepth = id * ip2;
+    if (P.lvl == 0 && (i & 31) == 0) {  // flow indicators :538-566
+        float q0, q1, q2, iq;
+        project(P.Ki, P.t, x, y, id, true, q0, q1, q2); iq = fast_div(1.0f, q2);
+        const float KuT = P.fx * (q0 * iq) + P.cx, KvT = P.fy * (q1 * iq) + P.cy;
+        project(P.Ki, P.t, x, y, id, false, q0, q1, q2); iq = fast_div(1.0f, q2);
+        const float KuT2 = P.fx * (q0 * iq) + P.cx, KvT2 = P.fy * (q1 * iq) + P.cy;
+        project(P.RKi, P.t, x, y, id, false, q0, q1, q2); iq = fast_div(1.0f, q2);
+        const float Ku3 = P.fx * (q0 * iq) + P.cx, Kv3 = P.fy * (q1 * iq) + P.cy;
+        f[12] = (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y) + (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
+        f[13] = (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y) + (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
+        f[14] = 2.0f;
+    }
+    int st = 0;
+    float hit0 = 0, hit1 = 0, hit2 = 0, residual = 0, hw = 0;
+    if (Ku > 2 && Kv > 2 && Ku < P.wl - 3 && Kv < P.hl - 3 && new_idepth > 0) {
+        interp33(img, Ku, Kv, P.wl, hit0, hit1, hit2);
+        if (isfinite(hit0)) {
+            residual = hit0 - (P.affLL0 * refColor + P.affLL1);
+            const float ar = fabsf(residual);
+            hw = ar < P.huber ? 1.0f : fast_div(P.huber, ar);
+            if (ar > P.cutoff) {
+                st = 2;
+                f[9] = P.maxEnergy;
+                f[10] = 1.0f;
+            } else {
+                st = 1;
+                f[9] = hw * residual * residual * (2 - hw);
+                f[11] = 1.0f;
+                const float dx = hit1 * P.fx;
+                const float dy = hit2 * P.fy;
+                f[0] = new_idepth * dx;
+                f[1] = new_idepth * dy;
+                f[2] = -new_idepth * (u * dx + v * dy);
+                f[3] = -((u * v) * dx + dy * (1.0f + v * v));
+                f[4] = (u * v) * dy + dx * (1.0f + u * u);
+                f[5] = u * dy - v * dx;
+                f[6] = P.affLL0 * (P.b0 - refColor);
+                f[7] = -1.0f;
+                f[8] = residual;
+                w = hw;
+            }
+        }
+    }
+    if (WRITE_TERMS) {
+        const int n = P.n;
+        const bool in = (st == 1);
+        terms[0 * n + i] = in ? new_idepth : 0.0f;
+        terms[1 * n + i] = in ? u : 0.0f;
+        terms[2 * n + i] = in ? v : 0.0f;
+        terms[3 * n + i] = in ? hit1 : 0.0f;
+        terms[4 * n + i] = in ? hit2 : 0.0f;
+        terms[5 * n + i] = in ? residual : 0.0f;
+        terms[6 * n + i] = in ? hw : 0.0f;
+        terms[7 * n + i] = in ? refColor : 0.0f;
+        status[i] = st;
+    }
+}
+
 // ----------------------------------------------------------------------------------------------------
 // The 45-term weighted sum of calcGSSSE (Accumulator9) as a Gram matrix on the matrix cores.
 // A wave stages its 64 points as a [16 features][64 points] LDS tile (row stride 66 floats: conflict-free fragment reads),
@@ -258,14 +341,20 @@ __device__ __forceinline__ void block_gram_reduce_to(const f32x4_t& G, float* sm
     }
 }
 
-// grid = (chunks, B).  params[b] describes problem b (pose/affine specific); all problems share the reference
-// points `pc` and the target level image `img`.  partial: [B][chunks][kNRed] floats.
-template <bool WRITE_TERMS, int MODE = PREC_F32>
+// grid = (chunks, B).  params[b] describes problem b (pose/affine specific).  All problems share the reference points `pc` and the
+// target level image `img` (the hypotheses of one frame) unless `ptrs` is given: then problem b works on its own template and its own
+// image (independent tracking problems side by side -- many frames / agents per launch; same level geometry and point count).
+// ARITH 0: the reference's arithmetic operation by operation (default, bit-exact terms); 1: tolerance mode (point_features_fast).
+// partial: [B][chunks][kNRed] floats.
+struct ProblemPtrs { const float4* pc; const float* img; };
+template <bool WRITE_TERMS, int MODE = PREC_F32, int ARITH = 0>
 __global__ void __launch_bounds__(256) k_res_gs(const float4* __restrict__ pc, const float* __restrict__ img,
                                                 const LevelParams* __restrict__ params, float* __restrict__ partial,
-                                                float* __restrict__ terms, int* __restrict__ status) {
+                                                float* __restrict__ terms, int* __restrict__ status, const ProblemPtrs* __restrict__ ptrs = nullptr) {
     __shared__ float smem[4 * kTrkTileFloats];
-    const LevelParams P = params[blockIdx.y];
+    const int prob = blockIdx.y;
+    const LevelParams P = params[prob];
+    if (ptrs) { pc = ptrs[prob].pc; img = ptrs[prob].img; }
     const int wave = threadIdx.x >> 6;
     float* tile = smem + wave * kTrkTileFloats;
     f32x4_t G = {0, 0, 0, 0};
@@ -275,11 +364,12 @@ __global__ void __launch_bounds__(256) k_res_gs(const float4* __restrict__ pc, c
         const int i = base + threadIdx.x;
         const bool valid = i < P.n;
         float f[16], w;
-        point_features<WRITE_TERMS, MODE>(P, img, valid ? pc[i] : make_float4(0, 0, 0, 0), i, valid, f, w, terms, status);
+        if (ARITH == 0) point_features<WRITE_TERMS, MODE>(P, img, valid ? pc[i] : make_float4(0, 0, 0, 0), i, valid, f, w, terms, status);
+        else point_features_fast<WRITE_TERMS>(P, img, valid ? pc[i] : make_float4(0, 0, 0, 0), i, valid, f, w, terms, status);
         wave_gram_points<MODE>(f, w, tile, G);
     }
     __syncthreads();   // staging tiles are dead: reuse smem for the combine
-    block_gram_reduce_to<float>(G, smem, partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kNRed);
+    block_gram_reduce_to<float>(G, smem, partial + ((size_t)prob * gridDim.x + blockIdx.x) * kNRed);
 }
 
 // Tail of calcGSSSE (:468-483: 1/n, cast to double, SCALE_* on rows and columns) and of calcRes (:625-633: the Vec6)

@@ -145,3 +145,83 @@ class ShardedEnergyFunctional:
     def optimize(self, its, fixed_its=False, want_trace=False):
         with self.torch.cuda.stream(self.stream):
             return self.ef.optimize(its, want_trace=want_trace, fixed_its=fixed_its)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Coarse tracker, hypothesis-parallel (tracker row (i)).
+#
+# FullSystem::trackNewCoarse (FullSystem.cpp:341-470) tries up to ~31 initial poses one after the other (constant motion, half / double
+# / zero motion, 26 small rotations) and keeps the one with the smallest level-0 residual.  The tries are independent Levenberg-Marquardt
+# runs against the same reference template and the same new frame, so they shard: rank r runs the tries r, r + world, r + 2 world, ...
+# (interleaved: the likely winners at the head of the list land on different GPUs) as ONE device-resident batch (k_track, one workgroup
+# per try), ONE all-reduce carries every try's 18 result doubles (ok, lastResiduals[5], pose 7, affine 2, flow 3) to every rank, and
+# every rank replays the reference's selection loop over the complete table -- same winner on all ranks, no broadcast.
+# Difference to the sequential reference (stated in SURVEY.md 8e): every try runs to the end; the reference passes the best residuals so
+# far as `minResForAbort` into later tries (a later try that is 1.5x worse on a coarse level is cut short and cannot win) and stops
+# trying once a result is below setting_reTrackThreshold x the last frame's RMSE.  The replay keeps both rules on the finished results
+# (a try whose coarse-level residuals would have triggered the abort is not eligible; tries behind the early-out are ignored), so the
+# winner is the reference's whenever the per-level residuals of a completed run equal those of the run the reference would have cut.
+# ---------------------------------------------------------------------------------------------------------------------------------
+HYP_COLS = 18   # ok | lastResiduals[5] | pose7 | aff2 | flow3
+
+
+def hypothesis_slice(n, rank, world):
+    """indices of the tries rank `rank` evaluates"""
+    return list(range(rank, n, world))
+
+
+def select_hypothesis(table, last_coarse_rmse0=None, retrack_threshold=1.5, abort_factor=1.5):
+    """The selection loop of FullSystem::trackNewCoarse (FullSystem.cpp:412-463) replayed on the finished results `table`
+    [n][HYP_COLS] in try order.  Returns dict(good, index, pose, aff, flow, achieved_res, tries)."""
+    n = table.shape[0]
+    achieved = np.full(5, np.nan)
+    good, win = False, -1
+    tries = 0
+    for i in range(n):
+        ok = table[i, 0] > 0.5
+        res = table[i, 1:6]
+        tries += 1
+        # CoarseTracker.cpp:810: a try is abandoned on level l when its residual exceeds 1.5 x the best achieved one on that level
+        aborted = any(np.isfinite(achieved[l]) and np.isfinite(res[l]) and res[l] > abort_factor * achieved[l] for l in range(1, 5))
+        if ok and not aborted and np.isfinite(np.float32(res[0])) and not (res[0] >= achieved[0]):
+            good, win = True, i
+        if good:
+            for l in range(5):
+                if not np.isfinite(np.float32(achieved[l])) or achieved[l] > res[l]:
+                    achieved[l] = res[l]
+        if good and last_coarse_rmse0 is not None and achieved[0] < last_coarse_rmse0 * retrack_threshold:
+            break
+    if not good:
+        return dict(good=False, index=0, pose=None, aff=None, flow=np.zeros(3), achieved_res=achieved, tries=tries)
+    return dict(good=True, index=win, pose=table[win, 6:13].copy(), aff=table[win, 13:15].copy(), flow=table[win, 15:18].copy(),
+                achieved_res=achieved, tries=tries)
+
+
+def track_hypotheses(evaluate, poses7, aff, coarsest, rank=0, world=1, group=None, last_coarse_rmse0=None, retrack_threshold=1.5):
+    """Shard the tries of trackNewCoarse over the ranks.  `evaluate(poses[B,7], affs[B,2], coarsest) -> (ok[B], poses[B,7], affs[B,2],
+    lastResiduals[B,5], flow[B,3])` is CoarseTracker.trackBatch of this rank's tracker (every rank holds the same reference template and
+    new frame).  One all-reduce(sum) of an [n][18] fp64 table in which every rank fills only its rows."""
+    poses7 = np.asarray(poses7, np.float64).reshape(-1, 7)
+    n = poses7.shape[0]
+    mine = hypothesis_slice(n, rank, world)
+    table = np.zeros((n, HYP_COLS))
+    if mine:
+        ok, p, a, lr, fl = evaluate(poses7[mine], np.tile(np.asarray(aff, np.float64), (len(mine), 1)), coarsest)
+        table[mine, 0] = np.asarray(ok, np.float64)
+        table[mine, 1:6] = np.nan_to_num(lr, nan=1e300, posinf=1e300)     # a NaN row would poison the sum; 1e300 loses every comparison
+        table[mine, 6:13] = p
+        table[mine, 13:15] = a
+        table[mine, 15:18] = fl
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if dist.get_backend(group) == "nccl":
+            t = torch.from_numpy(table).cuda()
+            dist.all_reduce(t, group=group)
+            table = t.cpu().numpy()
+        else:
+            t = torch.from_numpy(table)
+            dist.all_reduce(t, group=group)
+            table = t.numpy()
+    table[:, 1:6] = np.where(table[:, 1:6] >= 1e299, np.nan, table[:, 1:6])
+    return select_hypothesis(table, last_coarse_rmse0, retrack_threshold), table

@@ -415,3 +415,15 @@ def test_sharded_path_single_rank_nccl(api, orc, window, direct, monkeypatch):
         del S
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nF", [5, 6, 7])
+def test_full_size_linearize_other_window_sizes(api, orc, nF):
+    """k_ef_linearize's XCD-aware work order (target-major eighths of the grid) on windows of 5, 6 and 7 key-frames x 2000 points at KITTI
+    resolution: Jacobians, states and energies bit-identical to the oracle, and one solve on top."""
+    from sdv_loam_amd import synthetic as syn
+    W = syn.make_window(w=1241, h=376, nF=nF, pts_per_kf=2000, seed=10 + nF, calib=syn.KITTI00)
+    G, O = pair(api, orc, W)
+    check_linearize(G, O)
+    G.applyRes(); O.applyRes()
+    check_solve(G, O, 0, 0.1)

@@ -251,3 +251,43 @@ def test_optimize_trace_carries_threshold_and_finish(orc, small_window):
     assert np.all(rb[ng > 0] > 0) and np.all(rb[ng == 0] == 0)
     want = _th_mirror(rs["energy_with_outlier"], W.r_target, W.r_isLinearized, W.nF)
     assert E.frame_energy_th()[-1] == want
+
+
+def test_nullspaces_known_answers():
+    """FrameHessian::setStateZero's central differences have closed forms: T exp(eps) T^-1 = exp(Ad_T eps), so the pose columns are the
+    columns of Ad_T; scaling the translation gives T_s T^-1 = (I, (s - 1) t), so the scale vector is [(1.00001 - 1/1.00001) / 2e-3 * t, 0].
+    getNullspaces then divides the translation part by SCALE_XI_TRANS (x2) and the rotation part by SCALE_XI_ROT (x1)."""
+    import oracle
+    from oracle.backend import OracleEF
+    from sdv_loam_amd import synthetic as syn
+    W = syn.make_window(w=320, h=160, nF=4, pts_per_kf=40, seed=5, calib=dict(fx=200., fy=205., cx=159.5, cy=79.5))
+    O = OracleEF(W.w, W.h).load(W)
+    ns = O.compute_nullspaces()
+    assert ns.shape == (7, 4 + 6 * W.nF) and np.all(ns[:, :4] == 0)
+    sinv = np.array([2.0, 2.0, 2.0, 1.0, 1.0, 1.0])
+    for h in range(W.nF):
+        T = np.asarray(W.evalPT[h], np.float64)
+        Ad = oracle.se3_adj(T)
+        got = ns[:6, 4 + 6 * h:10 + 6 * h]                    # [direction i][row r]
+        assert np.allclose(got, (Ad * sinv[:, None]).T, rtol=1e-6, atol=1e-9)
+        t = T[4:7]
+        k = (1.00001 - 1 / 1.00001) / 2e-3
+        assert np.allclose(ns[6, 4 + 6 * h:7 + 6 * h], 2.0 * k * t, rtol=1e-5, atol=1e-12)
+        assert np.allclose(ns[6, 7 + 6 * h:10 + 6 * h], 0, atol=1e-9)
+
+
+def test_nullspaces_product_matches_oracle():
+    """sdvgn_ef_compute_nullspaces (host arithmetic of the product, exercised on a host-only handle) against the oracle, then the
+    projected solve uses them: x is orthogonal to the installed gauge directions up to the reference's 0.5 (N Npi^T + Npi N^T) form."""
+    from oracle.backend import OracleEF
+    from sdv_loam_amd import backend_api, synthetic as syn
+    W = syn.make_window(w=320, h=160, nF=5, pts_per_kf=40, seed=6, calib=dict(fx=200., fy=205., cx=159.5, cy=79.5))
+    O = OracleEF(W.w, W.h).load(W)
+    no = O.compute_nullspaces()
+    G = backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP, device=-1)
+    c = np.ascontiguousarray
+    G.nF = W.nF
+    assert G.L.sdvgn_ef_set_frames(G.h_, W.nF, c(W.evalPT, np.float64).reshape(-1), c(W.state, np.float64).reshape(-1), c(W.state_zero, np.float64).reshape(-1),
+                                   c(W.frameID, np.int32), c(W.ab_exposure, np.float32), c(W.frameEnergyTH, np.float32)) == 0
+    ng = G.compute_nullspaces()
+    assert ng.shape == no.shape and np.allclose(ng, no, rtol=1e-12, atol=1e-13)

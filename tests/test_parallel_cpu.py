@@ -90,3 +90,68 @@ def test_sharded_accumulate_allreduce_solve_gloo(orc, sdvgn_lib):
     assert np.array_equal(xs[0], xs[1])                                   # every rank solves the same system
     assert np.linalg.norm(xs[0] - ref[1]) / np.linalg.norm(ref[1]) < 1e-6  # == single-process solve of the full window
     assert ref[2] == ref[3]
+
+
+# ---- coarse tracker, hypothesis-parallel (SURVEY 8e tracker row): host logic with the CPU oracle as the evaluator -----------------------------
+def _hyp_problem():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from common import load_problem, small_problem, start_pose
+    P = small_problem(seed=3, n=500, w=256, h=192, levels=3, noise=1.0)
+    O = load_problem(oracle.OracleTracker(P.w, P.h, P.levels), P)
+    # 7 tries: the true start last but one, the others displaced more and more (like the rotation fan of trackNewCoarse)
+    poses = np.stack([start_pose(oracle, P, 100 + i, sigma_t=0.02 * (6 - i) + 0.01, sigma_r=0.004 * (6 - i) + 0.001) for i in range(7)])
+
+    def evaluate(ps, affs, coarsest):
+        out = [O.trackNewestCoarse(p, tuple(a), coarsest) for p, a in zip(ps, affs)]
+        return (np.array([o[0] for o in out]), np.stack([o[1] for o in out]), np.stack([o[2] for o in out]),
+                np.stack([o[3] for o in out]), np.stack([o[4] for o in out]))
+    return P, O, poses, evaluate
+
+
+def _hyp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from sdv_loam_amd import parallel
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    P, O, poses, evaluate = _hyp_problem()
+    sel, table = parallel.track_hypotheses(evaluate, poses, (0.0, 0.0), P.levels - 1, rank=rank, world=world)
+    q.put((rank, sel, table))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_tracker_hypothesis_split_gloo(orc, sdvgn_lib):
+    import torch.multiprocessing as mp
+    from sdv_loam_amd import parallel
+    assert parallel.hypothesis_slice(7, 0, 2) == [0, 2, 4, 6] and parallel.hypothesis_slice(7, 1, 2) == [1, 3, 5]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + (os.getpid() % 40)
+    procs = [ctx.Process(target=_hyp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, s0, t0), (_, s1, t1) = res
+    assert np.array_equal(t0, t1, equal_nan=True)                       # one collective: every rank holds the full table
+    assert s0["good"] and s0["index"] == s1["index"] and np.array_equal(s0["pose"], s1["pose"])
+    # single process, all tries: same table, same winner
+    P, O, poses, evaluate = _hyp_problem()
+    s, t = parallel.track_hypotheses(evaluate, poses, (0.0, 0.0), P.levels - 1)
+    assert np.array_equal(t, t0, equal_nan=True) and s["index"] == s0["index"]
+    # the reference's sequential loop (later tries receive achievedRes as minResForAbort, FullSystem.cpp:412-463) picks the same try
+    achieved, good, win = np.full(5, np.nan), False, -1
+    for i in range(len(poses)):
+        ok, p, a, lr, fl, _ = O.trackNewestCoarse(poses[i], (0.0, 0.0), P.levels - 1, min_res=achieved)
+        if ok and np.isfinite(np.float32(lr[0])) and not (lr[0] >= achieved[0]):
+            good, win = True, i
+        if good:
+            for l in range(5):
+                if not np.isfinite(np.float32(achieved[l])) or achieved[l] > lr[l]:
+                    achieved[l] = lr[l]
+    assert good and win == s0["index"]
+    assert np.allclose(achieved[:P.levels], s0["achieved_res"][:P.levels], rtol=1e-12)

@@ -222,3 +222,111 @@ def test_res_and_gs_batch_matches_single_calls(orc, B):
             assert got[i, 1] == r[1] and got[i, 78] >= 0                      # counters exact
             assert rel_err(got[i, 0], r[0]) < 1e-5 and rel_err(got[i, 2:6], r[2:6]) < 1e-5
             assert rel_err(got[i, 6:70].reshape(8, 8), H) < 1e-5 and rel_err(got[i, 70:78], b) < 1e-5
+
+
+def _track_both(api, orc, P, start, aff0=(0.0, 0.0), settings=None, **load_kw):
+    G, O = pair(api, orc, P, **load_kw)
+    if settings is not None:
+        G.set_settings(**settings); O.set_settings(**settings)
+    rg = G.trackNewestCoarse(start, aff0, P.levels - 1)
+    ro = O.trackNewestCoarse(start, aff0, P.levels - 1)
+    rb = G.trackBatch(start[None], np.array([aff0]), P.levels - 1)
+    return rg, ro, rb
+
+
+def _assert_same_track(orc, P, start, rg, ro, rb):
+    okg, pg, ag, lrg, flg, trg = rg
+    oko, po, ao, lro, flo, tro = ro
+    assert okg == oko
+    do = orc.se3_log(orc.se3_mul(po, orc.se3_inverse(start)))
+    for p in (pg, rb[1][0]):                       # host-driven LM and the device-resident k_track
+        dg = orc.se3_log(orc.se3_mul(p, orc.se3_inverse(start)))
+        assert rel_err(dg, do) < 1e-4
+    for a in (ag, rb[2][0]):
+        assert abs(a[0] - ao[0]) < 1e-4 * max(1, abs(ao[0])) and abs(a[1] - ao[1]) < 1e-4 * max(1, abs(ao[1]))
+    assert np.allclose(lrg[:P.levels], lro[:P.levels], rtol=1e-4)
+    assert len(trg) == len(tro) and np.array_equal(trg[:, [0, 1, 3]], tro[:, [0, 1, 3]])      # same LM path, same decisions
+
+
+@pytest.mark.parametrize("modes", [(-1.0, -1.0), (-1.0, 0.0), (0.0, -1.0)])
+def test_track_affine_opt_modes(api, orc, modes):
+    """setting_affineOptModeA / B < 0 fix a and / or b during tracking: the three reduced-system branches of the LM step
+    (CoarseTracker.cpp:726-748; the fork's `mode=2` launch sets both to -1, main.cpp:460-462)."""
+    P = small_problem(seed=4, n=600, w=320, h=240, levels=3, noise=1.5)
+    start = start_pose(orc, P, 4)
+    aff0 = (0.01, 1.0)
+    rg, ro, rb = _track_both(api, orc, P, start, aff0, settings=dict(huber=6.0, cutoff=20.0, aff_a=modes[0], aff_b=modes[1]))
+    _assert_same_track(orc, P, start, rg, ro, rb)
+    # a parameter that is not optimised is reported as 0 (CoarseTracker.cpp:836-837: `if(setting_affineOptModeA < 0) aff_g2l_out.a=0`)
+    if modes[0] < 0:
+        assert rg[2][0] == 0 and ro[2][0] == 0 and rb[2][0][0] == 0
+    if modes[1] < 0:
+        assert rg[2][1] == 0 and ro[2][1] == 0 and rb[2][0][1] == 0
+
+
+@pytest.mark.parametrize("exposures", [(0.7, 1.9), (2.5, 0.4), (0.0, 1.3), (1.2, 0.0)])
+def test_track_with_exposures(api, orc, exposures):
+    """AffLight::fromToVecExposure with exposure times != 1 and with a zero exposure (both are then forced to 1, NumType.h:149-158)."""
+    P = small_problem(seed=5, n=600, w=320, h=240, levels=3, noise=1.0)
+    start = start_pose(orc, P, 5)
+    rg, ro, rb = _track_both(api, orc, P, start, (0.0, 0.0), ref_aff=(0.02, -1.5), exposures=exposures)
+    _assert_same_track(orc, P, start, rg, ro, rb)
+    # a trial at the start pose: same affine transfer, same energy and counters
+    G, O = pair(api, orc, P, ref_aff=(0.02, -1.5), exposures=exposures)
+    check_res_gs(G, O, 0, start, 0.03, 1.0, 20.0)
+
+
+def test_res_and_gs_multi_independent_problems(orc):
+    """sdvgn_tracker_res_and_gs_multi: B independent problems (own template, own level image) in one launch equal the per-handle calls."""
+    import torch
+    from sdv_loam_amd import api, synthetic as syn
+    Ps = [small_problem(seed=20 + k, n=640) for k in range(3)]
+    Gs = [load_problem(api.CoarseTracker(P.w, P.h, P.levels, max_points=4096, max_batch=64), P) for P in Ps]
+    B = 12
+    which = [i % 3 for i in range(B)]
+    poses = np.stack([orc.se3_mul(orc.se3_exp(syn.perturbation(300 + i, 0.03, 0.004)), Ps[which[i]].gt_pose) for i in range(B)])
+    affs = np.stack([[0.01 * (i % 4), 0.4 * (i % 3)] for i in range(B)]).astype(np.float64)
+    out = torch.zeros((B, 80), dtype=torch.float64, device="cuda")
+    for lvl in (0, 2):
+        pcs = [Gs[w].ref_dev(lvl) for w in which]
+        imgs = [Gs[w].pyr_dev(lvl) for w in which]
+        Gs[0].resAndGSMulti(lvl, pcs, imgs, poses, affs, 20.0, out_dev_ptr=C.c_void_p(out.data_ptr()))
+        torch.cuda.ExternalStream(Gs[0].stream()).synchronize()
+        got = out.cpu().numpy()
+        for i in range(B):
+            r, H, b = Gs[which[i]].resAndGS(lvl, poses[i], affs[i, 0], affs[i, 1], 20.0)
+            assert got[i, 1] == r[1]
+            assert rel_err(got[i, 0], r[0]) < 1e-5 and rel_err(got[i, 6:70].reshape(8, 8), H) < 1e-5 and rel_err(got[i, 70:78], b) < 1e-5
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg5", "small"])
+def test_tolerance_mode_arithmetic(api, orc, cfg):
+    """sdvgn_tracker_set_arith(1) (fused multiply-adds, reciprocal divisions) against the exact oracle: BASELINE.json's tolerance -- pose
+    increments within 1e-4 relative -- holds; counters stay exact away from the decision boundaries; the exact mode remains the default."""
+    from sdv_loam_amd import synthetic as syn
+    if cfg == "cfg2":
+        P = syn.make_tracker_problem(1241, 376, 4, 2000, seed=0, calib=syn.KITTI00, gt_xi=[0.1, -0.05, 0.2, 0.01, -0.02, 0.005], gt_aff=(0.05, 3.0))
+    elif cfg == "cfg5":
+        P = syn.make_tracker_problem(1408, 376, 4, 3000, seed=1, calib=syn.KITTI360, gt_xi=[0.08, 0.04, 0.15, -0.008, 0.01, 0.004], gt_aff=(0.03, 2.0))
+    else:
+        P = small_problem(seed=8, n=600, w=320, h=240, levels=3, noise=1.5)
+    G, O = pair(api, orc, P)
+    start = start_pose(orc, P, 2)
+    # one trial: H, b and the increment they give
+    G.set_arith(1)
+    r1, H1, b1 = G.resAndGS(0, start, 0.01, 1.0, 20.0)
+    G.set_arith(0)
+    r0, H0, b0 = G.resAndGS(0, start, 0.01, 1.0, 20.0)
+    assert abs(r1[1] - r0[1]) <= 2 and rel_err(r1[0], r0[0]) < 1e-4
+    assert rel_err(H1, H0) < 1e-4 and rel_err(b1, b0) < 1e-4
+    inc1, inc0 = np.linalg.solve(H1 + 0.01 * np.diag(np.diag(H1)), -b1), np.linalg.solve(H0 + 0.01 * np.diag(np.diag(H0)), -b0)
+    assert rel_err(inc1, inc0) < 1e-4
+    # a whole trackNewestCoarse call in tolerance mode against the exact oracle
+    G.set_arith(1)
+    okg, pg, ag, lrg, _, _ = G.trackNewestCoarse(start, (0.0, 0.0), P.levels - 1)
+    oko, po, ao, lro, _, _ = O.trackNewestCoarse(start, (0.0, 0.0), P.levels - 1)
+    assert okg == oko
+    dg = orc.se3_log(orc.se3_mul(pg, orc.se3_inverse(start)))
+    do = orc.se3_log(orc.se3_mul(po, orc.se3_inverse(start)))
+    assert rel_err(dg, do) < 1e-4
+    assert np.allclose(lrg[:P.levels], lro[:P.levels], rtol=1e-3, atol=2e-4)     # RMSE at convergence on noise-free images is ~1e-4: absolute
