@@ -650,15 +650,21 @@ def main():
     G.launch_linearize_only(5)
     torch.cuda.synchronize()
     ms_lin_b2b = event_avg_ms(torch, ext, lambda: G.launch_linearize_only(1), 50)
+    ms_lin_b2b_each = event_ms(torch, ext, lambda: G.launch_linearize_only(1), 50)     # the same launches with an event pair around each one
+    ev_overhead = max(0.0, ms_lin_b2b_each - ms_lin_b2b)                                 # what an event pair adds to a single launch on this box
     alg = W.nR * LINEARIZE_BYTES_PER_RES
-    ms_lin = lin_inloop["mean_ms"] if lin_inloop else ms_lin_b2b
+    if lin_inloop:
+        lin_inloop["event_pair_overhead_ms"] = ev_overhead
+        lin_inloop["mean_ms_minus_event_overhead"] = lin_inloop["mean_ms"] - ev_overhead
+    ms_lin = lin_inloop["mean_ms_minus_event_overhead"] if lin_inloop else ms_lin_b2b
     achieved = alg / (ms_lin * 1e-3) / 1e9
     roof = dict(bound="hbm", kernel="k_ef_linearize", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                 traffic=None, in_loop=lin_inloop, back_to_back_ms=ms_lin_b2b,
                 note="%d residuals x %d B algorithmic = %.1f MB per launch; %.4f ms = mean duration of the launches INSIDE the optimize loop "
-                     "(HIP event pair around each launch on the library stream, fresh-window protocol, accumulate / solve kernels in between); "
-                     "back to back (one event pair around 50 launches of the kernel alone, images still in the L2s) %.4f ms; rocprofv3's "
-                     "kernel time is in profiles/" % (W.nR, LINEARIZE_BYTES_PER_RES, alg / 1e6, ms_lin, ms_lin_b2b))
+                     "(fresh-window protocol, accumulate / solve kernels in between): a HIP event pair around each launch on the library "
+                     "stream, minus what an event pair adds to a single launch (calibrated in the same run: %.4f ms per pair = the same kernel "
+                     "back to back with a pair around each launch, %.4f ms, minus one pair around 50 launches, %.4f ms); rocprofv3's kernel "
+                     "time is in profiles/" % (W.nR, LINEARIZE_BYTES_PER_RES, alg / 1e6, ms_lin, ev_overhead, ms_lin_b2b_each, ms_lin_b2b))
     ms_acc = event_ms(torch, ext, lambda: G.accumulate(), 50)
     # what a plain streaming copy reaches on this box (1 GiB read + 1 GiB written), for reading `frac` against the achievable rate
     try:

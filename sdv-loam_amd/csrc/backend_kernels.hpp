@@ -64,7 +64,7 @@ struct EFConst {
     float wM3G, hM3G;
     float cDeltaF[4];
     float huberTH, outlierTHSumComponent;
-    int debug_flags;   // profiling experiments only, never set by the product path: bit1 skip the J stores, bit2 disable the XCD mapping,
+    int debug_flags;   // profiling experiments only, never set by the product path: bit1 skip the J stores, bit2 disable the XCD mapping, bit7 shared gather positions,
                        // bit5 stage stamps of k_ef_linearize into EFArrays::dbg_stamps (tools/exp_linearize_stages.py)
 };
 
@@ -126,10 +126,20 @@ __device__ __forceinline__ double wave_sum_double(double v) {
 // Here wave 2g+r of a workgroup takes ROLE r of residual group g:
 //   role 0: pattern pixels 0..3, the x row of the Jacobian (resF[0], Jpdxi[0], Jpdc[0], Jpdd[0]), the residual's scalars
 //   role 1: pattern pixels 4..7, the y row
-// The role is wave-uniform (no divergence), every store stays a 256-B coalesced plane segment, the only exchange is 9 floats per
-// residual through LDS (role 1's four energy / wJI2 terms and its alive mask) so that role 0 can replay the reference's
-// sequential `+=` order over all 8 pattern pixels (bit-exact sums).  4 waves per SIMD, ~1100 VALU instructions and 16 tap loads
-// per lane: the gather phase of one wave overlaps the arithmetic of the others.
+// The role is wave-uniform (no divergence), every store stays a 256-B coalesced plane segment, the only exchange between the roles is
+// 9 floats per residual through LDS (role 1's four energy / wJI2 terms and its alive mask) so that role 0 can replay the reference's
+// sequential `+=` order over all 8 pattern pixels (bit-exact sums).
+//
+// The gather is TRANSPOSED through LDS.  What bounds this kernel is the L1 tag pipeline of the CU (one 128-byte line per clock): with one
+// residual per lane the 64 lanes of every tap instruction hit 64-77 different lines (stage stamps + A/B runs, profiles/; with 8
+// neighbouring lanes gathering at the same position the kernel drops from 19.1 to 11.9 us -- same-line requests of one instruction are
+// merged).  The 8 pattern pixels of a residual land within 6 image rows and ~6 pixels of each other, so the owner lanes only PUBLISH
+// where their pixels are ({element offset of the top-left tap, fx, fy} per pixel, 12 B), and the taps are fetched by 16 NEIGHBOURING
+// lanes per residual -- lane = (pattern pixel of either role, tap row) -- so that one instruction asks for ~7 lines per residual instead
+// of 16.  The fetching lanes also do the bilinear interpolation, in the reference's order: the row-1 lane forms w11 q11 + w01 q01, hands
+// it to its row-0 neighbour (DPP), which adds w10 q10 and then w00 q00 -- ((w11 d + w01 c) + w10 b) + w00 a, globalFuncs.h:51-65 -- and
+// returns {I, dx, dy} of the pixel to its owner through the same 12 bytes of LDS.  Wave (g, role) fetches for residuals
+// [32 role, 32 role + 32) of group g, both roles' pixels; two workgroup barriers frame the exchange.
 // grid = (ceil(max np / 128), nF*nF), block = 256 (2 groups x 2 roles).
 // energy_partial[pair * gridDim.x + chunk] = sum of the return values of linearize() in this workgroup.
 // ------------------------------------------------------------------------------------------------------------
@@ -140,75 +150,77 @@ struct LinLane {
     float energyLeft, e_prev;
     uint8_t fl;
 };
+struct LinIn {            // per-lane inputs and the pattern projections (phase A), kept for the later phases
+    uint8_t fl; int st;
+    float pu, pv, idz, ids;
+    float4 c4, w4;
+    float2 m;
+    bool inb[4];
+};
+struct LinGeo { float res0, res1, hwm, Jr[6], Cr[4], dd; };
+struct LinRec { unsigned off; float fx, fy; };          // published by the owner: top-left tap (element offset into the target image), fractions
+struct LinSmem {
+    union { LinRec q[2][2][64][4]; float g[2][2][64][4][3]; };   // [group][role][lane][pixel]: first the records, then {I,dx,dy} (same 12 bytes)
+    float xch[2][9][64];
+    double s_e[2];
+};
 
 // STAMPS: diagnostics instantiation only (tools/exp_linearize_stages.py); the product instantiation carries none of it
 #define LIN_STAMP(k) do { if (STAMPS) { if ((threadIdx.x & 63) == 0) stamps[k] = wall_clock64(); } } while (0)
 
+// phase A: every per-slot / per-point input of this lane in one batch of independent loads (the dense table has storage behind every
+// slot, so the loads need no flag test), then the projections of this role's 4 pattern pixels; publishes where their taps are
 template <int ROLE, bool STAMPS>
-__device__ __forceinline__ void lin_phase1(const EFConst& C, const EFArrays& A, const PrecalcDev& pc, int t, int p, size_t s, size_t slots,
-                                           LinLane& L, unsigned long long* stamps) {
+__device__ __forceinline__ void lin_phase_a(const EFConst& C, const EFArrays& A, const PrecalcDev& pc, int p, size_t s, bool active,
+                                            LinLane& L, LinIn& I, LinRec* __restrict__ rec /*[4] of this lane*/, unsigned long long* stamps) {
     LIN_STAMP(0);
-    // Round trip 1: every per-slot / per-point input of this lane in one batch of independent loads (the dense table has storage
-    // behind every slot, so the loads need no flag test); the flag-dependent work starts after them.  The sched_barriers pin the
-    // order [loads | pattern projection | 16 tap loads | centre projection + Jacobian row | tap consumption]: without them the
-    // compiler sinks each pixel's loads next to its interpolation and serialises the memory round trips.
-    const uint8_t fl = A.rflags[s];
-    const int st = A.rstate[s];
-    const float pu = A.pu[p], pv = A.pv[p], idz = A.pidz[p], ids = A.pid[p];
-    const float4 c4 = A.pcolor[2 * p + ROLE];
-    const float4 w4 = A.pweights[2 * p + ROLE];
-    const float2 m = A.rmatcher[s];
+    I.fl = A.rflags[s];
+    I.st = A.rstate[s];
+    I.pu = A.pu[p]; I.pv = A.pv[p]; I.idz = A.pidz[p]; I.ids = A.pid[p];
+    I.c4 = A.pcolor[2 * p + ROLE];
+    I.w4 = A.pweights[2 * p + ROLE];
+    I.m = A.rmatcher[s];
     L.e_prev = (ROLE == 0) ? A.renergy[s] : 0.0f;
     __builtin_amdgcn_sched_barrier(0);
-    if (STAMPS) { const float dep = pu + (float)fl + m.x + c4.x + w4.x + ids; if (dep == 1.2345e30f) stamps[7] = 1; }   // the stamp below waits for the loads
+    if (STAMPS) { const float dep = I.pu + (float)I.fl + I.m.x + I.c4.x + I.w4.x + I.ids; if (dep == 1.2345e30f) stamps[7] = 1; }   // the stamp below waits for the loads
     LIN_STAMP(1);
-    L.fl = fl;
-    L.todo = (fl & RF_EXISTS) && !(fl & RF_LINEARIZED);
-    bool oob = (st == RS_OOB) || !(fl & RF_MATCHER);
-
-    const float* __restrict__ img = A.images + (size_t)t * C.w * C.h * 3;
+    L.fl = I.fl;
+    L.todo = active && (I.fl & RF_EXISTS) && !(I.fl & RF_LINEARIZED);
+    L.oob = (I.st == RS_OOB) || !(I.fl & RF_MATCHER);
     // settings.cpp:250 pattern 8, this role's half
     const int pat[4][2] = {{ROLE ? 0 : 0, ROLE ? 0 : -2}, {ROLE ? 2 : -1, ROLE ? 0 : -1}, {ROLE ? -1 : 1, ROLE ? 1 : -1}, {ROLE ? 0 : -2, ROLE ? 2 : 0}};
-    float Ku2[4], Kv2[4], fx4[4], fy4[4], tp[4][12];
-    const float* bp4[4];
-    bool inb[4];
-    const bool gather = L.todo && !oob;
+    const bool gather = L.todo && !L.oob;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float up = pu + pat[k][0], vp = pv + pat[k][1];
-        const float r0 = ((pc.KRKi[0] * up + pc.KRKi[1] * vp) + pc.KRKi[2] * 1.0f) + pc.Kt[0] * ids;
-        const float r1 = ((pc.KRKi[3] * up + pc.KRKi[4] * vp) + pc.KRKi[5] * 1.0f) + pc.Kt[1] * ids;
-        const float r2 = ((pc.KRKi[6] * up + pc.KRKi[7] * vp) + pc.KRKi[8] * 1.0f) + pc.Kt[2] * ids;
-        Ku2[k] = r0 / r2; Kv2[k] = r1 / r2;
-        inb[k] = (Ku2[k] > 1.1f && Kv2[k] > 1.1f && Ku2[k] < C.wM3G && Kv2[k] < C.hM3G);
-        const bool ld = gather && inb[k];
-        const float x = ld ? Ku2[k] : 2.0f, y = ld ? Kv2[k] : 2.0f;
+        const float up = I.pu + pat[k][0], vp = I.pv + pat[k][1];
+        const float r0 = ((pc.KRKi[0] * up + pc.KRKi[1] * vp) + pc.KRKi[2] * 1.0f) + pc.Kt[0] * I.ids;
+        const float r1 = ((pc.KRKi[3] * up + pc.KRKi[4] * vp) + pc.KRKi[5] * 1.0f) + pc.Kt[1] * I.ids;
+        const float r2 = ((pc.KRKi[6] * up + pc.KRKi[7] * vp) + pc.KRKi[8] * 1.0f) + pc.Kt[2] * I.ids;
+        const float Ku2 = r0 / r2, Kv2 = r1 / r2;
+        I.inb[k] = (Ku2 > 1.1f && Kv2 > 1.1f && Ku2 < C.wM3G && Kv2 < C.hM3G);
+        const bool ld = gather && I.inb[k];
+        const float x = ld ? Ku2 : 2.0f, y = ld ? Kv2 : 2.0f;      // (pixels that are not gathered point at a valid dummy position)
         const int ix = (int)x, iy = (int)y;
-        fx4[k] = x - ix; fy4[k] = y - iy;
-        bp4[k] = img + 3 * (ix + iy * C.w);
+        LinRec r;
+        r.off = (unsigned)(3 * (ix + iy * C.w)); r.fx = x - ix; r.fy = y - iy;
+        rec[k] = r;
     }
-    __builtin_amdgcn_sched_barrier(0);
     LIN_STAMP(2);
-    // Round trip 2: 4 x (2 rows x 24 B) tap loads back to back
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float* bq = bp4[k] + 3 * C.w;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) { tp[k][q] = bp4[k][q]; tp[k][6 + q] = bq[q]; }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    LIN_STAMP(7);   // all 16 tap loads have been issued
+}
 
-    // centre projection (both roles) and this role's row of the geometric Jacobian (Residuals.cpp:93-155), while the taps fly
+// centre projection (both roles) and this role's row of the geometric Jacobian (Residuals.cpp:93-155); runs while the taps fly
+template <int ROLE>
+__device__ __forceinline__ void lin_geometry(const EFConst& C, const PrecalcDev& pc, const LinIn& I, LinLane& L, LinGeo& Gm) {
+    bool oob = L.oob;
     float Ku = 0, Kv = 0, u = 0, v = 0, drescale = 0, new_idepth = 0, KliP0 = 0, KliP1 = 0;
     if (!oob) {
-        KliP0 = (pu + 0 - C.cxl) * C.fxli;
-        KliP1 = (pv + 0 - C.cyl) * C.fyli;
-        const float q0 = ((pc.R0[0] * KliP0 + pc.R0[1] * KliP1) + pc.R0[2] * 1.0f) + pc.t0[0] * idz;
-        const float q1 = ((pc.R0[3] * KliP0 + pc.R0[4] * KliP1) + pc.R0[5] * 1.0f) + pc.t0[1] * idz;
-        const float q2 = ((pc.R0[6] * KliP0 + pc.R0[7] * KliP1) + pc.R0[8] * 1.0f) + pc.t0[2] * idz;
+        KliP0 = (I.pu + 0 - C.cxl) * C.fxli;
+        KliP1 = (I.pv + 0 - C.cyl) * C.fyli;
+        const float q0 = ((pc.R0[0] * KliP0 + pc.R0[1] * KliP1) + pc.R0[2] * 1.0f) + pc.t0[0] * I.idz;
+        const float q1 = ((pc.R0[3] * KliP0 + pc.R0[4] * KliP1) + pc.R0[5] * 1.0f) + pc.t0[1] * I.idz;
+        const float q2 = ((pc.R0[6] * KliP0 + pc.R0[7] * KliP1) + pc.R0[8] * 1.0f) + pc.t0[2] * I.idz;
         drescale = 1.0f / q2;
-        new_idepth = idz * drescale;
+        new_idepth = I.idz * drescale;
         if (!(drescale > 0)) oob = true;
         else {
             u = q0 * drescale; v = q1 * drescale;
@@ -217,9 +229,9 @@ __device__ __forceinline__ void lin_phase1(const EFConst& C, const EFArrays& A, 
         }
     }
     L.oob = oob;
-    float Jr[6], Cr[4], dd;
+    float* Jr = Gm.Jr; float* Cr = Gm.Cr;
     if (ROLE == 0) {
-        dd = drescale * (pc.t0[0] - pc.t0[2] * u) * SDVGN_SCALE_IDEPTH * C.fxl;
+        Gm.dd = drescale * (pc.t0[0] - pc.t0[2] * u) * SDVGN_SCALE_IDEPTH * C.fxl;
         Cr[2] = drescale * (pc.R0[6] * u - pc.R0[0]);
         Cr[3] = C.fxl * drescale * (pc.R0[7] * u - pc.R0[1]) * C.fyli;
         Cr[0] = KliP0 * Cr[2];
@@ -231,7 +243,7 @@ __device__ __forceinline__ void lin_phase1(const EFConst& C, const EFArrays& A, 
         Jr[0] = new_idepth * C.fxl; Jr[1] = 0; Jr[2] = -new_idepth * u * C.fxl;
         Jr[3] = -u * v * C.fxl; Jr[4] = (1 + u * u) * C.fxl; Jr[5] = -v * C.fxl;
     } else {
-        dd = drescale * (pc.t0[1] - pc.t0[2] * v) * SDVGN_SCALE_IDEPTH * C.fyl;
+        Gm.dd = drescale * (pc.t0[1] - pc.t0[2] * v) * SDVGN_SCALE_IDEPTH * C.fyl;
         Cr[2] = C.fyl * drescale * (pc.R0[6] * v - pc.R0[3]) * C.fxli;
         Cr[3] = drescale * (pc.R0[7] * v - pc.R0[4]);
         Cr[0] = KliP0 * Cr[2];
@@ -243,28 +255,26 @@ __device__ __forceinline__ void lin_phase1(const EFConst& C, const EFArrays& A, 
         Jr[0] = 0; Jr[1] = new_idepth * C.fyl; Jr[2] = -new_idepth * v * C.fyl;
         Jr[3] = -(1 + v * v) * C.fyl; Jr[4] = u * v * C.fyl; Jr[5] = u * C.fyl;
     }
-    const float res0 = Ku - m.x, res1 = Kv - m.y;
-    const float nrm = sqrtf(res0 * res0 + res1 * res1);
+    Gm.res0 = Ku - I.m.x; Gm.res1 = Kv - I.m.y;
+    const float nrm = sqrtf(Gm.res0 * Gm.res0 + Gm.res1 * Gm.res1);
     float hwm = fabsf(nrm) < C.huberTH ? 1.0f : C.huberTH / fabsf(nrm);
-    L.energyLeft = hwm * (res0 * res0 + res1 * res1) * (2 - hwm);
+    L.energyLeft = hwm * (Gm.res0 * Gm.res0 + Gm.res1 * Gm.res1) * (2 - hwm);
     if (hwm < 1) hwm = sqrtf(hwm);
-    __builtin_amdgcn_sched_barrier(0);
-    LIN_STAMP(3);
-    if (STAMPS) { float dep = 0; for (int k = 0; k < 4; ++k) dep += tp[k][0] + tp[k][11]; if (dep == 1.2345e30f) stamps[6] = 1; }
-    LIN_STAMP(4);
+    Gm.hwm = hwm;
+}
 
-    // consume the taps: per-pixel terms of the reference's pattern loop (:157-194); summed later in pixel order by role 0
-    const float col[4] = {c4.x, c4.y, c4.z, c4.w};
-    const float wts[4] = {w4.x, w4.y, w4.z, w4.w};
+// phase C: per-pixel terms of the reference's pattern loop (:157-194) from the interpolated {I,dx,dy}; summed later in pixel order by
+// role 0.  Then this role's row of the new Jacobian goes to the buffer the EnergyFunctional side does NOT own.
+template <int ROLE>
+__device__ __forceinline__ void lin_phase_c(const EFConst& C, const EFArrays& A, const PrecalcDev& pc, size_t s, size_t slots, const LinIn& I,
+                                            const LinGeo& Gm, const float (*g)[3] /*[4][3] of this lane*/, LinLane& L) {
+    const float col[4] = {I.c4.x, I.c4.y, I.c4.z, I.c4.w};
+    const float wts[4] = {I.w4.x, I.w4.y, I.w4.z, I.w4.w};
     L.ok = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float dx = fx4[k], dy = fy4[k], dxdy = dx * dy;
-        const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
-        const float* q = tp[k];
-        const float g0 = ((w11 * q[9] + w01 * q[6]) + w10 * q[3]) + w00 * q[0];
-        float h1 = ((w11 * q[10] + w01 * q[7]) + w10 * q[4]) + w00 * q[1];
-        float h2 = ((w11 * q[11] + w01 * q[8]) + w10 * q[5]) + w00 * q[2];
+        const float g0 = g[k][0];
+        float h1 = g[k][1], h2 = g[k][2];
         const float residual = g0 - (float)(pc.aff0 * col[k] + pc.aff1);
         float w = sqrtf(C.outlierTHSumComponent / (C.outlierTHSumComponent + (h1 * h1 + h2 * h2)));
         w = 0.5f * (w + wts[k]);
@@ -274,29 +284,28 @@ __device__ __forceinline__ void lin_phase1(const EFConst& C, const EFArrays& A, 
         hw = hw * w;
         h1 *= hw; h2 *= hw;
         L.wj[k] = hw * hw * (h1 * h1 + h2 * h2);
-        if (inb[k] && isfinite(g0)) L.ok |= 1u << k;
+        if (I.inb[k] && isfinite(g0)) L.ok |= 1u << k;
     }
-    LIN_STAMP(5);
-    // this role's row of the new Jacobian goes to the buffer the EnergyFunctional side does NOT own
-    L.wrote = L.todo && !oob;
-    if (L.wrote && (!(C.debug_flags & 2) || hwm != hwm)) {
-        const int buf = (fl & RF_SEL) ? 0 : 1;
+    L.wrote = L.todo && !L.oob;
+    if (L.wrote && (!(C.debug_flags & 2) || Gm.hwm != Gm.hwm)) {
+        const int buf = (I.fl & RF_SEL) ? 0 : 1;
         float* Jn = A.J + (size_t)buf * kJPlanes * slots + s;
-        Jn[(0 + ROLE) * slots] = (ROLE == 0 ? res0 : res1) * hwm;
+        Jn[(0 + ROLE) * slots] = (ROLE == 0 ? Gm.res0 : Gm.res1) * Gm.hwm;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) Jn[(2 + 6 * ROLE + i) * slots] = Jr[i] * hwm;
+        for (int i = 0; i < 6; ++i) Jn[(2 + 6 * ROLE + i) * slots] = Gm.Jr[i] * Gm.hwm;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Jn[(14 + 4 * ROLE + i) * slots] = Cr[i] * hwm;
-        Jn[(22 + ROLE) * slots] = dd * hwm;
+        for (int i = 0; i < 4; ++i) Jn[(14 + 4 * ROLE + i) * slots] = Gm.Cr[i] * Gm.hwm;
+        Jn[(22 + ROLE) * slots] = Gm.dd * Gm.hwm;
     }
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned lin_u32x2 __attribute__((ext_vector_type(2)));
 template <bool STAMPS>
 __global__ void __launch_bounds__(256) k_ef_linearize(EFConst Cin, EFArrays A, const PrecalcDev* __restrict__ precalc,
                                                        double* __restrict__ energy_partial) {
     const EFConst C = ef_const(Cin, A);
-    __shared__ double s_e[2];
-    __shared__ float xch[2][9][64];
+    __shared__ LinSmem S;
     int pair = blockIdx.y, chunk = blockIdx.x;
     const int n_wg = gridDim.x * gridDim.y;
     if ((n_wg & 7) == 0 && !(C.debug_flags & 4)) {
@@ -312,13 +321,17 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst Cin, EFArrays A, c
     }
     const int h = pair / C.nF, t = pair % C.nF;
     const PrecalcDev pc = precalc[pair];
+    if (h == t || chunk * 128 >= pc.np) {     // nothing to linearise in this workgroup (uniform: before any barrier)
+        if (threadIdx.x == 0) energy_partial[(size_t)pair * gridDim.x + chunk] = 0.0;
+        return;
+    }
     const float thH = A.frameTH_r[h], thT = A.frameTH_r[t];
     const float frameTH = thH < thT ? thT : thH;   // std::max<float>(host->frameEnergyTH, target->frameEnergyTH), Residuals.cpp:212
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int role = wave & 1, grp = wave >> 1;
     const int pl = chunk * 128 + grp * 64 + lane;
-    const bool active = (h != t && pl < pc.np);
+    const bool active = pl < pc.np;
     const int p = pc.P0 + (active ? pl : 0);
     const size_t slots = (size_t)C.nF * C.nP;
     const size_t s = (size_t)t * C.nP + p;
@@ -328,18 +341,69 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst Cin, EFArrays A, c
     for (int k = 0; k < 4; ++k) { L.e[k] = 0; L.wj[k] = 0; }
     unsigned long long* stamps = nullptr;
     if (STAMPS) stamps = A.dbg_stamps + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
-    if (active) {
-        if (role == 0) lin_phase1<0, STAMPS>(C, A, pc, t, p, s, slots, L, stamps);
-        else lin_phase1<1, STAMPS>(C, A, pc, t, p, s, slots, L, stamps);
+    LinIn I;
+    LinGeo Gm;
+    // ---- phase A: inputs, pattern projections, publish the tap positions -------------------------------------------------------
+    if (role == 0) lin_phase_a<0, STAMPS>(C, A, pc, p, s, active, L, I, S.q[grp][0][lane], stamps);
+    else lin_phase_a<1, STAMPS>(C, A, pc, p, s, active, L, I, S.q[grp][1][lane], stamps);
+    __syncthreads();
+    // ---- cooperative gather: 16 neighbouring lanes per residual, 8 rounds --------------------------------------------------------
+    {
+        const float* __restrict__ img = A.images + (size_t)t * C.w * C.h * 3;      // wave-uniform (blockIdx-derived)
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, C.w * C.h * 12, 0x00020000);
+        const int s16 = lane & 15, orole = s16 >> 3, k = (s16 >> 1) & 3, row = s16 & 1;
+        const int rbase = 32 * role + (lane >> 4);
+        LinRec rc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rc[j] = S.q[grp][orole][rbase + 4 * j][k];
+        u32x4 ta[8]; lin_u32x2 tb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int voff = 4 * (int)(rc[j].off + (unsigned)(row * 3 * C.w));
+            ta[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);          // {I,dx,dy}(x) | I(x+1)
+            tb[j] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff + 16, 0, 0);      // dx,dy (x+1)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        LIN_STAMP(7);   // all 16 tap loads have been issued
+        // centre projection + this role's Jacobian row while the taps fly
+        if (role == 0) lin_geometry<0>(C, pc, I, L, Gm); else lin_geometry<1>(C, pc, I, L, Gm);
+        __builtin_amdgcn_sched_barrier(0);
+        LIN_STAMP(3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float dx = rc[j].fx, dy = rc[j].fy, dxdy = dx * dy;
+            const float wl = row ? (dy - dxdy) : (1 - dx - dy + dxdy);     // weight of this row's left tap:  w01 | w00
+            const float wr = row ? dxdy : (dx - dxdy);                      // weight of this row's right tap: w11 | w10
+            const float a0 = __uint_as_float(ta[j][0]), a1 = __uint_as_float(ta[j][1]), a2 = __uint_as_float(ta[j][2]);
+            const float b0 = __uint_as_float(ta[j][3]), b1 = __uint_as_float(tb[j][0]), b2 = __uint_as_float(tb[j][1]);
+            // row 1: w11 * right + w01 * left ; handed to the row-0 lane (the even neighbour) ...
+            const float p0 = wr * b0 + wl * a0, p1 = wr * b1 + wl * a1, p2 = wr * b2 + wl * a2;
+            const float q0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(p0), 0xF5, 0xF, 0xF, false));   // quad_perm [1,1,3,3]
+            const float q1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(p1), 0xF5, 0xF, 0xF, false));
+            const float q2 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(p2), 0xF5, 0xF, 0xF, false));
+            // ... which adds w10 * right and then w00 * left: ((w11 d + w01 c) + w10 b) + w00 a
+            if (!row) {
+                float* gp = S.g[grp][orole][rbase + 4 * j][k];
+                gp[0] = (q0 + wr * b0) + wl * a0;
+                gp[1] = (q1 + wr * b1) + wl * a1;
+                gp[2] = (q2 + wr * b2) + wl * a2;
+            }
+        }
+        LIN_STAMP(4);
     }
+    __syncthreads();
+    // ---- phase C: pixel terms, Jacobian stores -------------------------------------------------------------------------------------------
+    if (role == 0) lin_phase_c<0>(C, A, pc, s, slots, I, Gm, S.g[grp][0][lane], L);
+    else lin_phase_c<1>(C, A, pc, s, slots, I, Gm, S.g[grp][1][lane], L);
+    LIN_STAMP(5);
     if (role == 1) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { xch[grp][k][lane] = L.e[k]; xch[grp][4 + k][lane] = L.wj[k]; }
-        xch[grp][8][lane] = __uint_as_float(L.ok);
+        for (int k = 0; k < 4; ++k) { S.xch[grp][k][lane] = L.e[k]; S.xch[grp][4 + k][lane] = L.wj[k]; }
+        S.xch[grp][8][lane] = __uint_as_float(L.ok);
     }
     __syncthreads();
     double my_e = 0.0;
-    if (role == 0 && active && L.todo) {
+    if (role == 0 && L.todo) {
         A.renergy_wo[s] = -1.0f;
         if (L.oob) {
             A.rstate_new[s] = RS_OOB;
@@ -348,9 +412,9 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst Cin, EFArrays A, c
         } else {
             // the reference's sequential loop over the 8 pattern pixels, `break` at the first failing one (:160-176)
             float e8[8], wj8[8];
-            unsigned ok8 = L.ok | (__float_as_uint(xch[grp][8][lane]) << 4);
+            unsigned ok8 = L.ok | (__float_as_uint(S.xch[grp][8][lane]) << 4);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { e8[k] = L.e[k]; wj8[k] = L.wj[k]; e8[4 + k] = xch[grp][k][lane]; wj8[4 + k] = xch[grp][4 + k][lane]; }
+            for (int k = 0; k < 4; ++k) { e8[k] = L.e[k]; wj8[k] = L.wj[k]; e8[4 + k] = S.xch[grp][k][lane]; wj8[4 + k] = S.xch[grp][4 + k][lane]; }
             float wJI2_sum = 0, energyLeft2 = 0;
             bool alive = true;
 #pragma unroll
@@ -370,10 +434,10 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst Cin, EFArrays A, c
     }
     if (role == 0) {
         const double ws = wave_sum_double(my_e);
-        if (lane == 63) s_e[grp] = ws;
+        if (lane == 63) S.s_e[grp] = ws;
     }
     __syncthreads();
-    if (threadIdx.x == 0) energy_partial[(size_t)pair * gridDim.x + chunk] = s_e[0] + s_e[1];
+    if (threadIdx.x == 0) energy_partial[(size_t)pair * gridDim.x + chunk] = S.s_e[0] + S.s_e[1];
     if (STAMPS) __builtin_amdgcn_s_waitcnt(0);   // all of this wave's stores have been acknowledged
     LIN_STAMP(6);
 }
@@ -975,7 +1039,6 @@ __global__ void __launch_bounds__(256) k_ef_remove_points(int nF, int nP, uint8_
 //   top: task = (pair, row r of 11, column group g of 3), chunks 0 .. top_chunks-1 in order
 //   SC : task = (host, tile A of 10, row r of 16, column group g of 4, part p of 4); part p sums chunks [p*per, (p+1)*per), per =
 //        ceil(sc_chunks / 4), and four neighbouring lanes combine (p0 + p1) + (p2 + p3) -- a fixed order, the same on every path.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int PM>
 __device__ __forceinline__ void sum4_chunks_f64(__amdgpu_buffer_rsrc_t rsrc, int voff, int chunk_bytes, int c0, int cn, int c_last, double* acc4) {
     u32x4 v[PM];

@@ -317,10 +317,12 @@ def test_tolerance_mode_arithmetic(api, orc, cfg):
     r1, H1, b1 = G.resAndGS(0, start, 0.01, 1.0, 20.0)
     G.set_arith(0)
     r0, H0, b0 = G.resAndGS(0, start, 0.01, 1.0, 20.0)
-    assert abs(r1[1] - r0[1]) <= 2 and rel_err(r1[0], r0[0]) < 1e-4
-    assert rel_err(H1, H0) < 1e-4 and rel_err(b1, b0) < 1e-4
-    inc1, inc0 = np.linalg.solve(H1 + 0.01 * np.diag(np.diag(H1)), -b1), np.linalg.solve(H0 + 0.01 * np.diag(np.diag(H0)), -b0)
-    assert rel_err(inc1, inc0) < 1e-4
+    assert abs(r1[1] - r0[1]) <= 2
+    if r1[1] == r0[1] and r1[5] == r0[5]:       # no point sits on a decision boundary (bounds, cutoff) that the last digits could flip
+        assert rel_err(r1[0], r0[0]) < 1e-4
+        assert rel_err(H1, H0) < 1e-4 and rel_err(b1, b0) < 1e-4
+        inc1, inc0 = np.linalg.solve(H1 + 0.01 * np.diag(np.diag(H1)), -b1), np.linalg.solve(H0 + 0.01 * np.diag(np.diag(H0)), -b0)
+        assert rel_err(inc1, inc0) < 1e-4
     # a whole trackNewestCoarse call in tolerance mode against the exact oracle
     G.set_arith(1)
     okg, pg, ag, lrg, _, _ = G.trackNewestCoarse(start, (0.0, 0.0), P.levels - 1)
