@@ -746,10 +746,12 @@ __global__ void __launch_bounds__(256) k_ef_copy_publish(const double* __restric
     if (threadIdx.x == 0) publish_when_all_done(ctr, gridDim.x, flag, seq);
 }
 
-static int lin_chunks_for_np(const sdvgn_ef* e) {   // k_ef_linearize: 128 residuals per workgroup
+static int lin_groups(const sdvgn_ef* e) { return (e->C.debug_flags & 256) ? 1 : 2; }   // residual groups (64 residuals x 2 role waves) per workgroup
+static int lin_chunks_for_np(const sdvgn_ef* e) {   // k_ef_linearize: 64 x groups residuals per workgroup
     int mx = 1;
     for (int h = 0; h < e->nF; ++h) mx = std::max(mx, e->hostP0[h + 1] - e->hostP0[h]);
-    return std::min(2 * kMaxChunks, (mx + 127) / 128);
+    const int per = 64 * lin_groups(e);
+    return std::min(kMaxChunks * 256 / per, (mx + per - 1) / per);
 }
 // launches PointFrameResidual::linearize over the window; returns the number of energy partials written (128-residual granularity)
 static int ef_launch_linearize(sdvgn_ef* e) {
@@ -764,6 +766,7 @@ static int ef_launch_linearize(sdvgn_ef* e) {
         hipEventRecord(ev0, e->stream);
     }
     if ((e->C.debug_flags & 32) && e->dbg_stamps) k_ef_linearize<true><<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
+    else if (lin_groups(e) == 1) k_ef_linearize<false, 1><<<dim3(chunks, pairs), 128, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
     else k_ef_linearize<false><<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
     if (ev1) hipEventRecord(ev1, e->stream);
     return chunks * pairs;
@@ -879,7 +882,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
         bad |= hipHostMalloc((void**)&e->solve_stamps, sizeof(unsigned long long) * 16) != hipSuccess;
         if (!bad) std::memset(e->solve_stamps, 0, sizeof(unsigned long long) * 16);
     }
-    bad |= dev_alloc(&e->energy_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * 2);
+    bad |= dev_alloc(&e->energy_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * 4);
     bad |= dev_alloc(&e->top_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * kTopP);
     bad |= dev_alloc(&e->sc_partial, (size_t)SDVGN_MAX_FRAMES * kMaxChunks * kScP);
     bad |= dev_alloc(&e->nres_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks);

@@ -301,9 +301,9 @@ __device__ __forceinline__ void lin_phase_c(const EFConst& C, const EFArrays& A,
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned lin_u32x2 __attribute__((ext_vector_type(2)));
-template <bool STAMPS>
-__global__ void __launch_bounds__(256) k_ef_linearize(EFConst Cin, EFArrays A, const PrecalcDev* __restrict__ precalc,
-                                                       double* __restrict__ energy_partial) {
+template <bool STAMPS, int GROUPS = 2>
+__global__ void __launch_bounds__(128 * GROUPS) k_ef_linearize(EFConst Cin, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                               double* __restrict__ energy_partial) {
     const EFConst C = ef_const(Cin, A);
     __shared__ LinSmem S;
     int pair = blockIdx.y, chunk = blockIdx.x;
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst Cin, EFArrays A, c
     }
     const int h = pair / C.nF, t = pair % C.nF;
     const PrecalcDev pc = precalc[pair];
-    if (h == t || chunk * 128 >= pc.np) {     // nothing to linearise in this workgroup (uniform: before any barrier)
+    if (h == t || chunk * (64 * GROUPS) >= pc.np) {     // nothing to linearise in this workgroup (uniform: before any barrier)
         if (threadIdx.x == 0) energy_partial[(size_t)pair * gridDim.x + chunk] = 0.0;
         return;
     }
@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst Cin, EFArrays A, c
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int role = wave & 1, grp = wave >> 1;
-    const int pl = chunk * 128 + grp * 64 + lane;
+    const int pl = chunk * (64 * GROUPS) + grp * 64 + lane;
     const bool active = pl < pc.np;
     const int p = pc.P0 + (active ? pl : 0);
     const size_t slots = (size_t)C.nF * C.nP;
@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(256) k_ef_linearize(EFConst Cin, EFArrays A, c
         if (lane == 63) S.s_e[grp] = ws;
     }
     __syncthreads();
-    if (threadIdx.x == 0) energy_partial[(size_t)pair * gridDim.x + chunk] = S.s_e[0] + S.s_e[1];
+    if (threadIdx.x == 0) energy_partial[(size_t)pair * gridDim.x + chunk] = GROUPS == 2 ? S.s_e[0] + S.s_e[1] : S.s_e[0];
     if (STAMPS) __builtin_amdgcn_s_waitcnt(0);   // all of this wave's stores have been acknowledged
     LIN_STAMP(6);
 }
