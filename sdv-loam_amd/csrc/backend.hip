@@ -1851,7 +1851,7 @@ int sdvgn_ef_marginalize_points(sdvgn_ef* e, const unsigned char* marg, const un
     for (int h = 0; h < nF; ++h) mx = std::max(mx, e->hostP0[h + 1] - e->hostP0[h]);
     const int sc_chunks = std::min(kMaxChunks, (mx + 127) / 128);
     const int sc_ppb = ((mx + sc_chunks - 1) / sc_chunks + 63) / 64 * 64;
-    const int ntop = pairs * kTopE, nsc = nF * kScE, n_top = chunks * pairs, n_pt = (e->nP + 63) / 64;
+    const int n_top = chunks * pairs, n_pt = (e->nP + 63) / 64;
     // addPoint<2> + AccumulatedSCHessian::addPoint(p, false) over the flagged points (priorF *= setting_idepthFixPriorMargFac inside)
     k_ef_marg_stage1<<<n_top + n_pt, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, chunks, n_top,
                                                           e->marg_mask_dev, e->ppriorF);
