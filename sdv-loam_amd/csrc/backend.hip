@@ -143,7 +143,6 @@ struct sdvgn_ef {
     ImmPrecalc* imm_pc_host = nullptr;      // pinned
     void* imm_stage = nullptr;              // pinned candidate / result staging, grown on demand
     size_t imm_stage_bytes = 0;
-    unsigned short* sc_off_dev = nullptr;   // packed upper-triangle index (53x53) -> offset inside the 10 SC tiles
     double* acc_dev = nullptr;    // packed: top [nF*nF][256] | sc [nF][2560] | resInA
     double* acc_host = nullptr;   // pinned; the reduce kernels write it DIRECTLY (zero-copy) when no all-reduce is installed
     double* stats_host = nullptr; // pinned, 4 doubles: same for k_ef_sum_stats
@@ -160,12 +159,10 @@ struct sdvgn_ef {
     const PrecalcDev* precalc_staged = nullptr;   // pinned half the last ef_upload_precalc filled
     bool in_optimize_loop = false;                // finish_solve then also does doStepFromBackup's host part before its launch
     float step_sumT = 0, step_sumR = 0;
-    hipEvent_t ev_top = nullptr;  // (unused by the flag path; kept for the event fallback)
     ncclComm_t rccl_comm = nullptr;   // cfg4 with the collectives issued by the library itself (sdvgn_ef_init_rccl)
     int* flags_host = nullptr;    // pinned: [0] top accumulators done, [1] all accumulators done, [2] linearize statistics done
     unsigned* done_ctr = nullptr; // device: workgroup counters for the multi-workgroup publishers (2)
     int seq_top = 0, seq_acc = 0, seq_stats = 0;
-    bool split_pending = false;   // the SC part of acc_host is still in flight on the stream
     bool acc_in_host = false;     // the last accumulate wrote acc_host directly (acc_dev not updated)
     double* stats_dev = nullptr;   // {linearize energy, L-energy point part, sum step^2, sum |idepth_backup|}
     bool own_acc = true, own_stats = true;
@@ -628,15 +625,6 @@ __global__ void k_ef_sum_energy(const double* __restrict__ partial, int n, doubl
     for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) out[0] = s[0];
 }
-__global__ void k_ef_sum_nres(const int* __restrict__ partial, int n, double* __restrict__ out) {
-    __shared__ int s[256];
-    int a = 0;
-    for (int i = threadIdx.x; i < n; i += 256) a += partial[i];
-    s[threadIdx.x] = a;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) out[0] = (double)s[0];
-}
 // mode 0: backup = idepth ; 1: idepth = idepth_zero = backup + fac*step ; 2: idepth = idepth_zero = backup
 __global__ void k_ef_point_step(int nP, int mode, float fac, float* __restrict__ pid, float* __restrict__ pidz, float* __restrict__ backup,
                                 const float* __restrict__ step, float* __restrict__ pdeltaF) {
@@ -886,7 +874,6 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->top_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * kTopP);
     bad |= dev_alloc(&e->sc_partial, (size_t)SDVGN_MAX_FRAMES * kMaxChunks * kScP);
     bad |= dev_alloc(&e->nres_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks);
-    bad |= dev_alloc(&e->sc_off_dev, (size_t)kScE);
     bad |= dev_alloc(&e->imm_pc_dev, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES);
     const size_t accmax = (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kTopE + (size_t)SDVGN_MAX_FRAMES * kScE + 1;
     bad |= dev_alloc(&e->acc_dev, accmax);
@@ -911,18 +898,6 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     HIPCHK(hipMalloc((void**)&e->done_ctr, 2 * sizeof(unsigned)));
     HIPCHK(hipMemset(e->done_ctr, 0, 2 * sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void**)&e->imm_pc_host, sizeof(ImmPrecalc) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
-    HIPCHK(hipEventCreateWithFlags(&e->ev_top, hipEventDisableTiming));
-    {   // packed upper triangle of the live 53x53 SC Gram -> offset inside its ten 16x16 tiles (k_ef_sc_gram's layout)
-        unsigned short off[kScE];
-        int k = 0;
-        for (int r = 0; r < 53; ++r)
-            for (int c = r; c < 53; ++c) {
-                const int ti = r >> 4, tj = c >> 4;
-                const int a = ti * 4 - (ti * (ti - 1)) / 2 + (tj - ti);
-                off[k++] = (unsigned short)(a * 256 + (r & 15) * 16 + (c & 15));
-            }
-        HIPCHK(hipMemcpy(e->sc_off_dev, off, sizeof(off), hipMemcpyHostToDevice));
-    }
     HIPCHK(hipMemsetAsync(e->rflags, 0, slots, e->stream));
     HIPCHK(hipMemsetAsync(e->stats_partial, 0, sizeof(double) * 3 * (mp / 64 + 2), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -943,7 +918,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->rstate, e->rstate_new, e->rmatcher, e->renergy, e->renergy_new, e->renergy_wo, e->rres_toZero, e->J, e->JpJd, e->pHddA,
                     e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->images, e->img_stage,
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
-                    e->stats_dev, e->stats_partial, e->sc_off_dev, e->imm_pc_dev, e->rstate_new2, e->renergy_new2, e->renergy_wo2,
+                    e->stats_dev, e->stats_partial, e->imm_pc_dev, e->rstate_new2, e->renergy_new2, e->renergy_wo2,
                     e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->precalc_alt, e->dbg_stamps, e->marg_mask_dev, e->drop_mask_dev, e->th_dev, e->fin_dev,
                     e->win_dev, e->sstate_dev, e->calib_dev, e->rx_dev, e->sys_dev, e->pieces_dev};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -961,7 +936,6 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
     if (e->done_ctr) hipFree(e->done_ctr);
     if (e->imm_pc_host) hipHostFree(e->imm_pc_host);
     if (e->imm_stage) hipHostFree(e->imm_stage);
-    if (e->ev_top) hipEventDestroy(e->ev_top);
     if (e->own_stream) hipStreamDestroy(e->stream);
     delete e;
 }

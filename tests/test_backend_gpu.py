@@ -427,3 +427,31 @@ def test_full_size_linearize_other_window_sizes(api, orc, nF):
     check_linearize(G, O)
     G.applyRes(); O.applyRes()
     check_solve(G, O, 0, 0.1)
+
+
+@pytest.mark.parametrize("nF", [2, 3])
+def test_small_windows(api, orc, nF):
+    """Windows of 2 and 3 key-frames (system dimension 16 and 22: the blocked LDL^T ends on a 4- and a 2-column panel; optimize runs its
+    100 / 75 iteration budgets, FullSystemOptimize.cpp:349-350): linearise, solve and the whole loop against the oracle."""
+    from sdv_loam_amd import synthetic as syn
+    W = syn.make_window(w=320, h=160, nF=nF, pts_per_kf=150, seed=30 + nF, calib=dict(fx=200., fy=205., cx=159.5, cy=79.5), state_sigma=1e-3, idepth_sigma=0.01)
+    G, O = pair(api, orc, W)
+    check_linearize(G, O)
+    G.applyRes(); O.applyRes()
+    check_solve(G, O, 0, 0.1)
+    check_solve(G, O, 2, 1e-3)
+    G2, O2 = pair(api, orc, W)
+    tg, to = G2.optimize(), O2.optimize()
+    assert len(tg) == len(to) and np.array_equal(tg[:, 2], to[:, 2])
+    assert rel_err(G2.state()[1], O2.state()[1]) < 1e-4
+
+
+def test_many_points_per_host(api, orc):
+    """More than 4096 points on one host key-frame: the accumulate falls back to its two-launch form (several 64-point tiles per Schur-Gram
+    workgroup) and the reduce sums 64 chunks per host (16 per quarter) -- same results as the oracle."""
+    from sdv_loam_amd import synthetic as syn
+    W = syn.make_window(w=640, h=240, nF=3, pts_per_kf=4500, seed=41, calib=dict(fx=400., fy=410., cx=319.5, cy=119.5))
+    G, O = pair(api, orc, W)
+    check_linearize(G, O)
+    G.applyRes(); O.applyRes()
+    check_solve(G, O, 0, 0.1)
