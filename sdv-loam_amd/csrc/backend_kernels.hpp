@@ -644,9 +644,14 @@ struct PointSmem { float part[kMaxFrames][13][64]; };
 template <int MODE = 0>
 __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
                                            const int* __restrict__ phost, int p_base, int p_count, PointSmem& S,
-                                           const uint8_t* __restrict__ mask = nullptr, float* __restrict__ prior_w = nullptr) {
+                                           const uint8_t* __restrict__ mask = nullptr, float* __restrict__ prior_w = nullptr,
+                                           float (*pt_out)[64] = nullptr /* [6][64] LDS: Hcd[4], bdSum, Schur weight of the tile's points */) {
     float (*part)[13][64] = S.part;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (pt_out && wave == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pt_out[i][lane] = 0.0f;
+    }
     const int p = p_base + lane;
     const size_t slots = (size_t)C.nF * C.nP;
     int h = 0;
@@ -726,12 +731,19 @@ __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, 
     if (MODE == 2) { prior *= 600.0f * 600.0f; prior_w[p] = prior; }   // setting_idepthFixPriorMargFac, EnergyFunctional.cpp:527
     float H = HddA + HddL + prior;
     if (H < 1e-10) H = 1e-10;
-    A.pHdi[p] = (float)(1.0 / H);
+    const float hdi = (float)(1.0 / H);
+    A.pHdi[p] = hdi;
     float bds = bdA + bdL;
     if (MODE != 2) bds += prior * A.pdeltaF[p];  // shiftPriorToZero == true in accumulateSCF_MT, false in marginalizePointsF
     A.pbdSum[p] = bds;
 #pragma unroll
     for (int i = 0; i < 4; ++i) A.pHcd[(size_t)i * C.nP + p] = sum[2 + i] + sum[8 + i];
+    if (pt_out) {   // the fused accumulate's Schur Gram takes these from LDS (weight 0 for LiDAR points, AccumulatedSCHessian.cpp:36-37)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pt_out[i][lane] = sum[2 + i] + sum[8 + i];
+        pt_out[4][lane] = bds;
+        pt_out[5][lane] = A.psensor[p] ? 0.0f : hdi;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -934,6 +946,70 @@ __device__ __forceinline__ void sc_gram_wave(const EFConst& C, const EFArrays& A
 
 struct ScGramSmem { float tile[64 * kTileStride]; float wrow[64]; };
 
+// Single-tile Schur Gram of the fused accumulate (k_ef_acc_fused): the JpJdF / flag loads of the tile are issued BEFORE the per-point
+// phase -- they do not depend on it -- and Hcd / bdSum / weight arrive through LDS instead of a store -> load round trip through memory.
+template <int WAVE>
+__device__ __forceinline__ void sc_fused_prefetch(const EFConst& C, const EFArrays& A, int P0, int begin, int end, float* stage) {
+    const int lane = threadIdx.x & 63;
+    const size_t slots = (size_t)C.nF * C.nP;
+    const int pl = begin + lane;
+    const bool in = pl < end;
+    const int p = P0 + (in ? pl : 0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        constexpr int f0 = WAVE * 16;
+        const int f = f0 + j;
+        float v = 0.0f;
+        if (f < 48) {
+            const int t = f / 6, i = f - 6 * t;
+            const bool ok = in && t < C.nF;
+            const size_t s = ok ? (size_t)t * C.nP + p : 0;   // flag and value loaded side by side (one round trip), selected afterwards
+            const uint8_t fl = A.rflags[s];
+            const float jv = A.JpJd[(size_t)i * slots + s];
+            if (ok && (fl & RF_EXISTS) && (fl & RF_ACTIVE)) v = jv;
+        }
+        stage[j] = v;
+    }
+}
+template <int WAVE>
+__device__ __forceinline__ void sc_fused_finish(float* stage, const float (*pt)[64], float* tile, float* wrow, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        constexpr int f0 = WAVE * 16;
+        const int f = f0 + j;
+        if (f >= 48 && f < 52) stage[j] = pt[f - 48][lane];
+        else if (f == 52) stage[j] = pt[4][lane];
+        tile[(WAVE * 16 + j) * kTileStride + lane] = stage[j];
+    }
+    if (WAVE == 3) wrow[lane] = pt[5][lane];
+    __syncthreads();
+    constexpr int NQ = (WAVE + 8 < 10) ? 3 : 2;   // tiles WAVE, WAVE+4, WAVE+8 (< 10)
+    f32x4 acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q] = (f32x4){0, 0, 0, 0};
+    const int f = lane & 15, kq = lane >> 4;
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+        const int k = ks * 4 + kq;
+        float frag[4];
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) frag[ti] = tile[(ti * 16 + f) * kTileStride + k];
+        const float w = wrow[k];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ScTile<WAVE>::ti] * w, frag[ScTile<WAVE>::tj], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ScTile<WAVE + 4>::ti] * w, frag[ScTile<WAVE + 4>::tj], acc[1], 0, 0, 0);
+        if (NQ == 3) acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ScTile<(WAVE + 8) % 10>::ti] * w, frag[ScTile<(WAVE + 8) % 10>::tj], acc[2], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int a = WAVE + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[a * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[q][r];
+    }
+}
+
+
+
 template <int MODE = 0>
 __device__ __forceinline__ void sc_gram_body(const EFConst& C, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
                                              float* __restrict__ partial, int pts_per_block, int bx, int h, int gx, ScGramSmem& S,
@@ -958,7 +1034,8 @@ __global__ void __launch_bounds__(256) k_ef_sc_gram(EFConst C, EFArrays A, const
 
 // The whole accumulate of solveSystemF in ONE launch (windows with <= 64 * kMaxChunks points per host frame): workgroups [0, n_sc) take
 // one 64-point tile of one host frame each -- first the per-point sums of that tile (point_body), then, behind a workgroup barrier, its
-// Schur Gram (sc_gram_body reads the Hcd / bdSum / HdiF this workgroup just wrote) -- and the remaining workgroups the top Grams.  The
+// Schur Gram (its JpJdF loads already in flight before the per-point phase; Hcd / bdSum / weight through LDS) -- and the remaining
+// workgroups the top Grams.  The
 // two kinds are independent of each other, so the per-point launch + its kernel boundary leave the critical path of the loop body.
 __global__ void __launch_bounds__(256) k_ef_acc_fused(EFConst Cin, EFArrays A, const PrecalcDev* __restrict__ precalc,
                                                       const int* __restrict__ phost, float* __restrict__ top_partial,
@@ -970,10 +1047,29 @@ __global__ void __launch_bounds__(256) k_ef_acc_fused(EFConst Cin, EFArrays A, c
     if (b < n_sc) {
         const int h = b / sc_chunks, bx = b - h * sc_chunks;
         const int P0 = precalc[h * C.nF + h].P0, np = precalc[h * C.nF + h].np;   // np == 0 outside this rank's shard
-        const int begin = bx * 64;
-        if (begin < np) point_body(C, A, precalc, phost, P0 + begin, min(64, np - begin), S.p);
+        const int begin = bx * 64, end = min(np, begin + 64);
+        __shared__ float pt[6][64];
+        const int wave = threadIdx.x >> 6;
+        float stage[16];
+        switch (wave) {   // wave-uniform
+            case 0: sc_fused_prefetch<0>(C, A, P0, begin, end, stage); break;
+            case 1: sc_fused_prefetch<1>(C, A, P0, begin, end, stage); break;
+            case 2: sc_fused_prefetch<2>(C, A, P0, begin, end, stage); break;
+            default: sc_fused_prefetch<3>(C, A, P0, begin, end, stage); break;
+        }
+        if (begin < np) point_body(C, A, precalc, phost, P0 + begin, end - begin, S.p, nullptr, nullptr, pt);
+        else if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) pt[i][threadIdx.x & 63] = 0.0f;
+        }
         __syncthreads();
-        sc_gram_body(C, A, precalc, sc_partial, 64, bx, h, sc_chunks, S.s);
+        float* out = sc_partial + ((size_t)h * sc_chunks + bx) * 10 * 256;
+        switch (wave) {
+            case 0: sc_fused_finish<0>(stage, pt, S.s.tile, S.s.wrow, out); break;
+            case 1: sc_fused_finish<1>(stage, pt, S.s.tile, S.s.wrow, out); break;
+            case 2: sc_fused_finish<2>(stage, pt, S.s.tile, S.s.wrow, out); break;
+            default: sc_fused_finish<3>(stage, pt, S.s.tile, S.s.wrow, out); break;
+        }
     } else {
         const int q = b - n_sc;
         top_gram_body(C, A, precalc, top_partial, nres_partial, q % top_chunks, q / top_chunks, top_chunks, S.t);
