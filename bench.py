@@ -303,11 +303,16 @@ def tracker_extras(torch, local, batch, oracle, want_cpu):
     for B in (1, 31):
         starts = np.stack([oracle.se3_mul(oracle.se3_exp(syn.perturbation(i)), P.gt_pose) for i in range(B)])
         affs = np.tile([0.02, 2.0], (B, 1))
-        G.trackBatch(starts, affs, 3)
-        t0 = time.perf_counter()
-        for _ in range(20):
+        for team, tag in ((0, ""), (-1, "_one_workgroup")):      # k_track_team (automatic team size) and k_track
+            G.set_team(team)
             G.trackBatch(starts, affs, 3)
-        out["track_call_device_resident_B%d_ms" % B] = 1e3 * (time.perf_counter() - t0) / 20
+            t0 = time.perf_counter()
+            for _ in range(20):
+                G.trackBatch(starts, affs, 3)
+            out["track_call_device_resident_B%d%s_ms" % (B, tag)] = 1e3 * (time.perf_counter() - t0) / 20
+            if team == 0:
+                out["track_call_device_resident_B%d_team" % B] = G.last_team()
+        G.set_team(0)
     # (ii-b) PCIe-inclusive: a new frame handed over as a host buffer (H2D of w*h floats + 4 pyramid launches) followed by one
     # device-resident track -- what a caller that does not keep images on the device pays per frame.  Never the headline value.
     st1 = start[None].copy()
@@ -350,11 +355,15 @@ def tracker_extras(torch, local, batch, oracle, want_cpu):
     for _ in range(10):
         GT.trackNewestCoarse(dense_pose, (0.0, 0.0), 3)
     out["dense_template_track_call_host_driven_ms"] = 1e3 * (time.perf_counter() - t0) / 10
-    GT.trackBatch(dense_pose[None], np.zeros((1, 2)), 3)
-    t0 = time.perf_counter()
-    for _ in range(10):
+    for team, tag in ((0, ""), (-1, "_one_workgroup")):
+        GT.set_team(team)
         GT.trackBatch(dense_pose[None], np.zeros((1, 2)), 3)
-    out["dense_template_track_call_device_resident_ms"] = 1e3 * (time.perf_counter() - t0) / 10
+        t0 = time.perf_counter()
+        for _ in range(10):
+            GT.trackBatch(dense_pose[None], np.zeros((1, 2)), 3)
+        out["dense_template_track_call_device_resident%s_ms" % tag] = 1e3 * (time.perf_counter() - t0) / 10
+        if team == 0:
+            out["dense_template_team"] = GT.last_team()
     del GT
     # (iii) batched roofline run of the fused tracker kernel
     poses = np.stack([oracle.se3_mul(oracle.se3_exp(syn.perturbation(1000 + i)), P.gt_pose) for i in range(batch)])

@@ -60,6 +60,12 @@ int sdvgn_tracker_set_precision(sdvgn_tracker* t, int mode);
  * 1 = tolerance mode: fused multiply-adds and reciprocal-based divisions (v_rcp_f32 + one Newton step).  BASELINE.json's contract for this
  * path is 1e-4 relative on pose increments; mode 1 meets it (tests/test_tracker_gpu.py) with ~40 % fewer vector instructions per point. */
 int sdvgn_tracker_set_arith(sdvgn_tracker* t, int mode);
+/* Workgroups per pose hypothesis of sdvgn_tracker_track_batch: 0 = automatic (one pass of 256-lane workgroups over the largest level, at
+ * most 32, as long as the whole launch is resident at once; otherwise one 1024-lane workgroup per hypothesis), -1 = always one workgroup
+ * (k_track), 1..32 = that many (k_track_team).  Results do not depend on it beyond the summation order of the 52 totals.
+ * sdvgn_tracker_get_team: what the last track_batch call used (0 = k_track). */
+int sdvgn_tracker_set_team(sdvgn_tracker* t, int team);
+int sdvgn_tracker_get_team(sdvgn_tracker* t);
 
 /* CoarseTracker::makeK(CalibHessian*)   CoarseTracker.cpp:77-106  (level-0 fx,fy,cx,cy = HCalib->fxl()...) */
 int sdvgn_tracker_make_K(sdvgn_tracker* t, float fx, float fy, float cx, float cy);

@@ -26,6 +26,8 @@ PROTOTYPES = [
     ("sdvgn_tracker_set_settings", C.c_int, [vp, C.c_float, C.c_float, C.c_float, C.c_float]),
     ("sdvgn_tracker_set_precision", C.c_int, [vp, C.c_int]),
     ("sdvgn_tracker_set_arith", C.c_int, [vp, C.c_int]),
+    ("sdvgn_tracker_set_team", C.c_int, [vp, C.c_int]),
+    ("sdvgn_tracker_get_team", C.c_int, [vp]),
     ("sdvgn_tracker_res_and_gs_multi", C.c_int, [vp, C.c_int, C.c_int, vp, vp, f64p, f64p, C.c_float, vp]),
     ("sdvgn_tracker_ref_dev", vp, [vp, C.c_int]),
     ("sdvgn_tracker_make_K", C.c_int, [vp, C.c_float, C.c_float, C.c_float, C.c_float]),
@@ -136,6 +138,13 @@ class CoarseTracker:
 
     def set_arith(self, mode):
         check(self.L.sdvgn_tracker_set_arith(self.h_, mode))
+
+    def set_team(self, team):
+        """Workgroups per hypothesis of trackBatch: 0 automatic, -1 one 1024-lane workgroup (k_track), 1..32 fixed (k_track_team)."""
+        check(self.L.sdvgn_tracker_set_team(self.h_, team))
+
+    def last_team(self):
+        return self.L.sdvgn_tracker_get_team(self.h_)
 
     def ref_dev(self, lvl):
         return self.L.sdvgn_tracker_ref_dev(self.h_, lvl)

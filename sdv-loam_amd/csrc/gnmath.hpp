@@ -66,6 +66,31 @@ GN_HD Pose compose(const Pose& A, const Pose& B) {
     return C;
 }
 
+// sin and cos of one argument.  Host: libm.  Device: Cody-Waite reduction by pi/2 (two-part constant, fused multiply-adds) and the
+// fdlibm kernel polynomials on [-pi/4, pi/4] -- within ~1 ulp of libm for |x| < 1e5 (rotation increments are far below that; beyond, the
+// reduction loses digits gracefully).  The library's sin / cos carry a Payne-Hanek path for huge arguments whose tables live in the
+// private segment: with this, the device-resident LM kernels need no scratch memory.
+GN_HD void sincos_d(double x, double* sn, double* cs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double k = rint(x * 6.36619772367581382433e-01);                      // x * 2/pi
+    double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
+    r = __builtin_fma(-k, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                      z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double s = r + (r * z) * ps;
+    const double c = (1.0 - 0.5 * z) + (z * z) * pc;
+    const int q = (int)k & 3;
+    const double ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    *sn = (q & 2) ? -ss : ss;
+    *cs = ((q + 1) & 2) ? -cc : cc;
+#else
+    *sn = sin(x); *cs = cos(x);
+#endif
+}
+
 // exp of a twist [upsilon | omega]  (Sophus SE3::exp, se3.hpp:406-427; SO3::expAndTheta so3.hpp:342-369)
 GN_HD Pose exp_se3(const double* a) {
     const double wx = a[3], wy = a[4], wz = a[5];
@@ -78,8 +103,10 @@ GN_HD Pose exp_se3(const double* a) {
         im = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
         re = 1.0 - 0.5 * th2 + (1.0 / 384.0) * th4;
     } else {
-        im = sin(0.5 * th) / th;
-        re = cos(0.5 * th);
+        double sh_, ch_;
+        sincos_d(0.5 * th, &sh_, &ch_);
+        im = sh_ / th;
+        re = ch_;
     }
     Pose P;
     P.q[0] = im * wx; P.q[1] = im * wy; P.q[2] = im * wz; P.q[3] = re;
@@ -95,8 +122,10 @@ GN_HD Pose exp_se3(const double* a) {
     if (tiny) {
         rotation_matrix(P.q, V);
     } else {
-        const double c1 = (1.0 - cos(th)) / th2;
-        const double c2 = (th - sin(th)) / (th2 * th);
+        double st_, ct_;
+        sincos_d(th, &st_, &ct_);
+        const double c1 = (1.0 - ct_) / th2;
+        const double c2 = (th - st_) / (th2 * th);
         for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c1 * W[i] + c2 * W2[i];
     }
     for (int i = 0; i < 3; ++i) P.t[i] = V[i * 3] * a[0] + V[i * 3 + 1] * a[1] + V[i * 3 + 2] * a[2];
@@ -179,10 +208,13 @@ GN_HD void aff_from_to(float expF, float expT, double aF, double bF, double aT, 
 
 // In-place LDL^T with symmetric diagonal pivoting (largest |diag| first) + solve.  A is row-major NxN with
 // leading dimension lda; only the lower triangle is referenced; A and b are overwritten (b -> x).
-template <int MAXN>
-GN_HD void ldlt_solve_inplace(int n, double* A, int lda, double* b) {
-    int perm[MAXN];
-    double tmp[MAXN];
+// perm_ws / tmp_ws: optional caller-provided work space of MAXN entries each (a kernel passes LDS: no private-segment arrays).
+template <int MAXN, bool EXT_WS = false>
+GN_HD void ldlt_solve_inplace(int n, double* A, int lda, double* b, int* perm_ws = nullptr, double* tmp_ws = nullptr) {
+    int perm_local[EXT_WS ? 1 : MAXN];
+    double tmp_local[EXT_WS ? 1 : MAXN];
+    int* perm = EXT_WS ? perm_ws : perm_local;
+    double* tmp = EXT_WS ? tmp_ws : tmp_local;
 #define GN_A(r, c) A[(r) * lda + (c)]
     for (int k = 0; k < n; ++k) {
         int p = k;

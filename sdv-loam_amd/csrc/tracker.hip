@@ -77,6 +77,12 @@ struct sdvgn_tracker {
     int* status_dev = nullptr;
     int terms_lvl = -1;
     TrackState* track_host = nullptr;    // pinned
+    TeamMem* team_dev = nullptr;         // k_track_team: partial rows + counters per hypothesis (allocated on first use, zeroed)
+    int team_cap = 0;
+    int team_mode = 0;                   // sdvgn_tracker_set_team: 0 automatic, -1 always k_track (one workgroup), T >= 1 fixed team size
+    int last_team = 0;                   // team size of the last track_batch call (0: k_track)
+    int track_seq = 0;                   // sequence number of track_batch calls (TrackState::done)
+    unsigned team_seq = 0;               // launch number of k_track_team (20 bits; part of every exchanged word's tag)
 
     // side outputs of the last track() call
     std::vector<double> trace;
@@ -306,6 +312,7 @@ int sdvgn_tracker_create(sdvgn_tracker** out, int device, int w0, int h0, int le
     HIPCHK(hipMalloc(&t->terms_dev, sizeof(float) * 8 * (size_t)max_points));
     HIPCHK(hipMalloc(&t->status_dev, sizeof(int) * (size_t)max_points));
     HIPCHK(hipHostMalloc(&t->track_host, sizeof(TrackState) * max_batch));
+    std::memset(t->track_host, 0, sizeof(TrackState) * max_batch);
     HIPCHK(hipStreamSynchronize(t->stream));
     *out = t;
     return SDVGN_OK;
@@ -322,7 +329,7 @@ void sdvgn_tracker_destroy(sdvgn_tracker* t) {
     for (int l = 0; l < t->levels; ++l) { DFREE(t->pc_dev[l]); DFREE(t->pyr_dev[l]); if (t->pyr_half_dev[l]) DFREE(t->pyr_half_dev[l]); }
     DFREE(t->img_stage_dev); DFREE(t->params_dev); DFREE(t->ptrs_dev); HFREE(t->params_host); DFREE(t->partial_dev);
     DFREE(t->out_dev); HFREE(t->out_host); HFREE(t->flag_host); DFREE(t->terms_dev); DFREE(t->status_dev);
-    HFREE(t->track_host);
+    HFREE(t->track_host); DFREE(t->team_dev);
     HFREE(t->sp_stage_host); HFREE(t->sp_io_host);
     DFREE(t->tp_static_dev); HFREE(t->tp_state_host);
     DFREE(t->cd_maps); DFREE(t->cd_rows); HFREE(t->cd_n_host); HFREE(t->cd_stage);
@@ -346,6 +353,13 @@ int sdvgn_tracker_set_settings(sdvgn_tracker* t, float huberTH, float coarseCuto
     t->huberTH = huberTH; t->coarseCutoffTH = coarseCutoffTH; t->affineOptModeA = affA; t->affineOptModeB = affB;
     return SDVGN_OK;
 }
+
+int sdvgn_tracker_set_team(sdvgn_tracker* t, int team) {
+    if (!t || team < -1 || team > kTeamMax) return SDVGN_E_ARG;
+    t->team_mode = team;
+    return SDVGN_OK;
+}
+int sdvgn_tracker_get_team(sdvgn_tracker* t) { return t ? t->last_team : SDVGN_E_ARG; }
 
 int sdvgn_tracker_set_arith(sdvgn_tracker* t, int mode) {
     if (!t || mode < 0 || mode > 1) return SDVGN_E_ARG;
@@ -545,10 +559,49 @@ int sdvgn_tracker_track_batch(sdvgn_tracker* t, int B, double* pose7_io, double*
         for (int i = 0; i < 5; ++i) s.minRes[i] = minRes ? minRes[5 * b + i] : NAN;
         s.ok = 0; s.ntrials = 0;
     }
-    // no copy-engine transfers: the constants are a kernel argument, the per-hypothesis state blocks stay in pinned host memory
-    k_track<<<B, kTrackThreads, 0, t->stream>>>(tc, t->track_host);
+    // no copy-engine transfers: the constants are a kernel argument, the per-hypothesis state blocks stay in pinned host memory.
+    // Team size: enough workgroups of 256 lanes for one pass over the largest level (at most kTeamMax), as long as every workgroup of
+    // the launch is resident at once (two 256-lane workgroups per CU at its register count: 512 on 256 CUs); beyond that: one workgroup per hypothesis.
+    const int seq = ++t->track_seq;
+    int T = 0;
+    {
+        int nmax = 0;
+        for (int l = 0; l <= coarsestLvl; ++l) nmax = t->pc_n[l] > nmax ? t->pc_n[l] : nmax;
+        const int Bpad = (B + 7) & ~7;
+        int want = t->team_mode > 0 ? t->team_mode : (nmax + kTeamThreads - 1) / kTeamThreads;
+        if (want > kTeamMax) want = kTeamMax;
+        if (want > 512 / Bpad) want = 512 / Bpad;
+        // a fixed request of 1 runs the team kernel with a single member (tests); automatic mode needs at least two
+        if (t->team_mode >= 0 && (want >= 2 || (t->team_mode > 0 && want >= 1))) T = want;
+    }
+    t->last_team = T;
+    if (T >= 1) {
+        if (t->team_cap < B) {
+            HIPCHK(hipStreamSynchronize(t->stream));
+            if (t->team_dev) HIPCHK(hipFree(t->team_dev));
+            t->team_dev = nullptr; t->team_cap = 0;
+            const int cap = t->max_batch < 512 ? t->max_batch : 512;   // at most 512 resident workgroups
+            HIPCHK(hipMalloc(&t->team_dev, sizeof(TeamMem) * (size_t)cap));
+            HIPCHK(hipMemsetAsync(t->team_dev, 0, sizeof(TeamMem) * (size_t)cap, t->stream));
+            t->team_cap = cap;
+        }
+        const int Bpad = (B + 7) & ~7;
+        if (++t->team_seq >= (1u << 20)) {   // tags would repeat: start over on zeroed rows
+            HIPCHK(hipMemsetAsync(t->team_dev, 0, sizeof(TeamMem) * (size_t)t->team_cap, t->stream));
+            t->team_seq = 1;
+        }
+        k_track_team<<<Bpad * T, kTeamThreads, 0, t->stream>>>(tc, t->track_host, t->team_dev, B, T, t->team_seq << 12, seq);
+    } else {
+        k_track<<<B, kTrackThreads, 0, t->stream>>>(tc, t->track_host, seq);
+    }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(t->stream));
+    // every hypothesis' posting workgroup publishes `seq` behind its results: spin on the flags instead of a stream synchronisation
+    for (int b = 0; b < B; ++b) HIPCHK(wait_flag(&t->track_host[b].done, seq, t->stream));
+    if (T >= 1) {
+        bool dead = false;
+        for (int b = 0; b < B; ++b) dead = dead || t->track_host[b].ok == -2;
+        if (dead) return SDVGN_E_STATE;   // an exchange gave up (a team member never arrived)
+    }
     for (int b = 0; b < B; ++b) {
         const TrackState& s = t->track_host[b];
         std::memcpy(pose7_io + 7 * b, s.pose, sizeof(double) * 7);
@@ -559,7 +612,8 @@ int sdvgn_tracker_track_batch(sdvgn_tracker* t, int B, double* pose7_io, double*
     }
     if (getenv("SDVGN_PROFILE")) {
         const TrackState& s = t->track_host[0];
-        fprintf(stderr, "[sdvgn profile] k_track hyp0: serial %lld cyc, solve %lld cyc, eval %lld cyc over %lld evals, %d trials\n", s.dbg_cycles[0], s.dbg_cycles[1],
+        fprintf(stderr, "[sdvgn profile] team %d (its stamps: 10 ns ticks); ", T);
+        fprintf(stderr, "[sdvgn profile] k_track hyp0: state machine + solves %lld, %lld solves, evaluations %lld over %lld evals, %d trials\n", s.dbg_cycles[0], s.dbg_cycles[1],
                 s.dbg_cycles[2], s.dbg_cycles[3], s.ntrials);
     }
     return SDVGN_OK;

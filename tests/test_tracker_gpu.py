@@ -155,6 +155,52 @@ def test_track_batch_device_resident(api, orc, seed):
         assert np.allclose(lrb[i, :P.levels], lro[:P.levels], rtol=1e-4)
 
 
+@pytest.mark.parametrize("team", [-1, 1, 2, 3, 8, 32])
+def test_track_batch_team_sizes(api, orc, team):
+    """k_track (one workgroup per hypothesis) and k_track_team with 1..32 workgroups per hypothesis: the oracle's result for every
+    hypothesis, whatever the team size; consecutive calls on the same handle (the exchange counters are restored by the kernel)."""
+    P = small_problem(seed=4, n=900, w=320, h=240, levels=3, noise=1.5)
+    G, O = pair(api, orc, P)
+    G.set_team(team)
+    B = 11                                       # not a multiple of 8: the padded tail of the grid leaves at once
+    starts = np.stack([start_pose(orc, P, 40 + i) for i in range(B)])
+    ref = [O.trackNewestCoarse(starts[i], (0.0, 0.0), P.levels - 1) for i in range(B)]
+    first = None
+    for rep in range(3):
+        okb, pb, ab, lrb, flb = G.trackBatch(starts, np.zeros((B, 2)), P.levels - 1)
+        assert G.last_team() == (0 if team < 0 else team)
+        for i in range(B):
+            oko, po, ao, lro, flo, _ = ref[i]
+            assert bool(okb[i]) == oko
+            dg = orc.se3_log(orc.se3_mul(pb[i], orc.se3_inverse(starts[i])))
+            do = orc.se3_log(orc.se3_mul(po, orc.se3_inverse(starts[i])))
+            assert rel_err(dg, do) < 1e-4, (i, dg, do)
+            assert np.allclose(ab[i], ao, rtol=1e-4, atol=1e-4)
+            assert np.allclose(lrb[i, :P.levels], lro[:P.levels], rtol=1e-4)
+            assert np.allclose(flb[i], flo, rtol=1e-4)
+        if first is None:
+            first = (pb.copy(), ab.copy(), lrb.copy())
+        else:                                    # deterministic: fixed summation order inside and across the workgroups
+            assert np.array_equal(pb, first[0]) and np.array_equal(ab, first[1]) and np.array_equal(lrb, first[2], equal_nan=True)
+
+
+def test_track_batch_team_abort_paths(api, orc):
+    """Level abort (lastRes > 1.5 minRes) and cutoff doubling + level repeat inside the team kernel: every workgroup of a team takes the
+    same exit."""
+    P = small_problem(seed=6, n=300, noise=8.0)
+    G, O = pair(api, orc, P)
+    G.set_team(4)
+    start = start_pose(orc, P, 6)
+    okb, pb, ab, lrb, _ = G.trackBatch(start[None], np.zeros((1, 2)), P.levels - 1, min_res=np.full((1, 5), 1e-3))
+    oko, po, _, lro, _, _ = O.trackNewestCoarse(start, (0.0, 0.0), P.levels - 1, min_res=[1e-3] * 5)
+    assert G.last_team() == 4 and not okb[0] and not oko
+    assert np.allclose(lrb[0], lro, rtol=1e-4, equal_nan=True)
+    okb, pb, ab, lrb, _ = G.trackBatch(P.gt_pose[None], np.array([[0.04, 72.5]]), P.levels - 1)
+    oko, po, ao, lro, _, tro = O.trackNewestCoarse(P.gt_pose, (0.04, 72.5), P.levels - 1)
+    assert tro[:, 14].max() > 1 and bool(okb[0]) == oko
+    assert np.allclose(ab[0], ao, rtol=1e-4, atol=1e-4)
+
+
 def test_track_abort_and_cutoff_repeat(api, orc):
     P = small_problem(seed=6, n=300, noise=8.0)
     G, O = pair(api, orc, P)
