@@ -660,6 +660,7 @@ static int struct_pose_run(sdvgn_tracker* t, int mode, int n, const float* u, co
     }
     std::memset(t->sp_io_host, 0, sizeof(StructIO));
     for (int i = 0; i < 7; ++i) t->sp_io_host->pose[i] = pose7_in[i];
+    const int seq = ++t->track_seq;
     // zero-copy: the kernel reads the 29 kB of packed inputs once, coalesced, straight from pinned host memory and keeps its
     // result block there too -- two copy-engine round trips (10-20 us each) would cost more than the whole kernel's arithmetic
     StructConst C;
@@ -669,9 +670,9 @@ static int struct_pose_run(sdvgn_tracker* t, int mode, int n, const float* u, co
     C.n = n; C.n_hosts = n_hosts; C.mode = mode;
     const float* ds = (const float*)t->sp_stage_host;
     k_struct_pose<<<1, kStructThreads, 0, t->stream>>>(C, ds, ds + np, ds + 2 * np, (const int*)(ds + 3 * np), ds + 6 * np,
-                                                     (const float2*)(ds + 4 * np), t->sp_io_host);
+                                                     (const float2*)(ds + 4 * np), t->sp_io_host, seq);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(t->stream));
+    HIPCHK(wait_flag(&t->sp_io_host->done, seq, t->stream));   // published behind the results: no stream synchronisation
     return SDVGN_OK;
 }
 
