@@ -563,19 +563,33 @@ def marginalize_extras(torch, W, G, want_cpu):
 HEAD_KW = dict(state_sigma=3e-3, idepth_sigma=0.02)   # headline window: perturbed so that optimize(6) mixes accepted and rejected steps
 
 
-def run_protocol(runners, bodies, world, reload_with=None, **opt_kw):
+def run_protocol(runners, bodies, world, reload_with=None, warm=None, **opt_kw):
     """The fresh-window protocol: one FullSystem::optimize call (its initial linearizeAll + applyRes, then `nb` loop bodies) per resident
-    window, all inside ONE timed region (barrier + synchronize on both sides, max over ranks).  Returns (seconds, traces)."""
+    window, all inside ONE timed region (barrier + synchronize on both sides, max over ranks).  Returns (seconds, traces).
+    warm = (handle, bodies): the untimed warm-up bodies run on a window of their own, AFTER the timed windows were (re)loaded, i.e. right
+    before the timed region -- a reload is tens of milliseconds of PCIe copies with idle compute units."""
     if reload_with is not None:
         for r in runners:
             (r.reload if hasattr(r, "reload") else r.load)(reload_with)
+    if warm is not None:
+        wr, wb = warm
+        done = 0
+        while done < wb:
+            nb = min(6, wb - done)
+            wr.optimize(nb, fixed_its=True, want_trace=False)
+            done += nb
     barrier_sync(world)
     t0 = time.perf_counter()
     traces = []
+    marks = []
     for i, nb in enumerate(bodies):
         traces.append(runners[i % len(runners)].optimize(nb, fixed_its=True, **opt_kw))
+        marks.append(time.perf_counter() - t0)
     barrier_sync(world)
-    return max_over_ranks(time.perf_counter() - t0, world), traces
+    dt = time.perf_counter() - t0
+    if os.environ.get("SDVGN_BENCH_DEBUG"):
+        sys.stderr.write("[bench] region %.1f us; calls returned at %s us\n" % (1e6 * dt, np.round(1e6 * np.array(marks[:8]), 1)))
+    return max_over_ranks(dt, world), traces
 
 
 def main():
@@ -615,20 +629,37 @@ def main():
     if runners is None:
         # 80 MB per window: every window of the timed region is resident in HBM before it starts (288 GB would hold thousands)
         runners = [backend_api.EnergyFunctional(Wh.w, Wh.h, max_points=Wh.nP, device=local).load(Wh) for _ in range(min(n_calls, 1024))]
-    # ---- warm-up: Wm bodies, then the windows are reloaded (untimed) -------------------------------------------------------------------
-    done = 0
-    while done < Wm:
-        nb = min(6, Wm - done)
-        runners[(done // 6) % len(runners)].optimize(nb, fixed_its=True, want_trace=False)
-        done += nb
+    # ---- warm-up: Wm bodies on a window of its own, right before the timed region (after the timed windows were reloaded, untimed) ----
+    warm_runner = type(runners[0])(Wh, rank, world, local) if hasattr(runners[0], "reload") else \
+        backend_api.EnergyFunctional(Wh.w, Wh.h, max_points=Wh.nP, device=local).load(Wh)
     # ---- timed region: K loop bodies = ceil(K / 6) optimize calls on fresh windows --------------------------------------------------------
-    dt, traces = run_protocol(runners, bodies, world, reload_with=Wh, want_trace=(world == 1))
+    # the timed windows were loaded when their handles were created and have never been optimised: fresh by construction, no reload
+    dt, traces = run_protocol(runners, bodies, world, reload_with=None, warm=(warm_runner, Wm), want_trace=False)
     value = (world if scaling == "weak" else 1) * K / dt
     single = world == 1
-    accepted_fraction = float(np.mean(np.concatenate([t[:, 2] for t in traces]))) if single else None
+    accepted_fraction = None
+    if single:   # every handle remembers the accepted steps of its last call
+        R = len(runners)
+        last = {j % R: bodies[j] for j in range(n_calls)}
+        accepted_fraction = float(sum(runners[i].accepted_steps() for i in last)) / float(sum(last.values()))
     it_us = np.concatenate([(r.ef if hasattr(r, "ef") else r).iteration_times_us() for r in runners[:n_calls]])
     iter_stats = dict(median_us=float(np.median(it_us)), p10_us=float(np.percentile(it_us, 10)), p90_us=float(np.percentile(it_us, 90)),
                       n=int(len(it_us))) if len(it_us) else None
+
+    # ---- the same protocol with every window handed over as HOST buffers inside the timed region (8 images + points + residuals over
+    # PCIe, ~80 MB per window): what a caller that keeps nothing on the device pays.  Never the headline value.
+    upload_inclusive = None
+    if single and not args.quick:
+        nu = min(4, len(runners))
+        ext.synchronize()
+        t0u = time.perf_counter()
+        for r in runners[:nu]:
+            r.load(Wh)
+            r.optimize(6, fixed_its=True, want_trace=False)
+        ext.synchronize()
+        dtu = time.perf_counter() - t0u
+        upload_inclusive = dict(value=6 * nu / dtu, unit="GN iters/s", ms_per_window=1e3 * dtu / nu,
+                                note="load() of the whole window from host buffers + optimize(6) per window, both timed (PCIe-inclusive)")
 
     # ---- N > 1 only: the same protocol as N independent replicas (every rank optimises its own copies of the full window, no
     # collective) -- the weak-scaling view next to the strong-scaling headline that configs[3] asks for ----
@@ -636,17 +667,17 @@ def main():
     if world > 1 and scaling == "strong":
         reps = [backend_api.EnergyFunctional(Wh.w, Wh.h, max_points=Wh.nP, device=local).load(Wh) for _ in range(min(n_calls, 16))]
         reps[0].optimize(min(6, max(Wm, 1)), fixed_its=True, want_trace=False)
-        dt_r, _ = run_protocol(reps, bodies, world, reload_with=Wh, want_trace=False)
+        dt_r, _ = run_protocol(reps, bodies, world, warm=(warm_runner, Wm), reload_with=Wh, want_trace=False)
         replicas_value = world * K / dt_r
         del reps
 
     value_relin = value_reuse = soak = other = lin_inloop = None
     if single:
         # ---- the same protocol with the reference's literal re-linearisation after every rejected step (A/B; results identical) ----
-        dt_l, _ = run_protocol(runners, bodies, world, reload_with=Wh, want_trace=False, relinearize_on_reject=True)
+        dt_l, _ = run_protocol(runners, bodies, world, warm=(warm_runner, Wm), reload_with=Wh, want_trace=False, relinearize_on_reject=True)
         value_relin = K / dt_l
         # ---- opt-in flag bit2: bodies that follow a rejected step re-use the stitched system (bit-identical results; extra key only) ----
-        dt_u, _ = run_protocol(runners, bodies, world, reload_with=Wh, want_trace=False, reuse_after_reject=True)
+        dt_u, _ = run_protocol(runners, bodies, world, warm=(warm_runner, Wm), reload_with=Wh, want_trace=False, reuse_after_reject=True)
         value_reuse = K / dt_u
         # ---- k_ef_linearize inside the loop: a HIP event pair around every launch of the same protocol (own pass: the event packets
         # cost ~2 us per body, so this pass is not the headline) ----
@@ -669,7 +700,7 @@ def main():
         for name, kw in (("unperturbed", {}), ("all_steps_accepted", dict(state_sigma=1e-2, idepth_sigma=0.05))):
             Wx = syn.make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=syn.KITTI00, **kw)
             nx = min(len(runners), 8)
-            dtx, trx = run_protocol(runners[:nx], [6] * nx, world, reload_with=Wx, want_trace=True)
+            dtx, trx = run_protocol(runners[:nx], [6] * nx, world, warm=(warm_runner, Wm), reload_with=Wx, want_trace=True)
             other[name] = dict(value=6 * nx / dtx, accepted_fraction=float(np.mean(np.concatenate([t[:, 2] for t in trx]))), window=kw)
         G.load(W)
     del runners
@@ -683,7 +714,7 @@ def main():
         W7 = syn.make_window(w=1200, h=360, nF=7, pts_per_kf=286, seed=0, calib=cal7, **HEAD_KW)
         r7 = [backend_api.EnergyFunctional(W7.w, W7.h, max_points=W7.nP, device=local).load(W7) for _ in range(8)]
         r7[0].optimize(6, fixed_its=True, want_trace=False)
-        dt7, tr7 = run_protocol(r7, [6] * 8, world, reload_with=W7, want_trace=True)
+        dt7, tr7 = run_protocol(r7, [6] * 8, world, warm=(warm_runner, Wm), reload_with=W7, want_trace=True)
         it7 = np.concatenate([r.iteration_times_us() for r in r7])
         ref_shape = dict(workload="7 key-frames x 286 points (2002 points, %d residuals), 1200x360" % W7.nR, value=48 / dt7, unit="GN iters/s",
                          accepted_fraction=float(np.mean(np.concatenate([t[:, 2] for t in tr7]))), median_body_us=float(np.median(it7)))
@@ -759,6 +790,7 @@ def main():
         "other_windows_same_protocol": other,
         "reference_shape_7kf_2000pts": ref_shape,
         "replicas_value_weak_scaling": replicas_value,
+        "value_window_upload_inclusive": upload_inclusive,
     }
     if rank == 0 and world == 1 and not args.quick:
         traffic, how = measure_traffic()

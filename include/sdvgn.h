@@ -11,8 +11,10 @@
  *   - every function returns 0 on success, a negative hipError_t (as -(int)err) on a HIP failure, or one of
  *     the SDVGN_E_* codes; nothing throws.  A library built without a usable GPU fails at *_create.
  *   - `pose7` is exactly Sophus `SE3d::data()`: [qx qy qz qw tx ty tz] (Eigen quaternion coeff order).
- *   - one handle owns one HIP stream and is single-threaded, matching the reference's mutex discipline
- *     (coarseTracker under trackMutex, coarseTracker_forNewKF under mapMutex; FullSystem.h:277-327).
+ *   - one handle works on one HIP stream and is single-threaded, matching the reference's mutex discipline
+ *     (coarseTracker under trackMutex, coarseTracker_forNewKF under mapMutex; FullSystem.h:277-327).  `stream` = NULL at *_create:
+ *     tracker handles share one library stream per device, window (ef) handles another -- a stream per handle would be a hardware
+ *     queue per handle, and the first launch on a queue that has been idle costs 0.2-0.5 ms.  Pass streams to overlap two handles.
  *   - pointers are HOST pointers unless the parameter name ends in `_dev`.
  */
 #ifndef SDVGN_H
@@ -40,7 +42,7 @@ typedef struct sdvgn_tracker sdvgn_tracker;
 /* CoarseTracker::CoarseTracker(int w,int h)   CoarseTracker.cpp:34-69.
  * `levels` = pyrLevelsUsed (globalCalib.cpp:25-30); level l is (w0>>l) x (h0>>l) (CoarseTracker.cpp:89-90).
  * `max_points` bounds pc_n[lvl] (the reference allocates w*h per level); `max_batch` bounds the number of
- * pose hypotheses of sdvgn_tracker_track_batch.  `stream` is a hipStream_t or NULL (library creates one). */
+ * pose hypotheses of sdvgn_tracker_track_batch.  `stream` is a hipStream_t or NULL (the library's shared tracker stream of that device). */
 int sdvgn_tracker_create(sdvgn_tracker** out, int device, int w0, int h0, int levels, int max_points, int max_batch,
                          void* stream);
 /* CoarseTracker::~CoarseTracker   CoarseTracker.cpp:70-75 */
@@ -243,7 +245,8 @@ typedef struct sdvgn_ef sdvgn_ef;
 
 #define SDVGN_MAX_FRAMES 8 /* setting_maxFrames = 7 in the reference (src/util/settings.cpp:46-47) */
 
-/* EnergyFunctional::EnergyFunctional + the level-0 images of the window.  w,h = wG[0],hG[0]. */
+/* EnergyFunctional::EnergyFunctional + the level-0 images of the window.  w,h = wG[0],hG[0].  `stream`: hipStream_t or NULL (the library's
+ * shared window stream of that device). */
 int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, void* stream);
 void sdvgn_ef_destroy(sdvgn_ef* ef);
 void* sdvgn_ef_stream(sdvgn_ef* ef);
@@ -293,6 +296,11 @@ int sdvgn_ef_get_nullspaces(sdvgn_ef* ef, double* out, int cap_vectors);
 /* FullSystem::setPrecalcValues (FrameFramePrecalc::set for every pair, HessianBlocks.cpp:169-195) +
  * EnergyFunctional::setDeltaF (EnergyFunctional.cpp:131-156). */
 int sdvgn_ef_set_precalc(sdvgn_ef* ef);
+/* Finish handing a window over: whatever the setters above left on the host side -- the window constants of the device-side solve
+ * (adjoints, priors, marginalisation prior, null-space vectors), the frame states and the calibration value -- is copied to the device
+ * now and the stream is drained, so that the next sdvgn_ef_optimize call starts from HBM-resident inputs and issues no host-to-device
+ * copy.  Optional: optimize uploads what is still pending itself. */
+int sdvgn_ef_make_resident(sdvgn_ef* ef);
 /* EnergyFunctional::setAdjointsF (EnergyFunctional.cpp:21-71). */
 int sdvgn_ef_set_adjoints(sdvgn_ef* ef);
 
@@ -368,6 +376,8 @@ int sdvgn_ef_get_res_toZero(sdvgn_ef* ef, float* res_toZero2, unsigned char* isL
 int sdvgn_ef_get_state(sdvgn_ef* ef, double* value_scaled4, double* state10, float* idepth);
 /* wall time (microseconds, host steady_clock) of every loop body of the last sdvgn_ef_optimize call; returns their number */
 int sdvgn_ef_get_iteration_times(sdvgn_ef* ef, double* us, int cap);
+/* number of accepted steps of the last sdvgn_ef_optimize call (what a trace would show, without asking for one) */
+int sdvgn_ef_get_accepted_steps(sdvgn_ef* ef);
 /* durations (milliseconds, HIP events on the library's stream) of the k_ef_linearize launches of the last sdvgn_ef_optimize call that ran
  * with flags bit3, in launch order (the first is the call's initial linearizeAll); returns their number */
 int sdvgn_ef_get_linearize_times(sdvgn_ef* ef, float* ms, int cap);

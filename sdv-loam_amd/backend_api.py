@@ -24,6 +24,8 @@ PROTOTYPES = [
     ("sdvgn_ef_compute_nullspaces", C.c_int, [vp]),
     ("sdvgn_ef_get_nullspaces", C.c_int, [vp, vp, C.c_int]),
     ("sdvgn_ef_set_precalc", C.c_int, [vp]),
+    ("sdvgn_ef_make_resident", C.c_int, [vp]),
+    ("sdvgn_ef_get_accepted_steps", C.c_int, [vp]),
     ("sdvgn_ef_set_adjoints", C.c_int, [vp]),
     ("sdvgn_ef_linearize_all", C.c_int, [vp, vp]),
     ("sdvgn_ef_apply_res", C.c_int, [vp]),
@@ -117,7 +119,13 @@ class EnergyFunctional:
             ck(self.L.sdvgn_ef_set_nullspaces(self.h_, ns.shape[0], ns.reshape(-1)))
         self.setAdjointsF()
         self.setPrecalcValues()
+        self.make_resident()
         return self
+
+    def make_resident(self):
+        """Upload what the setters left pending (window constants, frame states, calib) and drain the stream: optimize() then starts from
+        HBM-resident inputs."""
+        self._check(self.L.sdvgn_ef_make_resident(self.h_))
 
     def setPrecalcValues(self):
         self._check(self.L.sdvgn_ef_set_precalc(self.h_))
@@ -296,6 +304,9 @@ class EnergyFunctional:
         lin = np.zeros(self.nR, np.uint8)
         self._check(self.L.sdvgn_ef_get_res_toZero(self.h_, out.ctypes.data_as(vp), lin.ctypes.data_as(vp)))
         return out, lin
+
+    def accepted_steps(self):
+        return self._check(self.L.sdvgn_ef_get_accepted_steps(self.h_))
 
     def iteration_times_us(self):
         n = self.L.sdvgn_ef_get_iteration_times(self.h_, None, 0)

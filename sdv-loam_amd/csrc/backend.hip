@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <vector>
 
 #define HIPCHK(expr)                                  \
@@ -123,6 +124,7 @@ struct sdvgn_ef {
     int th_log_n = 0;
     size_t stats_cap = 0;          // doubles behind stats_dev: 4 statistics + max_points quantile candidates (sharded path)
     std::vector<double> iter_us;   // wall time of every loop body of the last sdvgn_ef_optimize call (microseconds)
+    int n_accepted = 0;            // accepted steps of the last sdvgn_ef_optimize call
     bool time_lin = false;         // optimize flags bit3: HIP event pair around every k_ef_linearize launch of the call
     std::vector<hipEvent_t> lin_events;
     size_t lin_ev_used = 0;
@@ -845,7 +847,19 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     if (!e) return SDVGN_E_ARG;
     e->device = device; e->w = w; e->h = h; e->max_points = max_points;
     if (stream) e->stream = (hipStream_t)stream;
-    else { HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)); e->own_stream = true; }
+    else {
+        // Windows without a caller's stream share ONE library stream per device.  A stream of its own per window handle means a
+        // hardware queue per handle, and a queue that has been idle for a while is re-activated by the first launch that lands on it:
+        // measured 0.5 ms for the first kernel of the first optimize call on such a handle, 0.16 ms on the next one (bench.py, four
+        // windows created ahead of time) -- against 0.03 ms for the whole initial linearizeAll.  Calls on one device are issued one after
+        // the other anyway; a caller that wants two windows to overlap passes two streams.
+        static std::mutex mu;
+        static hipStream_t shared[64] = {};
+        std::lock_guard<std::mutex> lk(mu);
+        if (device < 0 || device >= 64) { delete e; return SDVGN_E_ARG; }
+        if (!shared[device]) HIPCHK(hipStreamCreateWithFlags(&shared[device], hipStreamNonBlocking));
+        e->stream = shared[device];
+    }
     const size_t mp = max_points, slots = mp * SDVGN_MAX_FRAMES;
     e->slots_cap = slots;
     int bad = 0;
@@ -1223,6 +1237,16 @@ int sdvgn_ef_set_precalc(sdvgn_ef* e) {
     if (!e || e->nF < 1 || !e->haveAdjoints) return SDVGN_E_STATE;
     if (!e->host_only) HIPCHK(hipSetDevice(e->device));
     return ef_upload_precalc(e);
+}
+
+int sdvgn_ef_make_resident(sdvgn_ef* e) {
+    if (!e || e->host_only || e->nF < 1 || !e->haveAdjoints) return SDVGN_E_STATE;
+    EF_DEVICE(e);
+    int rc;
+    if (!e->havePrecalc && (rc = ef_upload_precalc(e))) return rc;
+    if ((rc = ef_sync_window(e)) || (rc = ef_sync_state(e))) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SDVGN_OK;
 }
 
 int sdvgn_ef_linearize_all(sdvgn_ef* e, double* energy_out) {
@@ -1607,8 +1631,12 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     if (!fixed_its && nF < 4) mnumOptIts = 75;
     const size_t slots = (size_t)nF * e->nP;
     int rc;
+    static const bool opt_timing = getenv("SDVGN_OPT_TIMING") != nullptr;
+    const auto tt0 = std::chrono::steady_clock::now();
+    auto us_since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
     if (!e->havePrecalc && (rc = ef_upload_precalc(e))) return rc;
     if ((rc = ef_sync_window(e)) || (rc = ef_sync_state(e))) return rc;
+    const double tt_sync = us_since(tt0);
     struct CalibGuard { sdvgn_ef* e; ~CalibGuard() { e->A.calib = nullptr; } } calib_guard{e};   // outside the loop the kernels take EFConst by value
     e->A.calib = e->calib_dev + e->st_cur;
     k_ef_reset_oob<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(slots, e->A);
@@ -1616,14 +1644,19 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     e->th_log_n = 0;
     ef_select_new_set(e, e->new_cur, e->new_cur);
     ef_refresh_frame_deltas(e);
+    const double tt_pre = us_since(tt0);
     if ((rc = linearize_and_stats(e, &lastEnergy, &lastEnergyL, nullptr, nullptr))) return rc;
+    const double tt_lin = us_since(tt0);
     lastEnergyM = calc_M_energy(e);
     if ((rc = sdvgn_ef_apply_res(e))) return rc;
+    if (opt_timing) fprintf(stderr, "[sdvgn] optimize pre-loop: uploads %.1f | reset_oob launch %.1f | linearize + stats + wait %.1f | M energy + apply launch %.1f us\n",
+                            tt_sync, tt_pre - tt_sync, tt_lin - tt_pre, us_since(tt0) - tt_lin);
     double lambda = 1e-1;
     const float stepsize = 1, thOpt = 1.2f;
     std::vector<double> x(n);
     int it = 0;
     e->iter_us.clear();
+    e->n_accepted = 0;
     std::vector<int> th_idx;   // th_log slot of every trial linearisation (trace only)
     for (int iteration = 0; iteration < mnumOptIts; iteration++) {
         const auto t_iter = std::chrono::steady_clock::now();
@@ -1678,6 +1711,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         }
         it = iteration + 1;
         if (accept) {
+            ++e->n_accepted;
             e->new_cur = 1 - e->new_cur;                                                  // the trial sets become the current ones
             e->st_cur = st_trial;
             ef_select_new_set(e, e->new_cur, e->new_cur);
@@ -1846,6 +1880,7 @@ int sdvgn_ef_marginalize_points(sdvgn_ef* e, const unsigned char* marg, const un
     const double wfac = (double)(0.5f * 0.5f);   // setting_margWeightFac, settings.cpp:71
     for (size_t i = 0; i < (size_t)n * n; ++i) e->HM[i] += wfac * (e->HA[i] - e->Hsc[i]);
     for (int i = 0; i < n; ++i) e->bM[i] += wfac * (e->bA[i] - e->bsc[i]);
+    e->win_dirty = true; e->sys_valid = false;   // the device-side solve reads HM / bM from the window block
     return SDVGN_OK;
 }
 
@@ -1961,6 +1996,8 @@ int sdvgn_debug_launch_linearize(sdvgn_ef* e, int reps) {   // k_ef_linearize al
     HIPCHK(hipGetLastError());
     return SDVGN_OK;
 }
+
+int sdvgn_ef_get_accepted_steps(sdvgn_ef* e) { return e ? e->n_accepted : SDVGN_E_ARG; }
 
 int sdvgn_ef_get_iteration_times(sdvgn_ef* e, double* us, int cap) {
     if (!e) return SDVGN_E_ARG;

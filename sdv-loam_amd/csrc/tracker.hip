@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <vector>
 
 #define HIPCHK(expr)                                  \
@@ -295,7 +296,17 @@ int sdvgn_tracker_create(sdvgn_tracker** out, int device, int w0, int h0, int le
     t->max_chunks = 256;
     for (int l = 0; l < levels; ++l) { t->w[l] = w0 >> l; t->h[l] = h0 >> l; }
     if (stream) t->stream = (hipStream_t)stream;
-    else { HIPCHK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking)); t->own_stream = true; }
+    else {
+        // trackers without a caller's stream share one library stream per device (not the back end's: a frame is tracked while a window is
+        // optimised).  One stream per handle would mean one hardware queue per handle, and the first launch on a queue that has been idle
+        // pays its re-activation (measured 0.2-0.5 ms on the back-end handles, backend.hip)
+        static std::mutex mu;
+        static hipStream_t shared[64] = {};
+        std::lock_guard<std::mutex> lk(mu);
+        if (device < 0 || device >= 64) { delete t; return SDVGN_E_ARG; }
+        if (!shared[device]) HIPCHK(hipStreamCreateWithFlags(&shared[device], hipStreamNonBlocking));
+        t->stream = shared[device];
+    }
     for (int l = 0; l < levels; ++l) {
         HIPCHK(hipMalloc(&t->pc_dev[l], sizeof(float4) * max_points));
         HIPCHK(hipMalloc(&t->pyr_dev[l], sizeof(float) * 3 * (size_t)t->w[l] * t->h[l]));
