@@ -381,6 +381,9 @@ int sdvgn_ef_get_accepted_steps(sdvgn_ef* ef);
 /* durations (milliseconds, HIP events on the library's stream) of the k_ef_linearize launches of the last sdvgn_ef_optimize call that ran
  * with flags bit3, in launch order (the first is the call's initial linearizeAll); returns their number */
 int sdvgn_ef_get_linearize_times(sdvgn_ef* ef, float* ms, int cap);
+/* Diagnostics: k_ef_linearize `reps` times in different company (0 alone, 1 behind accumulate + reduce, 2 behind stitch + tail +
+ * resubstitute without a step, 3 behind a one-wave kernel that waits spin_us, 4 behind 1 and 2), for kernel traces */
+int sdvgn_debug_launch_pattern(sdvgn_ef* ef, int pattern, int reps, int spin_us);
 /* Diagnostics: k_ef_linearize alone, `reps` launches back to back on the library's stream (no statistics, no threshold select) */
 int sdvgn_debug_launch_linearize(sdvgn_ef* ef, int reps);
 /* Diagnostics (SDVGN_PROFILE=1 in the environment when the library is loaded): prints the accumulated host wall time per phase

@@ -26,6 +26,7 @@ PROTOTYPES = [
     ("sdvgn_ef_set_precalc", C.c_int, [vp]),
     ("sdvgn_ef_make_resident", C.c_int, [vp]),
     ("sdvgn_ef_get_accepted_steps", C.c_int, [vp]),
+    ("sdvgn_debug_launch_pattern", C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
     ("sdvgn_ef_set_adjoints", C.c_int, [vp]),
     ("sdvgn_ef_linearize_all", C.c_int, [vp, vp]),
     ("sdvgn_ef_apply_res", C.c_int, [vp]),

@@ -125,6 +125,12 @@ struct sdvgn_ef {
     size_t stats_cap = 0;          // doubles behind stats_dev: 4 statistics + max_points quantile candidates (sharded path)
     std::vector<double> iter_us;   // wall time of every loop body of the last sdvgn_ef_optimize call (microseconds)
     int n_accepted = 0;            // accepted steps of the last sdvgn_ef_optimize call
+    // deferred work of the optimize loop (see linearize_launch): the threshold select of the last linearisation and the re-classification
+    // after a rejected step ride in later launches as extra workgroups; whatever is still pending is launched on its own by ef_flush_pending
+    SelArgs pend_sel{}; bool pend_sel_valid = false;
+    int lin_partials = 0, lin_nL = 0;   // of the linearise launched last (linearize_launch_kernels -> linearize_launch_stats)
+    int* accept_dev = nullptr;          // verdict of the device-side accept test, read by the conditional k_ef_apply
+    ReclArgs pend_rc{}; bool pend_rc_valid = false;
     bool time_lin = false;         // optimize flags bit3: HIP event pair around every k_ef_linearize launch of the call
     std::vector<hipEvent_t> lin_events;
     size_t lin_ev_used = 0;
@@ -690,9 +696,14 @@ __global__ void __launch_bounds__(256) k_ef_point_stats(EFConst Cin, EFArrays A,
 }
 // out[0] = sum energy partials, out[1] = sum L partials (nL may be 0), out[2], out[3] = sums of the two halves of the
 // resubstitute partials (step^2, |idepth_backup|): one workgroup instead of four tiny launches
+// The accept / reject test of FullSystem::optimize (FullSystemOptimize.cpp:420) taken where the sums arrive: the host hands over the parts
+// it owns (the prior part of the L energy of the stepped state, the M energy, the right-hand side from the last accepted state) before the
+// sums exist, the kernel finishes the comparison with the same double operations in the same order and leaves the verdict for the
+// conditional k_ef_apply queued right behind it (accept_dev) and for the host (out[4]).
+struct DecideArgs { double En, EM, rhs; int* accept_dev; int on; };
 __device__ __forceinline__ void sum_stats_body(const double* __restrict__ pe, int nE, const double* __restrict__ pl, int nL,
                                                const double* __restrict__ ps, int nS, double* __restrict__ out, volatile int* done_flag, int done_seq,
-                                               double (*s)[256]) {
+                                               double (*s)[256], const DecideArgs& dec = DecideArgs{0, 0, 0, nullptr, 0}) {
     if (threadIdx.x < 256) {
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         for (int i = threadIdx.x; i < nE; i += 256) a0 += pe[i];
@@ -706,6 +717,13 @@ __device__ __forceinline__ void sum_stats_body(const double* __restrict__ pe, in
         __syncthreads();
     }
     if (threadIdx.x < 4) out[threadIdx.x] = s[threadIdx.x][0];
+    if (dec.on && threadIdx.x == 0) {
+        const double newEnergy = s[0][0];
+        const double newEnergyL = dec.En + (double)(float)s[1][0];                  // linearize_wait's expression
+        const bool accept = (newEnergy + newEnergyL) + dec.EM < dec.rhs;
+        *dec.accept_dev = accept ? 1 : 0;
+        out[4] = accept ? 1.0 : 0.0;
+    }
     if (done_flag) {   // single workgroup: publish after the four stores (waitflag.hpp)
         __syncthreads();
         if (threadIdx.x == 0) { __threadfence_system(); *done_flag = done_seq; }
@@ -718,12 +736,11 @@ __global__ void __launch_bounds__(256) k_ef_sum_stats(const double* __restrict__
 }
 // single-rank tail of a linearizeAll in ONE launch: workgroup 0 = the four statistics (+ flag for the host), workgroup 1 =
 // FullSystem::setNewFrameEnergyTH (k_ef_select_th's body) -- they are independent and run side by side on two CUs
-struct SelArgs { int nF, nP, own0, own1; const uint8_t* rflags; const float* wo; const float* th_prev; float* th_out; float* log_slot; };
 __global__ void __launch_bounds__(kSelLanes) k_ef_stats_select(const double* __restrict__ pe, int nE, const double* __restrict__ pl, int nL,
                                                                 const double* __restrict__ ps, int nS, double* __restrict__ out, volatile int* done_flag,
-                                                                int done_seq, SelArgs a) {
+                                                                int done_seq, SelArgs a, DecideArgs dec) {
     __shared__ union U { double s[4][256]; SelectSmem sel; __device__ U() {} } S;
-    if (blockIdx.x == 0) sum_stats_body(pe, nE, pl, nL, ps, nS, out, done_flag, done_seq, S.s);
+    if (blockIdx.x == 0) sum_stats_body(pe, nE, pl, nL, ps, nS, out, done_flag, done_seq, S.s, dec);
     else select_th_body<0>(a.nF, a.nP, a.own0, a.own1, a.rflags, a.wo, nullptr, a.th_prev, a.th_out, a.log_slot, S.sel);
 }
 
@@ -826,6 +843,20 @@ static void ef_launch_pack_th(sdvgn_ef* e) {
     k_ef_pack_th_candidates<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->nF, e->nP, own0, own1, e->rflags, e->A.renergy_wo, e->stats_dev + 4);
 }
 
+// launch what the optimize loop deferred and nothing has picked up: the select first (the re-classification reads its threshold)
+static void ef_flush_pending(sdvgn_ef* e) {
+    if (e->pend_sel_valid) {
+        const SelArgs& a = e->pend_sel;
+        k_ef_select_th<0><<<1, kSelLanes, 0, e->stream>>>(a.nF, a.nP, a.own0, a.own1, a.rflags, a.wo, nullptr, a.th_prev, a.th_out, a.log_slot);
+        e->pend_sel_valid = false;
+    }
+    if (e->pend_rc_valid) {
+        const int nthr = e->pend_rc.nP + e->pend_rc.np_last * (e->pend_rc.nF - 1);
+        k_ef_reclassify<<<(nthr + 255) / 256, 256, 0, e->stream>>>(e->pend_rc);
+        e->pend_rc_valid = false;
+    }
+}
+
 extern "C" {
 
 int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, void* stream) {
@@ -899,7 +930,8 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     if (bad) { sdvgn_ef_destroy(e); return -(int)hipErrorOutOfMemory; }
     HIPCHK(hipHostMalloc(&e->precalc_host, 2 * sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
     HIPCHK(hipHostMalloc(&e->acc_host, sizeof(double) * accmax));
-    HIPCHK(hipHostMalloc(&e->stats_host, sizeof(double) * 4));
+    HIPCHK(hipHostMalloc(&e->stats_host, sizeof(double) * 8));
+    HIPCHK(hipMalloc((void**)&e->accept_dev, 64));
     HIPCHK(hipHostMalloc((void**)&e->flags_host, 64));
     HIPCHK(hipHostMalloc((void**)&e->th_log, sizeof(float) * kThLog));
     HIPCHK(hipHostMalloc((void**)&e->win_host, sizeof(SolveWindow)));
@@ -939,6 +971,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
     if (e->precalc_host) hipHostFree(e->precalc_host);
     if (e->acc_host) hipHostFree(e->acc_host);
     if (e->stats_host) hipHostFree(e->stats_host);
+    if (e->accept_dev) hipFree(e->accept_dev);
     if (e->flags_host) hipHostFree(e->flags_host);
     if (e->th_log) hipHostFree(e->th_log);
     if (e->win_host) hipHostFree(e->win_host);
@@ -1273,7 +1306,8 @@ int sdvgn_ef_apply_res(sdvgn_ef* e) {
     if (!e || e->nP < 1) return SDVGN_E_STATE;
     EF_DEVICE(e);
     const size_t slots = (size_t)e->nF * e->nP;
-    k_ef_apply<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->nF, e->nP, e->A, e->precalc_dev, e->phost_dev);
+    // (a threshold select the optimize loop has pending stays pending: applyRes does not read the thresholds)
+    k_ef_apply<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->nF, e->nP, e->A, e->precalc_dev, e->phost_dev, nullptr);
     HIPCHK(hipGetLastError());
     return SDVGN_OK;
 }
@@ -1496,9 +1530,14 @@ static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_st
             // sharded window: the packed buffer of every rank is summed (ONE all-reduce per GN iteration), then every rank stitches and solves
             if (ef_sharded(e) && (rc = ef_allreduce(e, e->acc_dev, (int)acc_count(e)))) return rc;
         }
-        k_ef_stitch<<<nF + 1, kSolveLanes, 0, e->stream>>>(io);
+        const int has_sel = e->pend_sel_valid ? 1 : 0;
+        k_ef_stitch<<<nF + 1 + has_sel, kSolveLanes, 0, e->stream>>>(io, e->pend_sel, has_sel);
+        e->pend_sel_valid = false;
     }
-    k_ef_solve_tail<<<1, kSolveLanes, 0, e->stream>>>(io);
+    if (e->pend_sel_valid) ef_flush_pending(e);    // system re-used: no stitch launch to ride in
+    const int has_rc = e->pend_rc_valid ? 1 : 0;
+    k_ef_solve_tail<<<1 + (has_rc ? kReclBlocks : 0), kSolveLanes, 0, e->stream>>>(io, e->pend_rc, has_rc);
+    e->pend_rc_valid = false;
     HIPCHK(hipGetLastError());
     const int nblk = (e->nP + 63) / 64;
     k_ef_resubstitute_step<<<nblk + (do_step ? 1 : 0), 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->rx_dev, e->pidepth_backup,
@@ -1564,14 +1603,30 @@ static double calc_M_energy(sdvgn_ef* e) {   // EnergyFunctional::calcMEnergyF
 }
 // linearizeAll + the point statistics + setNewFrameEnergyTH, in two halves: the launches (asynchronous) and the wait for the four
 // sums {energy, L-energy point part, sum step^2, sum |idepth_backup|}
-static int linearize_launch(sdvgn_ef* e) {
+// defer_select (optimize loop, single rank): only the statistics are launched behind the linearise; setNewFrameEnergyTH is recorded in
+// e->pend_sel and rides as one more workgroup in the k_ef_stitch launch of the next loop body (ef_launch_solve) -- its result is needed by
+// the next linearise (accepted step) or by the re-classification in that body's k_ef_solve_tail (rejected step), not before -- instead of
+// sitting between the statistics and the host's decision on the stream (one workgroup of serial passes, ~7 us).
+static int linearize_launch_kernels(sdvgn_ef* e) {   // first half: the linearise itself (+ the point statistics when they are not trivially 0)
     if (!e->havePrecalc) return SDVGN_E_STATE;
-    const int n_partials = ef_launch_linearize(e);
-    int nL = 0;
+    ef_flush_pending(e);   // a pending select reads, a pending re-classification feeds, planes this linearise is about to overwrite / read
+    e->lin_partials = ef_launch_linearize(e);
+    e->lin_nL = 0;
     if (e->deltaF_nonzero || e->has_linearized) {
-        nL = (e->nP + 255) / 256;
-        k_ef_point_stats<<<nL, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->stats_partial);
+        e->lin_nL = (e->nP + 255) / 256;
+        k_ef_point_stats<<<e->lin_nL, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->stats_partial);
     }
+    HIPCHK(hipGetLastError());
+    return SDVGN_OK;
+}
+static double host_prior_energy(const sdvgn_ef* e) {   // calcLEnergyF_MT: frame + calib priors, of the host mirror's state
+    double En = 0;
+    for (const FrameH& f : e->frames) for (int i = 0; i < 6; ++i) En += f.delta_prior[i] * f.prior[i] * f.delta_prior[i];
+    { float a = 0; for (int i = 0; i < 4; ++i) a += e->C.cDeltaF[i] * (float)e->cPrior[i] * e->C.cDeltaF[i]; En += a; }
+    return En;
+}
+static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideArgs* dec = nullptr) {   // second half: the sums (+ threshold select)
+    const int n_partials = e->lin_partials, nL = e->lin_nL;
     const int nS = (e->nP + 63) / 64;
     const double* ps = e->stats_partial + (e->nP / 64 + 2);
     if (ef_sharded(e)) {
@@ -1583,31 +1638,35 @@ static int linearize_launch(sdvgn_ef* e) {
         ef_launch_select_th(e, true);
     } else {
         // statistics (the host waits for their flag; pinned memory, no copy engine) and setNewFrameEnergyTH (only the NEXT linearise
-        // needs it) side by side in one launch
+        // needs it) side by side in one launch -- or, deferred, the select as a workgroup of the next body's k_ef_stitch
         SelArgs a;
         a.nF = e->nF; a.nP = e->nP;
         ef_owned_points(e, a.own0, a.own1);
         a.rflags = e->rflags; a.wo = e->A.renergy_wo; a.th_prev = e->A.frameTH_r; a.th_out = e->A.frameTH_w;
         a.log_slot = e->th_log ? e->th_log + (e->th_log_n++ % kThLog) : nullptr;
-        k_ef_stats_select<<<2, kSelLanes, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host, e->flags_host + 2,
-                                                          ++e->seq_stats, a);
+        const DecideArgs none{0, 0, 0, nullptr, 0};
+        k_ef_stats_select<<<defer_select ? 1 : 2, kSelLanes, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host,
+                                                                              e->flags_host + 2, ++e->seq_stats, a, dec ? *dec : none);
+        if (defer_select) { e->pend_sel = a; e->pend_sel_valid = true; }
     }
     HIPCHK(hipGetLastError());
     return SDVGN_OK;
 }
+static int linearize_launch(sdvgn_ef* e, bool defer_select = false) {
+    const int rc = linearize_launch_kernels(e);
+    return rc ? rc : linearize_launch_stats(e, defer_select);
+}
 static int linearize_wait(sdvgn_ef* e, double* energy, double* EL, double* sumID, double* sumNID) {
     HIPCHK(wait_flag(e->flags_host + 2, e->seq_stats, e->stream));
     *energy = e->stats_host[0];
-    double En = 0;   // calcLEnergyF_MT: frame + calib priors on the host (of the host mirror's state), point part from the device
-    for (const FrameH& f : e->frames) for (int i = 0; i < 6; ++i) En += f.delta_prior[i] * f.prior[i] * f.delta_prior[i];
-    { float a = 0; for (int i = 0; i < 4; ++i) a += e->C.cDeltaF[i] * (float)e->cPrior[i] * e->C.cDeltaF[i]; En += a; }
+    const double En = host_prior_energy(e);   // calcLEnergyF_MT: frame + calib priors on the host, point part from the device
     *EL = En + (double)(float)e->stats_host[1];
     if (sumID) *sumID = e->stats_host[2];
     if (sumNID) *sumNID = e->stats_host[3];
     return SDVGN_OK;
 }
-static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* sumID, double* sumNID) {
-    const int rc = linearize_launch(e);
+static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* sumID, double* sumNID, bool defer_select = false) {
+    const int rc = linearize_launch(e, defer_select);
     return rc ? rc : linearize_wait(e, energy, EL, sumID, sumNID);
 }
 
@@ -1623,6 +1682,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     const bool fixed_its = (flags & 1) != 0;   // benchmark mode: exactly mnumOptIts loop bodies, no early break
     const bool relinearize_on_reject = (flags & 2) != 0;   // run the reference's redundant re-linearisation literally (A/B timing, tests)
     const bool reuse_after_reject = (flags & 4) != 0;      // opt-in: the solve after a rejected step reuses the stitched system (see header)
+    e->pend_sel_valid = e->pend_rc_valid = false;           // nothing of an earlier (failed) call is carried over
     e->time_lin = (flags & 8) != 0;                          // measurement: event pair around every k_ef_linearize launch
     e->lin_ev_used = 0; e->lin_ms.clear();
     struct TimeLinGuard { sdvgn_ef* e; ~TimeLinGuard() { e->time_lin = false; } } time_lin_guard{e};
@@ -1645,7 +1705,8 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     ef_select_new_set(e, e->new_cur, e->new_cur);
     ef_refresh_frame_deltas(e);
     const double tt_pre = us_since(tt0);
-    if ((rc = linearize_and_stats(e, &lastEnergy, &lastEnergyL, nullptr, nullptr))) return rc;
+    const bool defer = !ef_sharded(e) && !relinearize_on_reject;   // the literal variant keeps the reference's order of launches
+    if ((rc = linearize_and_stats(e, &lastEnergy, &lastEnergyL, nullptr, nullptr, defer))) return rc;
     const double tt_lin = us_since(tt0);
     lastEnergyM = calc_M_energy(e);
     if ((rc = sdvgn_ef_apply_res(e))) return rc;
@@ -1675,7 +1736,10 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         e->A.calib = e->calib_dev + st_trial;
         ef_select_new_set(e, 1 - e->new_cur, e->new_cur);                                 // trial linearisation goes to the other set
         th_idx.push_back(e->th_log_n % kThLog);
-        if ((rc = linearize_launch(e))) return rc;
+        // device-side accept test: the statistics launch waits for the host's parts of the comparison (after the mirror below), the
+        // linearise does not
+        const bool dev_decide = defer && !zero_differs;
+        if ((rc = dev_decide ? linearize_launch_kernels(e) : linearize_launch(e, defer))) return rc;
         g_pt.stop(PT_ACCUM);
         // x is in pinned memory as soon as the solve kernel is through: mirror doStepFromBackup on the host (FrameHessian::setState,
         // CalibHessian::setValue -- the same double-precision operations the device performed) while the GPU linearises
@@ -1695,15 +1759,26 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             ef_refresh_frame_deltas(e);
         }
         float sumT = e->sol_host->sumT, sumR = e->sol_host->sumR;
+        const double newEnergyM = calc_M_energy(e);
+        if (dev_decide) {
+            // the sums, the verdict and -- queued right behind, so that no launch latency separates it from the verdict -- applyRes of
+            // the trial linearisation, which returns at once when the step is rejected
+            DecideArgs dec;
+            dec.En = host_prior_energy(e); dec.EM = newEnergyM; dec.rhs = lastEnergy + lastEnergyL + lastEnergyM; dec.accept_dev = e->accept_dev; dec.on = 1;
+            if ((rc = linearize_launch_stats(e, defer, &dec))) return rc;
+            k_ef_apply<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->nF, e->nP, e->A, e->precalc_dev, e->phost_dev, e->accept_dev);
+            HIPCHK(hipGetLastError());
+        }
         g_pt.stop(PT_STEP);
         double newEnergy, newEnergyL, sID, sNID;
         if ((rc = linearize_wait(e, &newEnergy, &newEnergyL, &sID, &sNID))) return rc;
         g_pt.stop(PT_LIN);
-        const double newEnergyM = calc_M_energy(e);
         sumR /= nF; sumT /= nF;
         const float sumNID = (float)sNID / (float)e->nP;
         const bool canbreak = sqrtf(sumR) < 0.00005 * thOpt && sqrtf(sumT) * sumNID < 0.00005 * thOpt;
-        const bool accept = newEnergy + newEnergyL + newEnergyM < lastEnergy + lastEnergyL + lastEnergyM;
+        const bool accept_host = newEnergy + newEnergyL + newEnergyM < lastEnergy + lastEnergyL + lastEnergyM;
+        const bool accept = dev_decide ? (e->stats_host[4] != 0.0) : accept_host;
+        if (dev_decide && accept != accept_host) return SDVGN_E_STATE;   // the same IEEE operations on the same numbers: cannot happen
         if (trace && iteration < trace_cap) {
             double* tr = trace + (size_t)iteration * trace_stride;
             tr[0] = iteration; tr[1] = lambda; tr[2] = accept; tr[3] = newEnergy; tr[4] = newEnergyL; tr[5] = newEnergyM; tr[6] = canbreak;
@@ -1715,7 +1790,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             e->new_cur = 1 - e->new_cur;                                                  // the trial sets become the current ones
             e->st_cur = st_trial;
             ef_select_new_set(e, e->new_cur, e->new_cur);
-            if ((rc = sdvgn_ef_apply_res(e))) return rc;
+            if (!dev_decide && (rc = sdvgn_ef_apply_res(e))) return rc;      // (device-side test: the conditional apply is already queued)
             lastEnergy = newEnergy; lastEnergyL = newEnergyL; lastEnergyM = newEnergyM;
             lambda *= 0.25;
             prev_rejected_clean = false;
@@ -1743,15 +1818,26 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             // deltaF changed, so the kept energies do not describe the restored state -- re-linearise like the reference.
             const int trial = 1 - e->new_cur;
             if (relinearize_on_reject || zero_differs) {
+                ef_flush_pending(e);                       // the trial's threshold first: this re-linearisation classifies with it
                 ef_select_new_set(e, e->new_cur, e->new_cur, /*th_read=*/trial);
                 if ((rc = linearize_and_stats(e, &lastEnergy, &lastEnergyL, nullptr, nullptr))) return rc;
                 lastEnergyM = calc_M_energy(e);
             } else {
                 ef_select_new_set(e, e->new_cur, e->new_cur);
-                const int P0l = e->hostP0[nF - 1], npl = e->hostP0[nF] - P0l, nthr = e->nP + npl * (nF - 1);
-                k_ef_reclassify<<<(nthr + 255) / 256, 256, 0, e->stream>>>(nF, e->nP, P0l, npl, e->rflags, e->A.renergy_wo, e->A.rstate_new, e->A.renergy_new,
-                                                                           e->phost_dev, e->precalc_dev, e->th_dev + (size_t)trial * SDVGN_MAX_FRAMES);
-                HIPCHK(hipGetLastError());
+                ReclArgs ra;
+                ra.nF = nF; ra.nP = e->nP; ra.P0_last = e->hostP0[nF - 1]; ra.np_last = e->hostP0[nF] - ra.P0_last;
+                ra.rflags = e->rflags; ra.wo = e->A.renergy_wo; ra.rstate_new = e->A.rstate_new; ra.renergy_new = e->A.renergy_new;
+                ra.phost = e->phost_dev; ra.precalc = e->precalc_dev; ra.th = e->th_dev + (size_t)trial * SDVGN_MAX_FRAMES;
+                if (defer) {
+                    // nothing is launched here: the trial's select rides in the next body's k_ef_stitch, this re-classification in its
+                    // k_ef_solve_tail -- both through before that body's linearise (which reads the kept set's state_NewEnergy for
+                    // residuals that leave the image) -- or ef_flush_pending launches them when the loop ends
+                    e->pend_rc = ra; e->pend_rc_valid = true;
+                } else {
+                    const int nthr = e->nP + ra.np_last * (nF - 1);
+                    k_ef_reclassify<<<(nthr + 255) / 256, 256, 0, e->stream>>>(ra);
+                    HIPCHK(hipGetLastError());
+                }
             }
             ef_select_new_set(e, e->new_cur, e->new_cur);
             lambda *= 1e2;
@@ -1762,6 +1848,8 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         e->iter_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_iter).count());
         if (!fixed_its && canbreak && iteration >= 1) break;
     }
+    ef_flush_pending(e);
+    HIPCHK(hipGetLastError());
     if (g_pt.on) sdvgn_debug_phase_report(it);
     if (e->time_lin) {
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -1994,6 +2082,29 @@ int sdvgn_debug_launch_linearize(sdvgn_ef* e, int reps) {   // k_ef_linearize al
     EF_DEVICE(e);
     for (int i = 0; i < reps; ++i) ef_launch_linearize(e);
     HIPCHK(hipGetLastError());
+    return SDVGN_OK;
+}
+
+// Diagnostics: k_ef_linearize in different company, `reps` times each: 0 alone; 1 behind accumulate + reduce; 2 behind stitch + tail +
+// resubstitute (no step: the state is not touched); 3 behind a one-wave kernel that just waits `spin_us` (the chip idles like it does
+// during the small solve); 4 behind all of 1 and 2.  For kernel traces (tools/exp_linearize_context.py).
+__global__ void k_debug_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+int sdvgn_debug_launch_pattern(sdvgn_ef* e, int pattern, int reps, int spin_us) {
+    if (!e || e->host_only || !e->havePrecalc || e->nP < 1 || !e->haveAdjoints) return SDVGN_E_STATE;
+    EF_DEVICE(e);
+    int rc;
+    if ((rc = ef_accumulate(e, /*with_reduce=*/true))) return rc;
+    for (int i = 0; i < reps; ++i) {
+        if (pattern == 1 || pattern == 4) { if ((rc = ef_accumulate(e, true))) return rc; }
+        if (pattern == 2 || pattern == 4) { if ((rc = ef_launch_solve(e, 0, 0.1, /*do_step=*/false, -1.0f, /*reuse=*/false, /*accumulated=*/true))) return rc; }
+        if (pattern == 3) k_debug_spin<<<1, 64, 0, e->stream>>>((long long)spin_us * 100);
+        ef_launch_linearize(e);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
     return SDVGN_OK;
 }
 

@@ -596,17 +596,19 @@ __global__ void __launch_bounds__(64) k_ef_optimize_immature(EFConst C, const fl
 // applyRes(true): one thread per slot.  All per-slot inputs are loaded up front (independent loads, one round trip) and the J
 // planes of the buffer the flip would select right behind the flags, so that the kernel is two memory round trips deep instead
 // of six; which values are used is decided afterwards.
-__global__ void __launch_bounds__(256) k_ef_apply(int nF, int nP, EFArrays A, const PrecalcDev* __restrict__ precalc,
-                                                  const int* __restrict__ phost) {
+// cond (may be NULL): the verdict of the device-side accept test; 0 = the step was rejected, nothing is applied.
+__device__ __forceinline__ void apply_slot(int nF, int nP, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
+                                           const int* __restrict__ phost, size_t s, const int* __restrict__ cond) {
     const size_t slots = (size_t)nF * nP;
-    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= slots) return;
+    const int go = cond ? *cond : 1;
     const int hh = phost[s % nP];
     uint8_t fl = A.rflags[s];
     const int st = A.rstate[s];
     const int sn = A.rstate_new[s];
     const float en = A.renergy_new[s];
     __builtin_amdgcn_sched_barrier(0);
+    if (!go) return;
     const int np_h = precalc[hh * nF + hh].np;
     const int buf = (fl & RF_SEL) ? 0 : 1;              // the buffer the residual's freshly linearised J sits in
     const float* Je = A.J + (size_t)buf * kJPlanes * slots + s;
@@ -629,6 +631,10 @@ __global__ void __launch_bounds__(256) k_ef_apply(int nF, int nP, EFArrays A, co
     A.rflags[s] = fl;
     A.rstate[s] = (int8_t)(sn & RS_MASK);
     A.renergy[s] = en;
+}
+__global__ void __launch_bounds__(256) k_ef_apply(int nF, int nP, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                  const int* __restrict__ phost, const int* __restrict__ cond) {
+    apply_slot(nF, nP, A, precalc, phost, (size_t)blockIdx.x * blockDim.x + threadIdx.x, cond);
 }
 
 // Per-point sums of addPoint<0> (active, not linearised) and addPoint<1> (active, linearised), then the head of the
@@ -1428,6 +1434,9 @@ __device__ __forceinline__ void select_th_body(int nF, int nP, int own0, int own
     }
 }
 
+// arguments of one pending setNewFrameEnergyTH (SRC 0) when it rides in another kernel's launch as an extra workgroup
+struct SelArgs { int nF, nP, own0, own1; const uint8_t* rflags; const float* wo; const float* th_prev; float* th_out; float* log_slot; };
+
 template <int SRC>
 __global__ void __launch_bounds__(kSelLanes) k_ef_select_th(int nF, int nP, int own0, int own1, const uint8_t* __restrict__ rflags,
                                                             const float* __restrict__ wo, const double* __restrict__ cand,
@@ -1451,25 +1460,31 @@ __global__ void __launch_bounds__(256) k_ef_pack_th_candidates(int nF, int nP, i
 // state_NewEnergy: those are taken under the threshold the trial's linearizeAll just set (th), not the one the kept set was built
 // with.  This kernel repeats exactly that decision (Residuals.cpp:210-222) for the residuals that involve the newest frame (the
 // only threshold that moves): lanes [0, nP) = target == newest, then np_last x (nF-1) lanes = host == newest.
-__global__ void __launch_bounds__(256) k_ef_reclassify(int nF, int nP, int P0_last, int np_last, const uint8_t* __restrict__ rflags,
-                                                       const float* __restrict__ wo, int8_t* __restrict__ rstate_new, float* __restrict__ renergy_new,
-                                                       const int* __restrict__ phost, const PrecalcDev* __restrict__ precalc, const float* __restrict__ th) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+struct ReclArgs {
+    int nF, nP, P0_last, np_last;
+    const uint8_t* rflags; const float* wo; int8_t* rstate_new; float* renergy_new; const int* phost; const PrecalcDev* precalc; const float* th;
+};
+__device__ __forceinline__ int reclassify_count(const ReclArgs& a) { return a.nP + a.np_last * (a.nF - 1); }
+__device__ __forceinline__ void reclassify_slot(const ReclArgs& a, int i) {
+    const int nF = a.nF, nP = a.nP;
     int p, t;
     if (i < nP) { p = i; t = nF - 1; }
-    else { const int j = i - nP; if (j >= np_last * (nF - 1)) return; t = j / np_last; p = P0_last + j % np_last; }
-    const int h = phost[p];
-    if (h == t || precalc[h * nF + h].np == 0) return;
+    else { const int j = i - nP; if (j >= a.np_last * (nF - 1)) return; t = j / a.np_last; p = a.P0_last + j % a.np_last; }
+    const int h = a.phost[p];
+    if (h == t || a.precalc[h * nF + h].np == 0) return;
     const size_t s = (size_t)t * nP + p;
-    const uint8_t fl = rflags[s];
-    const int sn = rstate_new[s];
-    const float e = wo[s];
+    const uint8_t fl = a.rflags[s];
+    const int sn = a.rstate_new[s];
+    const float e = a.wo[s];
     if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED) || (sn & RS_MASK) == RS_OOB) return;
-    const float a = th[h], b = th[t];
-    const float frameTH = a < b ? b : a;
+    const float ta = a.th[h], tb = a.th[t];
+    const float frameTH = ta < tb ? tb : ta;
     const bool wjlow = (sn & RS_WJLOW) != 0;
-    if (e > frameTH || wjlow) { renergy_new[s] = frameTH; rstate_new[s] = (int8_t)(RS_OUTLIER | (wjlow ? RS_WJLOW : 0)); }
-    else { renergy_new[s] = e; rstate_new[s] = RS_IN; }
+    if (e > frameTH || wjlow) { a.renergy_new[s] = frameTH; a.rstate_new[s] = (int8_t)(RS_OUTLIER | (wjlow ? RS_WJLOW : 0)); }
+    else { a.renergy_new[s] = e; a.rstate_new[s] = RS_IN; }
+}
+__global__ void __launch_bounds__(256) k_ef_reclassify(ReclArgs a) {
+    reclassify_slot(a, blockIdx.x * 256 + threadIdx.x);
 }
 
 // linearizeAll(true)'s per-residual epilogue (FullSystemOptimize.cpp:32-52, 136-155) after linearize + applyRes: one lane per point.
