@@ -1706,11 +1706,11 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     ef_refresh_frame_deltas(e);
     const double tt_pre = us_since(tt0);
     const bool defer = !ef_sharded(e) && !relinearize_on_reject;   // the literal variant keeps the reference's order of launches
-    if ((rc = linearize_and_stats(e, &lastEnergy, &lastEnergyL, nullptr, nullptr, defer))) return rc;
+    // linearizeAll + applyRes: the apply does not depend on the sums -- it is queued before the host waits for them
+    if ((rc = linearize_launch(e, defer)) || (rc = sdvgn_ef_apply_res(e)) || (rc = linearize_wait(e, &lastEnergy, &lastEnergyL, nullptr, nullptr))) return rc;
     const double tt_lin = us_since(tt0);
     lastEnergyM = calc_M_energy(e);
-    if ((rc = sdvgn_ef_apply_res(e))) return rc;
-    if (opt_timing) fprintf(stderr, "[sdvgn] optimize pre-loop: uploads %.1f | reset_oob launch %.1f | linearize + stats + wait %.1f | M energy + apply launch %.1f us\n",
+    if (opt_timing) fprintf(stderr, "[sdvgn] optimize pre-loop: uploads %.1f | reset_oob launch %.1f | linearize + stats + apply + wait %.1f | M energy %.1f us\n",
                             tt_sync, tt_pre - tt_sync, tt_lin - tt_pre, us_since(tt0) - tt_lin);
     double lambda = 1e-1;
     const float stepsize = 1, thOpt = 1.2f;
@@ -1719,11 +1719,14 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     e->iter_us.clear();
     e->n_accepted = 0;
     std::vector<int> th_idx;   // th_log slot of every trial linearisation (trace only)
+    bool host_restore_pending = false;
     for (int iteration = 0; iteration < mnumOptIts; iteration++) {
         const auto t_iter = std::chrono::steady_clock::now();
         g_pt.start();
-        for (int i = 0; i < 4; ++i) e->value_backup[i] = e->value[i];                     // backupState
-        for (FrameH& f : e->frames) for (int i = 0; i < 10; ++i) f.state_backup[i] = f.state[i];
+        if (!host_restore_pending) {                                                      // backupState (after a rejected step the backup still IS the state)
+            for (int i = 0; i < 4; ++i) e->value_backup[i] = e->value[i];
+            for (FrameH& f : e->frames) for (int i = 0; i < 10; ++i) f.state_backup[i] = f.state[i];
+        }
         const bool zero_differs = e->deltaF_nonzero;   // idepth != idepth_zero before this trial (only possible right after a load)
         // solveSystemF + doStepFromBackup, all on the device: the trial state (frame states, calib, precalc table, idepths) goes to the
         // second copies; resubstitute also backs up the idepths and applies the point step
@@ -1757,6 +1760,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
                 frame_set_state(f, st);
             }
             ef_refresh_frame_deltas(e);
+            host_restore_pending = false;     // the mirror holds the new trial state
         }
         float sumT = e->sol_host->sumT, sumR = e->sol_host->sumR;
         const double newEnergyM = calc_M_energy(e);
@@ -1797,9 +1801,14 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         } else {
             // loadSateBackup: the idepths, the precalc table, the calib floats and the frame states of the backed-up state are still in
             // the copies the trial did not write -- switch back (no launch); the host mirror is recomputed from the backup
-            calib_set_value(e, e->value_backup);
-            for (FrameH& f : e->frames) frame_set_state(f, f.state_backup);
-            ef_refresh_frame_deltas(e);
+            // (the host mirror of the restored state is only needed by a literal re-linearisation or when the loop ends: the next body
+            // steps from the backup, which still is the state -- restoring it here would sit between the verdict and the next launches)
+            auto restore_host_mirror = [&]() {
+                calib_set_value(e, e->value_backup);
+                for (FrameH& f : e->frames) frame_set_state(f, f.state_backup);
+                ef_refresh_frame_deltas(e);
+            };
+            if (relinearize_on_reject || zero_differs) restore_host_mirror(); else host_restore_pending = true;
             ef_swap_point_copies(e);
             std::swap(e->precalc_dev, e->precalc_alt);
             e->A.calib = e->calib_dev + e->st_cur;
@@ -1850,6 +1859,11 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     }
     ef_flush_pending(e);
     HIPCHK(hipGetLastError());
+    if (host_restore_pending) {   // the loop ended on a rejected step: loadSateBackup for the host mirror
+        calib_set_value(e, e->value_backup);
+        for (FrameH& f : e->frames) frame_set_state(f, f.state_backup);
+        ef_refresh_frame_deltas(e);
+    }
     if (g_pt.on) sdvgn_debug_phase_report(it);
     if (e->time_lin) {
         HIPCHK(hipStreamSynchronize(e->stream));
