@@ -622,7 +622,7 @@ def main():
             runners = [ShardedEnergyFunctional(Wh, rank, world, local) for _ in range(min(n_calls, 16))]
             runners[0].optimize(2, want_trace=False, fixed_its=True)      # first collectives happen here: fail early, fall back below
             runners[0].reload(Wh)
-            parallelism = "host-keyframe shards %s + 1 all-reduce(154 kB fp64)/iteration over RCCL" % (shard_hosts(Wh.nF, world),)
+            parallelism = "host-keyframe shards %s + 2 all-reduces per iteration over RCCL (154 kB packed accumulators; 128 kB statistics + threshold candidates)" % (shard_hosts(Wh.nF, world),)
         except Exception as ex:  # noqa: BLE001
             runners = None
             parallelism, scaling = "replicas x%d (sharded path unavailable: %r)" % (world, ex), "weak"
