@@ -245,9 +245,12 @@ class EnergyFunctional:
 
     def optimize(self, its=6, cap=128, want_trace=True, fixed_its=False, relinearize_on_reject=False, reuse_after_reject=False, time_linearize=False):
         stride = 8 + self.dim   # ..., x[dim], frameEnergyTH of the newest frame after the trial linearizeAll
-        trace = np.zeros((cap, stride))
         flags = (1 if fixed_its else 0) | (2 if relinearize_on_reject else 0) | (4 if reuse_after_reject else 0) | (8 if time_linearize else 0)
-        n = self._check(self.L.sdvgn_ef_optimize(self.h_, its, flags, trace.ctypes.data_as(vp) if want_trace else None, stride, cap))
+        if not want_trace:      # nothing to allocate or zero on the way in: rows of zeros, one per body, on the way out
+            n = self._check(self.L.sdvgn_ef_optimize(self.h_, its, flags, None, stride, cap))
+            return np.zeros((n, stride))
+        trace = np.zeros((cap, stride))
+        n = self._check(self.L.sdvgn_ef_optimize(self.h_, its, flags, trace.ctypes.data_as(vp), stride, cap))
         return trace[:n]
 
     def linearize_times_ms(self):

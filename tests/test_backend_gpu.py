@@ -365,6 +365,31 @@ def test_kept_state_equals_relinearize_on_reject(api, orc, seed):
     assert np.array_equal(xa, xb)
 
 
+@pytest.mark.parametrize("seed", [2, 5])
+def test_untraced_call_counters_and_thresholds(api, orc, seed):
+    """A call without a trace (what bench.py times): same final state, thresholds and per-residual planes as the traced call and as the
+    literal variant, whatever the loop ended on (the deferred threshold select / re-classification are flushed when it ends), and the
+    handle's accepted-step counter equals the trace's; make_resident is idempotent."""
+    from sdv_loam_amd import synthetic as syn
+    W = low_thresholds(syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=seed, calib=dict(fx=400., fy=410., cx=319.5, cy=119.5)))
+    for its in (1, 2, 3, 5, 7):                                                # ends on accepted and on rejected steps
+        A = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+        B = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+        C = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+        A.make_resident(); A.make_resident()
+        ta = A.optimize(its, fixed_its=True, want_trace=False)
+        tb = B.optimize(its, fixed_its=True)
+        tc = C.optimize(its, fixed_its=True, relinearize_on_reject=True)
+        assert len(ta) == its and A.accepted_steps() == int(tb[:, 2].sum()) == B.accepted_steps() == C.accepted_steps()
+        assert np.array_equal(tb, tc)
+        for x, y, z in zip(A.state(), B.state(), C.state()):
+            assert np.array_equal(x, y) and np.array_equal(y, z)
+        assert np.array_equal(A.frame_energy_th(), B.frame_energy_th()) and np.array_equal(B.frame_energy_th(), C.frame_energy_th())
+        sa, sb, sc = A.residual_state(), B.residual_state(), C.residual_state()
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k]) and np.array_equal(sb[k], sc[k]), (its, k)
+
+
 @pytest.mark.parametrize("seed", [2, 3, 4])
 def test_reuse_after_reject_is_bit_identical(api, orc, seed):
     """flags bit2: the body after a rejected step re-uses the stitched system of its predecessor (same state, only lambda changed)
