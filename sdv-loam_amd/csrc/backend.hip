@@ -709,14 +709,13 @@ __device__ __forceinline__ void sum_stats_body(const double* __restrict__ pe, in
         for (int i = threadIdx.x; i < nE; i += 256) a0 += pe[i];
         for (int i = threadIdx.x; i < nL; i += 256) a1 += pl[i];
         for (int i = threadIdx.x; i < nS; i += 256) { a2 += ps[i]; a3 += ps[nS + i]; }
-        s[0][threadIdx.x] = a0; s[1][threadIdx.x] = a1; s[2][threadIdx.x] = a2; s[3][threadIdx.x] = a3;
+        // fixed order: 256 strided lane sums, a 64-lane tree per wave (DPP, no barrier), the four wave sums in index order
+        a0 = wave_sum_double(a0); a1 = wave_sum_double(a1); a2 = wave_sum_double(a2); a3 = wave_sum_double(a3);
+        if ((threadIdx.x & 63) == 63) { const int w = threadIdx.x >> 6; s[0][w] = a0; s[1][w] = a1; s[2][w] = a2; s[3][w] = a3; }
     }
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) for (int q = 0; q < 4; ++q) s[q][threadIdx.x] += s[q][threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x < 4) out[threadIdx.x] = s[threadIdx.x][0];
+    if (threadIdx.x < 4) { const int q = threadIdx.x; s[q][0] = ((s[q][0] + s[q][1]) + s[q][2]) + s[q][3]; out[q] = s[q][0]; }
+    __syncthreads();
     if (dec.on && threadIdx.x == 0) {
         const double newEnergy = s[0][0];
         const double newEnergyL = dec.En + (double)(float)s[1][0];                  // linearize_wait's expression
@@ -1531,7 +1530,7 @@ static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_st
             if (ef_sharded(e) && (rc = ef_allreduce(e, e->acc_dev, (int)acc_count(e)))) return rc;
         }
         const int has_sel = e->pend_sel_valid ? 1 : 0;
-        k_ef_stitch<<<nF + 1 + has_sel, kSolveLanes, 0, e->stream>>>(io, e->pend_sel, has_sel);
+        k_ef_stitch<<<kStitchParts * nF + 1 + has_sel, kSolveLanes, 0, e->stream>>>(io, e->pend_sel, has_sel);
         e->pend_sel_valid = false;
     }
     if (e->pend_sel_valid) ef_flush_pending(e);    // system re-used: no stitch launch to ride in
