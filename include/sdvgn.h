@@ -65,7 +65,10 @@ int sdvgn_tracker_set_arith(sdvgn_tracker* t, int mode);
 /* Workgroups per pose hypothesis of sdvgn_tracker_track_batch: 0 = automatic (one pass of 256-lane workgroups over the largest level, at
  * most 32, as long as the whole launch is resident at once; otherwise one 1024-lane workgroup per hypothesis), -1 = always one workgroup
  * (k_track), 1..32 = that many (k_track_team).  Results do not depend on it beyond the summation order of the 52 totals.
- * sdvgn_tracker_get_team: what the last track_batch call used (0 = k_track). */
+ * sdvgn_tracker_get_team: what the last track_batch call used (0 = k_track).
+ * The workgroups of a team wait for each other inside the kernel, so a team launch needs its whole grid resident (the size limit above takes
+ * care of that for ONE launch): do not run track_batch of two handles concurrently on one device through caller-provided streams -- the
+ * library's shared tracker stream serialises them; a team that cannot assemble gives up after ~1 s with SDVGN_E_STATE, it does not hang. */
 int sdvgn_tracker_set_team(sdvgn_tracker* t, int team);
 int sdvgn_tracker_get_team(sdvgn_tracker* t);
 
