@@ -129,7 +129,8 @@ struct sdvgn_ef {
     // after a rejected step ride in later launches as extra workgroups; whatever is still pending is launched on its own by ef_flush_pending
     SelArgs pend_sel{}; bool pend_sel_valid = false;
     int lin_partials = 0, lin_nL = 0;   // of the linearise launched last (linearize_launch_kernels -> linearize_launch_stats)
-    int* accept_dev = nullptr;          // verdict of the device-side accept test, read by the conditional k_ef_apply
+    int* accept_dev = nullptr;          // verdict of the device-side accept test ([0]; [4]: the tagged verdict word of k_ef_stats_apply)
+    unsigned seq_verdict = 0;
     ReclArgs pend_rc{}; bool pend_rc_valid = false;
     bool time_lin = false;         // optimize flags bit3: HIP event pair around every k_ef_linearize launch of the call
     std::vector<hipEvent_t> lin_events;
@@ -700,10 +701,10 @@ __global__ void __launch_bounds__(256) k_ef_point_stats(EFConst Cin, EFArrays A,
 // it owns (the prior part of the L energy of the stepped state, the M energy, the right-hand side from the last accepted state) before the
 // sums exist, the kernel finishes the comparison with the same double operations in the same order and leaves the verdict for the
 // conditional k_ef_apply queued right behind it (accept_dev) and for the host (out[4]).
-struct DecideArgs { double En, EM, rhs; int* accept_dev; int on; };
+struct DecideArgs { double En, EM, rhs; int* accept_dev; int on; unsigned* verdict; unsigned seq; };
 __device__ __forceinline__ void sum_stats_body(const double* __restrict__ pe, int nE, const double* __restrict__ pl, int nL,
                                                const double* __restrict__ ps, int nS, double* __restrict__ out, volatile int* done_flag, int done_seq,
-                                               double (*s)[256], const DecideArgs& dec = DecideArgs{0, 0, 0, nullptr, 0}) {
+                                               double (*s)[256], const DecideArgs& dec = DecideArgs{0, 0, 0, nullptr, 0, nullptr, 0}) {
     if (threadIdx.x < 256) {
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         for (int i = threadIdx.x; i < nE; i += 256) a0 += pe[i];
@@ -720,6 +721,8 @@ __device__ __forceinline__ void sum_stats_body(const double* __restrict__ pe, in
         const double newEnergy = s[0][0];
         const double newEnergyL = dec.En + (double)(float)s[1][0];                  // linearize_wait's expression
         const bool accept = (newEnergy + newEnergyL) + dec.EM < dec.rhs;
+        // first of all the verdict for the apply workgroups of the same launch (k_ef_stats_apply): one tagged word, relaxed device-scope store
+        if (dec.verdict) __hip_atomic_store(dec.verdict, (dec.seq << 1) | (accept ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *dec.accept_dev = accept ? 1 : 0;
         out[4] = accept ? 1.0 : 0.0;
     }
@@ -741,6 +744,22 @@ __global__ void __launch_bounds__(kSelLanes) k_ef_stats_select(const double* __r
     __shared__ union U { double s[4][256]; SelectSmem sel; __device__ U() {} } S;
     if (blockIdx.x == 0) sum_stats_body(pe, nE, pl, nL, ps, nS, out, done_flag, done_seq, S.s, dec);
     else select_th_body<0>(a.nF, a.nP, a.own0, a.own1, a.rflags, a.wo, nullptr, a.th_prev, a.th_out, a.log_slot, S.sel);
+}
+
+// The statistics of a trial linearizeAll, the accept test and applyRes in ONE launch (optimize loop, single rank): workgroup 0 sums, decides,
+// publishes the verdict word and then the sums + flag for the host; every other workgroup is k_ef_apply for 256 slots -- its loads in
+// flight while the verdict is being formed, its stores only if the verdict says accept.  Workgroup 0 is dispatched first and the whole
+// grid is resident at once (2 waves of 256-lane workgroups on 256 CUs), so the poll cannot starve it.
+__global__ void __launch_bounds__(256) k_ef_stats_apply(const double* __restrict__ pe, int nE, const double* __restrict__ pl, int nL,
+                                                        const double* __restrict__ ps, int nS, double* __restrict__ out, volatile int* done_flag,
+                                                        int done_seq, DecideArgs dec, int nF, int nP, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                        const int* __restrict__ phost) {
+    if (blockIdx.x == 0) {
+        __shared__ double s[4][256];
+        sum_stats_body(pe, nE, pl, nL, ps, nS, out, done_flag, done_seq, s, dec);
+        return;
+    }
+    apply_slot(nF, nP, A, precalc, phost, (size_t)(blockIdx.x - 1) * 256 + threadIdx.x, nullptr, dec.verdict, dec.seq);
 }
 
 // device buffer -> pinned host buffer + completion flag (waitflag.hpp): the read-back after an all-reduce without the copy engine
@@ -931,6 +950,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     HIPCHK(hipHostMalloc(&e->acc_host, sizeof(double) * accmax));
     HIPCHK(hipHostMalloc(&e->stats_host, sizeof(double) * 8));
     HIPCHK(hipMalloc((void**)&e->accept_dev, 64));
+    HIPCHK(hipMemset(e->accept_dev, 0, 64));
     HIPCHK(hipHostMalloc((void**)&e->flags_host, 64));
     HIPCHK(hipHostMalloc((void**)&e->th_log, sizeof(float) * kThLog));
     HIPCHK(hipHostMalloc((void**)&e->win_host, sizeof(SolveWindow)));
@@ -1643,7 +1663,13 @@ static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideAr
         ef_owned_points(e, a.own0, a.own1);
         a.rflags = e->rflags; a.wo = e->A.renergy_wo; a.th_prev = e->A.frameTH_r; a.th_out = e->A.frameTH_w;
         a.log_slot = e->th_log ? e->th_log + (e->th_log_n++ % kThLog) : nullptr;
-        const DecideArgs none{0, 0, 0, nullptr, 0};
+        const DecideArgs none{0, 0, 0, nullptr, 0, nullptr, 0};
+        if (dec && dec->verdict) {   // statistics + accept test + conditional applyRes of the trial set in one launch
+            const size_t slots = (size_t)e->nF * e->nP;
+            k_ef_stats_apply<<<1 + (unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host,
+                                                                                       e->flags_host + 2, ++e->seq_stats, *dec, e->nF, e->nP, e->A, e->precalc_dev,
+                                                                                       e->phost_dev);
+        } else
         k_ef_stats_select<<<defer_select ? 1 : 2, kSelLanes, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host,
                                                                               e->flags_host + 2, ++e->seq_stats, a, dec ? *dec : none);
         if (defer_select) { e->pend_sel = a; e->pend_sel_valid = true; }
@@ -1768,9 +1794,8 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             // the trial linearisation, which returns at once when the step is rejected
             DecideArgs dec;
             dec.En = host_prior_energy(e); dec.EM = newEnergyM; dec.rhs = lastEnergy + lastEnergyL + lastEnergyM; dec.accept_dev = e->accept_dev; dec.on = 1;
+            dec.verdict = (unsigned*)(e->accept_dev + 4); dec.seq = (unsigned)(++e->seq_verdict) & 0x7fffffffu;
             if ((rc = linearize_launch_stats(e, defer, &dec))) return rc;
-            k_ef_apply<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->nF, e->nP, e->A, e->precalc_dev, e->phost_dev, e->accept_dev);
-            HIPCHK(hipGetLastError());
         }
         g_pt.stop(PT_STEP);
         double newEnergy, newEnergyL, sID, sNID;

@@ -597,17 +597,30 @@ __global__ void __launch_bounds__(64) k_ef_optimize_immature(EFConst C, const fl
 // planes of the buffer the flip would select right behind the flags, so that the kernel is two memory round trips deep instead
 // of six; which values are used is decided afterwards.
 // cond (may be NULL): the verdict of the device-side accept test; 0 = the step was rejected, nothing is applied.
+// verdict (may be NULL): the same verdict as a tagged word (seq << 1 | accept) that ANOTHER workgroup of this launch publishes
+// (k_ef_stats_apply): polled after this lane's loads are in flight.
 __device__ __forceinline__ void apply_slot(int nF, int nP, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
-                                           const int* __restrict__ phost, size_t s, const int* __restrict__ cond) {
+                                           const int* __restrict__ phost, size_t s, const int* __restrict__ cond,
+                                           const unsigned* verdict = nullptr, unsigned seq = 0) {
     const size_t slots = (size_t)nF * nP;
     if (s >= slots) return;
-    const int go = cond ? *cond : 1;
+    int go = cond ? *cond : 1;
     const int hh = phost[s % nP];
     uint8_t fl = A.rflags[s];
     const int st = A.rstate[s];
     const int sn = A.rstate_new[s];
     const float en = A.renergy_new[s];
     __builtin_amdgcn_sched_barrier(0);
+    if (verdict) {
+        unsigned w = 0;
+        int polls = 0;
+        for (;;) {
+            w = __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((w >> 1) == seq || ++polls > (1 << 18)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        go = ((w >> 1) == seq) ? (int)(w & 1u) : 0;      // (a verdict that never arrives applies nothing; the host notices: the flag does not arrive either)
+    }
     if (!go) return;
     const int np_h = precalc[hh * nF + hh].np;
     const int buf = (fl & RF_SEL) ? 0 : 1;              // the buffer the residual's freshly linearised J sits in

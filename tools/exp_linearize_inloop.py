@@ -42,15 +42,17 @@ def main():
                        cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
         dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
         con = sqlite3.connect(dbs[0])
-        names = ["k_ef_linearize", "k_ef_acc_fused", "k_ef_acc_reduce", "k_ef_stitch", "k_ef_solve_tail", "k_ef_resubstitute_step", "k_ef_stats_select", "k_ef_apply"]
+        names = ["k_ef_linearize", "k_ef_acc_fused", "k_ef_acc_reduce", "k_ef_stitch", "k_ef_solve_tail", "k_ef_resubstitute_step", "k_ef_stats_select", "k_ef_stats_apply", "k_ef_apply", "k_ef_linearize"]
         print("# %s" % ("8 windows, a handle each" if mode == "many" else "one handle, reloaded before every call"))
         for nm in names:
             du = np.array([r[0] for r in con.execute("select duration from kernels where name like ? order by start", ("%" + nm + "%",))], np.float64) / 1e3
-            if nm == "k_ef_linearize":
+            if nm == "k_ef_linearize" and names.index(nm) == 0:
                 du = du[-56:].reshape(8, 7)
                 print("k_ef_linearize by position in the call (mean over 8 calls):", np.round(du.mean(axis=0), 2), " all: mean %.2f" % du.mean())
                 print("   first call:", np.round(du[0], 2), " last call:", np.round(du[-1], 2))
             else:
+                if not len(du):
+                    continue
                 k = len(du) * 8 // 9 if len(du) >= 9 else len(du)
                 print("%-26s mean %6.2f  median %6.2f  (n %d)" % (nm, du[-k:].mean(), np.median(du[-k:]), k))
         shutil.rmtree(d, ignore_errors=True)
