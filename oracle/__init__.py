@@ -1,4 +1,6 @@
-"""CPU oracle loader -- TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see oracle/README.md).
+"""CPU oracle loader -- TEST INFRASTRUCTURE ONLY.  PARITY PINNED IN PART: the accumulators, the bilinear taps and the affine-brightness
+transfer are checked bit for bit against the reference's own headers (oracle/refpin.py, tests/test_ref_pin.py); everything else is
+UNPINNED (see oracle/README.md).
 
 ctypes front-end for ``oracle/liborc.so`` (built by ``make -C oracle`` from orc_tracker.cpp /
 orc_backend.cpp, the plain-C++ restatement of the reference's CPU hot path).

@@ -114,6 +114,30 @@ struct AccumulatorApprox {
     }
 };
 
+// ---- Accumulator11 (MatrixAccumulators.h:69-146): one float in SSE lane 0, three tiers shifted up every 1000 entries ----------------
+struct Accumulator11 {
+    float S[4], S1k[4], S1m[4];
+    float numIn1, numIn1k, numIn1m;
+    size_t num;
+    float A;
+    void initialize() { std::memset(this, 0, sizeof(*this)); }
+    void shiftUp(bool force) {  // :130-145
+        if (numIn1 > 1000 || force) {
+            for (int i = 0; i < 4; ++i) S1k[i] = S[i] + S1k[i];
+            numIn1k += numIn1; numIn1 = 0;
+            std::memset(S, 0, sizeof(S));
+        }
+        if (numIn1k > 1000 || force) {
+            for (int i = 0; i < 4; ++i) S1m[i] = S1k[i] + S1m[i];
+            numIn1m += numIn1k; numIn1k = 0;
+            std::memset(S1k, 0, sizeof(S1k));
+        }
+    }
+    void updateSingle(float val) { S[0] += val; num++; numIn1++; shiftUp(false); }          // :92-98
+    void updateSingleNoShift(float val) { S[0] += val; num++; numIn1++; }                    // :109-114
+    void finish() { shiftUp(true); A = S1m[0] + S1m[1] + S1m[2] + S1m[3]; }                  // :86-90
+};
+
 // ---- AccumulatorXX<i,j> / AccumulatorX<i> (MatrixAccumulators.h:13-66,148-208), i,j <= 8 ---------------
 struct AccXX {
     int I, J;
@@ -918,7 +942,8 @@ static double calc_L_energy(EF* E) {
     double En = 0;
     for (const Frame& f : E->frames) for (int i = 0; i < 6; ++i) En += f.delta_prior[i] * f.prior[i] * f.delta_prior[i];
     { float a = 0; for (int i = 0; i < 4; ++i) a += E->cDeltaF[i] * E->cPriorF[i] * E->cDeltaF[i]; En += a; }
-    float acc = 0;   // Accumulator11 (float, tiered) -- only priors of points and linearised residuals contribute
+    Accumulator11 acc;   // float, tiered: residual terms enter without a shift check, every point's prior term with one (:322,:325)
+    acc.initialize();
     for (const Point& p : E->points) {
         for (int ri = p.r0; ri < p.r1; ++ri) {
             const Residual& r = E->res[ri];
@@ -928,11 +953,12 @@ static double calc_L_energy(EF* E) {
             for (int i = 0; i < 6; ++i) { dx += r.Jef.Jpdxi[0][i] * dp[i]; dy += r.Jef.Jpdxi[1][i] * dp[i]; }
             for (int i = 0; i < 4; ++i) { cx += r.Jef.Jpdc[0][i] * E->cDeltaF[i]; cy += r.Jef.Jpdc[1][i] * E->cDeltaF[i]; }
             const float jx = dx + cx + r.Jef.Jpdd[0] * p.deltaF, jy = dy + cy + r.Jef.Jpdd[1] * p.deltaF;
-            acc += (r.res_toZeroF[0] * jx + r.res_toZeroF[1] * jy) + (jx * r.res_toZeroF[0] + jy * r.res_toZeroF[1]) + (jx * jx + jy * jy);
+            acc.updateSingleNoShift((r.res_toZeroF[0] * jx + r.res_toZeroF[1] * jy) + (jx * r.res_toZeroF[0] + jy * r.res_toZeroF[1]) + (jx * jx + jy * jy));
         }
-        acc += p.deltaF * p.deltaF * p.priorF;
+        acc.updateSingle(p.deltaF * p.deltaF * p.priorF);
     }
-    return En + acc;
+    acc.finish();
+    return En + acc.A;
 }
 // EnergyFunctional::calcMEnergyF (:284-295)
 static double calc_M_energy(EF* E) {
@@ -1325,6 +1351,32 @@ static int imm_optimize(const EF* E, const ImmPt& pt, int minObs, ImmRes* res, f
 }
 
 extern "C" {
+// ---- hooks with the signatures of oracle/ref_glue.cpp (tests/test_ref_pin.py) ----
+void orc_kat_acc_approx(int n, const float* in, float* H169, double* num) {
+    AccumulatorApprox* acc = new AccumulatorApprox();
+    acc->initialize();
+    for (int i = 0; i < n; ++i) {
+        const float* p = in + (size_t)35 * i;
+        acc->update(p, p + 4, p + 10, p + 14, p[20], p[21], p[22]);
+        acc->updateTopRight(p, p + 4, p + 10, p + 14, p[23], p[24], p[25], p[26], p[27], p[28]);
+        acc->updateBotRight(p[29], p[30], p[31], p[32], p[33], p[34]);
+    }
+    acc->finish();
+    for (int a = 0; a < 13; ++a) for (int b = 0; b < 13; ++b) H169[a * 13 + b] = acc->H[a][b];
+    *num = (double)acc->num;
+    delete acc;
+}
+void orc_kat_acc11(int n, const float* vals, float* A) {
+    Accumulator11 acc;
+    acc.initialize();
+    for (int i = 0; i < n; ++i) acc.updateSingle(vals[i]);
+    acc.finish();
+    *A = acc.A;
+}
+void orc_kat_interp33_backend(const float* img3, int width, int n, const float* x, const float* y, float* out3) {
+    for (int i = 0; i < n; ++i) interp33(img3, x[i], y[i], width, out3 + 3 * i);
+}
+
 
 void* orc_ef_create(int w, int h) {
     EF* E = new EF();

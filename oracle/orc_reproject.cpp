@@ -310,6 +310,11 @@ static bool find_match(const Reproj* R, float u, float v, float idepth, const Rp
 using namespace orc;
 
 extern "C" {
+// hook with the signature of oracle/ref_glue.cpp (tests/test_ref_pin.py)
+void orc_kat_interp31_reproject(const float* img3, int width, int n, const float* x, const float* y, float* out) {
+    for (int i = 0; i < n; ++i) out[i] = interp_I(img3, x[i], y[i], width);
+}
+
 
 void* orc_rp_create(int w0, int h0, int levels) {
     Reproj* R = new Reproj();

@@ -195,6 +195,14 @@ static int trace_on(TracePt& P, const float* dI, int w, int h, const float* KRKi
 using namespace orc;
 
 extern "C" {
+// hooks with the signatures of oracle/ref_glue.cpp (tests/test_ref_pin.py)
+void orc_kat_interp31_trace(const float* img3, int width, int n, const float* x, const float* y, float* out) {
+    for (int i = 0; i < n; ++i) out[i] = interp31(img3, x[i], y[i], width);
+}
+void orc_kat_interp33_trace(const float* img3, int width, int n, const float* x, const float* y, float* out3) {
+    for (int i = 0; i < n; ++i) interp33t(img3, x[i], y[i], width, out3 + 3 * i);
+}
+
 
 // points: SoA in/out.  state[n][5] = {idepth_min, idepth_max, quality, lastTraceUV.x, lastTraceUV.y} and interval[n], status[n] are
 // updated in place; host_idx selects the per-host KRKi (9) / Kt (3) / aff (2) the caller computed as FullSystem::traceNewCoarse does.

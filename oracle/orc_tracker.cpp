@@ -831,4 +831,28 @@ void orc_se3_adj(const double A[7], double out36[36]) { SE3 a; std::memcpy(a.q, 
 void orc_ldlt_solve(int n, const double* A, const double* b, double* x) { ldlt_solve(n, A, b, x); }
 void orc_inv3f(const float* m, float* out) { inv3f(m, out); }
 void orc_interp33(const float* mat, float x, float y, int width, float out[3]) { interp33(mat, x, y, width, out); }
+
+// ---- hooks with the signatures of oracle/ref_glue.cpp: the restatements above, driven like the reference's own classes are there
+// (tests/test_ref_pin.py compares the two bit for bit) ----
+void orc_kat_aff_from_to(float exposureF, float exposureT, double aF, double bF, double aT, double bT, double* ab) {
+    aff_from_to(exposureF, exposureT, aF, bF, aT, bT, ab);
+}
+void orc_kat_interp33(const float* img3, int width, int n, const float* x, const float* y, float* out3) {
+    for (int i = 0; i < n; ++i) interp33(img3, x[i], y[i], width, out3 + 3 * i);
+}
+void orc_kat_acc9(int n4, const float* J, const float* w, float* H81, double* num) {
+    Accumulator9* acc = new Accumulator9();
+    acc->initialize();
+    const size_t N = (size_t)4 * n4;
+    for (int g = 0; g < n4; ++g) {
+        float Jg[9][4], wg[4];
+        for (int k = 0; k < 9; ++k) for (int l = 0; l < 4; ++l) Jg[k][l] = J[k * N + 4 * g + l];
+        for (int l = 0; l < 4; ++l) wg[l] = w[4 * g + l];
+        acc->updateWeighted(Jg, wg);
+    }
+    acc->finish();
+    for (int a = 0; a < 9; ++a) for (int b = 0; b < 9; ++b) H81[a * 9 + b] = acc->H[a][b];
+    *num = (double)acc->num;
+    delete acc;
+}
 }

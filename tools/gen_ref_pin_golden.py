@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""tests/golden/ref_pin.npz = outputs of the REFERENCE's own code (oracle/_ref/libref.so: three reference headers compiled unmodified, see
+oracle/ref_glue.cpp) for the input sets of oracle/refpin.py.  Run in the container that has /root/reference:
+    make -C oracle ref && python tools/gen_ref_pin_golden.py"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from oracle import refpin  # noqa: E402
+
+L = refpin.ref_lib()
+if L is None:
+    sys.exit("oracle/_ref/libref.so is missing: make -C oracle ref (needs /root/reference)")
+out = refpin.run(L, "ref_")
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "ref_pin.npz")
+np.savez_compressed(path, **out)
+print("wrote", path, {k: v.shape for k, v in out.items()})
