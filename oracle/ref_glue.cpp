@@ -2,7 +2,8 @@
 // where they lie under /root/reference, the three reference headers whose hot-path code has no dependency beyond Eigen's storage types --
 //     src/util/NumType.h                                AffLight::fromToVecExposure                      
 //     src/util/globalFuncs.h                            getInterpolatedElement33 / 31 / 33BiLin          (row a9)
-//     src/OptimizationBackend/MatrixAccumulators.h      Accumulator9, AccumulatorApprox, AccumulatorXX / X, Accumulator11   (rows a6, b3, b7)
+//     src/OptimizationBackend/MatrixAccumulators.h      Accumulator9, AccumulatorApprox, Accumulator11                   (rows a6, b3)
+// -- and, linked beside it, the reference's src/util/settings.cpp (every setting_* constant of the hot path; needs an empty boost/bind.hpp)
 // -- against the stand-in for Eigen's interface in oracle/ref_shim (see the header of ref_shim/Eigen/Core for what that stand-in does and
 // does not do).  Built by `make -C oracle ref` into oracle/_ref/libref.so when /root/reference is present; tests/test_ref_pin.py runs the
 // oracle's restatements of the same classes against it bit for bit, and tools/gen_ref_pin_golden.py stores its outputs as the
@@ -88,6 +89,67 @@ void ref_acc11(int n, const float* vals, float* A) {
     acc->finish();
     *A = acc->A;
     delete acc;
+}
+
+// The values of the reference's settings (src/util/settings.cpp, compiled unmodified into this library): the constants the oracle and the
+// product carry as literals are compared with these by name (tests/test_ref_pin.py).  Returns 1 and *out = value, or 0 for an unknown name.
+int ref_setting(const char* name, double* out) {
+    struct Entry { const char* name; double value; };
+    const Entry table[] = {
+    {"pyrLevelsUsed", (double)sdv_loam::pyrLevelsUsed},
+    {"setting_idepthFixPrior", (double)sdv_loam::setting_idepthFixPrior},
+    {"setting_idepthFixPriorMargFac", (double)sdv_loam::setting_idepthFixPriorMargFac},
+    {"setting_initialRotPrior", (double)sdv_loam::setting_initialRotPrior},
+    {"setting_initialTransPrior", (double)sdv_loam::setting_initialTransPrior},
+    {"setting_initialAffBPrior", (double)sdv_loam::setting_initialAffBPrior},
+    {"setting_initialAffAPrior", (double)sdv_loam::setting_initialAffAPrior},
+    {"setting_initialCalibHessian", (double)sdv_loam::setting_initialCalibHessian},
+    {"setting_solverMode", (double)sdv_loam::setting_solverMode},
+    {"setting_solverModeDelta", (double)sdv_loam::setting_solverModeDelta},
+    {"setting_minIdepthH_act", (double)sdv_loam::setting_minIdepthH_act},
+    {"setting_minIdepthH_marg", (double)sdv_loam::setting_minIdepthH_marg},
+    {"setting_maxPixSearch", (double)sdv_loam::setting_maxPixSearch},
+    {"setting_desiredImmatureDensity", (double)sdv_loam::setting_desiredImmatureDensity},
+    {"setting_desiredPointDensity", (double)sdv_loam::setting_desiredPointDensity},
+    {"setting_minPointsRemaining", (double)sdv_loam::setting_minPointsRemaining},
+    {"setting_maxLogAffFacInWindow", (double)sdv_loam::setting_maxLogAffFacInWindow},
+    {"setting_minFrames", (double)sdv_loam::setting_minFrames},
+    {"setting_maxFrames", (double)sdv_loam::setting_maxFrames},
+    {"setting_minFrameAge", (double)sdv_loam::setting_minFrameAge},
+    {"setting_maxOptIterations", (double)sdv_loam::setting_maxOptIterations},
+    {"setting_minOptIterations", (double)sdv_loam::setting_minOptIterations},
+    {"setting_thOptIterations", (double)sdv_loam::setting_thOptIterations},
+    {"setting_outlierTH", (double)sdv_loam::setting_outlierTH},
+    {"setting_outlierTHSumComponent", (double)sdv_loam::setting_outlierTHSumComponent},
+    {"setting_margWeightFac", (double)sdv_loam::setting_margWeightFac},
+    {"setting_GNItsOnPointActivation", (double)sdv_loam::setting_GNItsOnPointActivation},
+    {"setting_minTraceQuality", (double)sdv_loam::setting_minTraceQuality},
+    {"setting_minTraceTestRadius", (double)sdv_loam::setting_minTraceTestRadius},
+    {"setting_reTrackThreshold", (double)sdv_loam::setting_reTrackThreshold},
+    {"setting_affineOptModeA", (double)sdv_loam::setting_affineOptModeA},
+    {"setting_affineOptModeB", (double)sdv_loam::setting_affineOptModeB},
+    {"setting_forceAceptStep", (double)sdv_loam::setting_forceAceptStep},
+    {"setting_huberTH", (double)sdv_loam::setting_huberTH},
+    {"setting_frameEnergyTHConstWeight", (double)sdv_loam::setting_frameEnergyTHConstWeight},
+    {"setting_frameEnergyTHN", (double)sdv_loam::setting_frameEnergyTHN},
+    {"setting_frameEnergyTHFacMedian", (double)sdv_loam::setting_frameEnergyTHFacMedian},
+    {"setting_overallEnergyTHWeight", (double)sdv_loam::setting_overallEnergyTHWeight},
+    {"setting_coarseCutoffTH", (double)sdv_loam::setting_coarseCutoffTH},
+    {"setting_trace_stepsize", (double)sdv_loam::setting_trace_stepsize},
+    {"setting_trace_GNIterations", (double)sdv_loam::setting_trace_GNIterations},
+    {"setting_trace_GNThreshold", (double)sdv_loam::setting_trace_GNThreshold},
+    {"setting_trace_extraSlackOnTH", (double)sdv_loam::setting_trace_extraSlackOnTH},
+    {"setting_trace_slackInterval", (double)sdv_loam::setting_trace_slackInterval},
+    {"setting_trace_minImprovementFactor", (double)sdv_loam::setting_trace_minImprovementFactor},
+    {"multiThreading", (double)sdv_loam::multiThreading}
+    };
+    for (const Entry& e : table) if (!std::strcmp(e.name, name)) { *out = e.value; return 1; }
+    return 0;
+}
+int ref_setting_count() { return 46; }
+const char* ref_setting_name(int i) {
+    static const char* names[] = {"pyrLevelsUsed", "setting_idepthFixPrior", "setting_idepthFixPriorMargFac", "setting_initialRotPrior", "setting_initialTransPrior", "setting_initialAffBPrior", "setting_initialAffAPrior", "setting_initialCalibHessian", "setting_solverMode", "setting_solverModeDelta", "setting_minIdepthH_act", "setting_minIdepthH_marg", "setting_maxPixSearch", "setting_desiredImmatureDensity", "setting_desiredPointDensity", "setting_minPointsRemaining", "setting_maxLogAffFacInWindow", "setting_minFrames", "setting_maxFrames", "setting_minFrameAge", "setting_maxOptIterations", "setting_minOptIterations", "setting_thOptIterations", "setting_outlierTH", "setting_outlierTHSumComponent", "setting_margWeightFac", "setting_GNItsOnPointActivation", "setting_minTraceQuality", "setting_minTraceTestRadius", "setting_reTrackThreshold", "setting_affineOptModeA", "setting_affineOptModeB", "setting_forceAceptStep", "setting_huberTH", "setting_frameEnergyTHConstWeight", "setting_frameEnergyTHN", "setting_frameEnergyTHFacMedian", "setting_overallEnergyTHWeight", "setting_coarseCutoffTH", "setting_trace_stepsize", "setting_trace_GNIterations", "setting_trace_GNThreshold", "setting_trace_extraSlackOnTH", "setting_trace_slackInterval", "setting_trace_minImprovementFactor", "multiThreading"};
+    return (i >= 0 && i < 46) ? names[i] : "";
 }
 
 }  // extern "C"

@@ -51,6 +51,36 @@ def ref_lib():
     return L
 
 
+def ref_settings(L):
+    """{name: value} of the setting_* constants the reference's settings.cpp defines (compiled unmodified into libref.so)"""
+    L.ref_setting_name.restype = C.c_char_p
+    L.ref_setting.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
+    out = {}
+    v = C.c_double()
+    for i in range(L.ref_setting_count()):
+        nm = L.ref_setting_name(i)
+        assert L.ref_setting(nm, C.byref(v)) == 1
+        out[nm.decode()] = v.value
+    return out
+
+
+def source_settings(paths):
+    """`setting_xxx = <literal expression>` declarations found in source files -> [(file, name, value)]; the oracle and the product keep the
+    reference's names for the constants they carry as literals (a suffix after the reference's name, e.g. _imm, marks a second copy)."""
+    import re
+    found = []
+    pat = re.compile(r"\b(setting_[A-Za-z0-9_]+)\s*=\s*([-+0-9.eE*f ()]+?)\s*[,;]")
+    for p in paths:
+        for m in pat.finditer(open(p).read()):
+            expr = re.sub(r"(?<=[0-9.])f\b", "", m.group(2))
+            try:
+                val = float(eval(expr, {"__builtins__": {}}))
+            except Exception:  # noqa: BLE001
+                continue
+            found.append((os.path.basename(p), m.group(1), val))
+    return found
+
+
 def orc_fn(name):
     import oracle
     fn = getattr(oracle.lib(), name)

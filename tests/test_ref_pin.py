@@ -14,6 +14,8 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_p
 
 def _compare(ref, orc):
     for name, want in ref.items():
+        if name.startswith("settings_"):
+            continue
         got = [v for k, v in orc.items() if k == name or k.startswith(name + ":")]
         assert got, name
         for g in got:
@@ -32,9 +34,43 @@ def test_oracle_matches_reference_library():
     ref = refpin.run(L, "ref_")
     _compare(ref, refpin.run(None, None))
     gold = dict(np.load(GOLD))                      # and the committed fixture IS what the reference code produces
-    assert set(gold) == set(ref)
+    assert set(gold) - {"settings_names", "settings_values"} == set(ref)
     for k in ref:
         assert np.array_equal(ref[k], gold[k]), k
+    st = refpin.ref_settings(L)
+    assert list(gold["settings_names"]) == sorted(st) and np.array_equal(gold["settings_values"], [st[k] for k in sorted(st)])
+
+
+def test_literal_settings_match_reference_settings_cpp():
+    """Every `setting_xxx = literal` the oracle and the product carry equals the value the reference's own settings.cpp defines (compiled
+    unmodified into oracle/_ref; values from the committed fixture).  float settings compare as float32."""
+    import glob
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    gold = np.load(GOLD)
+    ref = dict(zip([str(n) for n in gold["settings_names"]], gold["settings_values"]))
+    srcs = glob.glob(os.path.join(root, "oracle", "orc_*.cpp")) + glob.glob(os.path.join(root, "oracle", "*.hpp")) + \
+        glob.glob(os.path.join(root, "sdv-loam_amd", "csrc", "*"))
+    found = refpin.source_settings(srcs)
+    checked = 0
+    for fname, name, val in found:
+        base = name
+        while base not in ref and "_" in base:          # a suffixed second copy (setting_huberTH_imm) checks against its base name
+            base = base.rsplit("_", 1)[0]
+        if base not in ref:
+            continue
+        assert np.float32(val) == np.float32(ref[base]), (fname, name, val, ref[base])
+        checked += 1
+    assert checked >= 30, checked
+    # the product's own names for some of them
+    import re
+    alias = {"kInitialRotPrior": "setting_initialRotPrior", "kInitialTransPrior": "setting_initialTransPrior",
+             "kInitialCalibHessian": "setting_initialCalibHessian", "kIdepthFixPrior": "setting_idepthFixPrior",
+             "huberTH": "setting_huberTH", "coarseCutoffTH": "setting_coarseCutoffTH"}
+    text = open(os.path.join(root, "sdv-loam_amd", "csrc", "backend.hip")).read() + open(os.path.join(root, "sdv-loam_amd", "csrc", "tracker.hip")).read()
+    for name, ref_name in alias.items():
+        m = re.search(r"\b%s\s*=\s*([-+0-9.eE* ]+)f?\s*[,;]" % name, text)
+        assert m, name
+        assert np.float32(eval(m.group(1), {"__builtins__": {}})) == np.float32(ref[ref_name]), (name, m.group(1), ref[ref_name])
 
 
 def test_tier_shift_matters():

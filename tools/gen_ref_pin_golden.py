@@ -14,6 +14,9 @@ L = refpin.ref_lib()
 if L is None:
     sys.exit("oracle/_ref/libref.so is missing: make -C oracle ref (needs /root/reference)")
 out = refpin.run(L, "ref_")
+st = refpin.ref_settings(L)
+out["settings_names"] = np.array(sorted(st))
+out["settings_values"] = np.array([st[k] for k in sorted(st)])
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "ref_pin.npz")
 np.savez_compressed(path, **out)
 print("wrote", path, {k: v.shape for k, v in out.items()})
