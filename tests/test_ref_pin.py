@@ -14,7 +14,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_p
 
 def _compare(ref, orc):
     for name, want in ref.items():
-        if name.startswith("settings_"):
+        if name.startswith("settings_") or name.startswith("scale_"):
             continue
         got = [v for k, v in orc.items() if k == name or k.startswith(name + ":")]
         assert got, name
@@ -34,7 +34,7 @@ def test_oracle_matches_reference_library():
     ref = refpin.run(L, "ref_")
     _compare(ref, refpin.run(None, None))
     gold = dict(np.load(GOLD))                      # and the committed fixture IS what the reference code produces
-    assert set(gold) - {"settings_names", "settings_values"} == set(ref)
+    assert set(gold) - {"settings_names", "settings_values", "scale_names", "scale_values"} == set(ref)
     for k in ref:
         assert np.array_equal(ref[k], gold[k]), k
     st = refpin.ref_settings(L)
@@ -81,3 +81,21 @@ def test_tier_shift_matters():
         seq = np.float32(seq + x)
     ref = dict(np.load(GOLD))["acc11_tiers"][0]
     assert ref != seq and abs(float(ref) - float(seq)) / float(seq) < 1e-4
+
+
+def test_scale_macros_match_reference_header():
+    """SCALE_* (HessianBlocks.h:33-40, read from the header text into the fixture) against the product's SDVGN_SCALE_* and the oracle's SCALE_*"""
+    import glob
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    gold = np.load(GOLD)
+    ref = dict(zip([str(n) for n in gold["scale_names"]], gold["scale_values"]))
+    assert len(ref) == 8
+    checked = 0
+    for p in glob.glob(os.path.join(root, "sdv-loam_amd", "csrc", "*")) + glob.glob(os.path.join(root, "oracle", "orc_*")):
+        text = open(p).read()
+        for name, val in re.findall(r"\b(?:SDVGN_)?(SCALE_[A-Z_]+)\s*(?:=\s*)?([0-9.]+)f", text):
+            if name in ref:
+                assert float(val) == ref[name], (p, name, val)
+                checked += 1
+    assert checked >= 10, checked

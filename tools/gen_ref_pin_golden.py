@@ -17,6 +17,12 @@ out = refpin.run(L, "ref_")
 st = refpin.ref_settings(L)
 out["settings_names"] = np.array(sorted(st))
 out["settings_values"] = np.array([st[k] for k in sorted(st)])
+# the SCALE_* macros of src/FullSystem/HessianBlocks.h:33-40 (a header that cannot be compiled here: read as text)
+import re  # noqa: E402
+hb = open("/root/reference/src/FullSystem/HessianBlocks.h").read()
+sc = dict(re.findall(r"#define (SCALE_[A-Z_]+) ([0-9.]+)f", hb))
+out["scale_names"] = np.array(sorted(sc))
+out["scale_values"] = np.array([float(sc[k]) for k in sorted(sc)])
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "ref_pin.npz")
 np.savez_compressed(path, **out)
 print("wrote", path, {k: v.shape for k, v in out.items()})
