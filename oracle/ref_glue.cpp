@@ -146,6 +146,11 @@ int ref_setting(const char* name, double* out) {
     for (const Entry& e : table) if (!std::strcmp(e.name, name)) { *out = e.value; return 1; }
     return 0;
 }
+// the residual pattern the reference uses (settings.h:174-176: patternNum offsets of patternP = staticPattern[8]); out[2*i], out[2*i+1]
+int ref_pattern(int* out) {
+    for (int i = 0; i < patternNum; ++i) { out[2 * i] = patternP[i][0]; out[2 * i + 1] = patternP[i][1]; }
+    return patternNum;
+}
 int ref_setting_count() { return 46; }
 const char* ref_setting_name(int i) {
     static const char* names[] = {"pyrLevelsUsed", "setting_idepthFixPrior", "setting_idepthFixPriorMargFac", "setting_initialRotPrior", "setting_initialTransPrior", "setting_initialAffBPrior", "setting_initialAffAPrior", "setting_initialCalibHessian", "setting_solverMode", "setting_solverModeDelta", "setting_minIdepthH_act", "setting_minIdepthH_marg", "setting_maxPixSearch", "setting_desiredImmatureDensity", "setting_desiredPointDensity", "setting_minPointsRemaining", "setting_maxLogAffFacInWindow", "setting_minFrames", "setting_maxFrames", "setting_minFrameAge", "setting_maxOptIterations", "setting_minOptIterations", "setting_thOptIterations", "setting_outlierTH", "setting_outlierTHSumComponent", "setting_margWeightFac", "setting_GNItsOnPointActivation", "setting_minTraceQuality", "setting_minTraceTestRadius", "setting_reTrackThreshold", "setting_affineOptModeA", "setting_affineOptModeB", "setting_forceAceptStep", "setting_huberTH", "setting_frameEnergyTHConstWeight", "setting_frameEnergyTHN", "setting_frameEnergyTHFacMedian", "setting_overallEnergyTHWeight", "setting_coarseCutoffTH", "setting_trace_stepsize", "setting_trace_GNIterations", "setting_trace_GNThreshold", "setting_trace_extraSlackOnTH", "setting_trace_slackInterval", "setting_trace_minImprovementFactor", "multiThreading"};

@@ -14,7 +14,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_p
 
 def _compare(ref, orc):
     for name, want in ref.items():
-        if name.startswith("settings_") or name.startswith("scale_"):
+        if name.startswith("settings_") or name.startswith("scale_") or name == "pattern":
             continue
         got = [v for k, v in orc.items() if k == name or k.startswith(name + ":")]
         assert got, name
@@ -34,7 +34,7 @@ def test_oracle_matches_reference_library():
     ref = refpin.run(L, "ref_")
     _compare(ref, refpin.run(None, None))
     gold = dict(np.load(GOLD))                      # and the committed fixture IS what the reference code produces
-    assert set(gold) - {"settings_names", "settings_values", "scale_names", "scale_values"} == set(ref)
+    assert set(gold) - {"settings_names", "settings_values", "scale_names", "scale_values", "pattern"} == set(ref)
     for k in ref:
         assert np.array_equal(ref[k], gold[k]), k
     st = refpin.ref_settings(L)
@@ -99,3 +99,20 @@ def test_scale_macros_match_reference_header():
                 assert float(val) == ref[name], (p, name, val)
                 checked += 1
     assert checked >= 10, checked
+
+
+def test_residual_pattern_matches_reference():
+    """patternP = staticPattern[8] of the reference's settings.cpp (from the compiled object, via the fixture) against every copy of the 8
+    offsets in the oracle and in the kernels"""
+    import glob
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    want = np.load(GOLD)["pattern"]
+    assert want.shape == (8, 2)
+    copies = 0
+    for p in glob.glob(os.path.join(root, "sdv-loam_amd", "csrc", "*")) + glob.glob(os.path.join(root, "oracle", "orc_*")):
+        for m in re.finditer(r"(?:pat|patternP)\[8\]\[2\]\s*=\s*\{((?:\s*\{\s*-?\d+\s*,\s*-?\d+\s*\}\s*,?)+)\}", open(p).read()):
+            got = np.array(re.findall(r"-?\d+", m.group(1)), np.int32).reshape(-1, 2)
+            assert np.array_equal(got, want), p
+            copies += 1
+    assert copies >= 4, copies

@@ -17,6 +17,10 @@ out = refpin.run(L, "ref_")
 st = refpin.ref_settings(L)
 out["settings_names"] = np.array(sorted(st))
 out["settings_values"] = np.array([st[k] for k in sorted(st)])
+import ctypes as C  # noqa: E402
+pat = (C.c_int * 80)()
+npat = L.ref_pattern(pat)
+out["pattern"] = np.array(list(pat)[:2 * npat], np.int32).reshape(npat, 2)
 # the SCALE_* macros of src/FullSystem/HessianBlocks.h:33-40 (a header that cannot be compiled here: read as text)
 import re  # noqa: E402
 hb = open("/root/reference/src/FullSystem/HessianBlocks.h").read()
