@@ -1696,9 +1696,10 @@ static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* 
 }
 
 // FullSystem::optimize, the loop (FullSystemOptimize.cpp:344-458).  The window's state lives on the device: per loop body the host
-// only launches -- accumulate, reduce + solve + step + precalc table (k_ef_reduce_solve), resubstitute + point step, linearize,
-// statistics + setNewFrameEnergyTH -- then mirrors the step from x (pinned memory) while the GPU still works, waits ONCE for the four
-// sums, takes the accept / reject decision and launches applyRes or the re-classification.
+// only launches -- accumulate + reduce, stitch (+ the previous linearisation's threshold select), LDL^T tail (+ the re-classification
+// after a rejected step), resubstitute + step + precalc table, linearize -- mirrors the step from x (pinned memory) while the GPU
+// linearises, hands its parts of the accept / reject comparison to the last launch (k_ef_stats_apply: statistics, the test itself and the
+// conditional applyRes), waits ONCE for the sums + verdict and does its own bookkeeping of the accepted or restored state.
 int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int trace_stride, int trace_cap) {
     if (!e || !e->haveAdjoints || e->nP < 1) return SDVGN_E_STATE;
     EF_DEVICE(e);
