@@ -1530,6 +1530,7 @@ static void ef_fill_solve_io(sdvgn_ef* e, SolveIO& io, int iteration, double lam
     io.pc_cur = e->precalc_dev; io.pc_trial = e->precalc_alt;
     io.rx = e->rx_dev; io.sys = e->sys_dev; io.out = e->sol_host;
     io.done_flag = e->flags_host + 3; io.done_seq = ++e->seq_solve;
+    io.ready_word = (unsigned*)(e->accept_dev + 8);
     io.lambda = lambda; io.iteration = iteration; io.do_step = do_step ? 1 : 0; io.reuse = reuse ? 1 : 0; io.stepsize = stepsize;
     io.stamps = e->solve_stamps;
 }
@@ -1555,12 +1556,11 @@ static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_st
     }
     if (e->pend_sel_valid) ef_flush_pending(e);    // system re-used: no stitch launch to ride in
     const int has_rc = e->pend_rc_valid ? 1 : 0;
-    k_ef_solve_tail<<<1 + (has_rc ? kReclBlocks : 0), kSolveLanes, 0, e->stream>>>(io, e->pend_rc, has_rc);
-    e->pend_rc_valid = false;
-    HIPCHK(hipGetLastError());
     const int nblk = (e->nP + 63) / 64;
-    k_ef_resubstitute_step<<<nblk + (do_step ? 1 : 0), 512, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->rx_dev, e->pidepth_backup,
-                                                                            e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, nblk, io);
+    k_ef_tail_resub<<<1 + (has_rc ? kReclBlocks : 0) + (nblk + 1) / 2 + (do_step ? 1 : 0), kSolveLanes, 0, e->stream>>>(
+        io, e->pend_rc, has_rc, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt,
+        e->pdeltaF_alt, nblk);
+    e->pend_rc_valid = false;
     HIPCHK(hipGetLastError());
     e->sys_on_device = true; e->sys_fetched = false; e->sys_valid = true;
     return SDVGN_OK;
@@ -1624,7 +1624,7 @@ static double calc_M_energy(sdvgn_ef* e) {   // EnergyFunctional::calcMEnergyF
 // sums {energy, L-energy point part, sum step^2, sum |idepth_backup|}
 // defer_select (optimize loop, single rank): only the statistics are launched behind the linearise; setNewFrameEnergyTH is recorded in
 // e->pend_sel and rides as one more workgroup in the k_ef_stitch launch of the next loop body (ef_launch_solve) -- its result is needed by
-// the next linearise (accepted step) or by the re-classification in that body's k_ef_solve_tail (rejected step), not before -- instead of
+// the next linearise (accepted step) or by the re-classification in that body's k_ef_tail_resub (rejected step), not before -- instead of
 // sitting between the statistics and the host's decision on the stream (one workgroup of serial passes, ~7 us).
 static int linearize_launch_kernels(sdvgn_ef* e) {   // first half: the linearise itself (+ the point statistics when they are not trivially 0)
     if (!e->havePrecalc) return SDVGN_E_STATE;
@@ -1864,7 +1864,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
                 ra.phost = e->phost_dev; ra.precalc = e->precalc_dev; ra.th = e->th_dev + (size_t)trial * SDVGN_MAX_FRAMES;
                 if (defer) {
                     // nothing is launched here: the trial's select rides in the next body's k_ef_stitch, this re-classification in its
-                    // k_ef_solve_tail -- both through before that body's linearise (which reads the kept set's state_NewEnergy for
+                    // k_ef_tail_resub -- both through before that body's linearise (which reads the kept set's state_NewEnergy for
                     // residuals that leave the image) -- or ef_flush_pending launches them when the loop ends
                     e->pend_rc = ra; e->pend_rc_valid = true;
                 } else {

@@ -1231,17 +1231,32 @@ __global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__
 // (idepth = idepth_zero = backup + step_fac * step, FullSystemOptimize.cpp:236-249) -- the optimize loop always does both.
 struct ResubX { float xc[4]; float xAd[kMaxFrames * kMaxFrames * 6]; };
 
-// (body of one workgroup of 512 lanes; the kernel -- k_ef_resubstitute_step, backend_solve.inc -- adds one extra workgroup that performs the
-// calib / frame part of doStepFromBackup and writes the precalc table of the stepped state beside it)
+// A launch may wait for a word another workgroup OF THE SAME LAUNCH publishes (k_ef_tail_resub: the factorisation workgroup's solution):
+// one lane polls with relaxed device-scope loads, the acquire fence behind it drops the CU's (and this XCD's) stale copies of what the
+// publisher wrote before its release fence, the workgroup barrier hands the result to the other waves.  Gives up after ~2^20 polls.
+__device__ __forceinline__ void wait_ready_word(const unsigned* word, unsigned seq) {
+    if (threadIdx.x == 0) {
+        int polls = 0;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq && ++polls < (1 << 20)) __builtin_amdgcn_s_sleep(8);
+        __threadfence();
+    }
+    __syncthreads();
+}
+
+// (body of HALF a workgroup of 1024 lanes: group g = threadIdx.x >> 9 takes the 64-point block `blk`, wave t of the group target t; the
+// kernel -- k_ef_tail_resub, backend_solve.inc -- runs these workgroups beside the factorisation workgroup whose solution they wait for,
+// with their own loads already in flight, plus one workgroup that performs the calib / frame part of doStepFromBackup and writes the
+// precalc table of the stepped state)
+struct ResubSmem { float part[2][kMaxFrames][2][64]; float sx[4 + kMaxFrames * kMaxFrames * 6]; };
 __device__ __forceinline__ void resubstitute_body(const EFConst& C, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
-                                                  const int* __restrict__ phost, const ResubX* __restrict__ Xp, float* __restrict__ backup,
+                                                  const int* __restrict__ phost, const ResubX* Xp, float* __restrict__ backup,
                                                   double* __restrict__ stats_partial, float step_fac,
                                                   float* __restrict__ pid_w, float* __restrict__ pidz_w, float* __restrict__ pdeltaF_w,
-                                                  int n_point_blocks) {
-    __shared__ float part[kMaxFrames][2][64];
-    __shared__ float sx[4 + kMaxFrames * kMaxFrames * 6];
-    const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
-    const int p = blockIdx.x * 64 + lane;
+                                                  int n_point_blocks, int blk, ResubSmem& S, const unsigned* ready, unsigned seq) {
+    float (*part)[2][64] = S.part[threadIdx.x >> 9];
+    float* sx = S.sx;
+    const int lane = threadIdx.x & 63, t = (threadIdx.x >> 6) & 7;
+    const int p = blk * 64 + lane;
     const size_t slots = (size_t)C.nF * C.nP;
     const bool inP = p < C.nP;
     const bool slot_ok = inP && t < C.nF;
@@ -1263,9 +1278,10 @@ __device__ __forceinline__ void resubstitute_body(const EFConst& C, const EFArra
     }
     // one pass over the argument block into LDS (the per-lane host index below would otherwise turn every use into a
     // vector load from the kernel-argument segment)
-    if (threadIdx.x < 4 + kMaxFrames * kMaxFrames * 6) sx[threadIdx.x] = reinterpret_cast<const float*>(Xp)[threadIdx.x];
     __builtin_amdgcn_sched_barrier(0);
     const bool mine = inP && precalc[h * C.nF + h].np != 0;
+    if (ready) wait_ready_word(ready, seq);       // this thread's loads above are in flight while the solution is being computed
+    if (threadIdx.x < 4 + kMaxFrames * kMaxFrames * 6) sx[threadIdx.x] = reinterpret_cast<const float*>(Xp)[threadIdx.x];
     __syncthreads();
     const float* xc = sx;
     const float* xAd = sx + 4;
@@ -1309,7 +1325,7 @@ __device__ __forceinline__ void resubstitute_body(const EFConst& C, const EFArra
         sa = (double)fabsf(idb);
     }
     s2 = wave_sum_double(s2); sa = wave_sum_double(sa);
-    if (lane == 63) { stats_partial[blockIdx.x] = s2; stats_partial[n_point_blocks + blockIdx.x] = sa; }
+    if (lane == 63 && blk < n_point_blocks) { stats_partial[blk] = s2; stats_partial[n_point_blocks + blk] = sa; }
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -42,7 +42,7 @@ def main():
                        cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
         dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
         con = sqlite3.connect(dbs[0])
-        names = ["k_ef_linearize", "k_ef_acc_fused", "k_ef_acc_reduce", "k_ef_stitch", "k_ef_solve_tail", "k_ef_resubstitute_step", "k_ef_stats_select", "k_ef_stats_apply", "k_ef_apply", "k_ef_linearize"]
+        names = ["k_ef_linearize", "k_ef_acc_fused", "k_ef_acc_reduce", "k_ef_stitch", "k_ef_tail_resub", "k_ef_stats_select", "k_ef_stats_apply", "k_ef_apply", "k_ef_linearize"]
         print("# %s" % ("8 windows, a handle each" if mode == "many" else "one handle, reloaded before every call"))
         for nm in names:
             du = np.array([r[0] for r in con.execute("select duration from kernels where name like ? order by start", ("%" + nm + "%",))], np.float64) / 1e3

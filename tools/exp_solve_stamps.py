@@ -2,7 +2,7 @@
 """Phase timeline of the device-side small solve (backend_solve.inc) from wall_clock64() stamps of lane 0 of the solve workgroup.
 
 usage (GPU box):  SDVGN_DEBUG_FLAGS=64 python tools/exp_solve_stamps.py [nF] [pts_per_kf]
-Stamps: 0 workgroup 0 of k_ef_stitch starts | 1 k_ef_solve_tail starts | 2 H, b assembled from the shares | 3 blocked LDL^T done | 4 back substitution +
+Stamps: 0 workgroup 0 of k_ef_stitch starts | 1 k_ef_tail_resub starts | 2 H, b assembled from the shares | 3 blocked LDL^T done | 4 back substitution +
 null-space projection done | 5 resubstitute inputs, step and precalc table written.  wall_clock64() ticks are 10 ns (constant 100 MHz);
 8 / 9 / 10: workgroup 0 after its sums / products / shares.
 Stamp 0 comes from another workgroup (possibly another XCD: the clocks agree to well under a microsecond)."""
@@ -21,7 +21,7 @@ nF = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 ppk = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 W = syn.make_window(w=1241, h=376, nF=nF, pts_per_kf=ppk, seed=0, calib=syn.KITTI00)
 G = backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
-names = ["k_ef_stitch start -> k_ef_solve_tail start", "H, b assembly from the shares", "blocked LDL^T",
+names = ["k_ef_stitch start -> k_ef_tail_resub start", "H, b assembly from the shares", "blocked LDL^T",
          "back substitution + orthogonalize", "xAd, step, precalc table"]
 rows, sub, blk = [], [], []
 for rep in range(12):
