@@ -622,7 +622,10 @@ def main():
             runners = [ShardedEnergyFunctional(Wh, rank, world, local) for _ in range(min(n_calls, 16))]
             runners[0].optimize(2, want_trace=False, fixed_its=True)      # first collectives happen here: fail early, fall back below
             runners[0].reload(Wh)
-            parallelism = "host-keyframe shards %s + 2 all-reduces per iteration over RCCL (154 kB packed accumulators; 128 kB statistics + threshold candidates)" % (shard_hosts(Wh.nF, world),)
+            import torch.distributed as dist
+            via = "RCCL, issued by the library" if getattr(runners[0], "direct_rccl", False) else ("torch.distributed/%s callback" % dist.get_backend())
+            parallelism = "host-keyframe shards %s + 2 all-reduces per iteration (154 kB packed accumulators; 128 kB statistics + threshold candidates) via %s" % (
+                shard_hosts(Wh.nF, world), via)
         except Exception as ex:  # noqa: BLE001
             runners = None
             parallelism, scaling = "replicas x%d (sharded path unavailable: %r)" % (world, ex), "weak"
