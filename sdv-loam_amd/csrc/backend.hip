@@ -790,9 +790,9 @@ static int ef_launch_linearize(sdvgn_ef* e) {
         e->lin_ev_used += 2;
         hipEventRecord(ev0, e->stream);
     }
-    if ((e->C.debug_flags & 32) && e->dbg_stamps) k_ef_linearize<true><<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
-    else if (lin_groups(e) == 1) k_ef_linearize<false, 1><<<dim3(chunks, pairs), 128, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
-    else k_ef_linearize<false><<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->energy_partial);
+    if ((e->C.debug_flags & 32) && e->dbg_stamps) k_ef_linearize<true><<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->energy_partial);
+    else if (lin_groups(e) == 1) k_ef_linearize<false, 1><<<dim3(chunks, pairs), 128, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->energy_partial);
+    else k_ef_linearize<false><<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->energy_partial);
     if (ev1) hipEventRecord(ev1, e->stream);
     return chunks * pairs;
 }
@@ -1354,7 +1354,7 @@ static int ef_accumulate(sdvgn_ef* e, bool with_reduce) {
     const int nF = e->nF, n_top = g.chunks * g.pairs, n_pt = (e->nP + 63) / 64;
     if (g.sc_ppb == 64) {
         const int n_sc = nF * g.sc_chunks;
-        k_ef_acc_fused<<<n_sc + n_top, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, e->sc_partial, g.sc_chunks, n_sc);
+        k_ef_acc_fused<<<n_sc + n_top, 256, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, e->sc_partial, g.sc_chunks, n_sc);
     } else {
         k_ef_acc_stage1<<<n_top + n_pt, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, n_top);
         k_ef_sc_gram<<<dim3(g.sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, g.sc_ppb);

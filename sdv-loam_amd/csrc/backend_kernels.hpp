@@ -302,7 +302,9 @@ __device__ __forceinline__ void lin_phase_c(const EFConst& C, const EFArrays& A,
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned lin_u32x2 __attribute__((ext_vector_type(2)));
 template <bool STAMPS, int GROUPS = 2>
-__global__ void __launch_bounds__(128 * GROUPS) k_ef_linearize(EFConst Cin, EFArrays A, const PrecalcDev* __restrict__ precalc,
+// (`precalc` leads the argument block: with the first 16 dwords preloaded into SGPRs -- csrc/Makefile -- the table load that heads the
+// workgroup's dependency chain goes out with the first instruction instead of behind a scalar load of its own pointer)
+__global__ void __launch_bounds__(128 * GROUPS) k_ef_linearize(const PrecalcDev* __restrict__ precalc, EFConst Cin, EFArrays A,
                                                                double* __restrict__ energy_partial) {
     const EFConst C = ef_const(Cin, A);
     __shared__ LinSmem S;
@@ -1056,7 +1058,7 @@ __global__ void __launch_bounds__(256) k_ef_sc_gram(EFConst C, EFArrays A, const
 // Schur Gram (its JpJdF loads already in flight before the per-point phase; Hcd / bdSum / weight through LDS) -- and the remaining
 // workgroups the top Grams.  The
 // two kinds are independent of each other, so the per-point launch + its kernel boundary leave the critical path of the loop body.
-__global__ void __launch_bounds__(256) k_ef_acc_fused(EFConst Cin, EFArrays A, const PrecalcDev* __restrict__ precalc,
+__global__ void __launch_bounds__(256) k_ef_acc_fused(const PrecalcDev* __restrict__ precalc, EFConst Cin, EFArrays A,
                                                       const int* __restrict__ phost, float* __restrict__ top_partial,
                                                       int* __restrict__ nres_partial, int top_chunks, float* __restrict__ sc_partial,
                                                       int sc_chunks, int n_sc) {
