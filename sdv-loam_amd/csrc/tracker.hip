@@ -80,6 +80,7 @@ struct sdvgn_tracker {
     TrackState* track_host = nullptr;    // pinned
     TeamMem* team_dev = nullptr;         // k_track_team: partial rows + counters per hypothesis (allocated on first use, zeroed)
     int team_cap = 0;
+    int cu_count = 0;                    // multiProcessorCount of the device (queried once)
     int team_mode = 0;                   // sdvgn_tracker_set_team: 0 automatic, -1 always k_track (one workgroup), T >= 1 fixed team size
     int last_team = 0;                   // team size of the last track_batch call (0: k_track)
     int track_seq = 0;                   // sequence number of track_batch calls (TrackState::done)
@@ -572,7 +573,8 @@ int sdvgn_tracker_track_batch(sdvgn_tracker* t, int B, double* pose7_io, double*
     }
     // no copy-engine transfers: the constants are a kernel argument, the per-hypothesis state blocks stay in pinned host memory.
     // Team size: enough workgroups of 256 lanes for one pass over the largest level (at most kTeamMax), as long as every workgroup of
-    // the launch is resident at once (two 256-lane workgroups per CU at its register count: 512 on 256 CUs); beyond that: one workgroup per hypothesis.
+    // the launch is resident at once (two 256-lane workgroups per CU at its register count: 512 on the 256 CUs of an MI355X); beyond that: one
+    // workgroup per hypothesis.
     const int seq = ++t->track_seq;
     int T = 0;
     {
@@ -581,7 +583,15 @@ int sdvgn_tracker_track_batch(sdvgn_tracker* t, int B, double* pose7_io, double*
         const int Bpad = (B + 7) & ~7;
         int want = t->team_mode > 0 ? t->team_mode : (nmax + kTeamThreads - 1) / kTeamThreads;
         if (want > kTeamMax) want = kTeamMax;
-        if (want > 512 / Bpad) want = 512 / Bpad;
+        // resident capacity: two 256-lane workgroups of this kernel per CU (its register count); the whole grid must fit, and so must one
+        // dispatch window of 8 interleaved teams (a partitioned device with few CUs gets small teams or the one-workgroup kernel)
+        if (t->cu_count <= 0) {
+            hipDeviceProp_t prop;
+            t->cu_count = (hipGetDeviceProperties(&prop, t->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 1;
+        }
+        const int capacity = 2 * t->cu_count;
+        if (want > capacity / Bpad) want = capacity / Bpad;
+        if (Bpad > 512) want = 0;      // the exchange rows are allocated for at most 512 hypotheses
         // a fixed request of 1 runs the team kernel with a single member (tests); automatic mode needs at least two
         if (t->team_mode >= 0 && (want >= 2 || (t->team_mode > 0 && want >= 1))) T = want;
     }
