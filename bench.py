@@ -150,10 +150,14 @@ def cpu_baseline_backend(W, budget_s=12.0):
 
 
 def pmc_child():
-    """Body of the profiled child process: the window is loaded and k_ef_linearize is launched 20 times."""
+    """Body of the profiled child process: the window is loaded and k_ef_linearize is launched 20 times (SDVGN_PMC_LOOP=1: ten bodies of
+    the optimize loop instead, so that every kernel of the loop appears in the counters)."""
     import torch  # noqa: F401
     W, G = backend_setup(0)
-    G.launch_linearize_only(20)
+    if os.environ.get("SDVGN_PMC_LOOP"):
+        G.optimize(10, fixed_its=True, want_trace=False)
+    else:
+        G.launch_linearize_only(20)
     torch.cuda.synchronize()
 
 

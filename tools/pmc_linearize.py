@@ -31,6 +31,9 @@ GROUPS = [
 def main():
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     kernel = sys.argv[1] if len(sys.argv) > 1 else "k_ef_linearize"
+    global GROUPS
+    if os.environ.get("SDVGN_PMC_SAFE"):     # the TA / TCP / TD groups never returned on this pool (profiles/r02_notes.txt): SQ + TCC only
+        GROUPS = [g for g in GROUPS if not g[0].startswith(("TA_", "TCP_", "TD_"))] + [["FETCH_SIZE"], ["WRITE_SIZE"]]
     print("# rocprofv3 --pmc <group> --kernel-trace -- python bench.py --pmc-child   (MI355X; %s, mean per launch)" % kernel)
     for grp in GROUPS:
         d = tempfile.mkdtemp(prefix="sdvgn_pmc_", dir="/tmp")
