@@ -109,7 +109,7 @@ struct sdvgn_ef {
     CalibDev* calib_host = nullptr;        // pinned staging
     int st_cur = 0;                        // which of the two sets holds the current state
     bool state_dirty = true;               // the host mirror changed outside the loop: upload before the next device solve
-    ResubX* rx_dev = nullptr;              // xc, xAd of the last solve (k_ef_resubstitute reads them)
+    ResubX* rx_dev = nullptr;              // xc, xAd of the last solve (the resubstitute workgroups of k_ef_tail_resub read them)
     SolveSys* sys_dev = nullptr;           // HA, bA, Hsc, bsc, HFinal, bFinal of the last solve
     SolveOut* sol_host = nullptr;          // pinned: x, step statistics, resInA, status
     SolvePieces* pieces_dev = nullptr;     // [SDVGN_MAX_FRAMES]: per-host shares of HA / bA / Hsc / bsc
@@ -155,7 +155,7 @@ struct sdvgn_ef {
     double* acc_dev = nullptr;    // packed: top [nF*nF][256] | sc [nF][2560] | resInA
     double* acc_host = nullptr;   // pinned; the reduce kernels write it DIRECTLY (zero-copy) when no all-reduce is installed
     double* stats_host = nullptr; // pinned, 4 doubles: same for k_ef_sum_stats
-    float fuse_step_fac = -1.0f;   // set by sdvgn_ef_optimize: k_ef_resubstitute also applies the point step
+    float fuse_step_fac = -1.0f;   // set by sdvgn_ef_optimize: the resubstitute workgroups also apply the point step
     bool reuse_system = false;     // set by sdvgn_ef_optimize (flags bit2) for the solve that follows a rejected step: HA/bA/Hsc/bsc and
                                    // the per-point Schur terms on the device are those of the identical state one body earlier
     // second copies of the planes a trial step overwrites (point idepths, precalc table): the optimize loop writes the trial values

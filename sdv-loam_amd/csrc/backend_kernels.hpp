@@ -8,12 +8,15 @@
 //                    b7  head of AccumulatedSCHessianSSE::addPoint src/OptimizationBackend/AccumulatedSCHessian.cpp:10-37
 //   top_gram_body    b2  acc[h,t].update/updateTopRight/BotRight   AccumulatedTopHessian.cpp:68-82 (AccumulatorApprox, b3)
 //   sc_gram_body     b7  accD / accE / accEB / accHcc / accbc      AccumulatedSCHessian.cpp:39-61
-//   k_ef_acc_stage1      launch 1 of an accumulate: top_gram_body workgroups | point_body workgroups (independent, side by side)
-//   k_ef_acc_stage2      launch 2: fp64 reduce of the top partials (+ "top done" flag) | sc_gram_body workgroups
-//   k_ef_sc_gram         sc_gram_body alone (sharded path, where one combined reduce follows)
+//   k_ef_acc_fused       the whole accumulate of a solveSystemF in one launch: per 64-point tile point_body then its sc_gram part | top_gram_body
+//   k_ef_acc_stage1      top_gram_body | point_body workgroups side by side (sharded windows and > 64 * kMaxChunks points per host)
+//   k_ef_sc_gram         sc_gram_body alone (same cases, where one combined reduce follows)
 //   k_ef_acc_reduce      fixed-order fp64 sum of the per-workgroup partial Gram tiles into the packed accumulator buffer
-//   k_ef_resubstitute b6 EnergyFunctional::resubstituteFPt         src/OptimizationBackend/EnergyFunctional.cpp:250-282
-//   k_ef_step            doStepFromBackup / loadSateBackup on the per-point idepths  FullSystemOptimize.cpp:165-262
+//   resubstitute_body b6 EnergyFunctional::resubstituteFPt         src/OptimizationBackend/EnergyFunctional.cpp:250-282
+//                        + doStepFromBackup on the per-point idepths  FullSystemOptimize.cpp:165-262   (workgroups of k_ef_tail_resub, backend_solve.inc)
+//   select_th_body       FullSystem::setNewFrameEnergyTH           FullSystemOptimize.cpp:63-97 (k_ef_select_th; a workgroup of k_ef_stitch in the loop)
+//   reclassify_slot      the IN / OUTLIER decision of the re-linearisation after a rejected step (k_ef_reclassify; workgroups of k_ef_tail_resub)
+//   apply_slot           body of k_ef_apply and of the apply workgroups of k_ef_stats_apply (backend.hip)
 //
 // Data layout in HBM (one window): points are sorted by host frame; the residual of point p in target frame t
 // lives in slot s = t*nP + p of every per-residual plane ("dense residual table": for a fixed (host,target) pair the
