@@ -155,7 +155,6 @@ struct sdvgn_ef {
     double* acc_dev = nullptr;    // packed: top [nF*nF][256] | sc [nF][2560] | resInA
     double* acc_host = nullptr;   // pinned; the reduce kernels write it DIRECTLY (zero-copy) when no all-reduce is installed
     double* stats_host = nullptr; // pinned, 4 doubles: same for k_ef_sum_stats
-    float fuse_step_fac = -1.0f;   // set by sdvgn_ef_optimize: the resubstitute workgroups also apply the point step
     bool reuse_system = false;     // set by sdvgn_ef_optimize (flags bit2) for the solve that follows a rejected step: HA/bA/Hsc/bsc and
                                    // the per-point Schur terms on the device are those of the identical state one body earlier
     // second copies of the planes a trial step overwrites (point idepths, precalc table): the optimize loop writes the trial values
