@@ -242,6 +242,7 @@ static void ef_fill_arrays(sdvgn_ef* e) {
     A.pHdi = e->pHdi; A.pbdSum = e->pbdSum; A.pHcd = e->pHcd; A.pstep = e->pstep;
     A.images = e->images;
     A.dbg_stamps = e->dbg_stamps;
+    A.reset_oob = 0;
 }
 
 static void ef_update_const(sdvgn_ef* e) {  // CalibHessian float views, HessianBlocks.h:302-330
@@ -1714,7 +1715,6 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     bool prev_rejected_clean = false;
     if (!fixed_its && nF < 3) mnumOptIts = 100;
     if (!fixed_its && nF < 4) mnumOptIts = 75;
-    const size_t slots = (size_t)nF * e->nP;
     int rc;
     static const bool opt_timing = getenv("SDVGN_OPT_TIMING") != nullptr;
     const auto tt0 = std::chrono::steady_clock::now();
@@ -1724,7 +1724,9 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     const double tt_sync = us_since(tt0);
     struct CalibGuard { sdvgn_ef* e; ~CalibGuard() { e->A.calib = nullptr; } } calib_guard{e};   // outside the loop the kernels take EFConst by value
     e->A.calib = e->calib_dev + e->st_cur;
-    k_ef_reset_oob<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(slots, e->A);
+    // resetOOB of every active residual (FullSystemOptimize.cpp:349-353) is folded into the call's first linearise + apply (EFArrays::reset_oob)
+    struct ResetGuard { sdvgn_ef* e; ~ResetGuard() { e->A.reset_oob = 0; } } reset_guard{e};
+    e->A.reset_oob = 1;
     double lastEnergy, lastEnergyL, lastEnergyM;
     e->th_log_n = 0;
     ef_select_new_set(e, e->new_cur, e->new_cur);
@@ -1733,6 +1735,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     const bool defer = !ef_sharded(e) && !relinearize_on_reject;   // the literal variant keeps the reference's order of launches
     // linearizeAll + applyRes: the apply does not depend on the sums -- it is queued before the host waits for them
     if ((rc = linearize_launch(e, defer)) || (rc = sdvgn_ef_apply_res(e)) || (rc = linearize_wait(e, &lastEnergy, &lastEnergyL, nullptr, nullptr))) return rc;
+    e->A.reset_oob = 0;
     const double tt_lin = us_since(tt0);
     lastEnergyM = calc_M_energy(e);
     if (opt_timing) fprintf(stderr, "[sdvgn] optimize pre-loop: uploads %.1f | reset_oob launch %.1f | linearize + stats + apply + wait %.1f | M energy %.1f us\n",

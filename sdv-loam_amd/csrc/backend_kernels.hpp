@@ -101,6 +101,10 @@ struct EFArrays {
     const struct CalibDev* calib;
     // diagnostics (SDVGN_DEBUG_FLAGS bit5): wall_clock64() stamps of k_ef_linearize's stages, [workgroup][wave][8]; NULL otherwise
     unsigned long long* dbg_stamps;
+    // 1: PointFrameResidual::resetOOB (Residuals.h:69-76) is folded into this linearise + applyRes pair -- every residual they process counts
+    // as state IN with state_energy = state_NewEnergy = 0 on entry (the first linearizeAll of FullSystem::optimize, which the reference
+    // precedes with a resetOOB loop); what the pair writes is what reset + linearise + apply would have written
+    int reset_oob;
 };
 
 struct CalibDev { float fxl, fyl, cxl, cyl, fxli, fyli; float cDeltaF[4]; float pad[2]; };
@@ -178,12 +182,12 @@ __device__ __forceinline__ void lin_phase_a(const EFConst& C, const EFArrays& A,
                                             LinLane& L, LinIn& I, LinRec* __restrict__ rec /*[4] of this lane*/, unsigned long long* stamps) {
     LIN_STAMP(0);
     I.fl = A.rflags[s];
-    I.st = A.rstate[s];
+    I.st = A.reset_oob ? (int)RS_IN : (int)A.rstate[s];
     I.pu = A.pu[p]; I.pv = A.pv[p]; I.idz = A.pidz[p]; I.ids = A.pid[p];
     I.c4 = A.pcolor[2 * p + ROLE];
     I.w4 = A.pweights[2 * p + ROLE];
     I.m = A.rmatcher[s];
-    L.e_prev = (ROLE == 0) ? A.renergy[s] : 0.0f;
+    L.e_prev = (ROLE == 0 && !A.reset_oob) ? A.renergy[s] : 0.0f;
     __builtin_amdgcn_sched_barrier(0);
     if (STAMPS) { const float dep = I.pu + (float)I.fl + I.m.x + I.c4.x + I.w4.x + I.ids; if (dep == 1.2345e30f) stamps[7] = 1; }   // the stamp below waits for the loads
     LIN_STAMP(1);
@@ -412,7 +416,7 @@ __global__ void __launch_bounds__(128 * GROUPS) k_ef_linearize(const PrecalcDev*
         A.renergy_wo[s] = -1.0f;
         if (L.oob) {
             A.rstate_new[s] = RS_OOB;
-            A.renergy_new[s] = A.renergy_new_prev[s];   // state_NewEnergy is left untouched by the reference's early return (:118-119)
+            A.renergy_new[s] = A.reset_oob ? 0.0f : A.renergy_new_prev[s];   // state_NewEnergy is left untouched by the reference's early return (:118-119)
             my_e = (double)L.e_prev;   // `return state_energy`
         } else {
             // the reference's sequential loop over the 8 pattern pixels, `break` at the first failing one (:160-176)
@@ -612,7 +616,7 @@ __device__ __forceinline__ void apply_slot(int nF, int nP, const EFArrays& A, co
     int go = cond ? *cond : 1;
     const int hh = phost[s % nP];
     uint8_t fl = A.rflags[s];
-    const int st = A.rstate[s];
+    const int st = A.reset_oob ? (int)RS_IN : (int)A.rstate[s];
     const int sn = A.rstate_new[s];
     const float en = A.renergy_new[s];
     __builtin_amdgcn_sched_barrier(0);
