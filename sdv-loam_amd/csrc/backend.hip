@@ -707,9 +707,21 @@ __device__ __forceinline__ void sum_stats_body(const double* __restrict__ pe, in
                                                double (*s)[256], const DecideArgs& dec = DecideArgs{0, 0, 0, nullptr, 0, nullptr, 0}) {
     if (threadIdx.x < 256) {
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        for (int i = threadIdx.x; i < nE; i += 256) a0 += pe[i];
+        // all loads of this lane in one batch (clamped indices, the out-of-range ones add 0), the sums in index order afterwards: one
+        // memory round trip instead of one per stride -- this workgroup is what every apply workgroup of k_ef_stats_apply waits for
+        constexpr int kB = 8;
+        double ve[kB], vs2[2], vs3[2];
+#pragma unroll
+        for (int k = 0; k < kB; ++k) { const int i = threadIdx.x + 256 * k; ve[k] = pe[i < nE ? i : 0]; }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { const int i = threadIdx.x + 256 * k; vs2[k] = ps[i < nS ? i : 0]; vs3[k] = ps[nS + (i < nS ? i : 0)]; }
+#pragma unroll
+        for (int k = 0; k < kB; ++k) if ((int)threadIdx.x + 256 * k < nE) a0 += ve[k];
+        for (int i = threadIdx.x + 256 * kB; i < nE; i += 256) a0 += pe[i];
         for (int i = threadIdx.x; i < nL; i += 256) a1 += pl[i];
-        for (int i = threadIdx.x; i < nS; i += 256) { a2 += ps[i]; a3 += ps[nS + i]; }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) if ((int)threadIdx.x + 256 * k < nS) { a2 += vs2[k]; a3 += vs3[k]; }
+        for (int i = threadIdx.x + 512; i < nS; i += 256) { a2 += ps[i]; a3 += ps[nS + i]; }
         // fixed order: 256 strided lane sums, a 64-lane tree per wave (DPP, no barrier), the four wave sums in index order
         a0 = wave_sum_double(a0); a1 = wave_sum_double(a1); a2 = wave_sum_double(a2); a3 = wave_sum_double(a3);
         if ((threadIdx.x & 63) == 63) { const int w = threadIdx.x >> 6; s[0][w] = a0; s[1][w] = a1; s[2][w] = a2; s[3][w] = a3; }
