@@ -1745,11 +1745,23 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     ef_refresh_frame_deltas(e);
     const double tt_pre = us_since(tt0);
     const bool defer = !ef_sharded(e) && !relinearize_on_reject;   // the literal variant keeps the reference's order of launches
-    // linearizeAll + applyRes: the apply does not depend on the sums -- it is queued before the host waits for them
-    if ((rc = linearize_launch(e, defer)) || (rc = sdvgn_ef_apply_res(e)) || (rc = linearize_wait(e, &lastEnergy, &lastEnergyL, nullptr, nullptr))) return rc;
+    // linearizeAll + applyRes: the apply does not depend on the sums, and neither does the first loop body's accumulate / solve / linearise --
+    // the host's parts of the energies (priors, M energy: functions of the host mirror, which the first body's step moves) are taken now,
+    // the device's sums are fetched when the first accept test needs them (take_initial_energies), by then long there
+    if ((rc = linearize_launch(e, defer)) || (rc = sdvgn_ef_apply_res(e))) return rc;
     e->A.reset_oob = 0;
-    const double tt_lin = us_since(tt0);
+    const double En_initial = host_prior_energy(e);
     lastEnergyM = calc_M_energy(e);
+    bool initial_pending = true;
+    auto take_initial_energies = [&]() -> int {
+        if (!initial_pending) return SDVGN_OK;
+        initial_pending = false;
+        HIPCHK(wait_flag(e->flags_host + 2, e->seq_stats, e->stream));
+        lastEnergy = e->stats_host[0];
+        lastEnergyL = En_initial + (double)(float)e->stats_host[1];       // linearize_wait's expression, with the mirror as it was at the launch
+        return SDVGN_OK;
+    };
+    const double tt_lin = us_since(tt0);
     if (opt_timing) fprintf(stderr, "[sdvgn] optimize pre-loop: uploads %.1f | reset_oob launch %.1f | linearize + stats + apply + wait %.1f | M energy %.1f us\n",
                             tt_sync, tt_pre - tt_sync, tt_lin - tt_pre, us_since(tt0) - tt_lin);
     double lambda = 1e-1;
@@ -1782,6 +1794,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         // device-side accept test: the statistics launch waits for the host's parts of the comparison (after the mirror below), the
         // linearise does not
         const bool dev_decide = defer && !zero_differs;
+        if (!dev_decide && (rc = take_initial_energies())) return rc;          // (that path launches its statistics right behind the linearise)
         if ((rc = dev_decide ? linearize_launch_kernels(e) : linearize_launch(e, defer))) return rc;
         g_pt.stop(PT_ACCUM);
         // x is in pinned memory as soon as the solve kernel is through: mirror doStepFromBackup on the host (FrameHessian::setState,
@@ -1804,6 +1817,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         }
         float sumT = e->sol_host->sumT, sumR = e->sol_host->sumR;
         const double newEnergyM = calc_M_energy(e);
+        if ((rc = take_initial_energies())) return rc;                         // first body: the call's initial sums, before this body's overwrite them
         if (dev_decide) {
             // the sums, the verdict and -- queued right behind, so that no launch latency separates it from the verdict -- applyRes of
             // the trial linearisation, which returns at once when the step is rejected
@@ -1896,6 +1910,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         e->iter_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_iter).count());
         if (!fixed_its && canbreak && iteration >= 1) break;
     }
+    if ((rc = take_initial_energies())) return rc;                             // (a call of zero bodies)
     ef_flush_pending(e);
     HIPCHK(hipGetLastError());
     if (host_restore_pending) {   // the loop ended on a rejected step: loadSateBackup for the host mirror
