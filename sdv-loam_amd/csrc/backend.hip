@@ -1361,13 +1361,16 @@ static AccGeom ef_acc_geom(const sdvgn_ef* e) {
     g.ntop = g.pairs * kTopE; g.nsc = nF * kScE;
     return g;
 }
-static int ef_accumulate(sdvgn_ef* e, bool with_reduce) {
+static int ef_accumulate(sdvgn_ef* e, bool with_reduce, const AccAlt* alt = nullptr) {
     const AccGeom g = ef_acc_geom(e);
     const int nF = e->nF, n_top = g.chunks * g.pairs, n_pt = (e->nP + 63) / 64;
     if (g.sc_ppb == 64) {
         const int n_sc = nF * g.sc_chunks;
-        k_ef_acc_fused<<<n_sc + n_top, 256, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, e->sc_partial, g.sc_chunks, n_sc);
+        const AccAlt none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        k_ef_acc_fused<<<n_sc + n_top, 256, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, e->sc_partial, g.sc_chunks, n_sc,
+                                                            alt ? *alt : none);
     } else {
+        if (alt) return SDVGN_E_STATE;   // (the speculative launch exists for the fused kernel only; callers check ef_acc_geom first)
         k_ef_acc_stage1<<<n_top + n_pt, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, n_top);
         k_ef_sc_gram<<<dim3(g.sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, g.sc_ppb);
     }
@@ -1772,6 +1775,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     e->n_accepted = 0;
     std::vector<int> th_idx;   // th_log slot of every trial linearisation (trace only)
     bool host_restore_pending = false;
+    bool pre_accumulated = false;   // the accumulate of the coming body was queued behind the previous body's accept test (AccAlt)
     for (int iteration = 0; iteration < mnumOptIts; iteration++) {
         const auto t_iter = std::chrono::steady_clock::now();
         g_pt.start();
@@ -1783,7 +1787,8 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         // solveSystemF + doStepFromBackup, all on the device: the trial state (frame states, calib, precalc table, idepths) goes to the
         // second copies; resubstitute also backs up the idepths and applies the point step
         const bool reuse = reuse_after_reject && prev_rejected_clean && e->sys_valid;
-        if ((rc = ef_launch_solve(e, iteration, lambda, /*do_step=*/true, stepsize, reuse, /*accumulated=*/false))) return rc;
+        if ((rc = ef_launch_solve(e, iteration, lambda, /*do_step=*/true, stepsize, reuse, /*accumulated=*/pre_accumulated))) return rc;
+        pre_accumulated = false;
         ef_swap_point_copies(e);                                                          // the stepped idepths are the ones every later launch reads
         e->deltaF_nonzero = false;
         std::swap(e->precalc_dev, e->precalc_alt);
@@ -1825,6 +1830,17 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             dec.En = host_prior_energy(e); dec.EM = newEnergyM; dec.rhs = lastEnergy + lastEnergyL + lastEnergyM; dec.accept_dev = e->accept_dev; dec.on = 1;
             dec.verdict = (unsigned*)(e->accept_dev + 4); dec.seq = (unsigned)(++e->seq_verdict) & 0x7fffffffu;
             if ((rc = linearize_launch_stats(e, defer, &dec))) return rc;
+            // the next body's accumulate, queued before the verdict is known (AccAlt): its arguments are the accepted case -- the state
+            // this body's launches run on --, the kept copies go along for the rejected one
+            pre_accumulated = false;
+            // (not when this body may be the call's last one -- the step is small enough for `canbreak`, whose second half the host only
+            // learns with the sums: the per-point planes must hold what the LAST executed solveSystemF left, like the reference's EFPoints)
+            const bool may_break = !fixed_its && iteration >= 1 && sqrtf(sumR / nF) < 0.00005 * thOpt;
+            if (!reuse_after_reject && !may_break && iteration + 1 < mnumOptIts && ef_acc_geom(e).sc_ppb == 64) {
+                const AccAlt alt{e->accept_dev, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->calib_dev + e->st_cur, e->precalc_alt};
+                if ((rc = ef_accumulate(e, /*with_reduce=*/true, &alt))) return rc;
+                pre_accumulated = true;
+            }
         }
         g_pt.stop(PT_STEP);
         double newEnergy, newEnergyL, sID, sNID;

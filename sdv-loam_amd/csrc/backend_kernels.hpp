@@ -1065,10 +1065,17 @@ __global__ void __launch_bounds__(256) k_ef_sc_gram(EFConst C, EFArrays A, const
 // Schur Gram (its JpJdF loads already in flight before the per-point phase; Hcd / bdSum / weight through LDS) -- and the remaining
 // workgroups the top Grams.  The
 // two kinds are independent of each other, so the per-point launch + its kernel boundary leave the critical path of the loop body.
+// alt (optimize loop): this accumulate was queued BEHIND the statistics + accept-test launch of a trial step, before the host knew the
+// verdict, so that no launch latency separates the two.  The arguments describe the window after an accepted step; when the verdict word
+// says "rejected", the state-dependent inputs -- the point copies, the calib floats, the precalc table -- are the kept ones instead.
+struct AccAlt { const int* verdict; const float* pid; const float* pidz; const float* pdeltaF; const CalibDev* calib; const PrecalcDev* precalc; };
 __global__ void __launch_bounds__(256) k_ef_acc_fused(const PrecalcDev* __restrict__ precalc, EFConst Cin, EFArrays A,
                                                       const int* __restrict__ phost, float* __restrict__ top_partial,
                                                       int* __restrict__ nres_partial, int top_chunks, float* __restrict__ sc_partial,
-                                                      int sc_chunks, int n_sc) {
+                                                      int sc_chunks, int n_sc, AccAlt alt) {
+    if (alt.verdict && *alt.verdict == 0) {
+        A.pid = alt.pid; A.pidz = alt.pidz; A.pdeltaF = alt.pdeltaF; A.calib = alt.calib; precalc = alt.precalc;
+    }
     const EFConst C = ef_const(Cin, A);
     __shared__ union U { TopGramSmem t; PointSmem p; ScGramSmem s; __device__ U() {} } S;
     const int b = blockIdx.x;
