@@ -329,6 +329,10 @@ int sdvgn_ef_set_frame_states(sdvgn_ef* ef, const double* state10);
  * then per iteration backupState / solveSystem / doStepFromBackup / linearizeAll / accept (applyRes, lambda*0.25) or
  * reject (loadSateBackup, re-linearise, lambda*100), break on a tiny step.  One loop body = one "Gauss-Newton
  * iteration" of BASELINE.json's metric.  trace rows: {iteration, lambda, accepted, E, E_L, E_M, canbreak, x[4+6nF]}.
+ * Everything runs on the device, the accept test included (the host supplies its parts of the comparison, mirrors the frame states and
+ * keeps the books); a body is six launches, the next body's accumulate is queued before the verdict of the current one is known, and
+ * setNewFrameEnergyTH / the re-classification after a rejected step ride in launches of the following body -- results are those of the
+ * literal order of operations (flags bit1), bit for bit.
  * Returns the number of iterations run (>= 0) or an error (< 0). */
 int sdvgn_ef_optimize(sdvgn_ef* ef, int mnumOptIts, int flags /* bit0: run exactly mnumOptIts bodies (bench); bit1: re-linearise after a
                       rejected step literally like FullSystemOptimize.cpp:446-449 instead of switching back to the kept state_New* set
