@@ -138,6 +138,32 @@ struct Accumulator11 {
     void finish() { shiftUp(true); A = S1m[0] + S1m[1] + S1m[2] + S1m[3]; }                  // :86-90
 };
 
+// ---- the small dot products Eigen itself evaluates (`a.dot(b)`, `row * col`) ------------------------------------------------
+// calcLEnergyPt, fixLinearizationF, addPoint<1> and resubstituteFPt contain 4- and 6-term float dot products written as Eigen expressions.
+// The order in which Eigen adds the terms depends on its version and on whether it vectorises the expression, and Eigen is not available
+// here to settle it (oracle/README.md).  The restatement adds left to right (order 0, what the kernels do as well); orders 1 and 2 exist
+// for the sensitivity test (tests/test_oracle_backend.py): 1 = the halving unroller of Eigen's scalar reductions
+// (redux_novec_unroller: f(0, n/2) + f(n/2, n - n/2), recursively), 2 = SSE packets (4 lanes multiplied at once, horizontal add
+// (p0 + p2) + (p1 + p3), a scalar tail of 2 added as (p4 + p5)).
+static int g_redux_order = 0;
+static float dot_tree(const float* a, const float* b, int n) {
+    if (n == 1) return a[0] * b[0];
+    const int h = n / 2;
+    return dot_tree(a, b, h) + dot_tree(a + h, b + h, n - h);
+}
+static inline float dot_small(const float* a, const float* b, int n) {   // n = 4 or 6
+    if (g_redux_order == 1) return dot_tree(a, b, n);
+    if (g_redux_order == 2) {
+        const float p0 = a[0] * b[0], p1 = a[1] * b[1], p2 = a[2] * b[2], p3 = a[3] * b[3];
+        float s = (p0 + p2) + (p1 + p3);
+        if (n == 6) s = s + (a[4] * b[4] + a[5] * b[5]);
+        return s;
+    }
+    float s = 0;
+    for (int i = 0; i < n; ++i) s += a[i] * b[i];
+    return s;
+}
+
 // ---- AccumulatorXX<i,j> / AccumulatorX<i> (MatrixAccumulators.h:13-66,148-208), i,j <= 8 ---------------
 struct AccXX {
     int I, J;
@@ -526,10 +552,8 @@ static void add_point_top(EF* E, std::vector<AccumulatorApprox>& acc, Point& p, 
         if (mode == 0) { resApprox[0] = rJ.resF[0]; resApprox[1] = rJ.resF[1]; }
         else if (mode == 2) { resApprox[0] = r.res_toZeroF[0]; resApprox[1] = r.res_toZeroF[1]; }   // :61-62
         else {
-            float dx = 0, dy = 0;
-            for (int i = 0; i < 6; ++i) { dx += rJ.Jpdxi[0][i] * dp[i]; dy += rJ.Jpdxi[1][i] * dp[i]; }
-            float cx = 0, cy = 0;
-            for (int i = 0; i < 4; ++i) { cx += rJ.Jpdc[0][i] * dc[i]; cy += rJ.Jpdc[1][i] * dc[i]; }
+            const float dx = dot_small(rJ.Jpdxi[0], dp, 6), dy = dot_small(rJ.Jpdxi[1], dp, 6);
+            const float cx = dot_small(rJ.Jpdc[0], dc, 4), cy = dot_small(rJ.Jpdc[1], dc, 4);
             const float Jp_delta_x = dx + cx + rJ.Jpdd[0] * dd;
             const float Jp_delta_y = dy + cy + rJ.Jpdd[1] * dd;
             resApprox[0] = r.res_toZeroF[0] + Jp_delta_x;
@@ -912,16 +936,12 @@ static void solve_system(EF* E, int iteration, double lambda) {
         for (int ri = p.r0; ri < p.r1; ++ri) if (E->res[ri].isActive) ngoodres++;
         if (ngoodres == 0) { p.step = 0; continue; }
         float b = p.bdSumF;
-        float dot = 0;
-        for (int i = 0; i < 4; ++i) dot += xF[i] * p.Hcd_accAF[i];
-        b -= dot;
+        b -= dot_small(xF.data(), p.Hcd_accAF, 4);
         for (int ri = p.r0; ri < p.r1; ++ri) {
             const Residual& r = E->res[ri];
             if (!r.isActive) continue;
             const float* xa = &xAd[(size_t)(r.host * nF + r.target) * 6];
-            float s = 0;
-            for (int i = 0; i < 6; ++i) s += xa[i] * r.JpJdF[i];
-            b -= s;
+            b -= dot_small(xa, r.JpJdF, 6);
         }
         p.step = p.isFromSensor ? 0 : -b * p.HdiF;
     }
@@ -949,9 +969,8 @@ static double calc_L_energy(EF* E) {
             const Residual& r = E->res[ri];
             if (!r.isLinearized || !r.isActive) continue;
             const float* dp = &E->adHTdeltaF[(size_t)(r.host + E->nF * r.target) * 6];
-            float dx = 0, dy = 0, cx = 0, cy = 0;
-            for (int i = 0; i < 6; ++i) { dx += r.Jef.Jpdxi[0][i] * dp[i]; dy += r.Jef.Jpdxi[1][i] * dp[i]; }
-            for (int i = 0; i < 4; ++i) { cx += r.Jef.Jpdc[0][i] * E->cDeltaF[i]; cy += r.Jef.Jpdc[1][i] * E->cDeltaF[i]; }
+            const float dx = dot_small(r.Jef.Jpdxi[0], dp, 6), dy = dot_small(r.Jef.Jpdxi[1], dp, 6);
+            const float cx = dot_small(r.Jef.Jpdc[0], E->cDeltaF, 4), cy = dot_small(r.Jef.Jpdc[1], E->cDeltaF, 4);
             const float jx = dx + cx + r.Jef.Jpdd[0] * p.deltaF, jy = dy + cy + r.Jef.Jpdd[1] * p.deltaF;
             acc.updateSingleNoShift((r.res_toZeroF[0] * jx + r.res_toZeroF[1] * jy) + (jx * r.res_toZeroF[0] + jy * r.res_toZeroF[1]) + (jx * jx + jy * jy));
         }
@@ -1148,9 +1167,8 @@ static void fix_linearization(EF* E, const uint8_t* mask) {
             Residual& r = E->res[ri];
             if (!r.isActive) continue;
             const float* dp = &E->adHTdeltaF[(size_t)(r.host + E->nF * r.target) * 6];
-            float dx = 0, dy = 0, cx = 0, cy = 0;
-            for (int i = 0; i < 6; ++i) { dx += r.Jef.Jpdxi[0][i] * dp[i]; dy += r.Jef.Jpdxi[1][i] * dp[i]; }
-            for (int i = 0; i < 4; ++i) { cx += r.Jef.Jpdc[0][i] * E->cDeltaF[i]; cy += r.Jef.Jpdc[1][i] * E->cDeltaF[i]; }
+            const float dx = dot_small(r.Jef.Jpdxi[0], dp, 6), dy = dot_small(r.Jef.Jpdxi[1], dp, 6);
+            const float cx = dot_small(r.Jef.Jpdc[0], E->cDeltaF, 4), cy = dot_small(r.Jef.Jpdc[1], E->cDeltaF, 4);
             const float Jp_delta_x = dx + cx + r.Jef.Jpdd[0] * p.deltaF;
             const float Jp_delta_y = dy + cy + r.Jef.Jpdd[1] * p.deltaF;
             r.res_toZeroF[0] = r.Jef.resF[0] - Jp_delta_x;
@@ -1366,6 +1384,8 @@ void orc_kat_acc_approx(int n, const float* in, float* H169, double* num) {
     *num = (double)acc->num;
     delete acc;
 }
+// 0: left to right (default); 1 / 2: the two orders Eigen may use for the small dot products (sensitivity test only; process-wide)
+void orc_set_redux_order(int order) { g_redux_order = order; }
 void orc_kat_acc11(int n, const float* vals, float* A) {
     Accumulator11 acc;
     acc.initialize();
