@@ -31,14 +31,37 @@ def build(force=False):
     return so
 
 
-def lib():
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    so = os.path.join(_HERE, "liborc.so")
-    if not os.path.exists(so):
-        build()
-    L = C.CDLL(so)
+
+class _Missing:
+    """an entry point the wrapped library does not have"""
+
+    def __init__(self, name):
+        object.__setattr__(self, "_name", name)
+
+    def __setattr__(self, k, v):
+        pass
+
+    def __call__(self, *a):
+        raise NotImplementedError(self._name)
+
+
+class _Prefixed:
+    """`P.orc_xxx` -> the function `<prefix>xxx` of the wrapped library: the reference-built library (oracle/_ref/libref.so,
+    oracle/ref_glue_*.cpp) exports the oracle's entry points under the prefix ref_ with the same signatures."""
+
+    def __init__(self, L, prefix):
+        object.__setattr__(self, "_L", L)
+        object.__setattr__(self, "_p", prefix)
+
+    def __getattr__(self, name):
+        assert name.startswith("orc_")
+        try:
+            return getattr(self._L, self._p + name[4:])
+        except AttributeError:
+            return _Missing(self._p + name[4:])
+
+
+def _bind_tracker(L):
     L.orc_tracker_create.restype = C.c_void_p
     L.orc_tracker_create.argtypes = [C.c_int, C.c_int, C.c_int]
     L.orc_tracker_destroy.argtypes = [C.c_void_p]
@@ -76,6 +99,18 @@ def lib():
     L.orc_ldlt_solve.argtypes = [C.c_int, f64p, f64p, f64p]
     L.orc_inv3f.argtypes = [f32p, f32p]
     L.orc_interp33.argtypes = [f32p, C.c_float, C.c_float, C.c_int, f32p]
+
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = os.path.join(_HERE, "liborc.so")
+    if not os.path.exists(so):
+        build()
+    L = C.CDLL(so)
+    _bind_tracker(L)
     _bind_backend(L)
     _LIB = L
     return L
@@ -153,8 +188,12 @@ IDENTITY_POSE = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
 class OracleTracker:
     """Mirror of the reference's CoarseTracker call surface (CoarseTracker.h:17-107) on the CPU oracle."""
 
+    @classmethod
+    def _library(cls):
+        return lib()
+
     def __init__(self, w, h, levels):
-        self.L = lib()
+        self.L = self._library()
         self.w, self.h, self.levels = w, h, levels
         self.h_ = self.L.orc_tracker_create(w, h, levels)
 
@@ -266,3 +305,39 @@ class OracleTracker:
         self.L.orc_struct_res_Hb(self.h_, len(u), u, v, idepth, host_idx, hp.reshape(-1), obs.reshape(-1),
                                  np.ascontiguousarray(worldToCur7, np.float64), H, b, C.byref(e), C.byref(n))
         return H.reshape(6, 6), b, e.value, n.value
+
+
+_REF_TRACKER_LIB = None
+
+
+class RefTracker(OracleTracker):
+    """The same call surface on the REFERENCE'S OWN CoarseTracker / FrameHessian::makeImages / Sophus, compiled unmodified into
+    oracle/_ref/libref.so (oracle/Makefile target `ref`) and driven by oracle/ref_glue_tracker.cpp.  trackNewestCoarse returns an
+    empty trace (the reference exposes none)."""
+
+    @classmethod
+    def _library(cls):
+        global _REF_TRACKER_LIB
+        if _REF_TRACKER_LIB is None:
+            from . import refpin
+            R = refpin.ref_lib()
+            if R is None:
+                raise RuntimeError("oracle/_ref/libref.so has not been built (needs /root/reference; `make -C oracle ref`)")
+            P = _Prefixed(R, "ref_")
+            _bind_tracker(P)
+            R.ref_tracker_make_coarse_depth_pts.argtypes = [C.c_void_p, C.c_int, f32p, f32p, f32p, f32p, C.c_int]
+            _REF_TRACKER_LIB = P
+        return _REF_TRACKER_LIB
+
+    def makeCoarseDepthPts(self, u, v, idepth, HdiF, first_frame=False):
+        u, v, idepth, HdiF = (np.ascontiguousarray(x, np.float32) for x in (u, v, idepth, HdiF))
+        self.L._L.ref_tracker_make_coarse_depth_pts(self.h_, len(u), u, v, idepth, HdiF, 1 if first_frame else 0)
+
+
+def ref_se3(name, *args):
+    """se3_exp / log / mul / inverse / matrix / adj evaluated by the vendored Sophus inside libref.so"""
+    P = RefTracker._library()
+    shapes = dict(exp=7, log=6, mul=7, inverse=7, matrix=9, adj=36)
+    out = np.zeros(shapes[name])
+    getattr(P, "orc_se3_" + name)(*[np.ascontiguousarray(a, np.float64) for a in args], out)
+    return out

@@ -3,17 +3,19 @@ import ctypes as C
 
 import numpy as np
 
-from . import f32p, f64p, i32p, lib
+from . import _Prefixed, f32p, f64p, i32p, lib
 
 u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 vp = C.c_void_p
-_bound = False
+_bound = set()
 
 
-def _L():
-    global _bound
-    L = lib()
-    if not _bound:
+def _L(raw=None, prefix="orc_"):
+    L = _Prefixed(lib() if raw is None else raw, prefix)
+    if True:
+        if prefix in _bound:
+            return L
+        _bound.add(prefix)
         L.orc_ef_create.restype = vp
         L.orc_ef_create.argtypes = [C.c_int, C.c_int]
         L.orc_ef_destroy.argtypes = [vp]
@@ -81,16 +83,16 @@ def _L():
         L.orc_ef_get_frame_energy_th.restype = None
         L.orc_ef_get_evalPT.argtypes = [vp, C.c_int, f64p, f64p]
         L.orc_ef_get_evalPT.restype = None
-        _bound = True
     return L
 
 
 class OracleEF:
     """Flattened EnergyFunctional window on the CPU oracle; method names follow the reference
     (EnergyFunctional.h:51-72, FullSystemOptimize.cpp)."""
+    _raw, _prefix = None, "orc_"
 
     def __init__(self, w, h):
-        self.L = _L()
+        self.L = _L(self._raw_lib(), self._prefix)
         self.w, self.h = w, h
         self.h_ = self.L.orc_ef_create(w, h)
 
@@ -99,6 +101,10 @@ class OracleEF:
             self.L.orc_ef_destroy(self.h_)
         except Exception:
             pass
+
+    @classmethod
+    def _raw_lib(cls):
+        return None
 
     def load(self, W):
         c = np.ascontiguousarray
@@ -311,3 +317,62 @@ class OracleEF:
         bc = np.zeros(4, np.float32)
         self.L.orc_ef_get_sc_acc(self.h_, accE.reshape(-1), accEB.reshape(-1), accD.reshape(-1), Hcc.reshape(-1), bc)
         return accE, accEB, accD, Hcc, bc
+
+
+class RefEF(OracleEF):
+    """The same window interface on the REFERENCE'S OWN code: oracle/_ref/libref.so = the reference's FullSystem / EnergyFunctional /
+    AccumulatedTop- and SCHessian / Residuals / HessianBlocks translation units compiled unmodified (oracle/Makefile target `ref`), driven by
+    oracle/ref_glue_ef.cpp.  `optimize_full` is the reference's FullSystem::optimize itself (loop + tail)."""
+    _prefix = "ref_"
+
+    @classmethod
+    def _raw_lib(cls):
+        from . import refpin
+        L = refpin.ref_lib()
+        if L is None:
+            raise RuntimeError("oracle/_ref/libref.so has not been built (needs /root/reference; `make -C oracle ref`)")
+        return L
+
+    def __init__(self, w, h):
+        super().__init__(w, h)
+        R = self.L._L
+        R.ref_ef_optimize_full.argtypes = [vp, C.c_int]
+        R.ref_ef_optimize_full.restype = C.c_double
+        R.ref_ef_last_log.argtypes = [vp, C.c_char_p, C.c_int]
+        R.ref_ef_last_log.restype = C.c_int
+        R.ref_ef_get_removed.argtypes = [vp, u8p]
+        R.ref_ef_get_point_stats.argtypes = [vp, f32p, i32p]
+        R.ref_ef_load_report.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        R.ref_ef_get_center_projected.argtypes = [vp, f32p]
+
+    def optimize_full(self, its=6):
+        """FullSystem::optimize(its) of the reference.  Returns (rmse, [(accepted, iteration, energy)...] parsed from its console output,
+        removed[nR])."""
+        import re
+        R = self.L._L
+        rmse = R.ref_ef_optimize_full(self.h_, int(its))
+        n = R.ref_ef_last_log(self.h_, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        R.ref_ef_last_log(self.h_, buf, n + 1)
+        log = buf.value.decode(errors="replace")
+        steps = [(m.group(1) == "ACCEPT", int(m.group(2)), float(m.group(3)))
+                 for m in re.finditer(r"(ACCEPT|REJECT) (\d+) \(L [^)]*\): \tA\(([-0-9.einfa]+)\)", log)]
+        removed = np.zeros(self.nR, np.uint8)
+        R.ref_ef_get_removed(self.h_, removed)
+        return rmse, steps, removed, log
+
+    def point_stats(self):
+        rb = np.zeros(self.nP, np.float32)
+        ng = np.zeros(self.nP, np.int32)
+        self.L._L.ref_ef_get_point_stats(self.h_, rb, ng)
+        return rb, ng
+
+    def load_report(self):
+        cm, gd = C.c_int(0), C.c_double(0)
+        self.L._L.ref_ef_load_report(self.h_, C.byref(cm), C.byref(gd))
+        return cm.value, gd.value
+
+    def center_projected(self):
+        out = np.zeros((self.nR, 3), np.float32)
+        self.L._L.ref_ef_get_center_projected(self.h_, out.reshape(-1))
+        return out

@@ -38,12 +38,19 @@ def ref_path():
     return os.path.join(_HERE, "_ref", "libref.so")
 
 
+_REF = None
+
+
 def ref_lib():
     """the reference-built library, or None when it has not been built (no /root/reference on this machine and no prebuilt file)"""
+    global _REF
+    if _REF is not None:
+        return _REF
     p = ref_path()
     if not os.path.exists(p):
         return None
     L = C.CDLL(p)
+    _REF = L
     for name, sig in _SIG.items():
         fn = getattr(L, "ref_" + name)
         fn.argtypes = sig
