@@ -153,6 +153,12 @@ static float dot_tree(const float* a, const float* b, int n) {
 }
 static inline float dot_small(const float* a, const float* b, int n) {   // n = 4 or 6
     if (g_redux_order == 1) return dot_tree(a, b, n);
+    if (g_redux_order == 3) {   // what Eigen 3.2.8 built for SSE2 does per operand type (oracle/ref_shim/Eigen/Core, header): a 4-float vector is one
+        // aligned packet (product, then the SSE2 horizontal add (p0 + p2) + (p1 + p3)); a 6-float vector has no packet access (24 bytes) and
+        // goes through the halving unroller.  With this order the oracle matches the reference-built library bit for bit (tests/test_ref_pin_backend.py)
+        if (n == 4) { const float p0 = a[0] * b[0], p1 = a[1] * b[1], p2 = a[2] * b[2], p3 = a[3] * b[3]; return (p0 + p2) + (p1 + p3); }
+        return dot_tree(a, b, n);
+    }
     if (g_redux_order == 2) {
         const float p0 = a[0] * b[0], p1 = a[1] * b[1], p2 = a[2] * b[2], p3 = a[3] * b[3];
         float s = (p0 + p2) + (p1 + p3);
@@ -1384,7 +1390,8 @@ void orc_kat_acc_approx(int n, const float* in, float* H169, double* num) {
     *num = (double)acc->num;
     delete acc;
 }
-// 0: left to right (default); 1 / 2: the two orders Eigen may use for the small dot products (sensitivity test only; process-wide)
+// 0: left to right (default); 1 / 2: the two orders Eigen may use for the small dot products; 3: the per-type mix Eigen 3.2.8 / SSE2 uses
+// (process-wide; the reference-pin tests run with 3)
 void orc_set_redux_order(int order) { g_redux_order = order; }
 void orc_kat_acc11(int n, const float* vals, float* A) {
     Accumulator11 acc;

@@ -139,6 +139,12 @@ inline void quat_rot(const double* q, const double* v, double* o) {
     o[1] = v[1] + q[3] * uv[1] + c[1];
     o[2] = v[2] + q[3] * uv[2] + c[2];
 }
+// SO3GroupBase::normalize (so3.hpp:196-202): coeffs /= coeffs.norm().  Eigen sums the four squares of a Matrix<double,4,1> as two
+// 2-double packets added lane-wise, then across: (x^2 + z^2) + (y^2 + w^2) (Redux.h packet form, SSE2).
+inline void quat_normalize(double* q) {
+    const double len = std::sqrt((q[0] * q[0] + q[2] * q[2]) + (q[1] * q[1] + q[3] * q[3]));
+    for (int i = 0; i < 4; ++i) q[i] /= len;
+}
 // SE3 operator* = fastMultiply + normalize (se3.hpp:158-166, 268-271; so3.hpp:196-202)
 inline SE3 se3_mul(const SE3& a, const SE3& b) {
     SE3 r;
@@ -146,13 +152,13 @@ inline SE3 se3_mul(const SE3& a, const SE3& b) {
     quat_rot(a.q, b.t, rt);
     for (int i = 0; i < 3; ++i) r.t[i] = a.t[i] + rt[i];
     quat_mul(a.q, b.q, r.q);
-    const double len = std::sqrt(r.q[0] * r.q[0] + r.q[1] * r.q[1] + r.q[2] * r.q[2] + r.q[3] * r.q[3]);
-    for (int i = 0; i < 4; ++i) r.q[i] /= len;
+    quat_normalize(r.q);
     return r;
 }
 inline SE3 se3_inverse(const SE3& a) {  // se3.hpp:169-173
     SE3 r;
     r.q[0] = -a.q[0]; r.q[1] = -a.q[1]; r.q[2] = -a.q[2]; r.q[3] = a.q[3];
+    quat_normalize(r.q);   // so3.hpp:170-172: inverse() = SO3Group(unit_quaternion().conjugate()), the normalising constructor
     double mt[3] = {-a.t[0], -a.t[1], -a.t[2]};
     quat_rot(r.q, mt, r.t);
     return r;
@@ -162,7 +168,7 @@ inline SE3 se3_exp(const double* a) {
     const double* ups = a;
     const double* om = a + 3;
     SE3 r;
-    const double theta_sq = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
+    const double theta_sq = om[0] * om[0] + (om[1] * om[1] + om[2] * om[2]);   // omega.squaredNorm(): Eigen's 3-term unrolled reduction = x0 + (x1 + x2)
     const double theta = std::sqrt(theta_sq);
     const double half_theta = 0.5 * theta;
     double imag, real;
@@ -176,6 +182,7 @@ inline SE3 se3_exp(const double* a) {
         real = std::cos(half_theta);
     }
     r.q[3] = real; r.q[0] = imag * om[0]; r.q[1] = imag * om[1]; r.q[2] = imag * om[2];
+    quat_normalize(r.q);   // `explicit SO3Group(const Quaternion&)` normalises (so3.hpp:596-598)
     // Omega = hat(omega), V
     const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
     double O2[9];
@@ -189,8 +196,9 @@ inline SE3 se3_exp(const double* a) {
     if (theta < kSophusEps) {
         quat_to_R(r.q, V);
     } else {
-        const double c1 = (1.0 - std::cos(theta)) / theta_sq;
-        const double c2 = (theta - std::sin(theta)) / (theta_sq * theta);
+        const double tsq = theta * theta;                      // se3.hpp:418 recomputes theta_sq = theta*theta (not omega.squaredNorm())
+        const double c1 = (1.0 - std::cos(theta)) / tsq;
+        const double c2 = (theta - std::sin(theta)) / (tsq * theta);
         for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c1 * O[i] + c2 * O2[i];
     }
     for (int i = 0; i < 3; ++i) r.t[i] = V[i * 3 + 0] * ups[0] + V[i * 3 + 1] * ups[1] + V[i * 3 + 2] * ups[2];
@@ -198,7 +206,7 @@ inline SE3 se3_exp(const double* a) {
 }
 // SO3::logAndTheta so3.hpp:491-531 ; SE3::log se3.hpp:560-585
 inline void se3_log(const SE3& T, double* out) {
-    const double sq = T.q[0] * T.q[0] + T.q[1] * T.q[1] + T.q[2] * T.q[2];
+    const double sq = T.q[0] * T.q[0] + (T.q[1] * T.q[1] + T.q[2] * T.q[2]);   // vec().squaredNorm(), same reduction shape
     const double n = std::sqrt(sq);
     const double w = T.q[3];
     double two_atan;

@@ -271,7 +271,14 @@ def make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=KITTI00, sen
         px = xs[:, None] + PATTERN8[None, :, 0]
         py = ys[:, None] + PATTERN8[None, :, 1]
         col += list(I[py, px, 0].astype(np.float32))
-        wts += list(np.sqrt(2500.0 / (2500.0 + g2[py, px])).astype(np.float32))
+        # ImmaturePoint's constructor (ImmaturePoint.cpp:14-27), float arithmetic: the pattern pixels go through
+        # getInterpolatedElement33BiLin (globalFuncs.h:142-166), whose "gradient" at an integer position is the FORWARD difference
+        # (I[x+1] - I[x], I[y+1] - I[y]) -- not the stored central differences; weights = sqrtf(c / (c + gx*gx + gy*gy)), c = 50*50
+        I0 = I[..., 0]
+        gx = (I0[py, px + 1] - I0[py, px]).astype(np.float32)
+        gy = (I0[py + 1, px] - I0[py, px]).astype(np.float32)
+        g2f = (gx * gx + gy * gy).astype(np.float32)
+        wts += list(np.sqrt(np.float32(2500.0) / (np.float32(2500.0) + g2f)).astype(np.float32))
         prior += [hk == 0] * len(xs)
         sensor += list(rng.random(len(xs)) < sensor_frac)
         for tk in range(nF):
@@ -431,8 +438,9 @@ def make_trace_problem(W, target=None, pose_err=(0.0, 0.0), seed=0):
     for i in range(P.n):
         I = W.pyr0[P.host_idx[i]]
         g = np.zeros((2, 2), np.float32)
-        for dx, dy in PATTERN8:
-            gv = I[int(P.v[i]) + dy, int(P.u[i]) + dx, 1:3]
+        for dx, dy in PATTERN8:      # gradH += ptc.tail<2>() * ptc.tail<2>().transpose() with the forward differences of 33BiLin (ImmaturePoint.cpp:22-25)
+            y0, x0 = int(P.v[i]) + dy, int(P.u[i]) + dx
+            gv = np.array([I[y0, x0 + 1, 0] - I[y0, x0, 0], I[y0 + 1, x0, 0] - I[y0, x0, 0]], np.float32)
             g = (g + np.outer(gv, gv).astype(np.float32)).astype(np.float32)
         gradH[i] = g.reshape(-1)
     P.gradH = gradH

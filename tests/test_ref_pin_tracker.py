@@ -1,0 +1,184 @@
+"""The CPU oracle against the REFERENCE'S OWN coarse-tracker code.
+
+oracle/_ref/libref.so holds the reference's CoarseTracker.cpp, HessianBlocks.cpp and the vendored Sophus compiled UNMODIFIED from
+/root/reference (oracle/Makefile target `ref`); oracle/ref_glue_tracker.cpp drives them with the oracle's call signatures.
+
+  SURVEY 8 row   reference function (file:line)                                   agreement asserted here
+  a1             FrameHessian::makeImages (HessianBlocks.cpp:107-167)             bit-identical pyramids (rows the reference defines)
+  a2             CoarseTracker::makeK (CoarseTracker.cpp:77-106)                  bit-identical fx.. and Ki per level
+  a3             makeCoarseDepthL0 / makeCoarseDepthForFirstFrame (:108-425)      identical template points (count, order, values)
+  a4             calcRes (:486-634)                                              bit-identical 6 outputs and 8 warped planes
+  a5, a6         calcGSSSE (:427-484) + Accumulator9                              bit-identical H (8x8) and b
+  a7             trackNewestCoarse (:662-838)                                    same verdict, aff / lastResiduals / flow identical, pose <= 1e-15
+  f1             structPoseEstimation / calcHandb / calculateRes (:840-1007)      bit-identical H, b, energy, count and final pose
+  Sophus         SE3 exp / log / * / inverse / matrix / Adj (se3.hpp, so3.hpp)    bit-identical
+
+Without the library the oracle is checked against tests/golden/ref_pin_tracker.npz (the reference's outputs, tools/gen_ref_pin_golden.py).
+"""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_pin_tracker.npz")
+
+PROBLEMS = [
+    dict(w=320, h=240, levels=3, n_points=500, seed=3, gt_xi=[0.03, -0.02, 0.05, 0.004, -0.006, 0.002], gt_aff=(0.03, 1.5),
+         calib=dict(fx=280.0, fy=280.0, cx=159.5, cy=119.5)),
+    dict(w=621, h=188, levels=4, n_points=700, seed=11, gt_xi=[-0.02, 0.01, 0.08, -0.003, 0.004, -0.001], gt_aff=(-0.02, -3.0),
+         calib=dict(fx=359.428, fy=359.428, cx=303.3464, cy=92.35785)),          # odd width: levels by w >> l like SURVEY 8's cfg2
+]
+
+
+def _have_ref():
+    from oracle import refpin
+    L = refpin.ref_lib()
+    return L is not None and hasattr(L, "ref_tracker_create")
+
+
+needs_ref = pytest.mark.skipif(not _have_ref(), reason="oracle/_ref/libref.so not built (no /root/reference here)")
+
+
+def _setup(orc, cfg, cls):
+    from sdv_loam_amd import synthetic as syn
+    P = syn.make_tracker_problem(**cfg)
+    T = cls(P.w, P.h, P.levels)
+    T.makeK(**P.calib)
+    for l in range(P.levels):
+        T.set_ref(l, **P.ref[l])
+    T.set_ref_frame(1.0, 0.01, 0.5)
+    T.set_new_image(P.image, 1.0)
+    return P, T
+
+
+@needs_ref
+@pytest.mark.parametrize("cfg", PROBLEMS)
+def test_tracker_functions_bit_identical(orc, cfg):
+    from sdv_loam_amd import synthetic as syn
+    P, O = _setup(orc, cfg, orc.OracleTracker)
+    _, R = _setup(orc, cfg, orc.RefTracker)
+    start = orc.se3_mul(orc.se3_exp(syn.perturbation(3, 0.02, 0.003)), P.gt_pose)
+    for l in range(P.levels):
+        assert np.array_equal(O.get_K(l)[0], R.get_K(l)[0]) and np.array_equal(O.get_K(l)[1], R.get_K(l)[1])
+        assert np.array_equal(O.get_pyr(l), R.get_pyr(l), equal_nan=True)
+        for cutoff, a, b in ((20.0, 0.02, 1.0), (3.0, -0.01, 0.0)):            # the small cutoff saturates many points
+            assert np.array_equal(O.calcRes(l, start, a, b, cutoff), R.calcRes(l, start, a, b, cutoff))
+            wo, wr = O.warped(), R.warped()
+            assert wo.shape == wr.shape and wo.shape[1] > 0 and np.array_equal(wo, wr)
+            Ho, bo = O.calcGS(l, a, b)
+            Hr, br = R.calcGS(l, a, b)
+            assert np.array_equal(Ho, Hr) and np.array_equal(bo, br)
+
+
+@needs_ref
+@pytest.mark.parametrize("cfg", PROBLEMS)
+@pytest.mark.parametrize("modes", [(0.0, 0.0), (-1.0, -1.0), (1e12, -1.0), (-1.0, 1e8)])
+def test_track_newest_coarse(orc, cfg, modes):
+    """whole LM driver incl. the affine-mode branches (:726-748), min-residual abort and the final sanity checks"""
+    from sdv_loam_amd import synthetic as syn
+    P, O = _setup(orc, cfg, orc.OracleTracker)
+    _, R = _setup(orc, cfg, orc.RefTracker)
+    for T in (O, R):
+        T.set_settings(6.0, 20.0, modes[0], modes[1])
+    for seed, min_res in ((3, None), (4, [1e-3] * 5), (5, [np.nan, np.nan, 100.0, 0.5, 100.0])):
+        start = orc.se3_mul(orc.se3_exp(syn.perturbation(seed, 0.03, 0.004)), P.gt_pose)
+        oko, po, ao, lro, flo, tro = O.trackNewestCoarse(start, (0.0, 0.0), P.levels - 1, min_res)
+        okr, pr, ar, lrr, flr, _ = R.trackNewestCoarse(start, (0.0, 0.0), P.levels - 1, min_res)
+        assert oko == okr
+        assert np.array_equal(lro, lrr, equal_nan=True) and np.array_equal(flo, flr)
+        if oko:                                                       # on `return false` the reference leaves its in/out arguments untouched
+            assert np.abs(po - pr).max() <= 1e-15 and np.array_equal(ao, ar)
+
+
+@needs_ref
+def test_sophus(orc):
+    """the oracle's SE3 (orc_math.hpp) against the vendored Sophus: bit-identical but for a last-place difference in under 2 % of the calls"""
+    rng = np.random.default_rng(0)
+    exact = total = 0
+    for i in range(300):
+        xi = np.concatenate([rng.normal(0, 1.0, 3), rng.normal(0, 0.6, 3)])
+        if i % 10 == 0:
+            xi[3:] = 0                                                # theta < epsilon branch
+        a = orc.se3_exp(xi)
+        b = orc.se3_exp(np.concatenate([rng.normal(0, 2.0, 3), rng.normal(0, 1.5, 3)]))
+        pairs = [(a, orc.ref_se3("exp", xi)), (orc.se3_log(a), orc.ref_se3("log", a)), (orc.se3_mul(a, b), orc.ref_se3("mul", a, b)),
+                 (orc.se3_inverse(a), orc.ref_se3("inverse", a)), (orc.se3_matrix(a).reshape(-1), orc.ref_se3("matrix", a)),
+                 (orc.se3_adj(a).reshape(-1), orc.ref_se3("adj", a))]
+        for x, y in pairs:
+            total += 1
+            exact += bool(np.array_equal(x, y))
+            assert np.abs(x - y).max() <= 4e-16 * max(1.0, np.abs(y).max())
+    assert exact >= 0.98 * total
+
+
+@needs_ref
+def test_struct_pose(orc):
+    from sdv_loam_amd import synthetic as syn
+    S = syn.make_struct_problem(n=300, n_hosts=5, w=320, h=240, seed=2, calib=dict(fx=280.0, fy=280.0, cx=159.5, cy=119.5))
+    O, R = orc.OracleTracker(S.w, S.h, 3), orc.RefTracker(S.w, S.h, 3)
+    for T in (O, R):
+        T.makeK(**S.calib)
+    args = (S.u, S.v, S.idepth, S.host_idx, S.host_poses7, S.obs)
+    w2c = orc.se3_inverse(S.init_curToWorld7)
+    Ho, bo, eo, no = O.structResHb(w2c, *args)
+    Hr, br, er, nr = R.structResHb(w2c, *args)
+    assert np.array_equal(Ho, Hr) and np.array_equal(bo, br) and eo == er and no == nr and 0 < no < S.n
+    po, tro, _ = O.structPoseEstimation(S.init_curToWorld7, *args)
+    pr, _, _ = R.structPoseEstimation(S.init_curToWorld7, *args)
+    assert len(tro) >= 2 and np.array_equal(po, pr)
+
+
+@needs_ref
+@pytest.mark.parametrize("first", [False, True])
+def test_make_coarse_depth(orc, first):
+    """makeCoarseDepthL0 / makeCoarseDepthForFirstFrame on real PointHessian objects against the oracle's splat-tuple form"""
+    from sdv_loam_amd import synthetic as syn
+    P = syn.make_tracker_problem(w=320, h=240, levels=3, n_points=10, seed=3, calib=dict(fx=280.0, fy=280.0, cx=159.5, cy=119.5))
+    O, R = orc.OracleTracker(P.w, P.h, P.levels), orc.RefTracker(P.w, P.h, P.levels)
+    rng = np.random.default_rng(5)
+    n = 800
+    u = rng.integers(3, P.w - 3, n).astype(np.float32) + np.float32(0.3) * first
+    v = rng.integers(3, P.h - 3, n).astype(np.float32) + np.float32(0.6) * first
+    idp = rng.uniform(0.02, 0.5, n).astype(np.float32)
+    hdi = rng.uniform(1e-4, 1e-1, n).astype(np.float32)
+    wgt = np.sqrt((1e-3 / (hdi.astype(np.float64) + 1e-12)).astype(np.float32))        # sqrtf(1e-3 / (HdiF + 1e-12)), :273 / :120
+    for T in (O, R):
+        T.makeK(**P.calib)
+        T.set_new_image(P.image, 1.0)
+    uu = (u + np.float32(0.5)).astype(np.int32) if first else u.astype(np.int32)      # `int u = ph->u + 0.5f` (:116) vs `int u = ph->u` (:270)
+    vv = (v + np.float32(0.5)).astype(np.int32) if first else v.astype(np.int32)
+    O.makeCoarseDepth(uu, vv, idp, wgt)
+    R.makeCoarseDepthPts(u, v, idp, hdi, first)
+    for l in range(P.levels):
+        a, b = O.get_ref(l), R.get_ref(l)
+        assert len(a["u"]) == len(b["u"]) > 100
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (l, k)
+
+
+@needs_ref
+def test_write_or_check_golden(orc):
+    from tools.gen_ref_pin_golden import TRACKER_CFG, tracker_reference_outputs
+    ref = tracker_reference_outputs(TRACKER_CFG)
+    g = np.load(GOLD)
+    for k in ref:
+        assert np.array_equal(np.asarray(ref[k]), g[k], equal_nan=True), k
+
+
+def test_oracle_against_reference_fixture(orc):
+    """runs everywhere: the oracle against the reference outputs stored in tests/golden/ref_pin_tracker.npz"""
+    from tools.gen_ref_pin_golden import TRACKER_CFG
+    g = np.load(GOLD)
+    P, O = _setup(orc, TRACKER_CFG, orc.OracleTracker)
+    start = g["start"]
+    for l in range(P.levels):
+        k4, ki = O.get_K(l)
+        assert np.array_equal(k4, g["K%d" % l]) and np.array_equal(ki, g["Ki%d" % l])
+        assert np.array_equal(O.get_pyr(l), g["pyr%d" % l], equal_nan=True)
+        assert np.array_equal(O.calcRes(l, start, 0.02, 1.0, 20.0), g["res%d" % l])
+        assert np.array_equal(O.warped(), g["warped%d" % l])
+        H, b = O.calcGS(l, 0.02, 1.0)
+        assert np.array_equal(H, g["H%d" % l]) and np.array_equal(b, g["b%d" % l])
+    ok, pose, aff, last_res, flow, _ = O.trackNewestCoarse(start, (0.0, 0.0), P.levels - 1)
+    assert ok == bool(g["track_ok"]) and np.abs(pose - g["track_pose"]).max() <= 1e-15 and np.array_equal(aff, g["track_aff"])
+    assert np.array_equal(last_res, g["track_lastres"], equal_nan=True) and np.array_equal(flow, g["track_flow"])
