@@ -1,6 +1,6 @@
-"""CPU oracle loader -- TEST INFRASTRUCTURE ONLY.  PARITY PINNED IN PART: the accumulators, the bilinear taps and the affine-brightness
-transfer are checked bit for bit against the reference's own headers (oracle/refpin.py, tests/test_ref_pin.py); everything else is
-UNPINNED (see oracle/README.md).
+"""CPU oracle loader -- TEST INFRASTRUCTURE ONLY.  PARITY PINNED: every function of the oracle is checked against the reference's own
+translation units compiled unmodified into oracle/_ref/libref.so (oracle/README.md; oracle/refpin.py, RefTracker below,
+oracle/backend.py::RefEF; tests/test_ref_pin*.py).
 
 ctypes front-end for ``oracle/liborc.so`` (built by ``make -C oracle`` from orc_tracker.cpp /
 orc_backend.cpp, the plain-C++ restatement of the reference's CPU hot path).

@@ -1,4 +1,4 @@
-// oracle/orc_backend.cpp -- TEST INFRASTRUCTURE ONLY (CPU oracle). PARITY UNPINNED.
+// oracle/orc_backend.cpp -- TEST INFRASTRUCTURE ONLY (CPU oracle). PARITY PINNED against the reference's own translation units (oracle/_ref/libref.so, oracle/README.md; tests/test_ref_pin*.py).
 //
 // Plain C++ restatement of the reference's sliding-window back end, SURVEY.md section 8 rows b1-b7, on a
 // flattened copy of the EnergyFunctional graph (frames / points / residuals in the reference's iteration
@@ -13,8 +13,9 @@
 //   b6 solveSystemF / resubstituteF_MT               EnergyFunctional.cpp:650-759, 221-282
 //   b7 AccumulatedSCHessianSSE::addPoint / stitch    src/OptimizationBackend/AccumulatedSCHessian.cpp:10-135
 //      AccumulatorXX / AccumulatorX                  MatrixAccumulators.h:13-66,148-208
-// The reference cannot be compiled here (Eigen3/Boost/ROS/OpenCV absent) and has no tests for this path:
-// "parity unpinned"; pinned by analytic known-answer tests in tests/test_oracle_backend.py.
+// The reference's own translation units are compiled unmodified into oracle/_ref/libref.so (oracle/Makefile target `ref`);
+// tests/test_ref_pin_backend.py runs every function of this file against that build (bit-identical where the reference writes its
+// arithmetic out).
 // Float32 / float64 usage, operand order and the 1k/1M tiered accumulation follow the reference.
 #include "orc_math.hpp"
 #include <omp.h>

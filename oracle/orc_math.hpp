@@ -1,4 +1,4 @@
-// oracle/orc_math.hpp -- TEST INFRASTRUCTURE ONLY (CPU oracle). PARITY UNPINNED (see oracle/README.md).
+// oracle/orc_math.hpp -- TEST INFRASTRUCTURE ONLY (CPU oracle). PARITY PINNED against the reference's own translation units (oracle/_ref/libref.so, oracle/README.md; tests/test_ref_pin*.py).
 //
 // Small dense maths the reference gets from Eigen3 (un-vendored, README pins >= 3.2.8) and from the
 // vendored Sophus 0.9a.  Restated in plain C++ (no Eigen) so that the oracle can be built with g++

@@ -1,4 +1,4 @@
-// oracle/orc_reproject.cpp -- TEST INFRASTRUCTURE ONLY (CPU oracle). PARITY UNPINNED.
+// oracle/orc_reproject.cpp -- TEST INFRASTRUCTURE ONLY (CPU oracle). PARITY PINNED against the reference's own translation units (oracle/_ref/libref.so, oracle/README.md; tests/test_ref_pin*.py).
 //
 // Plain C++ restatement of the per-candidate work of the reference's Reprojector, SURVEY.md section 8f row 2:
 //   Reprojector::reprojectPoint            src/FullSystem/Reprojector.cpp:602-616   (projection into the new frame, grid cell)

@@ -1,4 +1,4 @@
-// oracle/orc_trace.cpp -- TEST INFRASTRUCTURE ONLY (CPU oracle). PARITY UNPINNED.
+// oracle/orc_trace.cpp -- TEST INFRASTRUCTURE ONLY (CPU oracle). PARITY PINNED against the reference's own translation units (oracle/_ref/libref.so, oracle/README.md; tests/test_ref_pin*.py).
 //
 // Plain C++ restatement of ImmaturePoint::traceOn (src/FullSystem/ImmaturePoint.cpp:47-353), SURVEY.md section 8f row 4: the
 // epipolar-line search every immature point of every key-frame runs on each new frame (FullSystem::traceNewCoarse,

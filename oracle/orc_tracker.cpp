@@ -1,4 +1,4 @@
-// oracle/orc_tracker.cpp -- TEST INFRASTRUCTURE ONLY (CPU oracle). PARITY UNPINNED.
+// oracle/orc_tracker.cpp -- TEST INFRASTRUCTURE ONLY (CPU oracle). PARITY PINNED against the reference's own translation units (oracle/_ref/libref.so, oracle/README.md; tests/test_ref_pin*.py).
 //
 // Plain C++ restatement of the reference's photometric coarse tracker, SURVEY.md section 8 rows a1-a9:
 //   a1 FrameHessian::makeImages          src/FullSystem/HessianBlocks.cpp:107-167
@@ -9,9 +9,8 @@
 //   a7 CoarseTracker::trackNewestCoarse  src/FullSystem/CoarseTracker.cpp:662-838
 //   a8 AffLight::fromToVecExposure       src/util/NumType.h:149-158
 //   a9 getInterpolatedElement33          src/util/globalFuncs.h:51-65
-// The reference itself cannot be compiled in this environment (needs Eigen3, Boost, ROS, OpenCV, PCL,
-// Pangolin -- none installed, no network) and ships no tests/golden vectors for this path, so this
-// oracle is "parity unpinned": it is pinned only by analytic known-answer tests (tests/test_oracle_*.py).
+// The reference's third-party dependencies are absent here, but its own source files compile unmodified against the stand-ins of
+// oracle/ref_shim (oracle/Makefile target `ref`); tests/test_ref_pin_tracker.py runs every function of this file against that build.
 //
 // Arithmetic follows the reference operation by operation: float32 where the reference uses float,
 // the same operand order, no FMA contraction (build with -ffp-contract=off, baseline SSE2 like the

@@ -505,6 +505,33 @@ void ref_ef_get_point_stats(void* e, float* maxRelBaseline, int* numGoodResidual
     RefEF* E = (RefEF*)e;
     for (size_t i = 0; i < E->phs.size(); ++i) { maxRelBaseline[i] = E->phs[i]->maxRelBaseline; numGoodResiduals[i] = E->phs[i]->numGoodResiduals; }
 }
+// FullSystem::optimizeImmaturePoint (FullSystemOptPoint.cpp:18-185) for n immature points against the frames / precalc of the handle
+// (ref_ef_set_precalc first).  result[i]: 0 = not well constrained, -1 = rejected, 1 = activated (idepth[i] = its idepth); res_state[n][nF]
+void ref_ef_optimize_immature(void* e, int n, const int* host, const float* u, const float* v, const float* idepth_min, const float* idepth_max,
+                              const float* energyTH, const float* color8, const float* weights8, const uint8_t* isFromSensor, int minObs,
+                              int* result, float* idepth, int* res_state) {
+    RefEF* E = (RefEF*)e; E->on();
+    FullSystem* fs = E->fs;
+    const int nF = (int)E->fhs.size();
+    std::vector<ImmaturePointTemporaryResidual> tr((size_t)nF);
+    for (int i = 0; i < n; ++i) {
+        ImmaturePoint ip((int)u[i], (int)v[i], E->fhs[host[i]], 1, &fs->Hcalib);
+        ip.u = u[i]; ip.v = v[i];
+        ip.idepth_min = idepth_min[i]; ip.idepth_max = idepth_max[i]; ip.energyTH = energyTH[i];
+        for (int k = 0; k < 8; ++k) { ip.color[k] = color8[8 * i + k]; ip.weights[k] = weights8[8 * i + k]; }
+        ip.isFromSensor = isFromSensor[i] != 0;
+        ip.type = ImmaturePoint::CORNER;
+        PointHessian* p = fs->optimizeImmaturePoint(&ip, minObs, tr.data());
+        idepth[i] = NAN;
+        if (p == 0) result[i] = 0;
+        else if (p == (PointHessian*)((long)(-1))) result[i] = -1;
+        else { result[i] = 1; idepth[i] = p->idepth; delete p; }
+        for (int t = 0; t < nF; ++t) res_state[(size_t)i * nF + t] = -1;
+        int k = 0;
+        for (int t = 0; t < nF; ++t) if (t != host[i]) res_state[(size_t)i * nF + t] = (int)tr[k++].state_state;
+    }
+}
+
 // diagnostics of the loading step
 void ref_ef_load_report(void* e, int* color_mismatch, double* image_grad_maxdiff) {
     RefEF* E = (RefEF*)e; *color_mismatch = E->color_mismatch; *image_grad_maxdiff = E->image_grad_maxdiff;

@@ -8,13 +8,14 @@ from . import lib
 f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
-_bound = False
+_bound = set()
 
 
-def _L():
-    global _bound
-    L = lib()
-    if not _bound:
+def _L(raw=None, prefix="orc_"):
+    from . import _Prefixed
+    L = _Prefixed(lib() if raw is None else raw, prefix)
+    if prefix not in _bound:
+        _bound.add(prefix)
         L.orc_rp_create.restype = C.c_void_p
         L.orc_rp_create.argtypes = [C.c_int, C.c_int, C.c_int]
         L.orc_rp_destroy.argtypes = [C.c_void_p]
@@ -24,15 +25,20 @@ def _L():
         L.orc_rp_set_cur_level.argtypes = [C.c_void_p, C.c_int, f32p]
         L.orc_rp_project.argtypes = [C.c_void_p, C.c_int, f32p, f32p, f32p, i32p, f64p, i32p, f32p]
         L.orc_rp_find_match.argtypes = [C.c_void_p, C.c_int, f32p, f32p, f32p, i32p, i32p, i32p, f64p, i32p, i32p]
-        _bound = True
     return L
 
 
 class OracleReprojector:
     """Per-candidate part of class Reprojector (src/FullSystem/Reprojector.h:17-112) on the CPU oracle."""
 
+    _prefix = "orc_"
+
+    @classmethod
+    def _raw(cls):
+        return None
+
     def __init__(self, w, h, levels):
-        self.L = _L()
+        self.L = _L(self._raw(), self._prefix)
         self.w, self.h, self.levels = w, h, levels
         self.h_ = self.L.orc_rp_create(w, h, levels)
 
@@ -72,3 +78,16 @@ class OracleReprojector:
         lvl = np.zeros(n, np.int32)
         self.L.orc_rp_find_match(self.h_, n, u, v, idepth, host_idx, ref_idx, ptype, px.reshape(-1), ok, lvl)
         return ok.astype(bool), px, lvl
+
+
+class RefReprojector(OracleReprojector):
+    """the same calls on the REFERENCE'S OWN Reprojector (Reprojector.cpp compiled unmodified into oracle/_ref/libref.so; oracle/ref_glue_misc.cpp)"""
+    _prefix = "ref_"
+
+    @classmethod
+    def _raw(cls):
+        from . import refpin
+        R = refpin.ref_lib()
+        if R is None:
+            raise RuntimeError("oracle/_ref/libref.so has not been built")
+        return R

@@ -49,6 +49,13 @@ GN_HD void quat_rotate(const double* q, const double* v, double* o) {
     o[2] = v[2] + q[3] * az + (q[0] * ay - q[1] * ax);
 }
 
+// SO3GroupBase::normalize (so3.hpp:196-202): q /= |q|.  The four squares are added the way Eigen's reduction adds a 4-double vector
+// (two 2-lane packets added lane-wise, then across): (x^2 + z^2) + (y^2 + w^2)
+GN_HD void quat_normalize(double* q) {
+    const double len = sqrt((q[0] * q[0] + q[2] * q[2]) + (q[1] * q[1] + q[3] * q[3]));
+    for (int i = 0; i < 4; ++i) q[i] /= len;
+}
+
 // C = A * B  (group product, then quaternion re-normalisation -- Sophus operator*)
 GN_HD Pose compose(const Pose& A, const Pose& B) {
     Pose C;
@@ -61,8 +68,7 @@ GN_HD Pose compose(const Pose& A, const Pose& B) {
     C.q[0] = aw * bx + ax * bw + ay * bz - az * by;
     C.q[1] = aw * by + ay * bw + az * bx - ax * bz;
     C.q[2] = aw * bz + az * bw + ax * by - ay * bx;
-    const double len = sqrt(C.q[0] * C.q[0] + C.q[1] * C.q[1] + C.q[2] * C.q[2] + C.q[3] * C.q[3]);
-    for (int i = 0; i < 4; ++i) C.q[i] /= len;
+    quat_normalize(C.q);
     return C;
 }
 
@@ -94,7 +100,7 @@ GN_HD void sincos_d(double x, double* sn, double* cs) {
 // exp of a twist [upsilon | omega]  (Sophus SE3::exp, se3.hpp:406-427; SO3::expAndTheta so3.hpp:342-369)
 GN_HD Pose exp_se3(const double* a) {
     const double wx = a[3], wy = a[4], wz = a[5];
-    const double th2 = wx * wx + wy * wy + wz * wz;
+    const double th2 = wx * wx + (wy * wy + wz * wz);       // omega.squaredNorm(): Eigen's unrolled 3-term reduction x0 + (x1 + x2)
     const double th = sqrt(th2);
     const bool tiny = th < 1e-10;
     double im, re;
@@ -110,6 +116,7 @@ GN_HD Pose exp_se3(const double* a) {
     }
     Pose P;
     P.q[0] = im * wx; P.q[1] = im * wy; P.q[2] = im * wz; P.q[3] = re;
+    quat_normalize(P.q);                                    // the SO3Group(Quaternion) constructor normalises (so3.hpp:596-598)
     const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
     double W2[9];
     for (int i = 0; i < 3; ++i)
@@ -124,8 +131,9 @@ GN_HD Pose exp_se3(const double* a) {
     } else {
         double st_, ct_;
         sincos_d(th, &st_, &ct_);
-        const double c1 = (1.0 - ct_) / th2;
-        const double c2 = (th - st_) / (th2 * th);
+        const double tsq = th * th;                            // se3.hpp:418 recomputes theta*theta
+        const double c1 = (1.0 - ct_) / tsq;
+        const double c2 = (th - st_) / (tsq * th);
         for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c1 * W[i] + c2 * W2[i];
     }
     for (int i = 0; i < 3; ++i) P.t[i] = V[i * 3] * a[0] + V[i * 3 + 1] * a[1] + V[i * 3 + 2] * a[2];
@@ -135,7 +143,7 @@ GN_HD Pose exp_se3(const double* a) {
 
 // log of a rigid transform -> twist [upsilon | omega]  (Sophus SE3::log se3.hpp:560-585, SO3::logAndTheta so3.hpp:491-531)
 GN_HD void log_se3(const Pose& T, double* out) {
-    const double sq = T.q[0] * T.q[0] + T.q[1] * T.q[1] + T.q[2] * T.q[2];
+    const double sq = T.q[0] * T.q[0] + (T.q[1] * T.q[1] + T.q[2] * T.q[2]);   // vec().squaredNorm(), same reduction shape
     const double nrm = sqrt(sq), w = T.q[3];
     double k;                                    // omega = k * vec(q), theta = k * |vec(q)|
     if (nrm < 1e-10) k = 2.0 / w - 2.0 * sq / (w * w * w);
@@ -164,6 +172,7 @@ GN_HD void log_se3(const Pose& T, double* out) {
 GN_HD Pose inverse(const Pose& A) {
     Pose R;
     R.q[0] = -A.q[0]; R.q[1] = -A.q[1]; R.q[2] = -A.q[2]; R.q[3] = A.q[3];
+    quat_normalize(R.q);                                    // so3.hpp:170-172: the conjugate goes through the normalising constructor
     const double mt[3] = {-A.t[0], -A.t[1], -A.t[2]};
     quat_rotate(R.q, mt, R.t);
     return R;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/*.npz from the CPU oracle (NOT from the reference, which cannot be built here -- see
-oracle/README.md: parity unpinned).  The vectors pin the oracle against accidental change and give the GPU tests a
+"""Generates tests/golden/*.npz from the CPU oracle (the reference's own outputs are in ref_pin*.npz, written by
+tools/gen_ref_pin_golden.py -- see oracle/README.md).  The vectors pin the oracle against accidental change and give the GPU tests a
 fixture that does not depend on scipy's image synthesis.  Run from the repo root:  python tests/golden/make_golden.py
 """
 import os

@@ -1,6 +1,6 @@
 """Oracle KATs for the marginalisation step around FullSystem::optimize: EFResidual::fixLinearizationF
 (EnergyFunctionalStructs.cpp:45-55), EnergyFunctional::marginalizePointsF (EnergyFunctional.cpp:514-576, addPoint<2>) and
-marginalizeFrame (:434-512).  The reference holds no vectors for these (parity unpinned): numpy mirrors + properties."""
+marginalizeFrame (:434-512).  The reference holds no vectors for these (the pin against its own code: tests/test_ref_pin_backend.py::test_marginalisation): numpy mirrors + properties."""
 import numpy as np
 import pytest
 

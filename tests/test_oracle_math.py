@@ -1,6 +1,6 @@
 """Known-answer tests that pin the oracle's maths (CPU only).
 
-The reference holds no tests for the hot path ("parity unpinned").  The only reference-held
+The reference holds no tests for the hot path (the pin against its own code is tests/test_ref_pin*.py).  The only reference-held
 checks that touch it are Sophus' group tests (thirdparty/Sophus/sophus/test_se3.cpp:40-92, tests.hpp:70-110:
 exp(log(G)) == G and exp(x) == expm(hat(x))), which the reference does not build; they are re-run here against the
 oracle's restatement of SE3::exp/log, on the same group elements and tangent vectors.

@@ -182,3 +182,74 @@ def test_oracle_against_reference_fixture(orc):
     ok, pose, aff, last_res, flow, _ = O.trackNewestCoarse(start, (0.0, 0.0), P.levels - 1)
     assert ok == bool(g["track_ok"]) and np.abs(pose - g["track_pose"]).max() <= 1e-15 and np.array_equal(aff, g["track_aff"])
     assert np.array_equal(last_res, g["track_lastres"], equal_nan=True) and np.array_equal(flow, g["track_flow"])
+
+
+# ---- Reprojector, ImmaturePoint::traceOn, optimizeImmaturePoint ---------------------------------------------------
+def _window():
+    from sdv_loam_amd import synthetic as syn
+    return syn.make_window(w=320, h=160, nF=5, pts_per_kf=100, seed=9, calib=dict(fx=240., fy=242., cx=159.5, cy=79.5))
+
+
+@needs_ref
+def test_reprojector(orc):
+    """reprojectPoint and findMatchDirect (getWarpMatrixAffine, getBestSearchLevel, warpAffine, align1D / align2D; Reprojector.cpp:17-616)"""
+    from oracle.reproject import OracleReprojector, RefReprojector
+    from sdv_loam_amd import synthetic as syn
+    W = _window()
+    P = syn.make_reproject_problem(W, levels=3, seed=1)
+    out = []
+    for cls in (OracleReprojector, RefReprojector):
+        R = cls(P.w, P.h, P.levels)
+        R.set_calib(**P.calib)
+        for k in range(len(P.frame_poses7)):
+            R.set_frame(k, P.frame_poses7[k], P.frame_images[k], float(P.frame_exposure[k]), *P.frame_aff[k])
+        R.set_cur(P.cur_pose7, P.cur_pyr, float(P.cur_exposure), *P.cur_aff)
+        px, cell, q = R.project(P.u, P.v, P.idepth, P.host_idx)
+        ok, pxm, lvl = R.find_match(P.u, P.v, P.idepth, P.host_idx, P.ref_idx, P.type, px)
+        out.append((px, cell, q, ok, pxm, lvl))
+    (px0, c0, q0, ok0, m0, l0), (px1, c1, q1, ok1, m1, l1) = out
+    assert np.abs(px0 - px1).max() <= 1e-10 and np.array_equal(c0, c1) and np.array_equal(q0, q1)
+    assert np.array_equal(ok0, ok1) and ok0.sum() > 0.3 * len(ok0) and (~ok0).sum() > 0
+    assert np.array_equal(l0[l1 >= 0], l1[l1 >= 0])
+    # matched positions: float iterates started from the projected pixel (equal to ~1e-13 in double, then cast to float): identical but for
+    # the few starts that land on the other side of a float rounding boundary
+    assert np.abs(m0[ok0] - m1[ok0]).max() <= 4e-6 and (m0[ok0] == m1[ok0]).mean() > 0.99
+
+
+@needs_ref
+def test_trace_on(orc):
+    from oracle import trace as otr
+    from sdv_loam_amd import synthetic as syn
+    W = _window()
+    P = syn.make_trace_problem(W, pose_err=(0.02, 0.002), seed=2)
+    args = (P, P.dI, P.idepth_min, P.idepth_max, P.quality, P.status)
+    a = otr.trace_on(*args)
+    b = otr.trace_on(*args, reference=True)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert len(set(a["status"].tolist())) >= 3
+    # second pass from the first pass' state (the bounded-interval branch, ImmaturePoint.cpp:76-145)
+    a2 = otr.trace_on(P, P.dI, a["idepth_min"], a["idepth_max"], a["quality"], a["status"], a["lastTraceUV"], a["interval"])
+    b2 = otr.trace_on(P, P.dI, b["idepth_min"], b["idepth_max"], b["quality"], b["status"], b["lastTraceUV"], b["interval"], reference=True)
+    for k in a2:
+        assert np.array_equal(a2[k], b2[k], equal_nan=True), k
+
+
+@needs_ref
+def test_optimize_immature_point(orc):
+    from oracle.backend import OracleEF, RefEF
+    W = _window()
+    rng = np.random.default_rng(3)
+    n = 300
+    sel = rng.choice(W.nP, n, replace=False)
+    idmin = (W.idepth[sel] * rng.uniform(0.6, 0.95, n)).astype(np.float32)
+    idmax = (W.idepth[sel] * rng.uniform(1.05, 1.6, n)).astype(np.float32)
+    eth = np.full(n, 8 * 12 * 12, np.float32)
+    sensor = (rng.random(n) < 0.3).astype(np.uint8)
+    res = []
+    for cls in (OracleEF, RefEF):
+        E = cls(W.w, W.h).load(W)
+        res.append(E.optimizeImmature(W.host[sel], W.u[sel], W.v[sel], idmin, idmax, eth, W.color[sel], W.weights[sel], sensor, minObs=1))
+    (r0, i0, s0), (r1, i1, s1) = res
+    assert np.array_equal(r0, r1) and np.array_equal(s0, s1) and np.array_equal(i0, i1, equal_nan=True)
+    assert (r0 == 1).sum() > 50 and len(set(r0.tolist())) >= 2
