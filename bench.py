@@ -138,17 +138,60 @@ def cpu_baseline_backend(W, budget_s=12.0):
             per_body.append(1e3 * dt1 / max(len(tr), 1))
         return its, tt, per_body
 
-    its, tt, pb = run(1, budget_s * 0.5)
-    its6, tt6, _ = run(6, budget_s * 0.25)
-    return dict(value=its / tt, unit="GN iters/s", cores=1, kind="port",
+    its, tt, pb = run(1, budget_s * 0.4)
+    its6, tt6, _ = run(6, budget_s * 0.2)
+    port = dict(value=its / tt, unit="GN iters/s", cores=1, kind="port",
                 ms_per_body=dict(median=float(np.median(pb)), p10=float(np.percentile(pb, 10)), p90=float(np.percentile(pb, 90)), calls=len(pb)),
                 sample="%d optimize-loop bodies (8 KF x 2000 pts, 112000 residuals; the headline's window and protocol: fresh window, "
                        "optimize(6) timed, load untimed) in %.1f s on 1 host thread; host has %d logical CPUs" % (its, tt, os.cpu_count()),
                 threads6=dict(value=its6 / tt6, unit="GN iters/s", cores=6,
                               sample="%d loop bodies in %.1f s with 6 OpenMP workers on linearizeAll / accumulate / resubstitute "
                                      "(reference: multiThreading=true, NUM_THREADS=6)" % (its6, tt6)))
+    ref = cpu_baseline_reference(W, budget_s * 0.4)
+    if ref is None:
+        return port
+    ref["port"] = port            # the oracle (plain-C++ restatement) on the same protocol, for comparison
+    return ref
 
 
+def cpu_baseline_reference(W, budget_s):
+    """The REFERENCE'S OWN FullSystem::optimize (oracle/_ref/libref.so: its translation units compiled unmodified with its own flags,
+    -O3 / SSE2, against the Eigen stand-in of oracle/ref_shim -- see oracle/README.md) on the same windows, 1 thread (its default).
+    Each timed call is optimize(6) with setting_minOptIterations = 6, i.e. exactly 6 loop bodies plus the function's fixed part (initial
+    linearizeAll + applyRes; tail: setEvalPT, adjoints, precalc, linearizeAll(true)); the fixed part is measured with optimize(0) on
+    fresh windows and subtracted, so that the figure is loop bodies per second like the headline.  None if the library is absent."""
+    try:
+        from oracle.backend import RefEF
+        R = RefEF(W.w, W.h).load(W)
+    except Exception:  # noqa: BLE001
+        return None
+    R.compute_nullspaces()
+    R.optimize_full(1, min_its=1)                 # warm-up
+    fixed = []
+    for _ in range(2):
+        R = RefEF(W.w, W.h).load(W); R.compute_nullspaces()
+        R.optimize_full(0, min_its=0)
+        fixed.append(R.last_seconds)
+    F = float(np.median(fixed))
+    tt, bodies, per_body = 0.0, 0, []
+    while tt < budget_s:
+        R = RefEF(W.w, W.h).load(W); R.compute_nullspaces()
+        _, steps, _, _ = R.optimize_full(6, min_its=6)
+        assert len(steps) == 6
+        tt += R.last_seconds
+        bodies += len(steps)
+        per_body.append(1e3 * (R.last_seconds - F) / 6)
+    calls = len(per_body)
+    return dict(value=bodies / (tt - calls * F), unit="GN iters/s", cores=1, kind="reference",
+                ms_per_body=dict(median=float(np.median(per_body)), p10=float(np.percentile(per_body, 10)), p90=float(np.percentile(per_body, 90)), calls=calls),
+                fixed_part_ms=1e3 * F,
+                sample="%d loop bodies of the reference's own FullSystem::optimize (8 KF x 2000 pts, 112000 residuals, the headline's window; "
+                       "%d calls of optimize(6) on fresh windows, %.1f s, the call's fixed part of %.0f ms measured with optimize(0) and "
+                       "subtracted) on 1 host thread; reference translation units compiled unmodified (-O3, SSE2) against the Eigen stand-in "
+                       "of oracle/ref_shim; host has %d logical CPUs" % (bodies, calls, tt, 1e3 * F, os.cpu_count()))
+
+
+# ------------------------------------------------------------------------------------------------------------
 def pmc_child():
     """Body of the profiled child process: the window is loaded and k_ef_linearize is launched 20 times (SDVGN_PMC_LOOP=1: ten bodies of
     the optimize loop instead, so that every kernel of the loop appears in the counters)."""

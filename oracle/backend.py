@@ -345,12 +345,17 @@ class RefEF(OracleEF):
         R.ref_ef_load_report.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         R.ref_ef_get_center_projected.argtypes = [vp, f32p]
 
-    def optimize_full(self, its=6):
+    def optimize_full(self, its=6, min_its=None):
         """FullSystem::optimize(its) of the reference.  Returns (rmse, [(accepted, iteration, energy)...] parsed from its console output,
-        removed[nR])."""
+        removed[nR], log).  min_its: value of setting_minOptIterations during the call (= its: exactly `its` loop bodies);
+        self.last_seconds = wall time of the optimize() call alone."""
         import re
         R = self.L._L
+        R.ref_ef_last_seconds.restype = C.c_double
+        R.ref_ef_set_min_its(-1 if min_its is None else int(min_its))
         rmse = R.ref_ef_optimize_full(self.h_, int(its))
+        R.ref_ef_set_min_its(-1)
+        self.last_seconds = R.ref_ef_last_seconds()
         n = R.ref_ef_last_log(self.h_, None, 0)
         buf = C.create_string_buffer(n + 1)
         R.ref_ef_last_log(self.h_, buf, n + 1)

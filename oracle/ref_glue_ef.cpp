@@ -12,6 +12,7 @@
 
 #include <map>
 #include <set>
+#include <time.h>
 
 using namespace refglue;
 
@@ -482,13 +483,28 @@ void ref_ef_marginalize_frame(void* e, int idx, double* HM_out, double* bM_out) 
 // FullSystem::optimize (FullSystemOptimize.cpp:344-502), the WHOLE function: loop and tail (setEvalPT of the newest frame, adjoints, precalc,
 // linearizeAll(true) which deletes the residuals that are not active).  The reference reports its accept / reject decisions through printf
 // only; its console output is captured and returned by ref_ef_last_log.  Returns the function's return value (the RMSE).
+// min_its >= 0 sets setting_minOptIterations for the call (settings.cpp:56 default 1; = mnumOptIts makes the loop run exactly that many
+// bodies, the timing protocol of bench.py's cpu_baseline leg); seconds_out: wall time of the optimize() call alone.
+static int g_min_its = -1;
+static double g_last_seconds = 0;
+void ref_ef_set_min_its(int n) { g_min_its = n; }
+double ref_ef_last_seconds() { return g_last_seconds; }
 double ref_ef_optimize_full(void* e, int mnumOptIts) {
     RefEF* E = (RefEF*)e; E->on();
     FullSystem* fs = E->fs;
     std::vector<PointFrameResidual*> before = E->prs;
     float rmse = 0;
+    const int saved_min = setting_minOptIterations;
+    if (g_min_its >= 0) setting_minOptIterations = g_min_its;
     setting_debugout_runquiet = false;
-    E->last_log = capture_stdout([&] { rmse = fs->optimize(mnumOptIts); });
+    E->last_log = capture_stdout([&] {
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        rmse = fs->optimize(mnumOptIts);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        g_last_seconds = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    });
+    setting_minOptIterations = saved_min;
     setting_debugout_runquiet = true;
     refresh_live(E);
     for (size_t i = 0; i < E->prs.size(); ++i) E->removed_by_finish[i] = (before[i] && !E->prs[i]) ? 1 : 0;
