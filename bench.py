@@ -650,9 +650,22 @@ def main():
     if args.trace_child:
         trace_child()
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` from a bare shell: launch the N ranks ourselves (one process per GPU over RCCL), the way the driver
+        # does with torch.distributed.run; rank 0 of the children prints the JSON line, which passes through
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     import torch
     from sdv_loam_amd import backend_api, synthetic as syn
     rank, local, world = dist_setup()
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; the launcher's world size is used" % (args.gpus, world), file=sys.stderr)
     K, Wm = args.steps, args.warmup
     W, G = backend_setup(local)                       # the unperturbed window: kernel timings, per-row extras, the soak
     Wh = syn.make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=syn.KITTI00, **HEAD_KW)

@@ -243,6 +243,7 @@ static void ef_fill_arrays(sdvgn_ef* e) {
     A.images = e->images;
     A.dbg_stamps = e->dbg_stamps;
     A.reset_oob = 0;
+    A.err = e->stats_host ? (unsigned*)(e->stats_host + 6) : nullptr;
 }
 
 static void ef_update_const(sdvgn_ef* e) {  // CalibHessian float views, HessianBlocks.h:302-330
@@ -961,6 +962,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     HIPCHK(hipHostMalloc(&e->precalc_host, 2 * sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
     HIPCHK(hipHostMalloc(&e->acc_host, sizeof(double) * accmax));
     HIPCHK(hipHostMalloc(&e->stats_host, sizeof(double) * 8));
+    std::memset(e->stats_host, 0, sizeof(double) * 8);   // [0..3] sums, [4] verdict, [6] (as unsigned) the sticky intra-launch wait error word
     HIPCHK(hipMalloc((void**)&e->accept_dev, 64));
     HIPCHK(hipMemset(e->accept_dev, 0, 64));
     HIPCHK(hipHostMalloc((void**)&e->flags_host, 64));
@@ -1043,6 +1045,7 @@ int sdvgn_ef_set_frames(sdvgn_ef* e, int nF, const double* evalPT7, const double
     if (!e || nF < 1 || nF > SDVGN_MAX_FRAMES || !evalPT7 || !state10 || !state_zero10 || !frameID || !ab_exposure || !frameEnergyTH)
         return SDVGN_E_ARG;
     e->nF = nF;
+    if (e->stats_host) *reinterpret_cast<volatile unsigned*>(e->stats_host + 6) = 0;   // a new window: the sticky wait-error word starts clean
     e->frames.resize(nF);
     for (int i = 0; i < nF; ++i) {
         FrameH& f = e->frames[i];
@@ -1546,6 +1549,7 @@ static void ef_fill_solve_io(sdvgn_ef* e, SolveIO& io, int iteration, double lam
     io.rx = e->rx_dev; io.sys = e->sys_dev; io.out = e->sol_host;
     io.done_flag = e->flags_host + 3; io.done_seq = ++e->seq_solve;
     io.ready_word = (unsigned*)(e->accept_dev + 8);
+    io.err_word = e->stats_host ? (unsigned*)(e->stats_host + 6) : nullptr;
     io.lambda = lambda; io.iteration = iteration; io.do_step = do_step ? 1 : 0; io.reuse = reuse ? 1 : 0; io.stepsize = stepsize;
     io.stamps = e->solve_stamps;
 }
@@ -1580,8 +1584,12 @@ static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_st
     e->sys_on_device = true; e->sys_fetched = false; e->sys_valid = true;
     return SDVGN_OK;
 }
+static inline bool ef_wait_error(const sdvgn_ef* e) {   // a workgroup gave up an intra-launch wait (EFArrays::err): the window is not trustworthy
+    return e->stats_host && *reinterpret_cast<volatile const unsigned*>(e->stats_host + 6) != 0;
+}
 static int ef_wait_solve(sdvgn_ef* e, double* x_out) {
     HIPCHK(wait_flag(e->flags_host + 3, e->seq_solve, e->stream));
+    if (ef_wait_error(e)) return SDVGN_E_STATE;
     const int n = CPARS + 6 * e->nF;
     e->lastX.assign(e->sol_host->x, e->sol_host->x + n);
     e->resInA = e->sol_host->resInA;
@@ -1698,6 +1706,7 @@ static int linearize_launch(sdvgn_ef* e, bool defer_select = false) {
 }
 static int linearize_wait(sdvgn_ef* e, double* energy, double* EL, double* sumID, double* sumNID) {
     HIPCHK(wait_flag(e->flags_host + 2, e->seq_stats, e->stream));
+    if (ef_wait_error(e)) return SDVGN_E_STATE;
     *energy = e->stats_host[0];
     const double En = host_prior_energy(e);   // calcLEnergyF_MT: frame + calib priors on the host, point part from the device
     *EL = En + (double)(float)e->stats_host[1];
@@ -1776,6 +1785,20 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     std::vector<int> th_idx;   // th_log slot of every trial linearisation (trace only)
     bool host_restore_pending = false;
     bool pre_accumulated = false;   // the accumulate of the coming body was queued behind the previous body's accept test (AccAlt)
+    // an error exit from inside the loop leaves launches queued whose host-side bookkeeping (set flips, copy swaps) did not happen: the host
+    // mirror goes back to the backed-up state and the handle refuses further work until the window is loaded again (sdvgn_ef_set_frames)
+    struct LoopGuard {
+        sdvgn_ef* e; bool* restore_pending; bool ok = false;
+        ~LoopGuard() {
+            if (ok) return;
+            if (*restore_pending) {
+                calib_set_value(e, e->value_backup);
+                for (FrameH& f : e->frames) frame_set_state(f, f.state_backup);
+            }
+            hipStreamSynchronize(e->stream);
+            e->sys_valid = false; e->haveAdjoints = false; e->havePrecalc = false;   // E_STATE from every compute entry point until reloaded
+        }
+    } loop_guard{e, &host_restore_pending};
     for (int iteration = 0; iteration < mnumOptIts; iteration++) {
         const auto t_iter = std::chrono::steady_clock::now();
         g_pt.start();
@@ -1929,6 +1952,8 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     if ((rc = take_initial_energies())) return rc;                             // (a call of zero bodies)
     ef_flush_pending(e);
     HIPCHK(hipGetLastError());
+    if (ef_wait_error(e)) return SDVGN_E_STATE;
+    loop_guard.ok = true;
     if (host_restore_pending) {   // the loop ended on a rejected step: loadSateBackup for the host mirror
         calib_set_value(e, e->value_backup);
         for (FrameH& f : e->frames) frame_set_state(f, f.state_backup);

@@ -105,7 +105,14 @@ struct EFArrays {
     // as state IN with state_energy = state_NewEnergy = 0 on entry (the first linearizeAll of FullSystem::optimize, which the reference
     // precedes with a resetOOB loop); what the pair writes is what reset + linearise + apply would have written
     int reset_oob;
+    // sticky error word in pinned host memory (may be NULL): a workgroup that gives up waiting for a word another workgroup of the same
+    // launch publishes ORs a code into it (1: the accept verdict, 2: the solution); sdvgn_ef_optimize and the solve check it and return
+    // SDVGN_E_STATE instead of carrying on with a partially applied / unstepped window
+    unsigned* err;
 };
+__device__ __forceinline__ void ef_raise(unsigned* err, unsigned code) {
+    if (err) __hip_atomic_fetch_or(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 struct CalibDev { float fxl, fyl, cxl, cyl, fxli, fyli; float cDeltaF[4]; float pad[2]; };
 // the EFConst a kernel computes with: calibration floats from device memory when the window's state lives there
@@ -628,7 +635,8 @@ __device__ __forceinline__ void apply_slot(int nF, int nP, const EFArrays& A, co
             if ((w >> 1) == seq || ++polls > (1 << 18)) break;
             __builtin_amdgcn_s_sleep(1);
         }
-        go = ((w >> 1) == seq) ? (int)(w & 1u) : 0;      // (a verdict that never arrives applies nothing; the host notices: the flag does not arrive either)
+        go = ((w >> 1) == seq) ? (int)(w & 1u) : 0;      // a verdict that did not arrive in time applies nothing here -- and is an error of the
+        if ((w >> 1) != seq) ef_raise(A.err, 1u);        // call: the publisher may only be late, other slots may have applied (A.err, sticky)
     }
     if (!go) return;
     const int np_h = precalc[hh * nF + hh].np;
@@ -1249,11 +1257,12 @@ struct ResubX { float xc[4]; float xAd[kMaxFrames * kMaxFrames * 6]; };
 
 // A launch may wait for a word another workgroup OF THE SAME LAUNCH publishes (k_ef_tail_resub: the factorisation workgroup's solution):
 // one lane polls with relaxed device-scope loads, the acquire fence behind it drops the CU's (and this XCD's) stale copies of what the
-// publisher wrote before its release fence, the workgroup barrier hands the result to the other waves.  Gives up after ~2^20 polls.
-__device__ __forceinline__ void wait_ready_word(const unsigned* word, unsigned seq) {
+// publisher wrote before its release fence, the workgroup barrier hands the result to the other waves.  Gives up after ~2^20 polls and raises the handle's sticky error word.
+__device__ __forceinline__ void wait_ready_word(const unsigned* word, unsigned seq, unsigned* err = nullptr) {
     if (threadIdx.x == 0) {
         int polls = 0;
         while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq && ++polls < (1 << 20)) __builtin_amdgcn_s_sleep(8);
+        if (polls >= (1 << 20)) ef_raise(err, 2u);       // gave up: what follows reads whatever x / xAd is in memory -- the call must fail (sticky)
         __threadfence();
     }
     __syncthreads();
@@ -1296,7 +1305,7 @@ __device__ __forceinline__ void resubstitute_body(const EFConst& C, const EFArra
     // vector load from the kernel-argument segment)
     __builtin_amdgcn_sched_barrier(0);
     const bool mine = inP && precalc[h * C.nF + h].np != 0;
-    if (ready) wait_ready_word(ready, seq);       // this thread's loads above are in flight while the solution is being computed
+    if (ready) wait_ready_word(ready, seq, A.err);       // this thread's loads above are in flight while the solution is being computed
     if (threadIdx.x < 4 + kMaxFrames * kMaxFrames * 6) sx[threadIdx.x] = reinterpret_cast<const float*>(Xp)[threadIdx.x];
     __syncthreads();
     const float* xc = sx;

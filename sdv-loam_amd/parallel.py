@@ -159,8 +159,9 @@ class ShardedEnergyFunctional:
 # Difference to the sequential reference (stated in SURVEY.md 8e): every try runs to the end; the reference passes the best residuals so
 # far as `minResForAbort` into later tries (a later try that is 1.5x worse on a coarse level is cut short and cannot win) and stops
 # trying once a result is below setting_reTrackThreshold x the last frame's RMSE.  The replay keeps both rules on the finished results
-# (a try whose coarse-level residuals would have triggered the abort is not eligible; tries behind the early-out are ignored), so the
-# winner is the reference's whenever the per-level residuals of a completed run equal those of the run the reference would have cut.
+# (a try whose coarse-level residuals would have triggered the abort is not eligible and contributes only the residuals of the levels
+# it would have finished; tries behind the early-out are ignored), so the winner and the achieved residuals are the reference's
+# whenever the per-level residuals of a completed run equal those of the run the reference would have cut.
 # ---------------------------------------------------------------------------------------------------------------------------------
 HYP_COLS = 18   # ok | lastResiduals[5] | pose7 | aff2 | flow3
 
@@ -170,20 +171,28 @@ def hypothesis_slice(n, rank, world):
     return list(range(rank, n, world))
 
 
-def select_hypothesis(table, last_coarse_rmse0=None, retrack_threshold=1.5, abort_factor=1.5):
+def select_hypothesis(table, last_coarse_rmse0=None, retrack_threshold=1.5, abort_factor=1.5, coarsest=4):
     """The selection loop of FullSystem::trackNewCoarse (FullSystem.cpp:412-463) replayed on the finished results `table`
-    [n][HYP_COLS] in try order.  Returns dict(good, index, pose, aff, flow, achieved_res, tries)."""
+    [n][HYP_COLS] in try order.  Returns dict(good, index, pose, aff, flow, achieved_res, tries).
+
+    Every try in the table ran to the end.  In the reference a later try receives the residuals achieved so far as `minResForAbort` and
+    is cut on the first level L (coarsest first) whose residual exceeds 1.5 x the achieved one (CoarseTracker.cpp:808-810): it returns
+    false with lastResiduals[l < L] still NaN (:674), so it can neither win nor lower the achieved residuals of the finer levels nor
+    trigger the early-out with them.  The replay reproduces exactly that view of the finished run."""
     n = table.shape[0]
     achieved = np.full(5, np.nan)
     good, win = False, -1
     tries = 0
     for i in range(n):
         ok = table[i, 0] > 0.5
-        res = table[i, 1:6]
+        res = table[i, 1:6].copy()
         tries += 1
-        # CoarseTracker.cpp:810: a try is abandoned on level l when its residual exceeds 1.5 x the best achieved one on that level
-        aborted = any(np.isfinite(achieved[l]) and np.isfinite(res[l]) and res[l] > abort_factor * achieved[l] for l in range(1, 5))
-        if ok and not aborted and np.isfinite(np.float32(res[0])) and not (res[0] >= achieved[0]):
+        for l in range(min(coarsest, 4), -1, -1):                        # levels in the order the tracker visits them
+            if np.isfinite(res[l]) and res[l] > abort_factor * achieved[l]:          # (NaN achieved: comparison false, no abort)
+                ok = False
+                res[:l] = np.nan
+                break
+        if ok and np.isfinite(np.float32(res[0])) and not (res[0] >= achieved[0]):
             good, win = True, i
         if good:
             for l in range(5):
@@ -224,4 +233,4 @@ def track_hypotheses(evaluate, poses7, aff, coarsest, rank=0, world=1, group=Non
             dist.all_reduce(t, group=group)
             table = t.numpy()
     table[:, 1:6] = np.where(table[:, 1:6] >= 1e299, np.nan, table[:, 1:6])
-    return select_hypothesis(table, last_coarse_rmse0, retrack_threshold), table
+    return select_hypothesis(table, last_coarse_rmse0, retrack_threshold, coarsest=coarsest), table

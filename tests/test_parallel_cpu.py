@@ -155,3 +155,28 @@ def test_tracker_hypothesis_split_gloo(orc, sdvgn_lib):
                     achieved[l] = lr[l]
     assert good and win == s0["index"]
     assert np.allclose(achieved[:P.levels], s0["achieved_res"][:P.levels], rtol=1e-12)
+
+
+def test_select_hypothesis_aborted_try_with_smallest_level0(sdvgn_lib):
+    """A try the reference would have cut on a coarse level (residual > 1.5 x the achieved one, CoarseTracker.cpp:808-810) returns with its
+    finer-level residuals still NaN (:674): even if its complete run ends with the smallest level-0 residual it must neither win nor
+    lower the level-0 bar for a later, legitimate try."""
+    from sdv_loam_amd import parallel
+    nan = np.nan
+    T = np.zeros((3, parallel.HYP_COLS))
+    T[:, 0] = 1
+    T[0, 1:6] = [1.0, 2.0, 3.0, nan, nan]
+    T[1, 1:6] = [0.5, 2.0, 5.0, nan, nan]          # level 2: 5.0 > 1.5 * 3.0 -> cut there; 0.5 and 2.0 never exist in the reference
+    T[2, 1:6] = [0.8, 1.9, 2.9, nan, nan]
+    T[:, 6:13] = np.arange(21).reshape(3, 7)
+    s = parallel.select_hypothesis(T, coarsest=2)
+    assert s["good"] and s["index"] == 2
+    assert np.array_equal(s["achieved_res"][:3], [0.8, 1.9, 2.9])
+    # the early-out must not fire on a residual the winning pose does not have
+    s = parallel.select_hypothesis(T, last_coarse_rmse0=0.4, retrack_threshold=1.5, coarsest=2)     # bar 0.6: only the phantom 0.5 is below
+    assert s["tries"] == 3 and s["index"] == 2
+    # a try cut on level 1 still lowers the achieved residual of the level it finished (2)
+    T2 = T.copy()
+    T2[1, 1:6] = [0.5, 3.5, 2.5, nan, nan]         # level 2 fine (2.5 < 4.5), level 1: 3.5 > 3.0 -> cut after level 1
+    s = parallel.select_hypothesis(T2, coarsest=2)
+    assert s["index"] == 2 and np.array_equal(s["achieved_res"][:3], [0.8, 1.9, 2.5])
