@@ -66,11 +66,14 @@ int sdvgn_tracker_set_arith(sdvgn_tracker* t, int mode);
  * most 32, as long as the whole launch is resident at once; otherwise one 1024-lane workgroup per hypothesis), -1 = always one workgroup
  * (k_track), 1..32 = that many (k_track_team).  Results do not depend on it beyond the summation order of the 52 totals.
  * sdvgn_tracker_get_team: what the last track_batch call used (0 = k_track).
- * The workgroups of a team wait for each other inside the kernel, so a team launch needs its whole grid resident (the size limit above takes
- * care of that for ONE launch): do not run track_batch of two handles concurrently on one device through caller-provided streams -- the
- * library's shared tracker stream serialises them; a team that cannot assemble gives up after ~1 s with SDVGN_E_STATE, it does not hang. */
+ * The workgroups of a team wait for each other inside the kernel, so a team launch needs its whole grid resident.  The team size is limited to
+ * three quarters of what the device can hold of the kernel at once (occupancy query x CUs), which leaves room for what runs beside it (the
+ * back end on its own stream, other handles); if members still fail to meet -- the device was busier than that -- their poll gives up after
+ * ~1 s, the batch is re-run on the one-workgroup kernel and the call succeeds (sdvgn_tracker_get_team then reports 0,
+ * sdvgn_tracker_get_team_fallbacks counts such re-runs). */
 int sdvgn_tracker_set_team(sdvgn_tracker* t, int team);
 int sdvgn_tracker_get_team(sdvgn_tracker* t);
+int sdvgn_tracker_get_team_fallbacks(sdvgn_tracker* t);
 
 /* CoarseTracker::makeK(CalibHessian*)   CoarseTracker.cpp:77-106  (level-0 fx,fy,cx,cy = HCalib->fxl()...) */
 int sdvgn_tracker_make_K(sdvgn_tracker* t, float fx, float fy, float cx, float cy);
@@ -316,8 +319,10 @@ int sdvgn_ef_apply_res(sdvgn_ef* ef);
  * (accumulateAF/LF/SCF, HM/bM, damped Jacobi-preconditioned LDLT, orthogonalize for iteration >= 2, resubstitute).
  * x_out[4+6nF] = lastX; frame/calib steps are -x, point steps stay on the device (sdvgn_ef_get_points). */
 int sdvgn_ef_solve_system(sdvgn_ef* ef, int iteration, double lambda, double* x_out);
-/* 1 if a pivot of the last device-side LDL^T was not positive / finite (x was set to 0: the caller's energy test rejects the step), else 0.
- * The reference's `HFinalScaled.ldlt().solve()` (EnergyFunctional.cpp:743) has no failure path either. */
+/* 0: the last device-side solve used the fast unpivoted LDL^T (the system was positive definite, as it is by construction); 2: a pivot was
+ * not positive / finite (an indefinite system, e.g. an indefinite marginalisation prior) and the solve fell back to Eigen's diagonally
+ * pivoted LDL^T (LDLT.h: pivot = largest remaining |diagonal|; pseudo-inverse of D), which like the reference's
+ * `HFinalScaled.ldlt().solve()` (EnergyFunctional.cpp:743) returns a finite x on such a system.  No failure path. */
 int sdvgn_ef_get_solve_status(sdvgn_ef* ef);
 /* doStepFromBackup / backupState / loadSateBackup for the per-point idepths (FullSystemOptimize.cpp:165-321):
  * mode 0: backup = idepth; mode 1: idepth = idepth_zero = backup + stepfac*step; mode 2: idepth = idepth_zero = backup */

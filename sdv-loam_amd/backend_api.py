@@ -168,6 +168,10 @@ class EnergyFunctional:
         self._check(self.L.sdvgn_ef_solve_system(self.h_, iteration, lam, x.ctypes.data_as(vp)))
         return x
 
+    def solve_status(self):
+        """0: the last solve used the fast unpivoted LDL^T; 2: it fell back to the pivoted one (indefinite system)"""
+        return self.L.sdvgn_ef_get_solve_status(self.h_)
+
     def accumulate(self):
         self._check(self.L.sdvgn_ef_accumulate(self.h_))
 

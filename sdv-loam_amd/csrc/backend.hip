@@ -1594,8 +1594,8 @@ static int ef_wait_solve(sdvgn_ef* e, double* x_out) {
     e->lastX.assign(e->sol_host->x, e->sol_host->x + n);
     e->resInA = e->sol_host->resInA;
     if (x_out) std::memcpy(x_out, e->lastX.data(), sizeof(double) * n);
-    // a non-positive / non-finite pivot is not an error of the call: like Eigen's ldlt().solve() on such a system the step is simply
-    // useless (here x = 0, the energy test rejects it and lambda grows); the condition can be queried (sdvgn_ef_get_solve_status)
+    // a non-positive / non-finite pivot is not an error of the call: the device falls back to Eigen's pivoted LDL^T (status 2), which like
+    // the reference's ldlt().solve() returns a finite x on an indefinite system (sdvgn_ef_get_solve_status)
     e->solve_status = e->sol_host->status;
     return SDVGN_OK;
 }

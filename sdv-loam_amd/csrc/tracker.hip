@@ -81,6 +81,8 @@ struct sdvgn_tracker {
     TeamMem* team_dev = nullptr;         // k_track_team: partial rows + counters per hypothesis (allocated on first use, zeroed)
     int team_cap = 0;
     int cu_count = 0;                    // multiProcessorCount of the device (queried once)
+    int team_capacity = 0;               // workgroups of k_track_team this handle lets one launch occupy (occupancy x CUs x 3/4)
+    int team_fallbacks = 0;              // batches re-run on k_track because a team's members did not meet
     int team_mode = 0;                   // sdvgn_tracker_set_team: 0 automatic, -1 always k_track (one workgroup), T >= 1 fixed team size
     int last_team = 0;                   // team size of the last track_batch call (0: k_track)
     int track_seq = 0;                   // sequence number of track_batch calls (TrackState::done)
@@ -372,6 +374,7 @@ int sdvgn_tracker_set_team(sdvgn_tracker* t, int team) {
     return SDVGN_OK;
 }
 int sdvgn_tracker_get_team(sdvgn_tracker* t) { return t ? t->last_team : SDVGN_E_ARG; }
+int sdvgn_tracker_get_team_fallbacks(sdvgn_tracker* t) { return t ? t->team_fallbacks : SDVGN_E_ARG; }
 
 int sdvgn_tracker_set_arith(sdvgn_tracker* t, int mode) {
     if (!t || mode < 0 || mode > 1) return SDVGN_E_ARG;
@@ -583,13 +586,19 @@ int sdvgn_tracker_track_batch(sdvgn_tracker* t, int B, double* pose7_io, double*
         const int Bpad = (B + 7) & ~7;
         int want = t->team_mode > 0 ? t->team_mode : (nmax + kTeamThreads - 1) / kTeamThreads;
         if (want > kTeamMax) want = kTeamMax;
-        // resident capacity: two 256-lane workgroups of this kernel per CU (its register count); the whole grid must fit, and so must one
-        // dispatch window of 8 interleaved teams (a partitioned device with few CUs gets small teams or the one-workgroup kernel)
+        // resident capacity: what the device can hold of THIS kernel at once (occupancy query: workgroups per CU at its register / LDS
+        // use x CUs), less a quarter as headroom for whatever runs beside it -- the back end has a stream of its own precisely so that a
+        // window is optimised while a frame is tracked, and a caller may run several handles or ranks on one device.  The whole grid must
+        // fit, and so must one dispatch window of 8 interleaved teams (a partitioned device with few CUs gets small teams or the
+        // one-workgroup kernel).  If members still fail to meet (the poll gives up, ok == -2) the batch is re-run on k_track below.
         if (t->cu_count <= 0) {
             hipDeviceProp_t prop;
             t->cu_count = (hipGetDeviceProperties(&prop, t->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 1;
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_team, kTeamThreads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+            t->team_capacity = (3 * per_cu * t->cu_count) / 4;
         }
-        const int capacity = 2 * t->cu_count;
+        const int capacity = t->team_capacity;
         if (want > capacity / Bpad) want = capacity / Bpad;
         if (Bpad > 512) want = 0;      // the exchange rows are allocated for at most 512 hypotheses
         // a fixed request of 1 runs the team kernel with a single member (tests); automatic mode needs at least two
@@ -621,7 +630,25 @@ int sdvgn_tracker_track_batch(sdvgn_tracker* t, int B, double* pose7_io, double*
     if (T >= 1) {
         bool dead = false;
         for (int b = 0; b < B; ++b) dead = dead || t->track_host[b].ok == -2;
-        if (dead) return SDVGN_E_STATE;   // an exchange gave up (a team member never arrived)
+        if (dead) {
+            // an exchange gave up: some member of a team was not resident while the others polled (the device was busier than the headroom
+            // allows for).  Nothing of the batch is used; it runs again on the one-workgroup kernel, which needs no co-residency.
+            ++t->team_fallbacks;
+            HIPCHK(hipStreamSynchronize(t->stream));
+            HIPCHK(hipMemsetAsync(t->team_dev, 0, sizeof(TeamMem) * (size_t)t->team_cap, t->stream));   // half-written exchange rows
+            for (int b = 0; b < B; ++b) {
+                TrackState& s = t->track_host[b];
+                std::memcpy(s.pose, pose7_io + 7 * b, sizeof(double) * 7);
+                s.aff[0] = aff_io[2 * b]; s.aff[1] = aff_io[2 * b + 1];
+                for (int i = 0; i < 5; ++i) s.minRes[i] = minRes ? minRes[5 * b + i] : NAN;
+                s.ok = 0; s.ntrials = 0;
+            }
+            const int seq2 = ++t->track_seq;
+            t->last_team = 0;
+            k_track<<<B, kTrackThreads, 0, t->stream>>>(tc, t->track_host, seq2);
+            HIPCHK(hipGetLastError());
+            for (int b = 0; b < B; ++b) HIPCHK(wait_flag(&t->track_host[b].done, seq2, t->stream));
+        }
     }
     for (int b = 0; b < B; ++b) {
         const TrackState& s = t->track_host[b];

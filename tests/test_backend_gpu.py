@@ -480,3 +480,36 @@ def test_many_points_per_host(api, orc):
     check_linearize(G, O)
     G.applyRes(); O.applyRes()
     check_solve(G, O, 0, 0.1)
+
+
+@pytest.mark.parametrize("scale", [1e9, 3e10])
+def test_indefinite_system_pivoted_fallback(api, orc, window, scale):
+    """Eigen's pivoted `HFinalScaled.ldlt().solve()` (EnergyFunctional.cpp:743) returns a finite x on an indefinite system.  An
+    indefinite marginalisation prior (2x2 block [[1, 2], [2, 1]] * scale between two pose coordinates: eigenvalues 3, -1) makes the stitched
+    system indefinite with a positive diagonal; the device's unpivoted factorisation meets a negative pivot and must fall back to the pivoted
+    one (status 2) with the oracle's x -- and the optimize loop on that window must follow the oracle's decisions."""
+    W = copy.copy(window)
+    n = 4 + 6 * W.nF
+    HM = np.array(W.HM, np.float64).copy()
+    i, j = 4 + 6 * 1 + 1, 4 + 6 * 3 + 2
+    HM[i, :] = HM[:, i] = 0; HM[j, :] = HM[:, j] = 0
+    HM[i, i] = HM[j, j] = scale
+    HM[i, j] = HM[j, i] = 2 * scale
+    W.HM = HM
+    G, O = pair(api, orc, W)
+    check_linearize(G, O)
+    G.applyRes(); O.applyRes()
+    xg = G.solveSystemF(0, 0.1)
+    O.solveSystemF(0, 0.1)
+    so = O.system()
+    assert np.linalg.eigvalsh(so["HFinal"]).min() < 0 and np.all(np.diag(so["HFinal"]) > 0)     # indefinite, positive diagonal
+    assert G.solve_status() == 2
+    assert np.all(np.isfinite(xg)) and rel_err(xg, so["x"]) < 1e-6
+    assert rel_err(G.points()[:, 8], O.points()[:, 8]) < 1e-4
+    # a definite window right after it goes back to the fast path
+    G2, O2 = pair(api, orc, window)
+    G2.linearizeAll(); G2.applyRes(); G2.solveSystemF(0, 0.1)
+    assert G2.solve_status() == 0
+    # whole loop on the indefinite window
+    G, O = pair(api, orc, W)
+    check_optimize(G, O, 5)

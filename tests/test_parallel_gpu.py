@@ -88,3 +88,55 @@ def test_tracker_hypotheses_on_device_match_sequential_oracle(orc, sdvgn_lib):
     motion = orc.se3_log(orc.se3_mul(wpose, orc.se3_inverse(poses[win])))
     assert np.linalg.norm(d) < 1e-3 * np.linalg.norm(motion)
     assert np.allclose(table[win, 1:1 + P.levels], O.trackNewestCoarse(poses[win], (0.0, 0.0), P.levels - 1)[3][:P.levels], rtol=1e-4)
+
+
+def test_track_team_beside_running_back_end(sdvgn_lib, orc):
+    """VERDICT r02 item 3: trackBatch(31) -- team launches whose members poll for each other -- while FullSystem::optimize loops on the
+    back end's stream from a second thread (k_ef_linearize alone keeps 4 096 waves in flight).  Every batch must succeed (team or, if the
+    members could not meet, the k_track re-run) with the results of a quiet device; 100 repetitions."""
+    import threading
+    from common import load_problem, rel_err, start_pose
+    from sdv_loam_amd import api, backend_api, synthetic as syn
+    P = syn.make_tracker_problem(w=1241, h=376, levels=4, n_points=2000, seed=0, calib=syn.KITTI00,
+                                 gt_xi=[0.03, -0.02, 0.05, 0.004, -0.006, 0.002], gt_aff=(0.03, 1.5))
+    G = load_problem(api.CoarseTracker(P.w, P.h, P.levels, max_points=1 << 16, max_batch=40), P)
+    B = 31
+    poses = np.stack([start_pose(orc, P, 200 + i, 0.01 + 0.002 * i, 0.001 + 0.0003 * i) for i in range(B)])
+    affs = np.zeros((B, 2))
+    ok0, p0, a0, lr0, fl0 = G.trackBatch(poses, affs, P.levels - 1)                  # quiet device
+    assert G.last_team() >= 1 and ok0.sum() >= B // 2
+    W = syn.make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=syn.KITTI00, state_sigma=1e-3, idepth_sigma=0.01)
+    E = backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+    stop, errs, bodies = threading.Event(), [], [0]
+
+    def back_end():
+        try:
+            while not stop.is_set():
+                E.load(W)
+                bodies[0] += len(E.optimize(6, fixed_its=True, want_trace=True))
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+
+    th = threading.Thread(target=back_end)
+    th.start()
+    try:
+        for _ in range(100):
+            ok, p, a, lr, fl = G.trackBatch(poses, affs, P.levels - 1)
+            assert np.array_equal(ok, ok0)
+            for b in range(B):
+                if ok0[b]:
+                    d0 = orc.se3_log(orc.se3_mul(p0[b], orc.se3_inverse(poses[b])))
+                    d = orc.se3_log(orc.se3_mul(p[b], orc.se3_inverse(poses[b])))
+                    assert rel_err(d, d0) < 1e-4
+    finally:
+        stop.set()
+        th.join(120)
+    assert not errs and bodies[0] >= 6
+    # and against the oracle for a few of them
+    O = load_problem(orc.OracleTracker(P.w, P.h, P.levels), P)
+    for b in (0, 7, 30):
+        oko, po, ao, lro, flo, _ = O.trackNewestCoarse(poses[b], (0.0, 0.0), P.levels - 1)
+        assert bool(ok0[b]) == oko
+        if oko:
+            assert rel_err(orc.se3_log(orc.se3_mul(p0[b], orc.se3_inverse(poses[b]))), orc.se3_log(orc.se3_mul(po, orc.se3_inverse(poses[b])))) < 1e-4
+    print("team fallbacks during the run:", G.team_fallbacks(), "back-end bodies:", bodies[0])
