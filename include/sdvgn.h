@@ -393,19 +393,6 @@ int sdvgn_ef_get_accepted_steps(sdvgn_ef* ef);
 /* durations (milliseconds, HIP events on the library's stream) of the k_ef_linearize launches of the last sdvgn_ef_optimize call that ran
  * with flags bit3, in launch order (the first is the call's initial linearizeAll); returns their number */
 int sdvgn_ef_get_linearize_times(sdvgn_ef* ef, float* ms, int cap);
-/* Diagnostics: k_ef_linearize `reps` times in different company (0 alone, 1 behind accumulate + reduce, 2 behind stitch + tail +
- * resubstitute without a step, 3 behind a one-wave kernel that waits spin_us, 4 behind 1 and 2), for kernel traces */
-int sdvgn_debug_launch_pattern(sdvgn_ef* ef, int pattern, int reps, int spin_us);
-/* Diagnostics: k_ef_linearize alone, `reps` launches back to back on the library's stream (no statistics, no threshold select) */
-int sdvgn_debug_launch_linearize(sdvgn_ef* ef, int reps);
-/* Diagnostics (SDVGN_PROFILE=1 in the environment when the library is loaded): prints the accumulated host wall time per phase
- * of the solve / optimize path to stderr, divided by `per`, and clears the counters.  Returns 1 if a report was printed, else 0. */
-int sdvgn_debug_phase_report(int per);
-/* SDVGN_DEBUG_FLAGS bit 6: wall_clock64() (100 MHz) stamps of the phases of the last device-side small solve; returns the word count (16) */
-int sdvgn_debug_solve_stamps(sdvgn_ef* ef, unsigned long long* out16);
-/* Diagnostics (SDVGN_DEBUG_FLAGS bit5 = 32 set when the handle is created): wall_clock64() stamps (10 ns) of k_ef_linearize's stages
- * from the last launch, [workgroup][wave][8] 64-bit words (tools/exp_linearize_stages.py).  Returns the number of words copied, 0 if the diagnostics are off. */
-int sdvgn_debug_read_stamps(sdvgn_ef* ef, unsigned long long* out, int cap_words);
 /* Device pointer of key-frame idx's level-0 image (dI, AoS {I,dx,dy}) held by the window, for sdvgn_reproj_set_frame(.., dI_aos3_dev);
  * NULL if idx is out of range or the handle is host-only.  Valid until that frame's image is replaced or the handle is destroyed. */
 const float* sdvgn_ef_frame_image_dev(sdvgn_ef* ef, int idx);

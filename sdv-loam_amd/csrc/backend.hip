@@ -8,6 +8,7 @@
 //           (4+6nF)^2 system, the Jacobi-preconditioned LDLT solve and the null-space projection -- all O(nF^3) and
 //           independent of the number of points ("tiny; keep on host").
 #include "../../include/sdvgn.h"
+#include "sdvgn_debug.h"
 #include "backend_kernels.hpp"
 
 #include <dlfcn.h>

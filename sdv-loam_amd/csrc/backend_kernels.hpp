@@ -67,7 +67,7 @@ struct EFConst {
     float wM3G, hM3G;
     float cDeltaF[4];
     float huberTH, outlierTHSumComponent;
-    int debug_flags;   // profiling experiments only, never set by the product path: bit1 skip the J stores, bit2 disable the XCD mapping, bit7 shared gather positions,
+    int debug_flags;   // profiling experiments only, read by the diagnostic instantiation k_ef_linearize<true> alone (SDVGN_DEBUG_FLAGS bit5), never by the product's: bit1 skip the J stores, bit2 disable the XCD mapping, bit7 shared gather positions,
                        // bit5 stage stamps of k_ef_linearize into EFArrays::dbg_stamps (tools/exp_linearize_stages.py)
 };
 
@@ -279,7 +279,7 @@ __device__ __forceinline__ void lin_geometry(const EFConst& C, const PrecalcDev&
 
 // phase C: per-pixel terms of the reference's pattern loop (:157-194) from the interpolated {I,dx,dy}; summed later in pixel order by
 // role 0.  Then this role's row of the new Jacobian goes to the buffer the EnergyFunctional side does NOT own.
-template <int ROLE>
+template <int ROLE, bool DBG = false>
 __device__ __forceinline__ void lin_phase_c(const EFConst& C, const EFArrays& A, const PrecalcDev& pc, size_t s, size_t slots, const LinIn& I,
                                             const LinGeo& Gm, const float (*g)[3] /*[4][3] of this lane*/, LinLane& L) {
     const float col[4] = {I.c4.x, I.c4.y, I.c4.z, I.c4.w};
@@ -301,7 +301,7 @@ __device__ __forceinline__ void lin_phase_c(const EFConst& C, const EFArrays& A,
         if (I.inb[k] && isfinite(g0)) L.ok |= 1u << k;
     }
     L.wrote = L.todo && !L.oob;
-    if (L.wrote && (!(C.debug_flags & 2) || Gm.hwm != Gm.hwm)) {
+    if (L.wrote && (!DBG || !(C.debug_flags & 2) || Gm.hwm != Gm.hwm)) {   // (experiment switches exist in the diagnostic instantiation only)
         const int buf = (I.fl & RF_SEL) ? 0 : 1;
         float* Jn = A.J + (size_t)buf * kJPlanes * slots + s;
         Jn[(0 + ROLE) * slots] = (ROLE == 0 ? Gm.res0 : Gm.res1) * Gm.hwm;
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(128 * GROUPS) k_ef_linearize(const PrecalcDev*
     __shared__ LinSmem S;
     int pair = blockIdx.y, chunk = blockIdx.x;
     const int n_wg = gridDim.x * gridDim.y;
-    if ((n_wg & 7) == 0 && !(C.debug_flags & 4)) {
+    if ((n_wg & 7) == 0 && !(STAMPS && (C.debug_flags & 4))) {
         // XCD-aware mapping: workgroups go round-robin to the 8 XCDs by linear id, so id % 8 is the XCD.  The work items are ordered
         // TARGET-major (target, host, chunk) and XCD x takes the x-th eighth of that order: with 8 key-frames XCD x linearises every
         // residual whose target is frame x, with 5-7 key-frames an XCD sees at most two targets -- its 4 MB L2 then gathers from one or
@@ -409,8 +409,8 @@ __global__ void __launch_bounds__(128 * GROUPS) k_ef_linearize(const PrecalcDev*
     }
     __syncthreads();
     // ---- phase C: pixel terms, Jacobian stores -------------------------------------------------------------------------------------------
-    if (role == 0) lin_phase_c<0>(C, A, pc, s, slots, I, Gm, S.g[grp][0][lane], L);
-    else lin_phase_c<1>(C, A, pc, s, slots, I, Gm, S.g[grp][1][lane], L);
+    if (role == 0) lin_phase_c<0, STAMPS>(C, A, pc, s, slots, I, Gm, S.g[grp][0][lane], L);
+    else lin_phase_c<1, STAMPS>(C, A, pc, s, slots, I, Gm, S.g[grp][1][lane], L);
     LIN_STAMP(5);
     if (role == 1) {
 #pragma unroll

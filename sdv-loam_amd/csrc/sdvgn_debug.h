@@ -1,0 +1,23 @@
+/* sdvgn_debug.h -- PRIVATE diagnostics entry points of libsdvgn.so (profiling experiments under tools/, never part of the drop-in
+ * boundary declared in include/sdvgn.h).  The symbols are exported so that the experiment scripts can reach them through ctypes. */
+#pragma once
+#include "../../include/sdvgn.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Diagnostics: k_ef_linearize `reps` times in different company (0 alone, 1 behind accumulate + reduce, 2 behind stitch + tail +
+ * resubstitute without a step, 3 behind a one-wave kernel that waits spin_us, 4 behind 1 and 2), for kernel traces */
+int sdvgn_debug_launch_pattern(sdvgn_ef* ef, int pattern, int reps, int spin_us);
+/* Diagnostics: k_ef_linearize alone, `reps` launches back to back on the library's stream (no statistics, no threshold select) */
+int sdvgn_debug_launch_linearize(sdvgn_ef* ef, int reps);
+/* Diagnostics (SDVGN_PROFILE=1 in the environment when the library is loaded): prints the accumulated host wall time per phase
+ * of the solve / optimize path to stderr, divided by `per`, and clears the counters.  Returns 1 if a report was printed, else 0. */
+int sdvgn_debug_phase_report(int per);
+/* SDVGN_DEBUG_FLAGS bit 6: wall_clock64() (100 MHz) stamps of the phases of the last device-side small solve; returns the word count (16) */
+int sdvgn_debug_solve_stamps(sdvgn_ef* ef, unsigned long long* out16);
+/* Diagnostics (SDVGN_DEBUG_FLAGS bit5 = 32 set when the handle is created): wall_clock64() stamps (10 ns) of k_ef_linearize's stages
+ * from the last launch, [workgroup][wave][8] 64-bit words (tools/exp_linearize_stages.py).  Returns the number of words copied, 0 if the diagnostics are off. */
+int sdvgn_debug_read_stamps(sdvgn_ef* ef, unsigned long long* out, int cap_words);
+#ifdef __cplusplus
+}
+#endif
