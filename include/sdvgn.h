@@ -324,6 +324,12 @@ int sdvgn_ef_solve_system(sdvgn_ef* ef, int iteration, double lambda, double* x_
  * pivoted LDL^T (LDLT.h: pivot = largest remaining |diagonal|; pseudo-inverse of D), which like the reference's
  * `HFinalScaled.ldlt().solve()` (EnergyFunctional.cpp:743) returns a finite x on such a system.  No failure path. */
 int sdvgn_ef_get_solve_status(sdvgn_ef* ef);
+/* Arithmetic of k_ef_linearize (PointFrameResidual::linearize, Residuals.cpp:60-224): 0 = the reference's float arithmetic operation by
+ * operation (default: IEEE divisions / square roots, no contraction; J, energies and residual states bit-identical with the CPU path),
+ * 1 = tolerance mode: fused multiply-adds and the hardware's 1-ulp reciprocal / square root (v_rcp_f32, v_sqrt_f32) for the 34 divisions and
+ * 18 square roots per residual.  BASELINE.json's contract for this path is 1e-4 relative on the increments; mode 1 keeps it, with residual
+ * states identical except at threshold ties (tests/test_backend_gpu.py).  Affects every later linearise of the handle. */
+int sdvgn_ef_set_arith(sdvgn_ef* ef, int mode);
 /* doStepFromBackup / backupState / loadSateBackup for the per-point idepths (FullSystemOptimize.cpp:165-321):
  * mode 0: backup = idepth; mode 1: idepth = idepth_zero = backup + stepfac*step; mode 2: idepth = idepth_zero = backup */
 int sdvgn_ef_point_step(sdvgn_ef* ef, int mode, float stepfacD);

@@ -52,6 +52,7 @@ PROTOTYPES = [
     ("sdvgn_ef_get_linearize_times", C.c_int, [vp, vp, C.c_int]),
     ("sdvgn_debug_launch_linearize", C.c_int, [vp, C.c_int]),
     ("sdvgn_ef_get_solve_status", C.c_int, [vp]),
+    ("sdvgn_ef_set_arith", C.c_int, [vp, C.c_int]),
     ("sdvgn_ef_frame_image_dev", vp, [vp, C.c_int]),
     ("sdvgn_rccl_unique_id", C.c_int, [vp]),
     ("sdvgn_ef_init_rccl", C.c_int, [vp, vp, C.c_int, C.c_int]),
@@ -171,6 +172,10 @@ class EnergyFunctional:
     def solve_status(self):
         """0: the last solve used the fast unpivoted LDL^T; 2: it fell back to the pivoted one (indefinite system)"""
         return self.L.sdvgn_ef_get_solve_status(self.h_)
+
+    def set_arith(self, mode):
+        """0: the reference's arithmetic in linearize (default, bit-exact); 1: tolerance mode (FMA, v_rcp / v_sqrt)"""
+        self._check(self.L.sdvgn_ef_set_arith(self.h_, int(mode)))
 
     def accumulate(self):
         self._check(self.L.sdvgn_ef_accumulate(self.h_))

@@ -156,6 +156,7 @@ struct sdvgn_ef {
     double* acc_dev = nullptr;    // packed: top [nF*nF][256] | sc [nF][2560] | resInA
     double* acc_host = nullptr;   // pinned; the reduce kernels write it DIRECTLY (zero-copy) when no all-reduce is installed
     double* stats_host = nullptr; // pinned, 4 doubles: same for k_ef_sum_stats
+    int arith = 0;                 // sdvgn_ef_set_arith: 0 = the reference's arithmetic in k_ef_linearize (default), 1 = tolerance mode (lin_fast)
     bool reuse_system = false;     // set by sdvgn_ef_optimize (flags bit2) for the solve that follows a rejected step: HA/bA/Hsc/bsc and
                                    // the per-point Schur terms on the device are those of the identical state one body earlier
     // second copies of the planes a trial step overwrites (point idepths, precalc table): the optimize loop writes the trial values
@@ -806,6 +807,7 @@ static int ef_launch_linearize(sdvgn_ef* e) {
     }
     if ((e->C.debug_flags & 32) && e->dbg_stamps) k_ef_linearize<true><<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->energy_partial);
     else if (lin_groups(e) == 1) k_ef_linearize<false, 1><<<dim3(chunks, pairs), 128, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->energy_partial);
+    else if (e->arith == 1) lin_fast::k_ef_linearize<false><<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->energy_partial);
     else k_ef_linearize<false><<<dim3(chunks, pairs), 256, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->energy_partial);
     if (ev1) hipEventRecord(ev1, e->stream);
     return chunks * pairs;
@@ -2164,6 +2166,11 @@ int sdvgn_debug_read_stamps(sdvgn_ef* e, unsigned long long* out, int cap_words)
 }
 
 int sdvgn_ef_get_solve_status(sdvgn_ef* e) { return e ? e->solve_status : SDVGN_E_ARG; }
+int sdvgn_ef_set_arith(sdvgn_ef* e, int mode) {
+    if (!e || mode < 0 || mode > 1) return SDVGN_E_ARG;
+    e->arith = mode;
+    return SDVGN_OK;
+}
 
 int sdvgn_debug_solve_stamps(sdvgn_ef* e, unsigned long long* out16) {
     if (!e || !out16 || !e->solve_stamps) return 0;

@@ -179,284 +179,30 @@ struct LinSmem {
     double s_e[2];
 };
 
-// STAMPS: diagnostics instantiation only (tools/exp_linearize_stages.py); the product instantiation carries none of it
-#define LIN_STAMP(k) do { if (STAMPS) { if ((threadIdx.x & 63) == 0) stamps[k] = wall_clock64(); } } while (0)
-
-// phase A: every per-slot / per-point input of this lane in one batch of independent loads (the dense table has storage behind every
-// slot, so the loads need no flag test), then the projections of this role's 4 pattern pixels; publishes where their taps are
-template <int ROLE, bool STAMPS>
-__device__ __forceinline__ void lin_phase_a(const EFConst& C, const EFArrays& A, const PrecalcDev& pc, int p, size_t s, bool active,
-                                            LinLane& L, LinIn& I, LinRec* __restrict__ rec /*[4] of this lane*/, unsigned long long* stamps) {
-    LIN_STAMP(0);
-    I.fl = A.rflags[s];
-    I.st = A.reset_oob ? (int)RS_IN : (int)A.rstate[s];
-    I.pu = A.pu[p]; I.pv = A.pv[p]; I.idz = A.pidz[p]; I.ids = A.pid[p];
-    I.c4 = A.pcolor[2 * p + ROLE];
-    I.w4 = A.pweights[2 * p + ROLE];
-    I.m = A.rmatcher[s];
-    L.e_prev = (ROLE == 0 && !A.reset_oob) ? A.renergy[s] : 0.0f;
-    __builtin_amdgcn_sched_barrier(0);
-    if (STAMPS) { const float dep = I.pu + (float)I.fl + I.m.x + I.c4.x + I.w4.x + I.ids; if (dep == 1.2345e30f) stamps[7] = 1; }   // the stamp below waits for the loads
-    LIN_STAMP(1);
-    L.fl = I.fl;
-    L.todo = active && (I.fl & RF_EXISTS) && !(I.fl & RF_LINEARIZED);
-    L.oob = (I.st == RS_OOB) || !(I.fl & RF_MATCHER);
-    // settings.cpp:250 pattern 8, this role's half
-    const int pat[4][2] = {{ROLE ? 0 : 0, ROLE ? 0 : -2}, {ROLE ? 2 : -1, ROLE ? 0 : -1}, {ROLE ? -1 : 1, ROLE ? 1 : -1}, {ROLE ? 0 : -2, ROLE ? 2 : 0}};
-    const bool gather = L.todo && !L.oob;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float up = I.pu + pat[k][0], vp = I.pv + pat[k][1];
-        const float r0 = ((pc.KRKi[0] * up + pc.KRKi[1] * vp) + pc.KRKi[2] * 1.0f) + pc.Kt[0] * I.ids;
-        const float r1 = ((pc.KRKi[3] * up + pc.KRKi[4] * vp) + pc.KRKi[5] * 1.0f) + pc.Kt[1] * I.ids;
-        const float r2 = ((pc.KRKi[6] * up + pc.KRKi[7] * vp) + pc.KRKi[8] * 1.0f) + pc.Kt[2] * I.ids;
-        const float Ku2 = r0 / r2, Kv2 = r1 / r2;
-        I.inb[k] = (Ku2 > 1.1f && Kv2 > 1.1f && Ku2 < C.wM3G && Kv2 < C.hM3G);
-        const bool ld = gather && I.inb[k];
-        const float x = ld ? Ku2 : 2.0f, y = ld ? Kv2 : 2.0f;      // (pixels that are not gathered point at a valid dummy position)
-        const int ix = (int)x, iy = (int)y;
-        LinRec r;
-        r.off = (unsigned)(3 * (ix + iy * C.w)); r.fx = x - ix; r.fy = y - iy;
-        rec[k] = r;
-    }
-    LIN_STAMP(2);
-}
-
-// centre projection (both roles) and this role's row of the geometric Jacobian (Residuals.cpp:93-155); runs while the taps fly
-template <int ROLE>
-__device__ __forceinline__ void lin_geometry(const EFConst& C, const PrecalcDev& pc, const LinIn& I, LinLane& L, LinGeo& Gm) {
-    bool oob = L.oob;
-    float Ku = 0, Kv = 0, u = 0, v = 0, drescale = 0, new_idepth = 0, KliP0 = 0, KliP1 = 0;
-    if (!oob) {
-        KliP0 = (I.pu + 0 - C.cxl) * C.fxli;
-        KliP1 = (I.pv + 0 - C.cyl) * C.fyli;
-        const float q0 = ((pc.R0[0] * KliP0 + pc.R0[1] * KliP1) + pc.R0[2] * 1.0f) + pc.t0[0] * I.idz;
-        const float q1 = ((pc.R0[3] * KliP0 + pc.R0[4] * KliP1) + pc.R0[5] * 1.0f) + pc.t0[1] * I.idz;
-        const float q2 = ((pc.R0[6] * KliP0 + pc.R0[7] * KliP1) + pc.R0[8] * 1.0f) + pc.t0[2] * I.idz;
-        drescale = 1.0f / q2;
-        new_idepth = I.idz * drescale;
-        if (!(drescale > 0)) oob = true;
-        else {
-            u = q0 * drescale; v = q1 * drescale;
-            Ku = u * C.fxl + C.cxl; Kv = v * C.fyl + C.cyl;
-            oob = !(Ku > 1.1f && Kv > 1.1f && Ku < C.wM3G && Kv < C.hM3G);
-        }
-    }
-    L.oob = oob;
-    float* Jr = Gm.Jr; float* Cr = Gm.Cr;
-    if (ROLE == 0) {
-        Gm.dd = drescale * (pc.t0[0] - pc.t0[2] * u) * SDVGN_SCALE_IDEPTH * C.fxl;
-        Cr[2] = drescale * (pc.R0[6] * u - pc.R0[0]);
-        Cr[3] = C.fxl * drescale * (pc.R0[7] * u - pc.R0[1]) * C.fyli;
-        Cr[0] = KliP0 * Cr[2];
-        Cr[1] = KliP1 * Cr[3];
-        Cr[0] = (Cr[0] + u) * SDVGN_SCALE_F;
-        Cr[1] *= SDVGN_SCALE_F;
-        Cr[2] = (Cr[2] + 1) * SDVGN_SCALE_C;
-        Cr[3] *= SDVGN_SCALE_C;
-        Jr[0] = new_idepth * C.fxl; Jr[1] = 0; Jr[2] = -new_idepth * u * C.fxl;
-        Jr[3] = -u * v * C.fxl; Jr[4] = (1 + u * u) * C.fxl; Jr[5] = -v * C.fxl;
-    } else {
-        Gm.dd = drescale * (pc.t0[1] - pc.t0[2] * v) * SDVGN_SCALE_IDEPTH * C.fyl;
-        Cr[2] = C.fyl * drescale * (pc.R0[6] * v - pc.R0[3]) * C.fxli;
-        Cr[3] = drescale * (pc.R0[7] * v - pc.R0[4]);
-        Cr[0] = KliP0 * Cr[2];
-        Cr[1] = KliP1 * Cr[3];
-        Cr[0] *= SDVGN_SCALE_F;
-        Cr[1] = (Cr[1] + v) * SDVGN_SCALE_F;
-        Cr[2] *= SDVGN_SCALE_C;
-        Cr[3] = (Cr[3] + 1) * SDVGN_SCALE_C;
-        Jr[0] = 0; Jr[1] = new_idepth * C.fyl; Jr[2] = -new_idepth * v * C.fyl;
-        Jr[3] = -(1 + v * v) * C.fyl; Jr[4] = u * v * C.fyl; Jr[5] = u * C.fyl;
-    }
-    Gm.res0 = Ku - I.m.x; Gm.res1 = Kv - I.m.y;
-    const float nrm = sqrtf(Gm.res0 * Gm.res0 + Gm.res1 * Gm.res1);
-    float hwm = fabsf(nrm) < C.huberTH ? 1.0f : C.huberTH / fabsf(nrm);
-    L.energyLeft = hwm * (Gm.res0 * Gm.res0 + Gm.res1 * Gm.res1) * (2 - hwm);
-    if (hwm < 1) hwm = sqrtf(hwm);
-    Gm.hwm = hwm;
-}
-
-// phase C: per-pixel terms of the reference's pattern loop (:157-194) from the interpolated {I,dx,dy}; summed later in pixel order by
-// role 0.  Then this role's row of the new Jacobian goes to the buffer the EnergyFunctional side does NOT own.
-template <int ROLE, bool DBG = false>
-__device__ __forceinline__ void lin_phase_c(const EFConst& C, const EFArrays& A, const PrecalcDev& pc, size_t s, size_t slots, const LinIn& I,
-                                            const LinGeo& Gm, const float (*g)[3] /*[4][3] of this lane*/, LinLane& L) {
-    const float col[4] = {I.c4.x, I.c4.y, I.c4.z, I.c4.w};
-    const float wts[4] = {I.w4.x, I.w4.y, I.w4.z, I.w4.w};
-    L.ok = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float g0 = g[k][0];
-        float h1 = g[k][1], h2 = g[k][2];
-        const float residual = g0 - (float)(pc.aff0 * col[k] + pc.aff1);
-        float w = sqrtf(C.outlierTHSumComponent / (C.outlierTHSumComponent + (h1 * h1 + h2 * h2)));
-        w = 0.5f * (w + wts[k]);
-        float hw = fabsf(residual) < C.huberTH ? 1.0f : C.huberTH / fabsf(residual);
-        L.e[k] = w * w * hw * residual * residual * (2 - hw);
-        if (hw < 1) hw = sqrtf(hw);
-        hw = hw * w;
-        h1 *= hw; h2 *= hw;
-        L.wj[k] = hw * hw * (h1 * h1 + h2 * h2);
-        if (I.inb[k] && isfinite(g0)) L.ok |= 1u << k;
-    }
-    L.wrote = L.todo && !L.oob;
-    if (L.wrote && (!DBG || !(C.debug_flags & 2) || Gm.hwm != Gm.hwm)) {   // (experiment switches exist in the diagnostic instantiation only)
-        const int buf = (I.fl & RF_SEL) ? 0 : 1;
-        float* Jn = A.J + (size_t)buf * kJPlanes * slots + s;
-        Jn[(0 + ROLE) * slots] = (ROLE == 0 ? Gm.res0 : Gm.res1) * Gm.hwm;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) Jn[(2 + 6 * ROLE + i) * slots] = Gm.Jr[i] * Gm.hwm;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Jn[(14 + 4 * ROLE + i) * slots] = Gm.Cr[i] * Gm.hwm;
-        Jn[(22 + ROLE) * slots] = Gm.dd * Gm.hwm;
-    }
-}
-
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned lin_u32x2 __attribute__((ext_vector_type(2)));
-template <bool STAMPS, int GROUPS = 2>
-// (`precalc` leads the argument block: with the first 16 dwords preloaded into SGPRs -- csrc/Makefile -- the table load that heads the
-// workgroup's dependency chain goes out with the first instruction instead of behind a scalar load of its own pointer)
-__global__ void __launch_bounds__(128 * GROUPS) k_ef_linearize(const PrecalcDev* __restrict__ precalc, EFConst Cin, EFArrays A,
-                                                               double* __restrict__ energy_partial) {
-    const EFConst C = ef_const(Cin, A);
-    __shared__ LinSmem S;
-    int pair = blockIdx.y, chunk = blockIdx.x;
-    const int n_wg = gridDim.x * gridDim.y;
-    if ((n_wg & 7) == 0 && !(STAMPS && (C.debug_flags & 4))) {
-        // XCD-aware mapping: workgroups go round-robin to the 8 XCDs by linear id, so id % 8 is the XCD.  The work items are ordered
-        // TARGET-major (target, host, chunk) and XCD x takes the x-th eighth of that order: with 8 key-frames XCD x linearises every
-        // residual whose target is frame x, with 5-7 key-frames an XCD sees at most two targets -- its 4 MB L2 then gathers from one or
-        // two 5.6 MB images instead of all of them (measured at nF = 8: -17 % kernel time, HBM-side fetch 88 -> 43 MB per launch;
-        // profiles/r01_linearize_experiments.txt).
-        const int id = blockIdx.x + gridDim.x * blockIdx.y;
-        const int item = (id & 7) * (n_wg >> 3) + (id >> 3);
-        const int tt = item / (C.nF * (int)gridDim.x), rest = item - tt * C.nF * (int)gridDim.x;
-        pair = (rest / (int)gridDim.x) * C.nF + tt; chunk = rest % (int)gridDim.x;
-    }
-    const int h = pair / C.nF, t = pair % C.nF;
-    const PrecalcDev pc = precalc[pair];
-    if (h == t || chunk * (64 * GROUPS) >= pc.np) {     // nothing to linearise in this workgroup (uniform: before any barrier)
-        if (threadIdx.x == 0) energy_partial[(size_t)pair * gridDim.x + chunk] = 0.0;
-        return;
-    }
-    const float thH = A.frameTH_r[h], thT = A.frameTH_r[t];
-    const float frameTH = thH < thT ? thT : thH;   // std::max<float>(host->frameEnergyTH, target->frameEnergyTH), Residuals.cpp:212
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int role = wave & 1, grp = wave >> 1;
-    const int pl = chunk * (64 * GROUPS) + grp * 64 + lane;
-    const bool active = pl < pc.np;
-    const int p = pc.P0 + (active ? pl : 0);
-    const size_t slots = (size_t)C.nF * C.nP;
-    const size_t s = (size_t)t * C.nP + p;
-    LinLane L;
-    L.todo = false; L.oob = true; L.wrote = false; L.ok = 0; L.energyLeft = 0; L.e_prev = 0; L.fl = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { L.e[k] = 0; L.wj[k] = 0; }
-    unsigned long long* stamps = nullptr;
-    if (STAMPS) stamps = A.dbg_stamps + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
-    LinIn I;
-    LinGeo Gm;
-    // ---- phase A: inputs, pattern projections, publish the tap positions -------------------------------------------------------
-    if (role == 0) lin_phase_a<0, STAMPS>(C, A, pc, p, s, active, L, I, S.q[grp][0][lane], stamps);
-    else lin_phase_a<1, STAMPS>(C, A, pc, p, s, active, L, I, S.q[grp][1][lane], stamps);
-    __syncthreads();
-    // ---- cooperative gather: 16 neighbouring lanes per residual, 8 rounds --------------------------------------------------------
-    {
-        const float* __restrict__ img = A.images + (size_t)t * C.w * C.h * 3;      // wave-uniform (blockIdx-derived)
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, C.w * C.h * 12, 0x00020000);
-        const int s16 = lane & 15, orole = s16 >> 3, k = (s16 >> 1) & 3, row = s16 & 1;
-        const int rbase = 32 * role + (lane >> 4);
-        LinRec rc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rc[j] = S.q[grp][orole][rbase + 4 * j][k];
-        u32x4 ta[8]; lin_u32x2 tb[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int voff = 4 * (int)(rc[j].off + (unsigned)(row * 3 * C.w));
-            ta[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);          // {I,dx,dy}(x) | I(x+1)
-            tb[j] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff + 16, 0, 0);      // dx,dy (x+1)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        LIN_STAMP(7);   // all 16 tap loads have been issued
-        // centre projection + this role's Jacobian row while the taps fly
-        if (role == 0) lin_geometry<0>(C, pc, I, L, Gm); else lin_geometry<1>(C, pc, I, L, Gm);
-        __builtin_amdgcn_sched_barrier(0);
-        LIN_STAMP(3);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float dx = rc[j].fx, dy = rc[j].fy, dxdy = dx * dy;
-            const float wl = row ? (dy - dxdy) : (1 - dx - dy + dxdy);     // weight of this row's left tap:  w01 | w00
-            const float wr = row ? dxdy : (dx - dxdy);                      // weight of this row's right tap: w11 | w10
-            const float a0 = __uint_as_float(ta[j][0]), a1 = __uint_as_float(ta[j][1]), a2 = __uint_as_float(ta[j][2]);
-            const float b0 = __uint_as_float(ta[j][3]), b1 = __uint_as_float(tb[j][0]), b2 = __uint_as_float(tb[j][1]);
-            // row 1: w11 * right + w01 * left ; handed to the row-0 lane (the even neighbour) ...
-            const float p0 = wr * b0 + wl * a0, p1 = wr * b1 + wl * a1, p2 = wr * b2 + wl * a2;
-            const float q0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(p0), 0xF5, 0xF, 0xF, false));   // quad_perm [1,1,3,3]
-            const float q1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(p1), 0xF5, 0xF, 0xF, false));
-            const float q2 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(p2), 0xF5, 0xF, 0xF, false));
-            // ... which adds w10 * right and then w00 * left: ((w11 d + w01 c) + w10 b) + w00 a
-            if (!row) {
-                float* gp = S.g[grp][orole][rbase + 4 * j][k];
-                gp[0] = (q0 + wr * b0) + wl * a0;
-                gp[1] = (q1 + wr * b1) + wl * a1;
-                gp[2] = (q2 + wr * b2) + wl * a2;
-            }
-        }
-        LIN_STAMP(4);
-    }
-    __syncthreads();
-    // ---- phase C: pixel terms, Jacobian stores -------------------------------------------------------------------------------------------
-    if (role == 0) lin_phase_c<0, STAMPS>(C, A, pc, s, slots, I, Gm, S.g[grp][0][lane], L);
-    else lin_phase_c<1, STAMPS>(C, A, pc, s, slots, I, Gm, S.g[grp][1][lane], L);
-    LIN_STAMP(5);
-    if (role == 1) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { S.xch[grp][k][lane] = L.e[k]; S.xch[grp][4 + k][lane] = L.wj[k]; }
-        S.xch[grp][8][lane] = __uint_as_float(L.ok);
-    }
-    __syncthreads();
-    double my_e = 0.0;
-    if (role == 0 && L.todo) {
-        A.renergy_wo[s] = -1.0f;
-        if (L.oob) {
-            A.rstate_new[s] = RS_OOB;
-            A.renergy_new[s] = A.reset_oob ? 0.0f : A.renergy_new_prev[s];   // state_NewEnergy is left untouched by the reference's early return (:118-119)
-            my_e = (double)L.e_prev;   // `return state_energy`
-        } else {
-            // the reference's sequential loop over the 8 pattern pixels, `break` at the first failing one (:160-176)
-            float e8[8], wj8[8];
-            unsigned ok8 = L.ok | (__float_as_uint(S.xch[grp][8][lane]) << 4);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { e8[k] = L.e[k]; wj8[k] = L.wj[k]; e8[4 + k] = S.xch[grp][k][lane]; wj8[4 + k] = S.xch[grp][4 + k][lane]; }
-            float wJI2_sum = 0, energyLeft2 = 0;
-            bool alive = true;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (alive) {
-                    if (!((ok8 >> k) & 1)) alive = false;
-                    else { energyLeft2 += e8[k]; wJI2_sum += wj8[k]; }
-                }
-            }
-            A.renergy_wo[s] = energyLeft2;
-            const bool wjlow = wJI2_sum < 2;
-            if (energyLeft2 > frameTH || wjlow) { energyLeft2 = frameTH; A.rstate_new[s] = (int8_t)(RS_OUTLIER | (wjlow ? RS_WJLOW : 0)); }
-            else A.rstate_new[s] = RS_IN;
-            A.renergy_new[s] = energyLeft2;
-            my_e = (double)L.energyLeft;
-        }
-    }
-    if (role == 0) {
-        const double ws = wave_sum_double(my_e);
-        if (lane == 63) S.s_e[grp] = ws;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) energy_partial[(size_t)pair * gridDim.x + chunk] = GROUPS == 2 ? S.s_e[0] + S.s_e[1] : S.s_e[0];
-    if (STAMPS) __builtin_amdgcn_s_waitcnt(0);   // all of this wave's stores have been acknowledged
-    LIN_STAMP(6);
-}
+// ---- the kernel and its phases live in backend_linearize.inc, instantiated twice (see its header) ---------------------------------------
+#define LIN_NS lin_exact
+#define LIN_DIV(a, b) ((a) / (b))
+#define LIN_SQRT(x) sqrtf(x)
+#define LIN_FP_CONTRACT
+#include "backend_linearize.inc"
+#undef LIN_NS
+#undef LIN_DIV
+#undef LIN_SQRT
+#undef LIN_FP_CONTRACT
+#undef LIN_STAMP
+#define LIN_NS lin_fast
+#define LIN_DIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
+#define LIN_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#define LIN_FP_CONTRACT _Pragma("clang fp contract(fast)")
+#include "backend_linearize.inc"
+#undef LIN_NS
+#undef LIN_DIV
+#undef LIN_SQRT
+#undef LIN_FP_CONTRACT
+#undef LIN_STAMP
+using lin_exact::k_ef_linearize;   // the name every other launch site uses
 
 // ------------------------------------------------------------------------------------------------------------
 // SURVEY 8f-4 (part 2): FullSystem::optimizeImmaturePoint (FullSystemOptPoint.cpp:18-185) with

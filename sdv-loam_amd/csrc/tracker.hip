@@ -81,7 +81,7 @@ struct sdvgn_tracker {
     TeamMem* team_dev = nullptr;         // k_track_team: partial rows + counters per hypothesis (allocated on first use, zeroed)
     int team_cap = 0;
     int cu_count = 0;                    // multiProcessorCount of the device (queried once)
-    int team_capacity = 0;               // workgroups of k_track_team this handle lets one launch occupy (occupancy x CUs x 3/4)
+    int team_capacity = 0;               // workgroups of k_track_team the device holds at once (occupancy query x CUs)
     int team_fallbacks = 0;              // batches re-run on k_track because a team's members did not meet
     int team_mode = 0;                   // sdvgn_tracker_set_team: 0 automatic, -1 always k_track (one workgroup), T >= 1 fixed team size
     int last_team = 0;                   // team size of the last track_batch call (0: k_track)
@@ -596,9 +596,10 @@ int sdvgn_tracker_track_batch(sdvgn_tracker* t, int B, double* pose7_io, double*
             t->cu_count = (hipGetDeviceProperties(&prop, t->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 1;
             int per_cu = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_track_team, kTeamThreads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-            t->team_capacity = (3 * per_cu * t->cu_count) / 4;
+            t->team_capacity = per_cu * t->cu_count;
         }
-        const int capacity = t->team_capacity;
+        // (an explicit team size -- sdvgn_tracker_set_team(1..32), tests -- may use the whole resident capacity; the automatic choice leaves a quarter)
+        const int capacity = t->team_mode > 0 ? t->team_capacity : (3 * t->team_capacity) / 4;
         if (want > capacity / Bpad) want = capacity / Bpad;
         if (Bpad > 512) want = 0;      // the exchange rows are allocated for at most 512 hypotheses
         // a fixed request of 1 runs the team kernel with a single member (tests); automatic mode needs at least two
