@@ -257,6 +257,8 @@ def trace_child():
     from sdv_loam_amd import backend_api, synthetic as syn
     Wh = syn.make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=syn.KITTI00, **HEAD_KW)
     rs = [backend_api.EnergyFunctional(Wh.w, Wh.h, max_points=Wh.nP).load(Wh) for _ in range(8)]
+    for r in rs:
+        r.set_arith(int(os.environ.get("SDVGN_BENCH_ARITH", "0")))
     rs[0].optimize(6, fixed_its=True, want_trace=False)
     rs[0].load(Wh)
     for r in rs:
@@ -264,7 +266,7 @@ def trace_child():
     torch.cuda.synchronize()
 
 
-def measure_inloop_kernel(kernel="k_ef_linearize", timeout=240):
+def measure_inloop_kernel(kernel="k_ef_linearize", timeout=240, arith=0):
     """Duration of every launch of `kernel` inside the optimize loops of the headline protocol, from a rocprofv3 --kernel-trace of a child
     process that runs nothing but that protocol (HIP event pairs around single launches inside a loop read several us too long)."""
     import shutil
@@ -277,7 +279,8 @@ def measure_inloop_kernel(kernel="k_ef_linearize", timeout=240):
     d = tempfile.mkdtemp(prefix="sdvgn_trace_", dir="/tmp")
     try:
         subprocess.run([exe, "--kernel-trace", "-d", d, "-o", "tr", "--", sys.executable, os.path.abspath(__file__), "--trace-child"],
-                       cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+                       cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", SDVGN_BENCH_ARITH=str(arith)), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       timeout=timeout, check=True)
         dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
         con = sqlite3.connect(dbs[0])
         du = np.array([r[0] for r in con.execute("select duration from kernels where name like ?", ("%" + kernel + "%",))], np.float64) / 1e6
@@ -735,6 +738,18 @@ def main():
         del reps
 
     value_relin = value_reuse = soak = other = lin_inloop = None
+    tol = None
+    if single:
+        # ---- the same protocol in tolerance-mode arithmetic of k_ef_linearize (sdvgn_ef_set_arith(1): FMA, v_rcp_f32 / v_sqrt_f32; increments
+        # within the contract's 1e-4, tests/test_backend_gpu.py::test_arith_mode_tolerance) ----
+        for r in runners:
+            r.set_arith(1)
+        warm_runner.set_arith(1)
+        dt_t, _ = run_protocol(runners, bodies, world, warm=(warm_runner, Wm), reload_with=Wh, want_trace=False)
+        tol = dict(value=K / dt_t, ms_per_step=1e3 * dt_t / K)
+        for r in runners:
+            r.set_arith(0)
+        warm_runner.set_arith(0)
     if single:
         # ---- the same protocol with the reference's literal re-linearisation after every rejected step (A/B; results identical) ----
         dt_l, _ = run_protocol(runners, bodies, world, warm=(warm_runner, Wm), reload_with=Wh, want_trace=False, relinearize_on_reject=True)
@@ -816,6 +831,16 @@ def main():
                      "stream: %.4f ms; a HIP event pair around every single in-loop launch reads several us too long (in_loop_event_pairs: "
                      "the pair adds %.4f ms even back to back) and is reported for completeness only" % (
                          W.nR, LINEARIZE_BYTES_PER_RES, alg / 1e6, ms_lin, how, ms_lin_b2b, ev_overhead))
+    if tol is not None:
+        G.set_arith(1)
+        G.launch_linearize_only(3)
+        tol_b2b = event_avg_ms(torch, ext, lambda: G.launch_linearize_only(1), 50)
+        G.set_arith(0)
+        tr_t = measure_inloop_kernel(arith=1) if (rank == 0 and world == 1 and not args.quick) else None
+        ms_t = tr_t["mean_ms"] if (tr_t and "mean_ms" in tr_t) else tol_b2b
+        tol["roofline"] = dict(bound="hbm", kernel="k_ef_linearize (lin_fast)", achieved=alg / (ms_t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                               frac=alg / (ms_t * 1e-3) / 1e9 / HBM_PEAK_GBS, in_loop_trace=tr_t, back_to_back_ms=tol_b2b)
+        tol["note"] = "sdvgn_ef_set_arith(1) on every window: k_ef_linearize with fused multiply-adds and 1-ulp v_rcp_f32 / v_sqrt_f32 instead of IEEE division / sqrt sequences; same protocol, same windows"
     ms_acc = event_ms(torch, ext, lambda: G.accumulate(), 50)
     # what a plain streaming copy reaches on this box (1 GiB read + 1 GiB written), for reading `frac` against the achievable rate
     try:
@@ -847,6 +872,7 @@ def main():
         "accepted_fraction": accepted_fraction,
         "iteration_us": iter_stats,
         "kernel_ms": {"k_ef_linearize_back_to_back": ms_lin_b2b, "accumulate(fused point+top+sc, reduce)": ms_acc},
+        "tolerance_arith": tol,
         "value_with_literal_relinearize_on_reject": value_relin,
         "value_with_system_reuse_after_rejected_steps": value_reuse,
         "one_window_soak": soak,

@@ -532,7 +532,8 @@ def test_arith_mode_tolerance(api, orc):
     same = ~differ & (se["new_state"] != 1)
     assert not np.array_equal(Je[same], Jf[same])                                 # (it IS different arithmetic)
     assert np.abs(Je[same] - Jf[same]).max() <= 2e-5 * np.abs(Je[same]).max()
-    assert np.allclose(se["energy_with_outlier"][same], sf["energy_with_outlier"][same], rtol=2e-5, atol=1e-5)
+    # photometric energies: a last-place change of an interpolated intensity (~150) against residuals of a few grey levels
+    assert np.allclose(se["energy_with_outlier"][same], sf["energy_with_outlier"][same], rtol=3e-4, atol=1e-3)
     assert rel_err(ef, ee) < 1e-6
     O = __import__("oracle.backend", fromlist=["OracleEF"]).OracleEF(W.w, W.h).load(W)
     Ge.load(W); Gf.load(W)
