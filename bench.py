@@ -738,7 +738,32 @@ def main():
         del reps
 
     value_relin = value_reuse = soak = other = lin_inloop = None
-    tol = None
+    tol = batched = None
+    if single and not args.quick:
+        # ---- B independent windows side by side (sdvgn_ef_optimize_batch: own stream + host thread per window): aggregate loop bodies / s.
+        # B x 80 MB of window data is live at once (B = 16: 1.3 GB, beyond the 256 MB Infinity Cache) ----
+        batched = {}
+        for Bw in (2, 4, 8, 16):
+            try:
+                hs = [backend_api.EnergyFunctional(Wh.w, Wh.h, max_points=Wh.nP, device=local, stream=backend_api.EnergyFunctional.STREAM_OWN).load(Wh)
+                      for _ in range(Bw)]
+                backend_api.optimize_batch(hs, 6, fixed_its=True)              # warm-up (queues, thread pool)
+                reps = 6
+                tt = 0.0
+                for _ in range(reps):
+                    for h_ in hs:
+                        h_.load(Wh)
+                    torch.cuda.synchronize()
+                    t0b = time.perf_counter()
+                    backend_api.optimize_batch(hs, 6, fixed_its=True)
+                    torch.cuda.synchronize()
+                    tt += time.perf_counter() - t0b
+                batched["B%d" % Bw] = dict(value=6 * Bw * reps / tt, unit="GN iters/s (aggregate)", ms_per_batch_call=1e3 * tt / reps)
+                del hs
+            except Exception as ex:  # noqa: BLE001
+                batched["B%d" % Bw] = dict(error=repr(ex))
+        batched["note"] = ("B fresh perturbed windows per call, optimize(6) each, all B calls issued together through sdvgn_ef_optimize_batch; "
+                           "compare with the headline value (the same calls one after the other)")
     if single:
         # ---- the same protocol in tolerance-mode arithmetic of k_ef_linearize (sdvgn_ef_set_arith(1): FMA, v_rcp_f32 / v_sqrt_f32; increments
         # within the contract's 1e-4, tests/test_backend_gpu.py::test_arith_mode_tolerance) ----
@@ -873,6 +898,7 @@ def main():
         "iteration_us": iter_stats,
         "kernel_ms": {"k_ef_linearize_back_to_back": ms_lin_b2b, "accumulate(fused point+top+sc, reduce)": ms_acc},
         "tolerance_arith": tol,
+        "batched_windows_side_by_side": batched,
         "value_with_literal_relinearize_on_reject": value_relin,
         "value_with_system_reuse_after_rejected_steps": value_reuse,
         "one_window_soak": soak,

@@ -251,8 +251,10 @@ typedef struct sdvgn_ef sdvgn_ef;
 
 #define SDVGN_MAX_FRAMES 8 /* setting_maxFrames = 7 in the reference (src/util/settings.cpp:46-47) */
 
-/* EnergyFunctional::EnergyFunctional + the level-0 images of the window.  w,h = wG[0],hG[0].  `stream`: hipStream_t or NULL (the library's
- * shared window stream of that device). */
+/* EnergyFunctional::EnergyFunctional + the level-0 images of the window.  w,h = wG[0],hG[0].  `stream`: a hipStream_t, NULL (the library's
+ * shared window stream of that device) or SDVGN_STREAM_OWN (a stream of the handle's own: windows that are optimised side by side,
+ * sdvgn_ef_optimize_batch). */
+#define SDVGN_STREAM_OWN ((void*)1)
 int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, void* stream);
 void sdvgn_ef_destroy(sdvgn_ef* ef);
 void* sdvgn_ef_stream(sdvgn_ef* ef);
@@ -324,6 +326,12 @@ int sdvgn_ef_solve_system(sdvgn_ef* ef, int iteration, double lambda, double* x_
  * pivoted LDL^T (LDLT.h: pivot = largest remaining |diagonal|; pseudo-inverse of D), which like the reference's
  * `HFinalScaled.ldlt().solve()` (EnergyFunctional.cpp:743) returns a finite x on such a system.  No failure path. */
 int sdvgn_ef_get_solve_status(sdvgn_ef* ef);
+/* FullSystem::optimize (sdvgn_ef_optimize, no trace) on B INDEPENDENT windows side by side -- several maps / agents / sub-maps on one GPU.
+ * One loop body of one window is a chain of six short launches that occupies a fraction of the chip for ~75 us; the chains of different
+ * windows overlap on the device when every handle has its own stream (create with SDVGN_STREAM_OWN), one host thread of a library-owned
+ * pool driving each.  its_out[b] (may be NULL) = return value of window b's sdvgn_ef_optimize.  Returns SDVGN_OK or the error of a window.
+ * Results of every window are those of its own sdvgn_ef_optimize call, bit for bit. */
+int sdvgn_ef_optimize_batch(sdvgn_ef* const* handles, int B, int mnumOptIts, int flags, int* its_out);
 /* Arithmetic of k_ef_linearize (PointFrameResidual::linearize, Residuals.cpp:60-224): 0 = the reference's float arithmetic operation by
  * operation (default: IEEE divisions / square roots, no contraction; J, energies and residual states bit-identical with the CPU path),
  * 1 = tolerance mode: fused multiply-adds and the hardware's 1-ulp reciprocal / square root (v_rcp_f32, v_sqrt_f32) for the 34 divisions and

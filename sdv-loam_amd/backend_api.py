@@ -53,6 +53,7 @@ PROTOTYPES = [
     ("sdvgn_debug_launch_linearize", C.c_int, [vp, C.c_int]),
     ("sdvgn_ef_get_solve_status", C.c_int, [vp]),
     ("sdvgn_ef_set_arith", C.c_int, [vp, C.c_int]),
+    ("sdvgn_ef_optimize_batch", C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
     ("sdvgn_ef_frame_image_dev", vp, [vp, C.c_int]),
     ("sdvgn_rccl_unique_id", C.c_int, [vp]),
     ("sdvgn_ef_init_rccl", C.c_int, [vp, vp, C.c_int, C.c_int]),
@@ -75,6 +76,8 @@ PROTOTYPES = [
 class EnergyFunctional:
     """Flattened EnergyFunctional window on the GPU; method names follow the reference
     (EnergyFunctional.h:51-72, FullSystemOptimize.cpp:99-159, 504-520)."""
+
+    STREAM_OWN = 1      # SDVGN_STREAM_OWN: a HIP stream of the handle's own (windows optimised side by side, optimize_batch)
 
     def __init__(self, w, h, max_points, device=0, stream=None):
         from .api import check, load_library
@@ -333,3 +336,14 @@ class EnergyFunctional:
         idp = np.zeros(self.nP, np.float32)
         self._check(self.L.sdvgn_ef_get_state(self.h_, vs.ctypes.data_as(vp), st.ctypes.data_as(vp), idp.ctypes.data_as(vp)))
         return vs, st.reshape(self.nF, 10), idp
+
+
+def optimize_batch(windows, its=6, fixed_its=False):
+    """sdvgn_ef_optimize_batch: FullSystem::optimize on independent windows side by side (handles created with stream=EnergyFunctional.STREAM_OWN
+    overlap on the device).  Returns the loop bodies every window ran."""
+    from .api import check
+    B = len(windows)
+    arr = (vp * B)(*[w.h_ for w in windows])
+    out = (C.c_int * B)()
+    check(windows[0].L.sdvgn_ef_optimize_batch(C.cast(arr, vp), B, int(its), 1 if fixed_its else 0, C.cast(out, vp)))
+    return list(out)

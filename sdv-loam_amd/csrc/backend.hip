@@ -19,6 +19,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -911,7 +913,10 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     sdvgn_ef* e = new (std::nothrow) sdvgn_ef();
     if (!e) return SDVGN_E_ARG;
     e->device = device; e->w = w; e->h = h; e->max_points = max_points;
-    if (stream) e->stream = (hipStream_t)stream;
+    if (stream == SDVGN_STREAM_OWN) {   // a stream (hardware queue) of this handle's own: windows optimised side by side, sdvgn_ef_optimize_batch
+        HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->own_stream = true;
+    } else if (stream) e->stream = (hipStream_t)stream;
     else {
         // Windows without a caller's stream share ONE library stream per device.  A stream of its own per window handle means a
         // hardware queue per handle, and a queue that has been idle for a while is re-activated by the first launch that lands on it:
@@ -1978,6 +1983,75 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
 // linearisation point, state = zero except the affine part), setAdjointsF, setPrecalcValues, linearizeAll(true) = linearize +
 // applyRes(true) per active residual + the isNew bookkeeping of the points (:34-47) + setNewFrameEnergyTH + the toRemove list
 // (:136-155: every residual that is not active afterwards is dropped; its slot ceases to exist here as well).
+// B independent windows optimised side by side: one host thread per handle, every handle on its own HIP stream, so that the launch chains
+// of different windows -- each a sequence of short, latency-bound kernels that fill a fraction of the chip -- overlap on the device.
+// The threads are kept (a pool grown on demand): a call costs two condition-variable hand-offs per extra window.
+namespace {
+struct BatchPool {
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::vector<std::thread> workers;
+    struct Job { sdvgn_ef* e; int its, flags, rc; };
+    std::vector<Job> jobs;
+    size_t next = 0, done = 0;
+    unsigned long long epoch = 0;
+    bool quit = false;
+    void worker() {
+        unsigned long long seen = 0;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_go.wait(lk, [&] { return quit || (epoch != seen && next < jobs.size()) ; });
+            if (quit) return;
+            while (next < jobs.size()) {
+                const size_t k = next++;
+                Job j = jobs[k];
+                lk.unlock();
+                const int rc = sdvgn_ef_optimize(j.e, j.its, j.flags, nullptr, 0, 0);
+                lk.lock();
+                jobs[k].rc = rc;
+                if (++done == jobs.size()) cv_done.notify_all();
+            }
+            seen = epoch;
+        }
+    }
+    ~BatchPool() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv_go.notify_all();
+        for (std::thread& t : workers) t.join();
+    }
+};
+BatchPool& batch_pool() { static BatchPool* p = new BatchPool(); return *p; }   // (leaked on purpose: no join at library unload)
+}  // namespace
+
+int sdvgn_ef_optimize_batch(sdvgn_ef* const* handles, int B, int mnumOptIts, int flags, int* its_out) {
+    if (!handles || B < 1 || B > 256) return SDVGN_E_ARG;
+    for (int b = 0; b < B; ++b) {
+        if (!handles[b]) return SDVGN_E_ARG;
+        for (int c = 0; c < b; ++c) if (handles[c] == handles[b]) return SDVGN_E_ARG;   // a handle is single-threaded
+    }
+    if (B == 1) { const int rc = sdvgn_ef_optimize(handles[0], mnumOptIts, flags, nullptr, 0, 0); if (its_out) its_out[0] = rc; return rc < 0 ? rc : SDVGN_OK; }
+    BatchPool& P = batch_pool();
+    std::unique_lock<std::mutex> lk(P.mu);
+    while ((int)P.workers.size() < B - 1) P.workers.emplace_back([&P] { P.worker(); });
+    P.jobs.clear();
+    for (int b = 0; b < B; ++b) P.jobs.push_back(BatchPool::Job{handles[b], mnumOptIts, flags, 0});
+    P.next = 0; P.done = 0; ++P.epoch;
+    P.cv_go.notify_all();
+    while (P.next < P.jobs.size()) {                    // the calling thread takes its share
+        const size_t k = P.next++;
+        BatchPool::Job j = P.jobs[k];
+        lk.unlock();
+        const int rc = sdvgn_ef_optimize(j.e, j.its, j.flags, nullptr, 0, 0);
+        lk.lock();
+        P.jobs[k].rc = rc;
+        ++P.done;
+    }
+    P.cv_done.wait(lk, [&] { return P.done == P.jobs.size(); });
+    int worst = SDVGN_OK;
+    for (int b = 0; b < B; ++b) { if (its_out) its_out[b] = P.jobs[b].rc; if (P.jobs[b].rc < 0) worst = P.jobs[b].rc; }
+    return worst;
+}
+
 int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_max, int* ngood_inc, unsigned char* removed) {
     if (!e || e->host_only || e->nP < 1 || e->nR < 0 || e->nF < 1) return SDVGN_E_STATE;
     EF_DEVICE(e);

@@ -545,3 +545,29 @@ def test_arith_mode_tolerance(api, orc):
     for i in range(len(to)):
         assert rel_err(tf[i, 7:7 + n], to[i, 7:7 + n]) < 1e-4                     # increments
     assert rel_err(Gf.state()[1], O.state()[1]) < 1e-4 and rel_err(Gf.state()[2], O.state()[2]) < 1e-5
+
+
+def test_optimize_batch_side_by_side(api, orc):
+    """sdvgn_ef_optimize_batch: B independent windows, each on its own stream and host thread -- every window ends exactly where its own
+    sdvgn_ef_optimize call ends (bit for bit), whatever runs beside it."""
+    from sdv_loam_amd import synthetic as syn
+    Ws = [low_thresholds(syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=20 + k, calib=dict(fx=400., fy=410., cx=319.5, cy=119.5),
+                                         state_sigma=1e-3, idepth_sigma=0.01)) for k in range(6)]
+    solo = []
+    for W in Ws:
+        G = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+        tr = G.optimize(6)
+        solo.append((len(tr), G.state(), G.residual_state()))
+    for rep in range(3):
+        Gs = [api.EnergyFunctional(W.w, W.h, max_points=W.nP, stream=api.EnergyFunctional.STREAM_OWN).load(W) for W in Ws]
+        its = api.optimize_batch(Gs, 6)
+        for G, n, (n0, st0, rs0) in zip(Gs, its, solo):
+            assert n == n0
+            st = G.state()
+            assert np.array_equal(st[0], st0[0]) and np.array_equal(st[1], st0[1]) and np.array_equal(st[2], st0[2])
+            rs = G.residual_state()
+            assert np.array_equal(rs["state"], rs0["state"]) and np.array_equal(rs["active"], rs0["active"])
+    # a handle twice in one batch is refused
+    import ctypes as C
+    arr = (C.c_void_p * 2)(Gs[0].h_, Gs[0].h_)
+    assert Gs[0].L.sdvgn_ef_optimize_batch(C.cast(arr, C.c_void_p), 2, 6, 0, None) < 0
