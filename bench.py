@@ -224,7 +224,7 @@ def load_tracker(api, P, local, max_batch):
     return G
 
 
-def distinct_batch(api, oracle, P, G, local, batch, n_problems=64):
+def distinct_batch(api, oracle, P, G, local, batch, n_problems=64, records=False):
     """`batch` LM trials as n_problems INDEPENDENT tracking problems x batch / n_problems poses: every problem has its own reference
     template and its own target pyramid in HBM (n_problems x 5.6 MB of level-0 image = 360 MB at 64, beyond the 256 MB Infinity Cache),
     so the bytes the launch moves are its algorithmic bytes.  Returns (trackers, launch)."""
@@ -234,7 +234,11 @@ def distinct_batch(api, oracle, P, G, local, batch, n_problems=64):
     poses = np.stack([oracle.se3_mul(oracle.se3_exp(syn.perturbation(1000 + i)), P.gt_pose) for i in range(batch)])
     affs = np.tile([0.02, 2.0], (batch, 1))
     pcs = [Gs[i // per].ref_dev(0) for i in range(batch)]
-    imgs = [Gs[i // per].pyr_dev(0) for i in range(batch)]
+    if records:      # set_precision(4): every problem's level-0 image as 64-byte neighbourhood records (30 MB per problem: 1.9 GB at 64)
+        G.set_precision(4)
+        imgs = [Gs[i // per].records_dev(0) for i in range(batch)]
+    else:
+        imgs = [Gs[i // per].pyr_dev(0) for i in range(batch)]
     return Gs, (lambda: G.resAndGSMulti(0, pcs, imgs, poses, affs, 20.0))
 
 
@@ -245,7 +249,7 @@ def pmc_child_tracker(batch):
     from sdv_loam_amd import api
     P = tracker_problem()
     G = load_tracker(api, P, 0, max(batch, 64))
-    Gs, launch = distinct_batch(api, oracle, P, G, 0, batch)
+    Gs, launch = distinct_batch(api, oracle, P, G, 0, batch, records=os.environ.get("SDVGN_BENCH_RECORDS") == "1")
     for _ in range(6):
         launch()
     torch.cuda.synchronize()
@@ -294,7 +298,7 @@ def measure_inloop_kernel(kernel="k_ef_linearize", timeout=240, arith=0):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def measure_traffic(kernel="k_ef_linearize", timeout=240, child=("--pmc-child",)):
+def measure_traffic(kernel="k_ef_linearize", timeout=240, child=("--pmc-child",), env_extra=None):
     """HBM-side bytes per launch of `kernel` from rocprofv3 PMC counters, two separate passes (FETCH_SIZE, WRITE_SIZE; the TCC
     block cannot hold both), corrected as MI355X_MICROARCH.md prescribes and as profiles/r01_counter_calibration.txt confirms
     for this project's access patterns: FETCH_SIZE x2 (128-B requests are tallied at 64 B), WRITE_SIZE x1, KiB -> bytes.
@@ -310,7 +314,7 @@ def measure_traffic(kernel="k_ef_linearize", timeout=240, child=("--pmc-child",)
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="sdvgn_pmc_", dir="/tmp")
-            env = dict(os.environ, TMPDIR="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp", **(env_extra or {}))
             subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__)] + list(child),
                            cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
             dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
@@ -444,6 +448,17 @@ def tracker_extras(torch, local, batch, oracle, want_cpu):
         dist[name] = dict(ms_per_launch=msd, gn_iters_per_s=batch / (msd * 1e-3), algorithmic_GBps=alg / (msd * 1e-3) / 1e9,
                           frac_of_hbm_peak=alg / (msd * 1e-3) / 1e9 / HBM_PEAK_GBS)
     G.set_arith(0)
+    del Gs
+    # the same launch on the gather-friendly record copies of the 64 pyramids (set_precision(4); bit-identical results)
+    Gs, launch = distinct_batch(api, oracle, P, G, local, batch, records=True)
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    msr = event_ms(torch, ext, launch, 20)
+    dist["record_layout"] = dict(ms_per_launch=msr, gn_iters_per_s=batch / (msr * 1e-3), algorithmic_GBps=alg / (msr * 1e-3) / 1e9,
+                                 frac_of_hbm_peak=alg / (msr * 1e-3) / 1e9 / HBM_PEAK_GBS, footprint_MB=len(Gs) * (P.w * P.h * 64) / 1e6,
+                                 note="level-0 images as 64-byte 2x2-neighbourhood records per pixel (sdvgn_tracker_set_precision(4)): one 128-byte line per lookup")
+    G.set_precision(0)
     del Gs
     out["batched_independent_problems"] = dist
     if want_cpu:
@@ -925,6 +940,15 @@ def main():
             bi["hbm_traffic_GBps"] = tb / (ms_sp * 1e-3) / 1e9
             bi["hbm_traffic_frac_of_peak"] = bi["hbm_traffic_GBps"] / HBM_PEAK_GBS
         bi["traffic_note"] = how + "; exact arithmetic; sparse 24-byte gathers pull whole 128-byte lines, so the launch is bound by HBM TRAFFIC, not by its algorithmic bytes"
+        tbr, howr = measure_traffic(kernel="k_res_gs", child=("--pmc-child-tracker", "--batch", str(args.batch)), env_extra={"SDVGN_BENCH_RECORDS": "1"})
+        rl = bi.get("record_layout")
+        if rl is not None:
+            rl["hbm_traffic_bytes_per_launch"] = tbr
+            rl["traffic_over_algorithmic"] = (tbr / alg_t) if tbr else None
+            if tbr:
+                rl["hbm_traffic_GBps"] = tbr / (rl["ms_per_launch"] * 1e-3) / 1e9
+                rl["hbm_traffic_frac_of_peak"] = rl["hbm_traffic_GBps"] / HBM_PEAK_GBS
+            rl["traffic_note"] = howr
     if rank == 0 and world == 1 and not args.quick:
         out["reprojector"] = reproject_extras(W, G, local, not args.no_cpu)
         out["trace_points"] = trace_extras(W, local, not args.no_cpu)

@@ -55,8 +55,15 @@ int sdvgn_tracker_set_settings(sdvgn_tracker* t, float huberTH, float coarseCuto
 
 /* Tolerance study of BASELINE.json configs[4] (not a reference feature): 0 = fp32 (default, the product path),
  * 1 = fp16 pyramid, 2 = + fp16 Jacobian/residual operands, 3 = + fp16 accumulation.  Affects calc_gs / res_and_gs /
- * track (host-driven) only; calc_res (parity hook) and track_batch always run in fp32. */
+ * track (host-driven) only; calc_res (parity hook) and track_batch always run in fp32.
+ * 4 = fp32 on a GATHER-FRIENDLY device copy of the target pyramid: per pixel one 64-byte record with the {I,dx,dy} of its 2x2 neighbourhood,
+ * so that the four taps of a lookup come from one 128-byte line instead of two image rows (the reference's row-major AoS float3,
+ * HessianBlocks.cpp:135-155, stays the hand-over format of sdvgn_tracker_set_new_pyr).  Results are bit-identical to mode 0 -- only
+ * addresses change; HBM traffic of independent tracking problems drops ~2.5x.  4.3x the device memory of a pyramid. */
 int sdvgn_tracker_set_precision(sdvgn_tracker* t, int mode);
+/* Device pointer of level lvl's record copy (mode 4), built on demand: the per-problem image pointer sdvgn_tracker_res_and_gs_multi takes
+ * when the calling handle is in mode 4. */
+const void* sdvgn_tracker_records_dev(sdvgn_tracker* t, int lvl);
 /* Arithmetic of the fused calcRes + calcGSSSE kernel (k_res_gs: calc_gs / res_and_gs / res_and_gs_batch / res_and_gs_multi / track, the
  * host-driven paths): 0 = the reference's float arithmetic operation by operation (default; per-point terms bit-identical to the CPU path),
  * 1 = tolerance mode: fused multiply-adds and reciprocal-based divisions (v_rcp_f32 + one Newton step).  BASELINE.json's contract for this

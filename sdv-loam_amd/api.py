@@ -28,6 +28,7 @@ PROTOTYPES = [
     ("sdvgn_tracker_set_arith", C.c_int, [vp, C.c_int]),
     ("sdvgn_tracker_set_team", C.c_int, [vp, C.c_int]),
     ("sdvgn_tracker_get_team", C.c_int, [vp]),
+    ("sdvgn_tracker_records_dev", vp, [vp, C.c_int]),
     ("sdvgn_tracker_get_team_fallbacks", C.c_int, [vp]),
     ("sdvgn_tracker_res_and_gs_multi", C.c_int, [vp, C.c_int, C.c_int, vp, vp, f64p, f64p, C.c_float, vp]),
     ("sdvgn_tracker_ref_dev", vp, [vp, C.c_int]),
@@ -150,6 +151,10 @@ class CoarseTracker:
     def team_fallbacks(self):
         """batches trackBatch re-ran on k_track because the members of a team did not meet (a busy device)"""
         return self.L.sdvgn_tracker_get_team_fallbacks(self.h_)
+
+    def records_dev(self, lvl):
+        """device pointer of the 64-byte-record copy of level lvl (set_precision(4)); built on demand"""
+        return self.L.sdvgn_tracker_records_dev(self.h_, lvl)
 
     def ref_dev(self, lvl):
         return self.L.sdvgn_tracker_ref_dev(self.h_, lvl)

@@ -59,6 +59,8 @@ struct sdvgn_tracker {
     float* pyr_dev[SDVGN_MAX_LEVELS] = {};  // AoS {I,dx,dy}
     __half* pyr_half_dev[SDVGN_MAX_LEVELS] = {};  // precision study only: fp16 {I,dx,dy,0}, built lazily
     bool half_valid = false;
+    float4* pyr_rec_dev[SDVGN_MAX_LEVELS] = {};   // PREC_F32_REC: 64-byte neighbourhood records per pixel (k_pyr_to_records), built lazily
+    bool rec_valid = false;
     int precision = PREC_F32;
     int arith = 0;                    // 0: the reference's arithmetic (default); 1: tolerance mode (FMA + rcp divisions), sdvgn_tracker_set_arith
     ProblemPtrs* ptrs_dev = nullptr;  // per-problem template / image pointers of sdvgn_tracker_res_and_gs_multi (max_batch entries)
@@ -149,6 +151,18 @@ static void fill_params(const sdvgn_tracker* t, int lvl, const double* pose7, do
 // zero_copy (the host-driven single-trial path): the kernels read the 152-B LevelParams record straight from the pinned host
 // buffer and k_finalize stores its 640 B of results straight into pinned host memory -- no copy engine in the loop (a small
 // hipMemcpyAsync costs 10-20 us of fixed latency each way, the PCIe transfers themselves well under 1 us).
+static int ensure_records(sdvgn_tracker* t) {
+    if (t->rec_valid) return SDVGN_OK;
+    for (int l = 0; l < t->levels; ++l) {
+        const int npix = t->w[l] * t->h[l];
+        if (!t->pyr_rec_dev[l]) HIPCHK(hipMalloc(&t->pyr_rec_dev[l], sizeof(float4) * 4 * (size_t)npix));
+        k_pyr_to_records<<<(npix + 255) / 256, 256, 0, t->stream>>>(t->pyr_dev[l], t->pyr_rec_dev[l], t->w[l], t->h[l]);
+    }
+    HIPCHK(hipGetLastError());
+    t->rec_valid = true;
+    return SDVGN_OK;
+}
+
 static int launch_res_gs(sdvgn_tracker* t, int lvl, int B, const double* pose7, const double* aff, float cutoffTH,
                          bool write_terms, double* out_dev, bool zero_copy = false, const ProblemPtrs* ptrs = nullptr) {
     if (!t->haveK || !t->haveNew) return SDVGN_E_STATE;
@@ -160,7 +174,14 @@ static int launch_res_gs(sdvgn_tracker* t, int lvl, int B, const double* pose7, 
     const int n = t->pc_n[lvl];
     const int chunks = chunks_for(t, n, B);
     dim3 grid(chunks, B), block(256);
-    if (t->precision != PREC_F32) {
+    if (t->precision == PREC_F32_REC) {
+        // fp32 on the gather-friendly record copy of the pyramid: bit-identical results, one 128-byte line per lookup
+        if (write_terms) return SDVGN_E_ARG;
+        int rcr = ensure_records(t);
+        if (rcr) return rcr;
+        const float* rimg = reinterpret_cast<const float*>(t->pyr_rec_dev[lvl]);
+        k_res_gs<false, PREC_F32_REC><<<grid, block, 0, t->stream>>>(t->pc_dev[lvl], rimg, params, t->partial_dev, nullptr, nullptr, ptrs);
+    } else if (t->precision != PREC_F32) {
         // tolerance study (configs[4]): same kernel on an fp16 pyramid / fp16 operands / fp16 accumulator
         if (write_terms) return SDVGN_E_ARG;
         if (!t->half_valid) {
@@ -340,7 +361,7 @@ void sdvgn_tracker_destroy(sdvgn_tracker* t) {
     auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && dbg) fprintf(stderr, "[sdvgn] tracker destroy: %s -> %d (%s)\n", what, (int)e, hipGetErrorString(e)); };
 #define DFREE(p) chk(hipFree(p), "hipFree(" #p ")")
 #define HFREE(p) chk(hipHostFree(p), "hipHostFree(" #p ")")
-    for (int l = 0; l < t->levels; ++l) { DFREE(t->pc_dev[l]); DFREE(t->pyr_dev[l]); if (t->pyr_half_dev[l]) DFREE(t->pyr_half_dev[l]); }
+    for (int l = 0; l < t->levels; ++l) { DFREE(t->pc_dev[l]); DFREE(t->pyr_dev[l]); if (t->pyr_half_dev[l]) DFREE(t->pyr_half_dev[l]); if (t->pyr_rec_dev[l]) DFREE(t->pyr_rec_dev[l]); }
     DFREE(t->img_stage_dev); DFREE(t->params_dev); DFREE(t->ptrs_dev); HFREE(t->params_host); DFREE(t->partial_dev);
     DFREE(t->out_dev); HFREE(t->out_host); HFREE(t->flag_host); DFREE(t->terms_dev); DFREE(t->status_dev);
     HFREE(t->track_host); DFREE(t->team_dev);
@@ -383,9 +404,14 @@ int sdvgn_tracker_set_arith(sdvgn_tracker* t, int mode) {
 }
 
 int sdvgn_tracker_set_precision(sdvgn_tracker* t, int mode) {
-    if (!t || mode < 0 || mode > 3) return SDVGN_E_ARG;
-    t->precision = mode;
+    if (!t || mode < 0 || mode > 4) return SDVGN_E_ARG;
+    t->precision = mode == 4 ? PREC_F32_REC : mode;
     return SDVGN_OK;
+}
+const void* sdvgn_tracker_records_dev(sdvgn_tracker* t, int lvl) {
+    if (!t || lvl < 0 || lvl >= t->levels || !t->haveNew) return nullptr;
+    if (hipSetDevice(t->device) != hipSuccess || ensure_records(t) != SDVGN_OK || hipStreamSynchronize(t->stream) != hipSuccess) return nullptr;
+    return t->pyr_rec_dev[lvl];
 }
 
 int sdvgn_tracker_make_K(sdvgn_tracker* t, float fx, float fy, float cx, float cy) {  // CoarseTracker.cpp:77-106
@@ -451,7 +477,7 @@ int sdvgn_tracker_set_new_image(sdvgn_tracker* t, const float* image, float expo
     int rc = build_pyramid(t, t->img_stage_dev);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(t->stream));  // `image` may be pageable: do not return before the copy is done
-    t->new_exposure = exposure; t->haveNew = true; t->half_valid = false;
+    t->new_exposure = exposure; t->haveNew = true; t->half_valid = false; t->rec_valid = false;
     return SDVGN_OK;
 }
 
@@ -460,7 +486,7 @@ int sdvgn_tracker_set_new_image_dev(sdvgn_tracker* t, const float* image_dev, fl
     HIPCHK(hipSetDevice(t->device));
     int rc = build_pyramid(t, image_dev);
     if (rc) return rc;
-    t->new_exposure = exposure; t->haveNew = true; t->half_valid = false;
+    t->new_exposure = exposure; t->haveNew = true; t->half_valid = false; t->rec_valid = false;
     return SDVGN_OK;
 }
 
@@ -469,7 +495,7 @@ int sdvgn_tracker_set_new_pyr(sdvgn_tracker* t, int lvl, const float* aos3, floa
     HIPCHK(hipSetDevice(t->device));
     HIPCHK(hipMemcpyAsync(t->pyr_dev[lvl], aos3, sizeof(float) * 3 * (size_t)t->w[lvl] * t->h[lvl], hipMemcpyHostToDevice, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
-    t->new_exposure = exposure; t->haveNew = true; t->half_valid = false;
+    t->new_exposure = exposure; t->haveNew = true; t->half_valid = false; t->rec_valid = false;
     return SDVGN_OK;
 }
 
@@ -510,7 +536,7 @@ int sdvgn_tracker_res_and_gs_batch(sdvgn_tracker* t, int lvl, int B, const doubl
 int sdvgn_tracker_res_and_gs_multi(sdvgn_tracker* t, int lvl, int B, const void* const* pc_dev, const void* const* img_dev, const double* pose7,
                                    const double* aff, float cutoffTH, double* out_dev) {
     if (!t || !pose7 || !aff || !pc_dev || !img_dev || B < 1 || B > t->max_batch) return SDVGN_E_ARG;
-    if (t->precision != PREC_F32) return SDVGN_E_STATE;
+    if (t->precision != PREC_F32 && t->precision != PREC_F32_REC) return SDVGN_E_STATE;   // (record mode: img_dev[b] = sdvgn_tracker_records_dev of problem b)
     HIPCHK(hipSetDevice(t->device));
     if (!t->ptrs_dev) HIPCHK(hipMalloc(&t->ptrs_dev, sizeof(ProblemPtrs) * t->max_batch));
     std::vector<ProblemPtrs> hp(B);

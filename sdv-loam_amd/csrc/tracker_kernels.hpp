@@ -33,7 +33,12 @@ namespace sdvgn {
 //   1  fp16 pyramid {I,dx,dy,0} (8 B/px, one 8-B load per tap), everything else fp32
 //   2  mode 1 + Jacobian/residual operands rounded to fp16 before the Gram (== f16-input MFMA, fp32 accumulate)
 //   3  mode 2 + the Gram accumulator rounded to fp16 after every 4-point MFMA step ("fp16 residual accumulation")
-enum { PREC_F32 = 0, PREC_H_PYR = 1, PREC_H_OPER = 2, PREC_H_ACC = 3 };
+enum { PREC_F32 = 0, PREC_H_PYR = 1, PREC_H_OPER = 2, PREC_H_ACC = 3,
+       // fp32 arithmetic on the GATHER-FRIENDLY copy of the pyramid (k_pyr_to_records): per pixel one 64-byte record holding the {I,dx,dy}
+       // of its 2x2 neighbourhood -- the four taps of a bilinear lookup at any position come out of ONE 64-byte-aligned record (three
+       // 16-byte loads, one 128-byte line) instead of two image rows = two to four lines.  Same 12 floats, same operations: results are
+       // bit-identical to PREC_F32; only the addresses change.  (Negative so that the `MODE >= PREC_H_*` tests of the study modes stay false.)
+       PREC_F32_REC = -1 };
 
 constexpr int kNAcc = 45;                 // upper triangle of the 9x9 [J r][J r]^T
 constexpr int kNRed = 52;                 // 45 + E + nE + nSat + nWarped + flowT + flowRT + flowNum
@@ -69,6 +74,23 @@ __device__ __forceinline__ void interp33(const float* __restrict__ img, float x,
     const float* bq = bp + 3 * width;
     const float a0 = bp[0], a1 = bp[1], a2 = bp[2], b0 = bp[3], b1 = bp[4], b2 = bp[5];
     const float c0 = bq[0], c1 = bq[1], c2 = bq[2], d0 = bq[3], d1 = bq[4], d2 = bq[5];
+    const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+    o0 = ((w11 * d0 + w01 * c0) + w10 * b0) + w00 * a0;
+    o1 = ((w11 * d1 + w01 * c1) + w10 * b1) + w00 * a1;
+    o2 = ((w11 * d2 + w01 * c2) + w10 * b2) + w00 * a2;
+}
+
+// PREC_F32_REC: the four taps from the pixel's neighbourhood record [a(3) b(3) c(3) d(3) pad(4)] (a = (ix,iy), b = (ix+1,iy), c = (ix,iy+1), d = (ix+1,iy+1))
+__device__ __forceinline__ void interp33_rec(const float* __restrict__ rec16, float x, float y, int width, float& o0, float& o1, float& o2) {
+    const int ix = (int)x;
+    const int iy = (int)y;
+    const float dx = x - ix;
+    const float dy = y - iy;
+    const float dxdy = dx * dy;
+    const float4* r = reinterpret_cast<const float4*>(rec16) + 4 * (size_t)(ix + iy * width);
+    const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+    const float a0 = r0.x, a1 = r0.y, a2 = r0.z, b0 = r0.w, b1 = r1.x, b2 = r1.y;
+    const float c0 = r1.z, c1 = r1.w, c2 = r2.x, d0 = r2.y, d1 = r2.z, d2 = r2.w;
     const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
     o0 = ((w11 * d0 + w01 * c0) + w10 * b0) + w00 * a0;
     o1 = ((w11 * d1 + w01 * c1) + w10 * b1) + w00 * a1;
@@ -143,6 +165,7 @@ __device__ __forceinline__ void point_features(const LevelParams& P, const float
     float hit0 = 0, hit1 = 0, hit2 = 0, residual = 0, hw = 0;
     if (Ku > 2 && Kv > 2 && Ku < P.wl - 3 && Kv < P.hl - 3 && new_idepth > 0) {
         if (MODE == PREC_F32) interp33(img, Ku, Kv, P.wl, hit0, hit1, hit2);
+        else if (MODE == PREC_F32_REC) interp33_rec(img, Ku, Kv, P.wl, hit0, hit1, hit2);
         else interp33_h(reinterpret_cast<const __half*>(img), Ku, Kv, P.wl, hit0, hit1, hit2);
         if (isfinite(hit0)) {
             residual = hit0 - (float)(P.affLL0 * refColor + P.affLL1);
@@ -460,6 +483,26 @@ static __global__ void __launch_bounds__(256) k_pyr_level(const float* __restric
     }
     if (has_next && qx < wn && qy < hn)
         aos_next[3 * (qx + qy * wn)] = 0.25f * (((Iq[0] + Iq[1]) + Iq[2]) + Iq[3]);
+}
+
+// Gather-friendly copy of one pyramid level (PREC_F32_REC): record (x, y) = the {I,dx,dy} of pixels (x,y), (x+1,y), (x,y+1), (x+1,y+1) + 16 bytes of
+// padding = 64 bytes.  The last column / row have no right / lower neighbour: those slots are 0 (calcRes only looks up positions with
+// Ku < wl - 3, Kv < hl - 3).  4.3x the memory of the AoS level (30 MB at 1241x376), written once per frame.
+static __global__ void __launch_bounds__(256) k_pyr_to_records(const float* __restrict__ aos3, float4* __restrict__ rec, int w, int h) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w * h) return;
+    const int x = i % w, y = i / w;
+    const bool xr = x + 1 < w, yd = y + 1 < h;
+    const float* a = aos3 + 3 * (size_t)i;
+    const float* b = a + 3; const float* c = a + 3 * (size_t)w; const float* d = c + 3;
+    const float b0 = xr ? b[0] : 0.f, b1 = xr ? b[1] : 0.f, b2 = xr ? b[2] : 0.f;
+    const float c0 = yd ? c[0] : 0.f, c1 = yd ? c[1] : 0.f, c2 = yd ? c[2] : 0.f;
+    const float d0 = (xr && yd) ? d[0] : 0.f, d1 = (xr && yd) ? d[1] : 0.f, d2 = (xr && yd) ? d[2] : 0.f;
+    float4* r = rec + 4 * (size_t)i;
+    r[0] = make_float4(a[0], a[1], a[2], b0);
+    r[1] = make_float4(b1, b2, c0, c1);
+    r[2] = make_float4(c2, d0, d1, d2);
+    r[3] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // fp16 copy of one pyramid level for the precision study: AoS float3 -> half4 {I,dx,dy,0}

@@ -378,3 +378,39 @@ def test_tolerance_mode_arithmetic(api, orc, cfg):
     do = orc.se3_log(orc.se3_mul(po, orc.se3_inverse(start)))
     assert rel_err(dg, do) < 1e-4
     assert np.allclose(lrg[:P.levels], lro[:P.levels], rtol=1e-3, atol=2e-4)     # RMSE at convergence on noise-free images is ~1e-4: absolute
+
+
+@pytest.mark.parametrize("shape", [(1241, 376, 4), (256, 192, 3)])
+def test_record_layout_bit_identical(api, orc, shape):
+    """set_precision(4): the fused calcRes + calcGSSSE kernel on the gather-friendly 64-byte neighbourhood records -- the same twelve floats
+    per lookup, so E, counters, H, b and a whole host-driven trackNewestCoarse are bit-identical with the row-major AoS pyramid;
+    also for independent problems side by side (resAndGSMulti with per-problem record pointers)."""
+    from sdv_loam_amd import synthetic as syn
+    w, h, levels = shape
+    P = small_problem(seed=3, n=1500, w=w, h=h, levels=levels, noise=1.5) if w < 1000 else \
+        syn.make_tracker_problem(w=w, h=h, levels=levels, n_points=2000, seed=0, calib=syn.KITTI00, gt_xi=[0.03, -0.02, 0.05, 0.004, -0.006, 0.002], gt_aff=(0.03, 1.5))
+    G = load_problem(api.CoarseTracker(P.w, P.h, P.levels, max_points=1 << 16, max_batch=8), P, ref_aff=(0.01, 1.0))
+    pose = start_pose(orc, P, 2)
+    ref = []
+    for lvl in range(P.levels):
+        ref.append(G.resAndGS(lvl, pose, 0.03, 2.0, 20.0))
+    tr0 = G.trackNewestCoarse(pose, (0.0, 0.0), P.levels - 1)
+    G.set_precision(4)
+    for lvl in range(P.levels):
+        r, H, b = G.resAndGS(lvl, pose, 0.03, 2.0, 20.0)
+        assert np.array_equal(r, ref[lvl][0], equal_nan=True) and np.array_equal(H, ref[lvl][1], equal_nan=True) and np.array_equal(b, ref[lvl][2], equal_nan=True)
+    tr1 = G.trackNewestCoarse(pose, (0.0, 0.0), P.levels - 1)
+    assert tr0[0] == tr1[0] and np.array_equal(tr0[1], tr1[1]) and np.array_equal(tr0[2], tr1[2]) and np.array_equal(tr0[3], tr1[3], equal_nan=True)
+    # independent problems: two trackers with their own pyramids / templates, one launch
+    P2 = small_problem(seed=9, n=1500, w=w, h=h, levels=levels, noise=1.0) if w < 1000 else \
+        syn.make_tracker_problem(w=w, h=h, levels=levels, n_points=2000, seed=5, calib=syn.KITTI00, gt_xi=[0.01, 0.02, -0.03, 0.002, 0.003, -0.001], gt_aff=(0.0, 0.5))
+    G2 = load_problem(api.CoarseTracker(P.w, P.h, P.levels, max_points=1 << 16, max_batch=8), P2, ref_aff=(0.01, 1.0))
+    poses = np.stack([pose, pose, start_pose(orc, P2, 4), start_pose(orc, P2, 5)])
+    affs = np.tile([0.03, 2.0], (4, 1))
+    pcs = [G.ref_dev(0), G.ref_dev(0), G2.ref_dev(0), G2.ref_dev(0)]
+    G.set_precision(0)
+    out0 = G.resAndGSMulti(0, pcs, [G.pyr_dev(0), G.pyr_dev(0), G2.pyr_dev(0), G2.pyr_dev(0)], poses, affs, 20.0)
+    G.set_precision(4)
+    out4 = G.resAndGSMulti(0, pcs, [G.records_dev(0), G.records_dev(0), G2.records_dev(0), G2.records_dev(0)], poses, affs, 20.0)
+    for a, b in zip(out0, out4):
+        assert np.array_equal(a, b, equal_nan=True)
