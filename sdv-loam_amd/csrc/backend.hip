@@ -1584,9 +1584,16 @@ static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_st
     if (e->pend_sel_valid) ef_flush_pending(e);    // system re-used: no stitch launch to ride in
     const int has_rc = e->pend_rc_valid ? 1 : 0;
     const int nblk = (e->nP + 63) / 64;
-    k_ef_tail_resub<<<1 + (has_rc ? kReclBlocks : 0) + (nblk + 1) / 2 + (do_step ? 1 : 0), kSolveLanes, 0, e->stream>>>(
+    const int head = 1 + (has_rc ? kReclBlocks : 0), rest = (nblk + 1) / 2 + (do_step ? 1 : 0);
+    if (e->own_stream) {   // a window that runs beside others: no spinning workgroups (see k_ef_tail_resub)
+        k_ef_tail_resub<<<head, kSolveLanes, 0, e->stream>>>(io, e->pend_rc, has_rc, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup,
+                                                             e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, nblk, 0, 0);
+        k_ef_tail_resub<<<rest, kSolveLanes, 0, e->stream>>>(io, e->pend_rc, has_rc, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup,
+                                                             e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, nblk, head, 1);
+    } else
+    k_ef_tail_resub<<<head + rest, kSolveLanes, 0, e->stream>>>(
         io, e->pend_rc, has_rc, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt,
-        e->pdeltaF_alt, nblk);
+        e->pdeltaF_alt, nblk, 0, 0);
     e->pend_rc_valid = false;
     HIPCHK(hipGetLastError());
     e->sys_on_device = true; e->sys_fetched = false; e->sys_valid = true;
@@ -1695,7 +1702,14 @@ static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideAr
         a.rflags = e->rflags; a.wo = e->A.renergy_wo; a.th_prev = e->A.frameTH_r; a.th_out = e->A.frameTH_w;
         a.log_slot = e->th_log ? e->th_log + (e->th_log_n++ % kThLog) : nullptr;
         const DecideArgs none{0, 0, 0, nullptr, 0, nullptr, 0};
-        if (dec && dec->verdict) {   // statistics + accept test + conditional applyRes of the trial set in one launch
+        if (dec && dec->verdict && e->own_stream) {
+            // a window that runs beside others (sdvgn_ef_optimize_batch): the same two steps as two launches -- the apply workgroups would
+            // otherwise sit on the CUs polling the verdict word while other windows' kernels wait for a place
+            const size_t slots = (size_t)e->nF * e->nP;
+            DecideArgs d2 = *dec; d2.verdict = nullptr;
+            k_ef_stats_select<<<1, kSelLanes, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host, e->flags_host + 2, ++e->seq_stats, a, d2);
+            k_ef_apply<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->nF, e->nP, e->A, e->precalc_dev, e->phost_dev, e->accept_dev);
+        } else if (dec && dec->verdict) {   // statistics + accept test + conditional applyRes of the trial set in one launch
             const size_t slots = (size_t)e->nF * e->nP;
             k_ef_stats_apply<<<1 + (unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host,
                                                                                        e->flags_host + 2, ++e->seq_stats, *dec, e->nF, e->nP, e->A, e->precalc_dev,
