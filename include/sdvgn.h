@@ -446,6 +446,16 @@ int sdvgn_ef_accumulators_dev(sdvgn_ef* ef, double** buf_dev, int* count);
 /* solve_system split for multi-GPU: accumulate only (fills the packed buffer), then finish (stitch, solve, resubstitute)
  * after the caller has all-reduced the buffer. */
 int sdvgn_ef_accumulate(sdvgn_ef* ef);
+/* Sharded window, ONE collective per loop body (configs[3]; north_star: a single all-reduce per Gauss-Newton iteration).  With a collective
+ * buffer installed -- `buf_dev`: device memory of >= 2 x sdvgn_ef_collective_stride(ef) doubles (e.g. a torch tensor the all-reduce callback
+ * can address), or NULL for a library allocation -- sdvgn_ef_optimize of a sharded handle (sdvgn_ef_init_rccl / sdvgn_ef_set_allreduce)
+ * sends ONE message per loop body, + one per call: [packed accumulators | 4 statistics | max_points quantile candidates].  It applies the
+ * trial linearisation and accumulates it BEFORE the accept test (whose energy rides in the same message): an accepted step costs nothing
+ * extra, a rejected one takes the apply back and recomputes the rank-local per-point planes.  Results are those of the two-collective loop
+ * bit for bit.  sdvgn_ef_collective_count: all-reduces the handle has issued so far. */
+int sdvgn_ef_collective_stride(sdvgn_ef* ef);
+int sdvgn_ef_set_collective_buffer(sdvgn_ef* ef, double* buf_dev, int capacity);
+unsigned long long sdvgn_ef_collective_count(sdvgn_ef* ef);
 int sdvgn_ef_finish_solve(sdvgn_ef* ef, int iteration, double lambda, double* x_out);
 /* host part of solveSystemF on a caller-supplied (e.g. all-reduced) accumulator buffer in host memory; works on a
  * host-only handle (sdvgn_ef_create with device = -1: no kernels, only frames/adjoints/priors and this function). */

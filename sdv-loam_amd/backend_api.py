@@ -53,6 +53,9 @@ PROTOTYPES = [
     ("sdvgn_debug_launch_linearize", C.c_int, [vp, C.c_int]),
     ("sdvgn_ef_get_solve_status", C.c_int, [vp]),
     ("sdvgn_ef_set_arith", C.c_int, [vp, C.c_int]),
+    ("sdvgn_ef_collective_stride", C.c_int, [vp]),
+    ("sdvgn_ef_set_collective_buffer", C.c_int, [vp, vp, C.c_int]),
+    ("sdvgn_ef_collective_count", C.c_ulonglong, [vp]),
     ("sdvgn_ef_optimize_batch", C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
     ("sdvgn_ef_frame_image_dev", vp, [vp, C.c_int]),
     ("sdvgn_rccl_unique_id", C.c_int, [vp]),

@@ -178,6 +178,14 @@ struct sdvgn_ef {
     bool acc_in_host = false;     // the last accumulate wrote acc_host directly (acc_dev not updated)
     double* stats_dev = nullptr;   // {linearize energy, L-energy point part, sum step^2, sum |idepth_backup|}
     bool own_acc = true, own_stats = true;
+    // sharded window, ONE collective per loop body (sdvgn_ef_set_collective_buffer): two message buffers [acc | 4 statistics | nP quantile
+    // candidates]; coll_cur holds the reduced accumulators of the CURRENT state, the other one receives the speculative message of a trial
+    double* coll[2] = {nullptr, nullptr};
+    size_t coll_stride = 0;        // doubles per message buffer
+    int coll_cur = 0;
+    bool own_coll = false;
+    ApplyBackup apply_bak{nullptr, nullptr, nullptr, nullptr};
+    unsigned long long n_collectives = 0;   // all-reduces issued through ef_allreduce (tests)
     void (*allreduce)(void*, double*, int) = nullptr;   // cfg4: sum a device buffer over the ranks (RCCL), in stream order
     void* allreduce_user = nullptr;
     bool host_only = false;
@@ -852,6 +860,7 @@ static int ef_allreduce(sdvgn_ef* e, double* buf_dev, int count) {
         const ncclResult_t r = rccl_api().AllReduce(buf_dev, buf_dev, (size_t)count, ncclDouble, ncclSum, e->rccl_comm, e->stream);
         return r == ncclSuccess ? SDVGN_OK : SDVGN_E_STATE;
     }
+    ++e->n_collectives;
     if (e->allreduce) e->allreduce(e->allreduce_user, buf_dev, count);
     return SDVGN_OK;
 }
@@ -1024,6 +1033,8 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
     if (e->done_ctr) hipFree(e->done_ctr);
     if (e->imm_pc_host) hipHostFree(e->imm_pc_host);
     if (e->imm_stage) hipHostFree(e->imm_stage);
+    if (e->own_coll && e->coll[0]) hipFree(e->coll[0]);
+    if (e->apply_bak.fl) { hipFree(e->apply_bak.fl); hipFree(e->apply_bak.st); hipFree(e->apply_bak.en); hipFree(e->apply_bak.JpJd); }
     if (e->own_stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1411,6 +1422,33 @@ int sdvgn_ef_set_external_buffers(sdvgn_ef* e, double* acc_dev, int acc_capacity
     return SDVGN_OK;
 }
 
+// One collective per loop body: `buf_dev` (device, >= 2 x sdvgn_ef_collective_stride doubles; NULL: the library allocates) becomes two
+// message buffers [packed accumulators | 4 statistics | max_points quantile candidates]; sdvgn_ef_optimize then all-reduces ONE message per
+// loop body (+ one per call) instead of the accumulators and the statistics separately.
+static size_t coll_stride_for(const sdvgn_ef* e) {
+    return (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kTopE + (size_t)SDVGN_MAX_FRAMES * kScE + 1 + 4 + (size_t)e->max_points;
+}
+int sdvgn_ef_collective_stride(sdvgn_ef* e) { return e && !e->host_only ? (int)coll_stride_for(e) : SDVGN_E_ARG; }
+int sdvgn_ef_set_collective_buffer(sdvgn_ef* e, double* buf_dev, int capacity) {
+    if (!e || e->host_only) return SDVGN_E_ARG;
+    EF_DEVICE(e);
+    const size_t stride = coll_stride_for(e);
+    if (buf_dev && (size_t)capacity < 2 * stride) return SDVGN_E_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->own_coll && e->coll[0]) hipFree(e->coll[0]);
+    e->own_coll = false;
+    if (!buf_dev) { HIPCHK(hipMalloc((void**)&buf_dev, sizeof(double) * 2 * stride)); e->own_coll = true; }
+    HIPCHK(hipMemsetAsync(buf_dev, 0, sizeof(double) * 2 * stride, e->stream));
+    e->coll[0] = buf_dev; e->coll[1] = buf_dev + stride; e->coll_stride = stride; e->coll_cur = 0;
+    if (!e->apply_bak.fl) {
+        const size_t slots = e->slots_cap;
+        HIPCHK(hipMalloc((void**)&e->apply_bak.fl, slots)); HIPCHK(hipMalloc((void**)&e->apply_bak.st, slots));
+        HIPCHK(hipMalloc((void**)&e->apply_bak.en, sizeof(float) * slots)); HIPCHK(hipMalloc((void**)&e->apply_bak.JpJd, sizeof(float) * 6 * slots));
+    }
+    return SDVGN_OK;
+}
+unsigned long long sdvgn_ef_collective_count(sdvgn_ef* e) { return e ? e->n_collectives : 0; }
+
 int sdvgn_ef_set_allreduce(sdvgn_ef* e, void (*fn)(void*, double*, int), void* user) {
     if (!e) return SDVGN_E_ARG;
     e->allreduce = fn; e->allreduce_user = user;
@@ -1741,6 +1779,33 @@ static int linearize_and_stats(sdvgn_ef* e, double* energy, double* EL, double* 
     return rc ? rc : linearize_wait(e, energy, EL, sumID, sumNID);
 }
 
+// ---- sharded window, ONE collective per loop body (BASELINE.json north_star: "a single RCCL all-reduce ... before the tiny
+// Cholesky").  The accept test needs the global energy of the trial linearisation, the next solve the global accumulators of the accepted
+// state: one message carries both if the accumulate is SPECULATIVE -- the trial is applied (what it overwrites is backed up), this rank's
+// shard is accumulated as if the step had been accepted, and [accumulators | 4 statistics | quantile candidates] go out as one all-reduce.
+// accept: the message buffer becomes the current accumulators (nothing else to do); reject: the apply is taken back (k_ef_apply_revert), the
+// per-point planes are recomputed for the kept state (an accumulate without its reduce: they are local), and the kept message buffer -- whose
+// system differs from the next one only in lambda -- serves the next solve.
+static inline bool ef_one_collective(const sdvgn_ef* e) { return ef_sharded(e) && e->coll[0] != nullptr; }
+static void ef_use_coll(sdvgn_ef* e, int p) { e->acc_dev = e->coll[p]; e->stats_dev = e->coll[p] + acc_count(e); }
+static int ef_sharded_message(sdvgn_ef* e, int p, bool speculative) {
+    ef_use_coll(e, p);
+    const int nS = (e->nP + 63) / 64;
+    const double* ps = e->stats_partial + (e->nP / 64 + 2);
+    k_ef_sum_stats<<<1, 256, 0, e->stream>>>(e->energy_partial, e->lin_partials, e->stats_partial, e->lin_nL, ps, nS, e->stats_dev, nullptr, 0);
+    ef_launch_pack_th(e);
+    const size_t slots = (size_t)e->nF * e->nP;
+    if (speculative) k_ef_apply_backup<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->nF, e->nP, e->A, e->precalc_dev, e->phost_dev, e->apply_bak);
+    else k_ef_apply<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->nF, e->nP, e->A, e->precalc_dev, e->phost_dev, nullptr);
+    int rc = ef_accumulate(e, /*with_reduce=*/true);
+    if (rc) return rc;
+    if ((rc = ef_allreduce(e, e->coll[p], (int)acc_count(e) + 4 + e->nP))) return rc;
+    k_ef_copy_publish<<<1, 256, 0, e->stream>>>(e->stats_dev, e->stats_host, 4, e->done_ctr, e->flags_host + 2, ++e->seq_stats);
+    ef_launch_select_th(e, true);
+    HIPCHK(hipGetLastError());
+    return SDVGN_OK;
+}
+
 // FullSystem::optimize, the loop (FullSystemOptimize.cpp:344-458).  The window's state lives on the device: per loop body the host
 // only launches -- accumulate + reduce, stitch (+ the previous linearisation's threshold select), LDL^T tail (+ the re-classification
 // after a rejected step), resubstitute + step + precalc table, linearize -- mirrors the step from x (pinned memory) while the GPU
@@ -1782,6 +1847,12 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     // linearizeAll + applyRes: the apply does not depend on the sums, and neither does the first loop body's accumulate / solve / linearise --
     // the host's parts of the energies (priors, M energy: functions of the host mirror, which the first body's step moves) are taken now,
     // the device's sums are fetched when the first accept test needs them (take_initial_energies), by then long there
+    const bool onecoll = ef_one_collective(e) && !relinearize_on_reject;
+    struct CollGuard { sdvgn_ef* e; double* a; double* s; ~CollGuard() { e->acc_dev = a; e->stats_dev = s; } } coll_guard{e, e->acc_dev, e->stats_dev};
+    if (onecoll) {
+        // the call's one extra collective: initial linearizeAll + applyRes + accumulate, their sums and accumulators in one message
+        if ((rc = linearize_launch_kernels(e)) || (rc = ef_sharded_message(e, e->coll_cur, /*speculative=*/false))) return rc;
+    } else
     if ((rc = linearize_launch(e, defer)) || (rc = sdvgn_ef_apply_res(e))) return rc;
     e->A.reset_oob = 0;
     const double En_initial = host_prior_energy(e);
@@ -1832,7 +1903,8 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         // solveSystemF + doStepFromBackup, all on the device: the trial state (frame states, calib, precalc table, idepths) goes to the
         // second copies; resubstitute also backs up the idepths and applies the point step
         const bool reuse = reuse_after_reject && prev_rejected_clean && e->sys_valid;
-        if ((rc = ef_launch_solve(e, iteration, lambda, /*do_step=*/true, stepsize, reuse, /*accumulated=*/pre_accumulated))) return rc;
+        if (onecoll) ef_use_coll(e, e->coll_cur);                                        // the reduced accumulators of the current state
+        if ((rc = ef_launch_solve(e, iteration, lambda, /*do_step=*/true, stepsize, reuse, /*accumulated=*/pre_accumulated || onecoll))) return rc;
         pre_accumulated = false;
         ef_swap_point_copies(e);                                                          // the stepped idepths are the ones every later launch reads
         e->deltaF_nonzero = false;
@@ -1845,6 +1917,11 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         // linearise does not
         const bool dev_decide = defer && !zero_differs;
         if (!dev_decide && (rc = take_initial_energies())) return rc;          // (that path launches its statistics right behind the linearise)
+        const bool spec = onecoll && !zero_differs;
+        if (spec) {
+            // trial linearise, then its sums + the speculative apply / accumulate and the body's ONE collective (ef_sharded_message)
+            if ((rc = linearize_launch_kernels(e)) || (rc = ef_sharded_message(e, 1 - e->coll_cur, /*speculative=*/true))) return rc;
+        } else
         if ((rc = dev_decide ? linearize_launch_kernels(e) : linearize_launch(e, defer))) return rc;
         g_pt.stop(PT_ACCUM);
         // x is in pinned memory as soon as the solve kernel is through: mirror doStepFromBackup on the host (FrameHessian::setState,
@@ -1908,7 +1985,12 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             e->new_cur = 1 - e->new_cur;                                                  // the trial sets become the current ones
             e->st_cur = st_trial;
             ef_select_new_set(e, e->new_cur, e->new_cur);
-            if (!dev_decide && (rc = sdvgn_ef_apply_res(e))) return rc;      // (device-side test: the conditional apply is already queued)
+            if (spec) e->coll_cur = 1 - e->coll_cur;                          // the speculative message IS the accepted state's: applied, accumulated, reduced
+            else if (!dev_decide && (rc = sdvgn_ef_apply_res(e))) return rc;  // (device-side test: the conditional apply is already queued)
+            if (onecoll && !spec) {   // (idepth_zero differed before this trial: the body ran the two-collective way; rebuild the current message)
+                ef_use_coll(e, e->coll_cur);
+                if ((rc = ef_accumulate(e, true)) || (rc = ef_allreduce(e, e->acc_dev, (int)acc_count(e)))) return rc;
+            }
             lastEnergy = newEnergy; lastEnergyL = newEnergyL; lastEnergyM = newEnergyM;
             lambda *= 0.25;
             prev_rejected_clean = false;
@@ -1923,6 +2005,10 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
                 ef_refresh_frame_deltas(e);
             };
             if (relinearize_on_reject || zero_differs) restore_host_mirror(); else host_restore_pending = true;
+            if (spec) {   // take the speculative applyRes back before anything else touches the residual planes
+                const size_t slots_r = (size_t)nF * e->nP;
+                k_ef_apply_revert<<<(unsigned)((slots_r + 255) / 256), 256, 0, e->stream>>>(nF, e->nP, e->A, e->apply_bak);
+            }
             ef_swap_point_copies(e);
             std::swap(e->precalc_dev, e->precalc_alt);
             e->A.calib = e->calib_dev + e->st_cur;
@@ -1963,6 +2049,11 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
                 }
             }
             ef_select_new_set(e, e->new_cur, e->new_cur);
+            if (spec) {   // the per-point planes (Hdd / bd / Hcd sums, HdiF, bdSum: inputs of the next resubstitute) back to the kept state: they
+                // are local to the rank, so an accumulate WITHOUT its reduce -- the kept message buffer stays as it is
+                ef_use_coll(e, e->coll_cur);
+                if ((rc = ef_accumulate(e, /*with_reduce=*/false))) return rc;
+            }
             lambda *= 1e2;
             // the restored state is the one this body's system was built on, bit for bit (unless idepth_zero just changed, above)
             prev_rejected_clean = !zero_differs;

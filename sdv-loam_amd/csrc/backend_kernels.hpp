@@ -361,11 +361,16 @@ __global__ void __launch_bounds__(64) k_ef_optimize_immature(EFConst C, const fl
 // cond (may be NULL): the verdict of the device-side accept test; 0 = the step was rejected, nothing is applied.
 // verdict (may be NULL): the same verdict as a tagged word (seq << 1 | accept) that ANOTHER workgroup of this launch publishes
 // (k_ef_stats_apply): polled after this lane's loads are in flight.
+// bak (may be NULL): what this slot's applyRes overwrites -- flags, state, energy, JpJd -- is saved there first, so that a SPECULATIVE
+// apply (the sharded loop applies the trial linearisation before the all-reduce that carries the energy of the accept test, backend.hip)
+// can be taken back by k_ef_apply_revert; bak.fl[s] = 0xFF marks a slot the apply did not touch.
+struct ApplyBackup { uint8_t* fl; int8_t* st; float* en; float* JpJd; };
 __device__ __forceinline__ void apply_slot(int nF, int nP, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
                                            const int* __restrict__ phost, size_t s, const int* __restrict__ cond,
-                                           const unsigned* verdict = nullptr, unsigned seq = 0) {
+                                           const unsigned* verdict = nullptr, unsigned seq = 0, const ApplyBackup* bak = nullptr) {
     const size_t slots = (size_t)nF * nP;
     if (s >= slots) return;
+    if (bak) bak->fl[s] = 0xFF;
     int go = cond ? *cond : 1;
     const int hh = phost[s % nP];
     uint8_t fl = A.rflags[s];
@@ -396,6 +401,13 @@ __device__ __forceinline__ void apply_slot(int nF, int nP, const EFArrays& A, co
     if (np_h == 0) return;   // host frame not in this rank's shard
     if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED)) return;
     if (st == RS_OOB) return;
+    if (bak) {
+        bak->fl[s] = fl; bak->st[s] = A.rstate[s]; bak->en[s] = A.renergy[s];
+        if ((sn & RS_MASK) == RS_IN) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) bak->JpJd[(size_t)i * slots + s] = A.JpJd[(size_t)i * slots + s];
+        }
+    }
     if ((sn & RS_MASK) == RS_IN) {
         fl |= RF_ACTIVE;
         fl ^= RF_SEL;                                   // takeDataF: swap J with the residual's freshly linearised J
@@ -411,6 +423,24 @@ __device__ __forceinline__ void apply_slot(int nF, int nP, const EFArrays& A, co
 __global__ void __launch_bounds__(256) k_ef_apply(int nF, int nP, EFArrays A, const PrecalcDev* __restrict__ precalc,
                                                   const int* __restrict__ phost, const int* __restrict__ cond) {
     apply_slot(nF, nP, A, precalc, phost, (size_t)blockIdx.x * blockDim.x + threadIdx.x, cond);
+}
+__global__ void __launch_bounds__(256) k_ef_apply_backup(int nF, int nP, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                         const int* __restrict__ phost, ApplyBackup bak) {
+    apply_slot(nF, nP, A, precalc, phost, (size_t)blockIdx.x * blockDim.x + threadIdx.x, nullptr, nullptr, 0, &bak);
+}
+// takes a speculative applyRes back (the step was rejected): every touched slot gets its flags, state, energy and -- if the apply had
+// swapped the Jacobian buffers -- its JpJd back
+__global__ void __launch_bounds__(256) k_ef_apply_revert(int nF, int nP, EFArrays A, ApplyBackup bak) {
+    const size_t slots = (size_t)nF * nP, s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= slots) return;
+    const uint8_t old = bak.fl[s];
+    if (old == 0xFF) return;
+    const uint8_t cur = A.rflags[s];
+    if ((cur ^ old) & RF_SEL) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) A.JpJd[(size_t)i * slots + s] = bak.JpJd[(size_t)i * slots + s];
+    }
+    A.rflags[s] = old; A.rstate[s] = bak.st[s]; A.renergy[s] = bak.en[s];
 }
 
 // Per-point sums of addPoint<0> (active, not linearised) and addPoint<1> (active, linearised), then the head of the

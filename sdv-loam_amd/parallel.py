@@ -2,9 +2,11 @@
 
 One process per GPU.  Key-frames are sharded by HOST frame: rank r linearises / accumulates only the residuals whose
 host frame lies in its range (target images are replicated on every rank).  Per Gauss-Newton iteration the ranks sum
-one packed fp64 accumulator buffer (top Gram nF^2 x 121 | Schur Gram nF x 1431 | resInA -- 154 kB at nF = 8) with a
-single all-reduce (RCCL over xGMI through torch.distributed's "nccl" backend; latency-bound at this size), and 4
-doubles of energy / step statistics once per linearizeAll.  The small solve then runs redundantly on every rank on
+ONE packed fp64 message -- accumulators (top Gram nF^2 x 121 | Schur Gram nF x 1431 | resInA: 154 kB at nF = 8) | the 4 energy / step
+statistics of the trial linearisation | the candidates of setNewFrameEnergyTH's quantile (nP) -- with a single all-reduce (RCCL over xGMI
+through the library's own ncclAllReduce or torch.distributed's "nccl" backend; latency-bound at this size): sdvgn_ef_optimize applies and
+accumulates the trial speculatively, so that the energy the accept test needs and the accumulators the next solve needs travel together
+(one_collective=False keeps the earlier two-collective loop for comparison).  The small solve then runs redundantly on every rank on
 bitwise-identical inputs, so all ranks take the same accept / reject decisions without further communication.
 """
 import ctypes as C
@@ -74,7 +76,7 @@ class ShardedEnergyFunctional:
     All library work and the collectives are issued on one torch stream (`self.stream`), so the all-reduce is ordered
     after the accumulate kernels and before the read-back of the packed buffer without host synchronisation."""
 
-    def __init__(self, W, rank, world, device, group=None, force_collective=False):
+    def __init__(self, W, rank, world, device, group=None, force_collective=False, one_collective=True):
         import torch
         import torch.distributed as dist
         from .backend_api import EnergyFunctional
@@ -89,6 +91,18 @@ class ShardedEnergyFunctional:
         self.stream.synchronize()
         L = self.ef.L
         self.ef._check(L.sdvgn_ef_set_external_buffers(self.ef.h_, self.acc.data_ptr(), self.acc.numel(), self.stats.data_ptr(), self.stats.numel()))
+        # ONE collective per loop body (BASELINE.json north_star): two message buffers [accumulators | 4 statistics | quantile candidates];
+        # sdvgn_ef_optimize applies + accumulates the trial speculatively and all-reduces one message per body (+ one per call)
+        self.one_collective = bool(one_collective)
+        self.coll = None
+        if self.one_collective:
+            L.sdvgn_ef_collective_stride.argtypes = [C.c_void_p]
+            L.sdvgn_ef_set_collective_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+            stride = L.sdvgn_ef_collective_stride(self.ef.h_)
+            with torch.cuda.stream(self.stream):
+                self.coll = torch.zeros(2 * stride, dtype=torch.float64, device="cuda")
+            self.stream.synchronize()
+            self.ef._check(L.sdvgn_ef_set_collective_buffer(self.ef.h_, self.coll.data_ptr(), self.coll.numel()))
         self.max_points = W.nP
         self.lo, self.hi = shard_hosts(W.nF, world)[rank]
         self.ef.set_host_range(self.lo, self.hi)
@@ -119,9 +133,16 @@ class ShardedEnergyFunctional:
 
             via_host = dist.get_backend(self.group) == "gloo"   # test rigs without RCCL peers (e.g. two ranks sharing one GPU)
 
+            coll_ptr = self.coll.data_ptr() if self.coll is not None else 0
+            coll_n = self.coll.numel() if self.coll is not None else 0
+
             def _allreduce(user, buf, count):
-                assert buf in (acc_ptr, stats_ptr)
-                t = self.acc[:count] if buf == acc_ptr else self.stats[:count]
+                if coll_n and coll_ptr <= buf < coll_ptr + 8 * coll_n:           # a message buffer of the one-collective loop
+                    off = (buf - coll_ptr) // 8
+                    t = self.coll[off:off + count]
+                else:
+                    assert buf in (acc_ptr, stats_ptr)
+                    t = self.acc[:count] if buf == acc_ptr else self.stats[:count]
                 with torch.cuda.stream(self.stream):
                     if via_host:
                         h = t.cpu()                      # synchronises this stream: the accumulate kernels are done

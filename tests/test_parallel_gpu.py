@@ -14,14 +14,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CAL = dict(fx=400., fy=410., cx=319.5, cy=119.5)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, one_collective=True):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
     from sdv_loam_amd import parallel, synthetic as syn
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    W = syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=2, calib=CAL)
-    S = parallel.ShardedEnergyFunctional(W, rank, world, 0)
+    W = syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=2, calib=CAL, state_sigma=1e-3, idepth_sigma=0.01)
+    S = parallel.ShardedEnergyFunctional(W, rank, world, 0, one_collective=one_collective)
     tr = S.optimize(6, want_trace=True)
     vs, st, idp = S.ef.state()
     # every rank holds the full frame / calibration state; point inverse depths only for its own hosts
@@ -33,13 +33,16 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_one_gpu_reproduce_single_process(sdvgn_lib):
+@pytest.mark.parametrize("one_collective", [True, False])
+def test_two_ranks_one_gpu_reproduce_single_process(sdvgn_lib, one_collective):
+    """one_collective: the loop sends ONE message per body (+ one per call) -- accumulators, statistics and quantile candidates together,
+    the trial applied and accumulated speculatively (north_star's single all-reduce); False: the earlier two-collective loop."""
     import torch.multiprocessing as mp
     from sdv_loam_amd import backend_api, synthetic as syn
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29900 + (os.getpid() % 90)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port + (7 if one_collective else 0), q, one_collective)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=500) for _ in range(2)]
@@ -47,17 +50,21 @@ def test_two_ranks_one_gpu_reproduce_single_process(sdvgn_lib):
         p.join(timeout=60)
         assert p.exitcode == 0
     res.sort(key=lambda r: r[0])
-    W = syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=2, calib=CAL)
+    W = syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=2, calib=CAL, state_sigma=1e-3, idepth_sigma=0.01)
     G = backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
     tr = G.optimize(6)
     vs, st, idp = G.state()
+    assert (tr[:, 2] == 1).any() and (tr[:, 2] == 0).any()                               # accepted and rejected steps: both paths of the speculation
     for rank, trr, vsr, str_, idr, idx, ncoll in res:
         assert len(trr) == len(tr) and np.array_equal(trr[:, :3], tr[:, :3])            # iteration, lambda, accepted
         assert np.allclose(trr[:, 3:6], tr[:, 3:6], rtol=1e-9, atol=1e-9)                # energies (sums in another grouping)
         assert np.allclose(trr[:, 7:], tr[:, 7:], rtol=1e-6, atol=1e-12)                 # increments
         assert np.allclose(vsr, vs, rtol=1e-10) and np.allclose(str_, st, rtol=1e-7, atol=1e-12)
         assert np.allclose(idr, idp[idx], rtol=1e-6)
-        assert ncoll >= 2 * len(tr)                                                      # >= one accumulator + one statistics all-reduce per iteration
+        if one_collective:
+            assert ncoll == len(tr) + 1                                                  # exactly one all-reduce per loop body + one per call
+        else:
+            assert ncoll >= 2 * len(tr)                                                  # one accumulator + one statistics all-reduce per iteration
     assert np.array_equal(res[0][1], res[1][1])                                          # both ranks took bitwise the same path
 
 
