@@ -702,8 +702,12 @@ def main():
             runners[0].reload(Wh)
             import torch.distributed as dist
             via = "RCCL, issued by the library" if getattr(runners[0], "direct_rccl", False) else ("torch.distributed/%s callback" % dist.get_backend())
-            parallelism = "host-keyframe shards %s + 2 all-reduces per iteration (154 kB packed accumulators; 128 kB statistics + threshold candidates) via %s" % (
-                shard_hosts(Wh.nF, world), via)
+            if getattr(runners[0], "one_collective", False):
+                parallelism = "host-keyframe shards %s + ONE all-reduce per loop body (282 kB fp64: packed accumulators | 4 statistics | quantile candidates; trial applied and accumulated speculatively) via %s" % (
+                    shard_hosts(Wh.nF, world), via)
+            else:
+                parallelism = "host-keyframe shards %s + 2 all-reduces per iteration (154 kB packed accumulators; 128 kB statistics + threshold candidates) via %s" % (
+                    shard_hosts(Wh.nF, world), via)
         except Exception as ex:  # noqa: BLE001
             runners = None
             parallelism, scaling = "replicas x%d (sharded path unavailable: %r)" % (world, ex), "weak"

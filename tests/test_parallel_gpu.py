@@ -147,3 +147,21 @@ def test_track_team_beside_running_back_end(sdvgn_lib, orc):
         if oko:
             assert rel_err(orc.se3_log(orc.se3_mul(p0[b], orc.se3_inverse(poses[b]))), orc.se3_log(orc.se3_mul(po, orc.se3_inverse(poses[b])))) < 1e-4
     print("team fallbacks during the run:", G.team_fallbacks(), "back-end bodies:", bodies[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus2_from_a_bare_shell(sdvgn_lib):
+    """`python bench.py --gpus 2` with no launcher around it starts its own two ranks (torch.distributed.run), runs the sharded protocol and
+    prints ONE JSON line with n_gpus = 2 (SDVGN_BENCH_SHARE_GPU=1: both ranks on this box's one GPU, collectives through gloo)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SDVGN_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "6", "--quick", "--no-cpu"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 12 and out["value"] > 0
+    assert "ONE all-reduce per loop body" in out["config"]["parallelism"] and out["scaling"] == "strong"
