@@ -197,6 +197,7 @@ def pmc_child():
     the optimize loop instead, so that every kernel of the loop appears in the counters)."""
     import torch  # noqa: F401
     W, G = backend_setup(0)
+    G.set_arith(int(os.environ.get("SDVGN_BENCH_ARITH", "0")))
     if os.environ.get("SDVGN_PMC_LOOP"):
         G.optimize(10, fixed_its=True, want_trace=False)
     else:
@@ -290,6 +291,17 @@ def measure_inloop_kernel(kernel="k_ef_linearize", timeout=240, arith=0):
         du = np.array([r[0] for r in con.execute("select duration from kernels where name like ?", ("%" + kernel + "%",))], np.float64) / 1e6
         if not len(du):
             return None
+        try:   # the per-kernel summary of this trace as a file (gpurun_out/, copied to profiles/ by hand): what roofline.achieved is computed from
+            rows = con.execute("select name, count(*), avg(duration), sum(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc").fetchall()
+            tot = sum(r[3] for r in rows)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "inloop_trace_summary_arith%d.txt" % arith), "w") as fsum:
+                fsum.write("# rocprofv3 --kernel-trace -- python bench.py --trace-child   (SDVGN_BENCH_ARITH=%d; the headline protocol alone: 8 fresh windows x optimize(6))\n" % arith)
+                fsum.write("%-100s %8s %12s %10s %10s %10s %6s\n" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
+                for r in rows[:30]:
+                    fsum.write("%-100s %8d %12.1f %10.3f %10.3f %10.3f %6.2f\n" % (r[0][:100], r[1], r[3] / 1e3, r[2] / 1e3, r[4] / 1e3, r[5] / 1e3, 100 * r[3] / tot))
+        except Exception:  # noqa: BLE001
+            pass
         return dict(mean_ms=float(du.mean()), median_ms=float(np.median(du)), p90_ms=float(np.percentile(du, 90)), launches=int(len(du)),
                     source="rocprofv3 --kernel-trace of the protocol alone (8 windows x optimize(6))")
     except Exception as ex:  # noqa: BLE001

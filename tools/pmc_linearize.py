@@ -14,6 +14,8 @@ import tempfile
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 GROUPS = [
     ["GRBM_GUI_ACTIVE", "SQ_WAVES", "SQ_BUSY_CYCLES"],
+    ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU"],
+    ["SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS"],
     ["SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVE_CYCLES"],
     ["SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VMEM"],
     ["SQ_INST_CYCLES_VMEM_RD", "SQ_INST_CYCLES_VMEM_WR"],
