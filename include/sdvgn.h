@@ -476,6 +476,10 @@ int sdvgn_ef_set_allreduce(sdvgn_ef* ef, void (*fn)(void* user, double* buf_dev,
  * id128 == NULL drops the communicator again. */
 int sdvgn_rccl_unique_id(unsigned char* out128);
 int sdvgn_ef_init_rccl(sdvgn_ef* ef, const unsigned char* id128, int rank, int world);
+/* Handles of one process initialised with the same id share ONE communicator (reference-counted; the last handle to drop it destroys it):
+ * only the first sdvgn_ef_init_rccl with an id is collective.  An id whose communicator is gone must not be used again (like any
+ * ncclUniqueId); sdvgn_rccl_comm_alive tells whether this process still holds the communicator of `id128` (1) or not (0). */
+int sdvgn_rccl_comm_alive(const unsigned char* id128);
 /* restrict this rank's work to host frames [h0,h1) (cfg4: frames sharded across GPUs); default all. */
 int sdvgn_ef_set_host_range(sdvgn_ef* ef, int h0, int h1);
 

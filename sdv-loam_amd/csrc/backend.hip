@@ -853,14 +853,31 @@ static RcclApi& rccl_api() {
     api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy;
     return api;
 }
+// One communicator per (process, id): every handle initialised with the same 128-byte id shares it (reference-counted) -- a process that
+// optimises many sharded windows pays ncclCommInitRank once, not once per window.  The last handle to let go destroys it.
+namespace {
+struct SharedComm { unsigned char id[NCCL_UNIQUE_ID_BYTES]; ncclComm_t comm; int refs; };
+std::mutex g_comm_mu;
+std::vector<SharedComm> g_comms;
+}
+static void ef_release_comm(sdvgn_ef* e) {
+    if (!e->rccl_comm) return;
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    for (size_t i = 0; i < g_comms.size(); ++i)
+        if (g_comms[i].comm == e->rccl_comm) {
+            if (--g_comms[i].refs == 0) { rccl_api().CommDestroy(g_comms[i].comm); g_comms.erase(g_comms.begin() + (long)i); }
+            break;
+        }
+    e->rccl_comm = nullptr;
+}
 static inline bool ef_sharded(const sdvgn_ef* e) { return e->allreduce != nullptr || e->rccl_comm != nullptr; }
 // sum `count` doubles at buf_dev over all ranks, ordered on the library stream
 static int ef_allreduce(sdvgn_ef* e, double* buf_dev, int count) {
+    ++e->n_collectives;
     if (e->rccl_comm) {
         const ncclResult_t r = rccl_api().AllReduce(buf_dev, buf_dev, (size_t)count, ncclDouble, ncclSum, e->rccl_comm, e->stream);
         return r == ncclSuccess ? SDVGN_OK : SDVGN_E_STATE;
     }
-    ++e->n_collectives;
     if (e->allreduce) e->allreduce(e->allreduce_user, buf_dev, count);
     return SDVGN_OK;
 }
@@ -1009,7 +1026,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
     if (!e->own_stats) e->stats_dev = nullptr;
     hipSetDevice(e->device);
     hipStreamSynchronize(e->stream);
-    if (e->rccl_comm) { rccl_api().CommDestroy(e->rccl_comm); e->rccl_comm = nullptr; }
+    ef_release_comm(e);
     void* ptrs[] = {e->pu, e->pv, e->pidz, e->pid, e->pidepth_backup, e->ppriorF, e->pdeltaF, e->pcolor, e->pweights, e->psensor, e->rflags,
                     e->rstate, e->rstate_new, e->rmatcher, e->renergy, e->renergy_new, e->renergy_wo, e->rres_toZero, e->J, e->JpJd, e->pHddA,
                     e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->images, e->img_stage,
@@ -1468,20 +1485,34 @@ int sdvgn_rccl_unique_id(unsigned char* out128) {
 int sdvgn_ef_init_rccl(sdvgn_ef* e, const unsigned char* id128, int rank, int world) {
     if (e && !e->host_only && !id128) {   // id128 == NULL: drop the communicator, back to the callback / single-GPU behaviour
         EF_DEVICE(e);
-        if (e->rccl_comm) { hipStreamSynchronize(e->stream); rccl_api().CommDestroy(e->rccl_comm); e->rccl_comm = nullptr; }
+        if (e->rccl_comm) { hipStreamSynchronize(e->stream); ef_release_comm(e); }
         return SDVGN_OK;
     }
     if (!e || e->host_only || world < 1 || rank < 0 || rank >= world) return SDVGN_E_ARG;
     RcclApi& api = rccl_api();
     if (!api.ok) return SDVGN_E_STATE;
     EF_DEVICE(e);
-    if (e->rccl_comm) { api.CommDestroy(e->rccl_comm); e->rccl_comm = nullptr; }
+    if (e->rccl_comm) { hipStreamSynchronize(e->stream); ef_release_comm(e); }
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    for (SharedComm& c : g_comms)
+        if (!std::memcmp(c.id, id128, NCCL_UNIQUE_ID_BYTES)) { ++c.refs; e->rccl_comm = c.comm; return SDVGN_OK; }   // not collective: the communicator exists
     ncclUniqueId id;
     std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
     ncclComm_t comm = nullptr;
     if (api.CommInitRank(&comm, world, id, rank) != ncclSuccess) return SDVGN_E_STATE;   // collective: every rank calls it
+    SharedComm sc;
+    std::memcpy(sc.id, id128, NCCL_UNIQUE_ID_BYTES); sc.comm = comm; sc.refs = 1;
+    g_comms.push_back(sc);
     e->rccl_comm = comm;
     return SDVGN_OK;
+}
+
+int sdvgn_rccl_comm_alive(const unsigned char* id128) {
+    if (!id128) return 0;
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    for (const SharedComm& c : g_comms)
+        if (!std::memcmp(c.id, id128, NCCL_UNIQUE_ID_BYTES)) return 1;
+    return 0;
 }
 
 int sdvgn_ef_accumulator_count(sdvgn_ef* e) { return e ? (int)acc_count(e) : SDVGN_E_ARG; }
@@ -2125,7 +2156,7 @@ struct BatchPool {
         for (std::thread& t : workers) t.join();
     }
 };
-BatchPool& batch_pool() { static BatchPool* p = new BatchPool(); return *p; }   // (leaked on purpose: no join at library unload)
+static BatchPool& batch_pool() { static BatchPool* p = new BatchPool(); return *p; }   // (leaked on purpose: no join at library unload)
 }  // namespace
 
 int sdvgn_ef_optimize_batch(sdvgn_ef* const* handles, int B, int mnumOptIts, int flags, int* its_out) {

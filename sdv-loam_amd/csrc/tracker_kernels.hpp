@@ -307,25 +307,36 @@ __device__ __forceinline__ void point_features_fast(const LevelParams& P, const 
 // Fragment maps (cdna guide section 3): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D: col=l&15, row=4*(l>>4)+reg.
 // ----------------------------------------------------------------------------------------------------
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-constexpr int kTrkTileStride = 66;
-constexpr int kTrkTileFloats = 16 * kTrkTileStride + 64;   // tile + weight row, per wave
+constexpr int kTrkTileStride = 68;   // floats per feature row: a multiple of 4 (ds_read_b128 fragments), 4 banks apart from row to row
+constexpr int kTrkTileFloats = 16 * kTrkTileStride + 64;   // tile + weight row, per wave (16-byte aligned)
 
+// MFMA round ks of a wave's 64 points takes the four points {ks, 16 + ks, 32 + ks, 48 + ks}: lane (fi = lane & 15, kq = lane >> 4) then needs
+// feature fi of the 16 CONSECUTIVE points 16 kq .. 16 kq + 15 -- four 16-byte LDS reads for the values and four for their weights, all issued
+// before the first MFMA (the earlier form read one float per round behind a wait: 32 serial LDS latencies per 64 points).
+// Row 15 of A is all ones (column sums): the tile's feature row 15 holds 1.0 and the lanes with fi = 15 take their "weights" from that row.
 template <int MODE = PREC_F32>
-__device__ __forceinline__ void wave_gram_points(const float* f, float w, float* tile /*wave-private*/, f32x4_t& G) {
+__device__ __forceinline__ void wave_gram_points(const float* f, float w, float* tile /*wave-private, 16-byte aligned*/, f32x4_t& G) {
     const int lane = threadIdx.x & 63;
     float* wrow = tile + 16 * kTrkTileStride;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) tile[k * kTrkTileStride + lane] = f[k];
+    for (int k = 0; k < 15; ++k) tile[k * kTrkTileStride + lane] = f[k];
+    tile[15 * kTrkTileStride + lane] = 1.0f;
     wrow[lane] = w;
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed
     __builtin_amdgcn_wave_barrier();
     const int fi = lane & 15, kq = lane >> 4;
-#pragma unroll 4
+    const float4* fsrc = reinterpret_cast<const float4*>(tile + fi * kTrkTileStride + 16 * kq);
+    const float4* wsrc = reinterpret_cast<const float4*>((fi == 15 ? tile + 15 * kTrkTileStride : wrow) + 16 * kq);
+    float fv[16], wv[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 a = fsrc[q], b = wsrc[q];
+        fv[4 * q + 0] = a.x; fv[4 * q + 1] = a.y; fv[4 * q + 2] = a.z; fv[4 * q + 3] = a.w;
+        wv[4 * q + 0] = b.x; wv[4 * q + 1] = b.y; wv[4 * q + 2] = b.z; wv[4 * q + 3] = b.w;
+    }
+#pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-        const int k = ks * 4 + kq;
-        const float fv = tile[fi * kTrkTileStride + k];
-        const float av = (fi == 15) ? 1.0f : fv * wrow[k];
-        G = __builtin_amdgcn_mfma_f32_16x16x4f32(av, fv, G, 0, 0, 0);
+        G = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[ks] * wv[ks], fv[ks], G, 0, 0, 0);
         if (MODE == PREC_H_ACC) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) G[q] = __half2float(__float2half(G[q]));
@@ -374,7 +385,7 @@ template <bool WRITE_TERMS, int MODE = PREC_F32, int ARITH = 0>
 __global__ void __launch_bounds__(256) k_res_gs(const float4* __restrict__ pc, const float* __restrict__ img,
                                                 const LevelParams* __restrict__ params, float* __restrict__ partial,
                                                 float* __restrict__ terms, int* __restrict__ status, const ProblemPtrs* __restrict__ ptrs = nullptr) {
-    __shared__ float smem[4 * kTrkTileFloats];
+    __shared__ __attribute__((aligned(16))) float smem[4 * kTrkTileFloats];
     const int prob = blockIdx.y;
     const LevelParams P = params[prob];
     if (ptrs) { pc = ptrs[prob].pc; img = ptrs[prob].img; }

@@ -19,6 +19,9 @@ SC_E = SC_N * (SC_N + 1) // 2   # its upper triangle, row-major (1431)
 MAX_FRAMES = 8
 
 
+_GROUP_IDS = []   # (process group, 128-byte RCCL id) of the communicators this process created through sdvgn_ef_init_rccl
+
+
 def direct_rccl_disabled():
     import os
     return os.environ.get("SDVGN_NO_DIRECT_RCCL") == "1"
@@ -113,15 +116,23 @@ class ShardedEnergyFunctional:
         if (world > 1 or force_collective) and dist.get_backend(self.group) == "nccl" and not direct_rccl_disabled():
             # preferred: the library issues ncclAllReduce itself on its stream (no callback / Python in the iteration).  Rank 0's id
             # travels through the existing process group; any failure falls back to the callback path below.
-            ident = [None]
-            if rank == 0:
-                buf = (C.c_ubyte * 128)()
-                if L.sdvgn_rccl_unique_id(buf) == 0:
-                    ident = [bytes(buf)]
-            dist.broadcast_object_list(ident, src=0, group=self.group)      # always executed by every rank (None = no RCCL: all fall back)
+            # The communicator is shared by every sharded window of this process and group (the library reference-counts it by id): only
+            # the first window pays ncclCommInitRank.  An id may be reused only while its communicator is alive on EVERY rank -- the ranks
+            # agree on that with one MIN all-reduce (object lifetimes, hence the answer, could differ from rank to rank).
+            cached = next((i for g, i in _GROUP_IDS if g is self.group), None)
+            alive = torch.tensor([1 if (cached is not None and L.sdvgn_rccl_comm_alive(cached) == 1) else 0], device="cuda")
+            dist.all_reduce(alive, op=dist.ReduceOp.MIN, group=self.group)
+            ident = [cached if alive.item() == 1 else None]
+            if ident[0] is None:
+                if rank == 0:
+                    buf = (C.c_ubyte * 128)()
+                    if L.sdvgn_rccl_unique_id(buf) == 0:
+                        ident = [bytes(buf)]
+                dist.broadcast_object_list(ident, src=0, group=self.group)  # always executed by every rank (None = no RCCL: all fall back)
+                _GROUP_IDS[:] = [(g, i) for g, i in _GROUP_IDS if g is not self.group][-3:] + [(self.group, ident[0])]
             if ident[0] is not None:
                 idbuf = (C.c_ubyte * 128).from_buffer_copy(ident[0])
-                self.direct_rccl = L.sdvgn_ef_init_rccl(self.ef.h_, idbuf, rank, world) == 0   # collective (ncclCommInitRank)
+                self.direct_rccl = L.sdvgn_ef_init_rccl(self.ef.h_, idbuf, rank, world) == 0   # collective the first time (ncclCommInitRank)
                 if world > 1:   # agree on the outcome: one failing rank sends everybody to the callback path
                     okt = torch.tensor([1 if self.direct_rccl else 0], device="cuda")
                     dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=self.group)

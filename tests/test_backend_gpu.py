@@ -439,7 +439,22 @@ def test_sharded_path_single_rank_nccl(api, orc, window, direct, monkeypatch):
         tg = G.optimize(6)
         assert np.array_equal(ts, tg)
         assert np.array_equal(S.ef.state()[2], G.state()[2])
-        del S
+        if direct:
+            # a second sharded window of the same process group shares the first one's communicator (reference-counted in the library:
+            # no second ncclCommInitRank) and outlives it
+            from sdv_loam_amd import parallel
+            ident = next(i for g, i in parallel._GROUP_IDS if g is S.group)
+            S2 = ShardedEnergyFunctional(window, 0, 1, 0, force_collective=True)
+            assert S2.direct_rccl and next(i for g, i in parallel._GROUP_IDS if g is S2.group) == ident
+            del S
+            assert S2.ef.L.sdvgn_rccl_comm_alive(ident) == 1
+            assert np.array_equal(S2.optimize(6, want_trace=True), tg)
+            del S2
+            import gc
+            gc.collect()
+            assert G.L.sdvgn_rccl_comm_alive(ident) == 0
+        else:
+            del S
     finally:
         dist.destroy_process_group()
 
