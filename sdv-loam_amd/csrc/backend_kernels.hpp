@@ -40,7 +40,7 @@ namespace sdvgn {
 
 constexpr int kMaxFrames = 8;
 constexpr int kJPlanes = 24;   // resF(2) Jpdxi[0](6) Jpdxi[1](6) Jpdc[0](4) Jpdc[1](4) Jpdd(2)
-constexpr int kTileStride = 66;
+constexpr int kTileStride = 68;   // floats per feature row of a Gram tile: a multiple of 4 (16-byte fragment reads), 4 banks apart from row to row
 
 enum : int { RS_IN = 0, RS_OOB = 1, RS_OUTLIER = 2 };
 // bit kept next to state_NewState in its plane: the linearisation found wJI2_sum < 2 (Residuals.cpp:212), which k_ef_reclassify needs
@@ -478,21 +478,46 @@ __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, 
         mine = precalc[h * C.nF + h].np != 0;   // host frame in this rank's shard
         if (MODE == 2) mine = mine && mask[p] != 0;
     }
+    // this wave's two targets (wave, wave + 4): the flags of both in one round trip, then every Jacobian value of both in one batch of
+    // independent loads (the per-target form was flag -> values -> flag -> values: four dependent round trips per workgroup)
+    static_assert(kMaxFrames == 8, "two targets per wave");
+    uint8_t fl2[2] = {0, 0};
+    size_t s2[2] = {0, 0};
 #pragma unroll
-    for (int t = wave; t < kMaxFrames; t += 4) {
+    for (int k = 0; k < 2; ++k) {
+        const int t = wave + 4 * k;
+        if (mine && t < C.nF) { s2[k] = (size_t)t * C.nP + p; fl2[k] = A.rflags[s2[k]]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float jd[2][2], jc0[2][4], jc1[2][4], jr[2][2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint8_t fl = fl2[k];
+        const bool on = (fl & RF_EXISTS) && (fl & RF_ACTIVE);
+        const float* Je = A.J + (size_t)((fl & RF_SEL) ? 1 : 0) * kJPlanes * slots + s2[k];
+        jd[k][0] = on ? Je[22 * slots] : 0.0f; jd[k][1] = on ? Je[23 * slots] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { jc0[k][i] = on ? Je[(14 + i) * slots] : 0.0f; jc1[k][i] = on ? Je[(18 + i) * slots] : 0.0f; }
+        const bool lin = MODE != 2 && on && !(fl & RF_LINEARIZED);
+        jr[k][0] = lin ? Je[0] : 0.0f; jr[k][1] = lin ? Je[slots] : 0.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+    const int t = wave + 4 * k;
     float v[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) v[i] = 0.0f;   // bdA HddA HcdA[4] bdL HddL HcdL[4] ngood
     if (mine && t < C.nF) {
-        const size_t s = (size_t)t * C.nP + p;
-        const uint8_t fl = A.rflags[s];
+        const size_t s = s2[k];
+        const uint8_t fl = fl2[k];
         if ((fl & RF_EXISTS) && (fl & RF_ACTIVE)) {
             v[12] = 1.0f;
             const float* Je = A.J + (size_t)((fl & RF_SEL) ? 1 : 0) * kJPlanes * slots + s;
-            const float d0 = Je[22 * slots], d1 = Je[23 * slots];
+            const float d0 = jd[k][0], d1 = jd[k][1];
             float c0[4], c1[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { c0[i] = Je[(14 + i) * slots]; c1[i] = Je[(18 + i) * slots]; }
+            for (int i = 0; i < 4; ++i) { c0[i] = jc0[k][i]; c1[i] = jc1[k][i]; }
             if (MODE == 2) {
                 const float r0 = A.rres_toZero[s], r1 = A.rres_toZero[slots + s];
                 v[6] = r0 * d0 + r1 * d1;
@@ -500,7 +525,7 @@ __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[8 + i] = c0[i] * d0 + c1[i] * d1;
             } else if (!(fl & RF_LINEARIZED)) {
-                const float r0 = Je[0], r1 = Je[slots];
+                const float r0 = jr[k][0], r1 = jr[k][1];
                 v[0] = r0 * d0 + r1 * d1;
                 v[1] = d0 * d0 + d1 * d1;
 #pragma unroll
@@ -570,32 +595,37 @@ __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, 
 // ------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// MFMA round (q, j) takes the rows {4q + j, 16 + 4q + j, 32 + 4q + j, 48 + 4q + j} of the tile: lane (f, kq) then reads four CONSECUTIVE rows
+// 16 kq + 4q .. + 3 of its feature with one 16-byte LDS load per feature tile, issued ahead of the four rounds that use them.
+__device__ __forceinline__ f32x4 lds_frag4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 template <int NT>
-__device__ __forceinline__ void gram_tile_accumulate(const float* __restrict__ tileF, const float* __restrict__ tileW,
+__device__ __forceinline__ void gram_tile_accumulate(const float* __restrict__ tileF /*16-byte aligned*/, const float* __restrict__ tileW,
                                                      f32x4* acc) {
     const int lane = threadIdx.x & 63;
     const int f = lane & 15, kq = lane >> 4;
-#pragma unroll 4
-    for (int ks = 0; ks < 16; ++ks) {
-        const int k = ks * 4 + kq;
-        float frag[NT];
 #pragma unroll
-        for (int ti = 0; ti < NT; ++ti) frag[ti] = tileF[(ti * 16 + f) * kTileStride + k];
-        const float w = tileW ? tileW[k] : 1.0f;
-        int a = 0;
+    for (int q = 0; q < 4; ++q) {
+        f32x4 frag[NT];
 #pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
+        for (int ti = 0; ti < NT; ++ti) frag[ti] = lds_frag4(tileF + (ti * 16 + f) * kTileStride + 16 * kq + 4 * q);
+        const f32x4 w4 = tileW ? lds_frag4(tileW + 16 * kq + 4 * q) : (f32x4){1.0f, 1.0f, 1.0f, 1.0f};
 #pragma unroll
-            for (int tj = ti; tj < NT; ++tj) {
-                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ti] * w, frag[tj], acc[a], 0, 0, 0);
-                ++a;
-            }
+        for (int j = 0; j < 4; ++j) {
+            int a = 0;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < NT; ++tj) {
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ti][j] * w4[j], frag[tj][j], acc[a], 0, 0, 0);
+                    ++a;
+                }
+        }
     }
 }
 
 // top Gram: grid = (chunks, nF*nF), block = 256 (4 waves x 64 residual slots).  Features (16, 11 live):
 // 0-3 Jpdc, 4-9 Jpdxi, 10 res; two row sets (x and y).  partial: [pair][chunk][256] floats (row-major 16x16).
-struct TopGramSmem { float tile[4][2][16 * kTileStride]; float red[4][256]; int s_n[4]; };
+struct TopGramSmem { alignas(16) float tile[4][2][16 * kTileStride]; float red[4][256]; int s_n[4]; };
 
 // body for workgroup (bx of gx chunks, pair).  MODE 0: addPoint<0>; MODE 2: addPoint<2> over the points with mask[p] != 0 (all
 // active residuals, residual feature = res_toZeroF).
@@ -692,6 +722,28 @@ template <int A> struct ScTile {   // a-th upper tile of the 4x4 tile grid, row-
     static constexpr int tj = A < 4 ? A : (A < 7 ? A - 3 : (A < 9 ? A - 5 : 3));
 };
 
+// The Schur-Gram step of one wave on a staged [64 features][64 points] tile: the 2-3 output tiles the wave owns (ScTile), rows taken in the
+// order of gram_tile_accumulate (16-byte fragment reads, four MFMA rounds per read).
+template <int WAVE>
+__device__ __forceinline__ void sc_tile_accumulate(const float* tile, const float* wrow, f32x4* acc) {
+    constexpr int NQ = (WAVE + 8 < 10) ? 3 : 2;
+    const int lane = threadIdx.x & 63;
+    const int f = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 frag[4];
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) frag[ti] = lds_frag4(tile + (ti * 16 + f) * kTileStride + 16 * kq + 4 * q);
+        const f32x4 w4 = lds_frag4(wrow + 16 * kq + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ScTile<WAVE>::ti][j] * w4[j], frag[ScTile<WAVE>::tj][j], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ScTile<WAVE + 4>::ti][j] * w4[j], frag[ScTile<WAVE + 4>::tj][j], acc[1], 0, 0, 0);
+            if (NQ == 3) acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ScTile<(WAVE + 8) % 10>::ti][j] * w4[j], frag[ScTile<(WAVE + 8) % 10>::tj][j], acc[2], 0, 0, 0);
+        }
+    }
+}
+
 // body of k_ef_sc_gram for one wave; WAVE is a compile-time constant so that feature / tile indices fold
 template <int WAVE, int MODE = 0>
 __device__ __forceinline__ void sc_gram_wave(const EFConst& C, const EFArrays& A, int P0, int begin, int end, float* tile, float* wrow,
@@ -740,18 +792,7 @@ __device__ __forceinline__ void sc_gram_wave(const EFConst& C, const EFArrays& A
         if (WAVE == 3) wrow[lane] = stage_w;
         __syncthreads();
         if (base + 64 < end) fetch(base + 64);   // next tile's loads fly while this one is multiplied
-        const int f = lane & 15, kq = lane >> 4;
-#pragma unroll 4
-        for (int ks = 0; ks < 16; ++ks) {
-            const int k = ks * 4 + kq;
-            float frag[4];
-#pragma unroll
-            for (int ti = 0; ti < 4; ++ti) frag[ti] = tile[(ti * 16 + f) * kTileStride + k];
-            const float w = wrow[k];
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ScTile<WAVE>::ti] * w, frag[ScTile<WAVE>::tj], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ScTile<WAVE + 4>::ti] * w, frag[ScTile<WAVE + 4>::tj], acc[1], 0, 0, 0);
-            if (NQ == 3) acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ScTile<(WAVE + 8) % 10>::ti] * w, frag[ScTile<(WAVE + 8) % 10>::tj], acc[2], 0, 0, 0);
-        }
+        sc_tile_accumulate<WAVE>(tile, wrow, acc);
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -761,7 +802,7 @@ __device__ __forceinline__ void sc_gram_wave(const EFConst& C, const EFArrays& A
     }
 }
 
-struct ScGramSmem { float tile[64 * kTileStride]; float wrow[64]; };
+struct ScGramSmem { alignas(16) float tile[64 * kTileStride]; alignas(16) float wrow[64]; };
 
 // Single-tile Schur Gram of the fused accumulate (k_ef_acc_fused): the JpJdF / flag loads of the tile are issued BEFORE the per-point
 // phase -- they do not depend on it -- and Hcd / bdSum / weight arrive through LDS instead of a store -> load round trip through memory.
@@ -805,18 +846,7 @@ __device__ __forceinline__ void sc_fused_finish(float* stage, const float (*pt)[
     f32x4 acc[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) acc[q] = (f32x4){0, 0, 0, 0};
-    const int f = lane & 15, kq = lane >> 4;
-#pragma unroll 4
-    for (int ks = 0; ks < 16; ++ks) {
-        const int k = ks * 4 + kq;
-        float frag[4];
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) frag[ti] = tile[(ti * 16 + f) * kTileStride + k];
-        const float w = wrow[k];
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ScTile<WAVE>::ti] * w, frag[ScTile<WAVE>::tj], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ScTile<WAVE + 4>::ti] * w, frag[ScTile<WAVE + 4>::tj], acc[1], 0, 0, 0);
-        if (NQ == 3) acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ScTile<(WAVE + 8) % 10>::ti] * w, frag[ScTile<(WAVE + 8) % 10>::tj], acc[2], 0, 0, 0);
-    }
+    sc_tile_accumulate<WAVE>(tile, wrow, acc);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int a = WAVE + 4 * q;
