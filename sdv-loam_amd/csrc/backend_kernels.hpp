@@ -28,7 +28,7 @@
 // accumulate -- the same numerics class as the reference's float accumulators, in a different order):
 //   top:  for a pair (h,t)   G = sum_r [Jc;Jxi;res]_x [..]_x^T + [..]_y [..]_y^T        11 x 11  (AccumulatorApprox)
 //   SC:   for a host h       G = sum_p HdiF_p f_p f_p^T, f_p = [JpJdF_t(6) t=0..7 | Hcd(4) | bdSum]   53 x 53
-// Operands are staged through LDS as [feature][row] tiles (row stride 66 floats: conflict-free for the fragment reads).
+// Operands are staged through LDS as [feature][row] tiles (row stride 68 floats: 16-byte fragment reads, 4 banks apart from row to row).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>

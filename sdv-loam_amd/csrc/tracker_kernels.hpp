@@ -298,7 +298,7 @@ __device__ __forceinline__ void point_features_fast(const LevelParams& P, const 
 
 // ----------------------------------------------------------------------------------------------------
 // The 45-term weighted sum of calcGSSSE (Accumulator9) as a Gram matrix on the matrix cores.
-// A wave stages its 64 points as a [16 features][64 points] LDS tile (row stride 66 floats: conflict-free fragment reads),
+// A wave stages its 64 points as a [16 features][64 points] LDS tile (row stride 68 floats: 16-byte fragment reads, rows 4 banks apart),
 // then per 4 points issues ONE v_mfma_f32_16x16x4_f32  G += A F^T  with  A = [w .* F (rows 0..14) ; 1 (row 15)]:
 //     rows/cols 0..8 : sum_i hw_i [J_i; r_i][J_i; r_i]^T            (A = (J*w), B = J like MatrixAccumulators.h:1047-1110)
 //     row 15         : column sums of F: features 9..14 = E, nSat, nWarped, flow sums (unweighted)

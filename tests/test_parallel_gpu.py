@@ -33,19 +33,20 @@ def _worker(rank, world, port, q, one_collective=True):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("one_collective", [True, False])
-def test_two_ranks_one_gpu_reproduce_single_process(sdvgn_lib, one_collective):
+@pytest.mark.parametrize("world,one_collective", [(2, True), (2, False), (4, True), (8, True)])
+def test_ranks_on_one_gpu_reproduce_single_process(sdvgn_lib, world, one_collective):
     """one_collective: the loop sends ONE message per body (+ one per call) -- accumulators, statistics and quantile candidates together,
-    the trial applied and accumulated speculatively (north_star's single all-reduce); False: the earlier two-collective loop."""
+    the trial applied and accumulated speculatively (north_star's single all-reduce); False: the earlier two-collective loop.
+    world 4: uneven shards of the 5 key-frames (2, 1, 1, 1); world 8: three ranks host nothing (a 5-frame window on an 8-GPU node)."""
     import torch.multiprocessing as mp
     from sdv_loam_amd import backend_api, synthetic as syn
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29900 + (os.getpid() % 90)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port + (7 if one_collective else 0), q, one_collective)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port + 3 * world + (7 if one_collective else 0), q, one_collective)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=500) for _ in range(2)]
+    res = [q.get(timeout=500) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -65,7 +66,8 @@ def test_two_ranks_one_gpu_reproduce_single_process(sdvgn_lib, one_collective):
             assert ncoll == len(tr) + 1                                                  # exactly one all-reduce per loop body + one per call
         else:
             assert ncoll >= 2 * len(tr)                                                  # one accumulator + one statistics all-reduce per iteration
-    assert np.array_equal(res[0][1], res[1][1])                                          # both ranks took bitwise the same path
+    for r in res[1:]:
+        assert np.array_equal(res[0][1], r[1])                                           # all ranks took bitwise the same path
 
 
 def test_tracker_hypotheses_on_device_match_sequential_oracle(orc, sdvgn_lib):
