@@ -204,7 +204,7 @@ struct PhaseTimer {   // SDVGN_PROFILE=1: host wall time per phase of the optimi
     void start() { if (on) t0 = std::chrono::steady_clock::now(); }
     void stop(int k) { if (on) { auto t1 = std::chrono::steady_clock::now(); acc[k] += std::chrono::duration<double, std::micro>(t1 - t0).count(); cnt[k]++; t0 = t1; } }
 };
-static PhaseTimer g_pt;
+static thread_local PhaseTimer g_pt;   // per thread: sdvgn_ef_optimize_batch runs the loop on several host threads
 enum { PT_ACCUM = 0, PT_D2H, PT_STITCH_TOP, PT_STITCH_SC, PT_SOLVE, PT_RESUB, PT_STEP, PT_PRECALC, PT_LIN, PT_APPLY, PT_PREP, PT_N };
 static const char* kPtNames[PT_N] = {"launches (acc..solve..resub..linearize..stats)", "wait for x (solve flag)", "-", "-", "-", "-", "host mirror of the step", "-", "wait for the statistics", "decision + apply/restore", "-"};
 
@@ -1751,7 +1751,9 @@ static double host_prior_energy(const sdvgn_ef* e) {   // calcLEnergyF_MT: frame
     { float a = 0; for (int i = 0; i < 4; ++i) a += e->C.cDeltaF[i] * (float)e->cPrior[i] * e->C.cDeltaF[i]; En += a; }
     return En;
 }
-static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideArgs* dec = nullptr) {   // second half: the sums (+ threshold select)
+// final_body: the loop's last body by count -- nothing follows that could carry the deferred select (the next body's k_ef_stitch does
+// otherwise), so it runs beside the statistics in this launch instead of as a launch of its own after the host has seen the verdict
+static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideArgs* dec = nullptr, bool final_body = false) {   // second half: the sums (+ threshold select)
     const int n_partials = e->lin_partials, nL = e->lin_nL;
     const int nS = (e->nP + 63) / 64;
     const double* ps = e->stats_partial + (e->nP / 64 + 2);
@@ -1771,13 +1773,14 @@ static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideAr
         a.rflags = e->rflags; a.wo = e->A.renergy_wo; a.th_prev = e->A.frameTH_r; a.th_out = e->A.frameTH_w;
         a.log_slot = e->th_log ? e->th_log + (e->th_log_n++ % kThLog) : nullptr;
         const DecideArgs none{0, 0, 0, nullptr, 0, nullptr, 0};
-        if (dec && dec->verdict && e->own_stream) {
+        if (dec && dec->verdict && (e->own_stream || final_body)) {
             // a window that runs beside others (sdvgn_ef_optimize_batch): the same two steps as two launches -- the apply workgroups would
             // otherwise sit on the CUs polling the verdict word while other windows' kernels wait for a place
             const size_t slots = (size_t)e->nF * e->nP;
             DecideArgs d2 = *dec; d2.verdict = nullptr;
-            k_ef_stats_select<<<1, kSelLanes, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host, e->flags_host + 2, ++e->seq_stats, a, d2);
+            k_ef_stats_select<<<final_body ? 2 : 1, kSelLanes, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host, e->flags_host + 2, ++e->seq_stats, a, d2);
             k_ef_apply<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->nF, e->nP, e->A, e->precalc_dev, e->phost_dev, e->accept_dev);
+            if (final_body) defer_select = false;   // taken in this launch
         } else if (dec && dec->verdict) {   // statistics + accept test + conditional applyRes of the trial set in one launch
             const size_t slots = (size_t)e->nF * e->nP;
             k_ef_stats_apply<<<1 + (unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host,
@@ -1982,7 +1985,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             DecideArgs dec;
             dec.En = host_prior_energy(e); dec.EM = newEnergyM; dec.rhs = lastEnergy + lastEnergyL + lastEnergyM; dec.accept_dev = e->accept_dev; dec.on = 1;
             dec.verdict = (unsigned*)(e->accept_dev + 4); dec.seq = (unsigned)(++e->seq_verdict) & 0x7fffffffu;
-            if ((rc = linearize_launch_stats(e, defer, &dec))) return rc;
+            if ((rc = linearize_launch_stats(e, defer, &dec, /*final_body=*/iteration + 1 == mnumOptIts))) return rc;
             // the next body's accumulate, queued before the verdict is known (AccAlt): its arguments are the accepted case -- the state
             // this body's launches run on --, the kept copies go along for the rejected one
             pre_accumulated = false;
@@ -2124,6 +2127,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
 // The threads are kept (a pool grown on demand): a call costs two condition-variable hand-offs per extra window.
 namespace {
 struct BatchPool {
+    std::mutex call_mu;   // one batch call at a time (a second caller waits: the job list below belongs to the call in flight)
     std::mutex mu;
     std::condition_variable cv_go, cv_done;
     std::vector<std::thread> workers;
@@ -2167,6 +2171,7 @@ int sdvgn_ef_optimize_batch(sdvgn_ef* const* handles, int B, int mnumOptIts, int
     }
     if (B == 1) { const int rc = sdvgn_ef_optimize(handles[0], mnumOptIts, flags, nullptr, 0, 0); if (its_out) its_out[0] = rc; return rc < 0 ? rc : SDVGN_OK; }
     BatchPool& P = batch_pool();
+    std::lock_guard<std::mutex> one_call(P.call_mu);
     std::unique_lock<std::mutex> lk(P.mu);
     while ((int)P.workers.size() < B - 1) P.workers.emplace_back([&P] { P.worker(); });
     P.jobs.clear();
