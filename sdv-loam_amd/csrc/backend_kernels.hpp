@@ -182,11 +182,6 @@ struct LinSmem {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned lin_u32x2 __attribute__((ext_vector_type(2)));
 // ---- the kernel and its phases live in backend_linearize.inc, instantiated twice (see its header) ---------------------------------------
-#ifdef SDVGN_EXP_NT_JSTORE   // experiment (tools/exp_variants.sh): the Jacobian planes leave without allocating in the writing XCD's L2
-#define LIN_JSTORE(p, v) __builtin_nontemporal_store((v), (p))
-#else
-#define LIN_JSTORE(p, v) (*(p) = (v))
-#endif
 #define LIN_NS lin_exact
 #define LIN_DIV(a, b) ((a) / (b))
 #define LIN_SQRT(x) sqrtf(x)
