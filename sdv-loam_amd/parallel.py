@@ -19,6 +19,7 @@ SC_E = SC_N * (SC_N + 1) // 2   # its upper triangle, row-major (1431)
 MAX_FRAMES = 8
 
 
+_DEVICE_STREAMS = {}   # device index -> the torch stream every ShardedEnergyFunctional of this process issues its work on
 _GROUP_IDS = []   # (process group, 128-byte RCCL id) of the communicators this process created through sdvgn_ef_init_rccl
 
 
@@ -86,7 +87,11 @@ class ShardedEnergyFunctional:
         self.torch, self.dist, self.group = torch, dist, group
         self.rank, self.world = rank, world
         torch.cuda.set_device(device)
-        self.stream = torch.cuda.Stream(device=device)
+        # one stream per device for all sharded windows of the process: a stream of its own per window means a hardware queue per window, and
+        # the first launch on a queue that has been idle since its creation costs 0.2-0.5 ms
+        if device not in _DEVICE_STREAMS:
+            _DEVICE_STREAMS[device] = torch.cuda.Stream(device=device)
+        self.stream = _DEVICE_STREAMS[device]
         self.ef = EnergyFunctional(W.w, W.h, max_points=W.nP, device=device, stream=self.stream.cuda_stream)
         with torch.cuda.stream(self.stream):
             self.acc = torch.zeros(acc_capacity(), dtype=torch.float64, device="cuda")
