@@ -457,7 +457,8 @@ template <int MODE = 0>
 __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
                                            const int* __restrict__ phost, int p_base, int p_count, PointSmem& S,
                                            const uint8_t* __restrict__ mask = nullptr, float* __restrict__ prior_w = nullptr,
-                                           float (*pt_out)[64] = nullptr /* [6][64] LDS: Hcd[4], bdSum, Schur weight of the tile's points */) {
+                                           float (*pt_out)[64] = nullptr /* [6][64] LDS: Hcd[4], bdSum, Schur weight of the tile's points */,
+                                           int h_tile = -1 /* >= 0: every point of the tile is hosted by this key-frame of the rank's shard: no phost / table loads ahead of the flags */) {
     float (*part)[13][64] = S.part;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (pt_out && wave == 0) {
@@ -469,8 +470,8 @@ __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, 
     int h = 0;
     bool mine = false;
     if (lane < p_count) {
-        h = phost[p];
-        mine = precalc[h * C.nF + h].np != 0;   // host frame in this rank's shard
+        if (h_tile >= 0) { h = h_tile; mine = true; }
+        else { h = phost[p]; mine = precalc[h * C.nF + h].np != 0; }   // host frame in this rank's shard
         if (MODE == 2) mine = mine && mask[p] != 0;
     }
     // this wave's two targets (wave, wave + 4): the flags of both in one round trip, then every Jacobian value of both in one batch of
@@ -627,12 +628,13 @@ struct TopGramSmem { alignas(16) float tile[4][2][16 * kTileStride]; float red[4
 template <int MODE = 0>
 __device__ __forceinline__ void top_gram_body(const EFConst& C, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
                                               float* __restrict__ partial, int* __restrict__ nres_partial, int bx, int pair, int gx,
-                                              TopGramSmem& S, const uint8_t* __restrict__ mask = nullptr) {
+                                              TopGramSmem& S, const uint8_t* __restrict__ mask = nullptr,
+                                              const PrecalcDev* __restrict__ ranges = nullptr /* a table whose P0 / np are known without waiting (k_ef_acc_fused) */) {
     float (*tile)[2][16 * kTileStride] = S.tile;
     float (*red)[256] = S.red;
     int* s_n = S.s_n;
     const int h = pair / C.nF, t = pair % C.nF;
-    const PrecalcDev& pc = precalc[pair];
+    const PrecalcDev& pc = (ranges ? ranges : precalc)[pair];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int P0 = pc.P0, np = pc.np;
     const size_t slots = (size_t)C.nF * C.nP;
@@ -887,6 +889,7 @@ __global__ void __launch_bounds__(256) k_ef_acc_fused(const PrecalcDev* __restri
                                                       const int* __restrict__ phost, float* __restrict__ top_partial,
                                                       int* __restrict__ nres_partial, int top_chunks, float* __restrict__ sc_partial,
                                                       int sc_chunks, int n_sc, AccAlt alt) {
+    const PrecalcDev* __restrict__ ranges = precalc;   // point ranges / shard flags are the same in both tables: read them without waiting for the verdict
     if (alt.verdict && *alt.verdict == 0) {
         A.pid = alt.pid; A.pidz = alt.pidz; A.pdeltaF = alt.pdeltaF; A.calib = alt.calib; precalc = alt.precalc;
     }
@@ -895,7 +898,7 @@ __global__ void __launch_bounds__(256) k_ef_acc_fused(const PrecalcDev* __restri
     const int b = blockIdx.x;
     if (b < n_sc) {
         const int h = b / sc_chunks, bx = b - h * sc_chunks;
-        const int P0 = precalc[h * C.nF + h].P0, np = precalc[h * C.nF + h].np;   // np == 0 outside this rank's shard
+        const int P0 = ranges[h * Cin.nF + h].P0, np = ranges[h * Cin.nF + h].np;   // np == 0 outside this rank's shard
         const int begin = bx * 64, end = min(np, begin + 64);
         __shared__ float pt[6][64];
         const int wave = threadIdx.x >> 6;
@@ -906,7 +909,7 @@ __global__ void __launch_bounds__(256) k_ef_acc_fused(const PrecalcDev* __restri
             case 2: sc_fused_prefetch<2>(C, A, P0, begin, end, stage); break;
             default: sc_fused_prefetch<3>(C, A, P0, begin, end, stage); break;
         }
-        if (begin < np) point_body(C, A, precalc, phost, P0 + begin, end - begin, S.p, nullptr, nullptr, pt);
+        if (begin < np) point_body(C, A, precalc, phost, P0 + begin, end - begin, S.p, nullptr, nullptr, pt, h);   // (np != 0: the host is this rank's)
         else if (wave == 0) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) pt[i][threadIdx.x & 63] = 0.0f;
@@ -921,7 +924,7 @@ __global__ void __launch_bounds__(256) k_ef_acc_fused(const PrecalcDev* __restri
         }
     } else {
         const int q = b - n_sc;
-        top_gram_body(C, A, precalc, top_partial, nres_partial, q % top_chunks, q / top_chunks, top_chunks, S.t);
+        top_gram_body(C, A, precalc, top_partial, nres_partial, q % top_chunks, q / top_chunks, top_chunks, S.t, nullptr, ranges);
     }
 }
 
