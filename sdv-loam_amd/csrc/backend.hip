@@ -113,6 +113,7 @@ struct sdvgn_ef {
     int st_cur = 0;                        // which of the two sets holds the current state
     bool state_dirty = true;               // the host mirror changed outside the loop: upload before the next device solve
     ResubX* rx_dev = nullptr;              // xc, xAd of the last solve (the resubstitute workgroups of k_ef_tail_resub read them)
+    unsigned long long* xw_dev = nullptr;  // the same + x as tagged words (SolveIO::xw): the in-launch hand-off of k_ef_tail_resub
     SolveSys* sys_dev = nullptr;           // HA, bA, Hsc, bsc, HFinal, bFinal of the last solve
     SolveOut* sol_host = nullptr;          // pinned: x, step statistics, resInA, status
     SolvePieces* pieces_dev = nullptr;     // [SDVGN_MAX_FRAMES]: per-host shares of HA / bA / Hsc / bsc
@@ -1007,6 +1008,8 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     HIPCHK(hipHostMalloc((void**)&e->sol_host, sizeof(SolveOut)));
     std::memset(e->sol_host, 0, sizeof(SolveOut));
     HIPCHK(hipMemset(e->rx_dev, 0, sizeof(ResubX)));
+    HIPCHK(hipMalloc(&e->xw_dev, sizeof(unsigned long long) * 512));
+    HIPCHK(hipMemset(e->xw_dev, 0, sizeof(unsigned long long) * 512));   // tag 0 is never current (the solves count from 1)
     e->flags_host[0] = e->flags_host[1] = e->flags_host[2] = e->flags_host[3] = 0;
     HIPCHK(hipMalloc((void**)&e->done_ctr, 2 * sizeof(unsigned)));
     HIPCHK(hipMemset(e->done_ctr, 0, 2 * sizeof(unsigned)));
@@ -1033,7 +1036,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
                     e->stats_dev, e->stats_partial, e->imm_pc_dev, e->rstate_new2, e->renergy_new2, e->renergy_wo2,
                     e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->precalc_alt, e->dbg_stamps, e->marg_mask_dev, e->drop_mask_dev, e->th_dev, e->fin_dev,
-                    e->win_dev, e->sstate_dev, e->calib_dev, e->rx_dev, e->sys_dev, e->pieces_dev};
+                    e->win_dev, e->sstate_dev, e->calib_dev, e->rx_dev, e->xw_dev, e->sys_dev, e->pieces_dev};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->precalc_host) hipHostFree(e->precalc_host);
     if (e->acc_host) hipHostFree(e->acc_host);
@@ -1625,7 +1628,7 @@ static void ef_fill_solve_io(sdvgn_ef* e, SolveIO& io, int iteration, double lam
     io.pc_cur = e->precalc_dev; io.pc_trial = e->precalc_alt;
     io.rx = e->rx_dev; io.sys = e->sys_dev; io.out = e->sol_host;
     io.done_flag = e->flags_host + 3; io.done_seq = ++e->seq_solve;
-    io.ready_word = (unsigned*)(e->accept_dev + 8);
+    io.xw = e->xw_dev;
     io.err_word = e->stats_host ? (unsigned*)(e->stats_host + 6) : nullptr;
     io.lambda = lambda; io.iteration = iteration; io.do_step = do_step ? 1 : 0; io.reuse = reuse ? 1 : 0; io.stepsize = stepsize;
     io.stamps = e->solve_stamps;

@@ -1064,17 +1064,24 @@ __global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__
 // (idepth = idepth_zero = backup + step_fac * step, FullSystemOptimize.cpp:236-249) -- the optimize loop always does both.
 struct ResubX { float xc[4]; float xAd[kMaxFrames * kMaxFrames * 6]; };
 
-// A launch may wait for a word another workgroup OF THE SAME LAUNCH publishes (k_ef_tail_resub: the factorisation workgroup's solution):
-// one lane polls with relaxed device-scope loads, the acquire fence behind it drops the CU's (and this XCD's) stale copies of what the
-// publisher wrote before its release fence, the workgroup barrier hands the result to the other waves.  Gives up after ~2^20 polls and raises the handle's sticky error word.
-__device__ __forceinline__ void wait_ready_word(const unsigned* word, unsigned seq, unsigned* err = nullptr) {
-    if (threadIdx.x == 0) {
-        int polls = 0;
-        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq && ++polls < (1 << 20)) __builtin_amdgcn_s_sleep(8);
-        if (polls >= (1 << 20)) ef_raise(err, 2u);       // gave up: what follows reads whatever x / xAd is in memory -- the call must fail (sticky)
-        __threadfence();
+// A launch may wait for values another workgroup OF THE SAME LAUNCH publishes (k_ef_tail_resub: the factorisation workgroup's solution).
+// The solution travels WITHOUT fences: every value is one 64-bit word {number of the solve, payload}, written with one
+// relaxed device-scope atomic store (single-copy atomic: a reader sees the tag and its payload together or neither) and polled by the lane
+// that needs it until the tag is the current one.  The publisher's release fence (an L2 write-back on this part) and the readers' acquire
+// fence + second round trip for the payload are gone: measured 2.9 us from the publisher's last store to the first reader seeing the word
+// with the fence pair (tools/exp_solve_stamps.py), see profiles/r03_notes.txt for the tagged form.
+constexpr int kXwFloats = 4 + kMaxFrames * kMaxFrames * 6;     // ResubX as tagged words [0, kXwFloats), then x as (hi, lo) pairs
+__device__ __forceinline__ void store_tagged_u32(unsigned long long* w, unsigned seq, unsigned payload) {
+    __hip_atomic_store(w, ((unsigned long long)seq << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned poll_tagged_u32(const unsigned long long* w, unsigned seq, unsigned* err) {
+    unsigned long long v;
+    int polls = 0;
+    while ((unsigned)((v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != seq) {
+        if (++polls >= (1 << 20)) { ef_raise(err, 2u); break; }   // gave up: the call must fail (sticky)
+        __builtin_amdgcn_s_sleep(4);
     }
-    __syncthreads();
+    return (unsigned)v;
 }
 
 // (body of HALF a workgroup of 1024 lanes: group g = threadIdx.x >> 9 takes the 64-point block `blk`, wave t of the group target t; the
@@ -1086,7 +1093,7 @@ __device__ __forceinline__ void resubstitute_body(const EFConst& C, const EFArra
                                                   const int* __restrict__ phost, const ResubX* Xp, float* __restrict__ backup,
                                                   double* __restrict__ stats_partial, float step_fac,
                                                   float* __restrict__ pid_w, float* __restrict__ pidz_w, float* __restrict__ pdeltaF_w,
-                                                  int n_point_blocks, int blk, ResubSmem& S, const unsigned* ready, unsigned seq) {
+                                                  int n_point_blocks, int blk, ResubSmem& S, const unsigned long long* xw /*NULL: Xp is complete*/, unsigned seq) {
     float (*part)[2][64] = S.part[threadIdx.x >> 9];
     float* sx = S.sx;
     const int lane = threadIdx.x & 63, t = (threadIdx.x >> 6) & 7;
@@ -1114,8 +1121,9 @@ __device__ __forceinline__ void resubstitute_body(const EFConst& C, const EFArra
     // vector load from the kernel-argument segment)
     __builtin_amdgcn_sched_barrier(0);
     const bool mine = inP && precalc[h * C.nF + h].np != 0;
-    if (ready) wait_ready_word(ready, seq, A.err);       // this thread's loads above are in flight while the solution is being computed
-    if (threadIdx.x < 4 + kMaxFrames * kMaxFrames * 6) sx[threadIdx.x] = reinterpret_cast<const float*>(Xp)[threadIdx.x];
+    // this thread's loads above are in flight while the solution is being computed; its words of xc / xAd arrive tagged (same launch) or are in memory
+    if ((int)threadIdx.x < 4 + C.nF * C.nF * 6)     // (what the factorisation workgroup writes: xc and nF * nF rows of xAd)
+        sx[threadIdx.x] = xw ? __uint_as_float(poll_tagged_u32(xw + threadIdx.x, seq, A.err)) : reinterpret_cast<const float*>(Xp)[threadIdx.x];
     __syncthreads();
     const float* xc = sx;
     const float* xAd = sx + 4;

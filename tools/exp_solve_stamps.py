@@ -23,7 +23,7 @@ W = syn.make_window(w=1241, h=376, nF=nF, pts_per_kf=ppk, seed=0, calib=syn.KITT
 G = backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
 names = ["k_ef_stitch start -> k_ef_tail_resub start", "H, b assembly from the shares", "blocked LDL^T",
          "back substitution + orthogonalize", "xAd, step, precalc table"]
-rows, sub, blk = [], [], []
+rows, sub, blk, stp = [], [], [], []
 for rep in range(12):
     G.load(W)
     G.optimize(6, fixed_its=True)
@@ -35,6 +35,7 @@ for rep in range(12):
     b = buf.astype(np.int64)
     sub.append((np.array([b[8], b[9], b[10]]) - st[0]) / 100.0)
     blk.append(np.array([b[14] - b[2], b[15] - b[14], b[7] - b[15]]) / 100.0)
+    stp.append(np.array([b[11] - st[5], b[12] - b[11], b[13] - b[12], b[13] - st[1]]) / 100.0)
 rows = np.array(rows[2:])
 print("device-side solve, nF = %d, %d points per key-frame: phase durations of the last body of %d optimize(6) calls (us)" % (nF, ppk, len(rows)))
 print("%-44s %8s %8s %8s" % ("phase", "median", "min", "max"))
@@ -45,3 +46,5 @@ sub = np.array(sub[2:])
 print("k_ef_stitch, workgroup 0 (host frame 0), since its start: accumulators in LDS %.2f us | products %.2f us | shares written %.2f us" % tuple(np.median(sub, axis=0)))
 blk = np.array(blk[2:])
 print("first LDL^T block: scaling + first panel %.2f us | barrier %.2f us | update + barrier %.2f us" % tuple(np.median(blk, axis=0)))
+stp = np.array(stp[2:])
+print("step workgroup: sees the ready word %.2f us after workgroup 0's last stamp | x in LDS + frame states (exp, compose, inverse) %.2f us | precalc table %.2f us | its last store %.2f us after k_ef_tail_resub's workgroup 0 started" % tuple(np.median(stp, axis=0)))
