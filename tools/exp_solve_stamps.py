@@ -47,4 +47,4 @@ print("k_ef_stitch, workgroup 0 (host frame 0), since its start: accumulators in
 blk = np.array(blk[2:])
 print("first LDL^T block: scaling + first panel %.2f us | barrier %.2f us | update + barrier %.2f us" % tuple(np.median(blk, axis=0)))
 stp = np.array(stp[2:])
-print("step workgroup: sees the ready word %.2f us after workgroup 0's last stamp | x in LDS + frame states (exp, compose, inverse) %.2f us | precalc table %.2f us | its last store %.2f us after k_ef_tail_resub's workgroup 0 started" % tuple(np.median(stp, axis=0)))
+print("step workgroup: has its tagged words of x %.2f us after workgroup 0's last stamp | frame states (exp, compose, inverse) %.2f us | precalc table %.2f us | its last store %.2f us after k_ef_tail_resub's workgroup 0 started" % tuple(np.median(stp, axis=0)))
