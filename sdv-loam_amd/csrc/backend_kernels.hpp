@@ -482,20 +482,26 @@ __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, 
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int t = wave + 4 * k;
-        if (mine && t < C.nF) { s2[k] = (size_t)t * C.nP + p; fl2[k] = A.rflags[s2[k]]; }
+        const bool ex = mine && t < C.nF;
+        s2[k] = ex ? (size_t)t * C.nP + p : 0;
+        const uint8_t fr = A.rflags[s2[k]];
+        fl2[k] = ex ? fr : (uint8_t)0;
     }
+    // the per-point inputs of the Schur head below (wave 0 uses them behind the workgroup barrier): in flight with everything else
+    const int pq = (wave == 0 && mine) ? p : p_base;
+    const float prior_in = A.ppriorF[pq], delta_in = A.pdeltaF[pq];
+    const uint8_t sensor_in = A.psensor[pq];
     __builtin_amdgcn_sched_barrier(0);
+    // (unconditional loads -- slot s2 = 0 exists when the residual does not --: a load under `on ? ... : 0` is sunk into a branch of its own
+    // and the twelve values of a target arrive one round trip after the other)
     float jd[2][2], jc0[2][4], jc1[2][4], jr[2][2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const uint8_t fl = fl2[k];
-        const bool on = (fl & RF_EXISTS) && (fl & RF_ACTIVE);
-        const float* Je = A.J + (size_t)((fl & RF_SEL) ? 1 : 0) * kJPlanes * slots + s2[k];
-        jd[k][0] = on ? Je[22 * slots] : 0.0f; jd[k][1] = on ? Je[23 * slots] : 0.0f;
+        const float* Je = A.J + (size_t)((fl2[k] & RF_SEL) ? 1 : 0) * kJPlanes * slots + s2[k];
+        jd[k][0] = Je[22 * slots]; jd[k][1] = Je[23 * slots];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { jc0[k][i] = on ? Je[(14 + i) * slots] : 0.0f; jc1[k][i] = on ? Je[(18 + i) * slots] : 0.0f; }
-        const bool lin = MODE != 2 && on && !(fl & RF_LINEARIZED);
-        jr[k][0] = lin ? Je[0] : 0.0f; jr[k][1] = lin ? Je[slots] : 0.0f;
+        for (int i = 0; i < 4; ++i) { jc0[k][i] = Je[(14 + i) * slots]; jc1[k][i] = Je[(18 + i) * slots]; }
+        jr[k][0] = Je[0]; jr[k][1] = Je[slots];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -565,14 +571,14 @@ __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, 
         for (int i = 0; i < 4; ++i) A.pHcd[(size_t)i * C.nP + p] = 0;
         return;
     }
-    float prior = A.ppriorF[p];
+    float prior = prior_in;
     if (MODE == 2) { prior *= 600.0f * 600.0f; prior_w[p] = prior; }   // setting_idepthFixPriorMargFac, EnergyFunctional.cpp:527
     float H = HddA + HddL + prior;
     if (H < 1e-10) H = 1e-10;
     const float hdi = (float)(1.0 / H);
     A.pHdi[p] = hdi;
     float bds = bdA + bdL;
-    if (MODE != 2) bds += prior * A.pdeltaF[p];  // shiftPriorToZero == true in accumulateSCF_MT, false in marginalizePointsF
+    if (MODE != 2) bds += prior * delta_in;  // shiftPriorToZero == true in accumulateSCF_MT, false in marginalizePointsF
     A.pbdSum[p] = bds;
 #pragma unroll
     for (int i = 0; i < 4; ++i) A.pHcd[(size_t)i * C.nP + p] = sum[2 + i] + sum[8 + i];
@@ -580,7 +586,7 @@ __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) pt_out[i][lane] = sum[2 + i] + sum[8 + i];
         pt_out[4][lane] = bds;
-        pt_out[5][lane] = A.psensor[p] ? 0.0f : hdi;
+        pt_out[5][lane] = sensor_in ? 0.0f : hdi;
     }
 }
 
@@ -644,34 +650,32 @@ __device__ __forceinline__ void top_gram_body(const EFConst& C, const EFArrays& 
         for (int base = bx * 256 + wave * 64; base < np; base += gx * 256) {
             const int pl = base + lane;
             bool use = false;
-            size_t s = 0;
-            uint8_t fl = 0;
-            if (pl < np) {
-                s = (size_t)t * C.nP + (P0 + pl);
-                fl = A.rflags[s];
-                if (MODE == 2) use = (fl & RF_EXISTS) && (fl & RF_ACTIVE) && mask[P0 + pl] != 0;
-                else use = (fl & RF_EXISTS) && (fl & RF_ACTIVE) && !(fl & RF_LINEARIZED);
-            }
+            // the slot's flag, then its 22 values in ONE batch of unconditional loads (slot 0 stands in for a lane beyond the host's points): a
+            // load written `use ? Je[..] : 0` is sunk under a branch of its own and the values arrive in five or six round trips instead of one
+            const bool inr = pl < np;
+            const size_t s = inr ? (size_t)t * C.nP + (P0 + pl) : 0;
+            const uint8_t fl = A.rflags[s];
+            uint8_t mk = 1;
+            if (MODE == 2) mk = mask[inr ? P0 + pl : 0];
+            __builtin_amdgcn_sched_barrier(0);
+            if (MODE == 2) use = inr && (fl & RF_EXISTS) && (fl & RF_ACTIVE) && mk != 0;
+            else use = inr && (fl & RF_EXISTS) && (fl & RF_ACTIVE) && !(fl & RF_LINEARIZED);
             const float* Je = A.J + (size_t)((fl & RF_SEL) ? 1 : 0) * kJPlanes * slots + s;
+            float vx[11], vy[11];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { vx[i] = Je[(14 + i) * slots]; vy[i] = Je[(18 + i) * slots]; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { vx[4 + i] = Je[(2 + i) * slots]; vy[4 + i] = Je[(8 + i) * slots]; }
+            if (MODE == 2) { vx[10] = A.rres_toZero[s]; vy[10] = A.rres_toZero[slots + s]; }
+            else { vx[10] = Je[0]; vy[10] = Je[slots]; }
+            __builtin_amdgcn_sched_barrier(0);
             float* tx = tile[wave][0];
             float* ty = tile[wave][1];
             // feature f of row `lane`
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                tx[i * kTileStride + lane] = use ? Je[(14 + i) * slots] : 0.0f;
-                ty[i * kTileStride + lane] = use ? Je[(18 + i) * slots] : 0.0f;
-            }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                tx[(4 + i) * kTileStride + lane] = use ? Je[(2 + i) * slots] : 0.0f;
-                ty[(4 + i) * kTileStride + lane] = use ? Je[(8 + i) * slots] : 0.0f;
-            }
-            if (MODE == 2) {
-                tx[10 * kTileStride + lane] = use ? A.rres_toZero[s] : 0.0f;
-                ty[10 * kTileStride + lane] = use ? A.rres_toZero[slots + s] : 0.0f;
-            } else {
-                tx[10 * kTileStride + lane] = use ? Je[0] : 0.0f;
-                ty[10 * kTileStride + lane] = use ? Je[slots] : 0.0f;
+            for (int i = 0; i < 11; ++i) {
+                tx[i * kTileStride + lane] = use ? vx[i] : 0.0f;
+                ty[i * kTileStride + lane] = use ? vy[i] : 0.0f;
             }
 #pragma unroll
             for (int i = 11; i < 16; ++i) { tx[i * kTileStride + lane] = 0.0f; ty[i * kTileStride + lane] = 0.0f; }
@@ -810,20 +814,32 @@ __device__ __forceinline__ void sc_fused_prefetch(const EFConst& C, const EFArra
     const int pl = begin + lane;
     const bool in = pl < end;
     const int p = P0 + (in ? pl : 0);
+    // flag and value of every feature loaded side by side in ONE batch (clamped addresses: slot 0 always exists), selected behind the
+    // scheduling barrier -- written as `if (ok && flags) v = load` the compiler sinks each load under its branch: 16 serial round trips,
+    // 5.9 us of the workgroup's 10.7 (stamps, profiles/r03_notes.txt)
+    uint8_t fl[16];
+    float jv[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         constexpr int f0 = WAVE * 16;
         const int f = f0 + j;
-        float v = 0.0f;
-        if (f < 48) {
+        fl[j] = 0; jv[j] = 0.0f;
+        if (f < 48) {   // (compile-time)
             const int t = f / 6, i = f - 6 * t;
             const bool ok = in && t < C.nF;
-            const size_t s = ok ? (size_t)t * C.nP + p : 0;   // flag and value loaded side by side (one round trip), selected afterwards
-            const uint8_t fl = A.rflags[s];
-            const float jv = A.JpJd[(size_t)i * slots + s];
-            if (ok && (fl & RF_EXISTS) && (fl & RF_ACTIVE)) v = jv;
+            const size_t s = ok ? (size_t)t * C.nP + p : 0;
+            fl[j] = A.rflags[s];
+            jv[j] = A.JpJd[(size_t)i * slots + s];
         }
-        stage[j] = v;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        constexpr int f0 = WAVE * 16;
+        const int f = f0 + j;
+        const int t = f / 6;
+        const bool ok = f < 48 && in && t < C.nF;
+        stage[j] = (ok && (fl[j] & RF_EXISTS) && (fl[j] & RF_ACTIVE)) ? jv[j] : 0.0f;
     }
 }
 template <int WAVE>
