@@ -371,12 +371,25 @@ __device__ __forceinline__ void apply_slot(int nF, int nP, const EFArrays& A, co
     const size_t slots = (size_t)nF * nP;
     if (s >= slots) return;
     if (bak) bak->fl[s] = 0xFF;
-    int go = cond ? *cond : 1;
+    // every input of the slot in two batches of unconditional loads BEFORE the verdict is waited for: the slot's own planes, then (they depend
+    // on its flags / host) the freshly linearised Jacobian values and the host's shard flag -- behind the verdict only arithmetic and stores
+    // are left (a load under a condition gets a branch and a wait of its own)
+    const int go_in = cond ? *cond : 1;
     const int hh = phost[s % nP];
     uint8_t fl = A.rflags[s];
-    const int st = A.reset_oob ? (int)RS_IN : (int)A.rstate[s];
+    const int st_in = (int)A.rstate[s];
     const int sn = A.rstate_new[s];
     const float en = A.renergy_new[s];
+    __builtin_amdgcn_sched_barrier(0);
+    int go = go_in;
+    const int st = A.reset_oob ? (int)RS_IN : st_in;
+    const int np_h = precalc[hh * nF + hh].np;
+    const int buf = (fl & RF_SEL) ? 0 : 1;              // the buffer the residual's freshly linearised J sits in
+    const float* Je = A.J + (size_t)buf * kJPlanes * slots + s;
+    float jx[6], jy[6];
+    const float d0 = Je[22 * slots], d1 = Je[23 * slots];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { jx[i] = Je[(2 + i) * slots]; jy[i] = Je[(8 + i) * slots]; }
     __builtin_amdgcn_sched_barrier(0);
     if (verdict) {
         unsigned w = 0;
@@ -390,14 +403,6 @@ __device__ __forceinline__ void apply_slot(int nF, int nP, const EFArrays& A, co
         if ((w >> 1) != seq) ef_raise(A.err, 1u);        // call: the publisher may only be late, other slots may have applied (A.err, sticky)
     }
     if (!go) return;
-    const int np_h = precalc[hh * nF + hh].np;
-    const int buf = (fl & RF_SEL) ? 0 : 1;              // the buffer the residual's freshly linearised J sits in
-    const float* Je = A.J + (size_t)buf * kJPlanes * slots + s;
-    float jx[6], jy[6];
-    const float d0 = Je[22 * slots], d1 = Je[23 * slots];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { jx[i] = Je[(2 + i) * slots]; jy[i] = Je[(8 + i) * slots]; }
-    __builtin_amdgcn_sched_barrier(0);
     if (np_h == 0) return;   // host frame not in this rank's shard
     if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED)) return;
     if (st == RS_OOB) return;
