@@ -74,6 +74,9 @@ __device__ __forceinline__ void interp33(const float* __restrict__ img, float x,
     const float* bq = bp + 3 * width;
     const float a0 = bp[0], a1 = bp[1], a2 = bp[2], b0 = bp[3], b1 = bp[4], b2 = bp[5];
     const float c0 = bq[0], c1 = bq[1], c2 = bq[2], d0 = bq[3], d1 = bq[4], d2 = bq[5];
+    // all twelve values in flight together: without this the compiler sinks the loads of the gradient components (used only once the
+    // intensity has proved finite) under that branch -- a second round trip per lookup behind the first
+    asm volatile("" ::"v"(b1), "v"(b2), "v"(d1), "v"(d2));
     const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
     o0 = ((w11 * d0 + w01 * c0) + w10 * b0) + w00 * a0;
     o1 = ((w11 * d1 + w01 * c1) + w10 * b1) + w00 * a1;
