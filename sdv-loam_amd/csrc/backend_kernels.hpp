@@ -215,13 +215,26 @@ using lin_exact::k_ef_linearize;   // the name every other launch site uses
 struct ImmPrecalc {   // FrameFramePrecalc fields linearizeResidual reads: PRE_RTll, PRE_tTll, PRE_aff_mode, per (host,target)
     float R[9], t[3], aff[2], pad[2];
 };
+static_assert(sizeof(ImmPrecalc) == 64, "ImmPrecalc is fetched as four 16-byte words");
 
 struct ImmLaneRes { int state_state, state_NewState; double state_energy, state_NewEnergy; };
 
-__device__ __forceinline__ double imm_linearize_residual(const EFConst& C, const float* __restrict__ img, const ImmPrecalc& pc, float pu, float pv,
+__device__ __forceinline__ double imm_linearize_residual(const EFConst& C, const float* __restrict__ img, const ImmPrecalc& pc_in, float pu, float pv,
                                                          const float* col, const float* wts, float energyTH, float outlierTHSlack, ImmLaneRes& tmp,
                                                          float& Hdd, float& bd, float idepth) {
     if (tmp.state_state == RS_OOB) { tmp.state_NewState = RS_OOB; return tmp.state_energy; }
+    // the 16 floats of the (host,target) record in registers, all of them now: read through the reference where they are used, t[] and aff[]
+    // were fetched again for every pattern pixel, behind that pixel's isfinite() test -- eight more serial round trips per residual
+    ImmPrecalc pc;
+    {
+        const float4* src = reinterpret_cast<const float4*>(&pc_in);
+        float4 r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = src[k];
+        asm volatile("" ::"v"(r[2].y), "v"(r[2].z), "v"(r[2].w), "v"(r[3].x), "v"(r[3].y));
+        pc.R[0] = r[0].x; pc.R[1] = r[0].y; pc.R[2] = r[0].z; pc.R[3] = r[0].w; pc.R[4] = r[1].x; pc.R[5] = r[1].y; pc.R[6] = r[1].z; pc.R[7] = r[1].w;
+        pc.R[8] = r[2].x; pc.t[0] = r[2].y; pc.t[1] = r[2].z; pc.t[2] = r[2].w; pc.aff[0] = r[3].x; pc.aff[1] = r[3].y; pc.pad[0] = pc.pad[1] = 0;
+    }
     const int pat[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};
     float us[8], vs[8], dres[8], fx8[8], fy8[8], tp[8][12];
     bool ok[8];
@@ -251,6 +264,11 @@ __device__ __forceinline__ double imm_linearize_residual(const EFConst& C, const
 #pragma unroll
         for (int k = 0; k < 6; ++k) { tp[idx][k] = bp8[idx][k]; tp[idx][6 + k] = bq[k]; }
     }
+    // (the scheduling barriers alone do not keep the batch together: the loads of the gradient components are only used behind the
+    // isfinite() test of their pixel's intensity, and the compiler sinks them there -- two loads and a wait per pixel, eight times in a row;
+    // an empty asm that takes the values as inputs pins them here)
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) asm volatile("" ::"v"(tp[idx][4]), "v"(tp[idx][5]), "v"(tp[idx][10]), "v"(tp[idx][11]));
     __builtin_amdgcn_sched_barrier(0);
     float energyLeft = 0;
 #pragma unroll
