@@ -57,7 +57,7 @@ struct PrecalcDev {  // FrameFramePrecalc fields linearize reads (HessianBlocks.
     float aff0, aff1, b0;
     float unused_th;      // (thresholds live in EFArrays::frameTH_r: they change after every linearizeAll)
     float dp[6];          // adHTdeltaF[h + t*nF]  (EnergyFunctional.cpp:140-141)
-    int P0, np;           // point range of the host frame
+    int P0, np;           // point range of the host frame (8-byte aligned: read as one int2 where both are wanted at once)
     int pad[2];
 };
 
@@ -929,25 +929,27 @@ __global__ void __launch_bounds__(256) k_ef_acc_fused(const PrecalcDev* __restri
                                                       int* __restrict__ nres_partial, int top_chunks, float* __restrict__ sc_partial,
                                                       int sc_chunks, int n_sc, AccAlt alt) {
     const PrecalcDev* __restrict__ ranges = precalc;   // point ranges / shard flags are the same in both tables: read them without waiting for the verdict
-    if (alt.verdict && *alt.verdict == 0) {
-        A.pid = alt.pid; A.pidz = alt.pidz; A.pdeltaF = alt.pdeltaF; A.calib = alt.calib; precalc = alt.precalc;
-    }
-    const EFConst C = ef_const(Cin, A);
+    // the verdict word is FETCHED here and LOOKED AT where the state-dependent inputs are first needed: tested at once it heads the chain
+    // verdict -> point range -> flags -> values of every Schur workgroup with a round trip of its own
+    const int vd = alt.verdict ? *alt.verdict : 1;
     __shared__ union U { TopGramSmem t; PointSmem p; ScGramSmem s; __device__ U() {} } S;
     const int b = blockIdx.x;
     if (b < n_sc) {
         const int h = b / sc_chunks, bx = b - h * sc_chunks;
-        const int P0 = ranges[h * Cin.nF + h].P0, np = ranges[h * Cin.nF + h].np;   // np == 0 outside this rank's shard
+        const int2 rg = *reinterpret_cast<const int2*>(&ranges[h * Cin.nF + h].P0);   // {P0, np} in one load; np == 0 outside this rank's shard
+        const int P0 = rg.x, np = rg.y;
         const int begin = bx * 64, end = min(np, begin + 64);
         __shared__ float pt[6][64];
         const int wave = threadIdx.x >> 6;
         float stage[16];
-        switch (wave) {   // wave-uniform
-            case 0: sc_fused_prefetch<0>(C, A, P0, begin, end, stage); break;
-            case 1: sc_fused_prefetch<1>(C, A, P0, begin, end, stage); break;
-            case 2: sc_fused_prefetch<2>(C, A, P0, begin, end, stage); break;
-            default: sc_fused_prefetch<3>(C, A, P0, begin, end, stage); break;
+        switch (wave) {   // wave-uniform  (flags / JpJdF planes and nF, nP: the same for either verdict)
+            case 0: sc_fused_prefetch<0>(Cin, A, P0, begin, end, stage); break;
+            case 1: sc_fused_prefetch<1>(Cin, A, P0, begin, end, stage); break;
+            case 2: sc_fused_prefetch<2>(Cin, A, P0, begin, end, stage); break;
+            default: sc_fused_prefetch<3>(Cin, A, P0, begin, end, stage); break;
         }
+        if (vd == 0) { A.pid = alt.pid; A.pidz = alt.pidz; A.pdeltaF = alt.pdeltaF; A.calib = alt.calib; precalc = alt.precalc; }
+        const EFConst C = ef_const(Cin, A);
         if (begin < np) point_body(C, A, precalc, phost, P0 + begin, end - begin, S.p, nullptr, nullptr, pt, h);   // (np != 0: the host is this rank's)
         else if (wave == 0) {
 #pragma unroll
@@ -962,6 +964,8 @@ __global__ void __launch_bounds__(256) k_ef_acc_fused(const PrecalcDev* __restri
             default: sc_fused_finish<3>(stage, pt, S.s.tile, S.s.wrow, out); break;
         }
     } else {
+        if (vd == 0) { A.pid = alt.pid; A.pidz = alt.pidz; A.pdeltaF = alt.pdeltaF; A.calib = alt.calib; precalc = alt.precalc; }
+        const EFConst C = ef_const(Cin, A);
         const int q = b - n_sc;
         top_gram_body(C, A, precalc, top_partial, nres_partial, q % top_chunks, q / top_chunks, top_chunks, S.t, nullptr, ranges);
     }
