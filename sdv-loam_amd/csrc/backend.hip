@@ -113,7 +113,7 @@ struct sdvgn_ef {
     int st_cur = 0;                        // which of the two sets holds the current state
     bool state_dirty = true;               // the host mirror changed outside the loop: upload before the next device solve
     ResubX* rx_dev = nullptr;              // xc, xAd of the last solve (the resubstitute workgroups of k_ef_tail_resub read them)
-    unsigned long long* xw_dev = nullptr;  // the same + x as tagged words (SolveIO::xw): the in-launch hand-off of k_ef_tail_resub
+    unsigned long long* xw_dev = nullptr;  // the same + x as tagged words (SolveIO::xw): the in-launch hand-off of k_ef_tail_resub; [kXwTh, +8): thresholds of a select in that launch
     SolveSys* sys_dev = nullptr;           // HA, bA, Hsc, bsc, HFinal, bFinal of the last solve
     SolveOut* sol_host = nullptr;          // pinned: x, step statistics, resInA, status
     SolvePieces* pieces_dev = nullptr;     // [SDVGN_MAX_FRAMES]: per-host shares of HA / bA / Hsc / bsc
@@ -1649,23 +1649,35 @@ static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_st
             // sharded window: the packed buffer of every rank is summed (ONE all-reduce per GN iteration), then every rank stitches and solves
             if (ef_sharded(e) && (rc = ef_allreduce(e, e->acc_dev, (int)acc_count(e)))) return rc;
         }
-        const int has_sel = e->pend_sel_valid ? 1 : 0;
+        // the pending threshold select rides in the factorisation's launch (below); a handle that runs beside others keeps it in this one
+        const int has_sel = (e->own_stream && e->pend_sel_valid) ? 1 : 0;
         k_ef_stitch<<<kStitchParts * nF + 1 + has_sel, kSolveLanes, 0, e->stream>>>(io, e->pend_sel, has_sel);
-        e->pend_sel_valid = false;
+        if (has_sel) e->pend_sel_valid = false;
     }
-    if (e->pend_sel_valid) ef_flush_pending(e);    // system re-used: no stitch launch to ride in
+    if (e->pend_sel_valid && e->own_stream) ef_flush_pending(e);    // (own stream + system re-used: no launch to ride in)
     const int has_rc = e->pend_rc_valid ? 1 : 0;
     const int nblk = (e->nP + 63) / 64;
     const int head = 1 + (has_rc ? kReclBlocks : 0), rest = (nblk + 1) / 2 + (do_step ? 1 : 0);
+    const SelArgs sel = e->pend_sel;
     if (e->own_stream) {   // a window that runs beside others: no spinning workgroups (see k_ef_tail_resub)
         k_ef_tail_resub<<<head, kSolveLanes, 0, e->stream>>>(io, e->pend_rc, has_rc, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup,
-                                                             e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, nblk, 0, 0);
+                                                             e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, nblk, 0, 0,
+                                                             sel, -1, nullptr);
         k_ef_tail_resub<<<rest, kSolveLanes, 0, e->stream>>>(io, e->pend_rc, has_rc, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup,
-                                                             e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, nblk, head, 1);
-    } else
-    k_ef_tail_resub<<<head + rest, kSolveLanes, 0, e->stream>>>(
-        io, e->pend_rc, has_rc, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt,
-        e->pdeltaF_alt, nblk, 0, 0);
+                                                             e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, nblk, head, 1,
+                                                             sel, -1, nullptr);
+    } else {
+        // the pending select as the LAST workgroup of this launch; a re-classification of the same launch that reads the thresholds it writes
+        // takes them as tagged words
+        const int has_sel = e->pend_sel_valid ? 1 : 0;
+        ReclArgs rcl = e->pend_rc;
+        unsigned long long* thw = has_sel ? e->xw_dev + 500 : nullptr;
+        if (has_sel && has_rc && rcl.th == sel.th_out) { rcl.thw = thw; rcl.thseq = (unsigned)io.done_seq; }
+        k_ef_tail_resub<<<head + rest + has_sel, kSolveLanes, 0, e->stream>>>(
+            io, rcl, has_rc, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt,
+            e->pdeltaF_alt, nblk, 0, 0, sel, has_sel ? head + rest : -1, thw);
+        e->pend_sel_valid = false;
+    }
     e->pend_rc_valid = false;
     HIPCHK(hipGetLastError());
     e->sys_on_device = true; e->sys_fetched = false; e->sys_valid = true;

@@ -1264,7 +1264,8 @@ __device__ __forceinline__ unsigned sel_key(int p, int nF, int nP, int own0, int
 template <int SRC>
 __device__ __forceinline__ void select_th_body(int nF, int nP, int own0, int own1, const uint8_t* __restrict__ rflags, const float* __restrict__ wo,
                                                const double* __restrict__ cand, const float* __restrict__ th_prev, float* __restrict__ th_out,
-                                               float* __restrict__ log_slot, SelectSmem& S) {
+                                               float* __restrict__ log_slot, SelectSmem& S,
+                                               unsigned long long* __restrict__ thw = nullptr /* the thresholds as tagged words too: a reader in the same launch */, unsigned thseq = 0) {
     unsigned* s_hist = S.hist; unsigned* s_wsum = S.wsum; unsigned* s_sel = S.sel;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned key[kSelVPT];
@@ -1341,9 +1342,10 @@ __device__ __forceinline__ void select_th_body(int nF, int nP, int own0, int own
         th = th * th;
         th *= 1.0f * 1.0f;                            // setting_overallEnergyTHWeight^2
     }
-    if (tid < nF - 1) th_out[tid] = th_prev[tid];
+    if (tid < nF - 1) { const float tp = th_prev[tid]; th_out[tid] = tp; if (thw) store_tagged_u32(thw + tid, thseq, __float_as_uint(tp)); }
     if (tid == 0) {
         th_out[nF - 1] = th;
+        if (thw) store_tagged_u32(thw + nF - 1, thseq, __float_as_uint(th));
         if (log_slot) *log_slot = th;
     }
 }
@@ -1377,6 +1379,7 @@ __global__ void __launch_bounds__(256) k_ef_pack_th_candidates(int nF, int nP, i
 struct ReclArgs {
     int nF, nP, P0_last, np_last;
     const uint8_t* rflags; const float* wo; int8_t* rstate_new; float* renergy_new; const int* phost; const PrecalcDev* precalc; const float* th;
+    const unsigned long long* thw = nullptr; unsigned thseq = 0;   // non-NULL: the thresholds are being selected in THIS launch and arrive as tagged words (select_th_body)
 };
 __device__ __forceinline__ int reclassify_count(const ReclArgs& a) { return a.nP + a.np_last * (a.nF - 1); }
 __device__ __forceinline__ void reclassify_slot(const ReclArgs& a, int i) {
@@ -1391,7 +1394,9 @@ __device__ __forceinline__ void reclassify_slot(const ReclArgs& a, int i) {
     const int sn = a.rstate_new[s];
     const float e = a.wo[s];
     if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED) || (sn & RS_MASK) == RS_OOB) return;
-    const float ta = a.th[h], tb = a.th[t];
+    float ta, tb;
+    if (a.thw) { ta = __uint_as_float(poll_tagged_u32(a.thw + h, a.thseq, nullptr)); tb = __uint_as_float(poll_tagged_u32(a.thw + t, a.thseq, nullptr)); }
+    else { ta = a.th[h]; tb = a.th[t]; }
     const float frameTH = ta < tb ? tb : ta;
     const bool wjlow = (sn & RS_WJLOW) != 0;
     if (e > frameTH || wjlow) { a.renergy_new[s] = frameTH; a.rstate_new[s] = (int8_t)(RS_OUTLIER | (wjlow ? RS_WJLOW : 0)); }
