@@ -1768,7 +1768,9 @@ static double host_prior_energy(const sdvgn_ef* e) {   // calcLEnergyF_MT: frame
 }
 // final_body: the loop's last body by count -- nothing follows that could carry the deferred select (the next body's k_ef_stitch does
 // otherwise), so it runs beside the statistics in this launch instead of as a launch of its own after the host has seen the verdict
-static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideArgs* dec = nullptr, bool final_body = false) {   // second half: the sums (+ threshold select)
+// with_apply: applyRes of this linearisation in the same launch, unconditionally (the call's initial linearizeAll + applyRes: statistics
+// workgroup + apply workgroups side by side, nothing to wait for) -- single rank, shared stream only
+static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideArgs* dec = nullptr, bool final_body = false, bool with_apply = false) {   // second half: the sums (+ threshold select)
     const int n_partials = e->lin_partials, nL = e->lin_nL;
     const int nS = (e->nP + 63) / 64;
     const double* ps = e->stats_partial + (e->nP / 64 + 2);
@@ -1796,6 +1798,11 @@ static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideAr
             k_ef_stats_select<<<final_body ? 2 : 1, kSelLanes, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host, e->flags_host + 2, ++e->seq_stats, a, d2);
             k_ef_apply<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->nF, e->nP, e->A, e->precalc_dev, e->phost_dev, e->accept_dev);
             if (final_body) defer_select = false;   // taken in this launch
+        } else if (with_apply && !dec) {
+            const size_t slots = (size_t)e->nF * e->nP;
+            k_ef_stats_apply<<<1 + (unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host,
+                                                                                       e->flags_host + 2, ++e->seq_stats, none, e->nF, e->nP, e->A, e->precalc_dev,
+                                                                                       e->phost_dev);
         } else if (dec && dec->verdict) {   // statistics + accept test + conditional applyRes of the trial set in one launch
             const size_t slots = (size_t)e->nF * e->nP;
             k_ef_stats_apply<<<1 + (unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host,
@@ -1901,6 +1908,9 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     if (onecoll) {
         // the call's one extra collective: initial linearizeAll + applyRes + accumulate, their sums and accumulators in one message
         if ((rc = linearize_launch_kernels(e)) || (rc = ef_sharded_message(e, e->coll_cur, /*speculative=*/false))) return rc;
+    } else
+    if (defer && !e->own_stream) {   // linearise, then its statistics and applyRes in ONE launch (they do not depend on each other)
+        if ((rc = linearize_launch_kernels(e)) || (rc = linearize_launch_stats(e, defer, nullptr, false, /*with_apply=*/true))) return rc;
     } else
     if ((rc = linearize_launch(e, defer)) || (rc = sdvgn_ef_apply_res(e))) return rc;
     e->A.reset_oob = 0;
