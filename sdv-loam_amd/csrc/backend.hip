@@ -788,6 +788,20 @@ __global__ void __launch_bounds__(256) k_ef_stats_apply(const double* __restrict
     apply_slot(nF, nP, A, precalc, phost, (size_t)(blockIdx.x - 1) * 256 + threadIdx.x, nullptr, dec.verdict, dec.seq);
 }
 
+// The loop's LAST body by count: statistics + accept test | conditional applyRes | setNewFrameEnergyTH side by side in ONE launch (no later
+// launch could carry the deferred select).  The select reads the EXISTS / LINEARIZED bits of the flags and the energies the linearise
+// wrote; applyRes changes neither, so the two need no order.  Workgroup 0 = sums + verdict, the last workgroup = the select, the others
+// k_ef_apply for kSelLanes slots each (the whole grid is resident at once).
+__global__ void __launch_bounds__(kSelLanes) k_ef_stats_apply_select(const double* __restrict__ pe, int nE, const double* __restrict__ pl, int nL,
+                                                                      const double* __restrict__ ps, int nS, double* __restrict__ out, volatile int* done_flag,
+                                                                      int done_seq, DecideArgs dec, int nF, int nP, EFArrays A,
+                                                                      const PrecalcDev* __restrict__ precalc, const int* __restrict__ phost, SelArgs a) {
+    __shared__ union U { double s[4][256]; SelectSmem sel; __device__ U() {} } S;
+    if (blockIdx.x == 0) { sum_stats_body(pe, nE, pl, nL, ps, nS, out, done_flag, done_seq, S.s, dec); return; }
+    if (blockIdx.x == gridDim.x - 1) { select_th_body<0>(a.nF, a.nP, a.own0, a.own1, a.rflags, a.wo, nullptr, a.th_prev, a.th_out, a.log_slot, S.sel); return; }
+    apply_slot(nF, nP, A, precalc, phost, (size_t)(blockIdx.x - 1) * kSelLanes + threadIdx.x, nullptr, dec.verdict, dec.seq);
+}
+
 // device buffer -> pinned host buffer + completion flag (waitflag.hpp): the read-back after an all-reduce without the copy engine
 __global__ void __launch_bounds__(256) k_ef_copy_publish(const double* __restrict__ src, double* __restrict__ dst, int n, unsigned* __restrict__ ctr,
                                                          volatile int* flag, int seq) {
@@ -1790,6 +1804,13 @@ static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideAr
         a.rflags = e->rflags; a.wo = e->A.renergy_wo; a.th_prev = e->A.frameTH_r; a.th_out = e->A.frameTH_w;
         a.log_slot = e->th_log ? e->th_log + (e->th_log_n++ % kThLog) : nullptr;
         const DecideArgs none{0, 0, 0, nullptr, 0, nullptr, 0};
+        if (dec && dec->verdict && final_body && !e->own_stream) {
+            const size_t slots = (size_t)e->nF * e->nP;
+            k_ef_stats_apply_select<<<2 + (unsigned)((slots + kSelLanes - 1) / kSelLanes), kSelLanes, 0, e->stream>>>(
+                e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host, e->flags_host + 2, ++e->seq_stats, *dec, e->nF, e->nP, e->A,
+                e->precalc_dev, e->phost_dev, a);
+            defer_select = false;   // taken in this launch
+        } else
         if (dec && dec->verdict && (e->own_stream || final_body)) {
             // a window that runs beside others (sdvgn_ef_optimize_batch): the same two steps as two launches -- the apply workgroups would
             // otherwise sit on the CUs polling the verdict word while other windows' kernels wait for a place
