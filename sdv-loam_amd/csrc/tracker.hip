@@ -744,8 +744,12 @@ static int struct_pose_run(sdvgn_tracker* t, int mode, int n, const float* u, co
     C.wM3G = (float)(t->w[0] - 3); C.hM3G = (float)(t->h[0] - 3); // globalCalib.cpp:46-47
     C.n = n; C.n_hosts = n_hosts; C.mode = mode;
     const float* ds = (const float*)t->sp_stage_host;
-    k_struct_pose<<<1, kStructThreads, 0, t->stream>>>(C, ds, ds + np, ds + 2 * np, (const int*)(ds + 3 * np), ds + 6 * np,
-                                                     (const float2*)(ds + 4 * np), t->sp_io_host, seq);
+    if (n <= kStructSmallN)
+        k_struct_pose<kStructSmallThreads, kStructSmallPPL><<<1, kStructSmallThreads, 0, t->stream>>>(C, ds, ds + np, ds + 2 * np, (const int*)(ds + 3 * np), ds + 6 * np,
+                                                                                                      (const float2*)(ds + 4 * np), t->sp_io_host, seq);
+    else
+        k_struct_pose<kStructThreads, kStructPPL><<<1, kStructThreads, 0, t->stream>>>(C, ds, ds + np, ds + 2 * np, (const int*)(ds + 3 * np), ds + 6 * np,
+                                                                                       (const float2*)(ds + 4 * np), t->sp_io_host, seq);
     HIPCHK(hipGetLastError());
     HIPCHK(wait_flag(&t->sp_io_host->done, seq, t->stream));   // published behind the results: no stream synchronisation
     return SDVGN_OK;
