@@ -20,7 +20,7 @@ from sdv_loam_amd import backend_api, synthetic as syn  # noqa: E402
 nF = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 ppk = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 W = syn.make_window(w=1241, h=376, nF=nF, pts_per_kf=ppk, seed=0, calib=syn.KITTI00)
-G = backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+G = backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP, stream=(backend_api.EnergyFunctional.STREAM_OWN if os.environ.get("EXP_OWN_STREAM") else None)).load(W)   # EXP_OWN_STREAM=1: the factorisation workgroup in a launch of its own (no parked workgroups beside it)
 names = ["k_ef_stitch start -> k_ef_tail_resub start", "H, b assembly from the shares", "blocked LDL^T",
          "back substitution + orthogonalize", "xAd, step, precalc table"]
 rows, sub, blk, stp = [], [], [], []
