@@ -432,13 +432,17 @@ __device__ __forceinline__ void apply_slot(int nF, int nP, const EFArrays& A, co
         }
     }
     if ((sn & RS_MASK) == RS_IN) {
-        fl |= RF_ACTIVE;
-        fl ^= RF_SEL;                                   // takeDataF: swap J with the residual's freshly linearised J
+        fl |= RF_ACTIVE;                                // takeDataF: swap J with the residual's freshly linearised J (the flip below)
 #pragma unroll
         for (int i = 0; i < 6; ++i) A.JpJd[(size_t)i * slots + s] = jx[i] * d0 + jy[i] * d1;
     } else {
         fl &= (uint8_t)~RF_ACTIVE;
     }
+    // The buffers swap for EVERY residual the linearise wrote (new state IN or OUTLIER; an OOB one was not written), not only for the ones
+    // that stay active: the Jacobian of an inactive residual is never read (it becomes active again only through a later linearise + this
+    // swap), and residuals that are always written together then keep the same RF_SEL -- a wave's 64 stores of a Jacobian plane (and the
+    // accumulate's loads) go to ONE buffer instead of being split lane by lane between the two after a few accepted steps.
+    if ((sn & RS_MASK) != RS_OOB) fl ^= RF_SEL;
     A.rflags[s] = fl;
     A.rstate[s] = (int8_t)(sn & RS_MASK);
     A.renergy[s] = en;
@@ -459,7 +463,7 @@ __global__ void __launch_bounds__(256) k_ef_apply_revert(int nF, int nP, EFArray
     const uint8_t old = bak.fl[s];
     if (old == 0xFF) return;
     const uint8_t cur = A.rflags[s];
-    if ((cur ^ old) & RF_SEL) {
+    if ((cur & RF_ACTIVE) && ((cur ^ old) & RF_SEL)) {     // the apply made it active with the new Jacobian: JpJd was rewritten (and saved)
 #pragma unroll
         for (int i = 0; i < 6; ++i) A.JpJd[(size_t)i * slots + s] = bak.JpJd[(size_t)i * slots + s];
     }
