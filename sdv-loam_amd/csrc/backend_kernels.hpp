@@ -423,7 +423,11 @@ __device__ __forceinline__ void apply_slot(int nF, int nP, const EFArrays& A, co
     if (!go) return;
     if (np_h == 0) return;   // host frame not in this rank's shard
     if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED)) return;
-    if (st == RS_OOB) return;
+    if (st == RS_OOB) {          // applyRes leaves an OOB residual alone (:applyRes) -- except for the buffer swap, see below
+        if (bak) { bak->fl[s] = fl; bak->st[s] = A.rstate[s]; bak->en[s] = A.renergy[s]; }
+        A.rflags[s] = fl ^ RF_SEL;
+        return;
+    }
     if (bak) {
         bak->fl[s] = fl; bak->st[s] = A.rstate[s]; bak->en[s] = A.renergy[s];
         if ((sn & RS_MASK) == RS_IN) {
@@ -438,11 +442,11 @@ __device__ __forceinline__ void apply_slot(int nF, int nP, const EFArrays& A, co
     } else {
         fl &= (uint8_t)~RF_ACTIVE;
     }
-    // The buffers swap for EVERY residual the linearise wrote (new state IN or OUTLIER; an OOB one was not written), not only for the ones
-    // that stay active: the Jacobian of an inactive residual is never read (it becomes active again only through a later linearise + this
-    // swap), and residuals that are always written together then keep the same RF_SEL -- a wave's 64 stores of a Jacobian plane (and the
-    // accumulate's loads) go to ONE buffer instead of being split lane by lane between the two after a few accepted steps.
-    if ((sn & RS_MASK) != RS_OOB) fl ^= RF_SEL;
+    // The buffers swap for EVERY residual that exists and is not fixed (new state IN, OUTLIER or OOB), not only for the ones that stay active:
+    // the Jacobian of an inactive residual is never read (it becomes active again only through a later linearise + this swap), and all these
+    // residuals then keep the same RF_SEL for the life of the window -- a wave's 64 stores of a Jacobian plane (and the accumulate's loads)
+    // go to ONE buffer instead of being split lane by lane between the two after a few accepted steps.
+    fl ^= RF_SEL;
     A.rflags[s] = fl;
     A.rstate[s] = (int8_t)(sn & RS_MASK);
     A.renergy[s] = en;
