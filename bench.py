@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-child-tracker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -288,22 +289,33 @@ def measure_inloop_kernel(kernel="k_ef_linearize", timeout=240, arith=0):
                        timeout=timeout, check=True)
         dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
         con = sqlite3.connect(dbs[0])
-        du = np.array([r[0] for r in con.execute("select duration from kernels where name like ?", ("%" + kernel + "%",))], np.float64) / 1e6
-        if not len(du):
+        allk = con.execute("select name, start, duration from kernels order by start").fetchall()
+        lin = [(st, dur) for (nm, st, dur) in allk if kernel in nm]
+        if not lin:
             return None
+        # the child runs one untimed warm-up call and then the 8 calls that count (trace_child): the statistics cover the launches of those 8
+        # (the process's very first launches include code-object loading -- 0.1 ms once in a while -- and are warm-up in the bench proper too)
+        timed = lin[-(len(lin) * 8 // 9):] if len(lin) >= 9 else lin
+        t_cut = timed[0][0]
+        du = np.array([dur for (_, dur) in timed], np.float64) / 1e6
         try:   # the per-kernel summary of this trace as a file (gpurun_out/, copied to profiles/ by hand): what roofline.achieved is computed from
-            rows = con.execute("select name, count(*), avg(duration), sum(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc").fetchall()
+            agg = {}
+            for nm, st, dur in allk:
+                if st >= t_cut:
+                    agg.setdefault(nm, []).append(dur)
+            rows = sorted(((nm, len(v), float(np.mean(v)), float(np.sum(v)), float(np.min(v)), float(np.max(v))) for nm, v in agg.items()), key=lambda r: -r[3])
             tot = sum(r[3] for r in rows)
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             with open(os.path.join(ROOT, "gpurun_out", "inloop_trace_summary_arith%d.txt" % arith), "w") as fsum:
-                fsum.write("# rocprofv3 --kernel-trace -- python bench.py --trace-child   (SDVGN_BENCH_ARITH=%d; the headline protocol alone: 8 fresh windows x optimize(6))\n" % arith)
+                fsum.write("# rocprofv3 --kernel-trace -- python bench.py --trace-child   (SDVGN_BENCH_ARITH=%d; the headline protocol alone: 8 fresh windows x optimize(6); "
+                           "the untimed warm-up call and the window loads before it are not in the table)\n" % arith)
                 fsum.write("%-100s %8s %12s %10s %10s %10s %6s\n" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
                 for r in rows[:30]:
                     fsum.write("%-100s %8d %12.1f %10.3f %10.3f %10.3f %6.2f\n" % (r[0][:100], r[1], r[3] / 1e3, r[2] / 1e3, r[4] / 1e3, r[5] / 1e3, 100 * r[3] / tot))
         except Exception:  # noqa: BLE001
             pass
         return dict(mean_ms=float(du.mean()), median_ms=float(np.median(du)), p90_ms=float(np.percentile(du, 90)), launches=int(len(du)),
-                    source="rocprofv3 --kernel-trace of the protocol alone (8 windows x optimize(6))")
+                    source="rocprofv3 --kernel-trace of the protocol alone (8 windows x optimize(6); the untimed warm-up call before them excluded)")
     except Exception as ex:  # noqa: BLE001
         return dict(error=repr(ex))
     finally:
@@ -691,6 +703,28 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
+    if "WORLD_SIZE" not in os.environ and not args.worker and os.environ.get("SDVGN_BENCH_NO_WRAPPER") != "1":
+        # `python bench.py` from a bare shell, one GPU: the measurement runs in a worker process and its JSON line passes through.  A GPU
+        # memory fault aborts the process that owns the queue; one such abort was seen in the ~200 GPU runs of round 3 (not reproduced), and it
+        # must not cost the line: the worker is started again (the third attempt without the extras).  Timed regions live in the worker.
+        import subprocess
+        for attempt in range(3):
+            cmd = [sys.executable, os.path.abspath(__file__), "--worker"] + sys.argv[1:] + (["--quick"] if attempt == 2 and not args.quick else [])
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode == 0 and lines:
+                line = lines[-1]
+                if attempt:
+                    try:
+                        d = json.loads(line)
+                        d["bench_worker_attempts"] = attempt + 1
+                        line = json.dumps(d)
+                    except Exception:  # noqa: BLE001
+                        pass
+                print(line, flush=True)
+                return
+            sys.stderr.write("bench.py: worker attempt %d ended with rc %d and %d JSON line(s); starting it again\n" % (attempt + 1, p.returncode, len(lines)))
+        sys.exit(1)
     import torch
     from sdv_loam_amd import backend_api, synthetic as syn
     rank, local, world = dist_setup()
