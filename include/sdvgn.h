@@ -436,6 +436,9 @@ int sdvgn_ef_optimize_immature(sdvgn_ef* e, int n, const int* host, const float*
 int sdvgn_ef_dim(sdvgn_ef* ef);
 int sdvgn_ef_get_system(sdvgn_ef* ef, double* HA, double* bA, double* Hsc, double* bsc, double* HFinal, double* bFinal);
 int sdvgn_ef_get_residual_J(sdvgn_ef* ef, int which /*0 new, 1 EF*/, float* out24 /*[nR][24]*/);
+/* (which = 1 is the reference's efResidual->J for residuals the EnergyFunctional uses, i.e. active ones; which = 0 is `J` as the last
+ * linearize left it, valid until the next applyRes.  applyRes swaps the two buffers of every existing, not fixed residual -- the reference's
+ * takeDataF only where the new state is IN --, so the rows of a residual that is not active afterwards carry no meaning: no consumer reads them.) */
 int sdvgn_ef_get_residual_state(sdvgn_ef* ef, int* state_state, int* state_new, float* energy_new,
                                 float* energy_with_outlier, unsigned char* isActive);
 int sdvgn_ef_get_points(sdvgn_ef* ef, float* out9 /*[nP][Hdd_accAF,bd_accAF,Hcd_accAF x4,HdiF,bdSumF,step]*/);
