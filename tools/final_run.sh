@@ -7,7 +7,7 @@ timeout 900 python bench.py > gpurun_out/${R}_bench_final.json 2> gpurun_out/${R
 cp gpurun_out/inloop_trace_summary_arith0.txt gpurun_out/${R}_inloop_trace_summary_exact.txt 2>/dev/null
 cp gpurun_out/inloop_trace_summary_arith1.txt gpurun_out/${R}_inloop_trace_summary_tolerance.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ${R}h -- python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu --quick > /root/repo/gpurun_out/${R}_prof_bench.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ${R}h -- python /root/repo/bench.py --worker --steps 20 --warmup 5 --no-cpu --quick > /root/repo/gpurun_out/${R}_prof_bench.log 2>&1
 cd /root/repo
 python - <<'PY'
 import sqlite3, glob, json
@@ -17,7 +17,7 @@ db=glob.glob("/tmp/prof/**/*.db", recursive=True)[0]
 con=sqlite3.connect(db)
 rows=con.execute("select name, count(*), avg(duration), sum(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc").fetchall()
 tot=sum(r[3] for r in rows)
-out=["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu --quick   (MI355X, round 3, last build)",
+out=["# rocprofv3 --kernel-trace --stats -- python bench.py --worker --steps 20 --warmup 5 --no-cpu --quick   (MI355X, last build; --worker: the measuring process itself, not the restarting wrapper)",
      "%-100s %8s %12s %10s %10s %10s %6s" % ("kernel","calls","total_us","avg_us","min_us","max_us","%")]
 for r in rows[:45]:
     out.append("%-100s %8d %12.1f %10.3f %10.3f %10.3f %6.2f" % (r[0][:100], r[1], r[3]/1e3, r[2]/1e3, r[4]/1e3, r[5]/1e3, 100*r[3]/tot))
