@@ -712,12 +712,14 @@ def main():
             cmd = [sys.executable, os.path.abspath(__file__), "--worker"] + sys.argv[1:] + (["--quick"] if attempt == 2 and not args.quick else [])
             p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
             lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-            if p.returncode == 0 and lines:
+            if lines:   # (the line is the worker's last action: a non-zero exit code behind it can only come from the teardown)
                 line = lines[-1]
-                if attempt:
+                if attempt or p.returncode:
                     try:
                         d = json.loads(line)
                         d["bench_worker_attempts"] = attempt + 1
+                        if p.returncode:
+                            d["bench_worker_exit_code"] = p.returncode
                         line = json.dumps(d)
                     except Exception:  # noqa: BLE001
                         pass
