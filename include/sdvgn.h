@@ -298,6 +298,12 @@ int sdvgn_ef_set_points(sdvgn_ef* ef, int nP, const int* host, const float* u, c
 int sdvgn_ef_set_residuals(sdvgn_ef* ef, int nR, const int* point, const int* target, const int* state_state,
                            const unsigned char* hasMatcher, const double* matcher_xy, const unsigned char* isLinearized,
                            const unsigned char* isActive);
+/* EFResidual::takeDataF (EnergyFunctionalStructs.cpp:15-25) for a caller that keeps PointFrameResidual::linearize on the host: the
+ * Jacobians the EnergyFunctional side owns (efResidual->J: resF 2, Jpdxi[0] 6, Jpdxi[1] 6, Jpdc[0] 4, Jpdc[1] 4, Jpdd 2 -- the layout of
+ * sdvgn_ef_get_residual_J) and res_toZeroF (NULL: zeros) of the residuals given to sdvgn_ef_set_residuals, in that order.  JpJdF is formed
+ * here like takeDataF forms it.  After this call sdvgn_ef_solve_system runs EnergyFunctional::solveSystemF on exactly these values -- the
+ * drop-in for a host loop that is otherwise unchanged (oracle/dropin/EnergyFunctionalGPU.cpp). */
+int sdvgn_ef_set_residual_jacobians(sdvgn_ef* ef, int nR, const float* J24 /*[nR][24]*/, const float* res_toZero2 /*[nR][2] or NULL*/);
 /* EnergyFunctional::HM, bM (marginalisation prior) and lastNullspaces_pose + _scale (EnergyFunctional.h:96-119). */
 int sdvgn_ef_set_marg_prior(sdvgn_ef* ef, const double* HM, const double* bM);
 int sdvgn_ef_set_nullspaces(sdvgn_ef* ef, int k, const double* vectors);

@@ -13,9 +13,10 @@ _bound = set()
 def _L(raw=None, prefix="orc_"):
     L = _Prefixed(lib() if raw is None else raw, prefix)
     if True:
-        if prefix in _bound:
+        key = (prefix, id(raw))        # one binding per library object: libref.so and libref_dropin.so share the prefix ref_
+        if key in _bound:
             return L
-        _bound.add(prefix)
+        _bound.add(key)
         L.orc_ef_create.restype = vp
         L.orc_ef_create.argtypes = [C.c_int, C.c_int]
         L.orc_ef_destroy.argtypes = [vp]

@@ -548,6 +548,9 @@ void ref_ef_optimize_immature(void* e, int n, const int* host, const float* u, c
     }
 }
 
+// the EnergyFunctional object of the window (key of the drop-in's side table, oracle/dropin/EnergyFunctionalGPU.cpp)
+void* ref_ef_energy_functional(void* e) { RefEF* E = (RefEF*)e; return E->fs ? (void*)E->fs->ef : nullptr; }
+
 // diagnostics of the loading step
 void ref_ef_load_report(void* e, int* color_mismatch, double* image_grad_maxdiff) {
     RefEF* E = (RefEF*)e; *color_mismatch = E->color_mismatch; *image_grad_maxdiff = E->image_grad_maxdiff;

@@ -75,6 +75,7 @@ void ref_tracker_destroy(void* h) {
     delete T->Hcalib;
     delete T;
 }
+void* ref_tracker_object(void* h) { return ((RefTracker*)h)->ct; }   // key of the drop-in's side table (oracle/dropin/CoarseTrackerGPU.cpp)
 void ref_tracker_set_settings(void* h, float huberTH, float coarseCutoffTH, float affA, float affB) {
     RefTracker* T = (RefTracker*)h; T->huberTH = huberTH; T->coarseCutoffTH = coarseCutoffTH; T->affA = affA; T->affB = affB;
 }

@@ -19,6 +19,7 @@ PROTOTYPES = [
     ("sdvgn_ef_set_frame_image_raw", C.c_int, [vp, C.c_int, f32p]),
     ("sdvgn_ef_set_points", C.c_int, [vp, C.c_int, i32p, f32p, f32p, f32p, f32p, f32p, f32p, u8p, u8p]),
     ("sdvgn_ef_set_residuals", C.c_int, [vp, C.c_int, i32p, i32p, i32p, u8p, f64p, u8p, u8p]),
+    ("sdvgn_ef_set_residual_jacobians", C.c_int, [vp, C.c_int, f32p, vp]),
     ("sdvgn_ef_set_marg_prior", C.c_int, [vp, f64p, f64p]),
     ("sdvgn_ef_set_nullspaces", C.c_int, [vp, C.c_int, f64p]),
     ("sdvgn_ef_compute_nullspaces", C.c_int, [vp]),
@@ -130,6 +131,12 @@ class EnergyFunctional:
         self.setPrecalcValues()
         self.make_resident()
         return self
+
+    def set_residual_jacobians(self, J24, res_toZero2=None):
+        """EFResidual::takeDataF for Jacobians linearised by the caller ([nR][24] floats in sdvgn_ef_get_residual_J's layout)."""
+        J24 = np.ascontiguousarray(J24, np.float32)
+        r2z = None if res_toZero2 is None else np.ascontiguousarray(res_toZero2, np.float32)
+        self._check(self.L.sdvgn_ef_set_residual_jacobians(self.h_, J24.shape[0], J24.reshape(-1), None if r2z is None else r2z.ctypes.data))
 
     def make_resident(self):
         """Upload what the setters left pending (window constants, frame states, calib) and drain the stream: optimize() then starts from

@@ -9,6 +9,7 @@
 //           independent of the number of points ("tiny; keep on host").
 #include "../../include/sdvgn.h"
 #include "sdvgn_debug.h"
+#include "devmem.hpp"
 #include "backend_kernels.hpp"
 
 #include <dlfcn.h>
@@ -64,7 +65,8 @@ struct FrameH {
 };
 
 template <typename T>
-int dev_alloc(T** p, size_t n) { return hipMalloc((void**)p, sizeof(T) * (n ? n : 1)) == hipSuccess ? 0 : -1; }
+int dev_alloc_tagged(T** p, size_t n, const char* tag) { return gmem::dmalloc_impl((void**)p, sizeof(T) * (n ? n : 1), alignof(T), tag) == hipSuccess ? 0 : -1; }
+#define dev_alloc(p, n) dev_alloc_tagged((p), (n), #p)
 
 }  // namespace
 
@@ -992,7 +994,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
         if (!bad) hipMemset(e->dbg_stamps, 0, sizeof(unsigned long long) * kDbgStampWords);
     }
     if (getenv("SDVGN_DEBUG_FLAGS") && (atoi(getenv("SDVGN_DEBUG_FLAGS")) & 64)) {
-        bad |= hipHostMalloc((void**)&e->solve_stamps, sizeof(unsigned long long) * 16) != hipSuccess;
+        bad |= SDVGN_HMALLOC((void**)&e->solve_stamps, sizeof(unsigned long long) * 16) != hipSuccess;
         if (!bad) std::memset(e->solve_stamps, 0, sizeof(unsigned long long) * 16);
     }
     bad |= dev_alloc(&e->energy_partial, (size_t)SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES * kMaxChunks * 4);
@@ -1008,26 +1010,26 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->win_dev, 1) | dev_alloc(&e->sstate_dev, 2) | dev_alloc(&e->calib_dev, 2) | dev_alloc(&e->rx_dev, 1) | dev_alloc(&e->sys_dev, 1);
     bad |= dev_alloc(&e->pieces_dev, SDVGN_MAX_FRAMES);
     if (bad) { sdvgn_ef_destroy(e); return -(int)hipErrorOutOfMemory; }
-    HIPCHK(hipHostMalloc(&e->precalc_host, 2 * sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
-    HIPCHK(hipHostMalloc(&e->acc_host, sizeof(double) * accmax));
-    HIPCHK(hipHostMalloc(&e->stats_host, sizeof(double) * 8));
+    HIPCHK(SDVGN_HMALLOC(&e->precalc_host, 2 * sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
+    HIPCHK(SDVGN_HMALLOC(&e->acc_host, sizeof(double) * accmax));
+    HIPCHK(SDVGN_HMALLOC(&e->stats_host, sizeof(double) * 8));
     std::memset(e->stats_host, 0, sizeof(double) * 8);   // [0..3] sums, [4] verdict, [6] (as unsigned) the sticky intra-launch wait error word
-    HIPCHK(hipMalloc((void**)&e->accept_dev, 64));
+    HIPCHK(SDVGN_DMALLOC((void**)&e->accept_dev, 64));
     HIPCHK(hipMemset(e->accept_dev, 0, 64));
-    HIPCHK(hipHostMalloc((void**)&e->flags_host, 64));
-    HIPCHK(hipHostMalloc((void**)&e->th_log, sizeof(float) * kThLog));
-    HIPCHK(hipHostMalloc((void**)&e->win_host, sizeof(SolveWindow)));
-    HIPCHK(hipHostMalloc((void**)&e->sstate_host, sizeof(SolveState)));
-    HIPCHK(hipHostMalloc((void**)&e->calib_host, sizeof(CalibDev)));
-    HIPCHK(hipHostMalloc((void**)&e->sol_host, sizeof(SolveOut)));
+    HIPCHK(SDVGN_HMALLOC((void**)&e->flags_host, 64));
+    HIPCHK(SDVGN_HMALLOC((void**)&e->th_log, sizeof(float) * kThLog));
+    HIPCHK(SDVGN_HMALLOC((void**)&e->win_host, sizeof(SolveWindow)));
+    HIPCHK(SDVGN_HMALLOC((void**)&e->sstate_host, sizeof(SolveState)));
+    HIPCHK(SDVGN_HMALLOC((void**)&e->calib_host, sizeof(CalibDev)));
+    HIPCHK(SDVGN_HMALLOC((void**)&e->sol_host, sizeof(SolveOut)));
     std::memset(e->sol_host, 0, sizeof(SolveOut));
     HIPCHK(hipMemset(e->rx_dev, 0, sizeof(ResubX)));
-    HIPCHK(hipMalloc(&e->xw_dev, sizeof(unsigned long long) * 512));
+    HIPCHK(SDVGN_DMALLOC(&e->xw_dev, sizeof(unsigned long long) * 512));
     HIPCHK(hipMemset(e->xw_dev, 0, sizeof(unsigned long long) * 512));   // tag 0 is never current (the solves count from 1)
     e->flags_host[0] = e->flags_host[1] = e->flags_host[2] = e->flags_host[3] = 0;
-    HIPCHK(hipMalloc((void**)&e->done_ctr, 2 * sizeof(unsigned)));
+    HIPCHK(SDVGN_DMALLOC((void**)&e->done_ctr, 2 * sizeof(unsigned)));
     HIPCHK(hipMemset(e->done_ctr, 0, 2 * sizeof(unsigned)));
-    HIPCHK(hipHostMalloc((void**)&e->imm_pc_host, sizeof(ImmPrecalc) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
+    HIPCHK(SDVGN_HMALLOC((void**)&e->imm_pc_host, sizeof(ImmPrecalc) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
     HIPCHK(hipMemsetAsync(e->rflags, 0, slots, e->stream));
     HIPCHK(hipMemsetAsync(e->stats_partial, 0, sizeof(double) * 3 * (mp / 64 + 2), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1051,24 +1053,24 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->stats_dev, e->stats_partial, e->imm_pc_dev, e->rstate_new2, e->renergy_new2, e->renergy_wo2,
                     e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->precalc_alt, e->dbg_stamps, e->marg_mask_dev, e->drop_mask_dev, e->th_dev, e->fin_dev,
                     e->win_dev, e->sstate_dev, e->calib_dev, e->rx_dev, e->xw_dev, e->sys_dev, e->pieces_dev};
-    for (void* p : ptrs) if (p) hipFree(p);
-    if (e->precalc_host) hipHostFree(e->precalc_host);
-    if (e->acc_host) hipHostFree(e->acc_host);
-    if (e->stats_host) hipHostFree(e->stats_host);
-    if (e->accept_dev) hipFree(e->accept_dev);
-    if (e->flags_host) hipHostFree(e->flags_host);
-    if (e->th_log) hipHostFree(e->th_log);
-    if (e->win_host) hipHostFree(e->win_host);
-    if (e->sstate_host) hipHostFree(e->sstate_host);
-    if (e->calib_host) hipHostFree(e->calib_host);
-    if (e->sol_host) hipHostFree(e->sol_host);
+    for (void* p : ptrs) if (p) SDVGN_DFREE(p);
+    if (e->precalc_host) SDVGN_HFREE(e->precalc_host);
+    if (e->acc_host) SDVGN_HFREE(e->acc_host);
+    if (e->stats_host) SDVGN_HFREE(e->stats_host);
+    if (e->accept_dev) SDVGN_DFREE(e->accept_dev);
+    if (e->flags_host) SDVGN_HFREE(e->flags_host);
+    if (e->th_log) SDVGN_HFREE(e->th_log);
+    if (e->win_host) SDVGN_HFREE(e->win_host);
+    if (e->sstate_host) SDVGN_HFREE(e->sstate_host);
+    if (e->calib_host) SDVGN_HFREE(e->calib_host);
+    if (e->sol_host) SDVGN_HFREE(e->sol_host);
     for (hipEvent_t ev : e->lin_events) if (ev) hipEventDestroy(ev);
-    if (e->solve_stamps) hipHostFree(e->solve_stamps);
-    if (e->done_ctr) hipFree(e->done_ctr);
-    if (e->imm_pc_host) hipHostFree(e->imm_pc_host);
-    if (e->imm_stage) hipHostFree(e->imm_stage);
-    if (e->own_coll && e->coll[0]) hipFree(e->coll[0]);
-    if (e->apply_bak.fl) { hipFree(e->apply_bak.fl); hipFree(e->apply_bak.st); hipFree(e->apply_bak.en); hipFree(e->apply_bak.JpJd); }
+    if (e->solve_stamps) SDVGN_HFREE(e->solve_stamps);
+    if (e->done_ctr) SDVGN_DFREE(e->done_ctr);
+    if (e->imm_pc_host) SDVGN_HFREE(e->imm_pc_host);
+    if (e->imm_stage) SDVGN_HFREE(e->imm_stage);
+    if (e->own_coll && e->coll[0]) SDVGN_DFREE(e->coll[0]);
+    if (e->apply_bak.fl) { SDVGN_DFREE(e->apply_bak.fl); SDVGN_DFREE(e->apply_bak.st); SDVGN_DFREE(e->apply_bak.en); SDVGN_DFREE(e->apply_bak.JpJd); }
     if (e->own_stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1274,6 +1276,33 @@ int sdvgn_ef_set_residuals(sdvgn_ef* e, int nR, const int* point, const int* tar
     return SDVGN_OK;
 }
 
+// EFResidual::takeDataF for Jacobians linearised on the host (EnergyFunctionalStructs.cpp:15-25): the rows go to the buffer the
+// EnergyFunctional side owns (RF_SEL as sdvgn_ef_set_residuals left it), JpJdF = Jpdxi[0] * Jpdd[0] + Jpdxi[1] * Jpdd[1] in float like the reference
+int sdvgn_ef_set_residual_jacobians(sdvgn_ef* e, int nR, const float* J24, const float* res_toZero2) {
+    if (!e || !J24 || nR < 0 || nR != e->nR || e->nP < 1) return SDVGN_E_ARG;
+    EF_DEVICE(e);
+    const size_t slots = (size_t)e->nF * e->nP;
+    std::vector<uint8_t> fl(slots);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(fl.data(), e->rflags, slots, hipMemcpyDeviceToHost));
+    std::vector<float> J(2 * (size_t)kJPlanes * slots), JpJd(6 * slots, 0.0f), r2z(2 * slots, 0.0f);
+    HIPCHK(hipMemcpy(J.data(), e->J, sizeof(float) * J.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < nR; ++i) {
+        const size_t s = (size_t)e->r_slot[i];
+        const int buf = (fl[s] & RF_SEL) ? 1 : 0;
+        const float* j = J24 + (size_t)i * 24;
+        float* dst = J.data() + (size_t)buf * kJPlanes * slots + s;
+        for (int k = 0; k < kJPlanes; ++k) dst[(size_t)k * slots] = j[k];
+        for (int k = 0; k < 6; ++k) JpJd[(size_t)k * slots + s] = j[2 + k] * j[22] + j[8 + k] * j[23];
+        if (res_toZero2) { r2z[s] = res_toZero2[2 * i]; r2z[slots + s] = res_toZero2[2 * i + 1]; }
+    }
+    HIPCHK(hipMemcpy(e->J, J.data(), sizeof(float) * J.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->JpJd, JpJd.data(), sizeof(float) * JpJd.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->rres_toZero, r2z.data(), sizeof(float) * r2z.size(), hipMemcpyHostToDevice));
+    e->sys_valid = false;
+    return SDVGN_OK;
+}
+
 int sdvgn_ef_set_marg_prior(sdvgn_ef* e, const double* HM, const double* bM) {
     if (!e || !HM || !bM || e->nF < 1) return SDVGN_E_ARG;
     const int n = CPARS + 6 * e->nF;
@@ -1449,8 +1478,8 @@ int sdvgn_ef_set_external_buffers(sdvgn_ef* e, double* acc_dev, int acc_capacity
     if ((size_t)acc_capacity < accmax || (size_t)stats_capacity < 4 + (size_t)e->max_points) return SDVGN_E_ARG;
     EF_DEVICE(e);
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (e->own_acc) hipFree(e->acc_dev);
-    if (e->own_stats) hipFree(e->stats_dev);
+    if (e->own_acc) SDVGN_DFREE(e->acc_dev);
+    if (e->own_stats) SDVGN_DFREE(e->stats_dev);
     e->acc_dev = acc_dev; e->stats_dev = stats_dev;
     e->own_acc = e->own_stats = false;
     return SDVGN_OK;
@@ -1469,15 +1498,15 @@ int sdvgn_ef_set_collective_buffer(sdvgn_ef* e, double* buf_dev, int capacity) {
     const size_t stride = coll_stride_for(e);
     if (buf_dev && (size_t)capacity < 2 * stride) return SDVGN_E_ARG;
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (e->own_coll && e->coll[0]) hipFree(e->coll[0]);
+    if (e->own_coll && e->coll[0]) SDVGN_DFREE(e->coll[0]);
     e->own_coll = false;
-    if (!buf_dev) { HIPCHK(hipMalloc((void**)&buf_dev, sizeof(double) * 2 * stride)); e->own_coll = true; }
+    if (!buf_dev) { HIPCHK(SDVGN_DMALLOC((void**)&buf_dev, sizeof(double) * 2 * stride)); e->own_coll = true; }
     HIPCHK(hipMemsetAsync(buf_dev, 0, sizeof(double) * 2 * stride, e->stream));
     e->coll[0] = buf_dev; e->coll[1] = buf_dev + stride; e->coll_stride = stride; e->coll_cur = 0;
     if (!e->apply_bak.fl) {
         const size_t slots = e->slots_cap;
-        HIPCHK(hipMalloc((void**)&e->apply_bak.fl, slots)); HIPCHK(hipMalloc((void**)&e->apply_bak.st, slots));
-        HIPCHK(hipMalloc((void**)&e->apply_bak.en, sizeof(float) * slots)); HIPCHK(hipMalloc((void**)&e->apply_bak.JpJd, sizeof(float) * 6 * slots));
+        HIPCHK(SDVGN_DMALLOC((void**)&e->apply_bak.fl, slots)); HIPCHK(SDVGN_DMALLOC((void**)&e->apply_bak.st, slots));
+        HIPCHK(SDVGN_DMALLOC((void**)&e->apply_bak.en, sizeof(float) * slots)); HIPCHK(SDVGN_DMALLOC((void**)&e->apply_bak.JpJd, sizeof(float) * 6 * slots));
     }
     return SDVGN_OK;
 }
@@ -2259,9 +2288,9 @@ int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_m
     const size_t slots = (size_t)nF * e->nP, need = slots + 8 * (size_t)e->nP;
     if (need > e->fin_bytes) {
         HIPCHK(hipStreamSynchronize(e->stream));
-        if (e->fin_dev) hipFree(e->fin_dev);
+        if (e->fin_dev) SDVGN_DFREE(e->fin_dev);
         e->fin_dev = nullptr; e->fin_bytes = 0;
-        HIPCHK(hipMalloc(&e->fin_dev, need));
+        HIPCHK(SDVGN_DMALLOC(&e->fin_dev, need));
         e->fin_bytes = need;
     }
     float* relbs_dev = (float*)e->fin_dev;
@@ -2646,9 +2675,9 @@ int sdvgn_ef_optimize_immature(sdvgn_ef* e, int n, const int* host, const float*
     const size_t bytes = np * (4 * 6 + 32 + 32 + 4 + 4 + 4 + 4 * (size_t)nF);
     if (bytes > e->imm_stage_bytes) {
         HIPCHK(hipStreamSynchronize(e->stream));
-        if (e->imm_stage) hipHostFree(e->imm_stage);
+        if (e->imm_stage) SDVGN_HFREE(e->imm_stage);
         e->imm_stage = nullptr; e->imm_stage_bytes = 0;
-        HIPCHK(hipHostMalloc(&e->imm_stage, bytes * 2));
+        HIPCHK(SDVGN_HMALLOC(&e->imm_stage, bytes * 2));
         e->imm_stage_bytes = bytes * 2;
     }
     float* base = (float*)e->imm_stage;

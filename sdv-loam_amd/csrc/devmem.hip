@@ -1,0 +1,207 @@
+// devmem.hip -- allocation layer of libsdvgn with two debugging modes (see devmem.hpp).
+#include "devmem.hpp"
+
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace sdvgn {
+namespace gmem {
+namespace {
+
+struct Rec {
+    int kind;            // 1 = fenced device mapping, 2 = banded device buffer, 3 = fenced pinned host buffer
+    void* base;          // start of the reservation / hipMalloc block / mmap block
+    size_t mapped;       // bytes with storage behind them
+    size_t reserved;     // bytes of address space (kind 1, 3)
+    size_t bytes;        // what the caller asked for
+    hipMemGenericAllocationHandle_t handle;
+    const char* tag;
+    void* res = nullptr; // kind 1: start of the address reservation (front guard)
+};
+std::mutex g_mu;
+std::unordered_map<void*, Rec> g_recs;
+unsigned long long g_violations = 0;
+constexpr size_t kBand = 4096;
+constexpr unsigned char kPoison = 0xA5;
+
+size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+int env_int(const char* name, int dflt) { const char* s = getenv(name); return s ? atoi(s) : dflt; }
+bool log_on() { static const bool on = env_int("SDVGN_GUARD_LOG", 0) != 0; return on; }
+size_t guard_align() { static const size_t a = (size_t)std::max(1, env_int("SDVGN_GUARD_ALIGN", 16)); return a; }
+
+void log_alloc(const char* what, const Rec& r, void* user) {
+    if (!log_on()) return;
+    fprintf(stderr, "[sdvgn guard] %s %-40s [%p, %p) %zu bytes; storage [%p, %p), fence behind\n", what, r.tag, user, (char*)user + r.bytes, r.bytes,
+            r.base, (char*)r.base + r.mapped);
+}
+
+hipError_t fenced_device_alloc(void** p, size_t bytes, size_t align, const char* tag) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipMemAllocationProp prop;
+    std::memset(&prop, 0, sizeof(prop));
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess) return e;
+    if (gran == 0) gran = 1 << 21;
+    const size_t a = std::max(align, guard_align());
+    // [front guard | mapping | back guard]: both guards stay reserved and unmapped.  SDVGN_GUARD_PAD_MB (default 64) is their size -- an
+    // overrun must not be able to jump over the fence into the next buffer's mapping; SDVGN_GUARD_SIDE=front puts the buffer at the START of
+    // its mapping instead (reads / writes BEFORE the start of a buffer fault), default back (past the end)
+    static const size_t pad_mb = (size_t)std::max(0, env_int("SDVGN_GUARD_PAD_MB", 64));
+    static const bool front = getenv("SDVGN_GUARD_SIDE") && !strcmp(getenv("SDVGN_GUARD_SIDE"), "front");
+    const size_t guard = std::max(gran, round_up(pad_mb << 20, gran));
+    const size_t need = round_up(bytes ? bytes : 1, a), mapped = round_up(need, gran), reserved = guard + mapped + guard;
+    void* res = nullptr;
+    if ((e = hipMemAddressReserve(&res, reserved, gran, nullptr, 0)) != hipSuccess) return e;
+    void* va = (char*)res + guard;
+    hipMemGenericAllocationHandle_t h;
+    if ((e = hipMemCreate(&h, mapped, &prop, 0)) != hipSuccess) { hipMemAddressFree(res, reserved); return e; }
+    if ((e = hipMemMap(va, mapped, 0, h, 0)) != hipSuccess) { hipMemRelease(h); hipMemAddressFree(res, reserved); return e; }
+    hipMemAccessDesc desc;
+    std::memset(&desc, 0, sizeof(desc));
+    desc.location.type = hipMemLocationTypeDevice;
+    desc.location.id = dev;
+    desc.flags = hipMemAccessFlagsProtReadWrite;
+    if ((e = hipMemSetAccess(va, mapped, &desc, 1)) != hipSuccess) { hipMemUnmap(va, mapped); hipMemRelease(h); hipMemAddressFree(res, reserved); return e; }
+    void* user = front ? va : (void*)((char*)va + (mapped - need));
+    Rec r{1, va, mapped, reserved, bytes, h, tag};
+    r.res = res;
+    { std::lock_guard<std::mutex> lk(g_mu); g_recs[user] = r; }
+    log_alloc("device", r, user);
+    *p = user;
+    return hipSuccess;
+}
+
+hipError_t banded_device_alloc(void** p, size_t bytes, const char* tag) {
+    char* base = nullptr;
+    const size_t body = round_up(bytes ? bytes : 1, 256);
+    hipError_t e = hipMalloc((void**)&base, body + 2 * kBand);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemset(base, kPoison, kBand)) != hipSuccess || (e = hipMemset(base + kBand + bytes, kPoison, body - bytes + kBand)) != hipSuccess) { hipFree(base); return e; }
+    hipDeviceSynchronize();
+    void* user = base + kBand;
+    Rec r{2, base, body + 2 * kBand, 0, bytes, {}, tag};
+    { std::lock_guard<std::mutex> lk(g_mu); g_recs[user] = r; }
+    log_alloc("device(banded)", r, user);
+    *p = user;
+    return hipSuccess;
+}
+
+void check_bands(const Rec& r, void* user) {
+    const size_t tail = r.mapped - kBand - r.bytes;
+    std::vector<unsigned char> head(kBand), back(tail);
+    hipDeviceSynchronize();
+    if (hipMemcpy(head.data(), r.base, kBand, hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (hipMemcpy(back.data(), (char*)user + r.bytes, tail, hipMemcpyDeviceToHost) != hipSuccess) return;
+    long first_head = -1, first_back = -1;
+    for (size_t i = 0; i < kBand; ++i) if (head[i] != kPoison) { first_head = (long)i; }
+    for (size_t i = 0; i < tail; ++i) if (back[i] != kPoison) { first_back = (long)i; break; }
+    if (first_head >= 0 || first_back >= 0) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        ++g_violations;
+        fprintf(stderr, "[sdvgn guard] VIOLATION at %s (%zu bytes): %s%s (head byte %ld from the start of the band, tail byte %ld past the end)\n", r.tag, r.bytes,
+                first_head >= 0 ? "store BEFORE the buffer " : "", first_back >= 0 ? "store PAST the end of the buffer" : "", first_head, first_back);
+    }
+}
+
+}  // namespace
+
+int guard_mode() { static const int m = env_int("SDVGN_GUARD", 0); return m; }
+unsigned long long guard_violations() { std::lock_guard<std::mutex> lk(g_mu); return g_violations; }
+
+// SDVGN_ALLOC_FILL=<0..255>: every new device buffer is filled with that byte (any mode) -- 255 turns every float that is read before
+// it was written into a NaN, so a result that depends on uninitialised memory shows in the first test that computes with it
+static int alloc_fill() { static const int f = env_int("SDVGN_ALLOC_FILL", -1); return f; }
+hipError_t dmalloc_impl(void** p, size_t bytes, size_t align, const char* tag) {
+    const int m = guard_mode();
+    hipError_t e;
+    if (m == 1) e = fenced_device_alloc(p, bytes, align, tag);
+    else if (m == 2) e = banded_device_alloc(p, bytes, tag);
+    else e = hipMalloc(p, bytes ? bytes : 1);
+    if (e == hipSuccess && alloc_fill() >= 0) {
+        void* from = *p; size_t n = bytes ? bytes : 1;
+        if (m == 1) {   // the slack in front of an end-aligned buffer too: a read BEFORE the start of a buffer then shows like an uninitialised one
+            std::lock_guard<std::mutex> lk(g_mu);
+            const Rec& r = g_recs[*p];
+            from = r.base; n = r.mapped;
+        }
+        e = hipMemset(from, alloc_fill() & 255, n);
+        hipDeviceSynchronize();
+    }
+    return e;
+}
+
+hipError_t dfree(void* p) {
+    if (!p) return hipSuccess;
+    if (guard_mode() == 0) return hipFree(p);
+    Rec r;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_recs.find(p);
+        if (it == g_recs.end()) return hipFree(p);
+        r = it->second;
+        g_recs.erase(it);
+    }
+    if (r.kind == 2) { check_bands(r, p); return hipFree(r.base); }
+    hipDeviceSynchronize();
+    if (env_int("SDVGN_GUARD_NOFREE", 0)) return hipSuccess;   // experiment: never give a fenced mapping back (no reuse of its address range or pages)
+    hipError_t e = hipMemUnmap(r.base, r.mapped);
+    hipMemRelease(r.handle);
+    hipMemAddressFree(r.res, r.reserved);
+    return e;
+}
+
+static bool host_fence_on() { static const bool on = guard_mode() == 1 && env_int("SDVGN_GUARD_HOST", 1) != 0; return on; }
+hipError_t hmalloc_impl(void** p, size_t bytes, const char* tag) {
+    if (!host_fence_on()) return hipHostMalloc(p, bytes ? bytes : 1);
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+    const size_t need = round_up(bytes ? bytes : 1, std::max<size_t>(16, guard_align())), mapped = round_up(need, page), reserved = mapped + page;
+    void* base = mmap(nullptr, reserved, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (base == MAP_FAILED) return hipErrorOutOfMemory;
+    mprotect((char*)base + mapped, page, PROT_NONE);
+    std::memset(base, 0, mapped);
+    hipError_t e = hipHostRegister(base, mapped, hipHostRegisterDefault);
+    if (e != hipSuccess) { munmap(base, reserved); return e; }
+    void* user = (char*)base + (mapped - need);
+    Rec r{3, base, mapped, reserved, bytes, {}, tag};
+    { std::lock_guard<std::mutex> lk(g_mu); g_recs[user] = r; }
+    log_alloc("pinned host", r, user);
+    *p = user;
+    return hipSuccess;
+}
+
+hipError_t hfree(void* p) {
+    if (!p) return hipSuccess;
+    if (!host_fence_on()) return hipHostFree(p);
+    Rec r;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_recs.find(p);
+        if (it == g_recs.end()) return hipHostFree(p);
+        r = it->second;
+        g_recs.erase(it);
+    }
+    hipDeviceSynchronize();
+    hipError_t e = hipHostUnregister(r.base);
+    munmap(r.base, r.reserved);
+    return e;
+}
+
+}  // namespace gmem
+}  // namespace sdvgn
+
+extern "C" {
+int sdvgn_debug_guard_mode(void) { return sdvgn::gmem::guard_mode(); }
+unsigned long long sdvgn_debug_guard_violations(void) { return sdvgn::gmem::guard_violations(); }
+}

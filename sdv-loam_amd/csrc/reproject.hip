@@ -18,6 +18,7 @@
 // latency-bound; one workgroup = one wave so that 220+ workgroups spread over the chip.
 #include "../../include/sdvgn.h"
 #include "gnmath.hpp"
+#include "devmem.hpp"
 
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -386,12 +387,12 @@ int sdvgn_reproj_create(sdvgn_reproj** out, int device, int w0, int h0, int leve
     for (int l = 0; l < levels; ++l) { r->w[l] = w0 >> l; r->h[l] = h0 >> l; }
     if (stream) r->stream = (hipStream_t)stream;
     else { HIPCHK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking)); r->own_stream = true; }
-    HIPCHK(hipHostMalloc((void**)&r->C_host, sizeof(RpConst)));
-    HIPCHK(hipMalloc((void**)&r->C_dev, sizeof(RpConst)));
+    HIPCHK(SDVGN_HMALLOC((void**)&r->C_host, sizeof(RpConst)));
+    HIPCHK(SDVGN_DMALLOC((void**)&r->C_dev, sizeof(RpConst)));
     std::memset(r->C_host, 0, sizeof(RpConst));
     const size_t np = ((size_t)max_points + 63) & ~(size_t)63;
     r->stage_bytes = np * (4 * 6 + 16 + 4 + 4 + 4 + 16 + 4);   // u v idepth host ref type | px0 cell quality success px level
-    HIPCHK(hipHostMalloc(&r->stage, r->stage_bytes));
+    HIPCHK(SDVGN_HMALLOC(&r->stage, r->stage_bytes));
     *out = r;
     return SDVGN_OK;
 }
@@ -400,9 +401,9 @@ void sdvgn_reproj_destroy(sdvgn_reproj* r) {
     if (!r) return;
     hipSetDevice(r->device);
     hipStreamSynchronize(r->stream);
-    for (int k = 0; k < kRpMaxFrames; ++k) if (r->frame_img[k]) hipFree(r->frame_img[k]);
-    for (int l = 0; l < SDVGN_MAX_LEVELS; ++l) if (r->cur_img[l]) hipFree(r->cur_img[l]);
-    hipHostFree(r->C_host); hipFree(r->C_dev); hipHostFree(r->stage);
+    for (int k = 0; k < kRpMaxFrames; ++k) if (r->frame_img[k]) SDVGN_DFREE(r->frame_img[k]);
+    for (int l = 0; l < SDVGN_MAX_LEVELS; ++l) if (r->cur_img[l]) SDVGN_DFREE(r->cur_img[l]);
+    SDVGN_HFREE(r->C_host); SDVGN_DFREE(r->C_dev); SDVGN_HFREE(r->stage);
     if (r->own_stream) hipStreamDestroy(r->stream);
     delete r;
 }
@@ -429,12 +430,12 @@ int sdvgn_reproj_set_calib(sdvgn_reproj* r, float fx, float fy, float cx, float 
 
 static int rp_set_image(sdvgn_reproj* r, float** owned, const float** slot, const float* host_aos3, const float* dev_aos3, size_t npix) {
     if (dev_aos3) {
-        if (*owned) { HIPCHK(hipStreamSynchronize(r->stream)); hipFree(*owned); *owned = nullptr; }
+        if (*owned) { HIPCHK(hipStreamSynchronize(r->stream)); SDVGN_DFREE(*owned); *owned = nullptr; }
         *slot = dev_aos3;
         return SDVGN_OK;
     }
     if (!host_aos3) return SDVGN_OK;   // keep the current image
-    if (!*owned) HIPCHK(hipMalloc((void**)owned, sizeof(float) * 3 * npix));
+    if (!*owned) HIPCHK(SDVGN_DMALLOC((void**)owned, sizeof(float) * 3 * npix));
     HIPCHK(hipMemcpyAsync(*owned, host_aos3, sizeof(float) * 3 * npix, hipMemcpyHostToDevice, r->stream));
     HIPCHK(hipStreamSynchronize(r->stream));   // host_aos3 may be pageable and reused by the caller
     *slot = *owned;

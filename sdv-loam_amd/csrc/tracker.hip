@@ -10,6 +10,7 @@
 #include "gnmath.hpp"
 #include "tracker_kernels.hpp"
 #include "waitflag.hpp"
+#include "devmem.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -155,7 +156,7 @@ static int ensure_records(sdvgn_tracker* t) {
     if (t->rec_valid) return SDVGN_OK;
     for (int l = 0; l < t->levels; ++l) {
         const int npix = t->w[l] * t->h[l];
-        if (!t->pyr_rec_dev[l]) HIPCHK(hipMalloc(&t->pyr_rec_dev[l], sizeof(float4) * 4 * (size_t)npix));
+        if (!t->pyr_rec_dev[l]) HIPCHK(SDVGN_DMALLOC(&t->pyr_rec_dev[l], sizeof(float4) * 4 * (size_t)npix));
         k_pyr_to_records<<<(npix + 255) / 256, 256, 0, t->stream>>>(t->pyr_dev[l], t->pyr_rec_dev[l], t->w[l], t->h[l]);
     }
     HIPCHK(hipGetLastError());
@@ -187,7 +188,7 @@ static int launch_res_gs(sdvgn_tracker* t, int lvl, int B, const double* pose7, 
         if (!t->half_valid) {
             for (int l = 0; l < t->levels; ++l) {
                 const int npix = t->w[l] * t->h[l];
-                if (!t->pyr_half_dev[l]) HIPCHK(hipMalloc(&t->pyr_half_dev[l], sizeof(__half) * 4 * (size_t)npix));
+                if (!t->pyr_half_dev[l]) HIPCHK(SDVGN_DMALLOC(&t->pyr_half_dev[l], sizeof(__half) * 4 * (size_t)npix));
                 k_pyr_to_half<<<(npix + 255) / 256, 256, 0, t->stream>>>(t->pyr_dev[l], t->pyr_half_dev[l], npix);
             }
             t->half_valid = true;
@@ -332,21 +333,21 @@ int sdvgn_tracker_create(sdvgn_tracker** out, int device, int w0, int h0, int le
         t->stream = shared[device];
     }
     for (int l = 0; l < levels; ++l) {
-        HIPCHK(hipMalloc(&t->pc_dev[l], sizeof(float4) * max_points));
-        HIPCHK(hipMalloc(&t->pyr_dev[l], sizeof(float) * 3 * (size_t)t->w[l] * t->h[l]));
+        HIPCHK(SDVGN_DMALLOC(&t->pc_dev[l], sizeof(float4) * max_points));
+        HIPCHK(SDVGN_DMALLOC(&t->pyr_dev[l], sizeof(float) * 3 * (size_t)t->w[l] * t->h[l]));
         HIPCHK(hipMemsetAsync(t->pyr_dev[l], 0, sizeof(float) * 3 * (size_t)t->w[l] * t->h[l], t->stream));
     }
-    HIPCHK(hipMalloc(&t->img_stage_dev, sizeof(float) * (size_t)w0 * h0));
-    HIPCHK(hipMalloc(&t->params_dev, sizeof(LevelParams) * max_batch));
-    HIPCHK(hipHostMalloc(&t->params_host, sizeof(LevelParams) * max_batch));
-    HIPCHK(hipMalloc(&t->partial_dev, sizeof(float) * kNRed * (size_t)t->max_chunks * max_batch));
-    HIPCHK(hipMalloc(&t->out_dev, sizeof(double) * kOutStride * max_batch));
-    HIPCHK(hipHostMalloc(&t->out_host, sizeof(double) * kOutStride * max_batch));
-    HIPCHK(hipHostMalloc((void**)&t->flag_host, 64));
+    HIPCHK(SDVGN_DMALLOC(&t->img_stage_dev, sizeof(float) * (size_t)w0 * h0));
+    HIPCHK(SDVGN_DMALLOC(&t->params_dev, sizeof(LevelParams) * max_batch));
+    HIPCHK(SDVGN_HMALLOC(&t->params_host, sizeof(LevelParams) * max_batch));
+    HIPCHK(SDVGN_DMALLOC(&t->partial_dev, sizeof(float) * kNRed * (size_t)t->max_chunks * max_batch));
+    HIPCHK(SDVGN_DMALLOC(&t->out_dev, sizeof(double) * kOutStride * max_batch));
+    HIPCHK(SDVGN_HMALLOC(&t->out_host, sizeof(double) * kOutStride * max_batch));
+    HIPCHK(SDVGN_HMALLOC((void**)&t->flag_host, 64));
     *t->flag_host = 0;
-    HIPCHK(hipMalloc(&t->terms_dev, sizeof(float) * 8 * (size_t)max_points));
-    HIPCHK(hipMalloc(&t->status_dev, sizeof(int) * (size_t)max_points));
-    HIPCHK(hipHostMalloc(&t->track_host, sizeof(TrackState) * max_batch));
+    HIPCHK(SDVGN_DMALLOC(&t->terms_dev, sizeof(float) * 8 * (size_t)max_points));
+    HIPCHK(SDVGN_DMALLOC(&t->status_dev, sizeof(int) * (size_t)max_points));
+    HIPCHK(SDVGN_HMALLOC(&t->track_host, sizeof(TrackState) * max_batch));
     std::memset(t->track_host, 0, sizeof(TrackState) * max_batch);
     HIPCHK(hipStreamSynchronize(t->stream));
     *out = t;
@@ -359,8 +360,8 @@ void sdvgn_tracker_destroy(sdvgn_tracker* t) {
     hipStreamSynchronize(t->stream);
     const bool dbg = getenv("SDVGN_PROFILE") != nullptr;
     auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess && dbg) fprintf(stderr, "[sdvgn] tracker destroy: %s -> %d (%s)\n", what, (int)e, hipGetErrorString(e)); };
-#define DFREE(p) chk(hipFree(p), "hipFree(" #p ")")
-#define HFREE(p) chk(hipHostFree(p), "hipHostFree(" #p ")")
+#define DFREE(p) chk(SDVGN_DFREE(p), "SDVGN_DFREE(" #p ")")
+#define HFREE(p) chk(SDVGN_HFREE(p), "SDVGN_HFREE(" #p ")")
     for (int l = 0; l < t->levels; ++l) { DFREE(t->pc_dev[l]); DFREE(t->pyr_dev[l]); if (t->pyr_half_dev[l]) DFREE(t->pyr_half_dev[l]); if (t->pyr_rec_dev[l]) DFREE(t->pyr_rec_dev[l]); }
     DFREE(t->img_stage_dev); DFREE(t->params_dev); DFREE(t->ptrs_dev); HFREE(t->params_host); DFREE(t->partial_dev);
     DFREE(t->out_dev); HFREE(t->out_host); HFREE(t->flag_host); DFREE(t->terms_dev); DFREE(t->status_dev);
@@ -538,7 +539,7 @@ int sdvgn_tracker_res_and_gs_multi(sdvgn_tracker* t, int lvl, int B, const void*
     if (!t || !pose7 || !aff || !pc_dev || !img_dev || B < 1 || B > t->max_batch) return SDVGN_E_ARG;
     if (t->precision != PREC_F32 && t->precision != PREC_F32_REC) return SDVGN_E_STATE;   // (record mode: img_dev[b] = sdvgn_tracker_records_dev of problem b)
     HIPCHK(hipSetDevice(t->device));
-    if (!t->ptrs_dev) HIPCHK(hipMalloc(&t->ptrs_dev, sizeof(ProblemPtrs) * t->max_batch));
+    if (!t->ptrs_dev) HIPCHK(SDVGN_DMALLOC(&t->ptrs_dev, sizeof(ProblemPtrs) * t->max_batch));
     std::vector<ProblemPtrs> hp(B);
     for (int b = 0; b < B; ++b) { hp[b].pc = (const float4*)pc_dev[b]; hp[b].img = (const float*)img_dev[b]; if (!hp[b].pc || !hp[b].img) return SDVGN_E_ARG; }
     HIPCHK(hipMemcpyAsync(t->ptrs_dev, hp.data(), sizeof(ProblemPtrs) * B, hipMemcpyHostToDevice, t->stream));
@@ -635,10 +636,10 @@ int sdvgn_tracker_track_batch(sdvgn_tracker* t, int B, double* pose7_io, double*
     if (T >= 1) {
         if (t->team_cap < B) {
             HIPCHK(hipStreamSynchronize(t->stream));
-            if (t->team_dev) HIPCHK(hipFree(t->team_dev));
+            if (t->team_dev) HIPCHK(SDVGN_DFREE(t->team_dev));
             t->team_dev = nullptr; t->team_cap = 0;
             const int cap = t->max_batch < 512 ? t->max_batch : 512;   // at most 512 resident workgroups
-            HIPCHK(hipMalloc(&t->team_dev, sizeof(TeamMem) * (size_t)cap));
+            HIPCHK(SDVGN_DMALLOC(&t->team_dev, sizeof(TeamMem) * (size_t)cap));
             HIPCHK(hipMemsetAsync(t->team_dev, 0, sizeof(TeamMem) * (size_t)cap, t->stream));
             t->team_cap = cap;
         }
@@ -711,13 +712,13 @@ static int struct_pose_run(sdvgn_tracker* t, int mode, int n, const float* u, co
     const size_t bytes = np * 4 * 6 + (size_t)n_hosts * 12 * 4;
     if (bytes > t->sp_cap_bytes) {
         HIPCHK(hipStreamSynchronize(t->stream));
-        hipHostFree(t->sp_stage_host);
+        SDVGN_HFREE(t->sp_stage_host);
         t->sp_stage_host = nullptr; t->sp_cap_bytes = 0;
         const size_t cap = bytes * 2 + 4096;
-        HIPCHK(hipHostMalloc(&t->sp_stage_host, cap));
+        HIPCHK(SDVGN_HMALLOC(&t->sp_stage_host, cap));
         t->sp_cap_bytes = cap;
     }
-    if (!t->sp_io_host) HIPCHK(hipHostMalloc((void**)&t->sp_io_host, sizeof(StructIO)));
+    if (!t->sp_io_host) HIPCHK(SDVGN_HMALLOC((void**)&t->sp_io_host, sizeof(StructIO)));
     float* hs = (float*)t->sp_stage_host;
     float* hu = hs, *hv = hs + np, *hid = hs + 2 * np;
     int* hh = (int*)(hs + 3 * np);
@@ -798,11 +799,11 @@ int sdvgn_tracker_trace_set_points(sdvgn_tracker* t, int n, const float* u, cons
     const size_t np = ((size_t)n + 63) & ~(size_t)63;
     if ((int)np > t->tp_cap) {
         HIPCHK(hipStreamSynchronize(t->stream));
-        hipFree(t->tp_static_dev); hipHostFree(t->tp_state_host);
+        SDVGN_DFREE(t->tp_static_dev); SDVGN_HFREE(t->tp_state_host);
         t->tp_static_dev = nullptr; t->tp_state_host = nullptr; t->tp_cap = 0;
         const size_t cap = np + np / 2 + 1024;
-        HIPCHK(hipMalloc((void**)&t->tp_static_dev, sizeof(float) * 24 * cap));
-        HIPCHK(hipHostMalloc(&t->tp_state_host, sizeof(float) * 8 * cap));
+        HIPCHK(SDVGN_DMALLOC((void**)&t->tp_static_dev, sizeof(float) * 24 * cap));
+        HIPCHK(SDVGN_HMALLOC(&t->tp_state_host, sizeof(float) * 8 * cap));
         t->tp_cap = (int)cap;
     }
     t->tp_n = n;
@@ -864,18 +865,18 @@ int sdvgn_tracker_make_coarse_depth(sdvgn_tracker* t, int n, const int* u, const
     size_t npix = 0, nrows = 0;
     for (int l = 0; l < L; ++l) { npix += (size_t)t->w[l] * t->h[l]; nrows += t->h[l]; }
     if (!t->cd_maps) {
-        HIPCHK(hipMalloc((void**)&t->cd_maps, sizeof(float) * 3 * npix));
-        HIPCHK(hipMalloc((void**)&t->cd_rows, sizeof(int) * 2 * nrows));
-        HIPCHK(hipHostMalloc((void**)&t->cd_n_host, sizeof(int) * SDVGN_MAX_LEVELS));
+        HIPCHK(SDVGN_DMALLOC((void**)&t->cd_maps, sizeof(float) * 3 * npix));
+        HIPCHK(SDVGN_DMALLOC((void**)&t->cd_rows, sizeof(int) * 2 * nrows));
+        HIPCHK(SDVGN_HMALLOC((void**)&t->cd_n_host, sizeof(int) * SDVGN_MAX_LEVELS));
         t->cd_slot.assign((size_t)w0 * h0, 0);
         t->cd_stamp.assign((size_t)w0 * h0, 0);
     }
     if (n > t->cd_stage_cap) {
         HIPCHK(hipStreamSynchronize(t->stream));
-        hipHostFree(t->cd_stage);
+        SDVGN_HFREE(t->cd_stage);
         t->cd_stage = nullptr; t->cd_stage_cap = 0;
         const int cap = n + n / 2 + 1024;
-        HIPCHK(hipHostMalloc(&t->cd_stage, (size_t)cap * 12));
+        HIPCHK(SDVGN_HMALLOC(&t->cd_stage, (size_t)cap * 12));
         t->cd_stage_cap = cap;
     }
     // splat in tuple order (:266-293): tuples that hit one pixel are summed here, sequentially, exactly like `idepth[0][k] += ...`

@@ -1,0 +1,57 @@
+"""oracle/_ref/libref_dropin.so without a GPU: it loads (against the in-tree libsdvgn.so), the two replaced member functions are the GPU-backed
+definitions of oracle/dropin/*.cpp (they are what calls the C ABI), and nothing else of the reference was replaced."""
+import os
+import subprocess
+
+import pytest
+
+
+def _lib():
+    from oracle import dropin
+    return dropin.dropin_lib()
+
+
+needs_dropin = pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref",
+                                                                  "libref_dropin.so")), reason="oracle/_ref/libref_dropin.so not built here")
+
+SSF = "_ZN8sdv_loam16EnergyFunctional12solveSystemFEidPNS_12CalibHessianE"
+TNC = "_ZN8sdv_loam13CoarseTracker17trackNewestCoarseE"
+
+
+@needs_dropin
+def test_dropin_library_loads_and_binds_the_c_abi(sdvgn_lib):
+    from oracle import dropin
+    L = _lib()
+    assert L is not None
+    for name in ("ref_ef_create", "ref_ef_optimize_full", "ref_track", "sdvgn_dropin_ef_calls", "sdvgn_dropin_tracker_calls"):
+        assert hasattr(L, name), name
+    out = subprocess.check_output(["nm", "-D", dropin.dropin_path()], text=True)
+    undefined = {ln.split()[-1] for ln in out.splitlines() if " U " in ln}
+    for name in ("sdvgn_ef_solve_system", "sdvgn_ef_set_residual_jacobians", "sdvgn_ef_set_residuals", "sdvgn_tracker_track", "sdvgn_tracker_set_ref"):
+        assert name in undefined, name                     # the drop-in reaches the product only through include/sdvgn.h's entry points
+    defined = [ln.split()[-1] for ln in out.splitlines() if " T " in ln or " W " in ln]
+    assert SSF in defined and any(s.startswith(TNC) for s in defined)
+    needed = subprocess.check_output(["readelf", "-d", dropin.dropin_path()], text=True)
+    assert "libsdvgn.so" in needed
+
+
+@needs_dropin
+def test_only_the_two_members_were_replaced(sdvgn_lib):
+    """the all-CPU library and the drop-in export the same reference symbols; the replaced two call sdvgn_* in the drop-in only"""
+    from oracle import dropin, refpin
+    def syms(p):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", p], text=True)
+        return {ln.split()[-1] for ln in out.splitlines() if "sdv_loam" in ln}
+    a, b = syms(refpin.ref_path()), syms(dropin.dropin_path())
+    assert a == b
+    dis = subprocess.check_output(["objdump", "-d", "--no-show-raw-insn", dropin.dropin_path()], text=True)
+    def calls(sym_prefix):
+        body, on = [], False
+        for ln in dis.splitlines():
+            if ln.endswith(">:"):
+                on = ("<" + sym_prefix) in ln
+            elif on and "call" in ln:
+                body.append(ln)
+        return body
+    assert any("sdvgn_ef_solve_system" in c for c in calls(SSF))
+    assert any("sdvgn_tracker_track" in c for c in calls(TNC))
