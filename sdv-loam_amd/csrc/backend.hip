@@ -873,7 +873,7 @@ static RcclApi& rccl_api() {
 // One communicator per (process, id): every handle initialised with the same 128-byte id shares it (reference-counted) -- a process that
 // optimises many sharded windows pays ncclCommInitRank once, not once per window.  The last handle to let go destroys it.
 namespace {
-struct SharedComm { unsigned char id[NCCL_UNIQUE_ID_BYTES]; ncclComm_t comm; int refs; };
+struct SharedComm { unsigned char id[NCCL_UNIQUE_ID_BYTES]; ncclComm_t comm; int refs; int rank, world, device; };
 std::mutex g_comm_mu;
 std::vector<SharedComm> g_comms;
 }
@@ -1541,13 +1541,19 @@ int sdvgn_ef_init_rccl(sdvgn_ef* e, const unsigned char* id128, int rank, int wo
     if (e->rccl_comm) { hipStreamSynchronize(e->stream); ef_release_comm(e); }
     std::lock_guard<std::mutex> lk(g_comm_mu);
     for (SharedComm& c : g_comms)
-        if (!std::memcmp(c.id, id128, NCCL_UNIQUE_ID_BYTES)) { ++c.refs; e->rccl_comm = c.comm; return SDVGN_OK; }   // not collective: the communicator exists
+        if (!std::memcmp(c.id, id128, NCCL_UNIQUE_ID_BYTES)) {
+            // the communicator of this id exists in the process: share it -- but only as the SAME rank of the same clique on the same device
+            // (a second rank of one id inside one process would need a communicator of its own; not supported: say so instead of returning
+            // the first handle's and hanging or mis-summing later)
+            if (c.rank != rank || c.world != world || c.device != e->device) return SDVGN_E_ARG;
+            ++c.refs; e->rccl_comm = c.comm; return SDVGN_OK;   // not collective
+        }
     ncclUniqueId id;
     std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
     ncclComm_t comm = nullptr;
     if (api.CommInitRank(&comm, world, id, rank) != ncclSuccess) return SDVGN_E_STATE;   // collective: every rank calls it
     SharedComm sc;
-    std::memcpy(sc.id, id128, NCCL_UNIQUE_ID_BYTES); sc.comm = comm; sc.refs = 1;
+    std::memcpy(sc.id, id128, NCCL_UNIQUE_ID_BYTES); sc.comm = comm; sc.refs = 1; sc.rank = rank; sc.world = world; sc.device = e->device;
     g_comms.push_back(sc);
     e->rccl_comm = comm;
     return SDVGN_OK;
@@ -2146,6 +2152,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
                 ra.nF = nF; ra.nP = e->nP; ra.P0_last = e->hostP0[nF - 1]; ra.np_last = e->hostP0[nF] - ra.P0_last;
                 ra.rflags = e->rflags; ra.wo = e->A.renergy_wo; ra.rstate_new = e->A.rstate_new; ra.renergy_new = e->A.renergy_new;
                 ra.phost = e->phost_dev; ra.precalc = e->precalc_dev; ra.th = e->th_dev + (size_t)trial * SDVGN_MAX_FRAMES;
+                ra.err = e->A.err;
                 if (defer) {
                     // nothing is launched here: the trial's select rides in the next body's k_ef_stitch, this re-classification in its
                     // k_ef_tail_resub -- both through before that body's linearise (which reads the kept set's state_NewEnergy for
@@ -2158,6 +2165,13 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
                 }
             }
             ef_select_new_set(e, e->new_cur, e->new_cur);
+            if (onecoll && !spec) {
+                // (idepth_zero differed before this trial, so the body ran the two-collective way; the restore above moved idepth_zero, i.e.
+                // deltaF and with it bdSum / the linearised terms of the CURRENT state: the kept message no longer describes it -- rebuild it,
+                // like the accept branch does, instead of solving the next body on stale accumulators)
+                ef_use_coll(e, e->coll_cur);
+                if ((rc = ef_accumulate(e, /*with_reduce=*/true)) || (rc = ef_allreduce(e, e->acc_dev, (int)acc_count(e)))) return rc;
+            }
             if (spec) {   // the per-point planes (Hdd / bd / Hcd sums, HdiF, bdSum: inputs of the next resubstitute) back to the kept state: they
                 // are local to the rank, so an accumulate WITHOUT its reduce -- the kept message buffer stays as it is
                 ef_use_coll(e, e->coll_cur);
@@ -2244,6 +2258,9 @@ int sdvgn_ef_optimize_batch(sdvgn_ef* const* handles, int B, int mnumOptIts, int
         if (!handles[b]) return SDVGN_E_ARG;
         for (int c = 0; c < b; ++c) if (handles[c] == handles[b]) return SDVGN_E_ARG;   // a handle is single-threaded
     }
+    // sharded windows issue collectives on their communicator: several of them side by side would enqueue ncclAllReduce calls from several
+    // threads / streams in an order the other ranks do not share -- one at a time (plain sdvgn_ef_optimize), never as a batch
+    for (int b = 0; b < B && B > 1; ++b) if (ef_sharded(handles[b])) return SDVGN_E_ARG;
     if (B == 1) { const int rc = sdvgn_ef_optimize(handles[0], mnumOptIts, flags, nullptr, 0, 0); if (its_out) its_out[0] = rc; return rc < 0 ? rc : SDVGN_OK; }
     BatchPool& P = batch_pool();
     std::lock_guard<std::mutex> one_call(P.call_mu);

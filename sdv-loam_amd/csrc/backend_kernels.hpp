@@ -1388,6 +1388,7 @@ struct ReclArgs {
     int nF, nP, P0_last, np_last;
     const uint8_t* rflags; const float* wo; int8_t* rstate_new; float* renergy_new; const int* phost; const PrecalcDev* precalc; const float* th;
     const unsigned long long* thw = nullptr; unsigned thseq = 0;   // non-NULL: the thresholds are being selected in THIS launch and arrive as tagged words (select_th_body)
+    unsigned* err = nullptr;   // the handle's sticky error word (EFArrays::err): a threshold that did not arrive in time fails the call like every other intra-launch wait
 };
 __device__ __forceinline__ int reclassify_count(const ReclArgs& a) { return a.nP + a.np_last * (a.nF - 1); }
 __device__ __forceinline__ void reclassify_slot(const ReclArgs& a, int i) {
@@ -1403,7 +1404,7 @@ __device__ __forceinline__ void reclassify_slot(const ReclArgs& a, int i) {
     const float e = a.wo[s];
     if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED) || (sn & RS_MASK) == RS_OOB) return;
     float ta, tb;
-    if (a.thw) { ta = __uint_as_float(poll_tagged_u32(a.thw + h, a.thseq, nullptr)); tb = __uint_as_float(poll_tagged_u32(a.thw + t, a.thseq, nullptr)); }
+    if (a.thw) { ta = __uint_as_float(poll_tagged_u32(a.thw + h, a.thseq, a.err)); tb = __uint_as_float(poll_tagged_u32(a.thw + t, a.thseq, a.err)); }
     else { ta = a.th[h]; tb = a.th[t]; }
     const float frameTH = ta < tb ? tb : ta;
     const bool wjlow = (sn & RS_WJLOW) != 0;

@@ -14,13 +14,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CAL = dict(fx=400., fy=410., cx=319.5, cy=119.5)
 
 
-def _worker(rank, world, port, q, one_collective=True):
+def _window(variant):
+    from sdv_loam_amd import synthetic as syn
+    if variant == "zero_differs":
+        # loaded with idepth != idepth_zero and sitting at its optimum: the very first step is REJECTED, and the restore moves idepth_zero
+        # (FullSystemOptimize.cpp:276-277) -- the body that cannot run speculatively (its reject branch solved on a stale message)
+        W = syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=2, calib=CAL)
+        W.idepth_zero = (W.idepth + np.random.default_rng(5).normal(0, 2e-4, W.nP)).astype(np.float32)
+        return W
+    return syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=2, calib=CAL, state_sigma=1e-3, idepth_sigma=0.01)
+
+
+def _worker(rank, world, port, q, one_collective=True, variant="perturbed"):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
-    from sdv_loam_amd import parallel, synthetic as syn
+    from sdv_loam_amd import parallel
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    W = syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=2, calib=CAL, state_sigma=1e-3, idepth_sigma=0.01)
+    W = _window(variant)
     S = parallel.ShardedEnergyFunctional(W, rank, world, 0, one_collective=one_collective)
     tr = S.optimize(6, want_trace=True)
     vs, st, idp = S.ef.state()
@@ -33,8 +44,9 @@ def _worker(rank, world, port, q, one_collective=True):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,one_collective", [(2, True), (2, False), (4, True), (8, True)])
-def test_ranks_on_one_gpu_reproduce_single_process(sdvgn_lib, world, one_collective):
+@pytest.mark.parametrize("world,one_collective,variant", [(2, True, "perturbed"), (2, False, "perturbed"), (4, True, "perturbed"), (8, True, "perturbed"),
+                                                          (2, True, "zero_differs"), (2, False, "zero_differs")])
+def test_ranks_on_one_gpu_reproduce_single_process(sdvgn_lib, world, one_collective, variant):
     """one_collective: the loop sends ONE message per body (+ one per call) -- accumulators, statistics and quantile candidates together,
     the trial applied and accumulated speculatively (north_star's single all-reduce); False: the earlier two-collective loop.
     world 4: uneven shards of the 5 key-frames (2, 1, 1, 1); world 8: three ranks host nothing (a 5-frame window on an 8-GPU node)."""
@@ -43,7 +55,8 @@ def test_ranks_on_one_gpu_reproduce_single_process(sdvgn_lib, world, one_collect
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29900 + (os.getpid() % 90)
-    procs = [ctx.Process(target=_worker, args=(r, world, port + 3 * world + (7 if one_collective else 0), q, one_collective)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port + 3 * world + (7 if one_collective else 0) + (11 if variant != "perturbed" else 0), q,
+                                               one_collective, variant)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=500) for _ in range(world)]
@@ -51,19 +64,23 @@ def test_ranks_on_one_gpu_reproduce_single_process(sdvgn_lib, world, one_collect
         p.join(timeout=60)
         assert p.exitcode == 0
     res.sort(key=lambda r: r[0])
-    W = syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=2, calib=CAL, state_sigma=1e-3, idepth_sigma=0.01)
+    W = _window(variant)
     G = backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
     tr = G.optimize(6)
     vs, st, idp = G.state()
     assert (tr[:, 2] == 1).any() and (tr[:, 2] == 0).any()                               # accepted and rejected steps: both paths of the speculation
+    if variant == "zero_differs":
+        assert tr[0, 2] == 0 and len(tr) >= 3                                            # the first step is the rejected one
     for rank, trr, vsr, str_, idr, idx, ncoll in res:
         assert len(trr) == len(tr) and np.array_equal(trr[:, :3], tr[:, :3])            # iteration, lambda, accepted
         assert np.allclose(trr[:, 3:6], tr[:, 3:6], rtol=1e-9, atol=1e-9)                # energies (sums in another grouping)
         assert np.allclose(trr[:, 7:], tr[:, 7:], rtol=1e-6, atol=1e-12)                 # increments
         assert np.allclose(vsr, vs, rtol=1e-10) and np.allclose(str_, st, rtol=1e-7, atol=1e-12)
         assert np.allclose(idr, idp[idx], rtol=1e-6)
-        if one_collective:
+        if one_collective and variant == "perturbed":
             assert ncoll == len(tr) + 1                                                  # exactly one all-reduce per loop body + one per call
+        elif one_collective:
+            assert ncoll > len(tr) + 1                                                   # (+ the non-speculative first body's own collectives)
         else:
             assert ncoll >= 2 * len(tr)                                                  # one accumulator + one statistics all-reduce per iteration
     for r in res[1:]:

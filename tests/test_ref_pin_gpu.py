@@ -131,3 +131,114 @@ def test_track_vs_reference(tapi, orc, full):
         okb, pb, ab, _, _ = G.trackBatch(np.stack([start, start]), np.zeros((2, 2)), P.levels - 1)
         db = orc.se3_log(orc.se3_mul(pb[1], orc.se3_inverse(start)))
         assert bool(okb[1]) == okr and rel_err(db, dr) < 1e-4
+
+
+# ---- rows f1, f2, f4 and the marginalisation step: the HIP path against the reference's own members directly (round 4; until then these
+# rows were HIP vs oracle with the oracle pinned to the reference on the CPU) -----------------------------------------------------------------
+
+@needs_ref
+@pytest.mark.parametrize("seed,kw", [(0, {}), (1, dict(pose_err=(0.3, 0.02))), (3, dict(pose_err=(0.01, 0.001), outlier_frac=0.2))])
+def test_struct_pose_vs_reference(tapi, orc, seed, kw):
+    """f1 against CoarseTracker::structPoseEstimation / calcHandb / calculateRes (CoarseTracker.cpp:840-1007)"""
+    from sdv_loam_amd import synthetic as syn
+    S = syn.make_struct_problem(n=1200, seed=seed, **kw)
+    G = tapi.CoarseTracker(S.w, S.h, 4, max_points=2048)
+    R = orc.RefTracker(S.w, S.h, 4)
+    for T in (G, R):
+        T.makeK(**S.calib)
+    args = (S.u, S.v, S.idepth, S.host_idx, S.host_poses7, S.obs)
+    w2c = orc.se3_inverse(S.init_curToWorld7)
+    Hg, bg, eg, ng = G.structResHb(w2c, *args)
+    Hr, br, er, nr = R.structResHb(w2c, *args)
+    assert ng == nr and rel_err(Hg, Hr) < 1e-5 and rel_err(bg, br) < 1e-5 and abs(eg - er) <= 1e-5 * er
+    pg, _, _ = G.structPoseEstimation(S.init_curToWorld7, *args)
+    pr, _, _ = R.structPoseEstimation(S.init_curToWorld7, *args)
+    dg = orc.se3_log(orc.se3_mul(orc.se3_inverse(S.init_curToWorld7), pg))
+    dr = orc.se3_log(orc.se3_mul(orc.se3_inverse(S.init_curToWorld7), pr))
+    assert rel_err(dg, dr) < 1e-4
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,pose_err,edge", [(2, (0.01, 0.001), 0.3), (5, (0.05, 0.006), 0.5)])
+def test_reprojector_vs_reference(orc, sdvgn_lib, seed, pose_err, edge):
+    """f2 against Reprojector::reprojectPoint / findMatchDirect / align1D / align2D (Reprojector.cpp)"""
+    from oracle.reproject import RefReprojector
+    from sdv_loam_amd import reproject_api, synthetic as syn
+    import test_reproject_gpu as T
+    P = syn.make_reproject_problem(T._window(seed), levels=3, seed=seed, pose_err=pose_err, edgelet_frac=edge)
+    R = RefReprojector(P.w, P.h, P.levels)
+    G = reproject_api.Reprojector(P.w, P.h, P.levels, max_frames=8, max_points=4096)
+    for X in (R, G):
+        X.set_calib(**P.calib)
+        for k in range(len(P.frame_poses7)):
+            X.set_frame(k, P.frame_poses7[k], P.frame_images[k], 1.0, 0.0, 0.0)
+        X.set_cur(P.cur_pose7, P.cur_pyr, 1.0, 0.0, 0.0)
+    g, good = T._compare(P, G, R)                      # cells, qualities, success flags, levels exact; matched positions bit-identical
+    assert good.sum() > 0.3 * P.n
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,pose_err", [(2, (0.0, 0.0)), (4, (0.1, 0.01))])
+def test_trace_on_vs_reference(tapi, orc, seed, pose_err):
+    """f4 (part 1) against ImmaturePoint::traceOn (ImmaturePoint.cpp:47-353): all six outputs bit-identical"""
+    from oracle.trace import trace_on
+    from sdv_loam_amd import synthetic as syn
+    import test_trace_gpu as T
+    W = T._window(seed)
+    P = syn.make_trace_problem(W, target=2, pose_err=pose_err, seed=seed)
+    G = T._gpu(P)
+    sr = trace_on(P, P.dI, P.idepth_min, P.idepth_max, P.quality, P.status, reference=True)
+    sg = G.tracePoints(P.KRKi, P.Kt, P.aff, P.idepth_min, P.idepth_max, P.quality, P.status)
+    T._same(sg, sr)
+    assert (sr["status"] == syn.IPS_GOOD).sum() > 0.3 * P.n
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,rel", [(2, 0.2), (4, 0.6)])
+def test_optimize_immature_vs_reference(bapi, orc, seed, rel):
+    """f4 (part 2) against FullSystem::optimizeImmaturePoint + ImmaturePoint::linearizeResidual (FullSystemOptPoint.cpp:18-185)"""
+    from oracle.backend import RefEF
+    from sdv_loam_amd import synthetic as syn
+    import test_immature_gpu as T
+    W = syn.make_window(w=320, h=200, nF=4, pts_per_kf=250, seed=seed, calib=T.CAL)
+    G = bapi.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+    R = RefEF(W.w, W.h).load(W)
+    imin, imax, eth = T._args(W, seed, rel)
+    a = (W.host, W.u, W.v, imin, imax, eth, W.color, W.weights, W.isFromSensor)
+    rg, rr = G.optimizeImmature(*a), R.optimizeImmature(*a)
+    T._same(rg, rr)                                    # result codes, inverse depths, residual states bit-identical
+    assert (rr[0] == 1).sum() > 0.3 * W.nP
+
+
+@needs_ref
+def test_marginalization_vs_reference(bapi, orc):
+    """b2 mode 2 against EFResidual::fixLinearizationF, EnergyFunctional::marginalizePointsF / dropPointsF / marginalizeFrame
+    (EnergyFunctionalStructs.cpp:45-55, EnergyFunctional.cpp:434-597)"""
+    from oracle.backend import RefEF
+    from sdv_loam_amd import synthetic as syn
+    W = syn.make_window(w=640, h=240, nF=8, pts_per_kf=300, seed=9, calib=dict(fx=400., fy=410., cx=319.5, cy=119.5))
+    W.idepth_zero = (W.idepth + np.random.default_rng(5).normal(0, 2e-4, W.nP)).astype(np.float32)   # deltaF != 0
+    G, R = _pair_ef(bapi, W)
+    for X in (G, R):
+        X.linearizeAll(); X.applyRes()
+    rng = np.random.default_rng(1)
+    marg = (rng.random(W.nP) < 0.2).astype(np.uint8)
+    drop = ((rng.random(W.nP) < 0.1) & (marg == 0)).astype(np.uint8)
+    G.fixLinearization(marg); R.fixLinearization(marg)
+    rg, lg = G.res_toZero(); rr, lr = R.res_toZero()
+    assert np.array_equal(lg, lr) and lr.sum() > 20 and np.array_equal(rg, rr)     # res_toZeroF bit-identical
+    H0, b0 = R.marg_prior()
+    for idx in (0, 3):                                  # marginalizeFrame on the prior as it is now (a pure function of HM, bM, the frame prior)
+        Hg, bg = G.marginalizeFrame(idx)
+        Hr, br = R.marginalizeFrame(idx)
+        assert rel_err(Hg, Hr) < 1e-6 and rel_err(bg, br) < 1e-6
+    G.marginalizePoints(marg, drop); R.marginalizePoints(marg, drop)
+    Hg, bg = G.marg_prior(); Hr, br = R.marg_prior()
+    assert np.linalg.norm(Hr - H0) > 0
+    assert rel_err(Hg - H0, Hr - H0) < 1e-5 and rel_err(bg - b0, br - b0) < 1e-5 and rel_err(Hg, Hr) < 1e-6
+    for idx in (1, W.nF - 1):
+        Hgf, bgf = G.marginalizeFrame(idx)
+        Hrf, brf = R.marginalizeFrame(idx)
+        assert rel_err(Hgf, Hrf) < 1e-6 and rel_err(bgf, brf) < 1e-6
+    xg = G.solveSystemF(0, 0.1); R.solveSystemF(0, 0.1)
+    assert rel_err(xg, R.system()["x"]) < 1e-4
