@@ -74,14 +74,14 @@ def test_reference_solve_system_on_gpu(sdvgn_lib, orc):
     for it, lam in ((0, 0.1), (3, 1e-3)):
         R.solveSystemF(it, lam); D.solveSystemF(it, lam)
         sysr, sysd = R.system(), D.system()
-        assert rel_err(sysd["x"], sysr["x"]) < 1e-5      # float accumulators summed in another order; BASELINE asks for 1e-4
+        assert rel_err(sysd["x"], sysr["x"]) < 1e-4      # BASELINE.json's tolerance (float accumulators summed in another order: ~1e-6 .. 4e-5 here)
         assert rel_err(sysd["HFinal"], sysr["HFinal"]) < 1e-5 and rel_err(sysd["bFinal"], sysr["bFinal"]) < 1e-5
         pr, pd = R.points(), D.points()
         assert np.allclose(pd[:, 6:8], pr[:, 6:8], rtol=1e-5, atol=1e-12)          # HdiF, bdSumF
-        assert np.allclose(pd[:, 8], pr[:, 8], rtol=1e-4, atol=1e-7)               # PointHessian::step
+        assert rel_err(pd[:, 8], pr[:, 8]) < 1e-4                                   # PointHessian::step
         fr, cr = R.frame_steps()
         fd, cd = D.frame_steps()
-        assert rel_err(fd, fr) < 1e-5 and rel_err(cd, cr) < 1e-5
+        assert rel_err(fd, fr) < 1e-4 and rel_err(cd, cr) < 1e-4
         assert D.resInA() == R.resInA()
     assert D.gpu_solves() == 2
 
