@@ -116,3 +116,75 @@ class DropinTracker(RefTracker):
         except Exception:
             pass
         super().__del__()
+
+
+class RefFullSystemTracking:
+    """FullSystem::trackNewCoarse (FullSystem.cpp:283-517) of the reference on a small world built from flat arrays (oracle/ref_glue_fs.cpp);
+    `dropin=True` runs it in libref_dropin.so, where the trackNewestCoarse it calls (:419) is the GPU-backed definition."""
+
+    def __init__(self, w, h, levels, calib, dropin=False):
+        import numpy as np
+        from . import refpin
+        self.np = np
+        self.dropin = dropin
+        L = dropin_lib() if dropin else refpin.ref_lib()
+        if L is None:
+            raise RuntimeError("oracle/_ref/libref%s.so has not been built" % ("_dropin" if dropin else ""))
+        self.L = L
+        f32 = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+        f64 = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+        i32 = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+        L.ref_fs_create.restype = C.c_void_p
+        L.ref_fs_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.ref_fs_destroy.argtypes = [C.c_void_p]
+        L.ref_fs_add_keyframe.argtypes = [C.c_void_p, f64, f32, C.c_float, C.c_double, C.c_double]
+        L.ref_fs_add_points.argtypes = [C.c_void_p, C.c_int, i32, f32, f32, f32, i32]
+        L.ref_fs_set_tracker_ref.argtypes = [C.c_void_p, C.c_int, C.c_int, f32, f32, f32, f32]
+        L.ref_fs_set_new_frame.argtypes = [C.c_void_p, f32, C.c_float]
+        L.ref_fs_track_new_coarse.argtypes = [C.c_void_p, f64, f64, f64, f64, f64]
+        L.ref_fs_last_log.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.ref_fs_last_log.restype = C.c_int
+        L.ref_fs_coarse_tracker.restype = C.c_void_p
+        L.ref_fs_coarse_tracker.argtypes = [C.c_void_p]
+        L.ref_fs_set_last_coarse_rmse.argtypes = [C.c_void_p, C.c_double]
+        self.h_ = L.ref_fs_create(w, h, levels, calib["fx"], calib["fy"], calib["cx"], calib["cy"])
+
+    def __del__(self):
+        try:
+            if self.dropin:
+                self.L.sdvgn_dropin_tracker_release(self.L.ref_fs_coarse_tracker(self.h_))
+            self.L.ref_fs_destroy(self.h_)
+        except Exception:
+            pass
+
+    def add_keyframe(self, camToWorld7, dI_aos3, exposure=1.0, a=0.0, b=0.0):
+        np = self.np
+        self.L.ref_fs_add_keyframe(self.h_, np.ascontiguousarray(camToWorld7, np.float64), np.ascontiguousarray(dI_aos3, np.float32).reshape(-1), exposure, a, b)
+
+    def add_points(self, host, u, v, idepth, ptype):
+        np = self.np
+        self.L.ref_fs_add_points(self.h_, len(u), np.ascontiguousarray(host, np.int32), np.ascontiguousarray(u, np.float32), np.ascontiguousarray(v, np.float32),
+                                 np.ascontiguousarray(idepth, np.float32), np.ascontiguousarray(ptype, np.int32))
+
+    def set_tracker_ref(self, lvl, u, v, idepth, color):
+        np = self.np
+        u, v, idepth, color = (np.ascontiguousarray(x, np.float32) for x in (u, v, idepth, color))
+        self.L.ref_fs_set_tracker_ref(self.h_, lvl, len(u), u, v, idepth, color)
+
+    def set_new_frame(self, image, exposure=1.0):
+        self.L.ref_fs_set_new_frame(self.h_, self.np.ascontiguousarray(image, self.np.float32).reshape(-1), exposure)
+
+    def set_last_coarse_rmse(self, v):
+        self.L.ref_fs_set_last_coarse_rmse(self.h_, float(v))
+
+    def trackNewCoarse(self):
+        np = self.np
+        out4, c2w, c2r, aff, rmse = np.zeros(4), np.zeros(7), np.zeros(7), np.zeros(2), np.zeros(5)
+        self.L.ref_fs_track_new_coarse(self.h_, out4, c2w, c2r, aff, rmse)
+        n = self.L.ref_fs_last_log(self.h_, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self.L.ref_fs_last_log(self.h_, buf, n + 1)
+        return dict(ret=out4, camToWorld=c2w, camToTrackingRef=c2r, aff=aff, lastCoarseRMSE=rmse, log=buf.value.decode(errors="replace"))
+
+    def gpu_tracks(self):
+        return int(self.L.sdvgn_dropin_tracker_calls(self.L.ref_fs_coarse_tracker(self.h_))) if self.dropin else 0

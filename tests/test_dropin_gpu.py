@@ -118,3 +118,47 @@ def test_reference_tracker_call_on_gpu(sdvgn_lib, orc, full):
     assert not okr and not okd and np.array_equal(pd, pr) and np.array_equal(ad, ar)
     assert np.allclose(lrd, lrr, rtol=1e-4, atol=1e-4, equal_nan=True)
     assert D.gpu_tracks() == n + 1
+
+
+def _tracking_world(dropin, orc, seed=2):
+    """key-frames with images and active points, the tracking template of the newest one, and a new frame one key-frame step further"""
+    from oracle.dropin import RefFullSystemTracking
+    from sdv_loam_amd import synthetic as syn
+    cal = dict(fx=250., fy=252., cx=159.5, cy=99.5)
+    W = syn.make_window(w=320, h=200, nF=4, pts_per_kf=250, seed=seed, calib=cal)
+    RP = syn.make_reproject_problem(W, levels=3, seed=seed)
+    xi = orc.se3_log(orc.se3_mul(orc.se3_inverse(RP.gt_cur_pose7), RP.frame_poses7[-1]))        # newest key-frame -> new frame
+    TP = syn.make_tracker_problem(w=W.w, h=W.h, levels=3, n_points=1500, seed=seed + 3, calib=cal, gt_xi=xi, image=W.images[-1])
+    F = RefFullSystemTracking(W.w, W.h, 3, cal, dropin=dropin)
+    for k in range(len(RP.frame_poses7)):
+        F.add_keyframe(RP.frame_poses7[k], RP.frame_images[k])
+    F.add_points(RP.host_idx, RP.u, RP.v, RP.idepth, RP.type)
+    for l in range(3):
+        F.set_tracker_ref(l, **TP.ref[l])
+    F.set_new_frame(W.images[-1])
+    return F, RP, xi
+
+
+@needs_dropin
+@pytest.mark.parametrize("retrack", [False, True], ids=["first_try_wins", "all_31_tries"])
+def test_reference_track_new_coarse_call_site(sdvgn_lib, orc, retrack):
+    """FullSystem::trackNewCoarse itself (FullSystem.cpp:283-517): the motion-model tries, the call at :419, the winner / achievedRes / early-out
+    logic, then reprojectMap and structPoseEstimation -- all the reference's own host code, with the coarse tracker on the CPU vs on the GPU.
+    retrack: lastCoarseRMSE so small that the early-out (:462) never fires -- all 31 tries run, the later ones against minResForAbort."""
+    Fc, RP, xi = _tracking_world(False, orc)
+    Fg, _, _ = _tracking_world(True, orc)
+    if retrack:
+        Fc.set_last_coarse_rmse(1e-9); Fg.set_last_coarse_rmse(1e-9)
+    rc, rg = Fc.trackNewCoarse(), Fg.trackNewCoarse()
+    assert Fg.gpu_tracks() == (31 if retrack else 1)
+    assert rc["log"].count("RE-TRACK ATTEMPT") == rg["log"].count("RE-TRACK ATTEMPT") == (30 if retrack else 0)
+    assert "BIG ERROR" not in rc["log"] and "BIG ERROR" not in rg["log"]
+    assert np.allclose(rg["ret"], rc["ret"], rtol=1e-4, atol=1e-4)                              # achievedRes[0], flow indicators
+    assert np.allclose(rg["lastCoarseRMSE"], rc["lastCoarseRMSE"], rtol=1e-4, atol=1e-4, equal_nan=True)
+    assert np.allclose(rg["aff"], rc["aff"], rtol=1e-4, atol=1e-5)
+    motion = np.linalg.norm(xi)
+    for key in ("camToTrackingRef", "camToWorld"):                                               # after reprojectMap + structPoseEstimation
+        d = orc.se3_log(orc.se3_mul(orc.se3_inverse(rc[key]), rg[key]))
+        assert np.linalg.norm(d) < 1e-4 * motion, (key, d)
+    err = orc.se3_log(orc.se3_mul(orc.se3_inverse(rg["camToWorld"]), RP.gt_cur_pose7))           # and the frame really was tracked
+    assert np.linalg.norm(err) < 0.02 * motion
