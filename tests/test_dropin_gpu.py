@@ -155,7 +155,8 @@ def test_reference_track_new_coarse_call_site(sdvgn_lib, orc, retrack):
     assert "BIG ERROR" not in rc["log"] and "BIG ERROR" not in rg["log"]
     assert np.allclose(rg["ret"], rc["ret"], rtol=1e-4, atol=1e-4)                              # achievedRes[0], flow indicators
     assert np.allclose(rg["lastCoarseRMSE"], rc["lastCoarseRMSE"], rtol=1e-4, atol=1e-4, equal_nan=True)
-    assert np.allclose(rg["aff"], rc["aff"], rtol=1e-4, atol=1e-5)
+    # (the true brightness change is zero: a, b end at the noise floor of the last LM step -- a in e-folds, b in grey levels of 0..255)
+    assert abs(rg["aff"][0] - rc["aff"][0]) < 1e-6 and abs(rg["aff"][1] - rc["aff"][1]) < 1e-4
     motion = np.linalg.norm(xi)
     for key in ("camToTrackingRef", "camToWorld"):                                               # after reprojectMap + structPoseEstimation
         d = orc.se3_log(orc.se3_mul(orc.se3_inverse(rc[key]), rg[key]))
