@@ -804,7 +804,7 @@ def main():
         replicas_value = world * K / dt_r
         del reps
 
-    value_relin = value_reuse = soak = other = lin_inloop = None
+    value_relin = value_reuse = value_nospec = soak = other = lin_inloop = None
     tol = batched = None
     if single and not args.quick:
         # ---- B independent windows side by side (sdvgn_ef_optimize_batch: own stream + host thread per window): aggregate loop bodies / s.
@@ -849,6 +849,9 @@ def main():
         # ---- opt-in flag bit2: bodies that follow a rejected step re-use the stitched system (bit-identical results; extra key only) ----
         dt_u, _ = run_protocol(runners, bodies, world, warm=(warm_runner, Wm), reload_with=Wh, want_trace=False, reuse_after_reject=True)
         value_reuse = K / dt_u
+        # ---- A/B of round 4's default: without the rejected case solved ahead on the side stream (flags bit4; results bit-identical) ----
+        dt_ns, _ = run_protocol(runners, bodies, world, warm=(warm_runner, Wm), reload_with=Wh, want_trace=False, no_spec_solve=True)
+        value_nospec = K / dt_ns
         # ---- k_ef_linearize inside the loop: a HIP event pair around every launch of the same protocol (own pass: the event packets
         # cost ~2 us per body, so this pass is not the headline) ----
         nl = min(len(runners), 8)
@@ -968,6 +971,7 @@ def main():
         "batched_windows_side_by_side": batched,
         "value_with_literal_relinearize_on_reject": value_relin,
         "value_with_system_reuse_after_rejected_steps": value_reuse,
+        "value_without_rejected_case_solved_ahead": value_nospec,
         "one_window_soak": soak,
         "other_windows_same_protocol": other,
         "reference_shape_7kf_2000pts": ref_shape,

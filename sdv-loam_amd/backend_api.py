@@ -266,9 +266,11 @@ class EnergyFunctional:
     def stream(self):
         return self.L.sdvgn_ef_stream(self.h_)
 
-    def optimize(self, its=6, cap=128, want_trace=True, fixed_its=False, relinearize_on_reject=False, reuse_after_reject=False, time_linearize=False):
+    def optimize(self, its=6, cap=128, want_trace=True, fixed_its=False, relinearize_on_reject=False, reuse_after_reject=False, time_linearize=False,
+                 no_spec_solve=False):
         stride = 8 + self.dim   # ..., x[dim], frameEnergyTH of the newest frame after the trial linearizeAll
-        flags = (1 if fixed_its else 0) | (2 if relinearize_on_reject else 0) | (4 if reuse_after_reject else 0) | (8 if time_linearize else 0)
+        flags = (1 if fixed_its else 0) | (2 if relinearize_on_reject else 0) | (4 if reuse_after_reject else 0) | (8 if time_linearize else 0) | \
+            (16 if no_spec_solve else 0)
         if not want_trace:      # nothing to allocate or zero on the way in: rows of zeros, one per body, on the way out
             n = self._check(self.L.sdvgn_ef_optimize(self.h_, its, flags, None, stride, cap))
             return np.zeros((n, stride))

@@ -113,11 +113,23 @@ struct sdvgn_ef {
     CalibDev* calib_dev = nullptr;         // [2]: CalibHessian float views of the two state sets
     CalibDev* calib_host = nullptr;        // pinned staging
     int st_cur = 0;                        // which of the two sets holds the current state
+    double* en_em_dev = nullptr;           // [2 sets][2]: prior energy and M energy of the state in that set (step_energy_body, backend_solve.inc)
     bool state_dirty = true;               // the host mirror changed outside the loop: upload before the next device solve
     ResubX* rx_dev = nullptr;              // xc, xAd of the last solve (the resubstitute workgroups of k_ef_tail_resub read them)
     unsigned long long* xw_dev = nullptr;  // the same + x as tagged words (SolveIO::xw): the in-launch hand-off of k_ef_tail_resub; [kXwTh, +8): thresholds of a select in that launch
     SolveSys* sys_dev = nullptr;           // HA, bA, Hsc, bsc, HFinal, bFinal of the last solve
     SolveOut* sol_host = nullptr;          // pinned: x, step statistics, resInA, status
+    // the REJECTED case solved ahead (ef_launch_spec_solve): while a trial step is linearised, one workgroup on the library's side stream factors
+    // the system this body solved once more with the damping a rejection would bring (lambda * 100, iteration + 1).  If the step is rejected the
+    // next body finds its solution ready and skips accumulate, reduce, stitch and the factorisation; if it is accepted the result is dropped.
+    // No events: the side-stream launch waits for the main solve's x words (tagged, SolveIO::wait_xw) and publishes its own results as tagged
+    // words in xw_spec[buffer], which the next body's resubstitute / step workgroups poll exactly like they poll a solve of their own launch.
+    ResubX* rx_spec = nullptr;             // device: plain copies of xc, xAd of the speculative solve (nobody reads them; the kernel writes both forms)
+    unsigned long long* xw_spec = nullptr; // device: [2][512] tagged words, alternating per speculative solve
+    SolveOut* sol_spec = nullptr;          // pinned [2]: x, step statistics, status of the speculative solves (flags: flags_host[5 + buffer])
+    int seq_spec = 0;                      // tags of the speculative solves are kSpecTag | seq_spec: disjoint from the main solves' (seq_solve)
+    hipStream_t side = nullptr;            // the device's shared side stream (not owned)
+    int spec_last_buf = -1, spec_last_seq = 0;   // the speculative solve launched last (may still be running)
     SolvePieces* pieces_dev = nullptr;     // [SDVGN_MAX_FRAMES]: per-host shares of HA / bA / Hsc / bsc
     unsigned long long* solve_stamps = nullptr;   // pinned, 16 words: SDVGN_DEBUG_FLAGS bit6 only (phase stamps of the solve workgroup)
     int solve_status = 0;                  // status of the last device solve: 1 = a pivot of the LDL^T was not positive / finite (x = 0)
@@ -539,7 +551,11 @@ static int ef_sync_window(sdvgn_ef* e) {
         for (int i = 0; i < 6; ++i) W.fr[h].prior[i] = f.prior[i];
         W.fr[h].ab_exposure = f.ab_exposure; W.fr[h].frameID = f.frameID;
     }
-    if ((int)e->HM.size() == n * n) { std::memcpy(W.HM, e->HM.data(), sizeof(double) * n * n); std::memcpy(W.bM, e->bM.data(), sizeof(double) * n); }
+    if ((int)e->HM.size() == n * n) {
+        std::memcpy(W.HM, e->HM.data(), sizeof(double) * n * n); std::memcpy(W.bM, e->bM.data(), sizeof(double) * n);
+        for (double v : e->HM) if (v != 0.0) { W.hm_nonzero = 1; break; }
+        for (double v : e->bM) if (v != 0.0) { W.hm_nonzero = 1; break; }
+    }
     if (k > 0) {
         ef_prepare_nullspace(e, n);
         std::memcpy(W.nsN, e->ns_N.data(), sizeof(double) * (size_t)n * k);
@@ -717,10 +733,12 @@ __global__ void __launch_bounds__(256) k_ef_point_stats(EFConst Cin, EFArrays A,
 // it owns (the prior part of the L energy of the stepped state, the M energy, the right-hand side from the last accepted state) before the
 // sums exist, the kernel finishes the comparison with the same double operations in the same order and leaves the verdict for the
 // conditional k_ef_apply queued right behind it (accept_dev) and for the host (out[4]).
-struct DecideArgs { double En, EM, rhs; int* accept_dev; int on; unsigned* verdict; unsigned seq; };
+// en_em (device, may be NULL): the prior energy and the M energy of the stepped state as step_energy_body left them -- then En / EM of this block
+// are ignored and the host need not have seen x when it queues the launch; the two values go back to the host in out[5], out[7]
+struct DecideArgs { double En, EM, rhs; int* accept_dev; int on; unsigned* verdict; unsigned seq; const double* en_em; };
 __device__ __forceinline__ void sum_stats_body(const double* __restrict__ pe, int nE, const double* __restrict__ pl, int nL,
                                                const double* __restrict__ ps, int nS, double* __restrict__ out, volatile int* done_flag, int done_seq,
-                                               double (*s)[256], const DecideArgs& dec = DecideArgs{0, 0, 0, nullptr, 0, nullptr, 0}) {
+                                               double (*s)[256], const DecideArgs& dec = DecideArgs{0, 0, 0, nullptr, 0, nullptr, 0, nullptr}) {
     if (threadIdx.x < 256) {
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         // all loads of this lane in one batch (clamped indices, the out-of-range ones add 0), the sums in index order afterwards: one
@@ -746,9 +764,11 @@ __device__ __forceinline__ void sum_stats_body(const double* __restrict__ pe, in
     if (threadIdx.x < 4) { const int q = threadIdx.x; s[q][0] = ((s[q][0] + s[q][1]) + s[q][2]) + s[q][3]; out[q] = s[q][0]; }
     __syncthreads();
     if (dec.on && threadIdx.x == 0) {
+        const double En = dec.en_em ? dec.en_em[0] : dec.En, EM = dec.en_em ? dec.en_em[1] : dec.EM;
         const double newEnergy = s[0][0];
-        const double newEnergyL = dec.En + (double)(float)s[1][0];                  // linearize_wait's expression
-        const bool accept = (newEnergy + newEnergyL) + dec.EM < dec.rhs;
+        const double newEnergyL = En + (double)(float)s[1][0];                      // linearize_wait's expression
+        const bool accept = (newEnergy + newEnergyL) + EM < dec.rhs;
+        out[5] = En; out[7] = EM;
         // first of all the verdict for the apply workgroups of the same launch (k_ef_stats_apply): one tagged word, relaxed device-scope store
         if (dec.verdict) __hip_atomic_store(dec.verdict, (dec.seq << 1) | (accept ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *dec.accept_dev = accept ? 1 : 0;
@@ -1009,6 +1029,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->th_dev, 2 * SDVGN_MAX_FRAMES);
     bad |= dev_alloc(&e->win_dev, 1) | dev_alloc(&e->sstate_dev, 2) | dev_alloc(&e->calib_dev, 2) | dev_alloc(&e->rx_dev, 1) | dev_alloc(&e->sys_dev, 1);
     bad |= dev_alloc(&e->pieces_dev, SDVGN_MAX_FRAMES);
+    bad |= dev_alloc(&e->en_em_dev, 4);
     if (bad) { sdvgn_ef_destroy(e); return -(int)hipErrorOutOfMemory; }
     HIPCHK(SDVGN_HMALLOC(&e->precalc_host, 2 * sizeof(PrecalcDev) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
     HIPCHK(SDVGN_HMALLOC(&e->acc_host, sizeof(double) * accmax));
@@ -1023,10 +1044,25 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     HIPCHK(SDVGN_HMALLOC((void**)&e->calib_host, sizeof(CalibDev)));
     HIPCHK(SDVGN_HMALLOC((void**)&e->sol_host, sizeof(SolveOut)));
     std::memset(e->sol_host, 0, sizeof(SolveOut));
+    HIPCHK(SDVGN_HMALLOC((void**)&e->sol_spec, 2 * sizeof(SolveOut)));
+    std::memset(e->sol_spec, 0, 2 * sizeof(SolveOut));
+    HIPCHK(SDVGN_DMALLOC((void**)&e->rx_spec, sizeof(ResubX)));
+    HIPCHK(hipMemset(e->rx_spec, 0, sizeof(ResubX)));
+    HIPCHK(SDVGN_DMALLOC(&e->xw_spec, sizeof(unsigned long long) * 2 * 512));
+    HIPCHK(hipMemset(e->xw_spec, 0, sizeof(unsigned long long) * 2 * 512));
+    {   // one side stream per device, shared like the main one (handles on the shared stream are used one after the other)
+        static std::mutex mu2;
+        static hipStream_t side_streams[64] = {};
+        std::lock_guard<std::mutex> lk(mu2);
+        if (device < 64) {
+            if (!side_streams[device]) HIPCHK(hipStreamCreateWithFlags(&side_streams[device], hipStreamNonBlocking));
+            e->side = side_streams[device];
+        }
+    }
     HIPCHK(hipMemset(e->rx_dev, 0, sizeof(ResubX)));
     HIPCHK(SDVGN_DMALLOC(&e->xw_dev, sizeof(unsigned long long) * 512));
     HIPCHK(hipMemset(e->xw_dev, 0, sizeof(unsigned long long) * 512));   // tag 0 is never current (the solves count from 1)
-    e->flags_host[0] = e->flags_host[1] = e->flags_host[2] = e->flags_host[3] = 0;
+    for (int i = 0; i < 16; ++i) e->flags_host[i] = 0;
     HIPCHK(SDVGN_DMALLOC((void**)&e->done_ctr, 2 * sizeof(unsigned)));
     HIPCHK(hipMemset(e->done_ctr, 0, 2 * sizeof(unsigned)));
     HIPCHK(SDVGN_HMALLOC((void**)&e->imm_pc_host, sizeof(ImmPrecalc) * SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES));
@@ -1045,6 +1081,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
     if (!e->own_stats) e->stats_dev = nullptr;
     hipSetDevice(e->device);
     hipStreamSynchronize(e->stream);
+    if (e->side) hipStreamSynchronize(e->side);          // a speculative solve may still be reading this handle's system
     ef_release_comm(e);
     void* ptrs[] = {e->pu, e->pv, e->pidz, e->pid, e->pidepth_backup, e->ppriorF, e->pdeltaF, e->pcolor, e->pweights, e->psensor, e->rflags,
                     e->rstate, e->rstate_new, e->rmatcher, e->renergy, e->renergy_new, e->renergy_wo, e->rres_toZero, e->J, e->JpJd, e->pHddA,
@@ -1052,7 +1089,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
                     e->stats_dev, e->stats_partial, e->imm_pc_dev, e->rstate_new2, e->renergy_new2, e->renergy_wo2,
                     e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->precalc_alt, e->dbg_stamps, e->marg_mask_dev, e->drop_mask_dev, e->th_dev, e->fin_dev,
-                    e->win_dev, e->sstate_dev, e->calib_dev, e->rx_dev, e->xw_dev, e->sys_dev, e->pieces_dev};
+                    e->win_dev, e->sstate_dev, e->calib_dev, e->rx_dev, e->xw_dev, e->sys_dev, e->pieces_dev, e->en_em_dev};
     for (void* p : ptrs) if (p) SDVGN_DFREE(p);
     if (e->precalc_host) SDVGN_HFREE(e->precalc_host);
     if (e->acc_host) SDVGN_HFREE(e->acc_host);
@@ -1064,6 +1101,9 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
     if (e->sstate_host) SDVGN_HFREE(e->sstate_host);
     if (e->calib_host) SDVGN_HFREE(e->calib_host);
     if (e->sol_host) SDVGN_HFREE(e->sol_host);
+    if (e->sol_spec) SDVGN_HFREE(e->sol_spec);
+    if (e->rx_spec) SDVGN_DFREE(e->rx_spec);
+    if (e->xw_spec) SDVGN_DFREE(e->xw_spec);
     for (hipEvent_t ev : e->lin_events) if (ev) hipEventDestroy(ev);
     if (e->solve_stamps) SDVGN_HFREE(e->solve_stamps);
     if (e->done_ctr) SDVGN_DFREE(e->done_ctr);
@@ -1451,7 +1491,7 @@ static int ef_accumulate(sdvgn_ef* e, bool with_reduce, const AccAlt* alt = null
     const int nF = e->nF, n_top = g.chunks * g.pairs, n_pt = (e->nP + 63) / 64;
     if (g.sc_ppb == 64) {
         const int n_sc = nF * g.sc_chunks;
-        const AccAlt none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        const AccAlt none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
         k_ef_acc_fused<<<n_sc + n_top, 256, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, e->sc_partial, g.sc_chunks, n_sc,
                                                             alt ? *alt : none);
     } else {
@@ -1460,7 +1500,8 @@ static int ef_accumulate(sdvgn_ef* e, bool with_reduce, const AccAlt* alt = null
         k_ef_sc_gram<<<dim3(g.sc_chunks, nF), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->sc_partial, g.sc_ppb);
     }
     if (with_reduce)
-        k_ef_acc_reduce<<<acc_reduce_grid(g.pairs, nF), 256, 0, e->stream>>>(e->top_partial, g.pairs, g.chunks, e->sc_partial, nF, g.sc_chunks, e->nres_partial, e->acc_dev);
+        k_ef_acc_reduce<<<acc_reduce_grid(g.pairs, nF), 256, 0, e->stream>>>(e->top_partial, g.pairs, g.chunks, e->sc_partial, nF, g.sc_chunks, e->nres_partial, e->acc_dev,
+                                                                              (alt && alt->skip_on_reject) ? alt->verdict : nullptr);
     e->acc_in_host = false;
     HIPCHK(hipGetLastError());
     return SDVGN_OK;
@@ -1681,14 +1722,19 @@ static void ef_fill_solve_io(sdvgn_ef* e, SolveIO& io, int iteration, double lam
     io.err_word = e->stats_host ? (unsigned*)(e->stats_host + 6) : nullptr;
     io.lambda = lambda; io.iteration = iteration; io.do_step = do_step ? 1 : 0; io.reuse = reuse ? 1 : 0; io.stepsize = stepsize;
     io.stamps = e->solve_stamps;
+    io.wait_xw = nullptr; io.wait_seq = 0; io.spec = 0;
+    io.tri_ready = (reuse || !e->xw_dev) ? nullptr : e->xw_dev + 498;      // (a solve that stitches anew says when its system is in memory)
+    io.en_em_trial = (do_step && e->en_em_dev) ? e->en_em_dev + 2 * (1 - e->st_cur) : nullptr;
 }
 // solveSystemF on the device, all launches asynchronous: accumulate + reduce (unless the stitched system of the previous body is
 // re-used), per-host stitch, then the one-workgroup tail: LDL^T + null-space projection (+ the calib / frame part of doStepFromBackup
 // and the precalc table of the stepped state when do_step), then resubstituteF (+ the point part of doStepFromBackup when
 // step_fac >= 0).  x reaches the host through pinned memory; ef_wait_solve fetches it.
+static int ef_drain_spec(sdvgn_ef* e);
 static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_step, float step_fac, bool reuse, bool accumulated) {
     int rc;
     if ((rc = ef_sync_window(e)) || (rc = ef_sync_state(e))) return rc;
+    if (!reuse && (rc = ef_drain_spec(e))) return rc;       // this solve rewrites the system a speculative solve may still be reading
     const int nF = e->nF;
     SolveIO io;
     ef_fill_solve_io(e, io, iteration, lambda, do_step, do_step ? step_fac : 0.0f, reuse);
@@ -1706,7 +1752,7 @@ static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_st
     if (e->pend_sel_valid && e->own_stream) ef_flush_pending(e);    // (own stream + system re-used: no launch to ride in)
     const int has_rc = e->pend_rc_valid ? 1 : 0;
     const int nblk = (e->nP + 63) / 64;
-    const int head = 1 + (has_rc ? kReclBlocks : 0), rest = (nblk + 1) / 2 + (do_step ? 1 : 0);
+    const int head = 1 + (has_rc ? kReclBlocks : 0), rest = (nblk + 1) / 2 + (do_step ? (io.en_em_trial ? 2 : 1) : 0);   // + step (+ energy) workgroups
     const SelArgs sel = e->pend_sel;
     if (e->own_stream) {   // a window that runs beside others: no spinning workgroups (see k_ef_tail_resub)
         k_ef_tail_resub<<<head, kSolveLanes, 0, e->stream>>>(io, e->pend_rc, has_rc, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup,
@@ -1735,6 +1781,85 @@ static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_st
 static inline bool ef_wait_error(const sdvgn_ef* e) {   // a workgroup gave up an intra-launch wait (EFArrays::err): the window is not trustworthy
     return e->stats_host && *reinterpret_cast<volatile const unsigned*>(e->stats_host + 6) != 0;
 }
+// ---- the rejected case, solved ahead ------------------------------------------------------------------------------------------------
+// After a rejected step the reference restores the state and solves the SAME normal equations again with 100 x the damping
+// (FullSystemOptimize.cpp:446-458: lambda *= 1e2, next iteration).  Nothing of that solve depends on the trial: the stitched system of the
+// body that is running (SolveSys::tri), the next lambda and the next iteration number are all known the moment this body's solve has
+// been queued.  So one workgroup on the side stream runs the factorisation for that case (k_ef_tail_resub's workgroup 0 in its re-use form)
+// while the main stream linearises the trial; a rejection then finds x / xc / xAd ready and the next body is resubstitute + step + linearise.
+// Bit for bit the solve the body would have run itself (the re-use form is tested against it: test_reuse_after_reject_is_bit_identical).
+// No HIP events between the streams (an event record / wait pair per body cost more than the factorisation it hides: 61 -> 78 us per body,
+// profiles/r04_notes.txt): the side launch polls the main solve's tagged x words before it reads the system, and publishes its own results
+// as tagged words the next body's workgroups poll.
+constexpr unsigned kSpecTag = 0x40000000u;
+static int ef_launch_spec_solve(sdvgn_ef* e, int iteration_next, double lambda_next, bool main_solve_in_flight) {
+    const int buf = (e->seq_spec + 1) & 1;
+    SolveIO io;
+    std::memset(&io, 0, sizeof(io));
+    io.W = e->win_dev; io.sys = e->sys_dev; io.pieces = e->pieces_dev; io.acc = e->acc_dev;
+    io.rx = e->rx_spec; io.out = e->sol_spec + buf;
+    io.done_flag = e->flags_host + 5 + buf; io.done_seq = (int)(kSpecTag | (unsigned)(++e->seq_spec));
+    io.xw = e->xw_spec + (size_t)buf * 512;
+    io.err_word = nullptr;                             // a wait that gives up here fails nothing by itself: the host notices when (if) it needs the result
+    io.lambda = lambda_next; io.iteration = iteration_next; io.do_step = 0; io.reuse = 1; io.stepsize = 0.0f;
+    io.stamps = nullptr;
+    io.spec = 1;
+    // the system is written by the solve the main stream has just been handed (unless that body itself started from a speculative solution:
+    // then the system has not changed since an earlier body)
+    io.wait_xw = main_solve_in_flight ? e->xw_dev + 498 : nullptr; io.wait_seq = (unsigned)e->seq_solve;
+    const ReclArgs no_rc{};
+    const SelArgs no_sel{};
+    k_ef_tail_resub<<<1, kSolveLanes, 0, e->side>>>(io, no_rc, 0, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial, -1.0f,
+                                                    e->pid_alt, e->pidz_alt, e->pdeltaF_alt, 0, 0, 0, no_sel, -1, nullptr);
+    HIPCHK(hipGetLastError());
+    e->spec_last_buf = buf; e->spec_last_seq = io.done_seq;
+    return SDVGN_OK;
+}
+// before the main stream gets a launch that REWRITES the system (a solve that stitches anew): the speculative solve launched last must be
+// through -- it publishes a host flag when it is; normally it finished a whole linearise ago and this is one read of pinned memory
+static int ef_drain_spec(sdvgn_ef* e) {
+    if (e->spec_last_buf < 0) return SDVGN_OK;
+    HIPCHK(wait_flag(e->flags_host + 5 + e->spec_last_buf, e->spec_last_seq, e->side));
+    e->spec_last_buf = -1;
+    return SDVGN_OK;
+}
+// the body after a rejected step when its solution was computed ahead: resubstituteF + doStepFromBackup (+ the pending threshold select and
+// re-classification) -- k_ef_tail_resub without its workgroup 0; the workgroups poll the speculative solve's tagged words (normally long there)
+static int ef_launch_spec_rest(sdvgn_ef* e, int iteration, double lambda, float step_fac) {
+    int rc;
+    if ((rc = ef_sync_window(e)) || (rc = ef_sync_state(e))) return rc;
+    SolveIO io;
+    ef_fill_solve_io(e, io, iteration, lambda, /*do_step=*/true, step_fac, /*reuse=*/true);
+    io.rx = e->rx_spec;
+    io.xw = e->xw_spec + (size_t)e->spec_last_buf * 512;
+    io.done_seq = e->spec_last_seq;                     // the tag the polls wait for (and, being unique, the tag of this launch's threshold words)
+    const int has_rc = e->pend_rc_valid ? 1 : 0, has_sel = e->pend_sel_valid ? 1 : 0;
+    const int nblk = (e->nP + 63) / 64;
+    const int rest = (nblk + 1) / 2 + (io.en_em_trial ? 2 : 1);
+    const SelArgs sel = e->pend_sel;
+    ReclArgs rcl = e->pend_rc;
+    unsigned long long* thw = has_sel ? e->xw_dev + 500 : nullptr;
+    if (has_sel && has_rc && rcl.th == sel.th_out) { rcl.thw = thw; rcl.thseq = (unsigned)io.done_seq; }
+    const int lead = 1 + (has_rc ? kReclBlocks : 0);          // block indices [1, lead): the re-classification; block 0 (the factorisation) is not launched
+    k_ef_tail_resub<<<lead - 1 + rest + has_sel, kSolveLanes, 0, e->stream>>>(
+        io, rcl, has_rc, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt,
+        e->pdeltaF_alt, nblk, /*first_block=*/1, /*no_wait=*/0, sel, has_sel ? lead + rest : -1, thw);
+    e->pend_sel_valid = false; e->pend_rc_valid = false;
+    HIPCHK(hipGetLastError());
+    e->sys_on_device = true; e->sys_fetched = false; e->sys_valid = true;
+    return SDVGN_OK;
+}
+static int ef_wait_spec_solve(sdvgn_ef* e, int buf, int seq, double* x_out) {
+    HIPCHK(wait_flag(e->flags_host + 5 + buf, seq, e->side));
+    if (ef_wait_error(e)) return SDVGN_E_STATE;
+    const int n = CPARS + 6 * e->nF;
+    const SolveOut& o = e->sol_spec[buf];
+    e->lastX.assign(o.x, o.x + n);
+    if (x_out) std::memcpy(x_out, e->lastX.data(), sizeof(double) * n);
+    e->solve_status = o.status;
+    return SDVGN_OK;
+}
+
 static int ef_wait_solve(sdvgn_ef* e, double* x_out) {
     HIPCHK(wait_flag(e->flags_host + 3, e->seq_solve, e->stream));
     if (ef_wait_error(e)) return SDVGN_E_STATE;
@@ -1784,7 +1909,7 @@ static void calib_set_value(sdvgn_ef* e, const double* v) {   // CalibHessian::s
 }
 static double calc_M_energy(sdvgn_ef* e) {   // EnergyFunctional::calcMEnergyF
     const int nF = e->nF, n = CPARS + 6 * nF;
-    std::vector<double> d(n);
+    double d[CPARS + 6 * SDVGN_MAX_FRAMES];
     for (int i = 0; i < CPARS; ++i) d[i] = (double)e->C.cDeltaF[i];
     for (int h = 0; h < nF; ++h) for (int i = 0; i < 6; ++i) d[CPARS + 6 * h + i] = e->frames[h].delta[i];
     double s = 0;
@@ -1838,7 +1963,7 @@ static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideAr
         ef_owned_points(e, a.own0, a.own1);
         a.rflags = e->rflags; a.wo = e->A.renergy_wo; a.th_prev = e->A.frameTH_r; a.th_out = e->A.frameTH_w;
         a.log_slot = e->th_log ? e->th_log + (e->th_log_n++ % kThLog) : nullptr;
-        const DecideArgs none{0, 0, 0, nullptr, 0, nullptr, 0};
+        const DecideArgs none{0, 0, 0, nullptr, 0, nullptr, 0, nullptr};
         if (dec && dec->verdict && final_body && !e->own_stream) {
             const size_t slots = (size_t)e->nF * e->nP;
             k_ef_stats_apply_select<<<2 + (unsigned)((slots + kSelLanes - 1) / kSelLanes), kSelLanes, 0, e->stream>>>(
@@ -1931,6 +2056,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     const bool fixed_its = (flags & 1) != 0;   // benchmark mode: exactly mnumOptIts loop bodies, no early break
     const bool relinearize_on_reject = (flags & 2) != 0;   // run the reference's redundant re-linearisation literally (A/B timing, tests)
     const bool reuse_after_reject = (flags & 4) != 0;      // opt-in: the solve after a rejected step reuses the stitched system (see header)
+    const bool no_spec_solve = (flags & 16) != 0;          // A/B and tests: do not solve the rejected case ahead on the side stream
     e->pend_sel_valid = e->pend_rc_valid = false;           // nothing of an earlier (failed) call is carried over
     e->time_lin = (flags & 8) != 0;                          // measurement: event pair around every k_ef_linearize launch
     e->lin_ev_used = 0; e->lin_ms.clear();
@@ -1993,6 +2119,10 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     std::vector<int> th_idx;   // th_log slot of every trial linearisation (trace only)
     bool host_restore_pending = false;
     bool pre_accumulated = false;   // the accumulate of the coming body was queued behind the previous body's accept test (AccAlt)
+    // the rejected case solved ahead (ef_launch_spec_solve): single rank, shared stream, the product's default loop
+    const bool spec_enabled = defer && !e->own_stream && !no_spec_solve && !reuse_after_reject && e->side != nullptr;
+    bool spec_pending = false;      // this body's rejected-case solve has been queued on the side stream
+    bool spec_use = false;          // this body takes its solution from the solve its predecessor queued
     // an error exit from inside the loop leaves launches queued whose host-side bookkeeping (set flips, copy swaps) did not happen: the host
     // mirror goes back to the backed-up state and the handle refuses further work until the window is loaded again (sdvgn_ef_set_frames)
     struct LoopGuard {
@@ -2019,8 +2149,18 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         // second copies; resubstitute also backs up the idepths and applies the point step
         const bool reuse = reuse_after_reject && prev_rejected_clean && e->sys_valid;
         if (onecoll) ef_use_coll(e, e->coll_cur);                                        // the reduced accumulators of the current state
-        if ((rc = ef_launch_solve(e, iteration, lambda, /*do_step=*/true, stepsize, reuse, /*accumulated=*/pre_accumulated || onecoll))) return rc;
+        const bool from_spec = spec_use;                                                  // the predecessor was rejected and this very solve ran ahead
+        spec_use = false;
+        const int use_buf = e->spec_last_buf, use_seq = e->spec_last_seq;
+        if (from_spec) { if ((rc = ef_launch_spec_rest(e, iteration, lambda, stepsize))) return rc; }
+        else if ((rc = ef_launch_solve(e, iteration, lambda, /*do_step=*/true, stepsize, reuse, /*accumulated=*/pre_accumulated || onecoll))) return rc;
         pre_accumulated = false;
+        // ... and this body's own rejected case goes to the side stream now: same system (it is in SolveSys::tri), 100 x the damping, next iteration
+        spec_pending = false;
+        if (spec_enabled && !zero_differs && e->sys_valid && iteration + 1 < mnumOptIts) {
+            if ((rc = ef_launch_spec_solve(e, iteration + 1, lambda * 1e2, /*main_solve_in_flight=*/!from_spec))) return rc;
+            spec_pending = true;
+        }
         ef_swap_point_copies(e);                                                          // the stepped idepths are the ones every later launch reads
         e->deltaF_nonzero = false;
         std::swap(e->precalc_dev, e->precalc_alt);
@@ -2038,10 +2178,21 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             if ((rc = linearize_launch_kernels(e)) || (rc = ef_sharded_message(e, 1 - e->coll_cur, /*speculative=*/true))) return rc;
         } else
         if ((rc = dev_decide ? linearize_launch_kernels(e) : linearize_launch(e, defer))) return rc;
+        if (dev_decide) {
+            // the sums, the accept test and -- in the same launch -- applyRes of the trial linearisation, queued right behind the linearise: what
+            // the test needs from the stepped state (prior energy, M energy) was formed on the device beside the step (step_energy_body), what it
+            // needs from the last accepted state (the right-hand side) the host holds, so the host has not seen x yet and need not
+            if ((rc = take_initial_energies())) return rc;                     // first body: the call's initial sums, before this body's overwrite them
+            DecideArgs dec;
+            dec.En = dec.EM = 0; dec.en_em = e->en_em_dev + 2 * st_trial;
+            dec.rhs = lastEnergy + lastEnergyL + lastEnergyM; dec.accept_dev = e->accept_dev; dec.on = 1;
+            dec.verdict = (unsigned*)(e->accept_dev + 4); dec.seq = (unsigned)(++e->seq_verdict) & 0x7fffffffu;
+            if ((rc = linearize_launch_stats(e, defer, &dec, /*final_body=*/iteration + 1 == mnumOptIts))) return rc;
+        }
         g_pt.stop(PT_ACCUM);
         // x is in pinned memory as soon as the solve kernel is through: mirror doStepFromBackup on the host (FrameHessian::setState,
         // CalibHessian::setValue -- the same double-precision operations the device performed) while the GPU linearises
-        if ((rc = ef_wait_solve(e, x.data()))) return rc;
+        if ((rc = from_spec ? ef_wait_spec_solve(e, use_buf, use_seq, x.data()) : ef_wait_solve(e, x.data()))) return rc;
         g_pt.stop(PT_D2H);
         {
             double v[4];
@@ -2057,16 +2208,11 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             ef_refresh_frame_deltas(e);
             host_restore_pending = false;     // the mirror holds the new trial state
         }
-        float sumT = e->sol_host->sumT, sumR = e->sol_host->sumR;
-        const double newEnergyM = calc_M_energy(e);
-        if ((rc = take_initial_energies())) return rc;                         // first body: the call's initial sums, before this body's overwrite them
+        float sumT = from_spec ? e->sol_spec[use_buf].sumT : e->sol_host->sumT, sumR = from_spec ? e->sol_spec[use_buf].sumR : e->sol_host->sumR;
+        double newEnergyM = calc_M_energy(e);                                  // (host mirror: the value itself in the host-decided paths, the cross-check below otherwise)
+        const double En_host = host_prior_energy(e);
+        if ((rc = take_initial_energies())) return rc;
         if (dev_decide) {
-            // the sums, the verdict and -- queued right behind, so that no launch latency separates it from the verdict -- applyRes of
-            // the trial linearisation, which returns at once when the step is rejected
-            DecideArgs dec;
-            dec.En = host_prior_energy(e); dec.EM = newEnergyM; dec.rhs = lastEnergy + lastEnergyL + lastEnergyM; dec.accept_dev = e->accept_dev; dec.on = 1;
-            dec.verdict = (unsigned*)(e->accept_dev + 4); dec.seq = (unsigned)(++e->seq_verdict) & 0x7fffffffu;
-            if ((rc = linearize_launch_stats(e, defer, &dec, /*final_body=*/iteration + 1 == mnumOptIts))) return rc;
             // the next body's accumulate, queued before the verdict is known (AccAlt): its arguments are the accepted case -- the state
             // this body's launches run on --, the kept copies go along for the rejected one
             pre_accumulated = false;
@@ -2074,7 +2220,8 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             // learns with the sums: the per-point planes must hold what the LAST executed solveSystemF left, like the reference's EFPoints)
             const bool may_break = !fixed_its && iteration >= 1 && sqrtf(sumR / nF) < 0.00005 * thOpt;
             if (!reuse_after_reject && !may_break && iteration + 1 < mnumOptIts && ef_acc_geom(e).sc_ppb == 64) {
-                const AccAlt alt{e->accept_dev, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->calib_dev + e->st_cur, e->precalc_alt};
+                // (when the rejected case has been solved ahead, a rejection leaves this accumulate without a reader: it returns at once)
+                const AccAlt alt{e->accept_dev, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->calib_dev + e->st_cur, e->precalc_alt, spec_pending ? 1 : 0};
                 if ((rc = ef_accumulate(e, /*with_reduce=*/true, &alt))) return rc;
                 pre_accumulated = true;
             }
@@ -2082,6 +2229,13 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         g_pt.stop(PT_STEP);
         double newEnergy, newEnergyL, sID, sNID;
         if ((rc = linearize_wait(e, &newEnergy, &newEnergyL, &sID, &sNID))) return rc;
+        if (dev_decide) {
+            // the device formed the state's parts of the energies itself (stats_host[5], [7]); the host's mirror must give the same doubles -- the
+            // same IEEE operations in the same order on the same numbers (cannot differ; if it ever does, the call fails instead of drifting)
+            if (e->stats_host[5] != En_host || e->stats_host[7] != newEnergyM) return SDVGN_E_STATE;
+            newEnergyL = e->stats_host[5] + (double)(float)e->stats_host[1];
+            newEnergyM = e->stats_host[7];
+        }
         g_pt.stop(PT_LIN);
         sumR /= nF; sumT /= nF;
         const float sumNID = (float)sNID / (float)e->nP;
@@ -2180,12 +2334,14 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             lambda *= 1e2;
             // the restored state is the one this body's system was built on, bit for bit (unless idepth_zero just changed, above)
             prev_rejected_clean = !zero_differs;
+            spec_use = spec_pending && prev_rejected_clean;     // the next body's solution is (being) computed on the side stream
         }
         g_pt.stop(PT_APPLY);
         e->iter_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_iter).count());
         if (!fixed_its && canbreak && iteration >= 1) break;
     }
     if ((rc = take_initial_energies())) return rc;                             // (a call of zero bodies)
+    if ((rc = ef_drain_spec(e))) return rc;                                    // (normally one read of pinned memory: the last side-stream solve is through)
     ef_flush_pending(e);
     HIPCHK(hipGetLastError());
     if (ef_wait_error(e)) return SDVGN_E_STATE;

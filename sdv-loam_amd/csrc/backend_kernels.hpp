@@ -931,7 +931,9 @@ __global__ void __launch_bounds__(256) k_ef_sc_gram(EFConst C, EFArrays A, const
 // alt (optimize loop): this accumulate was queued BEHIND the statistics + accept-test launch of a trial step, before the host knew the
 // verdict, so that no launch latency separates the two.  The arguments describe the window after an accepted step; when the verdict word
 // says "rejected", the state-dependent inputs -- the point copies, the calib floats, the precalc table -- are the kept ones instead.
-struct AccAlt { const int* verdict; const float* pid; const float* pidz; const float* pdeltaF; const CalibDev* calib; const PrecalcDev* precalc; };
+// skip_on_reject: the solution of the rejected case was computed ahead on the side stream (ef_launch_spec_solve, backend.hip), so a "rejected"
+// verdict means this accumulate has no reader -- the planes it would rewrite already hold the kept state's values: every workgroup returns at once
+struct AccAlt { const int* verdict; const float* pid; const float* pidz; const float* pdeltaF; const CalibDev* calib; const PrecalcDev* precalc; int skip_on_reject; };
 __global__ void __launch_bounds__(256) k_ef_acc_fused(const PrecalcDev* __restrict__ precalc, EFConst Cin, EFArrays A,
                                                       const int* __restrict__ phost, float* __restrict__ top_partial,
                                                       int* __restrict__ nres_partial, int top_chunks, float* __restrict__ sc_partial,
@@ -940,6 +942,7 @@ __global__ void __launch_bounds__(256) k_ef_acc_fused(const PrecalcDev* __restri
     // the verdict word is FETCHED here and LOOKED AT where the state-dependent inputs are first needed: tested at once it heads the chain
     // verdict -> point range -> flags -> values of every Schur workgroup with a round trip of its own
     const int vd = alt.verdict ? *alt.verdict : 1;
+    if (alt.skip_on_reject && vd == 0) return;   // (uniform over the grid: before any barrier)
     __shared__ union U { TopGramSmem t; PointSmem p; ScGramSmem s; __device__ U() {} } S;
     const int b = blockIdx.x;
     if (b < n_sc) {
@@ -1054,7 +1057,9 @@ constexpr int kScTasksPerHost = 10 * 16 * 4 * 4;   // 2560
 static inline int acc_reduce_grid(int pairs, int nF) { return (nF * kScTasksPerHost) / 256 + (pairs * 33 + 255) / 256 + 1; }
 __global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__ top_partial, int pairs, int top_chunks,
                                                        const float* __restrict__ sc_partial, int nF, int sc_chunks,
-                                                       const int* __restrict__ nres_partial, double* __restrict__ out) {
+                                                       const int* __restrict__ nres_partial, double* __restrict__ out,
+                                                       const int* __restrict__ skip_verdict = nullptr /* non-NULL: return at once when it reads 0 (AccAlt::skip_on_reject) */) {
+    if (skip_verdict && *skip_verdict == 0) return;
     const int ntop = pairs * 121, nsc = nF * 1431;
     const int nb_sc = (nF * kScTasksPerHost) / 256, nb_top = (pairs * 33 + 255) / 256;
     const int b = blockIdx.x;

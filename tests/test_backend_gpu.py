@@ -414,6 +414,37 @@ def test_reuse_after_reject_is_bit_identical(api, orc, seed):
     assert np.array_equal(xa, xb)
 
 
+@pytest.mark.parametrize("seed,its", [(2, 12), (3, 12), (4, 7), (2, 1), (3, 2)])
+def test_rejected_case_solved_ahead_is_bit_identical(api, orc, seed, its):
+    """The default loop solves the rejected case of every body ahead on the side stream (ef_launch_spec_solve) and, after a rejection, starts
+    the next body from that solution instead of accumulating, stitching and factoring again.  Trace, final state, per-residual planes, point
+    planes and the next solve must not differ by a bit from the loop that does not (flags bit4) -- with single and consecutive rejections,
+    a rejection in the last body, and an accepted step in between."""
+    from sdv_loam_amd import synthetic as syn
+    kw = {} if seed == 2 else dict(state_sigma=1e-3, idepth_sigma=0.01)
+    W = low_thresholds(syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=seed, calib=dict(fx=400., fy=410., cx=319.5, cy=119.5), **kw))
+    A = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+    B = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+    ta = A.optimize(its, fixed_its=True)
+    tb = B.optimize(its, fixed_its=True, no_spec_solve=True)
+    rej = ta[:, 2] == 0
+    if seed == 2 and its >= 7:
+        assert rej.any() and (~rej).any()                                        # rejected and accepted steps
+    if seed == 2 and its >= 12:
+        assert (rej[:-1] & rej[1:]).any()                                        # consecutive rejections: a speculative solve on top of a speculative solution
+    assert np.array_equal(ta, tb)
+    for x, y in zip(A.state(), B.state()):
+        assert np.array_equal(x, y)
+    sa, sb = A.residual_state(), B.residual_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(A.frame_energy_th(), B.frame_energy_th())
+    xa, xb = A.solveSystemF(3, 0.1), B.solveSystemF(3, 0.1)
+    assert np.array_equal(xa, xb) and np.array_equal(A.points(), B.points())
+    # a second call on the same handles (a side-stream solve of the first call may have been left unused)
+    assert np.array_equal(A.optimize(4, fixed_its=True), B.optimize(4, fixed_its=True, no_spec_solve=True))
+
+
 @pytest.mark.parametrize("direct", [True, False])
 def test_sharded_path_single_rank_nccl(api, orc, window, direct, monkeypatch):
     """cfg4 plumbing on one GPU: external torch buffers, torch stream, and the collectives of a 1-rank RCCL group -- issued either by
