@@ -130,6 +130,8 @@ struct sdvgn_ef {
     int seq_spec = 0;                      // tags of the speculative solves are kSpecTag | seq_spec: disjoint from the main solves' (seq_solve)
     hipStream_t side = nullptr;            // the device's shared side stream (not owned)
     int spec_last_buf = -1, spec_last_seq = 0;   // the speculative solve launched last (may still be running)
+    bool spec_last_has_th = false;         // ... and whether the trial's thresholds were selected beside it
+    bool reduce_pending = false;           // the accumulate queued ahead of the verdict has run without its reduce (launched with the solve, accepted case only)
     SolvePieces* pieces_dev = nullptr;     // [SDVGN_MAX_FRAMES]: per-host shares of HA / bA / Hsc / bsc
     unsigned long long* solve_stamps = nullptr;   // pinned, 16 words: SDVGN_DEBUG_FLAGS bit6 only (phase stamps of the solve workgroup)
     int solve_status = 0;                  // status of the last device solve: 1 = a pivot of the LDL^T was not positive / finite (x = 0)
@@ -1743,7 +1745,13 @@ static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_st
             if ((rc = ef_accumulate(e, /*with_reduce=*/true))) return rc;
             // sharded window: the packed buffer of every rank is summed (ONE all-reduce per GN iteration), then every rank stitches and solves
             if (ef_sharded(e) && (rc = ef_allreduce(e, e->acc_dev, (int)acc_count(e)))) return rc;
+        } else if (e->reduce_pending) {
+            // the accumulate was queued before the verdict, its reduce waits until here: after a rejection whose solution was computed ahead it
+            // is never launched (an empty launch of its grid still cost ~5 us between the verdict and the next body)
+            const AccGeom g = ef_acc_geom(e);
+            k_ef_acc_reduce<<<acc_reduce_grid(g.pairs, nF), 256, 0, e->stream>>>(e->top_partial, g.pairs, g.chunks, e->sc_partial, nF, g.sc_chunks, e->nres_partial, e->acc_dev);
         }
+        e->reduce_pending = false;
         // the pending threshold select rides in the factorisation's launch (below); a handle that runs beside others keeps it in this one
         const int has_sel = (e->own_stream && e->pend_sel_valid) ? 1 : 0;
         k_ef_stitch<<<kStitchParts * nF + 1 + has_sel, kSolveLanes, 0, e->stream>>>(io, e->pend_sel, has_sel);
@@ -1752,13 +1760,14 @@ static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_st
     if (e->pend_sel_valid && e->own_stream) ef_flush_pending(e);    // (own stream + system re-used: no launch to ride in)
     const int has_rc = e->pend_rc_valid ? 1 : 0;
     const int nblk = (e->nP + 63) / 64;
-    const int head = 1 + (has_rc ? kReclBlocks : 0), rest = (nblk + 1) / 2 + (do_step ? (io.en_em_trial ? 2 : 1) : 0);   // + step (+ energy) workgroups
+    const int n_recl = has_rc ? kReclBlocks : 0;      // (beside the factorisation four workgroups are plenty: they have ~18 us)
+    const int head = 1 + n_recl, rest = (nblk + 1) / 2 + (do_step ? (io.en_em_trial ? 2 : 1) : 0);   // + step (+ energy) workgroups
     const SelArgs sel = e->pend_sel;
     if (e->own_stream) {   // a window that runs beside others: no spinning workgroups (see k_ef_tail_resub)
-        k_ef_tail_resub<<<head, kSolveLanes, 0, e->stream>>>(io, e->pend_rc, has_rc, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup,
+        k_ef_tail_resub<<<head, kSolveLanes, 0, e->stream>>>(io, e->pend_rc, n_recl, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup,
                                                              e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, nblk, 0, 0,
                                                              sel, -1, nullptr);
-        k_ef_tail_resub<<<rest, kSolveLanes, 0, e->stream>>>(io, e->pend_rc, has_rc, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup,
+        k_ef_tail_resub<<<rest, kSolveLanes, 0, e->stream>>>(io, e->pend_rc, n_recl, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup,
                                                              e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, nblk, head, 1,
                                                              sel, -1, nullptr);
     } else {
@@ -1769,7 +1778,7 @@ static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_st
         unsigned long long* thw = has_sel ? e->xw_dev + 500 : nullptr;
         if (has_sel && has_rc && rcl.th == sel.th_out) { rcl.thw = thw; rcl.thseq = (unsigned)io.done_seq; }
         k_ef_tail_resub<<<head + rest + has_sel, kSolveLanes, 0, e->stream>>>(
-            io, rcl, has_rc, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt,
+            io, rcl, n_recl, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt,
             e->pdeltaF_alt, nblk, 0, 0, sel, has_sel ? head + rest : -1, thw);
         e->pend_sel_valid = false;
     }
@@ -1792,7 +1801,12 @@ static inline bool ef_wait_error(const sdvgn_ef* e) {   // a workgroup gave up a
 // profiles/r04_notes.txt): the side launch polls the main solve's tagged x words before it reads the system, and publishes its own results
 // as tagged words the next body's workgroups poll.
 constexpr unsigned kSpecTag = 0x40000000u;
-static int ef_launch_spec_solve(sdvgn_ef* e, int iteration_next, double lambda_next, bool main_solve_in_flight) {
+// with_select: a second workgroup of the same launch takes setNewFrameEnergyTH of the trial linearisation this body is about to run -- it waits for
+// that trial's accept test (verdict number verdict_seq), then selects and leaves the thresholds as tagged words beside the speculative solution:
+// after a rejection the re-classification (which must precede the next linearise) finds them there instead of behind a select of ~7 us in
+// its own launch.  (After an accepted step the thresholds come from the select that rides in the next body's factorisation launch, as before.)
+static int ef_launch_spec_solve(sdvgn_ef* e, int iteration_next, double lambda_next, bool main_solve_in_flight, bool with_select = false,
+                                unsigned verdict_seq = 0) {
     const int buf = (e->seq_spec + 1) & 1;
     SolveIO io;
     std::memset(&io, 0, sizeof(io));
@@ -1808,11 +1822,19 @@ static int ef_launch_spec_solve(sdvgn_ef* e, int iteration_next, double lambda_n
     // then the system has not changed since an earlier body)
     io.wait_xw = main_solve_in_flight ? e->xw_dev + 498 : nullptr; io.wait_seq = (unsigned)e->seq_solve;
     const ReclArgs no_rc{};
-    const SelArgs no_sel{};
-    k_ef_tail_resub<<<1, kSolveLanes, 0, e->side>>>(io, no_rc, 0, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial, -1.0f,
-                                                    e->pid_alt, e->pidz_alt, e->pdeltaF_alt, 0, 0, 0, no_sel, -1, nullptr);
+    SelArgs sel{};
+    if (with_select) {
+        sel.nF = e->nF; sel.nP = e->nP;
+        ef_owned_points(e, sel.own0, sel.own1);
+        sel.rflags = e->rflags; sel.wo = e->A.renergy_wo; sel.th_prev = e->A.frameTH_r; sel.th_out = nullptr;      // (tagged words only: nothing on the main stream is ordered behind this launch)
+        sel.log_slot = e->th_log ? e->th_log + (e->th_log_n % kThLog) : nullptr;     // the slot this trial's select logs to (linearize_launch_stats takes the same one)
+        sel.wait_verdict = (const unsigned*)(e->accept_dev + 4); sel.wait_seq = verdict_seq;
+    }
+    k_ef_tail_resub<<<with_select ? 2 : 1, kSolveLanes, 0, e->side>>>(io, no_rc, 0, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial, -1.0f,
+                                                                     e->pid_alt, e->pidz_alt, e->pdeltaF_alt, 0, 0, 0, sel, with_select ? 1 : -1,
+                                                                     with_select ? io.xw + 500 : nullptr);
     HIPCHK(hipGetLastError());
-    e->spec_last_buf = buf; e->spec_last_seq = io.done_seq;
+    e->spec_last_buf = buf; e->spec_last_seq = io.done_seq; e->spec_last_has_th = with_select;
     return SDVGN_OK;
 }
 // before the main stream gets a launch that REWRITES the system (a solve that stitches anew): the speculative solve launched last must be
@@ -1833,6 +1855,10 @@ static int ef_launch_spec_rest(sdvgn_ef* e, int iteration, double lambda, float 
     io.rx = e->rx_spec;
     io.xw = e->xw_spec + (size_t)e->spec_last_buf * 512;
     io.done_seq = e->spec_last_seq;                     // the tag the polls wait for (and, being unique, the tag of this launch's threshold words)
+    // the rejected trial's thresholds: selected beside the speculative solve (tagged words behind its solution) -- the pending select is then
+    // dropped: only the re-classification of this launch ever reads that trial's thresholds
+    const bool th_ahead = e->spec_last_has_th && e->pend_rc_valid && e->pend_sel_valid && e->pend_rc.th == e->pend_sel.th_out;
+    if (th_ahead) e->pend_sel_valid = false;
     const int has_rc = e->pend_rc_valid ? 1 : 0, has_sel = e->pend_sel_valid ? 1 : 0;
     const int nblk = (e->nP + 63) / 64;
     const int rest = (nblk + 1) / 2 + (io.en_em_trial ? 2 : 1);
@@ -1840,9 +1866,13 @@ static int ef_launch_spec_rest(sdvgn_ef* e, int iteration, double lambda, float 
     ReclArgs rcl = e->pend_rc;
     unsigned long long* thw = has_sel ? e->xw_dev + 500 : nullptr;
     if (has_sel && has_rc && rcl.th == sel.th_out) { rcl.thw = thw; rcl.thseq = (unsigned)io.done_seq; }
-    const int lead = 1 + (has_rc ? kReclBlocks : 0);          // block indices [1, lead): the re-classification; block 0 (the factorisation) is not launched
+    if (th_ahead) { rcl.thw = io.xw + 500; rcl.thseq = (unsigned)io.done_seq; }
+    // the re-classification in ONE pass (one slot per lane): beside the factorisation four workgroups walking ~8 slots per lane were hidden,
+    // here they would be the launch's duration (measured: 19 us for resubstitute + step with them, profiles/r04_notes.txt)
+    const int n_recl = has_rc ? (rcl.nP + rcl.np_last * (rcl.nF - 1) + kSolveLanes - 1) / kSolveLanes : 0;
+    const int lead = 1 + n_recl;                              // block indices [1, lead): the re-classification; block 0 (the factorisation) is not launched
     k_ef_tail_resub<<<lead - 1 + rest + has_sel, kSolveLanes, 0, e->stream>>>(
-        io, rcl, has_rc, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt,
+        io, rcl, n_recl, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt,
         e->pdeltaF_alt, nblk, /*first_block=*/1, /*no_wait=*/0, sel, has_sel ? lead + rest : -1, thw);
     e->pend_sel_valid = false; e->pend_rc_valid = false;
     HIPCHK(hipGetLastError());
@@ -1958,7 +1988,7 @@ static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideAr
     } else {
         // statistics (the host waits for their flag; pinned memory, no copy engine) and setNewFrameEnergyTH (only the NEXT linearise
         // needs it) side by side in one launch -- or, deferred, the select as a workgroup of the next body's k_ef_stitch
-        SelArgs a;
+        SelArgs a{};
         a.nF = e->nF; a.nP = e->nP;
         ef_owned_points(e, a.own0, a.own1);
         a.rflags = e->rflags; a.wo = e->A.renergy_wo; a.th_prev = e->A.frameTH_r; a.th_out = e->A.frameTH_w;
@@ -2058,6 +2088,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     const bool reuse_after_reject = (flags & 4) != 0;      // opt-in: the solve after a rejected step reuses the stitched system (see header)
     const bool no_spec_solve = (flags & 16) != 0;          // A/B and tests: do not solve the rejected case ahead on the side stream
     e->pend_sel_valid = e->pend_rc_valid = false;           // nothing of an earlier (failed) call is carried over
+    e->reduce_pending = false;
     e->time_lin = (flags & 8) != 0;                          // measurement: event pair around every k_ef_linearize launch
     e->lin_ev_used = 0; e->lin_ms.clear();
     struct TimeLinGuard { sdvgn_ef* e; ~TimeLinGuard() { e->time_lin = false; } } time_lin_guard{e};
@@ -2152,15 +2183,9 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         const bool from_spec = spec_use;                                                  // the predecessor was rejected and this very solve ran ahead
         spec_use = false;
         const int use_buf = e->spec_last_buf, use_seq = e->spec_last_seq;
-        if (from_spec) { if ((rc = ef_launch_spec_rest(e, iteration, lambda, stepsize))) return rc; }
+        if (from_spec) { e->reduce_pending = false; if ((rc = ef_launch_spec_rest(e, iteration, lambda, stepsize))) return rc; }
         else if ((rc = ef_launch_solve(e, iteration, lambda, /*do_step=*/true, stepsize, reuse, /*accumulated=*/pre_accumulated || onecoll))) return rc;
         pre_accumulated = false;
-        // ... and this body's own rejected case goes to the side stream now: same system (it is in SolveSys::tri), 100 x the damping, next iteration
-        spec_pending = false;
-        if (spec_enabled && !zero_differs && e->sys_valid && iteration + 1 < mnumOptIts) {
-            if ((rc = ef_launch_spec_solve(e, iteration + 1, lambda * 1e2, /*main_solve_in_flight=*/!from_spec))) return rc;
-            spec_pending = true;
-        }
         ef_swap_point_copies(e);                                                          // the stepped idepths are the ones every later launch reads
         e->deltaF_nonzero = false;
         std::swap(e->precalc_dev, e->precalc_alt);
@@ -2168,6 +2193,14 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         e->A.calib = e->calib_dev + st_trial;
         ef_select_new_set(e, 1 - e->new_cur, e->new_cur);                                 // trial linearisation goes to the other set
         th_idx.push_back(e->th_log_n % kThLog);
+        // ... and this body's own rejected case goes to the side stream now: same system (it is in SolveSys::tri), 100 x the damping, next iteration;
+        // beside it the threshold select of the trial that is about to be linearised (it waits for that trial's accept test)
+        spec_pending = false;
+        if (spec_enabled && !zero_differs && e->sys_valid && iteration + 1 < mnumOptIts) {
+            if ((rc = ef_launch_spec_solve(e, iteration + 1, lambda * 1e2, /*main_solve_in_flight=*/!from_spec, /*with_select=*/true,
+                                           (unsigned)(e->seq_verdict + 1) & 0x7fffffffu))) return rc;
+            spec_pending = true;
+        }
         // device-side accept test: the statistics launch waits for the host's parts of the comparison (after the mirror below), the
         // linearise does not
         const bool dev_decide = defer && !zero_differs;

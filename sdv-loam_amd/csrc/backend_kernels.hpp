@@ -1254,15 +1254,23 @@ __device__ __forceinline__ unsigned wave_sum_dpp_u32(unsigned v) {
 __device__ __forceinline__ unsigned wave_scan_dpp_u32(unsigned v) { return wave_sum_dpp_u32(v); }   // the sum IS built as an inclusive scan
 struct SelectSmem { unsigned hist[2 * kSelLanes]; unsigned wsum[kSelLanes / 64]; unsigned sel[2]; };
 // own0/own1: the point range [own0, own1) hosted by this rank's key-frames (the planes of other points are not written here)
-template <int SRC>
+// COH: the planes were written by a kernel of ANOTHER stream with no kernel boundary in between (the side-stream select of a trial
+// linearisation, backend.hip): device-scope loads instead of loads this XCD's L2 may answer from a stale line
+template <bool COH> __device__ __forceinline__ uint8_t sel_load_u8(const uint8_t* p) {
+    return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool COH> __device__ __forceinline__ float sel_load_f32(const float* p) {
+    return COH ? __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : *p;
+}
+template <int SRC, bool COH = false>
 __device__ __forceinline__ unsigned sel_key(int p, int nF, int nP, int own0, int own1, const uint8_t* __restrict__ rflags,
                                              const float* __restrict__ wo, const double* __restrict__ cand) {
     if (p >= nP) return 0xFFFFFFFFu;
     float v;
     if (SRC == 0) {
         const size_t s = (size_t)(nF - 1) * nP + p;
-        const uint8_t fl = rflags[s];
-        v = wo[s];
+        const uint8_t fl = sel_load_u8<COH>(rflags + s);
+        v = sel_load_f32<COH>(wo + s);
         if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED) || p < own0 || p >= own1) return 0xFFFFFFFFu;
     } else {
         const double c = cand[p];
@@ -1274,7 +1282,7 @@ __device__ __forceinline__ unsigned sel_key(int p, int nF, int nP, int own0, int
 }
 
 // body for one workgroup of kSelLanes lanes
-template <int SRC>
+template <int SRC, bool COH = false>
 __device__ __forceinline__ void select_th_body(int nF, int nP, int own0, int own1, const uint8_t* __restrict__ rflags, const float* __restrict__ wo,
                                                const double* __restrict__ cand, const float* __restrict__ th_prev, float* __restrict__ th_out,
                                                float* __restrict__ log_slot, SelectSmem& S,
@@ -1289,7 +1297,7 @@ __device__ __forceinline__ void select_th_body(int nF, int nP, int own0, int own
 #pragma unroll
         for (int i = 0; i < kSelVPT; ++i) {
             const int p = min(tid + i * kSelLanes, nP - 1);
-            if (SRC == 0) { const size_t s = (size_t)(nF - 1) * nP + p; fl[i] = rflags[s]; v[i] = wo[s]; }
+            if (SRC == 0) { const size_t s = (size_t)(nF - 1) * nP + p; fl[i] = sel_load_u8<COH>(rflags + s); v[i] = sel_load_f32<COH>(wo + s); }
             else c[i] = cand[p];
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1320,7 +1328,7 @@ __device__ __forceinline__ void select_th_body(int nF, int nP, int own0, int own
         for (int i = 0; i < kSelVPT; ++i)
             if ((key[i] & pmask) == prefix) atomicAdd(&s_hist[(key[i] >> shift) & (nb - 1)], 1u);
         for (int p0 = p_tail; p0 < nP; p0 += kSelLanes) {   // windows beyond 16384 points: re-read (uniform trip count)
-            const unsigned k = sel_key<SRC>(p0 + tid, nF, nP, own0, own1, rflags, wo, cand);
+            const unsigned k = sel_key<SRC, COH>(p0 + tid, nF, nP, own0, own1, rflags, wo, cand);
             if ((k & pmask) == prefix) atomicAdd(&s_hist[(k >> shift) & (nb - 1)], 1u);
         }
         __syncthreads();
@@ -1355,16 +1363,19 @@ __device__ __forceinline__ void select_th_body(int nF, int nP, int own0, int own
         th = th * th;
         th *= 1.0f * 1.0f;                            // setting_overallEnergyTHWeight^2
     }
-    if (tid < nF - 1) { const float tp = th_prev[tid]; th_out[tid] = tp; if (thw) store_tagged_u32(thw + tid, thseq, __float_as_uint(tp)); }
+    if (tid == 0 && log_slot) *log_slot = th;
+    if (tid < nF - 1) { const float tp = sel_load_f32<COH>(th_prev + tid); if (th_out) th_out[tid] = tp; if (thw) store_tagged_u32(thw + tid, thseq, __float_as_uint(tp)); }
     if (tid == 0) {
-        th_out[nF - 1] = th;
+        if (th_out) th_out[nF - 1] = th;
         if (thw) store_tagged_u32(thw + nF - 1, thseq, __float_as_uint(th));
-        if (log_slot) *log_slot = th;
     }
 }
 
 // arguments of one pending setNewFrameEnergyTH (SRC 0) when it rides in another kernel's launch as an extra workgroup
-struct SelArgs { int nF, nP, own0, own1; const uint8_t* rflags; const float* wo; const float* th_prev; float* th_out; float* log_slot; };
+// wait_verdict (side-stream select only): the select first waits until the accept test of verdict number wait_seq has been published there --
+// the trial linearisation whose energies it reads is then complete -- and reads the planes with device-scope loads
+struct SelArgs { int nF, nP, own0, own1; const uint8_t* rflags; const float* wo; const float* th_prev; float* th_out; float* log_slot;
+                 const unsigned* wait_verdict; unsigned wait_seq; };
 
 template <int SRC>
 __global__ void __launch_bounds__(kSelLanes) k_ef_select_th(int nF, int nP, int own0, int own1, const uint8_t* __restrict__ rflags,
