@@ -489,6 +489,8 @@ int sdvgn_ef_init_rccl(sdvgn_ef* ef, const unsigned char* id128, int rank, int w
  * only the first sdvgn_ef_init_rccl with an id is collective.  An id whose communicator is gone must not be used again (like any
  * ncclUniqueId); sdvgn_rccl_comm_alive tells whether this process still holds the communicator of `id128` (1) or not (0). */
 int sdvgn_rccl_comm_alive(const unsigned char* id128);
+/* number of ranks of the RCCL communicator behind this handle's collectives (ncclCommCount); 0: no communicator (single GPU / callback path) */
+int sdvgn_ef_rccl_ranks(sdvgn_ef* ef);
 /* restrict this rank's work to host frames [h0,h1) (cfg4: frames sharded across GPUs); default all. */
 int sdvgn_ef_set_host_range(sdvgn_ef* ef, int h0, int h1);
 

@@ -62,6 +62,7 @@ PROTOTYPES = [
     ("sdvgn_rccl_unique_id", C.c_int, [vp]),
     ("sdvgn_ef_init_rccl", C.c_int, [vp, vp, C.c_int, C.c_int]),
     ("sdvgn_rccl_comm_alive", C.c_int, [C.c_char_p]),
+    ("sdvgn_ef_rccl_ranks", C.c_int, [vp]),
     ("sdvgn_ef_optimize_immature", C.c_int, [vp, C.c_int, i32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p, u8p, C.c_int, i32p, f32p, i32p]),
     ("sdvgn_ef_accumulators_dev", C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int)]),
     ("sdvgn_ef_accumulate", C.c_int, [vp]),

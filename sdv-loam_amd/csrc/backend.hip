@@ -876,6 +876,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     bool ok = false;
 };
 static RcclApi& rccl_api() {
@@ -889,6 +890,7 @@ static RcclApi& rccl_api() {
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
     api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+    api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
     api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy;
     return api;
 }
@@ -1600,6 +1602,14 @@ int sdvgn_ef_init_rccl(sdvgn_ef* e, const unsigned char* id128, int rank, int wo
     g_comms.push_back(sc);
     e->rccl_comm = comm;
     return SDVGN_OK;
+}
+
+// ranks of the RCCL communicator this handle issues its collectives on (ncclCommCount), 0 if it has none (single GPU, or the callback path)
+int sdvgn_ef_rccl_ranks(sdvgn_ef* e) {
+    if (!e) return SDVGN_E_ARG;
+    if (!e->rccl_comm || !rccl_api().CommCount) return 0;
+    int n = 0;
+    return rccl_api().CommCount(e->rccl_comm, &n) == ncclSuccess ? n : SDVGN_E_STATE;
 }
 
 int sdvgn_rccl_comm_alive(const unsigned char* id128) {

@@ -183,6 +183,12 @@ class ShardedEnergyFunctional:
         with self.torch.cuda.stream(self.stream):
             return self.ef.optimize(its, want_trace=want_trace, fixed_its=fixed_its)
 
+    def collective_count(self):
+        """all-reduces this window has issued so far, counted where they are issued (the library for RCCL / its callback, sdvgn_ef_collective_count)"""
+        self.ef.L.sdvgn_ef_collective_count.restype = C.c_ulonglong
+        self.ef.L.sdvgn_ef_collective_count.argtypes = [C.c_void_p]
+        return int(self.ef.L.sdvgn_ef_collective_count(self.ef.h_))
+
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # Coarse tracker, hypothesis-parallel (SURVEY.md 8e, tracker row (i)).
