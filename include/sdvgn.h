@@ -345,6 +345,14 @@ int sdvgn_ef_get_solve_status(sdvgn_ef* ef);
  * pool driving each.  its_out[b] (may be NULL) = return value of window b's sdvgn_ef_optimize.  Returns SDVGN_OK or the error of a window.
  * Results of every window are those of its own sdvgn_ef_optimize call, bit for bit. */
 int sdvgn_ef_optimize_batch(sdvgn_ef* const* handles, int B, int mnumOptIts, int flags, int* its_out);
+/* The form sdvgn_ef_optimize_batch takes by default: the B loops as ONE launch sequence -- every kernel of a loop body launched once for
+ * all windows (the window is a grid index), the accept / reject decision, lambda and the choice of state copies of every window kept in
+ * device memory, no host round trip inside the call (csrc/backend_lockstep.inc).  Single-rank windows in the product's default mode only
+ * (flags: bit0 = exactly mnumOptIts bodies); SDVGN_E_ARG otherwise (sdvgn_ef_optimize_batch then falls back to one host thread per window).
+ * trace (may be NULL): [B][trace_cap][trace_stride] doubles, the rows of sdvgn_ef_optimize's trace per window.  Per window the results are
+ * those of its own sdvgn_ef_optimize call, bit for bit (FullSystemOptimize.cpp:344-458). */
+int sdvgn_ef_optimize_lockstep(sdvgn_ef* const* handles, int B, int mnumOptIts, int flags, int* its_out, double* trace, int trace_stride,
+                               int trace_cap);
 /* Arithmetic of k_ef_linearize (PointFrameResidual::linearize, Residuals.cpp:60-224): 0 = the reference's float arithmetic operation by
  * operation (default: IEEE divisions / square roots, no contraction; J, energies and residual states bit-identical with the CPU path),
  * 1 = tolerance mode: fused multiply-adds and the hardware's 1-ulp reciprocal / square root (v_rcp_f32, v_sqrt_f32) for the 34 divisions and

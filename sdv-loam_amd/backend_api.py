@@ -58,6 +58,7 @@ PROTOTYPES = [
     ("sdvgn_ef_set_collective_buffer", C.c_int, [vp, vp, C.c_int]),
     ("sdvgn_ef_collective_count", C.c_ulonglong, [vp]),
     ("sdvgn_ef_optimize_batch", C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
+    ("sdvgn_ef_optimize_lockstep", C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int]),
     ("sdvgn_ef_frame_image_dev", vp, [vp, C.c_int]),
     ("sdvgn_rccl_unique_id", C.c_int, [vp]),
     ("sdvgn_ef_init_rccl", C.c_int, [vp, vp, C.c_int, C.c_int]),
@@ -361,3 +362,20 @@ def optimize_batch(windows, its=6, fixed_its=False):
     out = (C.c_int * B)()
     check(windows[0].L.sdvgn_ef_optimize_batch(C.cast(arr, vp), B, int(its), 1 if fixed_its else 0, C.cast(out, vp)))
     return list(out)
+
+
+def optimize_lockstep(windows, its=6, fixed_its=False, want_trace=True, cap=128):
+    """sdvgn_ef_optimize_lockstep: the B loops as ONE launch sequence (csrc/backend_lockstep.inc).  Returns (bodies per window, traces) --
+    traces[b] has the rows of EnergyFunctional.optimize's trace for window b (None without want_trace)."""
+    from .api import check
+    B = len(windows)
+    arr = (vp * B)(*[w.h_ for w in windows])
+    out = (C.c_int * B)()
+    stride = 8 + max(w.dim for w in windows)
+    trace = np.zeros((B, cap, stride)) if want_trace else None
+    check(windows[0].L.sdvgn_ef_optimize_lockstep(C.cast(arr, vp), B, int(its), 1 if fixed_its else 0, C.cast(out, vp),
+                                                   trace.ctypes.data_as(vp) if want_trace else None, stride, cap))
+    its_out = list(out)
+    if not want_trace:
+        return its_out, None
+    return its_out, [trace[b, :its_out[b], :8 + windows[b].dim] for b in range(B)]

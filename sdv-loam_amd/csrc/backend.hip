@@ -130,7 +130,6 @@ struct sdvgn_ef {
     int seq_spec = 0;                      // tags of the speculative solves are kSpecTag | seq_spec: disjoint from the main solves' (seq_solve)
     hipStream_t side = nullptr;            // the device's shared side stream (not owned)
     int spec_last_buf = -1, spec_last_seq = 0;   // the speculative solve launched last (may still be running)
-    bool spec_last_has_th = false;         // ... and whether the trial's thresholds were selected beside it
     bool reduce_pending = false;           // the accumulate queued ahead of the verdict has run without its reduce (launched with the solve, accepted case only)
     SolvePieces* pieces_dev = nullptr;     // [SDVGN_MAX_FRAMES]: per-host shares of HA / bA / Hsc / bsc
     unsigned long long* solve_stamps = nullptr;   // pinned, 16 words: SDVGN_DEBUG_FLAGS bit6 only (phase stamps of the solve workgroup)
@@ -695,11 +694,11 @@ __global__ void k_ef_reset_oob(size_t slots, EFArrays A, const uint8_t* __restri
 
 // per-block partial sums of calcLEnergyPt (EnergyFunctional.cpp:297-331); only launched when some residual is linearised
 // or some point has deltaF != 0 (otherwise the sum is exactly 0)
-__global__ void __launch_bounds__(256) k_ef_point_stats(EFConst Cin, EFArrays A, const PrecalcDev* __restrict__ precalc,
-                                                       const int* __restrict__ phost, double* __restrict__ partial) {
+__device__ __forceinline__ void point_stats_body(const EFConst& Cin, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
+                                                 const int* __restrict__ phost, double* __restrict__ partial, const int b) {
     const EFConst C = ef_const(Cin, A);
     __shared__ double sh[4];
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = b * 256 + threadIdx.x;
     double e = 0;
     if (p < C.nP) {
         const int h = phost[p];
@@ -727,7 +726,11 @@ __global__ void __launch_bounds__(256) k_ef_point_stats(EFConst Cin, EFArrays A,
     e = wave_sum_double(e);
     if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = e;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (threadIdx.x == 0) partial[b] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ void __launch_bounds__(256) k_ef_point_stats(EFConst Cin, EFArrays A, const PrecalcDev* __restrict__ precalc,
+                                                       const int* __restrict__ phost, double* __restrict__ partial) {
+    point_stats_body(Cin, A, precalc, phost, partial, (int)blockIdx.x);
 }
 // out[0] = sum energy partials, out[1] = sum L partials (nL may be 0), out[2], out[3] = sums of the two halves of the
 // resubstitute partials (step^2, |idepth_backup|): one workgroup instead of four tiny launches
@@ -1797,8 +1800,27 @@ static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_st
     e->sys_on_device = true; e->sys_fetched = false; e->sys_valid = true;
     return SDVGN_OK;
 }
+constexpr unsigned kSpecTagForDump = 0x40000000u;
 static inline bool ef_wait_error(const sdvgn_ef* e) {   // a workgroup gave up an intra-launch wait (EFArrays::err): the window is not trustworthy
     return e->stats_host && *reinterpret_cast<volatile const unsigned*>(e->stats_host + 6) != 0;
+}
+// an internal consistency check failed: the call returns SDVGN_E_STATE -- and says which one on stderr (these cannot happen in a correct build;
+// a bare error code from a 300-line loop would be all a bug report had)
+static int ef_state_failure(const sdvgn_ef* e, const char* what, double a = 0, double b = 0) {
+    fprintf(stderr, "[sdvgn] internal check failed: %s (%.17g vs %.17g; error word %u)\n", what, a, b,
+            e->stats_host ? *reinterpret_cast<volatile const unsigned*>(e->stats_host + 6) : 0u);
+    // the hand-off words as they are now (the launches in flight are drained first)
+    hipDeviceSynchronize();
+    unsigned long long tri = 0, thw[2] = {0, 0}, xs[2] = {0, 0}; unsigned ver = 0;
+    if (e->xw_dev) hipMemcpy(&tri, e->xw_dev + 498, 8, hipMemcpyDeviceToHost);
+    if (e->accept_dev) hipMemcpy(&ver, e->accept_dev + 4, 4, hipMemcpyDeviceToHost);
+    for (int q = 0; q < 2 && e->xw_spec; ++q) { hipMemcpy(&thw[q], e->xw_spec + q * 512 + 500, 8, hipMemcpyDeviceToHost); hipMemcpy(&xs[q], e->xw_spec + q * 512, 8, hipMemcpyDeviceToHost); }
+    fprintf(stderr, "[sdvgn]   seq_solve %d seq_spec %d (tag %#x) seq_verdict %u | spec_last buf %d seq %#x | flags solve %d spec %d %d stats %d (seq_stats %d)\n"
+                    "[sdvgn]   device words: tri_ready tag %u | verdict %u (seq %u) | spec x[0] tags %#x %#x | spec th[0] tags %#x %#x\n",
+            e->seq_solve, e->seq_spec, kSpecTagForDump | (unsigned)e->seq_spec, e->seq_verdict, e->spec_last_buf, (unsigned)e->spec_last_seq,
+            e->flags_host[3], e->flags_host[5], e->flags_host[6], e->flags_host[2], e->seq_stats,
+            (unsigned)(tri >> 32), ver, ver >> 1, (unsigned)(xs[0] >> 32), (unsigned)(xs[1] >> 32), (unsigned)(thw[0] >> 32), (unsigned)(thw[1] >> 32));
+    return SDVGN_E_STATE;
 }
 // ---- the rejected case, solved ahead ------------------------------------------------------------------------------------------------
 // After a rejected step the reference restores the state and solves the SAME normal equations again with 100 x the damping
@@ -1811,12 +1833,11 @@ static inline bool ef_wait_error(const sdvgn_ef* e) {   // a workgroup gave up a
 // profiles/r04_notes.txt): the side launch polls the main solve's tagged x words before it reads the system, and publishes its own results
 // as tagged words the next body's workgroups poll.
 constexpr unsigned kSpecTag = 0x40000000u;
-// with_select: a second workgroup of the same launch takes setNewFrameEnergyTH of the trial linearisation this body is about to run -- it waits for
-// that trial's accept test (verdict number verdict_seq), then selects and leaves the thresholds as tagged words beside the speculative solution:
-// after a rejection the re-classification (which must precede the next linearise) finds them there instead of behind a select of ~7 us in
-// its own launch.  (After an accepted step the thresholds come from the select that rides in the next body's factorisation launch, as before.)
-static int ef_launch_spec_solve(sdvgn_ef* e, int iteration_next, double lambda_next, bool main_solve_in_flight, bool with_select = false,
-                                unsigned verdict_seq = 0) {
+// The ONLY wait of the side-stream launch is for something the main stream was handed EARLIER (the solve whose system this one re-uses), and
+// the host makes sure this launch is through before it queues anything that polls its words (ef_launch_spec_rest).  An earlier form of this
+// round also selected the trial's thresholds on the side stream, waiting there for the body's accept test: 1 to 3 of 10 passes of the GPU
+// suite ended with that wait given up -- the side stream is not always served while the main stream runs (profiles/r04_fault_hunt.txt).
+static int ef_launch_spec_solve(sdvgn_ef* e, int iteration_next, double lambda_next, bool main_solve_in_flight) {
     const int buf = (e->seq_spec + 1) & 1;
     SolveIO io;
     std::memset(&io, 0, sizeof(io));
@@ -1824,7 +1845,7 @@ static int ef_launch_spec_solve(sdvgn_ef* e, int iteration_next, double lambda_n
     io.rx = e->rx_spec; io.out = e->sol_spec + buf;
     io.done_flag = e->flags_host + 5 + buf; io.done_seq = (int)(kSpecTag | (unsigned)(++e->seq_spec));
     io.xw = e->xw_spec + (size_t)buf * 512;
-    io.err_word = nullptr;                             // a wait that gives up here fails nothing by itself: the host notices when (if) it needs the result
+    io.err_word = e->stats_host ? (unsigned*)(e->stats_host + 6) : nullptr;   // (a wait that gives up -- ~1 s -- fails the call in flight, used or not)
     io.lambda = lambda_next; io.iteration = iteration_next; io.do_step = 0; io.reuse = 1; io.stepsize = 0.0f;
     io.stamps = nullptr;
     io.spec = 1;
@@ -1832,19 +1853,11 @@ static int ef_launch_spec_solve(sdvgn_ef* e, int iteration_next, double lambda_n
     // then the system has not changed since an earlier body)
     io.wait_xw = main_solve_in_flight ? e->xw_dev + 498 : nullptr; io.wait_seq = (unsigned)e->seq_solve;
     const ReclArgs no_rc{};
-    SelArgs sel{};
-    if (with_select) {
-        sel.nF = e->nF; sel.nP = e->nP;
-        ef_owned_points(e, sel.own0, sel.own1);
-        sel.rflags = e->rflags; sel.wo = e->A.renergy_wo; sel.th_prev = e->A.frameTH_r; sel.th_out = nullptr;      // (tagged words only: nothing on the main stream is ordered behind this launch)
-        sel.log_slot = e->th_log ? e->th_log + (e->th_log_n % kThLog) : nullptr;     // the slot this trial's select logs to (linearize_launch_stats takes the same one)
-        sel.wait_verdict = (const unsigned*)(e->accept_dev + 4); sel.wait_seq = verdict_seq;
-    }
-    k_ef_tail_resub<<<with_select ? 2 : 1, kSolveLanes, 0, e->side>>>(io, no_rc, 0, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial, -1.0f,
-                                                                     e->pid_alt, e->pidz_alt, e->pdeltaF_alt, 0, 0, 0, sel, with_select ? 1 : -1,
-                                                                     with_select ? io.xw + 500 : nullptr);
+    const SelArgs no_sel{};
+    k_ef_tail_resub<<<1, kSolveLanes, 0, e->side>>>(io, no_rc, 0, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial, -1.0f,
+                                                   e->pid_alt, e->pidz_alt, e->pdeltaF_alt, 0, 0, 0, no_sel, -1, nullptr);
     HIPCHK(hipGetLastError());
-    e->spec_last_buf = buf; e->spec_last_seq = io.done_seq; e->spec_last_has_th = with_select;
+    e->spec_last_buf = buf; e->spec_last_seq = io.done_seq;
     return SDVGN_OK;
 }
 // before the main stream gets a launch that REWRITES the system (a solve that stitches anew): the speculative solve launched last must be
@@ -1865,10 +1878,8 @@ static int ef_launch_spec_rest(sdvgn_ef* e, int iteration, double lambda, float 
     io.rx = e->rx_spec;
     io.xw = e->xw_spec + (size_t)e->spec_last_buf * 512;
     io.done_seq = e->spec_last_seq;                     // the tag the polls wait for (and, being unique, the tag of this launch's threshold words)
-    // the rejected trial's thresholds: selected beside the speculative solve (tagged words behind its solution) -- the pending select is then
-    // dropped: only the re-classification of this launch ever reads that trial's thresholds
-    const bool th_ahead = e->spec_last_has_th && e->pend_rc_valid && e->pend_sel_valid && e->pend_rc.th == e->pend_sel.th_out;
-    if (th_ahead) e->pend_sel_valid = false;
+    // the speculative solve is through (normally since a whole linearise): nothing queued below ever waits for the side stream on the device
+    HIPCHK(wait_flag(e->flags_host + 5 + e->spec_last_buf, e->spec_last_seq, e->side));
     const int has_rc = e->pend_rc_valid ? 1 : 0, has_sel = e->pend_sel_valid ? 1 : 0;
     const int nblk = (e->nP + 63) / 64;
     const int rest = (nblk + 1) / 2 + (io.en_em_trial ? 2 : 1);
@@ -1876,7 +1887,6 @@ static int ef_launch_spec_rest(sdvgn_ef* e, int iteration, double lambda, float 
     ReclArgs rcl = e->pend_rc;
     unsigned long long* thw = has_sel ? e->xw_dev + 500 : nullptr;
     if (has_sel && has_rc && rcl.th == sel.th_out) { rcl.thw = thw; rcl.thseq = (unsigned)io.done_seq; }
-    if (th_ahead) { rcl.thw = io.xw + 500; rcl.thseq = (unsigned)io.done_seq; }
     // the re-classification in ONE pass (one slot per lane): beside the factorisation four workgroups walking ~8 slots per lane were hidden,
     // here they would be the launch's duration (measured: 19 us for resubstitute + step with them, profiles/r04_notes.txt)
     const int n_recl = has_rc ? (rcl.nP + rcl.np_last * (rcl.nF - 1) + kSolveLanes - 1) / kSolveLanes : 0;
@@ -1891,7 +1901,7 @@ static int ef_launch_spec_rest(sdvgn_ef* e, int iteration, double lambda, float 
 }
 static int ef_wait_spec_solve(sdvgn_ef* e, int buf, int seq, double* x_out) {
     HIPCHK(wait_flag(e->flags_host + 5 + buf, seq, e->side));
-    if (ef_wait_error(e)) return SDVGN_E_STATE;
+    if (ef_wait_error(e)) return ef_state_failure(e, "a workgroup gave up an intra-launch wait (solve ahead)");
     const int n = CPARS + 6 * e->nF;
     const SolveOut& o = e->sol_spec[buf];
     e->lastX.assign(o.x, o.x + n);
@@ -1902,7 +1912,7 @@ static int ef_wait_spec_solve(sdvgn_ef* e, int buf, int seq, double* x_out) {
 
 static int ef_wait_solve(sdvgn_ef* e, double* x_out) {
     HIPCHK(wait_flag(e->flags_host + 3, e->seq_solve, e->stream));
-    if (ef_wait_error(e)) return SDVGN_E_STATE;
+    if (ef_wait_error(e)) return ef_state_failure(e, "a workgroup gave up an intra-launch wait (solve)");
     const int n = CPARS + 6 * e->nF;
     e->lastX.assign(e->sol_host->x, e->sol_host->x + n);
     e->resInA = e->sol_host->resInA;
@@ -2043,7 +2053,7 @@ static int linearize_launch(sdvgn_ef* e, bool defer_select = false) {
 }
 static int linearize_wait(sdvgn_ef* e, double* energy, double* EL, double* sumID, double* sumNID) {
     HIPCHK(wait_flag(e->flags_host + 2, e->seq_stats, e->stream));
-    if (ef_wait_error(e)) return SDVGN_E_STATE;
+    if (ef_wait_error(e)) return ef_state_failure(e, "a workgroup gave up an intra-launch wait (statistics)");
     *energy = e->stats_host[0];
     const double En = host_prior_energy(e);   // calcLEnergyF_MT: frame + calib priors on the host, point part from the device
     *EL = En + (double)(float)e->stats_host[1];
@@ -2207,8 +2217,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         // beside it the threshold select of the trial that is about to be linearised (it waits for that trial's accept test)
         spec_pending = false;
         if (spec_enabled && !zero_differs && e->sys_valid && iteration + 1 < mnumOptIts) {
-            if ((rc = ef_launch_spec_solve(e, iteration + 1, lambda * 1e2, /*main_solve_in_flight=*/!from_spec, /*with_select=*/true,
-                                           (unsigned)(e->seq_verdict + 1) & 0x7fffffffu))) return rc;
+            if ((rc = ef_launch_spec_solve(e, iteration + 1, lambda * 1e2, /*main_solve_in_flight=*/!from_spec))) return rc;
             spec_pending = true;
         }
         // device-side accept test: the statistics launch waits for the host's parts of the comparison (after the mirror below), the
@@ -2230,7 +2239,9 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             dec.En = dec.EM = 0; dec.en_em = e->en_em_dev + 2 * st_trial;
             dec.rhs = lastEnergy + lastEnergyL + lastEnergyM; dec.accept_dev = e->accept_dev; dec.on = 1;
             dec.verdict = (unsigned*)(e->accept_dev + 4); dec.seq = (unsigned)(++e->seq_verdict) & 0x7fffffffu;
-            if ((rc = linearize_launch_stats(e, defer, &dec, /*final_body=*/iteration + 1 == mnumOptIts))) return rc;
+            // (with the rejected case solved ahead the trial's thresholds are selected in this launch too, like in the loop's last body: after a
+            // rejection the re-classification -- which must precede the next linearise -- finds them in memory, not behind a select of ~7 us)
+            if ((rc = linearize_launch_stats(e, defer, &dec, /*final_body=*/iteration + 1 == mnumOptIts || spec_pending))) return rc;
         }
         g_pt.stop(PT_ACCUM);
         // x is in pinned memory as soon as the solve kernel is through: mirror doStepFromBackup on the host (FrameHessian::setState,
@@ -2275,7 +2286,8 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         if (dev_decide) {
             // the device formed the state's parts of the energies itself (stats_host[5], [7]); the host's mirror must give the same doubles -- the
             // same IEEE operations in the same order on the same numbers (cannot differ; if it ever does, the call fails instead of drifting)
-            if (e->stats_host[5] != En_host || e->stats_host[7] != newEnergyM) return SDVGN_E_STATE;
+            if (e->stats_host[5] != En_host) return ef_state_failure(e, "prior energy of the stepped state: device vs host mirror", e->stats_host[5], En_host);
+            if (e->stats_host[7] != newEnergyM) return ef_state_failure(e, "M energy of the stepped state: device vs host mirror", e->stats_host[7], newEnergyM);
             newEnergyL = e->stats_host[5] + (double)(float)e->stats_host[1];
             newEnergyM = e->stats_host[7];
         }
@@ -2285,7 +2297,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         const bool canbreak = sqrtf(sumR) < 0.00005 * thOpt && sqrtf(sumT) * sumNID < 0.00005 * thOpt;
         const bool accept_host = newEnergy + newEnergyL + newEnergyM < lastEnergy + lastEnergyL + lastEnergyM;
         const bool accept = dev_decide ? (e->stats_host[4] != 0.0) : accept_host;
-        if (dev_decide && accept != accept_host) return SDVGN_E_STATE;   // the same IEEE operations on the same numbers: cannot happen
+        if (dev_decide && accept != accept_host) return ef_state_failure(e, "accept test: device vs host", accept, accept_host);   // the same IEEE operations on the same numbers: cannot happen
         if (trace && iteration < trace_cap) {
             double* tr = trace + (size_t)iteration * trace_stride;
             tr[0] = iteration; tr[1] = lambda; tr[2] = accept; tr[3] = newEnergy; tr[4] = newEnergyL; tr[5] = newEnergyM; tr[6] = canbreak;
@@ -2387,7 +2399,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     if ((rc = ef_drain_spec(e))) return rc;                                    // (normally one read of pinned memory: the last side-stream solve is through)
     ef_flush_pending(e);
     HIPCHK(hipGetLastError());
-    if (ef_wait_error(e)) return SDVGN_E_STATE;
+    if (ef_wait_error(e)) return ef_state_failure(e, "a workgroup gave up an intra-launch wait (end of the loop)");
     loop_guard.ok = true;
     if (host_restore_pending) {   // the loop ended on a rejected step: loadSateBackup for the host mirror
         calib_set_value(e, e->value_backup);
@@ -2451,12 +2463,34 @@ struct BatchPool {
 static BatchPool& batch_pool() { static BatchPool* p = new BatchPool(); return *p; }   // (leaked on purpose: no join at library unload)
 }  // namespace
 
+#include "backend_lockstep.inc"
+
+static bool lock_batch_ok(sdvgn_ef* const* handles, int B, int flags) {
+    for (int b = 0; b < B; ++b) if (!lock_eligible(handles[b], flags) || handles[b]->device != handles[0]->device || handles[b]->arith != handles[0]->arith) return false;
+    return true;
+}
+int sdvgn_ef_optimize_lockstep(sdvgn_ef* const* handles, int B, int mnumOptIts, int flags, int* its_out, double* trace, int trace_stride, int trace_cap) {
+    if (!handles || B < 1 || B > 256 || mnumOptIts < 0) return SDVGN_E_ARG;
+    for (int b = 0; b < B; ++b) {
+        if (!handles[b]) return SDVGN_E_ARG;
+        for (int c = 0; c < b; ++c) if (handles[c] == handles[b]) return SDVGN_E_ARG;
+    }
+    if (trace && (trace_stride < 7 || trace_cap < 1)) return SDVGN_E_ARG;
+    if (!lock_batch_ok(handles, B, flags)) return SDVGN_E_ARG;
+    return ef_optimize_lockstep(handles, B, mnumOptIts, flags, its_out, trace, trace_stride, trace ? trace_cap : 0);
+}
+
 int sdvgn_ef_optimize_batch(sdvgn_ef* const* handles, int B, int mnumOptIts, int flags, int* its_out) {
     if (!handles || B < 1 || B > 256) return SDVGN_E_ARG;
     for (int b = 0; b < B; ++b) {
         if (!handles[b]) return SDVGN_E_ARG;
         for (int c = 0; c < b; ++c) if (handles[c] == handles[b]) return SDVGN_E_ARG;   // a handle is single-threaded
     }
+    // the default: ONE launch sequence for all B windows (backend_lockstep.inc); windows it does not take (and SDVGN_BATCH_THREADS=1, the A/B
+    // switch of the benchmark) run as B sdvgn_ef_optimize calls on B host threads, below
+    const bool force_threads = getenv("SDVGN_BATCH_THREADS") != nullptr;
+    if (B > 1 && !force_threads && mnumOptIts >= 0 && lock_batch_ok(handles, B, flags))
+        return ef_optimize_lockstep(handles, B, mnumOptIts, flags, its_out, nullptr, 0, 0);
     // sharded windows issue collectives on their communicator: several of them side by side would enqueue ncclAllReduce calls from several
     // threads / streams in an order the other ranks do not share -- one at a time (plain sdvgn_ef_optimize), never as a batch
     for (int b = 0; b < B && B > 1; ++b) if (ef_sharded(handles[b])) return SDVGN_E_ARG;

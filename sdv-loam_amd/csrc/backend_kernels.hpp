@@ -934,17 +934,17 @@ __global__ void __launch_bounds__(256) k_ef_sc_gram(EFConst C, EFArrays A, const
 // skip_on_reject: the solution of the rejected case was computed ahead on the side stream (ef_launch_spec_solve, backend.hip), so a "rejected"
 // verdict means this accumulate has no reader -- the planes it would rewrite already hold the kept state's values: every workgroup returns at once
 struct AccAlt { const int* verdict; const float* pid; const float* pidz; const float* pdeltaF; const CalibDev* calib; const PrecalcDev* precalc; int skip_on_reject; };
-__global__ void __launch_bounds__(256) k_ef_acc_fused(const PrecalcDev* __restrict__ precalc, EFConst Cin, EFArrays A,
-                                                      const int* __restrict__ phost, float* __restrict__ top_partial,
-                                                      int* __restrict__ nres_partial, int top_chunks, float* __restrict__ sc_partial,
-                                                      int sc_chunks, int n_sc, AccAlt alt) {
+// (body for workgroup b of the launch: k_ef_acc_fused launches it for one window, k_lock_acc -- backend_lockstep.inc -- for B windows in one grid)
+__device__ __forceinline__ void acc_fused_body(const PrecalcDev* __restrict__ precalc, const EFConst& Cin, EFArrays A,
+                                               const int* __restrict__ phost, float* __restrict__ top_partial,
+                                               int* __restrict__ nres_partial, int top_chunks, float* __restrict__ sc_partial,
+                                               int sc_chunks, int n_sc, const AccAlt& alt, const int b) {
     const PrecalcDev* __restrict__ ranges = precalc;   // point ranges / shard flags are the same in both tables: read them without waiting for the verdict
     // the verdict word is FETCHED here and LOOKED AT where the state-dependent inputs are first needed: tested at once it heads the chain
     // verdict -> point range -> flags -> values of every Schur workgroup with a round trip of its own
     const int vd = alt.verdict ? *alt.verdict : 1;
     if (alt.skip_on_reject && vd == 0) return;   // (uniform over the grid: before any barrier)
     __shared__ union U { TopGramSmem t; PointSmem p; ScGramSmem s; __device__ U() {} } S;
-    const int b = blockIdx.x;
     if (b < n_sc) {
         const int h = b / sc_chunks, bx = b - h * sc_chunks;
         const int2 rg = *reinterpret_cast<const int2*>(&ranges[h * Cin.nF + h].P0);   // {P0, np} in one load; np == 0 outside this rank's shard
@@ -980,6 +980,12 @@ __global__ void __launch_bounds__(256) k_ef_acc_fused(const PrecalcDev* __restri
         const int q = b - n_sc;
         top_gram_body(C, A, precalc, top_partial, nres_partial, q % top_chunks, q / top_chunks, top_chunks, S.t, nullptr, ranges);
     }
+}
+__global__ void __launch_bounds__(256) k_ef_acc_fused(const PrecalcDev* __restrict__ precalc, EFConst Cin, EFArrays A,
+                                                      const int* __restrict__ phost, float* __restrict__ top_partial,
+                                                      int* __restrict__ nres_partial, int top_chunks, float* __restrict__ sc_partial,
+                                                      int sc_chunks, int n_sc, AccAlt alt) {
+    acc_fused_body(precalc, Cin, A, phost, top_partial, nres_partial, top_chunks, sc_partial, sc_chunks, n_sc, alt, (int)blockIdx.x);
 }
 
 // ---- marginalizePointsF (EnergyFunctional.cpp:514-549): the same three bodies in MODE 2 over the points flagged by `mask` ----
@@ -1055,14 +1061,11 @@ __device__ __forceinline__ int sc_packed_index(int a, int b) { return a * 53 - (
 
 constexpr int kScTasksPerHost = 10 * 16 * 4 * 4;   // 2560
 static inline int acc_reduce_grid(int pairs, int nF) { return (nF * kScTasksPerHost) / 256 + (pairs * 33 + 255) / 256 + 1; }
-__global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__ top_partial, int pairs, int top_chunks,
-                                                       const float* __restrict__ sc_partial, int nF, int sc_chunks,
-                                                       const int* __restrict__ nres_partial, double* __restrict__ out,
-                                                       const int* __restrict__ skip_verdict = nullptr /* non-NULL: return at once when it reads 0 (AccAlt::skip_on_reject) */) {
-    if (skip_verdict && *skip_verdict == 0) return;
+__device__ __forceinline__ void acc_reduce_body(const float* __restrict__ top_partial, int pairs, int top_chunks,
+                                                const float* __restrict__ sc_partial, int nF, int sc_chunks,
+                                                const int* __restrict__ nres_partial, double* __restrict__ out, const int b) {
     const int ntop = pairs * 121, nsc = nF * 1431;
     const int nb_sc = (nF * kScTasksPerHost) / 256, nb_top = (pairs * 33 + 255) / 256;
-    const int b = blockIdx.x;
     if (b < nb_sc) {
         const int u = b * 256 + threadIdx.x;
         const int h = u / kScTasksPerHost, uu = u - h * kScTasksPerHost;      // wave-uniform: 2560 % 256 == 0
@@ -1109,6 +1112,13 @@ __global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__
         __syncthreads();
         if (threadIdx.x == 0) out[ntop + nsc] = (double)(part[0] + part[1] + part[2] + part[3]);
     }
+}
+__global__ void __launch_bounds__(256) k_ef_acc_reduce(const float* __restrict__ top_partial, int pairs, int top_chunks,
+                                                       const float* __restrict__ sc_partial, int nF, int sc_chunks,
+                                                       const int* __restrict__ nres_partial, double* __restrict__ out,
+                                                       const int* __restrict__ skip_verdict = nullptr /* non-NULL: return at once when it reads 0 (AccAlt::skip_on_reject) */) {
+    if (skip_verdict && *skip_verdict == 0) return;
+    acc_reduce_body(top_partial, pairs, top_chunks, sc_partial, nF, sc_chunks, nres_partial, out, (int)blockIdx.x);
 }
 
 // resubstituteFPt (EnergyFunctional.cpp:250-282): workgroup = 64 points x 8 waves; wave t forms xAd[h,t] . JpJdF of the
@@ -1254,23 +1264,15 @@ __device__ __forceinline__ unsigned wave_sum_dpp_u32(unsigned v) {
 __device__ __forceinline__ unsigned wave_scan_dpp_u32(unsigned v) { return wave_sum_dpp_u32(v); }   // the sum IS built as an inclusive scan
 struct SelectSmem { unsigned hist[2 * kSelLanes]; unsigned wsum[kSelLanes / 64]; unsigned sel[2]; };
 // own0/own1: the point range [own0, own1) hosted by this rank's key-frames (the planes of other points are not written here)
-// COH: the planes were written by a kernel of ANOTHER stream with no kernel boundary in between (the side-stream select of a trial
-// linearisation, backend.hip): device-scope loads instead of loads this XCD's L2 may answer from a stale line
-template <bool COH> __device__ __forceinline__ uint8_t sel_load_u8(const uint8_t* p) {
-    return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-template <bool COH> __device__ __forceinline__ float sel_load_f32(const float* p) {
-    return COH ? __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : *p;
-}
-template <int SRC, bool COH = false>
+template <int SRC>
 __device__ __forceinline__ unsigned sel_key(int p, int nF, int nP, int own0, int own1, const uint8_t* __restrict__ rflags,
                                              const float* __restrict__ wo, const double* __restrict__ cand) {
     if (p >= nP) return 0xFFFFFFFFu;
     float v;
     if (SRC == 0) {
         const size_t s = (size_t)(nF - 1) * nP + p;
-        const uint8_t fl = sel_load_u8<COH>(rflags + s);
-        v = sel_load_f32<COH>(wo + s);
+        const uint8_t fl = rflags[s];
+        v = wo[s];
         if (!(fl & RF_EXISTS) || (fl & RF_LINEARIZED) || p < own0 || p >= own1) return 0xFFFFFFFFu;
     } else {
         const double c = cand[p];
@@ -1282,7 +1284,7 @@ __device__ __forceinline__ unsigned sel_key(int p, int nF, int nP, int own0, int
 }
 
 // body for one workgroup of kSelLanes lanes
-template <int SRC, bool COH = false>
+template <int SRC>
 __device__ __forceinline__ void select_th_body(int nF, int nP, int own0, int own1, const uint8_t* __restrict__ rflags, const float* __restrict__ wo,
                                                const double* __restrict__ cand, const float* __restrict__ th_prev, float* __restrict__ th_out,
                                                float* __restrict__ log_slot, SelectSmem& S,
@@ -1297,7 +1299,7 @@ __device__ __forceinline__ void select_th_body(int nF, int nP, int own0, int own
 #pragma unroll
         for (int i = 0; i < kSelVPT; ++i) {
             const int p = min(tid + i * kSelLanes, nP - 1);
-            if (SRC == 0) { const size_t s = (size_t)(nF - 1) * nP + p; fl[i] = sel_load_u8<COH>(rflags + s); v[i] = sel_load_f32<COH>(wo + s); }
+            if (SRC == 0) { const size_t s = (size_t)(nF - 1) * nP + p; fl[i] = rflags[s]; v[i] = wo[s]; }
             else c[i] = cand[p];
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1328,7 +1330,7 @@ __device__ __forceinline__ void select_th_body(int nF, int nP, int own0, int own
         for (int i = 0; i < kSelVPT; ++i)
             if ((key[i] & pmask) == prefix) atomicAdd(&s_hist[(key[i] >> shift) & (nb - 1)], 1u);
         for (int p0 = p_tail; p0 < nP; p0 += kSelLanes) {   // windows beyond 16384 points: re-read (uniform trip count)
-            const unsigned k = sel_key<SRC, COH>(p0 + tid, nF, nP, own0, own1, rflags, wo, cand);
+            const unsigned k = sel_key<SRC>(p0 + tid, nF, nP, own0, own1, rflags, wo, cand);
             if ((k & pmask) == prefix) atomicAdd(&s_hist[(k >> shift) & (nb - 1)], 1u);
         }
         __syncthreads();
@@ -1364,7 +1366,7 @@ __device__ __forceinline__ void select_th_body(int nF, int nP, int own0, int own
         th *= 1.0f * 1.0f;                            // setting_overallEnergyTHWeight^2
     }
     if (tid == 0 && log_slot) *log_slot = th;
-    if (tid < nF - 1) { const float tp = sel_load_f32<COH>(th_prev + tid); if (th_out) th_out[tid] = tp; if (thw) store_tagged_u32(thw + tid, thseq, __float_as_uint(tp)); }
+    if (tid < nF - 1) { const float tp = th_prev[tid]; if (th_out) th_out[tid] = tp; if (thw) store_tagged_u32(thw + tid, thseq, __float_as_uint(tp)); }
     if (tid == 0) {
         if (th_out) th_out[nF - 1] = th;
         if (thw) store_tagged_u32(thw + nF - 1, thseq, __float_as_uint(th));
@@ -1372,10 +1374,7 @@ __device__ __forceinline__ void select_th_body(int nF, int nP, int own0, int own
 }
 
 // arguments of one pending setNewFrameEnergyTH (SRC 0) when it rides in another kernel's launch as an extra workgroup
-// wait_verdict (side-stream select only): the select first waits until the accept test of verdict number wait_seq has been published there --
-// the trial linearisation whose energies it reads is then complete -- and reads the planes with device-scope loads
-struct SelArgs { int nF, nP, own0, own1; const uint8_t* rflags; const float* wo; const float* th_prev; float* th_out; float* log_slot;
-                 const unsigned* wait_verdict; unsigned wait_seq; };
+struct SelArgs { int nF, nP, own0, own1; const uint8_t* rflags; const float* wo; const float* th_prev; float* th_out; float* log_slot; };
 
 template <int SRC>
 __global__ void __launch_bounds__(kSelLanes) k_ef_select_th(int nF, int nP, int own0, int own1, const uint8_t* __restrict__ rflags,

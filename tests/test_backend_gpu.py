@@ -599,10 +599,16 @@ def test_arith_mode_tolerance(api, orc):
     assert rel_err(Gf.state()[1], O.state()[1]) < 1e-3 and rel_err(Gf.state()[2], O.state()[2]) < 1e-4, (errs, rel_err(Gf.state()[1], O.state()[1]), rel_err(Gf.state()[2], O.state()[2]))
 
 
-def test_optimize_batch_side_by_side(api, orc):
-    """sdvgn_ef_optimize_batch: B independent windows, each on its own stream and host thread -- every window ends exactly where its own
-    sdvgn_ef_optimize call ends (bit for bit), whatever runs beside it."""
+@pytest.mark.parametrize("threads", [True, False])
+def test_optimize_batch_side_by_side(api, orc, threads, monkeypatch):
+    """sdvgn_ef_optimize_batch, both forms -- one launch sequence for all windows (the default, backend_lockstep.inc) and B windows on their own
+    streams and host threads (SDVGN_BATCH_THREADS=1) -- every window ends exactly where its own sdvgn_ef_optimize call ends (bit for bit),
+    whatever runs beside it."""
     from sdv_loam_amd import synthetic as syn
+    if threads:
+        monkeypatch.setenv("SDVGN_BATCH_THREADS", "1")
+    else:
+        monkeypatch.delenv("SDVGN_BATCH_THREADS", raising=False)
     Ws = [low_thresholds(syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=20 + k, calib=dict(fx=400., fy=410., cx=319.5, cy=119.5),
                                          state_sigma=1e-3, idepth_sigma=0.01)) for k in range(6)]
     solo = []
@@ -623,3 +629,87 @@ def test_optimize_batch_side_by_side(api, orc):
     import ctypes as C
     arr = (C.c_void_p * 2)(Gs[0].h_, Gs[0].h_)
     assert Gs[0].L.sdvgn_ef_optimize_batch(C.cast(arr, C.c_void_p), 2, 6, 0, None) < 0
+
+
+def _lock_windows(syn, kind):
+    cal = dict(fx=400., fy=410., cx=319.5, cy=119.5)
+    if kind == "mixed":      # different seeds AND different shapes in one call: 5 / 4 / 3 / 6 key-frames, 300 / 200 / 150 / 700 points per frame
+        specs = [dict(nF=5, pts_per_kf=300, seed=2), dict(nF=4, pts_per_kf=200, seed=3, state_sigma=1e-3, idepth_sigma=0.01),
+                 dict(nF=3, pts_per_kf=150, seed=4, state_sigma=1e-3, idepth_sigma=0.01), dict(nF=6, pts_per_kf=700, seed=5, state_sigma=1e-3, idepth_sigma=0.01),
+                 dict(nF=5, pts_per_kf=300, seed=3, state_sigma=1e-3, idepth_sigma=0.01)]
+    else:                    # the same shape, different data
+        specs = [dict(nF=5, pts_per_kf=300, seed=2)] + [dict(nF=5, pts_per_kf=300, seed=20 + k, state_sigma=1e-3, idepth_sigma=0.01) for k in range(7)]
+    return [low_thresholds(syn.make_window(w=640, h=240, calib=cal, **s)) for s in specs]
+
+
+def _same_window_result(A, B, solved=True):
+    for x, y in zip(A.state(), B.state()):
+        assert np.array_equal(x, y)
+    sa, sb = A.residual_state(), B.residual_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(A.frame_energy_th(), B.frame_energy_th())
+    if solved:                                   # (the per-point planes are the outputs of an accumulate: none has run in a call of zero bodies)
+        assert np.array_equal(A.points(), B.points())
+    assert A.accepted_steps() == B.accepted_steps()
+
+
+@pytest.mark.parametrize("kind,its,fixed", [("mixed", 12, True), ("mixed", 6, False), ("same", 6, True), ("same", 1, True), ("same", 0, True)])
+def test_lockstep_equals_own_optimize_call(api, orc, kind, its, fixed):
+    """sdvgn_ef_optimize_lockstep: B windows as ONE launch sequence, accept / reject, lambda and the choice of state copies per window in device
+    memory.  Every window must end where its own sdvgn_ef_optimize call ends, bit for bit -- trace rows (lambda, verdict, the three energies,
+    canbreak, x, the newest frame's threshold), final states, per-residual planes, point planes, thresholds, and what the next solve returns --
+    with rejected steps, consecutive rejections, a rejection in the last body, windows of different shapes, and loops that end early."""
+    from sdv_loam_amd import synthetic as syn
+    Ws = _lock_windows(syn, kind)
+    solo = [api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W) for W in Ws]
+    tr_solo = [G.optimize(its, fixed_its=fixed) for G in solo]
+    if kind == "mixed" and fixed:
+        rej = tr_solo[0][:, 2] == 0
+        assert rej.any() and (~rej).any() and (rej[:-1] & rej[1:]).any()
+    Gs = [api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W) for W in Ws]
+    n, tr = api.optimize_lockstep(Gs, its, fixed_its=fixed)
+    for b, (G, S) in enumerate(zip(Gs, solo)):
+        assert n[b] == len(tr_solo[b]), (b, n, [len(t) for t in tr_solo])
+        assert np.array_equal(tr[b], tr_solo[b]), (b, np.argwhere(tr[b] != tr_solo[b])[:8])
+        _same_window_result(G, S, solved=its > 0)
+    # the handles carry on like after a call of their own: the next solve, a second call (lock-step against single), the loop's tail
+    for G, S in zip(Gs, solo):
+        assert np.array_equal(G.solveSystemF(3, 0.1), S.solveSystemF(3, 0.1))
+    n2, tr2 = api.optimize_lockstep(Gs, 4, fixed_its=True)
+    for b, (G, S) in enumerate(zip(Gs, solo)):
+        assert np.array_equal(tr2[b], S.optimize(4, fixed_its=True)), b
+        _same_window_result(G, S)
+        ea, eb = G.optimize_finish(), S.optimize_finish()
+        assert ea[0] == eb[0] and all(np.array_equal(x, y) for x, y in zip(ea[1:], eb[1:]))
+
+
+def test_lockstep_full_size_and_batch_entry(api, orc):
+    """At the named window size (8 x 2000 points, 112 000 residuals): four windows through sdvgn_ef_optimize_batch -- which takes the lock-step
+    path for them -- against their own calls; and with linearised residuals in the window (the point part of calcLEnergy is not 0)."""
+    from sdv_loam_amd import synthetic as syn
+    Ws = [low_thresholds(syn.make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=k, calib=syn.KITTI00, state_sigma=1e-3, idepth_sigma=0.01)) for k in range(4)]
+    solo = [api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W) for W in Ws]
+    n_solo = [len(G.optimize(6, fixed_its=True)) for G in solo]
+    Gs = [api.EnergyFunctional(W.w, W.h, max_points=W.nP, stream=api.EnergyFunctional.STREAM_OWN).load(W) for W in Ws]
+    assert api.optimize_batch(Gs, 6, fixed_its=True) == n_solo
+    for G, S in zip(Gs, solo):
+        _same_window_result(G, S)
+    # the key-frame cycle in between: fix the linearisation of a third of the points, then optimise again
+    for G, S, W in zip(Gs, solo, Ws):
+        mask = (np.arange(W.nP) % 3 == 0).astype(np.uint8)
+        G.fixLinearization(mask); S.fixLinearization(mask)
+    n, tr = api.optimize_lockstep(Gs, 5, fixed_its=True)
+    for b, (G, S) in enumerate(zip(Gs, solo)):
+        assert np.array_equal(tr[b], S.optimize(5, fixed_its=True)), b
+        _same_window_result(G, S)
+
+
+def test_lockstep_refuses_what_it_does_not_take(api, orc, window):
+    import ctypes as C
+    G = api.EnergyFunctional(window.w, window.h, max_points=window.nP).load(window)
+    arr = (C.c_void_p * 2)(G.h_, G.h_)
+    assert G.L.sdvgn_ef_optimize_lockstep(C.cast(arr, C.c_void_p), 2, 6, 0, None, None, 0, 0) < 0        # a handle twice
+    arr1 = (C.c_void_p * 1)(G.h_)
+    assert G.L.sdvgn_ef_optimize_lockstep(C.cast(arr1, C.c_void_p), 1, 6, 2, None, None, 0, 0) < 0       # the literal re-linearisation: sdvgn_ef_optimize only
+    assert G.L.sdvgn_ef_optimize_lockstep(C.cast(arr1, C.c_void_p), 1, 6, 0, None, None, 0, 0) == 0
