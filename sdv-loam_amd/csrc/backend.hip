@@ -2239,9 +2239,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             dec.En = dec.EM = 0; dec.en_em = e->en_em_dev + 2 * st_trial;
             dec.rhs = lastEnergy + lastEnergyL + lastEnergyM; dec.accept_dev = e->accept_dev; dec.on = 1;
             dec.verdict = (unsigned*)(e->accept_dev + 4); dec.seq = (unsigned)(++e->seq_verdict) & 0x7fffffffu;
-            // (with the rejected case solved ahead the trial's thresholds are selected in this launch too, like in the loop's last body: after a
-            // rejection the re-classification -- which must precede the next linearise -- finds them in memory, not behind a select of ~7 us)
-            if ((rc = linearize_launch_stats(e, defer, &dec, /*final_body=*/iteration + 1 == mnumOptIts || spec_pending))) return rc;
+            if ((rc = linearize_launch_stats(e, defer, &dec, /*final_body=*/iteration + 1 == mnumOptIts))) return rc;
         }
         g_pt.stop(PT_ACCUM);
         // x is in pinned memory as soon as the solve kernel is through: mirror doStepFromBackup on the host (FrameHessian::setState,

@@ -1,8 +1,8 @@
-# A/B of the headline between library builds on one box: bash tools/ab_headline.sh tagA tagB ... (build/libsdvgn_<tag>.so), 3 alternating rounds
+# A/B of the headline between library builds on one box: bash tools/ab_headline.sh tagA tagB ... (tools/ab_libs/libsdvgn_<tag>.so), 3 alternating rounds
 cp sdv-loam_amd/libsdvgn.so /tmp/libsdvgn_keep.so
 for round in 1 2 3; do
   for tag in "$@"; do
-    cp build/libsdvgn_$tag.so sdv-loam_amd/libsdvgn.so
+    cp tools/ab_libs/libsdvgn_$tag.so sdv-loam_amd/libsdvgn.so
     timeout 200 python bench.py --no-cpu --quick 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
