@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-child-tracker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--lock-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -280,7 +281,23 @@ def trace_child():
     torch.cuda.synchronize()
 
 
-def measure_inloop_kernel(kernel="k_ef_linearize", timeout=240, arith=0):
+def lock_child(B):
+    """Body of the profiled child for the batched launch: B windows of the named size, one warm-up sdvgn_ef_optimize_lockstep call, then the two
+    that count (fresh windows each time)."""
+    import torch  # noqa: F401
+    from sdv_loam_amd import backend_api, synthetic as syn
+    Wh = syn.make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=syn.KITTI00, **HEAD_KW)
+    hs = [backend_api.EnergyFunctional(Wh.w, Wh.h, max_points=Wh.nP).load(Wh) for _ in range(B)]
+    for _ in range(3):
+        for h_ in hs:
+            h_.load(Wh)
+        torch.cuda.synchronize()
+        backend_api.optimize_lockstep(hs, 6, fixed_its=True, want_trace=False)
+    torch.cuda.synchronize()
+
+
+def measure_inloop_kernel(kernel="k_ef_linearize", timeout=240, arith=0, child=("--trace-child",), keep=(8, 9), summary="inloop_trace_summary_arith%d.txt",
+                          what="the headline protocol alone: 8 fresh windows x optimize(6); the untimed warm-up call and the window loads before it are not in the table"):
     """Duration of every launch of `kernel` inside the optimize loops of the headline protocol, from a rocprofv3 --kernel-trace of a child
     process that runs nothing but that protocol (HIP event pairs around single launches inside a loop read several us too long)."""
     import shutil
@@ -292,7 +309,7 @@ def measure_inloop_kernel(kernel="k_ef_linearize", timeout=240, arith=0):
         return None
     d = tempfile.mkdtemp(prefix="sdvgn_trace_", dir="/tmp")
     try:
-        subprocess.run([exe, "--kernel-trace", "-d", d, "-o", "tr", "--", sys.executable, os.path.abspath(__file__), "--trace-child"],
+        subprocess.run([exe, "--kernel-trace", "-d", d, "-o", "tr", "--", sys.executable, os.path.abspath(__file__)] + list(child),
                        cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", SDVGN_BENCH_ARITH=str(arith)), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                        timeout=timeout, check=True)
         dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
@@ -303,7 +320,7 @@ def measure_inloop_kernel(kernel="k_ef_linearize", timeout=240, arith=0):
             return None
         # the child runs one untimed warm-up call and then the 8 calls that count (trace_child): the statistics cover the launches of those 8
         # (the process's very first launches include code-object loading -- 0.1 ms once in a while -- and are warm-up in the bench proper too)
-        timed = lin[-(len(lin) * 8 // 9):] if len(lin) >= 9 else lin
+        timed = lin[-(len(lin) * keep[0] // keep[1]):] if len(lin) >= keep[1] else lin
         t_cut = timed[0][0]
         du = np.array([dur for (_, dur) in timed], np.float64) / 1e6
         try:   # the per-kernel summary of this trace as a file (gpurun_out/, copied to profiles/ by hand): what roofline.achieved is computed from
@@ -314,16 +331,15 @@ def measure_inloop_kernel(kernel="k_ef_linearize", timeout=240, arith=0):
             rows = sorted(((nm, len(v), float(np.mean(v)), float(np.sum(v)), float(np.min(v)), float(np.max(v))) for nm, v in agg.items()), key=lambda r: -r[3])
             tot = sum(r[3] for r in rows)
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", "inloop_trace_summary_arith%d.txt" % arith), "w") as fsum:
-                fsum.write("# rocprofv3 --kernel-trace -- python bench.py --trace-child   (SDVGN_BENCH_ARITH=%d; the headline protocol alone: 8 fresh windows x optimize(6); "
-                           "the untimed warm-up call and the window loads before it are not in the table)\n" % arith)
+            with open(os.path.join(ROOT, "gpurun_out", summary % arith if "%d" in summary else summary), "w") as fsum:
+                fsum.write("# rocprofv3 --kernel-trace -- python bench.py %s   (SDVGN_BENCH_ARITH=%d; %s)\n" % (" ".join(child), arith, what))
                 fsum.write("%-100s %8s %12s %10s %10s %10s %6s\n" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
                 for r in rows[:30]:
                     fsum.write("%-100s %8d %12.1f %10.3f %10.3f %10.3f %6.2f\n" % (r[0][:100], r[1], r[3] / 1e3, r[2] / 1e3, r[4] / 1e3, r[5] / 1e3, 100 * r[3] / tot))
         except Exception:  # noqa: BLE001
             pass
         return dict(mean_ms=float(du.mean()), median_ms=float(np.median(du)), p90_ms=float(np.percentile(du, 90)), launches=int(len(du)),
-                    source="rocprofv3 --kernel-trace of the protocol alone (8 windows x optimize(6); the untimed warm-up call before them excluded)")
+                    source="rocprofv3 --kernel-trace of a child process: " + what)
     except Exception as ex:  # noqa: BLE001
         return dict(error=repr(ex))
     finally:
@@ -788,6 +804,9 @@ def main():
     if args.trace_child:
         trace_child()
         return
+    if args.lock_child:
+        lock_child(args.lock_child)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` from a bare shell: launch the N ranks ourselves (one process per GPU over RCCL), the way the driver
         # does with torch.distributed.run; rank 0 of the children prints the JSON line, which passes through
@@ -911,30 +930,71 @@ def main():
     value_relin = value_reuse = value_nospec = soak = other = lin_inloop = None
     tol = batched = None
     if single and not args.quick:
-        # ---- B independent windows side by side (sdvgn_ef_optimize_batch: own stream + host thread per window): aggregate loop bodies / s.
-        # B x 80 MB of window data is live at once (B = 16: 1.3 GB, beyond the 256 MB Infinity Cache) ----
+        # ---- B independent windows in one call (sdvgn_ef_optimize_batch): the lock-step launch sequence (default, csrc/backend_lockstep.inc), the
+        # same calls one after the other (sdvgn_ef_optimize per window, same handles, same fresh windows), and -- at B = 8 -- the round-3 form
+        # (one host thread + stream per window, SDVGN_BATCH_THREADS=1).  B x 80 MB of window data is live at once (B = 16: 1.3 GB, beyond the
+        # 256 MB Infinity Cache) ----
         batched = {}
+
+        def time_calls(hs, fn, reps=6):
+            tt = 0.0
+            for r_ in range(reps + 1):
+                for h_ in hs:
+                    h_.load(Wh)
+                torch.cuda.synchronize()
+                t0b = time.perf_counter()
+                fn(hs)
+                torch.cuda.synchronize()
+                if r_:
+                    tt += time.perf_counter() - t0b
+            return tt / reps
+
+        def sequential(hs):
+            for h_ in hs:
+                h_.optimize(6, fixed_its=True, want_trace=False)
+
         for Bw in (2, 4, 8, 16):
             try:
-                hs = [backend_api.EnergyFunctional(Wh.w, Wh.h, max_points=Wh.nP, device=local, stream=backend_api.EnergyFunctional.STREAM_OWN).load(Wh)
-                      for _ in range(Bw)]
-                backend_api.optimize_batch(hs, 6, fixed_its=True)              # warm-up (queues, thread pool)
-                reps = 6
-                tt = 0.0
-                for _ in range(reps):
-                    for h_ in hs:
-                        h_.load(Wh)
-                    torch.cuda.synchronize()
-                    t0b = time.perf_counter()
-                    backend_api.optimize_batch(hs, 6, fixed_its=True)
-                    torch.cuda.synchronize()
-                    tt += time.perf_counter() - t0b
-                batched["B%d" % Bw] = dict(value=6 * Bw * reps / tt, unit="GN iters/s (aggregate)", ms_per_batch_call=1e3 * tt / reps)
+                hs = [backend_api.EnergyFunctional(Wh.w, Wh.h, max_points=Wh.nP, device=local).load(Wh) for _ in range(Bw)]
+                os.environ.pop("SDVGN_BATCH_THREADS", None)
+                t_lock = time_calls(hs, lambda hs_: backend_api.optimize_batch(hs_, 6, fixed_its=True))
+                t_seq = time_calls(hs, sequential)
+                row = dict(value=6 * Bw / t_lock, unit="GN iters/s (aggregate)", ms_per_batch_call=1e3 * t_lock,
+                           sequential_calls_value=6 * Bw / t_seq, speedup_vs_sequential_calls=t_seq / t_lock, speedup_vs_headline=6 * Bw / t_lock / value)
                 del hs
+                if Bw == 8:
+                    hs = [backend_api.EnergyFunctional(Wh.w, Wh.h, max_points=Wh.nP, device=local, stream=backend_api.EnergyFunctional.STREAM_OWN).load(Wh)
+                          for _ in range(Bw)]
+                    os.environ["SDVGN_BATCH_THREADS"] = "1"
+                    t_thr = time_calls(hs, lambda hs_: backend_api.optimize_batch(hs_, 6, fixed_its=True))
+                    os.environ.pop("SDVGN_BATCH_THREADS", None)
+                    row["host_thread_per_window_value"] = 6 * Bw / t_thr
+                    del hs
+                batched["B%d" % Bw] = row
             except Exception as ex:  # noqa: BLE001
+                os.environ.pop("SDVGN_BATCH_THREADS", None)
                 batched["B%d" % Bw] = dict(error=repr(ex))
-        batched["note"] = ("B fresh perturbed windows per call, optimize(6) each, all B calls issued together through sdvgn_ef_optimize_batch; "
-                           "compare with the headline value (the same calls one after the other)")
+        batched["note"] = ("B fresh perturbed windows per call, optimize(6) each (7 linearizeAll + 6 loop bodies per window).  value: ONE launch sequence for all "
+                           "B windows (sdvgn_ef_optimize_lockstep, the default of sdvgn_ef_optimize_batch): per window bit-identical to its own call "
+                           "(tests/test_backend_gpu.py::test_lockstep_*).  sequential_calls_value: the same handles and windows, sdvgn_ef_optimize one after "
+                           "the other, timed the same way; speedup_vs_headline divides by the headline value instead")
+        if rank == 0 and world == 1:
+            # the bandwidth kernel of the batched launch at B = 16 (1.3 GB of window data, beyond the Infinity Cache): duration from a kernel trace
+            # of a child that runs nothing else, HBM-side bytes from the PMC counters of the same child
+            Bt = 16
+            ltr = measure_inloop_kernel(kernel="k_lock_linearize", child=("--lock-child", str(Bt)), keep=(2, 3), summary="lockstep_trace_summary_B16.txt",
+                                        what="%d windows of the named size, sdvgn_ef_optimize_lockstep(6) x 3 calls, the first one untimed" % Bt)
+            alg_b = Bt * Wh.nR * LINEARIZE_BYTES_PER_RES
+            if ltr and "mean_ms" in ltr:
+                ach = alg_b / (ltr["mean_ms"] * 1e-3) / 1e9
+                tb_, how_ = measure_traffic(kernel="k_lock_linearize", child=("--lock-child", str(Bt)))
+                batched["roofline"] = dict(bound="hbm", kernel="k_lock_linearize (B = %d windows in one launch)" % Bt, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                                           frac=ach / HBM_PEAK_GBS, traffic=tb_, traffic_note=how_, traffic_over_algorithmic=(tb_ / alg_b) if tb_ else None,
+                                           in_loop_trace=ltr,
+                                           note="%d windows x %d residuals x %d B algorithmic = %.0f MB per launch; mean duration of the launches inside the "
+                                                "lock-step calls" % (Bt, Wh.nR, LINEARIZE_BYTES_PER_RES, alg_b / 1e6))
+            else:
+                batched["roofline"] = dict(error=repr(ltr))
     if single:
         # ---- the same protocol in tolerance-mode arithmetic of k_ef_linearize (sdvgn_ef_set_arith(1): FMA, v_rcp_f32 / v_sqrt_f32; increments
         # within the contract's 1e-4, tests/test_backend_gpu.py::test_arith_mode_tolerance) ----
@@ -1076,7 +1136,7 @@ def main():
         "iteration_us": iter_stats,
         "kernel_ms": {"k_ef_linearize_back_to_back": ms_lin_b2b, "accumulate(fused point+top+sc, reduce)": ms_acc},
         "tolerance_arith": tol,
-        "batched_windows_side_by_side": batched,
+        "batched_windows": batched,
         "value_with_literal_relinearize_on_reject": value_relin,
         "value_with_system_reuse_after_rejected_steps": value_reuse,
         "value_without_rejected_case_solved_ahead": value_nospec,

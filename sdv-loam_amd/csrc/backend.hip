@@ -104,6 +104,12 @@ struct sdvgn_ef {
     int8_t* rstate_new2 = nullptr;
     float *renergy_new2 = nullptr, *renergy_wo2 = nullptr;
     int new_cur = 0;   // which set holds the current state_New* values
+    // second copies of the four planes applyRes writes (flags, state, energy, JpJd): in the optimize loop the linearise leaves the result of
+    // applyRes in them (EFArrays::rflags_w) and an accepted step swaps the pointers -- no applyRes pass, nothing to undo after a rejected step.
+    // applied_synced: every slot a linearise does NOT process (no residual / fixed linearisation) holds the same values in both copies; any entry
+    // point that writes the first copies outside the loop clears it, the next optimize call copies once (ef_sync_applied)
+    uint8_t* rflags_alt = nullptr; int8_t* rstate_alt = nullptr; float *renergy_alt = nullptr, *JpJd_alt = nullptr;
+    bool applied_synced = false;
     // device-resident small solve (backend_solve.inc)
     SolveWindow* win_dev = nullptr;        // per-window constants of the solve (adjoints, priors, HM/bM, null-space basis, evalPT ...)
     SolveWindow* win_host = nullptr;       // pinned staging copy
@@ -271,7 +277,38 @@ static void ef_fill_arrays(sdvgn_ef* e) {
     A.images = e->images;
     A.dbg_stamps = e->dbg_stamps;
     A.reset_oob = 0;
+    A.rflags_w = nullptr; A.rstate_w = nullptr; A.renergy_w = nullptr; A.JpJd_w = nullptr;
     A.err = e->stats_host ? (unsigned*)(e->stats_host + 6) : nullptr;
+}
+// ---- applyRes fused into the linearise (EFArrays::rflags_w) ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ef_sync_applied(size_t slots, const uint8_t* __restrict__ fl, const int8_t* __restrict__ st, const float* __restrict__ en,
+                                                         const float* __restrict__ jd, uint8_t* __restrict__ fl2, int8_t* __restrict__ st2, float* __restrict__ en2,
+                                                         float* __restrict__ jd2) {
+    const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= slots) return;
+    const uint8_t f = fl[s];
+    fl2[s] = f;
+    if (!(f & RF_EXISTS)) return;
+    st2[s] = st[s]; en2[s] = en[s];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) jd2[(size_t)i * slots + s] = jd[(size_t)i * slots + s];
+}
+static int ef_sync_applied(sdvgn_ef* e) {
+    if (e->applied_synced) return SDVGN_OK;
+    const size_t slots = (size_t)e->nF * e->nP;
+    k_ef_sync_applied<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(slots, e->rflags, e->rstate, e->renergy, e->JpJd, e->rflags_alt, e->rstate_alt,
+                                                                              e->renergy_alt, e->JpJd_alt);
+    HIPCHK(hipGetLastError());
+    e->applied_synced = true;
+    return SDVGN_OK;
+}
+static void ef_flip_applied(sdvgn_ef* e) {      // the second copies become the current ones (an applyRes that has already been computed)
+    std::swap(e->rflags, e->rflags_alt); std::swap(e->rstate, e->rstate_alt); std::swap(e->renergy, e->renergy_alt); std::swap(e->JpJd, e->JpJd_alt);
+    e->A.rflags = e->rflags; e->A.rstate = e->rstate; e->A.renergy = e->renergy; e->A.JpJd = e->JpJd;
+}
+static void ef_set_apply_target(sdvgn_ef* e, bool on) {   // the next linearise launch also performs applyRes, into the second copies
+    e->A.rflags_w = on ? e->rflags_alt : nullptr; e->A.rstate_w = on ? e->rstate_alt : nullptr;
+    e->A.renergy_w = on ? e->renergy_alt : nullptr; e->A.JpJd_w = on ? e->JpJd_alt : nullptr;
 }
 
 static void ef_update_const(sdvgn_ef* e) {  // CalibHessian float views, HessianBlocks.h:302-330
@@ -1009,6 +1046,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->renergy, slots) | dev_alloc(&e->renergy_new, slots) | dev_alloc(&e->renergy_wo, slots) | dev_alloc(&e->rres_toZero, 2 * slots);
     bad |= dev_alloc(&e->rstate_new2, slots) | dev_alloc(&e->renergy_new2, slots) | dev_alloc(&e->renergy_wo2, slots);
     bad |= dev_alloc(&e->J, 2 * (size_t)kJPlanes * slots) | dev_alloc(&e->JpJd, 6 * slots);
+    bad |= dev_alloc(&e->rflags_alt, slots) | dev_alloc(&e->rstate_alt, slots) | dev_alloc(&e->renergy_alt, slots) | dev_alloc(&e->JpJd_alt, 6 * slots);
     bad |= dev_alloc(&e->pHddA, mp) | dev_alloc(&e->pbdA, mp) | dev_alloc(&e->pHcdA, 4 * mp) | dev_alloc(&e->pHddL, mp) | dev_alloc(&e->pbdL, mp) | dev_alloc(&e->pHcdL, 4 * mp);
     bad |= dev_alloc(&e->pHdi, mp) | dev_alloc(&e->pbdSum, mp) | dev_alloc(&e->pHcd, 4 * mp) | dev_alloc(&e->pstep, mp);
     bad |= dev_alloc(&e->images, (size_t)SDVGN_MAX_FRAMES * w * h * 3) | dev_alloc(&e->img_stage, (size_t)w * h);
@@ -1096,7 +1134,8 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
                     e->stats_dev, e->stats_partial, e->imm_pc_dev, e->rstate_new2, e->renergy_new2, e->renergy_wo2,
                     e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->precalc_alt, e->dbg_stamps, e->marg_mask_dev, e->drop_mask_dev, e->th_dev, e->fin_dev,
-                    e->win_dev, e->sstate_dev, e->calib_dev, e->rx_dev, e->xw_dev, e->sys_dev, e->pieces_dev, e->en_em_dev};
+                    e->win_dev, e->sstate_dev, e->calib_dev, e->rx_dev, e->xw_dev, e->sys_dev, e->pieces_dev, e->en_em_dev,
+                    e->rflags_alt, e->rstate_alt, e->renergy_alt, e->JpJd_alt};
     for (void* p : ptrs) if (p) SDVGN_DFREE(p);
     if (e->precalc_host) SDVGN_HFREE(e->precalc_host);
     if (e->acc_host) SDVGN_HFREE(e->acc_host);
@@ -1304,6 +1343,11 @@ int sdvgn_ef_set_residuals(sdvgn_ef* e, int nR, const int* point, const int* tar
     const hipStream_t s = e->stream;
     HIPCHK(hipMemcpyAsync(e->rflags, flags.data(), slots, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(e->rstate, st.data(), slots, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->rflags_alt, flags.data(), slots, hipMemcpyHostToDevice, s));      // (both copies of the planes applyRes writes)
+    HIPCHK(hipMemcpyAsync(e->rstate_alt, st.data(), slots, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(e->renergy_alt, 0, 4 * slots, s));
+    HIPCHK(hipMemsetAsync(e->JpJd_alt, 0, sizeof(float) * 6 * slots, s));
+    e->applied_synced = true;
     HIPCHK(hipMemcpyAsync(e->rmatcher, m.data(), sizeof(float2) * slots, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(e->rstate_new, RS_OUTLIER, slots, s));
     HIPCHK(hipMemsetAsync(e->renergy, 0, 4 * slots, s));
@@ -1328,6 +1372,7 @@ int sdvgn_ef_set_residuals(sdvgn_ef* e, int nR, const int* point, const int* tar
 int sdvgn_ef_set_residual_jacobians(sdvgn_ef* e, int nR, const float* J24, const float* res_toZero2) {
     if (!e || !J24 || nR < 0 || nR != e->nR || e->nP < 1) return SDVGN_E_ARG;
     EF_DEVICE(e);
+    e->applied_synced = false;   // (writes the first copies of the planes applyRes owns: see sdvgn_ef::applied_synced)
     const size_t slots = (size_t)e->nF * e->nP;
     std::vector<uint8_t> fl(slots);
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1468,6 +1513,7 @@ int sdvgn_ef_linearize_all(sdvgn_ef* e, double* energy_out) {
 int sdvgn_ef_apply_res(sdvgn_ef* e) {
     if (!e || e->nP < 1) return SDVGN_E_STATE;
     EF_DEVICE(e);
+    e->applied_synced = false;   // (writes the first copies of the planes applyRes owns: see sdvgn_ef::applied_synced)
     const size_t slots = (size_t)e->nF * e->nP;
     // (a threshold select the optimize loop has pending stays pending: applyRes does not read the thresholds)
     k_ef_apply<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->nF, e->nP, e->A, e->precalc_dev, e->phost_dev, nullptr);
@@ -1994,7 +2040,9 @@ static double host_prior_energy(const sdvgn_ef* e) {   // calcLEnergyF_MT: frame
 // otherwise), so it runs beside the statistics in this launch instead of as a launch of its own after the host has seen the verdict
 // with_apply: applyRes of this linearisation in the same launch, unconditionally (the call's initial linearizeAll + applyRes: statistics
 // workgroup + apply workgroups side by side, nothing to wait for) -- single rank, shared stream only
-static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideArgs* dec = nullptr, bool final_body = false, bool with_apply = false) {   // second half: the sums (+ threshold select)
+// fused: applyRes of this linearisation was computed by the linearise itself (EFArrays::rflags_w): sums, accept test (+ the select in the last body) only
+static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideArgs* dec = nullptr, bool final_body = false, bool with_apply = false,
+                                  bool fused = false) {   // second half: the sums (+ threshold select)
     const int n_partials = e->lin_partials, nL = e->lin_nL;
     const int nS = (e->nP + 63) / 64;
     const double* ps = e->stats_partial + (e->nP / 64 + 2);
@@ -2014,6 +2062,12 @@ static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideAr
         a.rflags = e->rflags; a.wo = e->A.renergy_wo; a.th_prev = e->A.frameTH_r; a.th_out = e->A.frameTH_w;
         a.log_slot = e->th_log ? e->th_log + (e->th_log_n++ % kThLog) : nullptr;
         const DecideArgs none{0, 0, 0, nullptr, 0, nullptr, 0, nullptr};
+        if (fused) {
+            const bool sel_now = final_body || !defer_select;
+            k_ef_stats_select<<<sel_now ? 2 : 1, kSelLanes, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host,
+                                                                           e->flags_host + 2, ++e->seq_stats, a, dec ? *dec : none);
+            if (sel_now) defer_select = false;
+        } else
         if (dec && dec->verdict && final_body && !e->own_stream) {
             const size_t slots = (size_t)e->nF * e->nP;
             k_ef_stats_apply_select<<<2 + (unsigned)((slots + kSelLanes - 1) / kSelLanes), kSelLanes, 0, e->stream>>>(
@@ -2138,9 +2192,20 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     // the device's sums are fetched when the first accept test needs them (take_initial_energies), by then long there
     const bool onecoll = ef_one_collective(e) && !relinearize_on_reject;
     struct CollGuard { sdvgn_ef* e; double* a; double* s; ~CollGuard() { e->acc_dev = a; e->stats_dev = s; } } coll_guard{e, e->acc_dev, e->stats_dev};
+    // applyRes fused into the linearise (single rank, shared stream, the product's default loop): see sdvgn_ef::rflags_alt
+    const bool fused = defer && !e->own_stream && !ef_sharded(e) && e->rflags_alt && !e->deltaF_nonzero && getenv("SDVGN_NO_FUSED_APPLY") == nullptr;
+    struct ApplyTargetGuard { sdvgn_ef* e; ~ApplyTargetGuard() { ef_set_apply_target(e, false); } } apply_target_guard{e};
     if (onecoll) {
         // the call's one extra collective: initial linearizeAll + applyRes + accumulate, their sums and accumulators in one message
         if ((rc = linearize_launch_kernels(e)) || (rc = ef_sharded_message(e, e->coll_cur, /*speculative=*/false))) return rc;
+    } else
+    if (fused) {                     // linearise + applyRes in one kernel, then the sums; the applied copies become the current ones at once
+        if ((rc = ef_sync_applied(e))) return rc;
+        ef_set_apply_target(e, true);
+        rc = linearize_launch_kernels(e);
+        ef_set_apply_target(e, false);
+        if (rc || (rc = linearize_launch_stats(e, defer, nullptr, false, false, /*fused=*/true))) return rc;
+        ef_flip_applied(e);
     } else
     if (defer && !e->own_stream) {   // linearise, then its statistics and applyRes in ONE launch (they do not depend on each other)
         if ((rc = linearize_launch_kernels(e)) || (rc = linearize_launch_stats(e, defer, nullptr, false, /*with_apply=*/true))) return rc;
@@ -2225,11 +2290,16 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         const bool dev_decide = defer && !zero_differs;
         if (!dev_decide && (rc = take_initial_energies())) return rc;          // (that path launches its statistics right behind the linearise)
         const bool spec = onecoll && !zero_differs;
+        const bool fused_body = fused && dev_decide;       // the trial linearise leaves its applyRes in the second copies
         if (spec) {
             // trial linearise, then its sums + the speculative apply / accumulate and the body's ONE collective (ef_sharded_message)
             if ((rc = linearize_launch_kernels(e)) || (rc = ef_sharded_message(e, 1 - e->coll_cur, /*speculative=*/true))) return rc;
-        } else
-        if ((rc = dev_decide ? linearize_launch_kernels(e) : linearize_launch(e, defer))) return rc;
+        } else {
+            if (fused_body) ef_set_apply_target(e, true);
+            rc = dev_decide ? linearize_launch_kernels(e) : linearize_launch(e, defer);
+            ef_set_apply_target(e, false);
+            if (rc) return rc;
+        }
         if (dev_decide) {
             // the sums, the accept test and -- in the same launch -- applyRes of the trial linearisation, queued right behind the linearise: what
             // the test needs from the stepped state (prior energy, M energy) was formed on the device beside the step (step_energy_body), what it
@@ -2239,7 +2309,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             dec.En = dec.EM = 0; dec.en_em = e->en_em_dev + 2 * st_trial;
             dec.rhs = lastEnergy + lastEnergyL + lastEnergyM; dec.accept_dev = e->accept_dev; dec.on = 1;
             dec.verdict = (unsigned*)(e->accept_dev + 4); dec.seq = (unsigned)(++e->seq_verdict) & 0x7fffffffu;
-            if ((rc = linearize_launch_stats(e, defer, &dec, /*final_body=*/iteration + 1 == mnumOptIts))) return rc;
+            if ((rc = linearize_launch_stats(e, defer, &dec, /*final_body=*/iteration + 1 == mnumOptIts, false, fused_body))) return rc;
         }
         g_pt.stop(PT_ACCUM);
         // x is in pinned memory as soon as the solve kernel is through: mirror doStepFromBackup on the host (FrameHessian::setState,
@@ -2273,8 +2343,14 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             const bool may_break = !fixed_its && iteration >= 1 && sqrtf(sumR / nF) < 0.00005 * thOpt;
             if (!reuse_after_reject && !may_break && iteration + 1 < mnumOptIts && ef_acc_geom(e).sc_ppb == 64) {
                 // (when the rejected case has been solved ahead, a rejection leaves this accumulate without a reader: it returns at once)
-                const AccAlt alt{e->accept_dev, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->calib_dev + e->st_cur, e->precalc_alt, spec_pending ? 1 : 0};
-                if ((rc = ef_accumulate(e, /*with_reduce=*/true, &alt))) return rc;
+                // (fused applyRes: the accepted case reads the copies the trial linearise wrote, the rejected one the kept copies)
+                if (fused_body) ef_flip_applied(e);
+                const AccAlt alt{e->accept_dev, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->calib_dev + e->st_cur, e->precalc_alt, spec_pending ? 1 : 0,
+                                 fused_body ? e->rflags_alt : nullptr, fused_body ? e->rstate_alt : nullptr, fused_body ? e->renergy_alt : nullptr,
+                                 fused_body ? e->JpJd_alt : nullptr};
+                rc = ef_accumulate(e, /*with_reduce=*/true, &alt);
+                if (fused_body) ef_flip_applied(e);        // (back: the verdict is not known yet)
+                if (rc) return rc;
                 pre_accumulated = true;
             }
         }
@@ -2307,6 +2383,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             e->new_cur = 1 - e->new_cur;                                                  // the trial sets become the current ones
             e->st_cur = st_trial;
             ef_select_new_set(e, e->new_cur, e->new_cur);
+            if (fused_body) ef_flip_applied(e);                               // applyRes: the copies the trial linearise wrote are the residuals' state now
             if (spec) e->coll_cur = 1 - e->coll_cur;                          // the speculative message IS the accepted state's: applied, accumulated, reduced
             else if (!dev_decide && (rc = sdvgn_ef_apply_res(e))) return rc;  // (device-side test: the conditional apply is already queued)
             if (onecoll && !spec) {   // (idepth_zero differed before this trial: the body ran the two-collective way; rebuild the current message)
@@ -2519,6 +2596,7 @@ int sdvgn_ef_optimize_batch(sdvgn_ef* const* handles, int B, int mnumOptIts, int
 int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_max, int* ngood_inc, unsigned char* removed) {
     if (!e || e->host_only || e->nP < 1 || e->nR < 0 || e->nF < 1) return SDVGN_E_STATE;
     EF_DEVICE(e);
+    e->applied_synced = false;   // (writes the first copies of the planes applyRes owns: see sdvgn_ef::applied_synced)
     const int nF = e->nF;
     FrameH& nf = e->frames[nF - 1];
     const double newStateZero[10] = {0, 0, 0, 0, 0, 0, nf.state[6], nf.state[7], 0, 0};
@@ -2564,6 +2642,7 @@ int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_m
 int sdvgn_ef_reset_oob(sdvgn_ef* e, const unsigned char* mask) {
     if (!e || e->nP < 1) return SDVGN_E_ARG;
     EF_DEVICE(e);
+    e->applied_synced = false;   // (writes the first copies of the planes applyRes owns: see sdvgn_ef::applied_synced)
     const size_t slots = (size_t)e->nF * e->nP;
     if (mask) HIPCHK(hipMemcpyAsync(e->marg_mask_dev, mask, e->nP, hipMemcpyHostToDevice, e->stream));
     k_ef_reset_oob<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(slots, e->A, mask ? e->marg_mask_dev : nullptr, e->nP);
@@ -2576,6 +2655,7 @@ int sdvgn_ef_fix_linearization(sdvgn_ef* e, const unsigned char* mask) {
     if (!e || !mask || e->nP < 1) return SDVGN_E_ARG;
     if (!e->havePrecalc || !e->haveAdjoints) return SDVGN_E_STATE;
     EF_DEVICE(e);
+    e->applied_synced = false;   // (writes the first copies of the planes applyRes owns: see sdvgn_ef::applied_synced)
     HIPCHK(hipMemcpyAsync(e->marg_mask_dev, mask, e->nP, hipMemcpyHostToDevice, e->stream));
     const size_t slots = (size_t)e->nF * e->nP;
     k_ef_fix_linearization<<<(unsigned)((slots + 255) / 256), 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, e->marg_mask_dev);
@@ -2590,6 +2670,7 @@ int sdvgn_ef_marginalize_points(sdvgn_ef* e, const unsigned char* marg, const un
     if (!e->havePrecalc || !e->haveAdjoints) return SDVGN_E_STATE;
     if (ef_sharded(e)) return SDVGN_E_STATE;   // single-GPU entry point (the key-frame cycle around optimize), not part of cfg4
     EF_DEVICE(e);
+    e->applied_synced = false;   // (writes the first copies of the planes applyRes owns: see sdvgn_ef::applied_synced)
     const int nF = e->nF, n = CPARS + 6 * nF, pairs = nF * nF, chunks = chunks_for_np(e);
     HIPCHK(hipMemcpyAsync(e->marg_mask_dev, marg, e->nP, hipMemcpyHostToDevice, e->stream));
     if (drop) HIPCHK(hipMemcpyAsync(e->drop_mask_dev, drop, e->nP, hipMemcpyHostToDevice, e->stream));

@@ -105,6 +105,13 @@ struct EFArrays {
     // as state IN with state_energy = state_NewEnergy = 0 on entry (the first linearizeAll of FullSystem::optimize, which the reference
     // precedes with a resetOOB loop); what the pair writes is what reset + linearise + apply would have written
     int reset_oob;
+    // applyRes FUSED into the linearise (EFResidual::takeDataF + the state / energy hand-over of PointFrameResidual::applyRes, Residuals.cpp:230-254,
+    // for every residual the linearise processes): non-NULL = the SECOND copies of the four planes applyRes writes.  The linearise then leaves
+    // in them what applyRes would have left in the first ones (flags with the Jacobian buffers swapped, state, energy, JpJd = Jpdxi^T Jpdd), reading
+    // the first copies only; the caller makes the second copies the current ones if the step is accepted (a pointer swap) and does nothing if
+    // it is not.  Slots the linearise does not process (no residual, or a fixed linearisation) hold the same values in both copies
+    // (backend.hip, ef_sync_applied).  NULL: applyRes is a pass of its own (k_ef_apply).
+    uint8_t* rflags_w; int8_t* rstate_w; float* renergy_w; float* JpJd_w;
     // sticky error word in pinned host memory (may be NULL): a workgroup that gives up waiting for a word another workgroup of the same
     // launch publishes ORs a code into it (1: the accept verdict, 2: the solution); sdvgn_ef_optimize and the solve check it and return
     // SDVGN_E_STATE instead of carrying on with a partially applied / unstepped window
@@ -175,12 +182,17 @@ struct LinGeo { float res0, res1, hwm, Jr[6], Cr[4], dd; };
 struct LinRec { unsigned off; float fx, fy; };          // published by the owner: top-left tap (element offset into the target image), fractions
 struct LinSmem {
     union { LinRec q[2][2][64][4]; float g[2][2][64][4][3]; };   // [group][role][lane][pixel]: first the records, then {I,dx,dy} (same 12 bytes)
-    float xch[2][9][64];
+    float xch[2][15][64];    // role 1 -> role 0: 4 energies, 4 gradient weights, the ok bits | (fused applyRes) its six terms of JpJd
     double s_e[2];
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned lin_u32x2 __attribute__((ext_vector_type(2)));
+// fused applyRes (EFArrays::rflags_w): JpJd = Jpdxi^T Jpdd (EnergyFunctionalStructs.cpp:20-24), one product per role and their sum, rounded
+// operation by operation like k_ef_apply's -- defined here, outside the instantiations' contraction pragma, so that both arithmetic modes of
+// the linearise leave what their applyRes pass left
+__device__ __forceinline__ float lin_jpjd_term(float jr, float hwm, float dd) { return (jr * hwm) * (dd * hwm); }
+__device__ __forceinline__ float lin_jpjd_sum(float tx, float ty) { return tx + ty; }
 // ---- the kernel and its phases live in backend_linearize.inc, instantiated twice (see its header) ---------------------------------------
 #define LIN_NS lin_exact
 #define LIN_DIV(a, b) ((a) / (b))
@@ -933,7 +945,9 @@ __global__ void __launch_bounds__(256) k_ef_sc_gram(EFConst C, EFArrays A, const
 // says "rejected", the state-dependent inputs -- the point copies, the calib floats, the precalc table -- are the kept ones instead.
 // skip_on_reject: the solution of the rejected case was computed ahead on the side stream (ef_launch_spec_solve, backend.hip), so a "rejected"
 // verdict means this accumulate has no reader -- the planes it would rewrite already hold the kept state's values: every workgroup returns at once
-struct AccAlt { const int* verdict; const float* pid; const float* pidz; const float* pdeltaF; const CalibDev* calib; const PrecalcDev* precalc; int skip_on_reject; };
+struct AccAlt { const int* verdict; const float* pid; const float* pidz; const float* pdeltaF; const CalibDev* calib; const PrecalcDev* precalc; int skip_on_reject;
+                // (fused applyRes: the planes applyRes writes also exist twice; NULL = they do not depend on the verdict)
+                uint8_t* rflags; int8_t* rstate; float* renergy; float* JpJd; };
 // (body for workgroup b of the launch: k_ef_acc_fused launches it for one window, k_lock_acc -- backend_lockstep.inc -- for B windows in one grid)
 __device__ __forceinline__ void acc_fused_body(const PrecalcDev* __restrict__ precalc, const EFConst& Cin, EFArrays A,
                                                const int* __restrict__ phost, float* __restrict__ top_partial,
@@ -944,6 +958,9 @@ __device__ __forceinline__ void acc_fused_body(const PrecalcDev* __restrict__ pr
     // verdict -> point range -> flags -> values of every Schur workgroup with a round trip of its own
     const int vd = alt.verdict ? *alt.verdict : 1;
     if (alt.skip_on_reject && vd == 0) return;   // (uniform over the grid: before any barrier)
+    // (fused applyRes: which copy of the flags / JpJd planes is current depends on the verdict; the Schur workgroups' first loads of them wait for
+    // the point range anyway, which was fetched together with the verdict)
+    if (vd == 0 && alt.rflags) { A.rflags = alt.rflags; A.rstate = alt.rstate; A.renergy = alt.renergy; A.JpJd = alt.JpJd; }
     __shared__ union U { TopGramSmem t; PointSmem p; ScGramSmem s; __device__ U() {} } S;
     if (b < n_sc) {
         const int h = b / sc_chunks, bx = b - h * sc_chunks;
@@ -953,7 +970,7 @@ __device__ __forceinline__ void acc_fused_body(const PrecalcDev* __restrict__ pr
         __shared__ float pt[6][64];
         const int wave = threadIdx.x >> 6;
         float stage[16];
-        switch (wave) {   // wave-uniform  (flags / JpJdF planes and nF, nP: the same for either verdict)
+        switch (wave) {   // wave-uniform
             case 0: sc_fused_prefetch<0>(Cin, A, P0, begin, end, stage); break;
             case 1: sc_fused_prefetch<1>(Cin, A, P0, begin, end, stage); break;
             case 2: sc_fused_prefetch<2>(Cin, A, P0, begin, end, stage); break;
