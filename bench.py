@@ -1118,6 +1118,14 @@ def main():
     except Exception:  # noqa: BLE001
         roof["hbm_copy_measured_GBps"] = None
 
+    if batched and isinstance(batched.get("roofline"), dict) and batched["roofline"].get("traffic") and roof.get("hbm_copy_measured_GBps"):
+        br = batched["roofline"]
+        br["traffic_rate_GBps"] = br["traffic"] / (br["in_loop_trace"]["mean_ms"] * 1e-3) / 1e9
+        br["hbm_copy_measured_GBps"] = roof["hbm_copy_measured_GBps"]
+        br["traffic_rate_over_measured_copy_rate"] = br["traffic_rate_GBps"] / roof["hbm_copy_measured_GBps"]
+        br["note"] += ("; the counters' bytes per launch / that duration = %.0f GB/s = %.2f of what a plain 1 GiB device-to-device copy reaches on this box "
+                       "(hbm_copy_measured_GBps): at B = 16 the working set is 1.3 GB, every launch streams from HBM" % (
+                           br["traffic_rate_GBps"], br["traffic_rate_over_measured_copy_rate"]))
     out = {
         "metric": "Gauss-Newton iters/sec (KITTI res, 8 KF x 2000 pts)",
         "value": value, "unit": "GN iters/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": 1e3 * dt / K,

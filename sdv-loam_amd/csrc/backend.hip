@@ -2192,8 +2192,12 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     // the device's sums are fetched when the first accept test needs them (take_initial_energies), by then long there
     const bool onecoll = ef_one_collective(e) && !relinearize_on_reject;
     struct CollGuard { sdvgn_ef* e; double* a; double* s; ~CollGuard() { e->acc_dev = a; e->stats_dev = s; } } coll_guard{e, e->acc_dev, e->stats_dev};
-    // applyRes fused into the linearise (single rank, shared stream, the product's default loop): see sdvgn_ef::rflags_alt
-    const bool fused = defer && !e->own_stream && !ef_sharded(e) && e->rflags_alt && !e->deltaF_nonzero && getenv("SDVGN_NO_FUSED_APPLY") == nullptr;
+    // applyRes fused into the linearise (sdvgn_ef::rflags_alt).  The batched launch sequence always runs that way (backend_lockstep.inc: no
+    // workgroups that poll a verdict, one pass over the residual planes less).  For ONE window it is a wash -- the apply workgroups run beside the
+    // statistics workgroup anyway, the linearise grows by the 30 bytes per residual applyRes writes (in-loop 16.1 -> 17.0 us, statistics launch
+    // 5.7 -> 5.4 us, headline 15.0 k it/s either way; profiles/r04_notes.txt) -- so the single-window loop keeps applyRes as workgroups of the
+    // statistics launch unless SDVGN_FUSED_APPLY is set (tests run both: bit-identical)
+    const bool fused = defer && !e->own_stream && !ef_sharded(e) && e->rflags_alt && !e->deltaF_nonzero && getenv("SDVGN_FUSED_APPLY") != nullptr;
     struct ApplyTargetGuard { sdvgn_ef* e; ~ApplyTargetGuard() { ef_set_apply_target(e, false); } } apply_target_guard{e};
     if (onecoll) {
         // the call's one extra collective: initial linearizeAll + applyRes + accumulate, their sums and accumulators in one message

@@ -713,3 +713,31 @@ def test_lockstep_refuses_what_it_does_not_take(api, orc, window):
     arr1 = (C.c_void_p * 1)(G.h_)
     assert G.L.sdvgn_ef_optimize_lockstep(C.cast(arr1, C.c_void_p), 1, 6, 2, None, None, 0, 0) < 0       # the literal re-linearisation: sdvgn_ef_optimize only
     assert G.L.sdvgn_ef_optimize_lockstep(C.cast(arr1, C.c_void_p), 1, 6, 0, None, None, 0, 0) == 0
+
+
+@pytest.mark.parametrize("seed,its", [(2, 12), (3, 6), (4, 7)])
+def test_fused_apply_single_window_is_bit_identical(api, orc, seed, its, monkeypatch):
+    """SDVGN_FUSED_APPLY=1: the linearise leaves applyRes in the second copies of the flag / state / energy / JpJd planes and an accepted step swaps
+    pointers (what the batched launch sequence always does) instead of apply workgroups in the statistics launch -- same trace, states, planes,
+    next solve and loop tail, bit for bit; also after operations that write the planes in place between two calls (fixLinearization)."""
+    from sdv_loam_amd import synthetic as syn
+    kw = {} if seed == 2 else dict(state_sigma=1e-3, idepth_sigma=0.01)
+    W = low_thresholds(syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=seed, calib=dict(fx=400., fy=410., cx=319.5, cy=119.5), **kw))
+    A = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+    B = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+    monkeypatch.delenv("SDVGN_FUSED_APPLY", raising=False)
+    ta = A.optimize(its, fixed_its=True)
+    monkeypatch.setenv("SDVGN_FUSED_APPLY", "1")
+    tb = B.optimize(its, fixed_its=True)
+    assert np.array_equal(ta, tb)
+    _same_window_result(A, B)
+    assert np.array_equal(A.residual_J(0), B.residual_J(0))
+    mask = (np.arange(W.nP) % 3 == 0).astype(np.uint8)
+    A.fixLinearization(mask); B.fixLinearization(mask)
+    tb2 = B.optimize(5, fixed_its=True)
+    monkeypatch.delenv("SDVGN_FUSED_APPLY")
+    ta2 = A.optimize(5, fixed_its=True)
+    assert np.array_equal(ta2, tb2)
+    _same_window_result(A, B)
+    ea, eb = A.optimize_finish(), B.optimize_finish()
+    assert ea[0] == eb[0] and all(np.array_equal(x, y) for x, y in zip(ea[1:], eb[1:]))
