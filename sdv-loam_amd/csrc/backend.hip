@@ -1891,7 +1891,7 @@ static int ef_launch_spec_solve(sdvgn_ef* e, int iteration_next, double lambda_n
     io.rx = e->rx_spec; io.out = e->sol_spec + buf;
     io.done_flag = e->flags_host + 5 + buf; io.done_seq = (int)(kSpecTag | (unsigned)(++e->seq_spec));
     io.xw = e->xw_spec + (size_t)buf * 512;
-    io.err_word = e->stats_host ? (unsigned*)(e->stats_host + 6) : nullptr;   // (a wait that gives up -- ~1 s -- fails the call in flight, used or not)
+    io.err_word = nullptr;                             // (its one wait gives up quietly: SolveOut::status 3, see solve_tail and ef_spec_valid)
     io.lambda = lambda_next; io.iteration = iteration_next; io.do_step = 0; io.reuse = 1; io.stepsize = 0.0f;
     io.stamps = nullptr;
     io.spec = 1;
@@ -1924,8 +1924,8 @@ static int ef_launch_spec_rest(sdvgn_ef* e, int iteration, double lambda, float 
     io.rx = e->rx_spec;
     io.xw = e->xw_spec + (size_t)e->spec_last_buf * 512;
     io.done_seq = e->spec_last_seq;                     // the tag the polls wait for (and, being unique, the tag of this launch's threshold words)
-    // the speculative solve is through (normally since a whole linearise): nothing queued below ever waits for the side stream on the device
-    HIPCHK(wait_flag(e->flags_host + 5 + e->spec_last_buf, e->spec_last_seq, e->side));
+    // (the speculative solve is through and valid: ef_spec_valid was asked before this body was entered -- nothing queued below waits for the side
+    // stream on the device)
     const int has_rc = e->pend_rc_valid ? 1 : 0, has_sel = e->pend_sel_valid ? 1 : 0;
     const int nblk = (e->nP + 63) / 64;
     const int rest = (nblk + 1) / 2 + (io.en_em_trial ? 2 : 1);
@@ -1943,6 +1943,16 @@ static int ef_launch_spec_rest(sdvgn_ef* e, int iteration, double lambda, float 
     e->pend_sel_valid = false; e->pend_rc_valid = false;
     HIPCHK(hipGetLastError());
     e->sys_on_device = true; e->sys_fetched = false; e->sys_valid = true;
+    return SDVGN_OK;
+}
+// after a rejected step: is the solution computed ahead there?  Waits for the side-stream launch's completion flag (normally published a whole
+// linearise ago: one read of pinned memory) and looks at its status -- 3 = it never saw the system it was to re-use (streams that are not served
+// side by side, e.g. under a serialising profiler): the loop then solves the rejected case itself
+static int ef_spec_valid(sdvgn_ef* e, bool* valid) {
+    *valid = false;
+    if (e->spec_last_buf < 0) return SDVGN_OK;
+    HIPCHK(wait_flag(e->flags_host + 5 + e->spec_last_buf, e->spec_last_seq, e->side));
+    *valid = e->sol_spec[e->spec_last_buf].status != 3;
     return SDVGN_OK;
 }
 static int ef_wait_spec_solve(sdvgn_ef* e, int buf, int seq, double* x_out) {
@@ -2469,6 +2479,11 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             // the restored state is the one this body's system was built on, bit for bit (unless idepth_zero just changed, above)
             prev_rejected_clean = !zero_differs;
             spec_use = spec_pending && prev_rejected_clean;     // the next body's solution is (being) computed on the side stream
+            if (spec_use) {
+                bool valid = false;
+                if ((rc = ef_spec_valid(e, &valid))) return rc;
+                if (!valid) { spec_use = false; pre_accumulated = false; }   // (the accumulate queued ahead returned at once on this rejection: the body accumulates itself)
+            }
         }
         g_pt.stop(PT_APPLY);
         e->iter_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_iter).count());
