@@ -339,11 +339,12 @@ int sdvgn_ef_solve_system(sdvgn_ef* ef, int iteration, double lambda, double* x_
  * pivoted LDL^T (LDLT.h: pivot = largest remaining |diagonal|; pseudo-inverse of D), which like the reference's
  * `HFinalScaled.ldlt().solve()` (EnergyFunctional.cpp:743) returns a finite x on such a system.  No failure path. */
 int sdvgn_ef_get_solve_status(sdvgn_ef* ef);
-/* FullSystem::optimize (sdvgn_ef_optimize, no trace) on B INDEPENDENT windows side by side -- several maps / agents / sub-maps on one GPU.
- * One loop body of one window is a chain of six short launches that occupies a fraction of the chip for ~75 us; the chains of different
- * windows overlap on the device when every handle has its own stream (create with SDVGN_STREAM_OWN), one host thread of a library-owned
- * pool driving each.  its_out[b] (may be NULL) = return value of window b's sdvgn_ef_optimize.  Returns SDVGN_OK or the error of a window.
- * Results of every window are those of its own sdvgn_ef_optimize call, bit for bit. */
+/* FullSystem::optimize (sdvgn_ef_optimize, no trace) on B INDEPENDENT windows in one call -- several maps / agents / sub-maps on one GPU.
+ * One loop body of one window is a chain of six short launches that occupies a fraction of the chip for ~65 us.  Default: the B loops run as ONE
+ * launch sequence (sdvgn_ef_optimize_lockstep below).  Windows that form does not take, and every window when SDVGN_BATCH_THREADS is set in the
+ * environment, run as B sdvgn_ef_optimize calls on a library-owned pool of host threads; their chains overlap on the device when every handle
+ * has its own stream (create with SDVGN_STREAM_OWN).  its_out[b] (may be NULL) = return value of window b's sdvgn_ef_optimize.  Returns
+ * SDVGN_OK or the error of a window.  Results of every window are those of its own sdvgn_ef_optimize call, bit for bit. */
 int sdvgn_ef_optimize_batch(sdvgn_ef* const* handles, int B, int mnumOptIts, int flags, int* its_out);
 /* The form sdvgn_ef_optimize_batch takes by default: the B loops as ONE launch sequence -- every kernel of a loop body launched once for
  * all windows (the window is a grid index), the accept / reject decision, lambda and the choice of state copies of every window kept in

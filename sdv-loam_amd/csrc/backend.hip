@@ -136,7 +136,6 @@ struct sdvgn_ef {
     int seq_spec = 0;                      // tags of the speculative solves are kSpecTag | seq_spec: disjoint from the main solves' (seq_solve)
     hipStream_t side = nullptr;            // the device's shared side stream (not owned)
     int spec_last_buf = -1, spec_last_seq = 0;   // the speculative solve launched last (may still be running)
-    bool reduce_pending = false;           // the accumulate queued ahead of the verdict has run without its reduce (launched with the solve, accepted case only)
     SolvePieces* pieces_dev = nullptr;     // [SDVGN_MAX_FRAMES]: per-host shares of HA / bA / Hsc / bsc
     unsigned long long* solve_stamps = nullptr;   // pinned, 16 words: SDVGN_DEBUG_FLAGS bit6 only (phase stamps of the solve workgroup)
     int solve_status = 0;                  // status of the last device solve: 1 = a pivot of the LDL^T was not positive / finite (x = 0)
@@ -1804,13 +1803,7 @@ static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_st
             if ((rc = ef_accumulate(e, /*with_reduce=*/true))) return rc;
             // sharded window: the packed buffer of every rank is summed (ONE all-reduce per GN iteration), then every rank stitches and solves
             if (ef_sharded(e) && (rc = ef_allreduce(e, e->acc_dev, (int)acc_count(e)))) return rc;
-        } else if (e->reduce_pending) {
-            // the accumulate was queued before the verdict, its reduce waits until here: after a rejection whose solution was computed ahead it
-            // is never launched (an empty launch of its grid still cost ~5 us between the verdict and the next body)
-            const AccGeom g = ef_acc_geom(e);
-            k_ef_acc_reduce<<<acc_reduce_grid(g.pairs, nF), 256, 0, e->stream>>>(e->top_partial, g.pairs, g.chunks, e->sc_partial, nF, g.sc_chunks, e->nres_partial, e->acc_dev);
         }
-        e->reduce_pending = false;
         // the pending threshold select rides in the factorisation's launch (below); a handle that runs beside others keeps it in this one
         const int has_sel = (e->own_stream && e->pend_sel_valid) ? 1 : 0;
         k_ef_stitch<<<kStitchParts * nF + 1 + has_sel, kSolveLanes, 0, e->stream>>>(io, e->pend_sel, has_sel);
@@ -1846,7 +1839,6 @@ static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_st
     e->sys_on_device = true; e->sys_fetched = false; e->sys_valid = true;
     return SDVGN_OK;
 }
-constexpr unsigned kSpecTagForDump = 0x40000000u;
 static inline bool ef_wait_error(const sdvgn_ef* e) {   // a workgroup gave up an intra-launch wait (EFArrays::err): the window is not trustworthy
     return e->stats_host && *reinterpret_cast<volatile const unsigned*>(e->stats_host + 6) != 0;
 }
@@ -1863,7 +1855,7 @@ static int ef_state_failure(const sdvgn_ef* e, const char* what, double a = 0, d
     for (int q = 0; q < 2 && e->xw_spec; ++q) { hipMemcpy(&thw[q], e->xw_spec + q * 512 + 500, 8, hipMemcpyDeviceToHost); hipMemcpy(&xs[q], e->xw_spec + q * 512, 8, hipMemcpyDeviceToHost); }
     fprintf(stderr, "[sdvgn]   seq_solve %d seq_spec %d (tag %#x) seq_verdict %u | spec_last buf %d seq %#x | flags solve %d spec %d %d stats %d (seq_stats %d)\n"
                     "[sdvgn]   device words: tri_ready tag %u | verdict %u (seq %u) | spec x[0] tags %#x %#x | spec th[0] tags %#x %#x\n",
-            e->seq_solve, e->seq_spec, kSpecTagForDump | (unsigned)e->seq_spec, e->seq_verdict, e->spec_last_buf, (unsigned)e->spec_last_seq,
+            e->seq_solve, e->seq_spec, 0x40000000u | (unsigned)e->seq_spec, e->seq_verdict, e->spec_last_buf, (unsigned)e->spec_last_seq,
             e->flags_host[3], e->flags_host[5], e->flags_host[6], e->flags_host[2], e->seq_stats,
             (unsigned)(tri >> 32), ver, ver >> 1, (unsigned)(xs[0] >> 32), (unsigned)(xs[1] >> 32), (unsigned)(thw[0] >> 32), (unsigned)(thw[1] >> 32));
     return SDVGN_E_STATE;
@@ -2172,7 +2164,6 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     const bool reuse_after_reject = (flags & 4) != 0;      // opt-in: the solve after a rejected step reuses the stitched system (see header)
     const bool no_spec_solve = (flags & 16) != 0;          // A/B and tests: do not solve the rejected case ahead on the side stream
     e->pend_sel_valid = e->pend_rc_valid = false;           // nothing of an earlier (failed) call is carried over
-    e->reduce_pending = false;
     e->time_lin = (flags & 8) != 0;                          // measurement: event pair around every k_ef_linearize launch
     e->lin_ev_used = 0; e->lin_ms.clear();
     struct TimeLinGuard { sdvgn_ef* e; ~TimeLinGuard() { e->time_lin = false; } } time_lin_guard{e};
@@ -2282,7 +2273,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         const bool from_spec = spec_use;                                                  // the predecessor was rejected and this very solve ran ahead
         spec_use = false;
         const int use_buf = e->spec_last_buf, use_seq = e->spec_last_seq;
-        if (from_spec) { e->reduce_pending = false; if ((rc = ef_launch_spec_rest(e, iteration, lambda, stepsize))) return rc; }
+        if (from_spec) { if ((rc = ef_launch_spec_rest(e, iteration, lambda, stepsize))) return rc; }
         else if ((rc = ef_launch_solve(e, iteration, lambda, /*do_step=*/true, stepsize, reuse, /*accumulated=*/pre_accumulated || onecoll))) return rc;
         pre_accumulated = false;
         ef_swap_point_copies(e);                                                          // the stepped idepths are the ones every later launch reads
@@ -2292,8 +2283,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         e->A.calib = e->calib_dev + st_trial;
         ef_select_new_set(e, 1 - e->new_cur, e->new_cur);                                 // trial linearisation goes to the other set
         th_idx.push_back(e->th_log_n % kThLog);
-        // ... and this body's own rejected case goes to the side stream now: same system (it is in SolveSys::tri), 100 x the damping, next iteration;
-        // beside it the threshold select of the trial that is about to be linearised (it waits for that trial's accept test)
+        // ... and this body's own rejected case goes to the side stream now: same system (it is in SolveSys::tri), 100 x the damping, next iteration
         spec_pending = false;
         if (spec_enabled && !zero_differs && e->sys_valid && iteration + 1 < mnumOptIts) {
             if ((rc = ef_launch_spec_solve(e, iteration + 1, lambda * 1e2, /*main_solve_in_flight=*/!from_spec))) return rc;

@@ -27,4 +27,3 @@ print("\n".join(out[:14]))
 PY
 SDVGN_PMC_SAFE=1 SDVGN_BENCH_ARITH=0 timeout 600 python tools/pmc_linearize.py > gpurun_out/${R}_linearize_counters_exact.txt 2>&1
 tail -20 gpurun_out/${R}_linearize_counters_exact.txt
-timeout 900 bash tools/pmc_loop_kernels.sh > /dev/null 2>&1; tail -5 gpurun_out/r04_loop_kernel_counters.txt
