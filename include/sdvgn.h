@@ -380,7 +380,15 @@ int sdvgn_ef_optimize(sdvgn_ef* ef, int mnumOptIts, int flags /* bit0: run exact
                       (same results, bit for bit -- tests/test_backend_gpu.py); bit2 (opt-in): the body that follows a rejected step
                       works on the state its predecessor's normal equations were built on, so it re-uses the stitched HA/bA/Hsc/bsc and the
                       per-point Schur terms (only lambda changed) instead of accumulating again -- same trace and final state, bit for bit;
-                      bit3 (measurement): a HIP event pair around every k_ef_linearize launch of the call, sdvgn_ef_get_linearize_times */,
+                      bit3 (measurement): a HIP event pair around every k_ef_linearize launch of the call, sdvgn_ef_get_linearize_times;
+                      bit4 (A/B, tests): do NOT solve the rejected case of every body ahead.  By default, while a trial step is linearised, one
+                      workgroup on the library's side stream factors the system the body has just solved with the damping a rejection would
+                      bring (lambda * 100, iteration + 1: FullSystemOptimize.cpp:446-458 solves the SAME normal equations again); a rejected
+                      step is then followed by resubstitute + step + linearise only.  Same trace and final state, bit for bit.  Where the
+                      side stream is not served beside the main one (a serialising profiler) the look-ahead gives up after a bounded wait
+                      and the loop solves the rejected case itself; nothing fails.
+                      Environment: SDVGN_FUSED_APPLY=1 lets the linearise leave applyRes in second copies of the planes it writes (what
+                      sdvgn_ef_optimize_lockstep always does) instead of apply workgroups in the statistics launch -- same results */,
                       double* trace, int trace_stride, int trace_cap);
 /* trace rows (continued): if trace_stride > 7 + (4+6nF), column 7 + (4+6nF) holds the newest frame's frameEnergyTH as the trial
  * linearizeAll of that iteration left it.
