@@ -45,3 +45,24 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".inc", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liborc" not in txt, f
+
+
+def test_batch_entry_points_check_their_arguments_without_a_gpu(sdvgn_lib):
+    """sdvgn_ef_optimize_batch / _lockstep refuse NULL tables, B out of range, NULL handles and a trace without a shape before anything touches
+    a device (no compute call is made here)."""
+    import ctypes as C
+    L = sdvgn_lib
+    E_ARG = -10001
+    L.sdvgn_ef_optimize_lockstep.restype = C.c_int
+    L.sdvgn_ef_optimize_lockstep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.sdvgn_ef_optimize_batch.restype = C.c_int
+    L.sdvgn_ef_optimize_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    arr = (C.c_void_p * 2)(None, None)
+    for B in (0, -1, 257):
+        assert L.sdvgn_ef_optimize_lockstep(C.cast(arr, C.c_void_p), B, 6, 0, None, None, 0, 0) == E_ARG
+        assert L.sdvgn_ef_optimize_batch(C.cast(arr, C.c_void_p), B, 6, 0, None) == E_ARG
+    assert L.sdvgn_ef_optimize_lockstep(None, 2, 6, 0, None, None, 0, 0) == E_ARG
+    assert L.sdvgn_ef_optimize_batch(None, 2, 6, 0, None) == E_ARG
+    assert L.sdvgn_ef_optimize_lockstep(C.cast(arr, C.c_void_p), 2, 6, 0, None, None, 0, 0) == E_ARG      # NULL handles
+    assert L.sdvgn_ef_optimize_batch(C.cast(arr, C.c_void_p), 2, 6, 0, None) == E_ARG
+    assert L.sdvgn_ef_optimize_lockstep(C.cast(arr, C.c_void_p), 2, -1, 0, None, None, 0, 0) == E_ARG     # negative body count
