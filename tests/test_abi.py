@@ -66,3 +66,23 @@ def test_batch_entry_points_check_their_arguments_without_a_gpu(sdvgn_lib):
     assert L.sdvgn_ef_optimize_lockstep(C.cast(arr, C.c_void_p), 2, 6, 0, None, None, 0, 0) == E_ARG      # NULL handles
     assert L.sdvgn_ef_optimize_batch(C.cast(arr, C.c_void_p), 2, 6, 0, None) == E_ARG
     assert L.sdvgn_ef_optimize_lockstep(C.cast(arr, C.c_void_p), 2, -1, 0, None, None, 0, 0) == E_ARG     # negative body count
+
+
+def test_batch_entry_points_refuse_host_only_handles(sdvgn_lib):
+    """Host-only handles (device -1: the CPU side of the multi-GPU logic) hold no device window: the batched optimize refuses them -- the
+    lock-step form with SDVGN_E_ARG, the per-window form with the error of sdvgn_ef_optimize -- instead of falling back to anything on the CPU."""
+    import ctypes as C
+    L = sdvgn_lib
+    hs = [C.c_void_p(), C.c_void_p()]
+    for h in hs:
+        assert L.sdvgn_ef_create(C.byref(h), -1, 64, 48, 16, None) == 0
+    arr = (C.c_void_p * 2)(hs[0], hs[1])
+    L.sdvgn_ef_optimize_lockstep.restype = C.c_int
+    L.sdvgn_ef_optimize_lockstep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.sdvgn_ef_optimize_batch.restype = C.c_int
+    L.sdvgn_ef_optimize_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    assert L.sdvgn_ef_optimize_lockstep(C.cast(arr, C.c_void_p), 2, 6, 0, None, None, 0, 0) == -10001
+    assert L.sdvgn_ef_optimize_batch(C.cast(arr, C.c_void_p), 2, 6, 0, None) < 0
+    assert L.sdvgn_ef_optimize_batch(C.cast(arr, C.c_void_p), 1, 6, 0, None) < 0
+    for h in hs:
+        L.sdvgn_ef_destroy(h)
