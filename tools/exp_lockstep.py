@@ -9,10 +9,11 @@ def main():
     W = syn.make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=syn.KITTI00, state_sigma=1e-3, idepth_sigma=0.01)
     Bs = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,2,4,8,16").split(",")]
     reps = 6
+    modes = (sys.argv[2] if len(sys.argv) > 2 else "sequential,threads,lockstep").split(",")
     for B in Bs:
         hs = [api.EnergyFunctional(W.w, W.h, max_points=W.nP, stream=api.EnergyFunctional.STREAM_OWN).load(W) for _ in range(B)]
-        res = {}
-        for mode in ("sequential", "threads", "lockstep"):
+        res = {m: float("nan") for m in ("sequential", "threads", "lockstep")}
+        for mode in modes:
             if mode == "threads":
                 os.environ["SDVGN_BATCH_THREADS"] = "1"
             else:
