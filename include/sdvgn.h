@@ -428,6 +428,67 @@ int sdvgn_ef_marginalize_frame(sdvgn_ef* ef, int idx, double* HM_out, double* bM
 /* EFResidual::res_toZeroF (nR x 2) and isLinearized (nR), in the order of sdvgn_ef_set_residuals (tests). */
 int sdvgn_ef_get_res_toZero(sdvgn_ef* ef, float* res_toZero2, unsigned char* isLinearized);
 
+/* ---- the window kept resident from key-frame to key-frame (csrc/backend_window.inc) -------------------------------------------------
+ * The reference never rebuilds its graph; between two FullSystem::optimize calls it MUTATES it (EnergyFunctional.h:51-58).  These entry
+ * points mirror those members, so that a key-frame costs one image upload and a few hundred kB of edits instead of every table and every
+ * image again (the whole-plane setters above).  Edits are collected on the host; sdvgn_ef_make_idx -- EnergyFunctional::makeIDX, the
+ * reference's own commit point (EnergyFunctional.cpp:761-782) -- applies them ON THE DEVICE (one gather pass over the per-point planes and the
+ * flags / state / matcher planes, new rows from one staged upload).  Until the commit every other entry point sees the window of the last
+ * commit.  After it the tables are bit-identical with a reload of the same graph in the same order through the setters above.
+ *   Points are addressed by stable ids (sdvgn_ef_insert_points returns them; a window loaded through sdvgn_ef_set_points has id = index),
+ *   frames by their CURRENT index (like EFFrame::idx, renumbered by a removal), residuals by (point id, target frame index).
+ *   Inside a host frame the points keep EFFrame::points' order: insertPoint appends, removePoint moves the LAST point into the hole
+ *   (EnergyFunctional.cpp:414-432, 597-620).  sdvgn_ef_get_point_ids gives the dense order after a commit; per-point getters and the
+ *   slot tables (slot = target * nP + dense index) follow it.
+ *   Surviving points keep what the device holds (the inverse depths of the last optimize), surviving residuals their state_state / matcher /
+ *   isActive; Jacobians and energies restart from zero like after sdvgn_ef_set_residuals (the next optimize re-linearises everything).  A
+ *   residual with a fixed linearisation cannot be carried over a commit (the reference's live inside ONE flagPointsForRemoval ->
+ *   marginalizePointsF pair, FullSystem.cpp:771-800): the next compute call fails with SDVGN_E_STATE.  Single-rank handles only.
+ *
+ * EFFrame* EnergyFunctional::insertFrame(FrameHessian*, CalibHessian*)  EnergyFunctional.cpp:352-398: the frame gets index nF (returned);
+ * HM / bM grow by six zero rows / columns (:363-368); its level-0 image -- dI_aos3 (FrameHessian::dI) or, if NULL, built on the device from
+ * `image` like FrameHessian::makeImages -- goes to a free image slot now (asynchronous on the handle's stream; the buffer may be reused
+ * after the next sdvgn_ef_make_idx). */
+int sdvgn_ef_insert_frame(sdvgn_ef* ef, const double* evalPT7, const double* state10, const double* state_zero10, int frameID, float ab_exposure,
+                          float frameEnergyTH, const float* dI_aos3, const float* image);
+/* void EnergyFunctional::marginalizeFrame(EFFrame*)  EnergyFunctional.cpp:434-512: HM, bM <- the Schur complement without the frame
+ * (sdvgn_ef_marginalize_frame's algebra on the edited window; or the caller's own HM_new / bM_new, (4+6(nF-1))^2 and 4+6(nF-1) doubles),
+ * the frames behind it move down by one (:495-503), its image slot is free.  Points it still hosts and residuals that still target it
+ * leave with it (the reference has dropped or marginalised them before: FullSystemMarginalize.cpp). */
+int sdvgn_ef_remove_frame(sdvgn_ef* ef, int idx, const double* HM_new, const double* bM_new);
+/* FrameHessian::setState / setEvalPT of the current frames ([nF][7], [nF][10], [nF][10], [nF]) without touching the tables: what the host
+ * loop changed since the last optimize (e.g. makeKeyFrame's setEvalPT_scaled of the new frame, FullSystem.cpp:1047).  Follow with
+ * sdvgn_ef_make_idx, sdvgn_ef_set_adjoints, sdvgn_ef_set_precalc. */
+int sdvgn_ef_update_frames(sdvgn_ef* ef, int nF, const double* evalPT7, const double* state10, const double* state_zero10, const float* ab_exposure);
+/* EFPoint* EnergyFunctional::insertPoint(PointHessian*)  :414-432, n points (arguments as sdvgn_ef_set_points); point_id_out[n] (may be NULL) */
+int sdvgn_ef_insert_points(sdvgn_ef* ef, int n, const int* host, const float* u, const float* v, const float* idepth, const float* idepth_zero,
+                           const float* color8, const float* weights8, const unsigned char* hasDepthPrior, const unsigned char* isFromSensor,
+                           int* point_id_out);
+/* void EnergyFunctional::removePoint(EFPoint*)  :597-620 (what dropPointsF :578-595 and marginalizePointsF :568-574 do to their points):
+ * the points leave with all their residuals */
+int sdvgn_ef_remove_points(sdvgn_ef* ef, int n, const int* point_id);
+/* EFResidual* EnergyFunctional::insertResidual(PointFrameResidual*)  :400-412: state_state, hasMatcher + matcher pixel as in
+ * sdvgn_ef_set_residuals; a new residual is neither linearised nor active.  Between two commits a (point, target) pair may be inserted once,
+ * updated once and dropped once; the commit applies all inserts, then all updates, then all drops. */
+int sdvgn_ef_insert_residuals(sdvgn_ef* ef, int n, const int* point_id, const int* target, const int* state_state, const unsigned char* hasMatcher,
+                              const double* matcher_xy);
+/* state_state and matcher of residuals that exist already (PointFrameResidual::findMatches gives an old residual its matcher when the
+ * key-frame that brings one arrives, FullSystem.cpp:1121-1133); residuals that do not exist are left alone */
+int sdvgn_ef_update_residuals(sdvgn_ef* ef, int n, const int* point_id, const int* target, const int* state_state, const unsigned char* hasMatcher,
+                              const double* matcher_xy);
+/* void EnergyFunctional::dropResidual(EFResidual*)  :578-595 */
+int sdvgn_ef_drop_residuals(sdvgn_ef* ef, int n, const int* point_id, const int* target);
+/* void EnergyFunctional::makeIDX()  :761-782: the edits since the last commit become the window.  Follow with sdvgn_ef_set_marg_prior (only if
+ * the prior changed outside sdvgn_ef_remove_frame, e.g. marginalizePointsF on the host), sdvgn_ef_set_adjoints, sdvgn_ef_set_precalc. */
+int sdvgn_ef_make_idx(sdvgn_ef* ef);
+/* id of the point at every dense index [nP]; returns nP */
+int sdvgn_ef_get_point_ids(sdvgn_ef* ef, int* id_of_index);
+/* the residual tables by slot (slot = target * nP + dense point index), nF * nP entries each, any output may be NULL: exists, state_state,
+ * state_NewState, state_energy, state_NewEnergy, state_NewEnergyWithOutlier, isActiveAndIsGoodNEW.  Returns nF * nP.  (On a handle whose
+ * window was edited in place sdvgn_ef_optimize_finish's `removed` output is such a table too: there is no caller-side residual list.) */
+int sdvgn_ef_get_residual_table(sdvgn_ef* ef, unsigned char* exists, signed char* state_state, signed char* state_new, float* energy, float* energy_new,
+                                float* energy_with_outlier, unsigned char* isActive);
+
 /* state after optimize: CalibHessian::value_scaled, FrameHessian::state (nF x 10), PointHessian::idepth (nP) */
 int sdvgn_ef_get_state(sdvgn_ef* ef, double* value_scaled4, double* state10, float* idepth);
 /* wall time (microseconds, host steady_clock) of every loop body of the last sdvgn_ef_optimize call; returns their number */

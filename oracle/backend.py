@@ -367,6 +367,86 @@ class RefEF(OracleEF):
         R.ref_ef_get_removed(self.h_, removed)
         return rmse, steps, removed, log
 
+    # ---- the key-frame cycle around optimize, driven through the reference's own members (oracle/ref_glue_ef.cpp) ----
+    def set_levels(self, levels):
+        """pyramid levels of this world, BEFORE load (default 1); keyframe_tail's setCoarseTrackingRef needs >= 2"""
+        self.L._L.ref_ef_set_levels.argtypes = [vp, C.c_int]
+        self.L._L.ref_ef_set_levels(self.h_, int(levels))
+        return self
+
+    def keyframe_tail(self, its=6, flag_frames=None):
+        """FullSystem::makeKeyFrame from its optimize call on (FullSystem.cpp:1133-1178): optimize, removeOutliers, setCoarseTrackingRef of the
+        next key-frame's tracker, flagPointsForRemoval, dropPointsF, getNullspaces, marginalizePointsF, marginalizeFrame of the frames flagged
+        in `flag_frames` (indices into the window).  Returns what optimize_full returns; afterwards nF is the window that is left, per-point
+        getters give NaN for points that left."""
+        import re
+        R = self.L._L
+        R.ref_ef_keyframe_tail.argtypes = [vp, C.c_int, u8p]
+        R.ref_ef_keyframe_tail.restype = C.c_double
+        R.ref_ef_window_frames.argtypes = [vp]
+        R.ref_ef_last_seconds.restype = C.c_double
+        fl = np.zeros(self.nF, np.uint8)
+        if flag_frames is not None:
+            fl[list(flag_frames)] = 1
+        rmse = R.ref_ef_keyframe_tail(self.h_, int(its), fl)
+        self.last_seconds = R.ref_ef_last_seconds()
+        self.nF = R.ref_ef_window_frames(self.h_)
+        n = R.ref_ef_last_log(self.h_, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        R.ref_ef_last_log(self.h_, buf, n + 1)
+        log = buf.value.decode(errors="replace")
+        steps = [(m.group(1) == "ACCEPT", int(m.group(2)), float(m.group(3)))
+                 for m in re.finditer(r"(ACCEPT|REJECT) (\d+) \(L [^)]*\): \tA\(([-0-9.einfa]+)\)", log)]
+        removed = np.zeros(self.nR, np.uint8)
+        R.ref_ef_get_removed(self.h_, removed)
+        return rmse, steps, removed, log
+
+    def point_hosts(self):
+        """index of every point's host frame in the window as it is now (-1: the point has left)"""
+        R = self.L._L
+        R.ref_ef_point_hosts.argtypes = [vp, i32p]
+        out = np.zeros(self.nP, np.int32)
+        R.ref_ef_point_hosts(self.h_, out)
+        return out
+
+    def tracking_ref(self, lvl=0):
+        """the template setCoarseTrackingRef built for the next key-frame (CoarseTracker::makeCoarseDepthL0): (pc_n[5], u, v, idepth, color) of level lvl"""
+        R = self.L._L
+        R.ref_ef_tracking_ref.argtypes = [vp, C.c_int, i32p, f32p, f32p, f32p, f32p]
+        n5 = np.zeros(5, np.int32)
+        cap = self.w * self.h
+        u, v, d, c = (np.zeros(cap, np.float32) for _ in range(4))
+        R.ref_ef_tracking_ref(self.h_, int(lvl), n5, u, v, d, c)
+        n = int(n5[lvl])
+        return n5, u[:n], v[:n], d[:n], c[:n]
+
+    def append_frame(self, evalPT7, state10, state_zero10, frameID, ab_exposure, frameEnergyTH, pyr0):
+        """a new key-frame at the end of the window (makeKeyFrame's insertFrame, FullSystem.cpp:1071-1077)"""
+        c = np.ascontiguousarray
+        self.L.orc_ef_set_frames(self.h_, 1, c(evalPT7, np.float64).reshape(-1), c(state10, np.float64).reshape(-1), c(state_zero10, np.float64).reshape(-1),
+                                 c([frameID], np.int32), c([ab_exposure], np.float32), c([frameEnergyTH], np.float32))
+        self.L.orc_ef_set_frame_image(self.h_, self.nF, c(pyr0, np.float32).reshape(-1))
+        self.nF += 1
+        return self.nF - 1
+
+    def append_points(self, host, u, v, idepth, idepth_zero, color, weights, hasDepthPrior, isFromSensor):
+        """new points (activatePointsMT's insertPoint); host = index in the window as it is now.  Returns their indices (over all points ever set)."""
+        c = np.ascontiguousarray
+        n = len(host)
+        self.L.orc_ef_set_points(self.h_, n, c(host, np.int32), c(u, np.float32), c(v, np.float32), c(idepth, np.float32), c(idepth_zero, np.float32),
+                                 c(color, np.float32).reshape(-1), c(weights, np.float32).reshape(-1), c(hasDepthPrior, np.uint8), c(isFromSensor, np.uint8))
+        self.nP += n
+        return np.arange(self.nP - n, self.nP)
+
+    def append_residuals(self, point, target, hasMatcher, matcher, state=None):
+        """new residuals (insertResidual); point = index over all points ever set, target = index in the window as it is now"""
+        c = np.ascontiguousarray
+        n = len(point)
+        st = np.zeros(n, np.int32) if state is None else c(state, np.int32)
+        z = np.zeros(n, np.uint8)
+        self.L.orc_ef_set_residuals(self.h_, n, c(point, np.int32), c(target, np.int32), st, c(hasMatcher, np.uint8), c(matcher, np.float64).reshape(-1), z, z)
+        self.nR += n
+
     def point_stats(self):
         rb = np.zeros(self.nP, np.float32)
         ng = np.zeros(self.nP, np.int32)

@@ -68,6 +68,64 @@ class DropinEF(RefEF):
         super().__del__()
 
 
+_OPT_LIB = None
+
+
+def dropin_opt_lib():
+    """oracle/_ref/libref_dropin_opt.so (oracle/Makefile target `dropin_opt`): as libref_dropin.so, plus FullSystem::optimize itself replaced by
+    oracle/dropin/FullSystemOptimizeGPU.cpp -- the resident-window form; None when it has not been built"""
+    global _OPT_LIB
+    if _OPT_LIB is not None:
+        return _OPT_LIB
+    p = os.path.join(_HERE, "_ref", "libref_dropin_opt.so")
+    if not os.path.exists(p):
+        return None
+    from sdv_loam_amd import api
+    api.load_library()
+    L = C.CDLL(p)
+    L.sdvgn_dropin_opt_calls.restype = C.c_ulonglong
+    L.sdvgn_dropin_opt_calls.argtypes = [C.c_void_p]
+    L.sdvgn_dropin_opt_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.sdvgn_dropin_opt_release.argtypes = [C.c_void_p]
+    L.ref_ef_full_system.restype = C.c_void_p
+    L.ref_ef_full_system.argtypes = [C.c_void_p]
+    _OPT_LIB = L
+    return L
+
+
+class DropinOptEF(RefEF):
+    """RefEF on libref_dropin_opt.so: the reference's FullSystem::optimize IS libsdvgn's loop on a window resident on the GPU; everything
+    around it (removeOutliers, flagPointsForRemoval, marginalizePointsF, marginalizeFrame, setCoarseTrackingRef ...) is the reference's own
+    host code working on what the drop-in wrote back."""
+
+    @classmethod
+    def _raw_lib(cls):
+        L = dropin_opt_lib()
+        if L is None:
+            raise RuntimeError("oracle/_ref/libref_dropin_opt.so has not been built (needs /root/reference; `make -C oracle dropin_opt`)")
+        return L
+
+    def gpu_calls(self):
+        R = self.L._L
+        return int(R.sdvgn_dropin_opt_calls(R.ref_ef_full_system(self.h_)))
+
+    def gpu_stats(self):
+        """dict: images / points / residuals sent since creation, and the three phases of the last call in microseconds"""
+        R = self.L._L
+        out = (C.c_double * 9)()
+        R.sdvgn_dropin_opt_stats(R.ref_ef_full_system(self.h_), out)
+        k = ("frames_uploaded", "points_inserted", "points_removed", "residuals_inserted", "residuals_dropped", "residuals_updated", "us_sync", "us_gpu", "us_writeback")
+        return dict(zip(k, list(out)))
+
+    def __del__(self):
+        try:
+            R = self.L._L
+            R.sdvgn_dropin_opt_release(R.ref_ef_full_system(self.h_))
+        except Exception:
+            pass
+        super().__del__()
+
+
 _DROPIN_TRACKER_LIB = None
 
 

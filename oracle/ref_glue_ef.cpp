@@ -10,9 +10,12 @@
 // way to build a window without its ROS front end).  No arithmetic of the path is restated here.
 #include "ref_common.hpp"
 
+#include <execinfo.h>
 #include <map>
 #include <set>
+#include <signal.h>
 #include <time.h>
+#include <unistd.h>
 
 using namespace refglue;
 
@@ -66,12 +69,18 @@ void* ref_ef_create(int w, int h) {
     return E;
 }
 
+// pyramid levels of the world (default 1: the back end works on level 0 only).  CoarseTracker::makeCoarseDepthL0 touches levels 0 and 1
+// whatever pyrLevelsUsed says (CoarseTracker.cpp:324-351), so a world that runs setCoarseTrackingRef (ref_ef_keyframe_tail) needs >= 2.
+// Before ref_ef_set_calib (which constructs the FullSystem and its trackers).
+void ref_ef_set_levels(void* e, int levels) { RefEF* E = (RefEF*)e; if (!E->fs) E->g.levels = levels; }
+
 void ref_ef_destroy(void* e) {
     RefEF* E = (RefEF*)e;
     E->on();
     if (E->fs) {
+        std::vector<FrameHessian*> alive = E->fs->frameHessians;    // (FullSystem::marginalizeFrame has deleted the frames that left the window)
         std::string sink = capture_stdout([&] { delete E->fs; });   // ~FullSystem deletes ef (which detaches every EF* back pointer)
-        for (FrameHessian* fh : E->fhs) delete fh;                     // ~FrameHessian releases its points and their residuals
+        for (FrameHessian* fh : alive) delete fh;                      // ~FrameHessian releases its points and their residuals
         for (FrameShell* s : E->shells) delete s;
     }
     delete E;
@@ -102,15 +111,16 @@ void ref_ef_set_frames(void* e, int nF, const double* evalPT7, const double* sta
     RefEF* E = (RefEF*)e;
     E->on();
     FullSystem* fs = E->fs;
-    assert(fs && E->fhs.empty());
+    assert(fs);
+    // (called again on a loaded window it APPENDS key-frames, like makeKeyFrame does, FullSystem.cpp:1071-1075: index = position in the window)
     for (int i = 0; i < nF; ++i) {
         FrameShell* sh = new FrameShell();
-        sh->id = i; sh->incoming_id = i;
+        sh->id = (int)E->shells.size(); sh->incoming_id = sh->id;
         FrameHessian* fh = new FrameHessian();
         fh->shell = sh;
         fh->ab_exposure = ab_exposure[i];
         fh->frameID = frameID[i];
-        fh->idx = i;
+        fh->idx = (int)fs->frameHessians.size();
         fh->dI = 0;
         for (int l = 0; l < PYR_LEVELS; ++l) { fh->dIp[l] = 0; fh->absSquaredGrad[l] = 0; }
         fh->worldToCam_evalPT = pose_from7(evalPT7 + 7 * i);
@@ -157,9 +167,9 @@ void ref_ef_set_points(void* e, int nP, const int* host, const float* u, const f
                        const float* color8, const float* weights8, const uint8_t* hasDepthPrior, const uint8_t* isFromSensor) {
     RefEF* E = (RefEF*)e; E->on();
     FullSystem* fs = E->fs;
-    assert(E->phs.empty());
+    // (called again it APPENDS points -- activatePointsMT's insertPoint, FullSystem.cpp:690-699; host = index in the window as it is now)
     for (int i = 0; i < nP; ++i) {
-        FrameHessian* fh = E->fhs[host[i]];
+        FrameHessian* fh = fs->frameHessians[host[i]];
         // ImmaturePoint constructor (ImmaturePoint.cpp:8-40): colour and weights of the 8 pattern pixels from the host image
         ImmaturePoint ip((int)u[i], (int)v[i], fh, 1, &fs->Hcalib);
         ip.idepth_min = ip.idepth_max = idepth[i];
@@ -200,19 +210,19 @@ void ref_ef_set_residuals(void* e, int nR, const int* point, const int* target, 
                           const double* matcher2, const uint8_t* isLinearized, const uint8_t* isActive) {
     RefEF* E = (RefEF*)e; E->on();
     FullSystem* fs = E->fs;
-    assert(E->prs.empty());
+    // (called again it APPENDS residuals; point = index over all points ever set, target = index in the window as it is now)
     // the matcher table of each point first: PointFrameResidual's constructor looks its target up there (Residuals.cpp:46-58)
     for (int i = 0; i < nR; ++i) {
         if (!hasMatcher[i]) continue;
         PointHessian* ph = E->phs[point[i]];
-        FrameHessian* tg = E->fhs[target[i]];
+        FrameHessian* tg = fs->frameHessians[target[i]];
         ph->matcher.targetFrames.push_back(tg);
         ph->matcher.pxs.push_back(Eigen::Vector2d(matcher2[2 * i], matcher2[2 * i + 1]));
         ph->matcher.frameIDs.push_back(tg->shell->id);
     }
     for (int i = 0; i < nR; ++i) {
         PointHessian* ph = E->phs[point[i]];
-        PointFrameResidual* r = new PointFrameResidual(ph, ph->host, E->fhs[target[i]]);
+        PointFrameResidual* r = new PointFrameResidual(ph, ph->host, fs->frameHessians[target[i]]);
         r->setState((ResState)state_state[i]);
         ph->residuals.push_back(r);
         fs->ef->insertResidual(r);
@@ -228,7 +238,7 @@ void ref_ef_set_residuals(void* e, int nR, const int* point, const int* target, 
         E->r_point.push_back(point[i]);
     }
     fs->ef->makeIDX();
-    E->removed_by_finish.assign((size_t)nR, 0);
+    E->removed_by_finish.assign(E->prs.size(), 0);
 }
 
 void ref_ef_set_marg_prior(void* e, const double* HM, const double* bM) {
@@ -340,8 +350,10 @@ void ref_ef_get_center_projected(void* e, float* out3) {
 void ref_ef_get_points(void* e, float* out9) {
     RefEF* E = (RefEF*)e;
     for (size_t i = 0; i < E->phs.size(); ++i) {
-        const PointHessian* ph = E->phs[i]; const EFPoint* p = ph->efPoint;
+        const PointHessian* ph = E->phs[i];
         float* o = out9 + 9 * i;
+        if (!ph) { for (int k = 0; k < 9; ++k) o[k] = NAN; continue; }
+        const EFPoint* p = ph->efPoint;
         o[0] = p->Hdd_accAF; o[1] = p->bd_accAF;
         for (int k = 0; k < 4; ++k) o[2 + k] = p->Hcd_accAF[k];
         o[6] = p->HdiF; o[7] = p->bdSumF; o[8] = ph->step;
@@ -388,7 +400,7 @@ void ref_ef_get_state(void* e, double* value_scaled4, double* state10, float* id
     RefEF* E = (RefEF*)e;
     for (int i = 0; i < 4; ++i) value_scaled4[i] = E->fs->Hcalib.value_scaled[i];
     for (size_t h = 0; h < E->fhs.size(); ++h) for (int i = 0; i < 10; ++i) state10[10 * h + i] = E->fhs[h]->state[i];
-    for (size_t i = 0; i < E->phs.size(); ++i) idepth[i] = E->phs[i]->idepth;
+    for (size_t i = 0; i < E->phs.size(); ++i) idepth[i] = E->phs[i] ? E->phs[i]->idepth : NAN;      // (NaN: the point has left the window)
 }
 void ref_ef_get_marg_prior(void* e, double* HM, double* bM) { RefEF* E = (RefEF*)e; to_rowmajor(E->fs->ef->HM, HM); to_rowmajor(E->fs->ef->bM, bM); }
 void ref_ef_get_res_toZero(void* e, float* out2, uint8_t* isLinearized) {
@@ -519,7 +531,7 @@ int ref_ef_last_log(void* e, char* buf, int cap) {
 void ref_ef_get_removed(void* e, uint8_t* removed) { RefEF* E = (RefEF*)e; std::memcpy(removed, E->removed_by_finish.data(), E->removed_by_finish.size()); }
 void ref_ef_get_point_stats(void* e, float* maxRelBaseline, int* numGoodResiduals) {
     RefEF* E = (RefEF*)e;
-    for (size_t i = 0; i < E->phs.size(); ++i) { maxRelBaseline[i] = E->phs[i]->maxRelBaseline; numGoodResiduals[i] = E->phs[i]->numGoodResiduals; }
+    for (size_t i = 0; i < E->phs.size(); ++i) { maxRelBaseline[i] = E->phs[i] ? E->phs[i]->maxRelBaseline : NAN; numGoodResiduals[i] = E->phs[i] ? E->phs[i]->numGoodResiduals : -1; }
 }
 // FullSystem::optimizeImmaturePoint (FullSystemOptPoint.cpp:18-185) for n immature points against the frames / precalc of the handle
 // (ref_ef_set_precalc first).  result[i]: 0 = not well constrained, -1 = rejected, 1 = activated (idepth[i] = its idepth); res_state[n][nF]
@@ -547,6 +559,81 @@ void ref_ef_optimize_immature(void* e, int n, const int* host, const float* u, c
         for (int t = 0; t < nF; ++t) if (t != host[i]) res_state[(size_t)i * nF + t] = (int)tr[k++].state_state;
     }
 }
+
+// The part of FullSystem::makeKeyFrame that follows the activation of new points (FullSystem.cpp:1133-1178), the reference's own statements in
+// the reference's own order: optimize, removeOutliers, setCoarseTrackingRef of the tracker for the next key-frame (makeCoarseDepthL0 reads
+// centerProjectedTo, lastResiduals and EFPoint::HdiF of what optimize left), flagPointsForRemoval, dropPointsF, getNullspaces,
+// marginalizePointsF, marginalizeFrame for every flagged frame.  flag[k] != 0 marks window frame k like flagFramesForMarginalization would.
+// Returns optimize's return value.  Afterwards the handle's frame / point lists describe the window that is left: points that were
+// dropped or marginalised read as NaN / -1 in the getters.
+static void refresh_after_keyframe(RefEF* E) {
+    FullSystem* fs = E->fs;
+    std::set<PointHessian*> live;
+    for (FrameHessian* fh : fs->frameHessians) for (PointHessian* ph : fh->pointHessians) live.insert(ph);
+    for (size_t i = 0; i < E->phs.size(); ++i) if (E->phs[i] && !live.count(E->phs[i])) E->phs[i] = nullptr;
+    std::set<PointFrameResidual*> liver;
+    for (PointHessian* ph : live) for (PointFrameResidual* r : ph->residuals) liver.insert(r);
+    for (size_t i = 0; i < E->prs.size(); ++i) if (E->prs[i] && !liver.count(E->prs[i])) E->prs[i] = nullptr;
+    E->fhs = fs->frameHessians;
+}
+double ref_ef_keyframe_tail(void* e, int mnumOptIts, const uint8_t* flag) {
+    RefEF* E = (RefEF*)e; E->on();
+    FullSystem* fs = E->fs;
+    std::vector<PointFrameResidual*> before = E->prs;
+    float rmse = 0;
+    setting_debugout_runquiet = false;
+    E->last_log = capture_stdout([&] {
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (size_t k = 0; k < fs->frameHessians.size(); ++k) fs->frameHessians[k]->flaggedForMarginalization = flag && flag[k];
+        static const bool tr = getenv("REF_GLUE_TRACE") != nullptr;
+        if (tr) signal(SIGSEGV, [](int) { void* bt[48]; const int n = backtrace(bt, 48); backtrace_symbols_fd(bt, n, 2); _exit(139); });
+#define KF_STAGE(name) do { if (tr) fprintf(stderr, "[ref glue] key-frame tail: %s\n", name); } while (0)
+        KF_STAGE("optimize");
+        rmse = fs->optimize(mnumOptIts);                                                    // :1134
+        KF_STAGE("removeOutliers");
+        fs->removeOutliers();                                                               // :1138
+        KF_STAGE("setCoarseTrackingRef");
+        fs->coarseTracker_forNewKF->makeK(&fs->Hcalib);                                     // :1143-1144
+        fs->coarseTracker_forNewKF->setCoarseTrackingRef(fs->frameHessians);
+        KF_STAGE("flagPointsForRemoval");
+        fs->flagPointsForRemoval();                                                         // :1152
+        KF_STAGE("dropPointsF");
+        fs->ef->dropPointsF();
+        fs->getNullspaces(fs->ef->lastNullspaces_pose, fs->ef->lastNullspaces_scale, fs->ef->lastNullspaces_affA, fs->ef->lastNullspaces_affB);
+        KF_STAGE("marginalizePointsF");
+        fs->ef->marginalizePointsF();
+        KF_STAGE("marginalizeFrame");
+        for (unsigned int i = 0; i < fs->frameHessians.size(); i++)                         // :1169-1171
+            if (fs->frameHessians[i]->flaggedForMarginalization) { fs->marginalizeFrame(fs->frameHessians[i]); i = 0; }
+        KF_STAGE("done");
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        g_last_seconds = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    });
+    setting_debugout_runquiet = true;
+    refresh_after_keyframe(E);
+    E->removed_by_finish.assign(E->prs.size(), 0);
+    for (size_t i = 0; i < E->prs.size(); ++i) E->removed_by_finish[i] = (before[i] && !E->prs[i]) ? 1 : 0;
+    return rmse;
+}
+// the window that is left: number of frames, and for every point ever set the index of its host frame in the window now (-1: the point is gone)
+int ref_ef_window_frames(void* e) { return (int)((RefEF*)e)->fs->frameHessians.size(); }
+void ref_ef_point_hosts(void* e, int* host) {
+    RefEF* E = (RefEF*)e;
+    for (size_t i = 0; i < E->phs.size(); ++i) host[i] = E->phs[i] ? E->phs[i]->host->idx : -1;
+}
+// the tracking template setCoarseTrackingRef built for the next key-frame (CoarseTracker::makeCoarseDepthL0, CoarseTracker.cpp:258-425): pc_n
+// of every level, and level `lvl`'s points (caller allocates w*h floats per array)
+void ref_ef_tracking_ref(void* e, int lvl, int* pc_n5, float* pc_u, float* pc_v, float* pc_idepth, float* pc_color) {
+    RefEF* E = (RefEF*)e;
+    CoarseTracker* ct = E->fs->coarseTracker_forNewKF;
+    for (int l = 0; l < 5; ++l) pc_n5[l] = l < pyrLevelsUsed ? ct->pc_n[l] : 0;
+    const int n = ct->pc_n[lvl];
+    std::memcpy(pc_u, ct->pc_u[lvl], sizeof(float) * n); std::memcpy(pc_v, ct->pc_v[lvl], sizeof(float) * n);
+    std::memcpy(pc_idepth, ct->pc_idepth[lvl], sizeof(float) * n); std::memcpy(pc_color, ct->pc_color[lvl], sizeof(float) * n);
+}
+void ref_ef_get_marg_prior_dim(void* e, int* n) { *n = (int)((RefEF*)e)->fs->ef->HM.rows(); }
+void* ref_ef_full_system(void* e) { return ((RefEF*)e)->fs; }
 
 // the EnergyFunctional object of the window (key of the drop-in's side table, oracle/dropin/EnergyFunctionalGPU.cpp)
 void* ref_ef_energy_functional(void* e) { RefEF* E = (RefEF*)e; return E->fs ? (void*)E->fs->ef : nullptr; }

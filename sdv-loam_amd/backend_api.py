@@ -77,6 +77,17 @@ PROTOTYPES = [
     ("sdvgn_ef_set_allreduce", C.c_int, [vp, vp, vp]),
     ("sdvgn_ef_optimize", C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]),
     ("sdvgn_ef_get_state", C.c_int, [vp, vp, vp, vp]),
+    ("sdvgn_ef_insert_frame", C.c_int, [vp, f64p, f64p, f64p, C.c_int, C.c_float, C.c_float, vp, vp]),
+    ("sdvgn_ef_remove_frame", C.c_int, [vp, C.c_int, vp, vp]),
+    ("sdvgn_ef_update_frames", C.c_int, [vp, C.c_int, f64p, f64p, f64p, f32p]),
+    ("sdvgn_ef_insert_points", C.c_int, [vp, C.c_int, i32p, f32p, f32p, f32p, f32p, f32p, f32p, u8p, u8p, vp]),
+    ("sdvgn_ef_remove_points", C.c_int, [vp, C.c_int, i32p]),
+    ("sdvgn_ef_insert_residuals", C.c_int, [vp, C.c_int, i32p, i32p, i32p, u8p, f64p]),
+    ("sdvgn_ef_update_residuals", C.c_int, [vp, C.c_int, i32p, i32p, i32p, u8p, f64p]),
+    ("sdvgn_ef_drop_residuals", C.c_int, [vp, C.c_int, i32p, i32p]),
+    ("sdvgn_ef_make_idx", C.c_int, [vp]),
+    ("sdvgn_ef_get_point_ids", C.c_int, [vp, vp]),
+    ("sdvgn_ef_get_residual_table", C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
 ]
 
 
@@ -106,9 +117,13 @@ class EnergyFunctional:
         except Exception:
             pass
 
+    def set_calib(self, value_scaled, value_minus_value_zero):
+        self._check(self.L.sdvgn_ef_set_calib(self.h_, np.ascontiguousarray(value_scaled, np.float64), np.ascontiguousarray(value_minus_value_zero, np.float64)))
+
     def load(self, W, raw_images=False):
         c = np.ascontiguousarray
         ck = self._check
+        self.table_mode = False
         self.nF, self.nP, self.nR = W.nF, W.nP, W.nR
         ck(self.L.sdvgn_ef_set_calib(self.h_, c(W.value_scaled, np.float64), c(W.value_minus_value_zero, np.float64)))
         ck(self.L.sdvgn_ef_set_frames(self.h_, W.nF, c(W.evalPT, np.float64).reshape(-1), c(W.state, np.float64).reshape(-1),
@@ -295,9 +310,10 @@ class EnergyFunctional:
         e = C.c_double(0)
         rb = np.zeros(self.nP, np.float32)
         ng = np.zeros(self.nP, np.int32)
-        rm = np.zeros(max(self.nR, 1), np.uint8)
+        table = getattr(self, "table_mode", False)     # a window edited in place: `removed` is a slot table [nF][nP]
+        rm = np.zeros(self.nF * self.nP if table else max(self.nR, 1), np.uint8)
         self._check(self.L.sdvgn_ef_optimize_finish(self.h_, C.byref(e), rb.ctypes.data_as(vp), ng.ctypes.data_as(vp), rm.ctypes.data_as(vp)))
-        return e.value, rb, ng, rm[:self.nR]
+        return e.value, rb, ng, (rm.reshape(self.nF, self.nP) if table else rm[:self.nR])
 
     def frame_energy_th(self):
         th = np.zeros(self.nF, np.float32)
@@ -351,6 +367,77 @@ class EnergyFunctional:
         idp = np.zeros(self.nP, np.float32)
         self._check(self.L.sdvgn_ef_get_state(self.h_, vs.ctypes.data_as(vp), st.ctypes.data_as(vp), idp.ctypes.data_as(vp)))
         return vs, st.reshape(self.nF, 10), idp
+
+
+    # ---- the window edited in place (EnergyFunctional.h:51-58; csrc/backend_window.inc) ----------------------------------------------
+    def insertFrame(self, evalPT7, state10, state_zero10, frameID, ab_exposure, frameEnergyTH, dI=None, image=None):
+        c = np.ascontiguousarray
+        a = None if dI is None else c(dI, np.float32).reshape(-1)
+        b = None if image is None else c(image, np.float32).reshape(-1)
+        self._keep = (a, b)      # (the upload is asynchronous: the buffers live until the commit)
+        idx = self._check(self.L.sdvgn_ef_insert_frame(self.h_, c(evalPT7, np.float64), c(state10, np.float64), c(state_zero10, np.float64), int(frameID),
+                                                       float(ab_exposure), float(frameEnergyTH), None if a is None else a.ctypes.data,
+                                                       None if b is None else b.ctypes.data))
+        return idx
+
+    def removeFrame(self, idx, HM=None, bM=None):
+        h = None if HM is None else np.ascontiguousarray(HM, np.float64)
+        b = None if bM is None else np.ascontiguousarray(bM, np.float64)
+        self._check(self.L.sdvgn_ef_remove_frame(self.h_, int(idx), None if h is None else h.ctypes.data, None if b is None else b.ctypes.data))
+
+    def updateFrames(self, evalPT, state, state_zero, ab_exposure):
+        c = np.ascontiguousarray
+        self._check(self.L.sdvgn_ef_update_frames(self.h_, len(ab_exposure), c(evalPT, np.float64).reshape(-1), c(state, np.float64).reshape(-1),
+                                                  c(state_zero, np.float64).reshape(-1), c(ab_exposure, np.float32)))
+
+    def insertPoints(self, host, u, v, idepth, idepth_zero, color, weights, hasDepthPrior, isFromSensor):
+        c = np.ascontiguousarray
+        n = len(host)
+        ids = np.zeros(max(n, 1), np.int32)
+        self._check(self.L.sdvgn_ef_insert_points(self.h_, n, c(host, np.int32), c(u, np.float32), c(v, np.float32), c(idepth, np.float32), c(idepth_zero, np.float32),
+                                                  c(color, np.float32).reshape(-1), c(weights, np.float32).reshape(-1), c(hasDepthPrior, np.uint8),
+                                                  c(isFromSensor, np.uint8), ids.ctypes.data_as(vp)))
+        return ids[:n]
+
+    def removePoints(self, ids):
+        ids = np.ascontiguousarray(ids, np.int32)
+        self._check(self.L.sdvgn_ef_remove_points(self.h_, len(ids), ids))
+
+    def insertResiduals(self, point_id, target, state=None, hasMatcher=None, matcher=None, update=False):
+        c = np.ascontiguousarray
+        n = len(point_id)
+        state = np.zeros(n, np.int32) if state is None else state
+        hasMatcher = np.ones(n, np.uint8) if hasMatcher is None else hasMatcher
+        fn = self.L.sdvgn_ef_update_residuals if update else self.L.sdvgn_ef_insert_residuals
+        self._check(fn(self.h_, n, c(point_id, np.int32), c(target, np.int32), c(state, np.int32), c(hasMatcher, np.uint8), c(matcher, np.float64).reshape(-1)))
+
+    def dropResiduals(self, point_id, target):
+        c = np.ascontiguousarray
+        self._check(self.L.sdvgn_ef_drop_residuals(self.h_, len(point_id), c(point_id, np.int32), c(target, np.int32)))
+
+    def makeIDX(self, nF=None):
+        """EnergyFunctional::makeIDX: commit the edits; returns the point id at every dense index"""
+        self._check(self.L.sdvgn_ef_make_idx(self.h_))
+        self.nF = self.L.sdvgn_ef_dim(self.h_)
+        self.nF = (self.nF - 4) // 6
+        ids = np.zeros(1 << 20, np.int32)
+        self.nP = self._check(self.L.sdvgn_ef_get_point_ids(self.h_, ids.ctypes.data_as(vp)))
+        self.nR = 0
+        self.table_mode = True
+        self._keep = None
+        return ids[:self.nP].copy()
+
+    def residual_table(self):
+        """the per-slot planes, [nF][nP] each"""
+        n = self.nF * self.nP
+        ex, act = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        st, sn = np.zeros(n, np.int8), np.zeros(n, np.int8)
+        en, enn, ew = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        self._check(self.L.sdvgn_ef_get_residual_table(self.h_, ex.ctypes.data_as(vp), st.ctypes.data_as(vp), sn.ctypes.data_as(vp), en.ctypes.data_as(vp),
+                                                       enn.ctypes.data_as(vp), ew.ctypes.data_as(vp), act.ctypes.data_as(vp)))
+        sh = (self.nF, self.nP)
+        return dict(exists=ex.reshape(sh), state=st.reshape(sh), new_state=sn.reshape(sh), energy=en.reshape(sh), new_energy=enn.reshape(sh),
+                    energy_with_outlier=ew.reshape(sh), active=act.reshape(sh))
 
 
 def optimize_batch(windows, its=6, fixed_its=False):

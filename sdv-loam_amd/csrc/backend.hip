@@ -28,6 +28,7 @@
 #include <cstring>
 #include <new>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #define HIPCHK(expr)                                  \
@@ -63,6 +64,11 @@ struct FrameH {
     int frameID;
     float ab_exposure, frameEnergyTH;
 };
+
+struct WinEdit;   // backend_window.inc
+WinEdit* win_new();
+void win_delete(WinEdit*);
+void win_forget(WinEdit*);
 
 template <typename T>
 int dev_alloc_tagged(T** p, size_t n, const char* tag) { return gmem::dmalloc_impl((void**)p, sizeof(T) * (n ? n : 1), alignof(T), tag) == hipSuccess ? 0 : -1; }
@@ -215,6 +221,11 @@ struct sdvgn_ef {
     bool havePrecalc = false, haveAdjoints = false;
     bool deltaF_nonzero = false, has_linearized = false;   // when both are false the point part of calcLEnergy is exactly 0
     int precalc_flip = 0;                                  // two pinned staging halves -> no host sync per upload
+    // the window edited in place (backend_window.inc): image slot of every frame (identity unless frames were inserted / removed), the edit
+    // state, and table_mode: the residual tables are addressed by slot, there is no caller-side residual list (r_slot empty, nR = 0)
+    uint8_t img_slot[SDVGN_MAX_FRAMES] = {0, 1, 2, 3, 4, 5, 6, 7};
+    WinEdit* win = nullptr;
+    bool table_mode = false;
 };
 
 struct PhaseTimer {   // SDVGN_PROFILE=1: host wall time per phase of the optimize loop, printed by sdvgn_ef_optimize
@@ -274,6 +285,8 @@ static void ef_fill_arrays(sdvgn_ef* e) {
     A.pHddA = e->pHddA; A.pbdA = e->pbdA; A.pHcdA = e->pHcdA; A.pHddL = e->pHddL; A.pbdL = e->pbdL; A.pHcdL = e->pHcdL;
     A.pHdi = e->pHdi; A.pbdSum = e->pbdSum; A.pHcd = e->pHcd; A.pstep = e->pstep;
     A.images = e->images;
+    A.img_slots = 0;
+    for (int t = 0; t < SDVGN_MAX_FRAMES; ++t) A.img_slots |= (unsigned)(e->img_slot[t] & 7) << (4 * t);
     A.dbg_stamps = e->dbg_stamps;
     A.reset_oob = 0;
     A.rflags_w = nullptr; A.rstate_w = nullptr; A.renergy_w = nullptr; A.JpJd_w = nullptr;
@@ -1113,6 +1126,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     HIPCHK(hipMemsetAsync(e->rflags, 0, slots, e->stream));
     HIPCHK(hipMemsetAsync(e->stats_partial, 0, sizeof(double) * 3 * (mp / 64 + 2), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    e->win = win_new();
     ef_fill_arrays(e);
     *out = e;
     return SDVGN_OK;
@@ -1156,6 +1170,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
     if (e->imm_stage) SDVGN_HFREE(e->imm_stage);
     if (e->own_coll && e->coll[0]) SDVGN_DFREE(e->coll[0]);
     if (e->apply_bak.fl) { SDVGN_DFREE(e->apply_bak.fl); SDVGN_DFREE(e->apply_bak.st); SDVGN_DFREE(e->apply_bak.en); SDVGN_DFREE(e->apply_bak.JpJd); }
+    win_delete(e->win);
     if (e->own_stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1164,7 +1179,7 @@ void* sdvgn_ef_stream(sdvgn_ef* e) { return e ? (void*)e->stream : nullptr; }
 const float* sdvgn_ef_frame_image_dev(sdvgn_ef* e, int idx) {
     if (!e || e->host_only || idx < 0 || idx >= e->nF || !e->images) return nullptr;
     if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) return nullptr;   // uploads / pyramid kernels done
-    return e->images + (size_t)idx * e->C.w * e->C.h * 3;
+    return e->images + (size_t)e->img_slot[idx] * e->C.w * e->C.h * 3;
 }
 
 int sdvgn_ef_set_calib(sdvgn_ef* e, const double vs[4], const double vmz[4]) {
@@ -1204,6 +1219,11 @@ int sdvgn_ef_set_frames(sdvgn_ef* e, int nF, const double* evalPT7, const double
     // so that nothing can run on a stale layout before sdvgn_ef_set_points / _set_residuals are called again
     e->nP = 0; e->nR = -1;
     e->hostP0.clear(); e->phost.clear(); e->r_slot.clear();
+    // a reload through the whole-plane setters: frame k's image is slot k again, point ids / frame uids of an edited window are forgotten
+    for (int t = 0; t < SDVGN_MAX_FRAMES; ++t) e->img_slot[t] = (uint8_t)t;
+    e->A.img_slots = 0x76543210u;
+    e->table_mode = false;
+    if (e->win) win_forget(e->win);
     e->win_dirty = e->state_dirty = true; e->sys_valid = false;
     if (!e->host_only) {
         float th[2 * SDVGN_MAX_FRAMES] = {0};
@@ -1250,7 +1270,7 @@ int sdvgn_ef_set_frame_image(sdvgn_ef* e, int idx, const float* dI) {
     if (!e || !dI || idx < 0 || idx >= SDVGN_MAX_FRAMES) return SDVGN_E_ARG;
     EF_DEVICE(e);
     const size_t n = (size_t)e->w * e->h * 3;
-    HIPCHK(hipMemcpyAsync(e->images + n * idx, dI, sizeof(float) * n, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->images + n * e->img_slot[idx], dI, sizeof(float) * n, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return SDVGN_OK;
 }
@@ -1261,7 +1281,7 @@ int sdvgn_ef_set_frame_image_raw(sdvgn_ef* e, int idx, const float* image) {
     const size_t n = (size_t)e->w * e->h;
     HIPCHK(hipMemcpyAsync(e->img_stage, image, sizeof(float) * n, hipMemcpyHostToDevice, e->stream));
     const int qw = (e->w + 1) >> 1, qh = (e->h + 1) >> 1;
-    k_pyr_level<<<dim3((qw + 255) / 256, qh), 256, 0, e->stream>>>(e->img_stage, e->images + 3 * n * idx, nullptr, e->w, e->h, 0);
+    k_pyr_level<<<dim3((qw + 255) / 256, qh), 256, 0, e->stream>>>(e->img_stage, e->images + 3 * n * e->img_slot[idx], nullptr, e->w, e->h, 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     return SDVGN_OK;
@@ -2643,7 +2663,10 @@ int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_m
     if (lastEnergy_out) *lastEnergy_out = energy;
     if (relbs_max) std::memcpy(relbs_max, rb.data(), 4 * (size_t)e->nP);
     if (ngood_inc) std::memcpy(ngood_inc, ng.data(), 4 * (size_t)e->nP);
-    if (removed) for (int i = 0; i < e->nR; ++i) removed[i] = rm[(size_t)e->r_slot[i]];
+    if (removed) {
+        if (e->table_mode) std::memcpy(removed, rm.data(), slots);    // by slot (target * nP + point index): the window is edited in place, there is no residual list
+        else for (int i = 0; i < e->nR; ++i) removed[i] = rm[(size_t)e->r_slot[i]];
+    }
     return SDVGN_OK;
 }
 
@@ -2738,18 +2761,17 @@ static void inverse6(const double* A, double* Ainv) {   // Gauss-Jordan with par
 // EnergyFunctional::marginalizeFrame (:434-512), the algebra on HM / bM only: frame idx moves to the end, its prior is added, the
 // Schur complement on the preconditioned last 6x6 block is taken.  Pure host function of the handle's HM, bM and frame prior; the
 // caller rebuilds the window without that frame and installs the outputs with sdvgn_ef_set_marg_prior.
-int sdvgn_ef_marginalize_frame(sdvgn_ef* e, int idx, double* HM_out, double* bM_out) {
-    if (!e || !HM_out || !bM_out || idx < 0 || idx >= e->nF || e->nF < 2) return SDVGN_E_ARG;
-    const int nF = e->nF, odim = CPARS + 6 * nF, ndim = odim - 6;
-    std::vector<double> H = e->HM, b = e->bM;
+static void marginalize_frame_algebra(int nF, const std::vector<double>& HM, const std::vector<double>& bM, const double* prior6, const double* delta_prior6, int idx,
+                                      double* HM_out, double* bM_out) {
+    const int odim = CPARS + 6 * nF, ndim = odim - 6;
+    std::vector<double> H = HM, b = bM;
     if ((int)H.size() != odim * odim) { H.assign((size_t)odim * odim, 0); b.assign(odim, 0); }
     std::vector<int> perm;
     for (int i = 0; i < odim; ++i) if (i < CPARS + 6 * idx || i >= CPARS + 6 * idx + 6) perm.push_back(i);
     for (int i = 0; i < 6; ++i) perm.push_back(CPARS + 6 * idx + i);
     std::vector<double> Hp((size_t)odim * odim), bp(odim);
     for (int i = 0; i < odim; ++i) { bp[i] = b[perm[i]]; for (int j = 0; j < odim; ++j) Hp[(size_t)i * odim + j] = H[(size_t)perm[i] * odim + perm[j]]; }
-    const FrameH& f = e->frames[idx];
-    for (int i = 0; i < 6; ++i) { Hp[(size_t)(ndim + i) * odim + ndim + i] += f.prior[i]; bp[ndim + i] += f.prior[i] * f.delta_prior[i]; }
+    for (int i = 0; i < 6; ++i) { Hp[(size_t)(ndim + i) * odim + ndim + i] += prior6[i]; bp[ndim + i] += prior6[i] * delta_prior6[i]; }
     std::vector<double> SVec(odim), SVecI(odim), Hs((size_t)odim * odim), bs(odim);
     for (int i = 0; i < odim; ++i) { SVec[i] = std::sqrt(std::fabs(Hp[(size_t)i * odim + i]) + 10); SVecI[i] = 1.0 / SVec[i]; }
     for (int i = 0; i < odim; ++i) { bs[i] = SVecI[i] * bp[i]; for (int j = 0; j < odim; ++j) Hs[(size_t)i * odim + j] = SVecI[i] * Hp[(size_t)i * odim + j] * SVecI[j]; }
@@ -2765,8 +2787,14 @@ int sdvgn_ef_marginalize_frame(sdvgn_ef* e, int idx, double* HM_out, double* bM_
     }
     for (int i = 0; i < odim; ++i) { bs[i] = SVec[i] * bs[i]; for (int j = 0; j < odim; ++j) Hs[(size_t)i * odim + j] = SVec[i] * Hs[(size_t)i * odim + j] * SVec[j]; }
     for (int r = 0; r < ndim; ++r) { bM_out[r] = bs[r]; for (int c = 0; c < ndim; ++c) HM_out[(size_t)r * ndim + c] = 0.5 * (Hs[(size_t)r * odim + c] + Hs[(size_t)c * odim + r]); }
+}
+int sdvgn_ef_marginalize_frame(sdvgn_ef* e, int idx, double* HM_out, double* bM_out) {
+    if (!e || !HM_out || !bM_out || idx < 0 || idx >= e->nF || e->nF < 2) return SDVGN_E_ARG;
+    marginalize_frame_algebra(e->nF, e->HM, e->bM, e->frames[idx].prior, e->frames[idx].delta_prior, idx, HM_out, bM_out);
     return SDVGN_OK;
 }
+
+#include "backend_window.inc"
 
 int sdvgn_ef_get_res_toZero(sdvgn_ef* e, float* res_toZero2, unsigned char* isLinearized) {
     if (!e || !res_toZero2 || !isLinearized || e->host_only) return SDVGN_E_ARG;
@@ -3029,7 +3057,7 @@ int sdvgn_ef_optimize_immature(sdvgn_ef* e, int n, const int* host, const float*
     std::memcpy(s_host, host, 4 * (size_t)n); std::memcpy(s_u, u, 4 * (size_t)n); std::memcpy(s_v, v, 4 * (size_t)n);
     std::memcpy(s_min, idepth_min, 4 * (size_t)n); std::memcpy(s_max, idepth_max, 4 * (size_t)n); std::memcpy(s_eth, energyTH, 4 * (size_t)n);
     std::memcpy(s_col, color8, 32 * (size_t)n); std::memcpy(s_wts, weights8, 32 * (size_t)n); std::memcpy(s_sens, isFromSensor, (size_t)n);
-    k_ef_optimize_immature<<<(n + 63) / 64, 64, 0, e->stream>>>(e->C, e->images, e->imm_pc_dev, n, minObs, s_host, s_u, s_v, s_min, s_max, s_eth,
+    k_ef_optimize_immature<<<(n + 63) / 64, 64, 0, e->stream>>>(e->C, e->images, e->A.img_slots, e->imm_pc_dev, n, minObs, s_host, s_u, s_v, s_min, s_max, s_eth,
                                                               (const float4*)s_col, (const float4*)s_wts, s_sens, s_res, s_id, s_rs);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -3038,7 +3066,8 @@ int sdvgn_ef_optimize_immature(sdvgn_ef* e, int n, const int* host, const float*
 }
 
 int sdvgn_ef_get_top_acc(sdvgn_ef* e, double* out, int* resInA) {
-    if (!e || !out) return SDVGN_E_STATE;
+    if (!e) return SDVGN_E_STATE;
+    if (!out) { if (resInA) *resInA = e->resInA; return SDVGN_OK; }   // (only EnergyFunctional::resInA of the last solve)
     EF_DEVICE(e);
     const int nF = e->nF;
     std::vector<double> g((size_t)nF * nF * kTopE);

@@ -91,7 +91,7 @@ struct EFArrays {
     float* pHdi; float* pbdSum; float* pHcd;  // SC inputs (Hcd = A + L)
     float* pstep;
     // images
-    const float* images;     // [nF][w*h*3]
+    const float* images;     // [image slot][w*h*3]; frame t's image lives in slot ef_img_slot(A, t)
     // frameEnergyTH per frame [nF]: the set k_ef_linearize classifies with / the set k_ef_select_th writes (one per state_New* set,
     // because FullSystem::setNewFrameEnergyTH moves the newest frame's threshold after EVERY linearizeAll, FullSystemOptimize.cpp:63-97,122)
     const float* frameTH_r;
@@ -116,7 +116,11 @@ struct EFArrays {
     // launch publishes ORs a code into it (1: the accept verdict, 2: the solution); sdvgn_ef_optimize and the solve check it and return
     // SDVGN_E_STATE instead of carrying on with a partially applied / unstepped window
     unsigned* err;
+    // image slot of frame t in nibble t (identity 0x76543210 unless frames were inserted / removed in place, backend_window.inc): a
+    // marginalised frame frees its slot, the frames behind it keep theirs -- no image ever moves
+    unsigned img_slots;
 };
+__device__ __host__ __forceinline__ int ef_img_slot(unsigned img_slots, int t) { return (int)((img_slots >> (4 * t)) & 7u); }
 __device__ __forceinline__ void ef_raise(unsigned* err, unsigned code) {
     if (err) __hip_atomic_fetch_or(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -308,7 +312,7 @@ __device__ __forceinline__ double imm_linearize_residual(const EFConst& C, const
     return energyLeft;
 }
 
-__global__ void __launch_bounds__(64) k_ef_optimize_immature(EFConst C, const float* __restrict__ images, const ImmPrecalc* __restrict__ precalc, int n,
+__global__ void __launch_bounds__(64) k_ef_optimize_immature(EFConst C, const float* __restrict__ images, unsigned img_slots, const ImmPrecalc* __restrict__ precalc, int n,
                                                              int minObs, const int* __restrict__ host, const float* __restrict__ u, const float* __restrict__ v,
                                                              const float* __restrict__ idepth_min, const float* __restrict__ idepth_max,
                                                              const float* __restrict__ energyTH, const float4* __restrict__ color,
@@ -334,7 +338,7 @@ __global__ void __launch_bounds__(64) k_ef_optimize_immature(EFConst C, const fl
 #pragma unroll
         for (int t = 0; t < kMaxFrames; ++t) {
             if (t < nF && t != hst) {
-                lastEnergy = (float)((double)lastEnergy + imm_linearize_residual(C, images + t * imgStride, precalc[hst * nF + t], pu, pv, col, wts, eTH, 1000.f,
+                lastEnergy = (float)((double)lastEnergy + imm_linearize_residual(C, images + ef_img_slot(img_slots, t) * imgStride, precalc[hst * nF + t], pu, pv, col, wts, eTH, 1000.f,
                                                                                  res[t], lastHdd, lastbd, currentIdepth));
                 res[t].state_state = res[t].state_NewState;
                 res[t].state_energy = res[t].state_NewEnergy;
@@ -351,7 +355,7 @@ __global__ void __launch_bounds__(64) k_ef_optimize_immature(EFConst C, const fl
 #pragma unroll
             for (int t = 0; t < kMaxFrames; ++t)
                 if (t < nF && t != hst)
-                    newEnergy = (float)((double)newEnergy + imm_linearize_residual(C, images + t * imgStride, precalc[hst * nF + t], pu, pv, col, wts, eTH, 1.f,
+                    newEnergy = (float)((double)newEnergy + imm_linearize_residual(C, images + ef_img_slot(img_slots, t) * imgStride, precalc[hst * nF + t], pu, pv, col, wts, eTH, 1.f,
                                                                                    res[t], newHdd, newbd, newIdepth));
             if (!isfinite(lastEnergy) || newHdd < 100.f) { code = 0; break; }
             if (newEnergy < lastEnergy) {

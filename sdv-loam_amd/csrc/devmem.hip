@@ -4,6 +4,7 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -105,7 +106,7 @@ void check_bands(const Rec& r, void* user) {
     if (hipMemcpy(head.data(), r.base, kBand, hipMemcpyDeviceToHost) != hipSuccess) return;
     if (hipMemcpy(back.data(), (char*)user + r.bytes, tail, hipMemcpyDeviceToHost) != hipSuccess) return;
     long first_head = -1, first_back = -1;
-    for (size_t i = 0; i < kBand; ++i) if (head[i] != kPoison) { first_head = (long)i; }
+    for (size_t i = 0; i < kBand; ++i) if (head[i] != kPoison) { first_head = (long)i; break; }
     for (size_t i = 0; i < tail; ++i) if (back[i] != kPoison) { first_back = (long)i; break; }
     if (first_head >= 0 || first_back >= 0) {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -123,12 +124,26 @@ unsigned long long guard_violations() { std::lock_guard<std::mutex> lk(g_mu); re
 // SDVGN_ALLOC_FILL=<0..255>: every new device buffer is filled with that byte (any mode) -- 255 turns every float that is read before
 // it was written into a NaN, so a result that depends on uninitialised memory shows in the first test that computes with it
 static int alloc_fill() { static const int f = env_int("SDVGN_ALLOC_FILL", -1); return f; }
+// SDVGN_FREE_POISON=1 (any mode): a buffer is filled with 0xFF (every float a NaN) before it is given back, so a kernel that still reads it
+// AFTER the free computes NaNs instead of plausible stale numbers.  Mode 0 keeps a size table for that (only when the switch is on).
+static bool free_poison() { static const bool on = env_int("SDVGN_FREE_POISON", 0) != 0; return on; }
+static bool guard_nofree() { static const bool on = env_int("SDVGN_GUARD_NOFREE", 0) != 0; return on; }
+// SDVGN_GUARD_QUARANTINE=1 (mode 1): a freed buffer's pages are unmapped and released but its ADDRESS RANGE is never handed back
+// (hipMemAddressFree is skipped), so no later allocation -- the library's, torch's, the runtime's -- can land there: a stale pointer
+// faults at its first use, in the kernel that uses it, on every run.  (Without it a freed range is typically re-used by the very next
+// reservation of the same size and the stale access silently reads or writes the new owner's data.)
+static bool guard_quarantine() { static const bool on = env_int("SDVGN_GUARD_QUARANTINE", 0) != 0; return on; }
+std::unordered_map<void*, size_t> g_plain_sizes;   // mode 0 + SDVGN_FREE_POISON only
+
 hipError_t dmalloc_impl(void** p, size_t bytes, size_t align, const char* tag) {
     const int m = guard_mode();
     hipError_t e;
     if (m == 1) e = fenced_device_alloc(p, bytes, align, tag);
     else if (m == 2) e = banded_device_alloc(p, bytes, tag);
-    else e = hipMalloc(p, bytes ? bytes : 1);
+    else {
+        e = hipMalloc(p, bytes ? bytes : 1);
+        if (e == hipSuccess && free_poison()) { std::lock_guard<std::mutex> lk(g_mu); g_plain_sizes[*p] = bytes ? bytes : 1; }
+    }
     if (e == hipSuccess && alloc_fill() >= 0) {
         void* from = *p; size_t n = bytes ? bytes : 1;
         if (m == 1) {   // the slack in front of an end-aligned buffer too: a read BEFORE the start of a buffer then shows like an uninitialised one
@@ -144,7 +159,14 @@ hipError_t dmalloc_impl(void** p, size_t bytes, size_t align, const char* tag) {
 
 hipError_t dfree(void* p) {
     if (!p) return hipSuccess;
-    if (guard_mode() == 0) return hipFree(p);
+    if (guard_mode() == 0) {
+        if (free_poison()) {
+            size_t n = 0;
+            { std::lock_guard<std::mutex> lk(g_mu); auto it = g_plain_sizes.find(p); if (it != g_plain_sizes.end()) { n = it->second; g_plain_sizes.erase(it); } }
+            if (n) { hipDeviceSynchronize(); hipMemset(p, 0xFF, n); hipDeviceSynchronize(); }
+        }
+        return hipFree(p);
+    }
     Rec r;
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -153,12 +175,14 @@ hipError_t dfree(void* p) {
         r = it->second;
         g_recs.erase(it);
     }
-    if (r.kind == 2) { check_bands(r, p); return hipFree(r.base); }
+    if (log_on()) fprintf(stderr, "[sdvgn guard] free   %-40s [%p, %p) %zu bytes\n", r.tag, p, (char*)p + r.bytes, r.bytes);
+    if (r.kind == 2) { check_bands(r, p); if (free_poison()) { hipMemset(p, 0xFF, r.bytes); hipDeviceSynchronize(); } return hipFree(r.base); }
     hipDeviceSynchronize();
-    if (env_int("SDVGN_GUARD_NOFREE", 0)) return hipSuccess;   // experiment: never give a fenced mapping back (no reuse of its address range or pages)
+    if (free_poison()) { hipMemset(r.base, 0xFF, r.mapped); hipDeviceSynchronize(); }
+    if (guard_nofree()) return hipSuccess;   // experiment: never give a fenced mapping back (no reuse of its address range or pages)
     hipError_t e = hipMemUnmap(r.base, r.mapped);
     hipMemRelease(r.handle);
-    hipMemAddressFree(r.res, r.reserved);
+    if (!guard_quarantine()) hipMemAddressFree(r.res, r.reserved);
     return e;
 }
 
@@ -201,7 +225,23 @@ hipError_t hfree(void* p) {
 }  // namespace gmem
 }  // namespace sdvgn
 
+__global__ void k_debug_peek(const double* p, double* out) { *out = *p; }
 extern "C" {
+// tools/probe_fence.py: one 8-byte device load from an arbitrary address (a stray one ends the process with the runtime's memory access fault)
+int sdvgn_debug_peek(const void* p, double* value_out) {
+    double* pin = nullptr;
+    if (hipHostMalloc((void**)&pin, 8) != hipSuccess) return -1;
+    *pin = 0;
+    k_debug_peek<<<1, 1>>>((const double*)p, pin);
+    const hipError_t e = hipDeviceSynchronize();
+    if (value_out) *value_out = *pin;
+    hipHostFree(pin);
+    return e == hipSuccess ? 0 : -(int)e;
+}
+// test rigs: caller-owned device buffers from the same fenced / banded / poisoned allocator (sdv-loam_amd/parallel.py, SDVGN_FENCE_EXTERNAL=1),
+// so that the buffers a caller hands to sdvgn_ef_set_external_buffers / _set_collective_buffer sit behind the same instruments as the library's own
+void* sdvgn_debug_dmalloc(size_t bytes) { void* p = nullptr; return sdvgn::gmem::dmalloc_impl(&p, bytes, 16, "caller-owned (sdvgn_debug_dmalloc)") == hipSuccess ? p : nullptr; }
+int sdvgn_debug_dfree(void* p) { return (int)sdvgn::gmem::dfree(p); }
 int sdvgn_debug_guard_mode(void) { return sdvgn::gmem::guard_mode(); }
 unsigned long long sdvgn_debug_guard_violations(void) { return sdvgn::gmem::guard_violations(); }
 }

@@ -93,11 +93,12 @@ class ShardedEnergyFunctional:
             _DEVICE_STREAMS[device] = torch.cuda.Stream(device=device)
         self.stream = _DEVICE_STREAMS[device]
         self.ef = EnergyFunctional(W.w, W.h, max_points=W.nP, device=device, stream=self.stream.cuda_stream)
-        with torch.cuda.stream(self.stream):
-            self.acc = torch.zeros(acc_capacity(), dtype=torch.float64, device="cuda")
-            self.stats = torch.zeros(4 + W.nP, dtype=torch.float64, device="cuda")   # 4 statistics + the quantile candidates
-        self.stream.synchronize()
         L = self.ef.L
+        self._fenced = []      # SDVGN_FENCE_EXTERNAL=1 (test rigs): the caller-owned buffers come from the library's fenced / poisoned allocator
+        with torch.cuda.stream(self.stream):
+            self.acc = self._zeros(acc_capacity())
+            self.stats = self._zeros(4 + W.nP)   # 4 statistics + the quantile candidates
+        self.stream.synchronize()
         self.ef._check(L.sdvgn_ef_set_external_buffers(self.ef.h_, self.acc.data_ptr(), self.acc.numel(), self.stats.data_ptr(), self.stats.numel()))
         # ONE collective per loop body (BASELINE.json north_star): two message buffers [accumulators | 4 statistics | quantile candidates];
         # sdvgn_ef_optimize applies + accumulates the trial speculatively and all-reduces one message per body (+ one per call)
@@ -108,7 +109,7 @@ class ShardedEnergyFunctional:
             L.sdvgn_ef_set_collective_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
             stride = L.sdvgn_ef_collective_stride(self.ef.h_)
             with torch.cuda.stream(self.stream):
-                self.coll = torch.zeros(2 * stride, dtype=torch.float64, device="cuda")
+                self.coll = self._zeros(2 * stride)
             self.stream.synchronize()
             self.ef._check(L.sdvgn_ef_set_collective_buffer(self.ef.h_, self.coll.data_ptr(), self.coll.numel()))
         self.max_points = W.nP
@@ -170,6 +171,28 @@ class ShardedEnergyFunctional:
 
             self._cb = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)(_allreduce)
             self.ef._check(L.sdvgn_ef_set_allreduce(self.ef.h_, C.cast(self._cb, C.c_void_p), None))
+
+    def _zeros(self, n):
+        """n zeroed doubles on the device: a torch tensor -- or, with SDVGN_FENCE_EXTERNAL=1, a torch view of a buffer from the library's
+        debugging allocator (csrc/devmem.hpp), so that what the caller hands to sdvgn_ef_set_external_buffers / _set_collective_buffer
+        sits behind the same fence / poison instruments as the library's own allocations"""
+        import os
+        torch = self.torch
+        if os.environ.get("SDVGN_FENCE_EXTERNAL") != "1":
+            return torch.zeros(n, dtype=torch.float64, device="cuda")
+        L = self.ef.L
+        L.sdvgn_debug_dmalloc.restype = C.c_void_p
+        L.sdvgn_debug_dmalloc.argtypes = [C.c_size_t]
+        ptr = L.sdvgn_debug_dmalloc(8 * n)
+        if not ptr:
+            raise MemoryError("sdvgn_debug_dmalloc(%d)" % (8 * n))
+        self._fenced.append(ptr)      # (never given back: a test rig's buffers live as long as the process, so no use-after-free of OURS can hide a library one)
+
+        class _Raw:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+        t = torch.as_tensor(_Raw(), device="cuda")
+        t.zero_()
+        return t
 
     def reload(self, W):
         if W.nP > self.max_points:

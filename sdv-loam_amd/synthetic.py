@@ -322,6 +322,44 @@ def make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=KITTI00, sen
     return W
 
 
+def subwindow(W, frames, points, residual_mask=None, HM=None, bM=None):
+    """The window restricted to `frames` (indices into W, in the order given) and `points` (indices into W, in the order given -- must be
+    grouped by host frame in the order of `frames`): residuals whose point and target both survive (and residual_mask allows) follow, in
+    point-major order.  What an EnergyFunctional looks like after removePoint / dropResidual / marginalizeFrame -- or, read the other way,
+    before insertPoint / insertResidual / insertFrame: both ends of a key-frame update are sub-windows of one larger synthetic window."""
+    import copy
+    frames = np.asarray(frames, int)
+    points = np.asarray(points, int)
+    S = copy.copy(W)
+    fmap = -np.ones(W.nF, int); fmap[frames] = np.arange(len(frames))
+    pmap = -np.ones(W.nP, int); pmap[points] = np.arange(len(points))
+    assert (fmap[W.host[points]] >= 0).all() and (np.diff(fmap[W.host[points]]) >= 0).all(), "points must be grouped by host in frame order"
+    S.nF = len(frames)
+    for name in ("evalPT", "state", "state_zero", "frameID", "ab_exposure", "frameEnergyTH", "gt_worldToCam"):
+        setattr(S, name, getattr(W, name)[frames].copy())
+    S.images = [W.images[k] for k in frames]
+    S.pyr0 = [W.pyr0[k] for k in frames]
+    for name in ("u", "v", "idepth", "idepth_zero", "color", "weights", "hasDepthPrior", "isFromSensor"):
+        setattr(S, name, getattr(W, name)[points].copy())
+    S.host = fmap[W.host[points]].astype(np.int32)
+    keep = (pmap[W.r_point] >= 0) & (fmap[W.r_target] >= 0)
+    if residual_mask is not None:
+        keep &= np.asarray(residual_mask, bool)
+    ridx = np.nonzero(keep)[0]
+    ridx = ridx[np.argsort(pmap[W.r_point[ridx]], kind="stable")]      # point-major in the NEW point order
+    S.r_src = ridx                                                      # index of every residual in W
+    S.r_point = pmap[W.r_point[ridx]].astype(np.int32)
+    S.r_target = fmap[W.r_target[ridx]].astype(np.int32)
+    for name in ("r_matcher", "r_state", "r_hasMatcher", "r_isLinearized", "r_isActive"):
+        setattr(S, name, getattr(W, name)[ridx].copy())
+    S.nP, S.nR = len(points), len(ridx)
+    n = 4 + 6 * S.nF
+    S.HM = np.zeros((n, n)) if HM is None else np.asarray(HM, np.float64)
+    S.bM = np.zeros(n) if bM is None else np.asarray(bM, np.float64)
+    S.p_src, S.f_src = points, frames
+    return S
+
+
 # =====================================================================================================
 # structPoseEstimation (SURVEY.md 8f-1): map points hosted in the window's key-frames, matched 2-D positions
 # in the current frame, and a perturbed initial camToWorld of the current frame.

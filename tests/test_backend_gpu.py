@@ -4,6 +4,7 @@ Tolerances: residual states / activity flags exact; Jacobians and per-residual e
 operations, no FMA contraction); (host,target) accumulators rel 1e-5; H, b of the stitched system rel 1e-5 / 1e-4;
 solution x and point steps rel 1e-4 (BASELINE.json north_star: 1e-4 relative on increments)."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -468,6 +469,8 @@ def test_sharded_path_single_rank_nccl(api, orc, window, direct, monkeypatch):
             assert S.ef.L.sdvgn_ef_collective_count(S.ef.h_) == len(ts) + 1
         G = api.EnergyFunctional(window.w, window.h, max_points=window.nP).load(window)
         tg = G.optimize(6)
+        if os.environ.get("SDVGN_DUMP_TRACES"):   # fault hunts (tools/hunt_uaf.sh): both traces to disk, whichever way the comparison goes
+            np.savez(os.path.join(os.environ["SDVGN_DUMP_TRACES"], "sharded_trace_direct%d.npz" % int(direct)), ts=np.asarray(ts), tg=np.asarray(tg))
         assert np.array_equal(ts, tg)
         assert np.array_equal(S.ef.state()[2], G.state()[2])
         if direct:
@@ -488,6 +491,54 @@ def test_sharded_path_single_rank_nccl(api, orc, window, direct, monkeypatch):
             del S
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("direct", [True, False])
+def test_sharded_idepth_zero_offset_first_step_rejected(api, orc, direct, monkeypatch):
+    """The sharded loop (ONE collective per body, speculative apply + accumulate) on a window loaded with idepth != idepth_zero whose first
+    step is rejected: that body runs the two-collective way and rebuilds the current message after the restore moved idepth_zero
+    (backend.hip, `onecoll && !spec`), the following bodies the speculative way.  Trace, states, points and the next solve must be those
+    of the plain handle, bit for bit -- through the library's own ncclAllReduce and through the torch.distributed callback on torch-owned
+    buffers (this edge was only tested single-GPU)."""
+    import torch
+    import torch.distributed as dist
+    from sdv_loam_amd import synthetic as syn
+    from sdv_loam_amd.parallel import ShardedEnergyFunctional
+    W = syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=3, calib=dict(fx=400., fy=410., cx=319.5, cy=119.5))
+    W.idepth_zero = (W.idepth + np.random.default_rng(1).normal(0, 2e-4, W.nP)).astype(np.float32)
+    if not direct:
+        monkeypatch.setenv("SDVGN_NO_DIRECT_RCCL", "1")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29743 + int(direct)), rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    try:
+        S = ShardedEnergyFunctional(W, 0, 1, 0, force_collective=True)
+        assert S.direct_rccl == direct
+        ts = S.optimize(6, want_trace=True, fixed_its=True)
+        G = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+        tg = G.optimize(6, fixed_its=True)
+        assert tg[0, 2] == 0 and len(tg) == 6                                 # first step rejected; five more bodies the speculative way
+        assert np.array_equal(ts, tg)
+        for a, b in zip(S.ef.state(), G.state()):
+            assert np.array_equal(a, b)
+        assert np.array_equal(S.ef.points(), G.points())
+        with torch.cuda.stream(S.stream):
+            xs = S.ef.solveSystemF(3, 0.1)
+        assert np.array_equal(xs, G.solveSystemF(3, 0.1))
+        del S
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fence_instruments_catch_stray_accesses():
+    """The allocation instruments the fault hunts rest on (csrc/devmem.hpp) are only evidence if a stray access really ends the process: one
+    element past the end / before the start of a fenced buffer, 3 MB past the end under 64 MB guards, and a read through a stale pointer
+    after the free under SDVGN_GUARD_QUARANTINE=1 must all fail loudly; accesses inside a buffer must not (tools/probe_fence.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "probe_fence.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("nF", [5, 6, 7])

@@ -163,3 +163,105 @@ def test_reference_track_new_coarse_call_site(sdvgn_lib, orc, retrack):
         assert np.linalg.norm(d) < 1e-4 * motion, (key, d)
     err = orc.se3_log(orc.se3_mul(orc.se3_inverse(rg["camToWorld"]), RP.gt_cur_pose7))           # and the frame really was tracked
     assert np.linalg.norm(err) < 0.02 * motion
+
+
+# ---- the drop-in as the FAST path: FullSystem::optimize itself on a window that stays on the GPU (INTEGRATION.md form B) ----------------------
+def _have_dropin_opt():
+    from oracle import dropin, refpin
+    L = refpin.ref_lib()
+    return L is not None and hasattr(L, "ref_ef_keyframe_tail") and dropin.dropin_opt_lib() is not None
+
+
+needs_dropin_opt = pytest.mark.skipif(not _have_dropin_opt(), reason="oracle/_ref/libref.so / libref_dropin_opt.so not present on this machine")
+
+KF_SMALL = dict(w=640, h=240, nF=7, pts_per_kf=300, seed=4, calib=dict(fx=400., fy=410., cx=319.5, cy=119.5), state_sigma=2e-3, idepth_sigma=0.02)
+KF_CFG3 = dict(w=1241, h=376, nF=9, pts_per_kf=2000, seed=0, state_sigma=3e-3, idepth_sigma=0.02)      # BASELINE.json configs[2] + one more key-frame
+
+
+def _compare_window(R, D, tag):
+    """the two worlds after the same sequence of reference host code: same window, states within BASELINE.json's 1e-4"""
+    assert R.nF == D.nF, tag
+    hr, hd = R.point_hosts(), D.point_hosts()
+    assert np.array_equal(hr, hd), (tag, int((hr != hd).sum()))                  # the same points were dropped / marginalised
+    vr, sr, ir = R.state()
+    vd, sd, idd = D.state()
+    live = hr >= 0
+    assert np.allclose(vd, vr, rtol=1e-6), tag
+    assert rel_err(sd, sr) < 1e-4 and rel_err(idd[live], ir[live]) < 1e-4, (tag, rel_err(sd, sr), rel_err(idd[live], ir[live]))
+    assert np.isnan(ir[~live]).all() and np.isnan(idd[~live]).all()
+    (HMr, bMr), (HMd, bMd) = R.marg_prior(), D.marg_prior()
+    assert HMr.shape == HMd.shape and rel_err(HMd, HMr) < 1e-4 and rel_err(bMd, bMr) < 1e-4, (tag, rel_err(HMd, HMr), rel_err(bMd, bMr))
+    rbr, ngr = R.point_stats()
+    rbd, ngd = D.point_stats()
+    assert np.array_equal(ngd[live], ngr[live]) and np.allclose(rbd[live], rbr[live], rtol=1e-4, atol=1e-7), tag
+
+
+@needs_dropin_opt
+@pytest.mark.parametrize("cfg", [KF_SMALL, KF_CFG3], ids=["small", "cfg3"])
+def test_reference_make_keyframe_on_gpu(sdvgn_lib, orc, cfg):
+    """FullSystem::makeKeyFrame's back half (FullSystem.cpp:1133-1178) -- optimize, removeOutliers, setCoarseTrackingRef, flagPointsForRemoval,
+    dropPointsF, marginalizePointsF, marginalizeFrame -- all-CPU vs with FullSystem::optimize replaced by the resident GPU window, TWICE, with a
+    new key-frame (its image, new points, new residuals) inserted in between by the reference's own insertFrame / insertPoint / insertResidual.
+    The accept / reject traces must be identical, the windows left behind the same, states / priors / the next tracking template within 1e-4;
+    and the GPU side must have received every key-frame image exactly once."""
+    from oracle.backend import RefEF
+    from oracle.dropin import DropinOptEF
+    from sdv_loam_amd import synthetic as syn
+    from test_backend_gpu import low_thresholds
+    W9 = low_thresholds(syn.make_window(**cfg))
+    nF0 = W9.nF - 1
+    rng = np.random.default_rng(1)
+    frames = list(range(nF0))
+    big = np.nonzero(np.isin(W9.host, frames) & (rng.random(W9.nP) < 0.85))[0]          # ref point index -> W9 point index
+    S = syn.subwindow(W9, frames, big, HM=W9.HM[:4 + 6 * nF0, :4 + 6 * nF0], bM=W9.bM[:4 + 6 * nF0])
+    R, D = RefEF(S.w, S.h).set_levels(3).load(S), DropinOptEF(S.w, S.h).set_levels(3).load(S)   # (levels: setCoarseTrackingRef touches levels 0 and 1)
+    R.compute_nullspaces(); D.compute_nullspaces()
+    rof = {(int(p), int(t)): k for k, (p, t) in enumerate(zip(W9.r_point, W9.r_target))}   # W9 residual of (point, target frame)
+
+    # ---- key-frame 1: optimize + marginalise frame 1 ----
+    out_r, out_d = R.keyframe_tail(6, [1]), D.keyframe_tail(6, [1])
+    assert D.gpu_calls() == 1
+    assert [s[0] for s in out_d[1]] == [s[0] for s in out_r[1]] and len(out_r[1]) >= 2, (out_r[1], out_d[1])
+    assert np.allclose([s[2] for s in out_d[1]], [s[2] for s in out_r[1]], rtol=1e-5, atol=2e-3)
+    assert abs(out_d[0] - out_r[0]) <= 1e-5 * out_r[0] and np.array_equal(out_d[2], out_r[2])
+    _compare_window(R, D, "after key-frame 1")
+    n5r, ur, vr_, dr, cr = R.tracking_ref(0)
+    n5d, ud, vd_, dd, cd = D.tracking_ref(0)
+    assert np.array_equal(n5d, n5r) and n5r[0] > 100                                     # makeCoarseDepthL0 on what optimize left (centerProjectedTo, HdiF, lastResiduals)
+    assert np.array_equal(ud, ur) and np.array_equal(vd_, vr_) and np.array_equal(cd, cr) and rel_err(dd, dr) < 1e-4
+    st = D.gpu_stats()
+    assert st["frames_uploaded"] == nF0 and st["points_inserted"] == S.nP
+
+    # ---- a new key-frame arrives: insertFrame, insertResidual for every point towards it, new points with their residuals (makeKeyFrame :1071-1104) ----
+    new_big = W9.nF - 1
+    win_big = [f for f in frames if f != 1] + [new_big]                                  # W9 frame of every window index
+    hosts = R.point_hosts()
+    cand = np.nonzero(np.isin(W9.host, win_big) & ~np.isin(np.arange(W9.nP), big))[0]
+    newp = np.sort(rng.choice(cand, min(len(cand), S.nP // 8), replace=False))
+    for E in (R, D):
+        k = E.append_frame(W9.evalPT[new_big], W9.state[new_big], W9.state_zero[new_big], int(W9.frameID[new_big]), 1.0, W9.frameEnergyTH[new_big], W9.pyr0[new_big])
+        assert k == len(win_big) - 1
+        old = np.nonzero(hosts >= 0)[0]
+        rr = np.array([rof[(int(big[i]), new_big)] for i in old])
+        E.append_residuals(old, np.full(len(old), k), W9.r_hasMatcher[rr], W9.r_matcher[rr])
+        ids = E.append_points([win_big.index(int(W9.host[p])) for p in newp], W9.u[newp], W9.v[newp], W9.idepth[newp], W9.idepth_zero[newp], W9.color[newp],
+                              W9.weights[newp], W9.hasDepthPrior[newp], W9.isFromSensor[newp])
+        pp, tt, rr = [], [], []
+        for i, p in zip(ids, newp):
+            for t, f in enumerate(win_big):
+                if f != W9.host[p]:
+                    pp.append(i); tt.append(t); rr.append(rof[(int(p), f)])
+        E.append_residuals(pp, tt, W9.r_hasMatcher[rr], W9.r_matcher[rr])
+        E.setAdjointsF(); E.setPrecalcValues()
+    big = np.concatenate([big, newp])
+
+    # ---- key-frame 2: the resident window is EDITED (one image, the new points / residuals, what left), optimised, frame 0 marginalised ----
+    out_r, out_d = R.keyframe_tail(6, [0]), D.keyframe_tail(6, [0])
+    assert D.gpu_calls() == 2
+    assert [s[0] for s in out_d[1]] == [s[0] for s in out_r[1]] and len(out_r[1]) >= 2, (out_r[1], out_d[1])
+    assert np.allclose([s[2] for s in out_d[1]], [s[2] for s in out_r[1]], rtol=1e-5, atol=2e-3)
+    assert np.array_equal(out_d[2], out_r[2])
+    _compare_window(R, D, "after key-frame 2")
+    st = D.gpu_stats()
+    assert st["frames_uploaded"] == nF0 + 1                                              # ONE image per key-frame, ever
+    assert st["points_inserted"] == S.nP + len(newp) and st["points_removed"] > 0 and st["residuals_inserted"] >= S.nR + len(old)

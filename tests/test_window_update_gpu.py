@@ -1,0 +1,220 @@
+"""The window edited in place (include/sdvgn.h: sdvgn_ef_insert_frame / _insert_points / _insert_residuals / _drop_residuals / _remove_points /
+_remove_frame / _update_residuals / _make_idx, csrc/backend_window.inc) against a full reload of the same graph through the whole-plane
+setters: after the commit the residual tables, states, optimize traces, per-point sums and the next solve must be BIT-IDENTICAL.
+
+The reference mutates its EnergyFunctional between two FullSystem::optimize calls (EnergyFunctional.h:51-58, FullSystem::makeKeyFrame
+FullSystem.cpp:1040-1180); both ends of such a key-frame step are cut out of ONE larger synthetic window (synthetic.subwindow), so that every
+image, point and matcher of the "after" graph is consistent with the "before" graph."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CAL = dict(fx=400., fy=410., cx=319.5, cy=119.5)
+
+
+@pytest.fixture(scope="module")
+def api(sdvgn_lib):
+    from sdv_loam_amd import backend_api
+    return backend_api
+
+
+@pytest.fixture(scope="module")
+def big():
+    from sdv_loam_amd import synthetic as syn
+    return syn.make_window(w=640, h=240, nF=7, pts_per_kf=300, seed=11, calib=CAL)
+
+
+class Mirror:
+    """Test-side book-keeping of one edited window: which big-window frame / point / residual every library-side object is."""
+
+    def __init__(self, api, W8, frames, points, rmask, seed):
+        from sdv_loam_amd import synthetic as syn
+        self.api, self.syn, self.W8 = api, syn, W8
+        self.rng = np.random.default_rng(seed)
+        n = 4 + 6 * len(frames)
+        A = self.rng.normal(0, 1, (n, n))
+        self.frames = list(frames)
+        S = syn.subwindow(W8, frames, points, rmask, HM=1e2 * (A @ A.T) / n, bM=self.rng.normal(0, 10, n))
+        self.G = api.EnergyFunctional(W8.w, W8.h, max_points=W8.nP).load(S)
+        self.id2big = {i: int(p) for i, p in enumerate(S.p_src)}          # a window loaded through the setters: id = dense index
+        self.order = list(range(S.nP))                                      # dense index -> id
+        self.rmask = np.zeros(W8.nR, bool); self.rmask[S.r_src] = True      # residuals of the big window that exist
+        self.W = S
+
+    def snapshot(self, vmz):
+        """what the device holds after an optimize, in the big window's indexing; calib re-installed the way a host loop re-sends it"""
+        G = self.G
+        vs, st, idp = G.state()
+        G.set_calib(vs, vmz)
+        tb = G.residual_table()
+        th = G.frame_energy_th()
+        return dict(vs=vs, vmz=np.asarray(vmz, np.float64), st=st, idp=idp, tb=tb, th=th, order=list(self.order), frames=list(self.frames),
+                    big_of_idx=np.array([self.id2big[i] for i in self.order]))
+
+    def reload_window(self, snap, ids, th_new, HM, bM, state_rows, evalPT_rows, zero_rows):
+        """the Window a full reload of the edited graph needs: big-window constants, device-held values for what survived"""
+        W8, syn = self.W8, self.syn
+        pts = np.array([self.id2big[i] for i in ids])
+        A = syn.subwindow(W8, self.frames, pts, self.rmask, HM=HM, bM=bM)
+        old_idx_of_big = {int(b): k for k, b in enumerate(snap["big_of_idx"])}
+        old_t_of_big = {int(f): k for k, f in enumerate(snap["frames"])}
+        for k, b in enumerate(pts):
+            if int(b) in old_idx_of_big:                       # a survivor: the inverse depth the last optimize left
+                A.idepth[k] = snap["idp"][old_idx_of_big[int(b)]]
+                A.idepth_zero[k] = A.idepth[k]
+        for r in range(A.nR):                                   # surviving residuals keep state_state / isActive
+            b, f = int(pts[A.r_point[r]]), int(self.frames[A.r_target[r]])
+            if b in old_idx_of_big and f in old_t_of_big and snap["tb"]["exists"][old_t_of_big[f], old_idx_of_big[b]]:
+                A.r_state[r] = snap["tb"]["state"][old_t_of_big[f], old_idx_of_big[b]]
+                A.r_isActive[r] = snap["tb"]["active"][old_t_of_big[f], old_idx_of_big[b]]
+        A.value_scaled, A.value_minus_value_zero = snap["vs"], snap["vmz"]
+        A.state, A.evalPT, A.state_zero = state_rows, evalPT_rows, zero_rows
+        A.frameEnergyTH = np.array([snap["th"][old_t_of_big[f]] if f in old_t_of_big else th_new for f in self.frames], np.float32)
+        return A
+
+
+def check_equal(G, R, its=6):
+    tg, tr = G.residual_table(), R.residual_table()
+    for k in ("exists", "state", "active"):
+        assert np.array_equal(tg[k], tr[k]), k
+    for a, b in zip(G.state(), R.state()):
+        assert np.array_equal(a, b)
+    assert np.array_equal(G.frame_energy_th(), R.frame_energy_th())
+    for a, b in zip(G.marg_prior(), R.marg_prior()):
+        assert np.array_equal(a, b)
+    ta, tb = G.optimize(its), R.optimize(its)
+    assert len(ta) >= 2 and (ta[:, 2] == 1).any()
+    assert np.array_equal(ta, tb)
+    for a, b in zip(G.state(), R.state()):
+        assert np.array_equal(a, b)
+    assert np.array_equal(G.points(), R.points())
+    tg, tr = G.residual_table(), R.residual_table()
+    for k in tg:
+        assert np.array_equal(tg[k], tr[k]), k
+    assert np.array_equal(G.solveSystemF(3, 0.1), R.solveSystemF(3, 0.1))
+    eg, er = G.optimize_finish(), R.optimize_finish()
+    assert eg[0] == er[0] and np.array_equal(eg[1], er[1]) and np.array_equal(eg[2], er[2])
+    return eg
+
+
+def keyframe_step(M, api, drop_frame_big, new_frame_big, n_remove, n_new, seed):
+    """one key-frame's worth of edits on M.G, then the same graph reloaded on a fresh handle; returns that handle"""
+    W8, G, rng = M.W8, M.G, np.random.default_rng(seed)
+    snap = M.snapshot(vmz=np.array([1e-3, -5e-4, 2e-3, 1e-3]) / 50. * (1 + 0.1 * seed))
+    nF_b = len(M.frames)
+    # ---- removePoint: random points + every point of the frame that is about to be marginalised ----
+    t_drop = M.frames.index(drop_frame_big)
+    alive = list(M.order)
+    gone = [i for i in alive if W8.host[M.id2big[i]] == drop_frame_big]
+    rest = [i for i in alive if i not in gone]
+    gone += list(rng.choice(rest, n_remove, replace=False))
+    G.removePoints(np.array(gone, np.int32))
+    for i in gone:
+        M.rmask[W8.r_point == M.id2big[i]] = False
+    alive = [i for i in alive if i not in set(gone)]
+    big2id = {M.id2big[i]: i for i in alive}
+    # ---- dropResidual: a tenth of what is left (by (id, target index BEFORE the frame leaves)) ----
+    live_r = np.nonzero(M.rmask & np.isin(W8.r_point, list(big2id)) & (W8.r_target != drop_frame_big))[0]
+    dr = rng.choice(live_r, len(live_r) // 10, replace=False)
+    G.dropResiduals([big2id[int(W8.r_point[r])] for r in dr], [M.frames.index(int(W8.r_target[r])) for r in dr])
+    M.rmask[dr] = False
+    # ---- marginalizeFrame (the library's Schur complement), insertFrame ----
+    HM_ref, bM_ref = G.marginalizeFrame(t_drop)                      # (pure function of the window before the edits)
+    G.removeFrame(t_drop)
+    M.rmask[W8.r_target == drop_frame_big] = False
+    M.frames.remove(drop_frame_big)
+    th_new = np.float32(8 * 8 * 8)
+    k = G.insertFrame(W8.evalPT[new_frame_big], W8.state[new_frame_big], W8.state_zero[new_frame_big], int(W8.frameID[new_frame_big]), 1.0, th_new,
+                      dI=W8.pyr0[new_frame_big] if seed % 2 else None, image=None if seed % 2 else W8.images[new_frame_big])
+    M.frames.append(new_frame_big)
+    assert k == len(M.frames) - 1
+    # ---- insertPoint: unused points of the big window hosted by surviving frames (and by the new one) ----
+    used = set(M.id2big.values())
+    cand = [p for p in range(W8.nP) if p not in used and W8.host[p] in M.frames]
+    newp = np.sort(rng.choice(cand, n_new, replace=False))
+    ids = G.insertPoints([M.frames.index(int(W8.host[p])) for p in newp], W8.u[newp], W8.v[newp], W8.idepth[newp], W8.idepth_zero[newp], W8.color[newp],
+                         W8.weights[newp], W8.hasDepthPrior[newp], W8.isFromSensor[newp])
+    for i, p in zip(ids, newp):
+        M.id2big[int(i)] = int(p)
+        big2id[int(p)] = int(i)
+    # ---- insertResidual: every surviving point towards the new frame + the new points towards every frame; a few old matchers move ----
+    add = np.nonzero(~M.rmask & np.isin(W8.r_point, list(big2id)) & np.isin(W8.r_target, M.frames) &
+                     ((W8.r_target == new_frame_big) | np.isin(W8.r_point, newp)))[0]
+    add = add[rng.random(len(add)) < 0.9]
+    hm = (rng.random(len(add)) < 0.95).astype(np.uint8)
+    G.insertResiduals([big2id[int(W8.r_point[r])] for r in add], [M.frames.index(int(W8.r_target[r])) for r in add], hasMatcher=hm, matcher=W8.r_matcher[add])
+    M.rmask[add] = True
+    W8.r_hasMatcher = W8.r_hasMatcher.copy(); W8.r_hasMatcher[add] = hm
+    old = np.nonzero(M.rmask & ~np.isin(np.arange(W8.nR), add))[0]
+    upd = rng.choice(old, 40, replace=False)
+    W8.r_matcher = W8.r_matcher.copy(); W8.r_matcher[upd] += rng.normal(0, 0.2, (len(upd), 2))
+    W8.r_hasMatcher[upd] = 1
+    # ---- the frames as the host loop leaves them, commit ----
+    old_t = {f: t for t, f in enumerate(snap["frames"])}
+    st_rows = np.array([snap["st"][old_t[f]] if f in old_t else W8.state[f] for f in M.frames])
+    G.updateFrames(W8.evalPT[M.frames], st_rows, W8.state_zero[M.frames], np.ones(len(M.frames), np.float32))
+    # (updates go by the CURRENT target index: after the removal / insertion above)
+    tb = snap["tb"]
+    ust = [int(tb["state"][old_t[int(W8.r_target[r])], snap["order"].index(big2id[int(W8.r_point[r])])]) for r in upd]
+    G.insertResiduals([big2id[int(W8.r_point[r])] for r in upd], [M.frames.index(int(W8.r_target[r])) for r in upd], state=np.array(ust, np.int32),
+                      hasMatcher=np.ones(len(upd), np.uint8), matcher=W8.r_matcher[upd], update=True)
+    order = G.makeIDX()
+    M.order = [int(i) for i in order]
+    assert G.nF == len(M.frames) and G.nP == len(alive) + n_new
+    G.setAdjointsF(); G.setPrecalcValues()
+    HM, bM = G.marg_prior()
+    n0 = 4 + 6 * (nF_b - 1)
+    assert np.array_equal(HM[:n0, :n0], HM_ref) and np.array_equal(bM[:n0], bM_ref) and not HM[n0:].any() and not HM[:, n0:].any() and not bM[n0:].any()
+    A = M.reload_window(snap, M.order, th_new, HM, bM, st_rows, W8.evalPT[M.frames], W8.state_zero[M.frames])
+    R = api.EnergyFunctional(W8.w, W8.h, max_points=W8.nP).load(A, raw_images=not (seed % 2))
+    return R
+
+
+def test_keyframe_updates_equal_full_reloads(api, big):
+    """Three key-frame steps in a row on one resident window (frames 0-4 of a 7-frame synthetic window; each step marginalises a frame,
+    removes points, drops residuals, inserts the next frame with its points and residuals, moves some matchers) -- after every commit a fresh
+    handle loaded with the same graph gives the same tables, optimize trace, states, point sums, next solve and optimize tail, bit for bit."""
+    import copy
+    W8 = copy.copy(big)
+    rng = np.random.default_rng(3)
+    frames = [0, 1, 2, 3, 4]
+    pts = np.nonzero(np.isin(W8.host, frames) & (rng.random(W8.nP) < 0.8))[0]
+    M = Mirror(api, W8, frames, pts, rng.random(W8.nR) < 0.9, seed=5)
+    t0 = M.G.optimize(4)
+    assert (t0[:, 2] == 1).any()
+    for step, (drop, new) in enumerate([(1, 5), (0, 6), (3, 1)]):
+        R = keyframe_step(M, api, drop, new, n_remove=60, n_new=150, seed=step + 1)
+        removed = check_equal(M.G, R)[3]
+        # linearizeAll(true)'s toRemove list took residuals out of the window (FullSystemOptimize.cpp:136-155): the mirror follows
+        ex = M.G.residual_table()["exists"]
+        idx_of_big = {M.id2big[i]: k for k, i in enumerate(M.order)}
+        t_of_big = {f: t for t, f in enumerate(M.frames)}
+        gone = 0
+        for r in np.nonzero(M.rmask)[0]:
+            if not ex[t_of_big[int(W8.r_target[r])], idx_of_big[int(W8.r_point[r])]]:
+                M.rmask[r] = False
+                gone += 1
+        assert removed.shape == ex.shape and gone == int(removed.sum())
+        del R
+
+
+def test_edit_entry_points_reject_bad_arguments(api, big):
+    from sdv_loam_amd import synthetic as syn
+    S = syn.subwindow(big, [0, 1, 2], np.nonzero(np.isin(big.host, [0, 1, 2]))[0][::3])
+    G = api.EnergyFunctional(big.w, big.h, max_points=big.nP).load(S)
+    L, h = G.L, G.h_
+    i32 = lambda *a: np.array(a, np.int32)
+    assert L.sdvgn_ef_remove_points(h, 1, i32(S.nP + 5)) < 0                     # no such id
+    assert L.sdvgn_ef_drop_residuals(h, 1, i32(0), i32(7)) < 0                   # no such frame
+    assert L.sdvgn_ef_drop_residuals(h, 1, i32(0), i32(int(S.host[0]))) < 0      # a point has no residual towards its own host
+    assert L.sdvgn_ef_remove_frame(h, 9, None, None) < 0
+    G.removePoints(i32(0))
+    assert L.sdvgn_ef_remove_points(h, 1, i32(0)) < 0                            # already gone
+    # until the commit the handle is the window of the last commit
+    assert G.nP == S.nP and len(G.optimize(2)) >= 1
+    order = G.makeIDX()
+    assert len(order) == S.nP - 1 and 0 not in order
+    # EFFrame::points order: the last point of the host took the place of the removed one
+    last_of_host0 = np.nonzero(S.host == 0)[0][-1]
+    assert order[0] == last_of_host0
