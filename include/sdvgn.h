@@ -495,6 +495,9 @@ int sdvgn_ef_get_state(sdvgn_ef* ef, double* value_scaled4, double* state10, flo
 int sdvgn_ef_get_iteration_times(sdvgn_ef* ef, double* us, int cap);
 /* number of accepted steps of the last sdvgn_ef_optimize call (what a trace would show, without asking for one) */
 int sdvgn_ef_get_accepted_steps(sdvgn_ef* ef);
+/* the look-ahead of the last sdvgn_ef_optimize call (flags bit4 switches it off; it also stands down where the side stream is not served beside
+ * the main one): rejected cases solved ahead on the side stream, and loop bodies that started from such a solution */
+int sdvgn_ef_get_look_ahead(sdvgn_ef* ef, int* launched, int* used);
 /* durations (milliseconds, HIP events on the library's stream) of the k_ef_linearize launches of the last sdvgn_ef_optimize call that ran
  * with flags bit3, in launch order (the first is the call's initial linearizeAll); returns their number */
 int sdvgn_ef_get_linearize_times(sdvgn_ef* ef, float* ms, int cap);

@@ -374,7 +374,7 @@ class RefEF(OracleEF):
         self.L._L.ref_ef_set_levels(self.h_, int(levels))
         return self
 
-    def keyframe_tail(self, its=6, flag_frames=None):
+    def keyframe_tail(self, its=6, flag_frames=None, min_its=None):
         """FullSystem::makeKeyFrame from its optimize call on (FullSystem.cpp:1133-1178): optimize, removeOutliers, setCoarseTrackingRef of the
         next key-frame's tracker, flagPointsForRemoval, dropPointsF, getNullspaces, marginalizePointsF, marginalizeFrame of the frames flagged
         in `flag_frames` (indices into the window).  Returns what optimize_full returns; afterwards nF is the window that is left, per-point
@@ -388,8 +388,12 @@ class RefEF(OracleEF):
         fl = np.zeros(self.nF, np.uint8)
         if flag_frames is not None:
             fl[list(flag_frames)] = 1
+        R.ref_ef_last_optimize_seconds.restype = C.c_double
+        R.ref_ef_set_min_its(-1 if min_its is None else int(min_its))
         rmse = R.ref_ef_keyframe_tail(self.h_, int(its), fl)
+        R.ref_ef_set_min_its(-1)
         self.last_seconds = R.ref_ef_last_seconds()
+        self.last_optimize_seconds = R.ref_ef_last_optimize_seconds()
         self.nF = R.ref_ef_window_frames(self.h_)
         n = R.ref_ef_last_log(self.h_, None, 0)
         buf = C.create_string_buffer(n + 1)

@@ -498,9 +498,10 @@ void ref_ef_marginalize_frame(void* e, int idx, double* HM_out, double* bM_out) 
 // min_its >= 0 sets setting_minOptIterations for the call (settings.cpp:56 default 1; = mnumOptIts makes the loop run exactly that many
 // bodies, the timing protocol of bench.py's cpu_baseline leg); seconds_out: wall time of the optimize() call alone.
 static int g_min_its = -1;
-static double g_last_seconds = 0;
+static double g_last_seconds = 0, g_last_optimize_seconds = 0;
 void ref_ef_set_min_its(int n) { g_min_its = n; }
 double ref_ef_last_seconds() { return g_last_seconds; }
+double ref_ef_last_optimize_seconds() { return g_last_optimize_seconds; }   // of the optimize call inside the last ref_ef_keyframe_tail
 double ref_ef_optimize_full(void* e, int mnumOptIts) {
     RefEF* E = (RefEF*)e; E->on();
     FullSystem* fs = E->fs;
@@ -590,7 +591,14 @@ double ref_ef_keyframe_tail(void* e, int mnumOptIts, const uint8_t* flag) {
         if (tr) signal(SIGSEGV, [](int) { void* bt[48]; const int n = backtrace(bt, 48); backtrace_symbols_fd(bt, n, 2); _exit(139); });
 #define KF_STAGE(name) do { if (tr) fprintf(stderr, "[ref glue] key-frame tail: %s\n", name); } while (0)
         KF_STAGE("optimize");
+        const int saved_min = setting_minOptIterations;
+        if (g_min_its >= 0) setting_minOptIterations = g_min_its;
+        struct timespec o0, o1;
+        clock_gettime(CLOCK_MONOTONIC, &o0);
         rmse = fs->optimize(mnumOptIts);                                                    // :1134
+        clock_gettime(CLOCK_MONOTONIC, &o1);
+        g_last_optimize_seconds = (o1.tv_sec - o0.tv_sec) + 1e-9 * (o1.tv_nsec - o0.tv_nsec);
+        setting_minOptIterations = saved_min;
         KF_STAGE("removeOutliers");
         fs->removeOutliers();                                                               // :1138
         KF_STAGE("setCoarseTrackingRef");

@@ -88,6 +88,7 @@ PROTOTYPES = [
     ("sdvgn_ef_make_idx", C.c_int, [vp]),
     ("sdvgn_ef_get_point_ids", C.c_int, [vp, vp]),
     ("sdvgn_ef_get_residual_table", C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
+    ("sdvgn_ef_get_look_ahead", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 ]
 
 
@@ -101,7 +102,7 @@ class EnergyFunctional:
         from .api import check, load_library
         self.L = load_library()
         self._check = check
-        self.w, self.h = w, h
+        self.w, self.h, self.max_points = w, h, max_points
         hnd = vp()
         check(self.L.sdvgn_ef_create(C.byref(hnd), device, w, h, max_points, stream))
         self.h_ = hnd
@@ -355,6 +356,12 @@ class EnergyFunctional:
     def accepted_steps(self):
         return self._check(self.L.sdvgn_ef_get_accepted_steps(self.h_))
 
+    def look_ahead(self):
+        """(rejected cases solved ahead, bodies that started from one) of the last optimize call"""
+        a, b = C.c_int(0), C.c_int(0)
+        self._check(self.L.sdvgn_ef_get_look_ahead(self.h_, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def iteration_times_us(self):
         n = self.L.sdvgn_ef_get_iteration_times(self.h_, None, 0)
         out = np.zeros(max(n, 1))
@@ -420,7 +427,7 @@ class EnergyFunctional:
         self._check(self.L.sdvgn_ef_make_idx(self.h_))
         self.nF = self.L.sdvgn_ef_dim(self.h_)
         self.nF = (self.nF - 4) // 6
-        ids = np.zeros(1 << 20, np.int32)
+        ids = np.empty(self.max_points, np.int32)
         self.nP = self._check(self.L.sdvgn_ef_get_point_ids(self.h_, ids.ctypes.data_as(vp)))
         self.nR = 0
         self.table_mode = True

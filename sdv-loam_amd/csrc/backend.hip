@@ -148,6 +148,7 @@ struct sdvgn_ef {
     int seq_solve = 0;                     // flags_host[3]
     bool sys_on_device = false, sys_fetched = false, sys_valid = false;
     void* fin_dev = nullptr;       // outputs of sdvgn_ef_optimize_finish (relbs_max, ngood_inc, removed), grown on demand
+    void* fin_host = nullptr;      // pinned mirror of fin_dev
     size_t fin_bytes = 0;
     float* th_dev = nullptr;       // frameEnergyTH [2 sets][SDVGN_MAX_FRAMES]: one per state_New* set (setNewFrameEnergyTH after every linearizeAll)
     float* th_log = nullptr;       // pinned ring: threshold of the newest frame after each linearizeAll of the last optimize call (trace, tests)
@@ -155,6 +156,7 @@ struct sdvgn_ef {
     size_t stats_cap = 0;          // doubles behind stats_dev: 4 statistics + max_points quantile candidates (sharded path)
     std::vector<double> iter_us;   // wall time of every loop body of the last sdvgn_ef_optimize call (microseconds)
     int n_accepted = 0;            // accepted steps of the last sdvgn_ef_optimize call
+    int n_spec_launched = 0, n_spec_used = 0;   // of the last call: rejected cases solved ahead on the side stream / bodies that started from such a solution
     // deferred work of the optimize loop (see linearize_launch): the threshold select of the last linearisation and the re-classification
     // after a rejected step ride in later launches as extra workgroups; whatever is still pending is launched on its own by ef_flush_pending
     SelArgs pend_sel{}; bool pend_sel_valid = false;
@@ -1168,6 +1170,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
     if (e->done_ctr) SDVGN_DFREE(e->done_ctr);
     if (e->imm_pc_host) SDVGN_HFREE(e->imm_pc_host);
     if (e->imm_stage) SDVGN_HFREE(e->imm_stage);
+    if (e->fin_host) SDVGN_HFREE(e->fin_host);
     if (e->own_coll && e->coll[0]) SDVGN_DFREE(e->coll[0]);
     if (e->apply_bak.fl) { SDVGN_DFREE(e->apply_bak.fl); SDVGN_DFREE(e->apply_bak.st); SDVGN_DFREE(e->apply_bak.en); SDVGN_DFREE(e->apply_bak.JpJd); }
     win_delete(e->win);
@@ -2257,6 +2260,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     int it = 0;
     e->iter_us.clear();
     e->n_accepted = 0;
+    e->n_spec_launched = e->n_spec_used = 0;
     std::vector<int> th_idx;   // th_log slot of every trial linearisation (trace only)
     bool host_restore_pending = false;
     bool pre_accumulated = false;   // the accumulate of the coming body was queued behind the previous body's accept test (AccAlt)
@@ -2293,7 +2297,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         const bool from_spec = spec_use;                                                  // the predecessor was rejected and this very solve ran ahead
         spec_use = false;
         const int use_buf = e->spec_last_buf, use_seq = e->spec_last_seq;
-        if (from_spec) { if ((rc = ef_launch_spec_rest(e, iteration, lambda, stepsize))) return rc; }
+        if (from_spec) { ++e->n_spec_used; if ((rc = ef_launch_spec_rest(e, iteration, lambda, stepsize))) return rc; }
         else if ((rc = ef_launch_solve(e, iteration, lambda, /*do_step=*/true, stepsize, reuse, /*accumulated=*/pre_accumulated || onecoll))) return rc;
         pre_accumulated = false;
         ef_swap_point_copies(e);                                                          // the stepped idepths are the ones every later launch reads
@@ -2308,6 +2312,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         if (spec_enabled && !zero_differs && e->sys_valid && iteration + 1 < mnumOptIts) {
             if ((rc = ef_launch_spec_solve(e, iteration + 1, lambda * 1e2, /*main_solve_in_flight=*/!from_spec))) return rc;
             spec_pending = true;
+            ++e->n_spec_launched;
         }
         // device-side accept test: the statistics launch waits for the host's parts of the comparison (after the mirror below), the
         // linearise does not
@@ -2384,8 +2389,11 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         if (dev_decide) {
             // the device formed the state's parts of the energies itself (stats_host[5], [7]); the host's mirror must give the same doubles -- the
             // same IEEE operations in the same order on the same numbers (cannot differ; if it ever does, the call fails instead of drifting)
-            if (e->stats_host[5] != En_host) return ef_state_failure(e, "prior energy of the stepped state: device vs host mirror", e->stats_host[5], En_host);
-            if (e->stats_host[7] != newEnergyM) return ef_state_failure(e, "M energy of the stepped state: device vs host mirror", e->stats_host[7], newEnergyM);
+            // (bit patterns, not values: a non-finite energy -- an overflowing prior term, 0 * inf in HM d -- is not a mismatch; the reference just
+            // rejects such a step, FullSystemOptimize.cpp:420: NaN < rhs is false, and so does the accept test below)
+            auto same_bits = [](double a, double b) { return std::memcmp(&a, &b, 8) == 0 || (std::isnan(a) && std::isnan(b)); };
+            if (!same_bits(e->stats_host[5], En_host)) return ef_state_failure(e, "prior energy of the stepped state: device vs host mirror", e->stats_host[5], En_host);
+            if (!same_bits(e->stats_host[7], newEnergyM)) return ef_state_failure(e, "M energy of the stepped state: device vs host mirror", e->stats_host[7], newEnergyM);
             newEnergyL = e->stats_host[5] + (double)(float)e->stats_host[1];
             newEnergyM = e->stats_host[7];
         }
@@ -2644,27 +2652,29 @@ int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_m
     if (need > e->fin_bytes) {
         HIPCHK(hipStreamSynchronize(e->stream));
         if (e->fin_dev) SDVGN_DFREE(e->fin_dev);
-        e->fin_dev = nullptr; e->fin_bytes = 0;
-        HIPCHK(SDVGN_DMALLOC(&e->fin_dev, need));
-        e->fin_bytes = need;
+        if (e->fin_host) SDVGN_HFREE(e->fin_host);
+        e->fin_dev = nullptr; e->fin_host = nullptr; e->fin_bytes = 0;
+        const size_t cap = std::max(need, (size_t)e->slots_cap + 8 * (size_t)e->max_points);
+        HIPCHK(SDVGN_DMALLOC(&e->fin_dev, cap));
+        HIPCHK(SDVGN_HMALLOC(&e->fin_host, cap));
+        e->fin_bytes = cap;
     }
     float* relbs_dev = (float*)e->fin_dev;
     int* ngood_dev = (int*)e->fin_dev + e->nP;
     uint8_t* removed_dev = (uint8_t*)e->fin_dev + 8 * (size_t)e->nP;
     k_ef_finish_points<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, relbs_dev, ngood_dev, removed_dev);
     HIPCHK(hipGetLastError());
-    std::vector<uint8_t> rm(slots);
-    std::vector<float> rb(e->nP);
-    std::vector<int> ng(e->nP);
-    HIPCHK(hipMemcpyAsync(rb.data(), relbs_dev, 4 * (size_t)e->nP, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(ng.data(), ngood_dev, 4 * (size_t)e->nP, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(rm.data(), removed_dev, slots, hipMemcpyDeviceToHost, e->stream));
+    // the three outputs lie back to back on the device: ONE copy into pinned memory, one wait
+    HIPCHK(hipMemcpyAsync(e->fin_host, e->fin_dev, need, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    const float* rb = (const float*)e->fin_host;
+    const int* ng = (const int*)e->fin_host + e->nP;
+    const uint8_t* rm = (const uint8_t*)e->fin_host + 8 * (size_t)e->nP;
     if (lastEnergy_out) *lastEnergy_out = energy;
-    if (relbs_max) std::memcpy(relbs_max, rb.data(), 4 * (size_t)e->nP);
-    if (ngood_inc) std::memcpy(ngood_inc, ng.data(), 4 * (size_t)e->nP);
+    if (relbs_max) std::memcpy(relbs_max, rb, 4 * (size_t)e->nP);
+    if (ngood_inc) std::memcpy(ngood_inc, ng, 4 * (size_t)e->nP);
     if (removed) {
-        if (e->table_mode) std::memcpy(removed, rm.data(), slots);    // by slot (target * nP + point index): the window is edited in place, there is no residual list
+        if (e->table_mode) std::memcpy(removed, rm, slots);    // by slot (target * nP + point index): the window is edited in place, there is no residual list
         else for (int i = 0; i < e->nR; ++i) removed[i] = rm[(size_t)e->r_slot[i]];
     }
     return SDVGN_OK;
@@ -2882,6 +2892,12 @@ int sdvgn_debug_launch_pattern(sdvgn_ef* e, int pattern, int reps, int spin_us) 
 }
 
 int sdvgn_ef_get_accepted_steps(sdvgn_ef* e) { return e ? e->n_accepted : SDVGN_E_ARG; }
+int sdvgn_ef_get_look_ahead(sdvgn_ef* e, int* launched, int* used) {
+    if (!e) return SDVGN_E_ARG;
+    if (launched) *launched = e->n_spec_launched;
+    if (used) *used = e->n_spec_used;
+    return SDVGN_OK;
+}
 
 int sdvgn_ef_get_iteration_times(sdvgn_ef* e, double* us, int cap) {
     if (!e) return SDVGN_E_ARG;
@@ -3042,6 +3058,7 @@ int sdvgn_ef_optimize_immature(sdvgn_ef* e, int n, const int* host, const float*
     if (bytes > e->imm_stage_bytes) {
         HIPCHK(hipStreamSynchronize(e->stream));
         if (e->imm_stage) SDVGN_HFREE(e->imm_stage);
+    if (e->fin_host) SDVGN_HFREE(e->fin_host);
         e->imm_stage = nullptr; e->imm_stage_bytes = 0;
         HIPCHK(SDVGN_HMALLOC(&e->imm_stage, bytes * 2));
         e->imm_stage_bytes = bytes * 2;

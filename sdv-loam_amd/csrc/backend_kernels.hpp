@@ -184,8 +184,16 @@ struct LinIn {            // per-lane inputs and the pattern projections (phase 
 };
 struct LinGeo { float res0, res1, hwm, Jr[6], Cr[4], dd; };
 struct LinRec { unsigned off; float fx, fy; };          // published by the owner: top-left tap (element offset into the target image), fractions
-struct LinSmem {
-    union { LinRec q[2][2][64][4]; float g[2][2][64][4][3]; };   // [group][role][lane][pixel]: first the records, then {I,dx,dy} (same 12 bytes)
+// LDS layout of the gather exchange: per (group, role) 64 lanes x 4 pattern pixels x 12 bytes -- first the records the owner publishes, then
+// {I,dx,dy} coming back in the same 12 bytes.  A lane's four records are 14 dwords apart, not 12, and role 1's array starts 16 dwords behind
+// a multiple of 32: with the packed layout every access of the exchange hit busy banks (SQ_LDS_BANK_CONFLICT 588 k cycles per launch against 351 k
+// SQ_ACTIVE_INST_LDS, profiles/r04_linearize_counters_exact.txt) -- the owner's 8-byte stores and phase C's 8-byte reads are serviced in
+// groups of 16 lanes whose 12-dword stride puts lanes l and l + 8 on one bank (14 = 2 x 7: sixteen distinct bank pairs), and the fetching
+// lanes of one instruction read both roles' records of a residual, 768 dwords apart = the same bank.
+constexpr int kLinLaneDw = 14;
+constexpr int kLinRoleDw = 64 * kLinLaneDw + 16;
+struct __align__(16) LinSmem {
+    unsigned qg[2][2][kLinRoleDw];   // [group][role][lane * kLinLaneDw + 3 * pixel + {0,1,2}]
     float xch[2][15][64];    // role 1 -> role 0: 4 energies, 4 gradient weights, the ok bits | (fused applyRes) its six terms of JpJd
     double s_e[2];
 };

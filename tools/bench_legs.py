@@ -1,0 +1,101 @@
+"""Legs of bench.py that time a KEY-FRAME, not a loop body: the window edited in place through the C ABI, and the
+reference's own FullSystem::optimize host code with libsdvgn linked in (both drop-in forms) beside the all-CPU reference.  N = 1, rank 0 only."""
+import time
+
+import numpy as np
+
+
+def keyframe_update_leg(steps=8, world=None):
+    """value_keyframe_update_inclusive: a sequence of `steps` key-frame insertions + marginalisations on ONE resident window
+    (tools/exp_keyframe_update.py), every edit, the commit and optimize(6) + the tail's linearizeAll(true) inside the timed region; next to it
+    the same key-frames through the whole-plane setters (value_window_reload_inclusive)."""
+    import torch
+    from sdv_loam_amd import backend_api as api, synthetic as syn
+    from tools import exp_keyframe_update as X
+    W = world or X.world()
+    RW = X.ResidentWindow(W, list(range(8)))
+    RW.G.optimize(6, want_trace=False, fixed_its=True); RW.G.optimize_finish()
+    for _ in range(2):
+        RW.prepare(); RW.step()
+    torch.cuda.synchronize()
+    t = []
+    for _ in range(steps):
+        RW.prepare()
+        t0 = time.perf_counter()
+        RW.step()
+        t.append(time.perf_counter() - t0)
+    prof = {}
+    for _ in range(4):
+        RW.prepare(); RW.step(prof=prof)
+    n = 4 + 6 * 8
+    S = syn.subwindow(W, RW.win, np.concatenate([W.pts_of[f] for f in RW.win]), HM=W.HM[:n, :n], bM=W.bM[:n])
+    G2 = api.EnergyFunctional(W.w, W.h, max_points=S.nP + 4096)
+    tl = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        G2.load(S, raw_images=True); G2.optimize(6, want_trace=False, fixed_its=True); G2.optimize_finish()
+        tl.append(time.perf_counter() - t0)
+    t, tl = np.array(t), np.array(tl[1:])
+    return dict(value=float(6 / np.median(t)), unit="GN iters/s", steps=steps, bodies_per_keyframe=6,
+                ms_per_keyframe=dict(median=float(1e3 * np.median(t)), min=float(1e3 * t.min()), max=float(1e3 * t.max())),
+                host_phases_us={k: float(1e6 * np.median(v)) for k, v in prof.items()},
+                value_window_reload_inclusive=float(6 / np.median(tl)), ms_per_keyframe_reload=float(1e3 * np.median(tl)),
+                note="per key-frame: removePoint x 2000, marginalizeFrame, insertFrame (1.87 MB raw image from pinned memory, level 0 built on the device), "
+                     "insertPoint x 2000, insertResidual x 28000, makeIDX (device-side re-pack), setAdjointsF, setPrecalcValues, optimize(6 bodies), "
+                     "linearizeAll(true); bit-identical with a reload of the same graph (tests/test_window_update_gpu.py).  "
+                     "value_window_reload_inclusive: the same key-frame through sdvgn_ef_set_frames / _set_frame_image_raw x 8 / _set_points / _set_residuals")
+
+
+def dropin_legs(W9, want_cpu=True):
+    """The reference's OWN host loop (oracle/ref_glue_ef.cpp drives FullSystem::optimize of the unmodified reference objects), three ways, on the same
+    two key-frames of a 9-frame world at the named shape: all-CPU (libref.so), form A (EnergyFunctional::solveSystemF on the GPU, linearize + loop on
+    the host: libref_dropin.so), form B (FullSystem::optimize = sdvgn_ef_optimize on a resident window: libref_dropin_opt.so).  Timed: the
+    FullSystem::optimize call alone, exactly 6 loop bodies (setting_minOptIterations = 6), wall clock inside the glue -- for form B that includes the
+    graph walk, the edits, the commit, the device work and the write-back into the reference's objects."""
+    from oracle import dropin, refpin
+    from oracle.backend import RefEF
+    from sdv_loam_amd import synthetic as syn
+    if refpin.ref_lib() is None or dropin.dropin_lib() is None or dropin.dropin_opt_lib() is None:
+        return dict(error="oracle/_ref/libref*.so not present on this machine")
+    nF0 = W9.nF - 1
+    frames = list(range(nF0))
+    big = np.nonzero(np.isin(W9.host, frames))[0]
+    n0 = 4 + 6 * nF0
+    S = syn.subwindow(W9, frames, big, HM=W9.HM[:n0, :n0], bM=W9.bM[:n0])
+    rof = (W9.r_point.astype(np.int64) * W9.nF + W9.r_target)
+    order = np.argsort(rof)
+
+    def rrow(p, t):       # index of W9's residual (point p, target t)
+        return order[np.searchsorted(rof[order], np.asarray(p, np.int64) * W9.nF + t)]
+
+    out = {}
+    legs = [("dropin_optimize", dropin.DropinOptEF), ("dropin_solveSystemF", dropin.DropinEF)]
+    if want_cpu:
+        legs.append(("cpu_reference", RefEF))
+    for key, cls in legs:
+        E = cls(S.w, S.h).set_levels(3).load(S)
+        E.compute_nullspaces()
+        E.keyframe_tail(6, [1], min_its=6)                                         # key-frame 1: optimize (first call: everything is new to the GPU), frame 1 marginalised
+        t_first = E.last_optimize_seconds
+        new_big = W9.nF - 1
+        win_big = [f for f in frames if f != 1] + [new_big]
+        hosts = E.point_hosts()
+        k = E.append_frame(W9.evalPT[new_big], W9.state[new_big], W9.state_zero[new_big], int(W9.frameID[new_big]), 1.0, W9.frameEnergyTH[new_big], W9.pyr0[new_big])
+        old = np.nonzero(hosts >= 0)[0]
+        rr = rrow(big[old], new_big)
+        E.append_residuals(old, np.full(len(old), k), W9.r_hasMatcher[rr], W9.r_matcher[rr])
+        E.setAdjointsF(); E.setPrecalcValues()
+        _, steps, _, _ = E.optimize_full(6, min_its=6)                             # key-frame 2: the steady state
+        t_kf = E.last_seconds
+        row = dict(its_per_s=6 / t_kf, ms_per_optimize_call=1e3 * t_kf, first_call_its_per_s=6 / t_first, bodies=len(steps), points=int((hosts >= 0).sum()),
+                   residuals_inserted_by_the_keyframe=int(len(old)))
+        if hasattr(E, "gpu_stats"):
+            row["gpu_window"] = E.gpu_stats()
+        out[key] = row
+        del E
+    out["note"] = ("FullSystem::optimize of the reference's own host loop on the second of two key-frames (8 key-frames in the window, ~16 000 points; between "
+                   "them the reference's removeOutliers / flagPointsForRemoval / marginalizePointsF / marginalizeFrame / insertFrame / insertResidual ran on the "
+                   "host): its_per_s = 6 bodies / wall time of the call.  dropin_optimize: oracle/dropin/FullSystemOptimizeGPU.cpp (resident window, one image "
+                   "upload per key-frame, graph walk + edits + write-back included); dropin_solveSystemF: oracle/dropin/EnergyFunctionalGPU.cpp (every plane "
+                   "and the CPU-computed Jacobians re-sent per solve); cpu_reference: libref.so, 1 thread, Eigen stand-in (a lower bound of a real Eigen build)")
+    return out

