@@ -1136,6 +1136,16 @@ def main():
     except Exception:  # noqa: BLE001
         roof["hbm_copy_measured_GBps"] = None
 
+    try:     # ... and what a hand-written float4 copy KERNEL reaches (the guide's practical peak: ~6.3 TB/s): the denominator `frac_of_practical_peak` uses
+        import ctypes as C_
+        L_ = G.L
+        L_.sdvgn_debug_copy_rate.restype = C_.c_double
+        L_.sdvgn_debug_copy_rate.argtypes = [C_.c_size_t, C_.c_int]
+        roof["hbm_copy_kernel_float4_GBps"] = float(L_.sdvgn_debug_copy_rate(1 << 30, 8))
+        if roof["hbm_copy_kernel_float4_GBps"] > 0:
+            roof["frac_of_practical_peak"] = roof["achieved"] / roof["hbm_copy_kernel_float4_GBps"]
+    except Exception:  # noqa: BLE001
+        roof["hbm_copy_kernel_float4_GBps"] = None
     if batched and isinstance(batched.get("roofline"), dict) and batched["roofline"].get("traffic") and roof.get("hbm_copy_measured_GBps"):
         br = batched["roofline"]
         br["traffic_rate_GBps"] = br["traffic"] / (br["in_loop_trace"]["mean_ms"] * 1e-3) / 1e9

@@ -2646,7 +2646,8 @@ int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_m
     if ((rc = ef_upload_precalc(e))) return rc;
     ef_select_new_set(e, e->new_cur, e->new_cur);
     double energy = 0, EL = 0;
-    if ((rc = linearize_and_stats(e, &energy, &EL, nullptr, nullptr))) return rc;
+    // everything is queued before anything is waited for: linearise + its sums, applyRes, the per-point bookkeeping, ONE copy of the outputs
+    if ((rc = linearize_launch(e))) return rc;
     if ((rc = sdvgn_ef_apply_res(e))) return rc;
     const size_t slots = (size_t)nF * e->nP, need = slots + 8 * (size_t)e->nP;
     if (need > e->fin_bytes) {
@@ -2666,6 +2667,7 @@ int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_m
     HIPCHK(hipGetLastError());
     // the three outputs lie back to back on the device: ONE copy into pinned memory, one wait
     HIPCHK(hipMemcpyAsync(e->fin_host, e->fin_dev, need, hipMemcpyDeviceToHost, e->stream));
+    if ((rc = linearize_wait(e, &energy, &EL, nullptr, nullptr))) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));
     const float* rb = (const float*)e->fin_host;
     const int* ng = (const int*)e->fin_host + e->nP;

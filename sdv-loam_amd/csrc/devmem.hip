@@ -226,6 +226,21 @@ hipError_t hfree(void* p) {
 }  // namespace sdvgn
 
 __global__ void k_debug_peek(const double* p, double* out) { *out = *p; }
+// the practical HBM peak of this box: float4 copy kernels (MI355X_MICROARCH.md: 6.29 TB/s measured of the 8 TB/s spec), three shapes
+typedef float copy_f4 __attribute__((ext_vector_type(4)));
+template <int UNROLL, bool NT>
+__global__ void __launch_bounds__(256) k_debug_copy4(const copy_f4* __restrict__ src, copy_f4* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
+        copy_f4 v[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) v[k] = NT ? __builtin_nontemporal_load(&src[i + k * stride]) : src[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) { if (NT) __builtin_nontemporal_store(v[k], &dst[i + k * stride]); else dst[i + k * stride] = v[k]; }
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
 extern "C" {
 // tools/probe_fence.py: one 8-byte device load from an arbitrary address (a stray one ends the process with the runtime's memory access fault)
 int sdvgn_debug_peek(const void* p, double* value_out) {
@@ -237,6 +252,36 @@ int sdvgn_debug_peek(const void* p, double* value_out) {
     if (value_out) *value_out = *pin;
     hipHostFree(pin);
     return e == hipSuccess ? 0 : -(int)e;
+}
+// bench: bytes read + bytes written per second (GB/s) of a float4 copy kernel over `bytes` bytes each way, `reps` launches timed with HIP events
+double sdvgn_debug_copy_rate(size_t bytes, int reps) {
+    copy_f4 *a = nullptr, *b = nullptr;
+    const size_t n = bytes / 16;
+    if (hipMalloc((void**)&a, n * 16) != hipSuccess || hipMalloc((void**)&b, n * 16) != hipSuccess) { if (a) hipFree(a); return -1.0; }
+    hipMemset(a, 1, n * 16);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    double best = -1.0;
+    for (int variant = 0; variant < 4; ++variant) {
+        const unsigned grid = variant == 3 ? 256 * 8 : 256 * 32;              // workgroups per CU x 256 CUs, grid-stride
+        auto launch = [&]() {
+            if (variant == 0) k_debug_copy4<1, false><<<grid, 256>>>(a, b, n);
+            else if (variant == 1) k_debug_copy4<4, false><<<grid, 256>>>(a, b, n);
+            else if (variant == 2) k_debug_copy4<4, true><<<grid, 256>>>(a, b, n);
+            else k_debug_copy4<8, false><<<grid, 256>>>(a, b, n);
+        };
+        launch();
+        hipEventRecord(e0);
+        for (int r = 0; r < reps; ++r) launch();
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms > 0) best = std::max(best, 2.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9);
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(a); hipFree(b);
+    return best;
 }
 // test rigs: caller-owned device buffers from the same fenced / banded / poisoned allocator (sdv-loam_amd/parallel.py, SDVGN_FENCE_EXTERNAL=1),
 // so that the buffers a caller hands to sdvgn_ef_set_external_buffers / _set_collective_buffer sit behind the same instruments as the library's own

@@ -27,6 +27,14 @@ def keyframe_update_leg(steps=8, world=None):
     prof = {}
     for _ in range(4):
         RW.prepare(); RW.step(prof=prof)
+    # the same steps from a plain-C host loop on include/sdvgn.h (tools/kf_host_loop.c): the ABI's consumer is a C++ host loop
+    tc = None
+    try:
+        ch = X.CHostLoop(RW)
+        ch.run(2)
+        tc = ch.run(steps)
+    except Exception as ex:  # noqa: BLE001
+        c_err = repr(ex)
     n = 4 + 6 * 8
     S = syn.subwindow(W, RW.win, np.concatenate([W.pts_of[f] for f in RW.win]), HM=W.HM[:n, :n], bM=W.bM[:n])
     G2 = api.EnergyFunctional(W.w, W.h, max_points=S.nP + 4096)
@@ -36,8 +44,11 @@ def keyframe_update_leg(steps=8, world=None):
         G2.load(S, raw_images=True); G2.optimize(6, want_trace=False, fixed_its=True); G2.optimize_finish()
         tl.append(time.perf_counter() - t0)
     t, tl = np.array(t), np.array(tl[1:])
-    return dict(value=float(6 / np.median(t)), unit="GN iters/s", steps=steps, bodies_per_keyframe=6,
-                ms_per_keyframe=dict(median=float(1e3 * np.median(t)), min=float(1e3 * t.min()), max=float(1e3 * t.max())),
+    tm = tc if tc is not None else t
+    return dict(value=float(6 / np.median(tm)), unit="GN iters/s", steps=steps, bodies_per_keyframe=6,
+                host_loop="C (tools/kf_host_loop.c on include/sdvgn.h)" if tc is not None else "Python (ctypes): the C harness did not load (%s)" % c_err,
+                ms_per_keyframe=dict(median=float(1e3 * np.median(tm)), min=float(1e3 * tm.min()), max=float(1e3 * tm.max())),
+                value_python_host_loop=float(6 / np.median(t)), ms_per_keyframe_python_host_loop=float(1e3 * np.median(t)),
                 host_phases_us={k: float(1e6 * np.median(v)) for k, v in prof.items()},
                 value_window_reload_inclusive=float(6 / np.median(tl)), ms_per_keyframe_reload=float(1e3 * np.median(tl)),
                 note="per key-frame: removePoint x 2000, marginalizeFrame, insertFrame (1.87 MB raw image from pinned memory, level 0 built on the device), "

@@ -114,6 +114,76 @@ class ResidentWindow:
         return tr
 
 
+class CHostLoop:
+    """the same steps from tools/kf_host_loop.c (plain C on include/sdvgn.h): what the cycle costs without a Python interpreter between the calls"""
+
+    def __init__(self, RW):
+        import ctypes as C
+        self.C = C
+        here = os.path.dirname(os.path.abspath(__file__))
+        self.lib = C.CDLL(os.path.join(here, "libkfloop.so"))
+        W = self.W = RW.W
+        self.RW = RW
+        F, P = W.nF, len(W.pts_of[0])
+        assert all(len(p) == P for p in W.pts_of)
+        f32, f64 = np.float32, np.float64
+        keep = self.keep = {}
+        keep["evalPT"] = np.ascontiguousarray(W.evalPT, f64); keep["state"] = np.ascontiguousarray(W.state, f64); keep["state_zero"] = np.ascontiguousarray(W.state_zero, f64)
+        keep["frameID"] = np.ascontiguousarray(W.frameID, np.int32); keep["th"] = np.ascontiguousarray(W.frameEnergyTH, f32)
+        for k, name in (("u", "u"), ("v", "v"), ("id", "idepth"), ("idz", "idepth_zero"), ("color", "color"), ("weights", "weights"), ("prior", "hasDepthPrior"),
+                        ("sensor", "isFromSensor")):
+            keep[k] = np.ascontiguousarray(np.concatenate([getattr(W, name)[W.pts_of[f]] for f in range(F)]))
+        keep["HM1"], keep["bM1"] = np.ascontiguousarray(RW.HM1, f64), np.ascontiguousarray(RW.bM1, f64)
+        img = (C.c_void_p * F)(*[im.ctypes.data for im in W.images])
+        keep["img"] = img
+
+        class KW(C.Structure):
+            _fields_ = [("F", C.c_int), ("P", C.c_int), ("w", C.c_int), ("h", C.c_int)] + [(n, C.c_void_p) for n in (
+                "evalPT7", "state10", "state_zero10", "frameID", "frameTH", "image", "u", "v", "idepth", "idepth_zero", "color8", "weights8", "prior", "sensor", "HM1", "bM1")]
+
+        class KS(C.Structure):
+            _fields_ = [("r_target", C.c_void_p), ("r_hasMatcher", C.c_void_p), ("r_matcher", C.c_void_p)]
+
+        class KSt(C.Structure):
+            _fields_ = [("win", C.c_int * 16), ("ids", C.c_void_p)]
+        self.KS = KS
+        p = lambda a: a.ctypes.data   # noqa: E731
+        self.kw = KW(F, P, W.w, W.h, p(keep["evalPT"]), p(keep["state"]), p(keep["state_zero"]), p(keep["frameID"]), p(keep["th"]), C.cast(img, C.c_void_p),
+                     p(keep["u"]), p(keep["v"]), p(keep["id"]), p(keep["idz"]), p(keep["color"]), p(keep["weights"]), p(keep["prior"]), p(keep["sensor"]),
+                     p(keep["HM1"]), p(keep["bM1"]))
+        self.ids = np.full((F, P), -1, np.int32)
+        for f, a in RW.ids.items():
+            self.ids[f] = a
+        self.st = KSt()
+        for k, f in enumerate(RW.win):
+            self.st.win[k] = f
+        self.st.ids = self.ids.ctypes.data
+        self.lib.kf_host_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+
+    def run(self, n_steps, its=6):
+        C, RW, W = self.C, self.RW, self.W
+        win = [self.st.win[k] for k in range(W.nF - 1)]
+        new_frames, steps, keep = [], (self.KS * n_steps)(), []
+        for s in range(n_steps):
+            RW.win = list(win)
+            RW.prepare()
+            new = [f for f in range(W.nF) if f not in win][0]
+            key = (new, tuple(win[1:]))
+            a, b, c = RW.r_target[new], RW.r_hm[key], RW.r_m[key]
+            keep.append((a, b, c))
+            steps[s] = self.KS(a.ctypes.data, b.ctypes.data, c.ctypes.data)
+            new_frames.append(new)
+            win = win[1:] + [new]
+        nf = np.array(new_frames, np.int32)
+        sec = np.zeros(n_steps)
+        rc = self.lib.kf_host_loop(RW.G.h_, C.byref(self.kw), C.byref(self.st), n_steps, nf.ctypes.data, C.cast(steps, C.c_void_p), its, sec.ctypes.data)
+        if rc:
+            raise RuntimeError("kf_host_loop: sdvgn error %d" % rc)
+        RW.win = win
+        RW.ids = {f: self.ids[f].copy() for f in win}
+        return sec
+
+
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     W = world()
@@ -145,7 +215,11 @@ def main():
         G2.load(S, raw_images=True); G2.optimize(6, want_trace=False, fixed_its=True); G2.optimize_finish()
         tl.append(time.perf_counter() - t0)
     tl = np.array(tl[1:]) * 1e3
+    ch = CHostLoop(RW)
+    ch.run(2)
+    tc = ch.run(steps) * 1e3
     out = dict(steps=steps, its_per_step=6, phases_host_us=phases,
+               c_host_loop_ms=dict(median=float(np.median(tc)), min=float(tc.min()), max=float(tc.max())), value_keyframe_update_inclusive_c_host_loop=float(6e3 / np.median(tc)),
                keyframe_update_ms=dict(median=float(np.median(t)), min=float(t.min()), max=float(t.max())),
                value_keyframe_update_inclusive=float(6e3 / np.median(t)),
                reload_ms=dict(median=float(np.median(tl)), min=float(tl.min()), max=float(tl.max())),

@@ -1,6 +1,6 @@
 """Profiling experiment (not product): time k_ef_linearize under the SDVGN_DEBUG_FLAGS variants."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from sdv_loam_amd import backend_api, synthetic as syn
 

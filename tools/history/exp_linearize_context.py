@@ -10,7 +10,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 PATTERNS = [(0, 0, "alone, back to back"), (1, 0, "behind accumulate + reduce"), (2, 0, "behind stitch + tail + resubstitute"),
             (3, 10, "behind a one-wave kernel waiting 10 us"), (3, 30, "behind a one-wave kernel waiting 30 us"),

@@ -12,7 +12,7 @@ import ctypes as C
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 os.environ.setdefault("SDVGN_DEBUG_FLAGS", "64")
 import torch  # noqa: E402,F401
 from sdv_loam_amd import backend_api, synthetic as syn  # noqa: E402

@@ -1,6 +1,6 @@
 """Profiling experiment (not product): time sdvgn_tracker_struct_pose."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from sdv_loam_amd import api, synthetic as syn
