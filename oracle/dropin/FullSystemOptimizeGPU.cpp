@@ -113,17 +113,24 @@ std::vector<EFPoint*> all_points(const EnergyFunctional* ef) {
 }
 
 // step 1 of the header comment: the graph as it is now against what the device holds
-void sync_window(GpuWindow& g, EnergyFunctional* ef, const std::vector<EFPoint*>& allPoints, CalibHessian& Hcalib) {
+// (the reference's objects are heap nodes scattered over memory: both walks below are chains of cache misses -- ~100 ns per residual object -- unless the
+// objects a few points ahead are requested early; pid_out[k] = library id of allPoints[k])
+void sync_window(GpuWindow& g, EnergyFunctional* ef, const std::vector<EFPoint*>& allPoints, CalibHessian& Hcalib, std::vector<int>& pid_out) {
     const int nF = ef->nFrames;
     ++g.epoch;
     // ---- points: seen -> known or new; not seen -> removed (removePoint :597-620) ----
     std::vector<int> new_host; std::vector<float> nu, nv, nid, nidz, ncol, nwt; std::vector<unsigned char> nprior, nsens;
     std::vector<const EFPoint*> new_pts;
-    for (const EFPoint* p : allPoints) {
+    const size_t nAll = allPoints.size();
+    pid_out.assign(nAll, -1);
+    for (size_t k_ = 0; k_ < nAll; ++k_) {
+        const EFPoint* p = allPoints[k_];
+        if (k_ + 8 < nAll) __builtin_prefetch(allPoints[k_ + 8]);
+        if (k_ + 4 < nAll) __builtin_prefetch(allPoints[k_ + 4]->data);
         auto it = g.id_of.find(p);
         if (it != g.id_of.end()) {
             PointMirror& m = g.pts[it->second];
-            if (m.ph == p->data && m.u == p->data->u && m.v == p->data->v && m.host_uid == p->host->data->shell->id) { m.seen = g.epoch; continue; }
+            if (m.ph == p->data && m.u == p->data->u && m.v == p->data->v && m.host_uid == p->host->data->shell->id) { m.seen = g.epoch; pid_out[k_] = it->second; continue; }
         }
         if (it != g.id_of.end()) g.id_of.erase(it);        // the address of a deleted EFPoint, re-used: the old id is removed below, this is a new point
         const PointHessian* ph = p->data;
@@ -194,8 +201,13 @@ void sync_window(GpuWindow& g, EnergyFunctional* ef, const std::vector<EFPoint*>
     std::vector<unsigned char> ins_hm, upd_hm; std::vector<double> ins_m, upd_m;
     int col_of_t[SDVGN_MAX_FRAMES];
     for (int t = 0; t < nF; ++t) col_of_t[t] = g.frame_col[t];
-    for (const EFPoint* p : allPoints) {
-        const int id = g.id_of[p];
+    for (size_t k_ = 0; k_ < nAll; ++k_) {
+        const EFPoint* p = allPoints[k_];
+        if (k_ + 6 < nAll) { const auto& v_ = allPoints[k_ + 6]->residualsAll; if (!v_.empty()) __builtin_prefetch(v_.data()); }
+        if (k_ + 3 < nAll) for (const EFResidual* r_ : allPoints[k_ + 3]->residualsAll) __builtin_prefetch(r_);
+        if (k_ + 1 < nAll) for (const EFResidual* r_ : allPoints[k_ + 1]->residualsAll) __builtin_prefetch(r_->data);
+        if (pid_out[k_] < 0) pid_out[k_] = g.id_of[p];
+        const int id = pid_out[k_];
         PointMirror& m = g.pts[id];
         int seen_here = 0;
         for (const EFResidual* r : p->residualsAll) {
@@ -291,7 +303,8 @@ float FullSystem::optimize(int mnumOptIts) {
     const auto t_0 = std::chrono::steady_clock::now();
     GpuWindow& g = window_for(this, nP);
     ++g.calls;
-    sync_window(g, ef, points, Hcalib);
+    std::vector<int> pid;
+    sync_window(g, ef, points, Hcalib, pid);
     g.us_sync = us_since(t_0);
 
     // ---- the loop (:353-458) and the tail's linearizeAll(true) (:460-470) on the device ----
@@ -372,8 +385,14 @@ float FullSystem::optimize(int mnumOptIts) {
         GPU_CK(sdvgn_ef_get_top_acc(g.h, nullptr, &resInA));
         ef->resInA = resInA;
     }
-    for (EFPoint* p : points) {
-        const int id = g.id_of[p], i = idx_of_id[id];
+    for (size_t k_ = 0; k_ < points.size(); ++k_) {
+        EFPoint* p = points[k_];
+        if (k_ + 8 < points.size()) __builtin_prefetch(points[k_ + 8]);
+        if (k_ + 6 < points.size()) __builtin_prefetch(points[k_ + 6]->data);
+        if (k_ + 4 < points.size()) { const auto& v_ = points[k_ + 4]->data->residuals; if (!v_.empty()) __builtin_prefetch(v_.data()); }
+        if (k_ + 2 < points.size()) for (PointFrameResidual* r_ : points[k_ + 2]->data->residuals) __builtin_prefetch(r_);
+        if (k_ + 1 < points.size()) for (PointFrameResidual* r_ : points[k_ + 1]->data->residuals) __builtin_prefetch(r_->efResidual);
+        const int id = pid[k_], i = idx_of_id[id];
         PointHessian* ph = p->data;
         const float* o = &pts9[9 * (size_t)i];
         ph->setIdepth(idp[i]);
