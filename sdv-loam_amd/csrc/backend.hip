@@ -149,6 +149,8 @@ struct sdvgn_ef {
     bool sys_on_device = false, sys_fetched = false, sys_valid = false;
     void* fin_dev = nullptr;       // outputs of sdvgn_ef_optimize_finish (relbs_max, ngood_inc, removed), grown on demand
     void* fin_host = nullptr;      // pinned mirror of fin_dev
+    void* jstage_dev = nullptr;    // staging of sdvgn_ef_set_residual_jacobians (slots | rows | res_toZero), grown on demand
+    size_t jstage_bytes = 0;
     size_t fin_bytes = 0;
     float* th_dev = nullptr;       // frameEnergyTH [2 sets][SDVGN_MAX_FRAMES]: one per state_New* set (setNewFrameEnergyTH after every linearizeAll)
     float* th_log = nullptr;       // pinned ring: threshold of the newest frame after each linearizeAll of the last optimize call (trace, tests)
@@ -1171,6 +1173,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
     if (e->imm_pc_host) SDVGN_HFREE(e->imm_pc_host);
     if (e->imm_stage) SDVGN_HFREE(e->imm_stage);
     if (e->fin_host) SDVGN_HFREE(e->fin_host);
+    if (e->jstage_dev) SDVGN_DFREE(e->jstage_dev);
     if (e->own_coll && e->coll[0]) SDVGN_DFREE(e->coll[0]);
     if (e->apply_bak.fl) { SDVGN_DFREE(e->apply_bak.fl); SDVGN_DFREE(e->apply_bak.st); SDVGN_DFREE(e->apply_bak.en); SDVGN_DFREE(e->apply_bak.JpJd); }
     win_delete(e->win);
@@ -1391,28 +1394,51 @@ int sdvgn_ef_set_residuals(sdvgn_ef* e, int nR, const int* point, const int* tar
 
 // EFResidual::takeDataF for Jacobians linearised on the host (EnergyFunctionalStructs.cpp:15-25): the rows go to the buffer the
 // EnergyFunctional side owns (RF_SEL as sdvgn_ef_set_residuals left it), JpJdF = Jpdxi[0] * Jpdd[0] + Jpdxi[1] * Jpdd[1] in float like the reference
+// (rows scattered on the device from one staged upload: the first version read all 48 Jacobian planes back, patched them on the host and wrote them
+// again -- 25 MB each way per call at the named size, for every solveSystemF of the drop-in's form A)
+__global__ void __launch_bounds__(256) k_ef_scatter_jacobians(int nR, size_t slots, const int* __restrict__ r_slot, const float* __restrict__ J24, const float* __restrict__ r2z,
+                                                              const uint8_t* __restrict__ rflags, float* __restrict__ J, float* __restrict__ JpJd, float* __restrict__ rres_toZero) {
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;     // 32 lanes per residual: 24 Jacobian planes | 6 JpJd | 2 res_toZero
+    if (i >= nR) return;
+    const size_t s = (size_t)r_slot[i];
+    const float* j = J24 + (size_t)i * 24;
+    if (k < kJPlanes) {
+        const int buf = (rflags[s] & RF_SEL) ? 1 : 0;
+        J[(size_t)buf * kJPlanes * slots + (size_t)k * slots + s] = j[k];
+    } else if (k < kJPlanes + 6) {
+        const int q = k - kJPlanes;
+        JpJd[(size_t)q * slots + s] = j[2 + q] * j[22] + j[8 + q] * j[23];        // takeDataF: Jpdxi[0] * Jpdd[0] + Jpdxi[1] * Jpdd[1], in float
+    } else if (r2z) {
+        const int q = k - kJPlanes - 6;
+        rres_toZero[(size_t)q * slots + s] = r2z[2 * i + q];
+    }
+}
 int sdvgn_ef_set_residual_jacobians(sdvgn_ef* e, int nR, const float* J24, const float* res_toZero2) {
     if (!e || !J24 || nR < 0 || nR != e->nR || e->nP < 1) return SDVGN_E_ARG;
     EF_DEVICE(e);
     e->applied_synced = false;   // (writes the first copies of the planes applyRes owns: see sdvgn_ef::applied_synced)
     const size_t slots = (size_t)e->nF * e->nP;
-    std::vector<uint8_t> fl(slots);
-    HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipMemcpy(fl.data(), e->rflags, slots, hipMemcpyDeviceToHost));
-    std::vector<float> J(2 * (size_t)kJPlanes * slots), JpJd(6 * slots, 0.0f), r2z(2 * slots, 0.0f);
-    HIPCHK(hipMemcpy(J.data(), e->J, sizeof(float) * J.size(), hipMemcpyDeviceToHost));
-    for (int i = 0; i < nR; ++i) {
-        const size_t s = (size_t)e->r_slot[i];
-        const int buf = (fl[s] & RF_SEL) ? 1 : 0;
-        const float* j = J24 + (size_t)i * 24;
-        float* dst = J.data() + (size_t)buf * kJPlanes * slots + s;
-        for (int k = 0; k < kJPlanes; ++k) dst[(size_t)k * slots] = j[k];
-        for (int k = 0; k < 6; ++k) JpJd[(size_t)k * slots + s] = j[2 + k] * j[22] + j[8 + k] * j[23];
-        if (res_toZero2) { r2z[s] = res_toZero2[2 * i]; r2z[slots + s] = res_toZero2[2 * i + 1]; }
+    const size_t need = (size_t)nR * (4 + 96 + 8);
+    if (need > e->jstage_bytes) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->jstage_dev) SDVGN_DFREE(e->jstage_dev);
+        e->jstage_dev = nullptr; e->jstage_bytes = 0;
+        const size_t cap = std::max(need, (size_t)e->slots_cap * (4 + 96 + 8) / 2);
+        HIPCHK(SDVGN_DMALLOC(&e->jstage_dev, cap));
+        e->jstage_bytes = cap;
     }
-    HIPCHK(hipMemcpy(e->J, J.data(), sizeof(float) * J.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->JpJd, JpJd.data(), sizeof(float) * JpJd.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->rres_toZero, r2z.data(), sizeof(float) * r2z.size(), hipMemcpyHostToDevice));
+    int* slot_d = (int*)e->jstage_dev;
+    float* j_d = (float*)((char*)e->jstage_dev + 4 * (size_t)nR);
+    float* z_d = j_d + 24 * (size_t)nR;
+    const hipStream_t s = e->stream;
+    HIPCHK(hipMemcpyAsync(slot_d, e->r_slot.data(), 4 * (size_t)nR, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(j_d, J24, 96 * (size_t)nR, hipMemcpyHostToDevice, s));
+    if (res_toZero2) HIPCHK(hipMemcpyAsync(z_d, res_toZero2, 8 * (size_t)nR, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(e->JpJd, 0, sizeof(float) * 6 * slots, s));               // (slots without a listed residual read 0, as before)
+    HIPCHK(hipMemsetAsync(e->rres_toZero, 0, sizeof(float) * 2 * slots, s));
+    if (nR > 0) k_ef_scatter_jacobians<<<(nR + 7) / 8, 256, 0, s>>>(nR, slots, slot_d, j_d, res_toZero2 ? z_d : nullptr, e->rflags, e->J, e->JpJd, e->rres_toZero);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));      // the caller's arrays may go away
     e->sys_valid = false;
     return SDVGN_OK;
 }
@@ -1915,7 +1941,7 @@ static int ef_launch_spec_solve(sdvgn_ef* e, int iteration_next, double lambda_n
     io.wait_xw = main_solve_in_flight ? e->xw_dev + 498 : nullptr; io.wait_seq = (unsigned)e->seq_solve;
     const ReclArgs no_rc{};
     const SelArgs no_sel{};
-    k_ef_tail_resub<<<1, kSolveLanes, 0, e->side>>>(io, no_rc, 0, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial, -1.0f,
+    k_ef_tail_lookahead<<<1, kSolveLanes, 0, e->side>>>(io, no_rc, 0, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial, -1.0f,
                                                    e->pid_alt, e->pidz_alt, e->pdeltaF_alt, 0, 0, 0, no_sel, -1, nullptr);
     HIPCHK(hipGetLastError());
     e->spec_last_buf = buf; e->spec_last_seq = io.done_seq;
@@ -1952,7 +1978,7 @@ static int ef_launch_spec_rest(sdvgn_ef* e, int iteration, double lambda, float 
     // here they would be the launch's duration (measured: 19 us for resubstitute + step with them, profiles/r04_notes.txt)
     const int n_recl = has_rc ? (rcl.nP + rcl.np_last * (rcl.nF - 1) + kSolveLanes - 1) / kSolveLanes : 0;
     const int lead = 1 + n_recl;                              // block indices [1, lead): the re-classification; block 0 (the factorisation) is not launched
-    k_ef_tail_resub<<<lead - 1 + rest + has_sel, kSolveLanes, 0, e->stream>>>(
+    k_ef_resub_after_reject<<<lead - 1 + rest + has_sel, kSolveLanes, 0, e->stream>>>(
         io, rcl, n_recl, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt,
         e->pdeltaF_alt, nblk, /*first_block=*/1, /*no_wait=*/0, sel, has_sel ? lead + rest : -1, thw);
     e->pend_sel_valid = false; e->pend_rc_valid = false;
@@ -2654,6 +2680,7 @@ int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_m
         HIPCHK(hipStreamSynchronize(e->stream));
         if (e->fin_dev) SDVGN_DFREE(e->fin_dev);
         if (e->fin_host) SDVGN_HFREE(e->fin_host);
+    if (e->jstage_dev) SDVGN_DFREE(e->jstage_dev);
         e->fin_dev = nullptr; e->fin_host = nullptr; e->fin_bytes = 0;
         const size_t cap = std::max(need, (size_t)e->slots_cap + 8 * (size_t)e->max_points);
         HIPCHK(SDVGN_DMALLOC(&e->fin_dev, cap));
@@ -3061,6 +3088,7 @@ int sdvgn_ef_optimize_immature(sdvgn_ef* e, int n, const int* host, const float*
         HIPCHK(hipStreamSynchronize(e->stream));
         if (e->imm_stage) SDVGN_HFREE(e->imm_stage);
     if (e->fin_host) SDVGN_HFREE(e->fin_host);
+    if (e->jstage_dev) SDVGN_DFREE(e->jstage_dev);
         e->imm_stage = nullptr; e->imm_stage_bytes = 0;
         HIPCHK(SDVGN_HMALLOC(&e->imm_stage, bytes * 2));
         e->imm_stage_bytes = bytes * 2;

@@ -756,6 +756,22 @@ def test_lockstep_full_size_and_batch_entry(api, orc):
         _same_window_result(G, S)
 
 
+def test_lockstep_grid_larger_than_the_chip(api, orc):
+    """k_lock_tail at B = 16 windows of the named size is a grid of 2 112 workgroups of 1 024 lanes -- four times what is resident at once -- in
+    which the resubstitute / step workgroups of every window spin on words its factorisation workgroup publishes: that ends only because the
+    factorisations (workgroup ids 0 .. B-1) are dispatched first (csrc/backend_lockstep.inc, comment at k_lock_tail).  All 16 loops must run to
+    the end without a give-up (no SDVGN_E_STATE) and leave every window where its own sdvgn_ef_optimize call leaves it, bit for bit."""
+    from sdv_loam_amd import synthetic as syn
+    Ws = [low_thresholds(syn.make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=k, calib=syn.KITTI00, state_sigma=3e-3, idepth_sigma=0.02)) for k in range(2)]
+    solo = [api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W) for W in Ws]
+    tr_solo = [G.optimize(6, fixed_its=True) for G in solo]
+    Gs = [api.EnergyFunctional(Ws[b % 2].w, Ws[b % 2].h, max_points=Ws[b % 2].nP).load(Ws[b % 2]) for b in range(16)]
+    n, tr = api.optimize_lockstep(Gs, 6, fixed_its=True)
+    for b, G in enumerate(Gs):
+        assert n[b] == 6 and np.array_equal(tr[b], tr_solo[b % 2]), b
+        _same_window_result(G, solo[b % 2])
+
+
 def test_lockstep_refuses_what_it_does_not_take(api, orc, window):
     import ctypes as C
     G = api.EnergyFunctional(window.w, window.h, max_points=window.nP).load(window)

@@ -265,3 +265,26 @@ def test_reference_make_keyframe_on_gpu(sdvgn_lib, orc, cfg):
     st = D.gpu_stats()
     assert st["frames_uploaded"] == nF0 + 1                                              # ONE image per key-frame, ever
     assert st["points_inserted"] == S.nP + len(newp) and st["points_removed"] > 0 and st["residuals_inserted"] >= S.nR + len(old)
+
+
+@needs_dropin_opt
+def test_reference_optimize_fast_path_idepth_zero_offset(sdvgn_lib, orc):
+    """The resident-window drop-in on a window whose points come with idepth != idepth_zero and whose first step is rejected (the reference's
+    loadSateBackup then moves idepth_zero, FullSystemOptimize.cpp:276-277): the reference's FullSystem::optimize all-CPU vs on the GPU window --
+    same accept / reject sequence, states within 1e-4 (this edge had only met the plain handle)."""
+    from oracle.backend import RefEF
+    from oracle.dropin import DropinOptEF
+    from sdv_loam_amd import synthetic as syn
+    W = syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=3, calib=dict(fx=400., fy=410., cx=319.5, cy=119.5))
+    W.idepth_zero = (W.idepth + np.random.default_rng(1).normal(0, 2e-4, W.nP)).astype(np.float32)
+    R, D = RefEF(W.w, W.h).load(W), DropinOptEF(W.w, W.h).load(W)
+    R.compute_nullspaces(); D.compute_nullspaces()
+    rmse_r, steps_r, removed_r, _ = R.optimize_full(6)
+    rmse_d, steps_d, removed_d, _ = D.optimize_full(6)
+    assert D.gpu_calls() == 1 and not steps_r[0][0]                                     # first step rejected
+    assert [s_[0] for s_ in steps_d] == [s_[0] for s_ in steps_r]
+    assert np.allclose([s_[2] for s_ in steps_d], [s_[2] for s_ in steps_r], rtol=1e-5, atol=2e-3)
+    vr, sr, ir = R.state()
+    vd, sd, idd = D.state()
+    assert np.allclose(vd, vr, rtol=1e-7) and rel_err(sd, sr) < 1e-4 and rel_err(idd, ir) < 1e-4
+    assert np.array_equal(removed_d, removed_r) and abs(rmse_d - rmse_r) <= 1e-5 * rmse_r
