@@ -2661,6 +2661,10 @@ int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_m
     EF_DEVICE(e);
     e->applied_synced = false;   // (writes the first copies of the planes applyRes owns: see sdvgn_ef::applied_synced)
     const int nF = e->nF;
+    static const bool fin_timing = getenv("SDVGN_OPT_TIMING") != nullptr;
+    using fclk = std::chrono::steady_clock;
+    fclk::time_point ft[6];
+    ft[0] = fclk::now();
     FrameH& nf = e->frames[nF - 1];
     const double newStateZero[10] = {0, 0, 0, 0, 0, 0, nf.state[6], nf.state[7], 0, 0};
     nf.evalPT = nf.PRE_worldToCam;
@@ -2672,6 +2676,7 @@ int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_m
     if ((rc = ef_upload_precalc(e))) return rc;
     ef_select_new_set(e, e->new_cur, e->new_cur);
     double energy = 0, EL = 0;
+    ft[1] = fclk::now();
     // everything is queued before anything is waited for: linearise + its sums, applyRes, the per-point bookkeeping, ONE copy of the outputs
     if ((rc = linearize_launch(e))) return rc;
     if ((rc = sdvgn_ef_apply_res(e))) return rc;
@@ -2694,8 +2699,11 @@ int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_m
     HIPCHK(hipGetLastError());
     // the three outputs lie back to back on the device: ONE copy into pinned memory, one wait
     HIPCHK(hipMemcpyAsync(e->fin_host, e->fin_dev, need, hipMemcpyDeviceToHost, e->stream));
+    ft[2] = fclk::now();
     if ((rc = linearize_wait(e, &energy, &EL, nullptr, nullptr))) return rc;
+    ft[3] = fclk::now();
     HIPCHK(hipStreamSynchronize(e->stream));
+    ft[4] = fclk::now();
     const float* rb = (const float*)e->fin_host;
     const int* ng = (const int*)e->fin_host + e->nP;
     const uint8_t* rm = (const uint8_t*)e->fin_host + 8 * (size_t)e->nP;
@@ -2705,6 +2713,12 @@ int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_m
     if (removed) {
         if (e->table_mode) std::memcpy(removed, rm, slots);    // by slot (target * nP + point index): the window is edited in place, there is no residual list
         else for (int i = 0; i < e->nR; ++i) removed[i] = rm[(size_t)e->r_slot[i]];
+    }
+    if (fin_timing) {
+        ft[5] = fclk::now();
+        auto us = [&](int a, int b) { return std::chrono::duration<double, std::micro>(ft[b] - ft[a]).count(); };
+        fprintf(stderr, "[sdvgn] optimize_finish: adjoints + precalc %.1f | launches %.1f | wait linearise %.1f | wait copy %.1f | outputs %.1f us\n",
+                us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5));
     }
     return SDVGN_OK;
 }
