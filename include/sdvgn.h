@@ -433,10 +433,15 @@ int sdvgn_ef_get_res_toZero(sdvgn_ef* ef, float* res_toZero2, unsigned char* isL
  * points mirror those members, so that a key-frame costs one image upload and a few hundred kB of edits instead of every table and every
  * image again (the whole-plane setters above).  Edits are collected on the host; sdvgn_ef_make_idx -- EnergyFunctional::makeIDX, the
  * reference's own commit point (EnergyFunctional.cpp:761-782) -- applies them ON THE DEVICE (one gather pass over the per-point planes and the
- * flags / state / matcher planes, new rows from one staged upload).  Until the commit every other entry point sees the window of the last
- * commit.  After it the tables are bit-identical with a reload of the same graph in the same order through the setters above.
- *   Points are addressed by stable ids (sdvgn_ef_insert_points returns them; a window loaded through sdvgn_ef_set_points has id = index),
- *   frames by their CURRENT index (like EFFrame::idx, renumbered by a removal), residuals by (point id, target frame index).
+ * flags / state / matcher planes; new points and residual edits from 96- / 16-byte records the entry points leave in pinned memory and send
+ * at once -- the argument arrays may be reused when a call returns -- resolved to table slots by the commit's kernels).  Until the commit
+ * every other entry point sees the window of the last commit.  After it the tables are bit-identical with a reload of the same graph in the
+ * same order through the setters above.
+ *   Points are addressed by ids (sdvgn_ef_insert_points returns them; a window loaded through sdvgn_ef_set_points has id = index) that stay
+ *   valid until the point is removed; the id of a removed point may be returned for a new point after the NEXT commit, never before (an edit
+ *   recorded on a point that leaves before the commit is void), so ids stay below 2 x max_points for any length of run.
+ *   Frames are addressed by their CURRENT index (like EFFrame::idx, renumbered by a removal), residuals by (point id, target frame index); an
+ *   edit towards a frame that is removed before the commit is void.
  *   Inside a host frame the points keep EFFrame::points' order: insertPoint appends, removePoint moves the LAST point into the hole
  *   (EnergyFunctional.cpp:414-432, 597-620).  sdvgn_ef_get_point_ids gives the dense order after a commit; per-point getters and the
  *   slot tables (slot = target * nP + dense index) follow it.

@@ -25,6 +25,9 @@
 //      ef->lastX / resInA, statistics_lastFineTrackRMSE, the shells' poses, isLost, the return value.
 //   NOT written back: RawResidualJacobian contents (efResidual->J, r->J) and projectedTo[] -- nothing on the host reads them before the next
 //   linearize rewrites them (flagPointsForRemoval re-linearises the residuals it fixes, FullSystem.cpp:771-783; projectedTo feeds debugPlot only).
+// The two graph walks (1. and 4.) are chains of cache misses over the reference's heap objects and independent point by point: they run on
+// SDVGN_DROPIN_THREADS host threads (default 4; 1 = in the calling thread), with everything that touches shared structures -- the edit calls, the
+// toRemove surgery, the mirror's id map -- kept in the calling thread in the reference's order, so the result does not depend on the thread count.
 // There is no CPU fallback: a failing sdvgn_* call aborts like the reference's live asserts do.
 #include "FullSystem/FullSystem.h"
 #include "FullSystem/ResidualProjections.h"
@@ -44,6 +47,8 @@ extern "C" {
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -80,6 +85,39 @@ void die(const char* what, int rc) {
 }
 #define GPU_CK(call) do { const int _rc = (call); if (_rc < 0) die(#call, _rc); } while (0)
 double us_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+
+int dropin_threads() {
+    const char* s = getenv("SDVGN_DROPIN_THREADS");
+    const int v = s ? atoi(s) : 4;
+    return v < 1 ? 1 : (v > 64 ? 64 : v);
+}
+// f(chunk, begin, end) over [0, n) in contiguous chunks, chunk c on its own thread (the last one on the caller's); returns the number of chunks
+template <class F>
+int for_chunks(size_t n, F f) {
+    int T = dropin_threads();
+    if ((size_t)T > n / 512 + 1) T = (int)(n / 512 + 1);
+    if (T <= 1) { f(0, (size_t)0, n); return 1; }
+    std::vector<std::thread> th;
+    th.reserve(T - 1);
+    const size_t per = (n + T - 1) / T;
+    for (int c = 0; c + 1 < T; ++c) th.emplace_back([=, &f] { f(c, std::min(n, c * per), std::min(n, (c + 1) * per)); });
+    f(T - 1, std::min(n, (T - 1) * per), n);
+    for (std::thread& t : th) t.join();
+    return T;
+}
+
+struct Laps {      // SDVGN_DROPIN_TIMING=1: where a call's host time goes, one line per call on stderr
+    bool on = getenv("SDVGN_DROPIN_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    std::string line;
+    void lap(const char* what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        char b[96]; snprintf(b, sizeof b, " %s %.0f |", what, std::chrono::duration<double, std::micro>(n - t).count());
+        line += b; t = n;
+    }
+    void print(const char* head) { if (on) fprintf(stderr, "[dropin] %s:%s us\n", head, line.c_str()); }
+};
 
 void pose7(const SE3& T, double* o) {     // Sophus data(): [qx qy qz qw], then the translation
     const double* q = T.so3().data();
@@ -118,23 +156,33 @@ std::vector<EFPoint*> all_points(const EnergyFunctional* ef) {
 void sync_window(GpuWindow& g, EnergyFunctional* ef, const std::vector<EFPoint*>& allPoints, CalibHessian& Hcalib, std::vector<int>& pid_out) {
     const int nF = ef->nFrames;
     ++g.epoch;
+    Laps L;
     // ---- points: seen -> known or new; not seen -> removed (removePoint :597-620) ----
     std::vector<int> new_host; std::vector<float> nu, nv, nid, nidz, ncol, nwt; std::vector<unsigned char> nprior, nsens;
     std::vector<const EFPoint*> new_pts;
     const size_t nAll = allPoints.size();
     pid_out.assign(nAll, -1);
-    for (size_t k_ = 0; k_ < nAll; ++k_) {
-        const EFPoint* p = allPoints[k_];
-        if (k_ + 8 < nAll) __builtin_prefetch(allPoints[k_ + 8]);
-        if (k_ + 4 < nAll) __builtin_prefetch(allPoints[k_ + 4]->data);
-        auto it = g.id_of.find(p);
-        if (it != g.id_of.end()) {
+    // known points (the map and the mirrors are only read / marked here: distinct points, distinct mirrors)
+    for_chunks(nAll, [&](int, size_t k0, size_t k1) {
+        for (size_t k_ = k0; k_ < k1; ++k_) {
+            const EFPoint* p = allPoints[k_];
+            if (k_ + 8 < k1) __builtin_prefetch(allPoints[k_ + 8]);
+            if (k_ + 4 < k1) __builtin_prefetch(allPoints[k_ + 4]->data);
+            auto it = g.id_of.find(p);
+            if (it == g.id_of.end()) continue;
             PointMirror& m = g.pts[it->second];
-            if (m.ph == p->data && m.u == p->data->u && m.v == p->data->v && m.host_uid == p->host->data->shell->id) { m.seen = g.epoch; pid_out[k_] = it->second; continue; }
+            if (m.ph == p->data && m.u == p->data->u && m.v == p->data->v && m.host_uid == p->host->data->shell->id) { m.seen = g.epoch; pid_out[k_] = it->second; }
         }
+    });
+    L.lap("known points");
+    std::vector<size_t> new_k;
+    for (size_t k_ = 0; k_ < nAll; ++k_) {
+        if (pid_out[k_] >= 0) continue;
+        const EFPoint* p = allPoints[k_];
+        auto it = g.id_of.find(p);
         if (it != g.id_of.end()) g.id_of.erase(it);        // the address of a deleted EFPoint, re-used: the old id is removed below, this is a new point
         const PointHessian* ph = p->data;
-        new_pts.push_back(p);
+        new_pts.push_back(p); new_k.push_back(k_);
         new_host.push_back(p->host->idx);
         nu.push_back(ph->u); nv.push_back(ph->v); nid.push_back(ph->idepth); nidz.push_back(ph->idepth_zero);
         for (int k = 0; k < 8; ++k) { ncol.push_back(ph->color[k]); nwt.push_back(ph->weights[k]); }
@@ -153,6 +201,7 @@ void sync_window(GpuWindow& g, EnergyFunctional* ef, const std::vector<EFPoint*>
         if (!gone.empty()) GPU_CK(sdvgn_ef_remove_points(g.h, (int)gone.size(), gone.data()));
         g.points_removed += gone.size();
     }
+    L.lap("new + gone points");
     // ---- frames that left (marginalizeFrame, EnergyFunctional.cpp:434-512) ----
     for (int t = (int)g.frames.size() - 1; t >= 0; --t) {
         bool alive = false;
@@ -193,55 +242,73 @@ void sync_window(GpuWindow& g, EnergyFunctional* ef, const std::vector<EFPoint*>
             m.p = new_pts[k]; m.ph = new_pts[k]->data; m.seen = g.epoch;
             m.u = m.ph->u; m.v = m.ph->v; m.host_uid = new_pts[k]->host->data->shell->id;
             g.id_of[new_pts[k]] = ids[k];
+            pid_out[new_k[k]] = ids[k];
         }
         g.points_inserted += new_pts.size();
     }
+    L.lap("frames + insert_points");
     // ---- residuals: inserted (insertResidual :400-412), matcher set since (findMatches, FullSystem.cpp:1121-1133), dropped (dropResidual :578-595) ----
-    std::vector<int> ins_id, ins_t, ins_st, upd_id, upd_t, upd_st, drp_id, drp_t;
-    std::vector<unsigned char> ins_hm, upd_hm; std::vector<double> ins_m, upd_m;
+    struct ResEdits { std::vector<int> ins_id, ins_t, ins_st, upd_id, upd_t, upd_st, drp_id, drp_t; std::vector<unsigned char> ins_hm, upd_hm; std::vector<double> ins_m, upd_m; };
+    std::vector<ResEdits> part(64);
     int col_of_t[SDVGN_MAX_FRAMES];
     for (int t = 0; t < nF; ++t) col_of_t[t] = g.frame_col[t];
-    for (size_t k_ = 0; k_ < nAll; ++k_) {
-        const EFPoint* p = allPoints[k_];
-        if (k_ + 6 < nAll) { const auto& v_ = allPoints[k_ + 6]->residualsAll; if (!v_.empty()) __builtin_prefetch(v_.data()); }
-        if (k_ + 3 < nAll) for (const EFResidual* r_ : allPoints[k_ + 3]->residualsAll) __builtin_prefetch(r_);
-        if (k_ + 1 < nAll) for (const EFResidual* r_ : allPoints[k_ + 1]->residualsAll) __builtin_prefetch(r_->data);
-        if (pid_out[k_] < 0) pid_out[k_] = g.id_of[p];
-        const int id = pid_out[k_];
-        PointMirror& m = g.pts[id];
-        int seen_here = 0;
-        for (const EFResidual* r : p->residualsAll) {
-            const int t = r->targetIDX, col = col_of_t[t];
-            ResMirror& rm = m.r[col];
-            const PointFrameResidual* pr = r->data;
-            const unsigned char hm = pr->hasMatcher ? 1 : 0;
-            const float mx = (float)pr->matcher[0], my = (float)pr->matcher[1];
-            if (rm.uid != g.frame_uid[t]) {
-                ins_id.push_back(id); ins_t.push_back(t); ins_st.push_back((int)pr->state_state); ins_hm.push_back(hm);
-                ins_m.push_back(pr->matcher[0]); ins_m.push_back(pr->matcher[1]);
-                rm.uid = g.frame_uid[t]; ++m.n_res;
-            } else if (rm.hasMatcher != hm || (hm && (rm.mx != mx || rm.my != my))) {
-                upd_id.push_back(id); upd_t.push_back(t); upd_st.push_back((int)pr->state_state); upd_hm.push_back(hm);
-                upd_m.push_back(pr->matcher[0]); upd_m.push_back(pr->matcher[1]);
+    const int n_part = for_chunks(nAll, [&](int c, size_t k0, size_t k1) {
+        ResEdits& E = part[c];
+        for (size_t k_ = k0; k_ < k1; ++k_) {
+            const EFPoint* p = allPoints[k_];
+            if (k_ + 6 < k1) { const auto& v_ = allPoints[k_ + 6]->residualsAll; if (!v_.empty()) __builtin_prefetch(v_.data()); }
+            if (k_ + 3 < k1) for (const EFResidual* r_ : allPoints[k_ + 3]->residualsAll) __builtin_prefetch(r_);
+            if (k_ + 1 < k1) for (const EFResidual* r_ : allPoints[k_ + 1]->residualsAll) __builtin_prefetch(r_->data);
+            const int id = pid_out[k_];
+            PointMirror& m = g.pts[id];
+            int seen_here = 0;
+            for (const EFResidual* r : p->residualsAll) {
+                const int t = r->targetIDX, col = col_of_t[t];
+                ResMirror& rm = m.r[col];
+                const PointFrameResidual* pr = r->data;
+                const unsigned char hm = pr->hasMatcher ? 1 : 0;
+                const float mx = (float)pr->matcher[0], my = (float)pr->matcher[1];
+                if (rm.uid != g.frame_uid[t]) {
+                    E.ins_id.push_back(id); E.ins_t.push_back(t); E.ins_st.push_back((int)pr->state_state); E.ins_hm.push_back(hm);
+                    E.ins_m.push_back(pr->matcher[0]); E.ins_m.push_back(pr->matcher[1]);
+                    rm.uid = g.frame_uid[t]; ++m.n_res;
+                } else if (rm.hasMatcher != hm || (hm && (rm.mx != mx || rm.my != my))) {
+                    E.upd_id.push_back(id); E.upd_t.push_back(t); E.upd_st.push_back((int)pr->state_state); E.upd_hm.push_back(hm);
+                    E.upd_m.push_back(pr->matcher[0]); E.upd_m.push_back(pr->matcher[1]);
+                }
+                rm.hasMatcher = hm; rm.mx = mx; rm.my = my; rm.seen = g.epoch;
+                ++seen_here;
             }
-            rm.hasMatcher = hm; rm.mx = mx; rm.my = my; rm.seen = g.epoch;
-            ++seen_here;
-        }
-        if (seen_here != m.n_res) {                 // some of this point's device residuals are gone on the host
-            for (int t = 0; t < nF; ++t) {
-                ResMirror& rm = m.r[col_of_t[t]];
-                if (rm.uid == g.frame_uid[t] && rm.seen != g.epoch) { drp_id.push_back(id); drp_t.push_back(t); rm = ResMirror(); --m.n_res; }
+            if (seen_here != m.n_res) {                 // some of this point's device residuals are gone on the host
+                for (int t = 0; t < nF; ++t) {
+                    ResMirror& rm = m.r[col_of_t[t]];
+                    if (rm.uid == g.frame_uid[t] && rm.seen != g.epoch) { E.drp_id.push_back(id); E.drp_t.push_back(t); rm = ResMirror(); --m.n_res; }
+                }
+                // (columns of frames that left were dropped with their frame)
+                int n = 0;
+                for (int t = 0; t < nF; ++t) if (m.r[col_of_t[t]].uid == g.frame_uid[t]) ++n;
+                m.n_res = n;
             }
-            // (columns of frames that left were dropped with their frame)
-            int n = 0;
-            for (int t = 0; t < nF; ++t) if (m.r[col_of_t[t]].uid == g.frame_uid[t]) ++n;
-            m.n_res = n;
         }
+    });
+    L.lap("residual diff");
+    // the chunks' edits in the order of the points (= what one thread would have recorded)
+    ResEdits& A = part[0];
+    for (int c = 1; c < n_part; ++c) {
+        ResEdits& E = part[c];
+        auto cat = [](auto& d, const auto& s_) { d.insert(d.end(), s_.begin(), s_.end()); };
+        cat(A.ins_id, E.ins_id); cat(A.ins_t, E.ins_t); cat(A.ins_st, E.ins_st); cat(A.ins_hm, E.ins_hm); cat(A.ins_m, E.ins_m);
+        cat(A.upd_id, E.upd_id); cat(A.upd_t, E.upd_t); cat(A.upd_st, E.upd_st); cat(A.upd_hm, E.upd_hm); cat(A.upd_m, E.upd_m);
+        cat(A.drp_id, E.drp_id); cat(A.drp_t, E.drp_t);
     }
+    std::vector<int>&ins_id = A.ins_id, &ins_t = A.ins_t, &ins_st = A.ins_st, &upd_id = A.upd_id, &upd_t = A.upd_t, &upd_st = A.upd_st, &drp_id = A.drp_id, &drp_t = A.drp_t;
+    std::vector<unsigned char>&ins_hm = A.ins_hm, &upd_hm = A.upd_hm;
+    std::vector<double>&ins_m = A.ins_m, &upd_m = A.upd_m;
     if (!drp_id.empty()) GPU_CK(sdvgn_ef_drop_residuals(g.h, (int)drp_id.size(), drp_id.data(), drp_t.data()));
     if (!ins_id.empty()) GPU_CK(sdvgn_ef_insert_residuals(g.h, (int)ins_id.size(), ins_id.data(), ins_t.data(), ins_st.data(), ins_hm.data(), ins_m.data()));
     if (!upd_id.empty()) GPU_CK(sdvgn_ef_update_residuals(g.h, (int)upd_id.size(), upd_id.data(), upd_t.data(), upd_st.data(), upd_hm.data(), upd_m.data()));
     g.res_inserted += ins_id.size(); g.res_dropped += drp_id.size(); g.res_updated += upd_id.size();
+    L.lap("residual edit calls");
     // ---- step 2: what the host loop owns and may have moved since the last call ----
     double vs[4], vmz[4];
     for (int k = 0; k < 4; ++k) { vs[k] = Hcalib.value_scaled[k]; vmz[k] = Hcalib.value_minus_value_zero[k]; }
@@ -255,7 +322,9 @@ void sync_window(GpuWindow& g, EnergyFunctional* ef, const std::vector<EFPoint*>
         abx[t] = fh->ab_exposure;
     }
     GPU_CK(sdvgn_ef_update_frames(g.h, nF, ev.data(), st.data(), sz.data(), abx.data()));
+    L.lap("calib + frames");
     GPU_CK(sdvgn_ef_make_idx(g.h));
+    L.lap("make_idx");
     const int n = CPARS + 6 * nF;
     std::vector<double> HMr((size_t)n * n), bMr(n);
     for (int r = 0; r < n; ++r) { bMr[r] = ef->bM[r]; for (int c = 0; c < n; ++c) HMr[(size_t)r * n + c] = ef->HM(r, c); }
@@ -263,6 +332,8 @@ void sync_window(GpuWindow& g, EnergyFunctional* ef, const std::vector<EFPoint*>
     GPU_CK(sdvgn_ef_compute_nullspaces(g.h));             // FullSystem::getNullspaces (:548-588): a function of the linearisation points
     GPU_CK(sdvgn_ef_set_adjoints(g.h));
     GPU_CK(sdvgn_ef_set_precalc(g.h));
+    L.lap("prior + nullspaces + adjoints + precalc");
+    L.print("sync");
 }
 
 }  // namespace
@@ -298,7 +369,9 @@ float FullSystem::optimize(int mnumOptIts) {
     if (frameHessians.size() < 2) return 0;                                   // FullSystemOptimize.cpp:347-349
     if (frameHessians.size() < 3) mnumOptIts = 100;
     if (frameHessians.size() < 4) mnumOptIts = 75;
+    Laps LP;
     const std::vector<EFPoint*> points = all_points(ef);
+    LP.lap("all_points");
     const int nF = ef->nFrames, n = CPARS + 6 * nF, nP = (int)points.size();
     const auto t_0 = std::chrono::steady_clock::now();
     GpuWindow& g = window_for(this, nP);
@@ -345,6 +418,7 @@ float FullSystem::optimize(int mnumOptIts) {
 
     // ---- step 4: what FullSystem::optimize leaves behind ----
     const auto t_2 = std::chrono::steady_clock::now();
+    Laps LW;
     {   // the tail on the reference's objects, with the reference's own members (:460-466)
         Vec10 newStateZero = Vec10::Zero();
         newStateZero.segment<2>(6) = frameHessians.back()->get_state().segment<2>(6);
@@ -354,6 +428,7 @@ float FullSystem::optimize(int mnumOptIts) {
         ef->setAdjointsF(&Hcalib);
         setPrecalcValues();
     }
+    LW.lap("setEvalPT + setAdjointsF + setPrecalcValues");
     std::vector<int> ids(nP);
     GPU_CK(sdvgn_ef_get_point_ids(g.h, ids.data()));
     std::vector<int> idx_of_id(g.pts.size(), -1);
@@ -385,49 +460,67 @@ float FullSystem::optimize(int mnumOptIts) {
         GPU_CK(sdvgn_ef_get_top_acc(g.h, nullptr, &resInA));
         ef->resInA = resInA;
     }
-    for (size_t k_ = 0; k_ < points.size(); ++k_) {
-        EFPoint* p = points[k_];
-        if (k_ + 8 < points.size()) __builtin_prefetch(points[k_ + 8]);
-        if (k_ + 6 < points.size()) __builtin_prefetch(points[k_ + 6]->data);
-        if (k_ + 4 < points.size()) { const auto& v_ = points[k_ + 4]->data->residuals; if (!v_.empty()) __builtin_prefetch(v_.data()); }
-        if (k_ + 2 < points.size()) for (PointFrameResidual* r_ : points[k_ + 2]->data->residuals) __builtin_prefetch(r_);
-        if (k_ + 1 < points.size()) for (PointFrameResidual* r_ : points[k_ + 1]->data->residuals) __builtin_prefetch(r_->efResidual);
-        const int id = pid[k_], i = idx_of_id[id];
-        PointHessian* ph = p->data;
-        const float* o = &pts9[9 * (size_t)i];
-        ph->setIdepth(idp[i]);
-        ph->setIdepthZero(idp[i]);                                             // doStepFromBackup / loadSateBackup keep both equal (:218,:279)
-        ph->step = o[8];
-        p->Hdd_accAF = o[0]; p->bd_accAF = o[1];
-        for (int k = 0; k < 4; ++k) p->Hcd_accAF[k] = o[2 + k];
-        p->HdiF = o[6]; p->bdSumF = o[7];
-        // AccumulatedSCHessianSSE::addPoint of the last solveSystemF (AccumulatedSCHessian.cpp:12-28)
-        if (o[6] == 0.0f) { ph->idepth_hessian = 0; ph->maxRelBaseline = 0; }
-        else { float H = p->Hdd_accAF + p->Hdd_accLF + p->priorF; if (H < 1e-10) H = 1e-10; ph->idepth_hessian = H; }
-        // linearizeAll(true), the isNew bookkeeping (FullSystemOptimize.cpp:34-47)
-        if (relbs[i] > ph->maxRelBaseline) ph->maxRelBaseline = relbs[i];
-        ph->numGoodResiduals += ngood[i];
-        PointMirror& m = g.pts[id];
-        for (size_t k = 0; k < ph->residuals.size(); ++k) {
-            PointFrameResidual* r = ph->residuals[k];
-            const int t = r->efResidual->targetIDX;
-            const size_t s = (size_t)t * nP + i;
-            if (!ex[s] && !removed[s]) die("a residual of the host graph does not exist on the device", -1);
-            r->state_NewEnergyWithOutlier = ewo[s];
-            r->state_NewState = (ResState)snew[s];
-            r->state_NewEnergy = enn[s];
-            r->setState((ResState)sst[s]);
-            r->state_energy = en[s];
-            r->efResidual->isActiveAndIsGoodNEW = act[s] != 0;
-            {   // centerProjectedTo as linearize leaves it (Residuals.cpp:90-97), by the reference's own projection
-                FrameFramePrecalc* pc = &(r->host->targetPrecalc[r->target->idx]);
-                float drescale, u, v, Ku, Kv, new_idepth; Vec3f KliP;
-                if (r->hasMatcher && projectPoint(ph->u, ph->v, ph->idepth_zero_scaled, 0, 0, &Hcalib, pc->PRE_RTll_0, pc->PRE_tTll_0, drescale, u, v, Ku, Kv, KliP, new_idepth))
-                    r->centerProjectedTo = Vec3f(Ku, Kv, new_idepth);
+    LW.lap("getters");
+    // per point: independent of every other point except for the toRemove surgery, which is collected and done below in the points' order
+    std::vector<std::vector<size_t>> with_removed(64);
+    const int n_part = for_chunks(points.size(), [&](int c, size_t k0, size_t k1) {
+        for (size_t k_ = k0; k_ < k1; ++k_) {
+            EFPoint* p = points[k_];
+            if (k_ + 8 < k1) __builtin_prefetch(points[k_ + 8]);
+            if (k_ + 6 < k1) __builtin_prefetch(points[k_ + 6]->data);
+            if (k_ + 4 < k1) { const auto& v_ = points[k_ + 4]->data->residuals; if (!v_.empty()) __builtin_prefetch(v_.data()); }
+            if (k_ + 2 < k1) for (PointFrameResidual* r_ : points[k_ + 2]->data->residuals) __builtin_prefetch(r_);
+            if (k_ + 1 < k1) for (PointFrameResidual* r_ : points[k_ + 1]->data->residuals) __builtin_prefetch(r_->efResidual);
+            const int id = pid[k_], i = idx_of_id[id];
+            PointHessian* ph = p->data;
+            const float* o = &pts9[9 * (size_t)i];
+            ph->setIdepth(idp[i]);
+            ph->setIdepthZero(idp[i]);                                             // doStepFromBackup / loadSateBackup keep both equal (:218,:279)
+            ph->step = o[8];
+            p->Hdd_accAF = o[0]; p->bd_accAF = o[1];
+            for (int k = 0; k < 4; ++k) p->Hcd_accAF[k] = o[2 + k];
+            p->HdiF = o[6]; p->bdSumF = o[7];
+            // AccumulatedSCHessianSSE::addPoint of the last solveSystemF (AccumulatedSCHessian.cpp:12-28)
+            if (o[6] == 0.0f) { ph->idepth_hessian = 0; ph->maxRelBaseline = 0; }
+            else { float H = p->Hdd_accAF + p->Hdd_accLF + p->priorF; if (H < 1e-10) H = 1e-10; ph->idepth_hessian = H; }
+            // linearizeAll(true), the isNew bookkeeping (FullSystemOptimize.cpp:34-47)
+            if (relbs[i] > ph->maxRelBaseline) ph->maxRelBaseline = relbs[i];
+            ph->numGoodResiduals += ngood[i];
+            bool any_removed = false;
+            for (size_t k = 0; k < ph->residuals.size(); ++k) {
+                PointFrameResidual* r = ph->residuals[k];
+                const int t = r->efResidual->targetIDX;
+                const size_t s = (size_t)t * nP + i;
+                if (!ex[s] && !removed[s]) die("a residual of the host graph does not exist on the device", -1);
+                r->state_NewEnergyWithOutlier = ewo[s];
+                r->state_NewState = (ResState)snew[s];
+                r->state_NewEnergy = enn[s];
+                r->setState((ResState)sst[s]);
+                r->state_energy = en[s];
+                r->efResidual->isActiveAndIsGoodNEW = act[s] != 0;
+                {   // centerProjectedTo as linearize leaves it (Residuals.cpp:90-97), by the reference's own projection
+                    FrameFramePrecalc* pc = &(r->host->targetPrecalc[r->target->idx]);
+                    float drescale, u, v, Ku, Kv, new_idepth; Vec3f KliP;
+                    if (r->hasMatcher && projectPoint(ph->u, ph->v, ph->idepth_zero_scaled, 0, 0, &Hcalib, pc->PRE_RTll_0, pc->PRE_tTll_0, drescale, u, v, Ku, Kv, KliP, new_idepth))
+                        r->centerProjectedTo = Vec3f(Ku, Kv, new_idepth);
+                }
+                if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].second = r->state_state;          // :128-134
+                else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].second = r->state_state;
+                any_removed = any_removed || removed[s];
             }
-            if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].second = r->state_state;          // :128-134
-            else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].second = r->state_state;
-            if (removed[s]) {                                                   // the toRemove list (:136-155)
+            if (any_removed) with_removed[c].push_back(k_);
+        }
+    });
+    LW.lap("points + residuals");
+    for (int c = 0; c < n_part; ++c)
+        for (size_t k_ : with_removed[c]) {                                         // the toRemove list (:136-155)
+            PointHessian* ph = points[k_]->data;
+            const int id = pid[k_], i = idx_of_id[id];
+            PointMirror& m = g.pts[id];
+            for (size_t k = 0; k < ph->residuals.size(); ++k) {
+                PointFrameResidual* r = ph->residuals[k];
+                const int t = r->efResidual->targetIDX;
+                if (!removed[(size_t)t * nP + i]) continue;
                 if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].first = 0;
                 else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].first = 0;
                 ef->dropResidual(r->efResidual);
@@ -437,7 +530,7 @@ float FullSystem::optimize(int mnumOptIts) {
                 if (rm.uid == g.frame_uid[t]) { rm = ResMirror(); --m.n_res; }
             }
         }
-    }
+    LW.lap("toRemove");
     activeResiduals.clear();     // (the reference leaves pointers to the residuals it has just deleted in here; nothing reads the vector before the next optimize rebuilds it)
     Vec3 lastEnergy(lastE, 0, 0);
     if (!std::isfinite((double)lastEnergy[0])) { printf("KF Tracking failed: LOST!\n"); isLost = true; }      // :472-476
@@ -454,6 +547,8 @@ float FullSystem::optimize(int mnumOptIts) {
             fh->shell->aff_g2l = fh->aff_g2l();
         }
     }
+    LW.lap("rest");
+    LW.print("write-back");
     g.us_writeback = us_since(t_2);
     return sqrtf((float)(lastEnergy[0] / (ef->resInA)));
 }

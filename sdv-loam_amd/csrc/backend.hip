@@ -638,6 +638,12 @@ static int ef_sync_state(sdvgn_ef* e) {
     return 0;
 }
 
+// device -> pinned host by stores of the kernel itself: for a few hundred kB the copy engine's start-up costs more than the transfer
+// (sdvgn_ef_optimize_finish's outputs: 256 kB at the named shape)
+__global__ void __launch_bounds__(256) k_ef_copy_out(const uint4* __restrict__ src, uint4* __restrict__ dst_pinned, int n16) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst_pinned[i] = src[i];
+}
+
 __global__ void __launch_bounds__(1024) k_ef_precalc_in(const unsigned long long* __restrict__ src_pinned, unsigned long long* __restrict__ dst, int n8) {
     for (int i = threadIdx.x; i < n8; i += 1024) dst[i] = src_pinned[i];
 }
@@ -2687,7 +2693,7 @@ int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_m
         if (e->fin_host) SDVGN_HFREE(e->fin_host);
     if (e->jstage_dev) SDVGN_DFREE(e->jstage_dev);
         e->fin_dev = nullptr; e->fin_host = nullptr; e->fin_bytes = 0;
-        const size_t cap = std::max(need, (size_t)e->slots_cap + 8 * (size_t)e->max_points);
+        const size_t cap = (std::max(need, (size_t)e->slots_cap + 8 * (size_t)e->max_points) + 15) / 16 * 16;
         HIPCHK(SDVGN_DMALLOC(&e->fin_dev, cap));
         HIPCHK(SDVGN_HMALLOC(&e->fin_host, cap));
         e->fin_bytes = cap;
@@ -2698,7 +2704,13 @@ int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_m
     k_ef_finish_points<<<(e->nP + 255) / 256, 256, 0, e->stream>>>(e->C, e->A, e->precalc_dev, e->phost_dev, relbs_dev, ngood_dev, removed_dev);
     HIPCHK(hipGetLastError());
     // the three outputs lie back to back on the device: ONE copy into pinned memory, one wait
-    HIPCHK(hipMemcpyAsync(e->fin_host, e->fin_dev, need, hipMemcpyDeviceToHost, e->stream));
+    static const bool fin_engine_copy = getenv("SDVGN_FINISH_ENGINE_COPY") != nullptr;   // (measurement: the copy as a hipMemcpyAsync)
+    if (fin_engine_copy) HIPCHK(hipMemcpyAsync(e->fin_host, e->fin_dev, need, hipMemcpyDeviceToHost, e->stream));
+    else {
+        const int n16 = (int)((need + 15) / 16);          // (both blocks are allocated in multiples of 16 bytes beyond `need`: see `cap`)
+        k_ef_copy_out<<<std::min(64, (n16 + 255) / 256), 256, 0, e->stream>>>((const uint4*)e->fin_dev, (uint4*)e->fin_host, n16);
+        HIPCHK(hipGetLastError());
+    }
     ft[2] = fclk::now();
     if ((rc = linearize_wait(e, &energy, &EL, nullptr, nullptr))) return rc;
     ft[3] = fclk::now();

@@ -218,3 +218,68 @@ def test_edit_entry_points_reject_bad_arguments(api, big):
     # EFFrame::points order: the last point of the host took the place of the removed one
     last_of_host0 = np.nonzero(S.host == 0)[0][-1]
     assert order[0] == last_of_host0
+
+
+def test_edits_that_cancel_each_other_and_reissued_ids(api, big):
+    """Residual edits are resolved ON THE DEVICE at the commit (point id -> dense index, image slot -> frame index): an edit whose point or frame
+    leaves before the commit must vanish -- also when the frame's image slot goes to a frame inserted in the same session -- and a point id is
+    re-issued only after the commit that follows its removal.  Handle A records edits that cancel, handle B never makes them: same window."""
+    from sdv_loam_amd import synthetic as syn
+    frames = [0, 1, 2, 3]
+    pts = np.nonzero(np.isin(big.host, frames))[0][::2]
+    rmask = np.ones(big.nR, bool)
+    n = 4 + 6 * len(frames)
+    Q = np.random.default_rng(9).normal(0, 1, (n, n))
+    S = syn.subwindow(big, frames, pts, rmask, HM=1e2 * (Q @ Q.T) / n, bM=np.zeros(n))
+    new_f = 5
+    th_new = np.float32(300.0)
+
+    def edited(cancelling):
+        G = api.EnergyFunctional(big.w, big.h, max_points=big.nP).load(S)
+        assert len(G.optimize(2)) >= 1
+        hosted1 = np.nonzero(S.host == 1)[0]
+        others = np.nonzero(S.host != 1)[0]
+        victims = others[:7].astype(np.int32)            # points removed in this session (ids = dense indices of the load)
+        keep = others[7:40].astype(np.int32)
+        if cancelling:
+            # edits towards frame 1 (it leaves below) and on points that leave below
+            G.dropResiduals(keep, np.full(len(keep), 1))
+            G.insertResiduals(keep, np.full(len(keep), 1), hasMatcher=np.ones(len(keep), np.uint8), matcher=np.full((len(keep), 2), 7.5), update=True)
+            tv = np.array([0 if S.host[v] != 0 else 2 for v in victims])
+            G.dropResiduals(victims, tv)
+        G.removePoints(np.concatenate([hosted1, victims]).astype(np.int32))
+        G.removeFrame(1)
+        k = G.insertFrame(big.evalPT[new_f], big.state[new_f], big.state_zero[new_f], int(big.frameID[new_f]), 1.0, th_new, dI=big.pyr0[new_f])
+        assert k == 3
+        newp = np.nonzero(big.host == new_f)[0][:25]
+        ids = G.insertPoints(np.full(len(newp), k), big.u[newp], big.v[newp], big.idepth[newp], big.idepth_zero[newp], big.color[newp], big.weights[newp],
+                             big.hasDepthPrior[newp], big.isFromSensor[newp])
+        retired = set(int(i) for i in np.concatenate([hosted1, victims]))
+        assert not (set(int(i) for i in ids) & retired)                       # not before the commit
+        tgt = np.repeat(np.arange(3), len(ids))
+        G.insertResiduals(np.tile(ids, 3), tgt, hasMatcher=np.zeros(len(tgt), np.uint8), matcher=np.zeros((len(tgt), 2)))
+        order = G.makeIDX()
+        G.setAdjointsF(); G.setPrecalcValues()
+        return G, [int(i) for i in order], retired
+
+    A, oa, retired = edited(True)
+    B, ob, _ = edited(False)
+    assert oa == ob
+    ta, tb = A.residual_table(), B.residual_table()
+    for k in ta:
+        assert np.array_equal(ta[k], tb[k]), k
+    assert np.array_equal(A.points(), B.points())
+    assert np.array_equal(A.optimize(3), B.optimize(3), equal_nan=True)
+    for a, b in zip(A.state(), B.state()):
+        assert np.array_equal(a, b, equal_nan=True)
+    # the next session may hand the retired ids out again -- and an edit on a re-issued id means the new point
+    newp = np.nonzero(big.host == new_f)[0][25:31]
+    for G in (A, B):
+        ids2 = G.insertPoints(np.full(len(newp), 3), big.u[newp], big.v[newp], big.idepth[newp], big.idepth_zero[newp], big.color[newp], big.weights[newp],
+                              big.hasDepthPrior[newp], big.isFromSensor[newp])
+        assert set(int(i) for i in ids2) <= retired
+        G.insertResiduals(ids2, np.zeros(len(ids2), np.int32), hasMatcher=np.zeros(len(ids2), np.uint8), matcher=np.zeros((len(ids2), 2)))
+        order = [int(i) for i in G.makeIDX()]
+        ex = G.residual_table()["exists"]
+        for i in ids2:
+            assert ex[0, order.index(int(i))] and not ex[1:, order.index(int(i))].any()
