@@ -772,6 +772,34 @@ def test_lockstep_grid_larger_than_the_chip(api, orc):
         _same_window_result(G, solo[b % 2])
 
 
+def test_two_lockstep_calls_at_a_time(api, orc):
+    """Two host threads, each driving a lock-step call on its own set of windows of ONE device at the same time (two launch-sequence pools per
+    device, csrc/backend_lockstep.inc `lock_pool_acquire`): every window ends where its own sdvgn_ef_optimize call leaves it, bit for bit."""
+    import threading
+    from sdv_loam_amd import synthetic as syn
+    Ws = [low_thresholds(syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=20 + k, calib=dict(fx=400., fy=410., cx=319.5, cy=119.5), state_sigma=2e-3,
+                                         idepth_sigma=0.02)) for k in range(2)]
+    solo = [api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W) for W in Ws]
+    tr_solo = [G.optimize(6, fixed_its=True) for G in solo]
+    for rep in range(3):
+        Gs = [api.EnergyFunctional(Ws[b % 2].w, Ws[b % 2].h, max_points=Ws[b % 2].nP).load(Ws[b % 2]) for b in range(6)]
+        out = {}
+
+        def run(key, hs):
+            out[key] = api.optimize_lockstep(hs, 6, fixed_its=True)
+        th = [threading.Thread(target=run, args=(0, Gs[:3])), threading.Thread(target=run, args=(1, Gs[3:]))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for key, hs in ((0, Gs[:3]), (1, Gs[3:])):
+            n, tr = out[key]
+            for j, G in enumerate(hs):
+                b = 3 * key + j
+                assert n[j] == 6 and np.array_equal(tr[j], tr_solo[b % 2]), (rep, b)
+                _same_window_result(G, solo[b % 2])
+
+
 def test_lockstep_refuses_what_it_does_not_take(api, orc, window):
     import ctypes as C
     G = api.EnergyFunctional(window.w, window.h, max_points=window.nP).load(window)
