@@ -25,9 +25,12 @@
 //      ef->lastX / resInA, statistics_lastFineTrackRMSE, the shells' poses, isLost, the return value.
 //   NOT written back: RawResidualJacobian contents (efResidual->J, r->J) and projectedTo[] -- nothing on the host reads them before the next
 //   linearize rewrites them (flagPointsForRemoval re-linearises the residuals it fixes, FullSystem.cpp:771-783; projectedTo feeds debugPlot only).
-// The two graph walks (1. and 4.) are chains of cache misses over the reference's heap objects and independent point by point: they run on
-// SDVGN_DROPIN_THREADS host threads (default 4; 1 = in the calling thread), with everything that touches shared structures -- the edit calls, the
-// toRemove surgery, the mirror's id map -- kept in the calling thread in the reference's order, so the result does not depend on the thread count.
+// The two graph walks (1. and 4.) are chains of cache misses over the reference's heap objects and independent point by point: with
+// SDVGN_DROPIN_THREADS=n they run on n host threads, everything that touches shared structures -- the edit calls, the toRemove surgery, the mirror's
+// id map -- staying in the calling thread in the reference's order, so the result does not depend on n.  Default 1: measured on a 7 426-point window,
+// 4 threads take 1.1 ms off the walks (residual diff 1.18 -> 0.81 ms, write-back walk 1.87 -> 1.12 ms) and the call is no faster, box to box -- what
+// dominates is serial and the reference's own: dropResidual + deleteOut of the toRemove list (1.4-3.2 ms), the new / gone point lists (0.4-1.2 ms).
+// SDVGN_DROPIN_TIMING=1 prints where a call's host time goes.
 // There is no CPU fallback: a failing sdvgn_* call aborts like the reference's live asserts do.
 #include "FullSystem/FullSystem.h"
 #include "FullSystem/ResidualProjections.h"
@@ -88,7 +91,7 @@ double us_since(std::chrono::steady_clock::time_point t0) { return std::chrono::
 
 int dropin_threads() {
     const char* s = getenv("SDVGN_DROPIN_THREADS");
-    const int v = s ? atoi(s) : 4;
+    const int v = s ? atoi(s) : 1;
     return v < 1 ? 1 : (v > 64 ? 64 : v);
 }
 // f(chunk, begin, end) over [0, n) in contiguous chunks, chunk c on its own thread (the last one on the caller's); returns the number of chunks

@@ -81,12 +81,12 @@ def dropin_legs(W9, want_cpu=True):
 
     out = {}
     import os
-    legs = [("dropin_optimize", dropin.DropinOptEF), ("dropin_optimize_1_host_thread", dropin.DropinOptEF), ("dropin_solveSystemF", dropin.DropinEF)]
+    legs = [("dropin_optimize", dropin.DropinOptEF), ("dropin_optimize_4_host_threads", dropin.DropinOptEF), ("dropin_solveSystemF", dropin.DropinEF)]
     if want_cpu:
         legs.append(("cpu_reference", RefEF))
     for key, cls in legs:
-        if key == "dropin_optimize_1_host_thread":
-            os.environ["SDVGN_DROPIN_THREADS"] = "1"
+        if key == "dropin_optimize_4_host_threads":
+            os.environ["SDVGN_DROPIN_THREADS"] = "4"
         else:
             os.environ.pop("SDVGN_DROPIN_THREADS", None)
         E = cls(S.w, S.h).set_levels(3).load(S)
@@ -107,13 +107,13 @@ def dropin_legs(W9, want_cpu=True):
                    residuals_inserted_by_the_keyframe=int(len(old)))
         if hasattr(E, "gpu_stats"):
             row["gpu_window"] = E.gpu_stats()
-            row["host_threads_of_the_graph_walks"] = int(os.environ.get("SDVGN_DROPIN_THREADS", "4"))
+            row["host_threads_of_the_graph_walks"] = int(os.environ.get("SDVGN_DROPIN_THREADS", "1"))
         out[key] = row
         del E
     out["note"] = ("FullSystem::optimize of the reference's own host loop on the second of two key-frames (8 key-frames in the window, ~16 000 points; between "
                    "them the reference's removeOutliers / flagPointsForRemoval / marginalizePointsF / marginalizeFrame / insertFrame / insertResidual ran on the "
                    "host): its_per_s = 6 bodies / wall time of the call.  dropin_optimize: oracle/dropin/FullSystemOptimizeGPU.cpp (resident window, one image "
-                   "upload per key-frame, graph walk + edits + write-back included; the two walks over the reference's heap objects on 4 host threads, "
-                   "dropin_optimize_1_host_thread: the same on the calling thread alone); dropin_solveSystemF: oracle/dropin/EnergyFunctionalGPU.cpp (every plane "
+                   "upload per key-frame, graph walk + edits + write-back included; dropin_optimize_4_host_threads: the two walks over the reference's heap "
+                   "objects on 4 host threads -- no faster, the serial part dominates); dropin_solveSystemF: oracle/dropin/EnergyFunctionalGPU.cpp (every plane "
                    "and the CPU-computed Jacobians re-sent per solve); cpu_reference: libref.so, 1 thread, Eigen stand-in (a lower bound of a real Eigen build)")
     return out
