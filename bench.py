@@ -1190,6 +1190,9 @@ def main():
         traffic, how = measure_traffic()
         roof["traffic"] = traffic
         roof["traffic_note"] = how
+        roof["counters_note"] = ("the PMC child runs the kernel alone, back to back: under --pmc the profiler serialises the streams, so the look-ahead of the "
+                                 "shipping loop (side-stream solve of the rejected case) cannot run beside the linearise there and stands down; timings in this "
+                                 "line (value, in_loop_trace) are of the shipping loop with the look-ahead active (look_ahead.active), counters are of the kernel")
     # the per-row extras and the CPU baseline are N = 1 material: at N > 1 the other ranks would only wait for rank 0 at the final barrier
     if rank == 0 and world == 1 and not args.quick:
         import oracle

@@ -130,7 +130,7 @@ def keyframe_step(M, api, drop_frame_big, new_frame_big, n_remove, n_new, seed):
     M.frames.append(new_frame_big)
     assert k == len(M.frames) - 1
     # ---- insertPoint: unused points of the big window hosted by surviving frames (and by the new one) ----
-    used = set(M.id2big.values())
+    used = set(big2id) | {M.id2big[i] for i in gone}                 # (a point that left at an EARLIER key-frame may come back: as a new point under a new id)
     cand = [p for p in range(W8.nP) if p not in used and W8.host[p] in M.frames]
     newp = np.sort(rng.choice(cand, n_new, replace=False))
     ids = G.insertPoints([M.frames.index(int(W8.host[p])) for p in newp], W8.u[newp], W8.v[newp], W8.idepth[newp], W8.idepth_zero[newp], W8.color[newp],
@@ -166,14 +166,21 @@ def keyframe_step(M, api, drop_frame_big, new_frame_big, n_remove, n_new, seed):
     HM, bM = G.marg_prior()
     n0 = 4 + 6 * (nF_b - 1)
     assert np.array_equal(HM[:n0, :n0], HM_ref) and np.array_equal(bM[:n0], bM_ref) and not HM[n0:].any() and not HM[:, n0:].any() and not bM[n0:].any()
+    # what marginalizePointsF on the host would have left on the new frame's block by the time the frame itself is marginalised (a frame whose block
+    # of HM is still zero cannot be eliminated: the reference inverts that block, EnergyFunctional.cpp:477-480) -- installed like a host loop does
+    Q = rng.normal(0, 1, (6, 6))
+    HM[n0:, n0:] += 50.0 * (Q @ Q.T) / 6 + 10.0 * np.eye(6)
+    bM[n0:] += rng.normal(0, 5, 6)
+    G.set_marg_prior(HM, bM)
     A = M.reload_window(snap, M.order, th_new, HM, bM, st_rows, W8.evalPT[M.frames], W8.state_zero[M.frames])
     R = api.EnergyFunctional(W8.w, W8.h, max_points=W8.nP).load(A, raw_images=not (seed % 2))
     return R
 
 
 def test_keyframe_updates_equal_full_reloads(api, big):
-    """Three key-frame steps in a row on one resident window (frames 0-4 of a 7-frame synthetic window; each step marginalises a frame,
-    removes points, drops residuals, inserts the next frame with its points and residuals, moves some matchers) -- after every commit a fresh
+    """Six key-frame steps in a row on one resident window (frames 0-4 of a 7-frame synthetic window; each step marginalises a frame,
+    removes points, drops residuals, inserts the next frame with its points and residuals, moves some matchers; from the second step on the new
+    points get ids that earlier points gave back, and frames come back into image slots others have left) -- after every commit a fresh
     handle loaded with the same graph gives the same tables, optimize trace, states, point sums, next solve and optimize tail, bit for bit."""
     import copy
     W8 = copy.copy(big)
@@ -183,7 +190,7 @@ def test_keyframe_updates_equal_full_reloads(api, big):
     M = Mirror(api, W8, frames, pts, rng.random(W8.nR) < 0.9, seed=5)
     t0 = M.G.optimize(4)
     assert (t0[:, 2] == 1).any()
-    for step, (drop, new) in enumerate([(1, 5), (0, 6), (3, 1)]):
+    for step, (drop, new) in enumerate([(1, 5), (0, 6), (3, 1), (2, 0), (5, 3), (4, 2)]):
         R = keyframe_step(M, api, drop, new, n_remove=60, n_new=150, seed=step + 1)
         removed = check_equal(M.G, R)[3]
         # linearizeAll(true)'s toRemove list took residuals out of the window (FullSystemOptimize.cpp:136-155): the mirror follows
