@@ -351,7 +351,9 @@ int sdvgn_ef_optimize_batch(sdvgn_ef* const* handles, int B, int mnumOptIts, int
  * device memory, no host round trip inside the call (csrc/backend_lockstep.inc).  Single-rank windows in the product's default mode only
  * (flags: bit0 = exactly mnumOptIts bodies); SDVGN_E_ARG otherwise (sdvgn_ef_optimize_batch then falls back to one host thread per window).
  * trace (may be NULL): [B][trace_cap][trace_stride] doubles, the rows of sdvgn_ef_optimize's trace per window.  Per window the results are
- * those of its own sdvgn_ef_optimize call, bit for bit (FullSystemOptimize.cpp:344-458). */
+ * those of its own sdvgn_ef_optimize call, bit for bit (FullSystemOptimize.cpp:344-458).  Thread-safe across disjoint sets of handles: the
+ * library keeps two launch-sequence pools (staging + stream) per device, so two host threads can each have a call in flight on one device (a third
+ * waits); measured, two sequences side by side are 10-15 % slower in aggregate than one sequence over all the windows. */
 int sdvgn_ef_optimize_lockstep(sdvgn_ef* const* handles, int B, int mnumOptIts, int flags, int* its_out, double* trace, int trace_stride,
                                int trace_cap);
 /* Arithmetic of k_ef_linearize (PointFrameResidual::linearize, Residuals.cpp:60-224): 0 = the reference's float arithmetic operation by
