@@ -118,12 +118,16 @@ struct sdvgn_ef {
     bool applied_synced = false;
     // device-resident small solve (backend_solve.inc)
     SolveWindow* win_dev = nullptr;        // per-window constants of the solve (adjoints, priors, HM/bM, null-space basis, evalPT ...)
-    SolveWindow* win_host = nullptr;       // pinned staging copy
+    SolveWindow* win_host = nullptr;       // pinned staging, TWO copies used in turn (ef_sync_window: the host never waits for the stream to refill one)
+    int win_flip = 0;
+    hipEvent_t up_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [window | state][half]: recorded behind the copy kernel that read that half
+    bool up_ev_used[2][2] = {{false, false}, {false, false}};
     bool win_dirty = true;
     SolveState* sstate_dev = nullptr;      // [2]: calib value + frame states, the current set and the trial set of the optimize loop
-    SolveState* sstate_host = nullptr;     // pinned staging
+    SolveState* sstate_host = nullptr;     // pinned staging, two copies used in turn
+    int st_flip = 0;
     CalibDev* calib_dev = nullptr;         // [2]: CalibHessian float views of the two state sets
-    CalibDev* calib_host = nullptr;        // pinned staging
+    CalibDev* calib_host = nullptr;        // pinned staging, two copies used in turn
     int st_cur = 0;                        // which of the two sets holds the current state
     double* en_em_dev = nullptr;           // [2 sets][2]: prior energy and M energy of the state in that set (step_energy_body, backend_solve.inc)
     bool state_dirty = true;               // the host mirror changed outside the loop: upload before the next device solve
@@ -575,13 +579,23 @@ static void orthogonalize_x(sdvgn_ef* e, std::vector<double>& x) {     // y = x 
     for (int i = 0; i < n; ++i) { double a = 0; for (int j = 0; j < k; ++j) a += N[(size_t)i * k + j] * tP[j] + Npi[(size_t)i * k + j] * tN[j]; x[i] -= 0.5 * a; }
 }
 
+// pinned host -> device by loads of the kernel itself, up to two blocks per launch (8-byte words)
+__global__ void __launch_bounds__(256) k_ef_copy_in(const unsigned long long* __restrict__ src0, unsigned long long* __restrict__ dst0, int n0,
+                                                    const unsigned long long* __restrict__ src1, unsigned long long* __restrict__ dst1, int n1) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n0; i += gridDim.x * 256) dst0[i] = src0[i];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n1; i += gridDim.x * 256) dst1[i] = src1[i];
+}
+
 // ---- device-resident solve: the window constants and the state set the solve kernel reads (backend_solve.inc) -------------------
 static int ef_sync_window(sdvgn_ef* e) {
     if (!e->win_dirty) return 0;
     const int nF = e->nF, n = CPARS + 6 * nF, k = (int)e->nullspaces.size();
     if (k > kMaxNs) return SDVGN_E_ARG;
-    HIPCHK(hipStreamSynchronize(e->stream));     // the staging copy may still feed an earlier upload
-    SolveWindow& W = *e->win_host;
+    // two pinned copies in turn: the one filled now fed the upload before the previous one, which has long passed (checked: its event) -- the host
+    // does not wait for the stream here (a key-frame's commit kernels may still be running on it: 50-60 us per key-frame when this was a stream sync)
+    const int half = (e->win_flip ^= 1);
+    if (e->up_ev_used[0][half]) HIPCHK(hipEventSynchronize(e->up_ev[0][half]));
+    SolveWindow& W = e->win_host[half];
     std::memset(&W, 0, sizeof(W));
     W.nF = nF; W.n = n; W.ns_k = k;
     if (e->haveAdjoints) {
@@ -615,7 +629,13 @@ static int ef_sync_window(sdvgn_ef* e) {
         std::memcpy(W.nsN, e->ns_N.data(), sizeof(double) * (size_t)n * k);
         std::memcpy(W.nsNpi, e->ns_Npi.data(), sizeof(double) * (size_t)n * k);
     }
-    HIPCHK(hipMemcpyAsync(e->win_dev, e->win_host, sizeof(SolveWindow), hipMemcpyHostToDevice, e->stream));
+    // (by a kernel reading the pinned block: for 68 kB the copy engine's start-up costs more than the transfer)
+    static_assert(sizeof(SolveWindow) % 8 == 0, "copied as 8-byte words");
+    k_ef_copy_in<<<16, 256, 0, e->stream>>>(reinterpret_cast<const unsigned long long*>(&W), reinterpret_cast<unsigned long long*>(e->win_dev), (int)(sizeof(SolveWindow) / 8),
+                                          nullptr, nullptr, 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->up_ev[0][half], e->stream));
+    e->up_ev_used[0][half] = true;
     e->win_dirty = false;
     return 0;
 }
@@ -627,13 +647,19 @@ static void ef_fill_calib(const sdvgn_ef* e, CalibDev& c) {
 // host mirror (calib value, frame states) -> the current device state set
 static int ef_sync_state(sdvgn_ef* e) {
     if (!e->state_dirty) return 0;
-    HIPCHK(hipStreamSynchronize(e->stream));
-    SolveState& S = *e->sstate_host;
+    const int half = (e->st_flip ^= 1);       // (two pinned copies in turn, like ef_sync_window)
+    if (e->up_ev_used[1][half]) HIPCHK(hipEventSynchronize(e->up_ev[1][half]));
+    SolveState& S = e->sstate_host[half];
     for (int i = 0; i < 4; ++i) S.value[i] = e->value[i];
     for (int h = 0; h < e->nF; ++h) for (int i = 0; i < 10; ++i) S.state[h][i] = e->frames[h].state[i];
-    ef_fill_calib(e, *e->calib_host);
-    HIPCHK(hipMemcpyAsync(e->sstate_dev + e->st_cur, e->sstate_host, sizeof(SolveState), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->calib_dev + e->st_cur, e->calib_host, sizeof(CalibDev), hipMemcpyHostToDevice, e->stream));
+    ef_fill_calib(e, e->calib_host[half]);
+    static_assert(sizeof(SolveState) % 8 == 0 && sizeof(CalibDev) % 8 == 0, "copied as 8-byte words");
+    k_ef_copy_in<<<1, 256, 0, e->stream>>>(reinterpret_cast<const unsigned long long*>(&S), reinterpret_cast<unsigned long long*>(e->sstate_dev + e->st_cur), (int)(sizeof(SolveState) / 8),
+                                         reinterpret_cast<const unsigned long long*>(e->calib_host + half), reinterpret_cast<unsigned long long*>(e->calib_dev + e->st_cur),
+                                         (int)(sizeof(CalibDev) / 8));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->up_ev[1][half], e->stream));
+    e->up_ev_used[1][half] = true;
     e->state_dirty = false;
     return 0;
 }
@@ -1106,9 +1132,10 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     HIPCHK(hipMemset(e->accept_dev, 0, 64));
     HIPCHK(SDVGN_HMALLOC((void**)&e->flags_host, 64));
     HIPCHK(SDVGN_HMALLOC((void**)&e->th_log, sizeof(float) * kThLog));
-    HIPCHK(SDVGN_HMALLOC((void**)&e->win_host, sizeof(SolveWindow)));
-    HIPCHK(SDVGN_HMALLOC((void**)&e->sstate_host, sizeof(SolveState)));
-    HIPCHK(SDVGN_HMALLOC((void**)&e->calib_host, sizeof(CalibDev)));
+    HIPCHK(SDVGN_HMALLOC((void**)&e->win_host, 2 * sizeof(SolveWindow)));
+    HIPCHK(SDVGN_HMALLOC((void**)&e->sstate_host, 2 * sizeof(SolveState)));
+    HIPCHK(SDVGN_HMALLOC((void**)&e->calib_host, 2 * sizeof(CalibDev)));
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) HIPCHK(hipEventCreateWithFlags(&e->up_ev[a][b], hipEventDisableTiming));
     HIPCHK(SDVGN_HMALLOC((void**)&e->sol_host, sizeof(SolveOut)));
     std::memset(e->sol_host, 0, sizeof(SolveOut));
     HIPCHK(SDVGN_HMALLOC((void**)&e->sol_spec, 2 * sizeof(SolveOut)));
@@ -1169,6 +1196,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
     if (e->win_host) SDVGN_HFREE(e->win_host);
     if (e->sstate_host) SDVGN_HFREE(e->sstate_host);
     if (e->calib_host) SDVGN_HFREE(e->calib_host);
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) if (e->up_ev[a][b]) hipEventDestroy(e->up_ev[a][b]);
     if (e->sol_host) SDVGN_HFREE(e->sol_host);
     if (e->sol_spec) SDVGN_HFREE(e->sol_spec);
     if (e->rx_spec) SDVGN_DFREE(e->rx_spec);
