@@ -290,3 +290,47 @@ def test_edits_that_cancel_each_other_and_reissued_ids(api, big):
         ex = G.residual_table()["exists"]
         for i in ids2:
             assert ex[0, order.index(int(i))] and not ex[1:, order.index(int(i))].any()
+
+
+def test_ids_stay_bounded_over_many_keyframes(api, big):
+    """40 commits in a row, each removing 40 points and inserting 40 (with residuals towards two frames): the ids handed out never exceed the
+    points alive + what one commit retires (they are re-issued after the next commit), and the tables follow: every inserted residual exists
+    at its point's current dense index, nothing else appeared."""
+    from sdv_loam_amd import synthetic as syn
+    frames = [0, 1, 2]
+    pts = np.nonzero(np.isin(big.host, frames))[0]
+    S = syn.subwindow(big, frames, pts[::2])
+    G = api.EnergyFunctional(big.w, big.h, max_points=big.nP).load(S)
+    rng = np.random.default_rng(4)
+    alive = list(range(S.nP))                                                  # a window loaded through the setters: id = dense index
+    host_of = {i: int(S.host[i]) for i in alive}
+    res = {(int(S.r_point[r]), int(S.r_target[r])) for r in range(S.nR)}       # (id, target)
+    pool = pts[1::2]
+    n0, top = S.nP, S.nP - 1
+    for step in range(40):
+        gone = [int(i) for i in rng.choice(alive, 40, replace=False)]
+        G.removePoints(np.array(gone, np.int32))
+        alive = [i for i in alive if i not in set(gone)]
+        res = {(i, t) for (i, t) in res if i not in set(gone)}
+        newp = rng.choice(pool, 40, replace=False)
+        hosts = np.array([frames.index(int(big.host[p])) for p in newp])
+        ids = G.insertPoints(hosts, big.u[newp], big.v[newp], big.idepth[newp], big.idepth_zero[newp], big.color[newp], big.weights[newp],
+                             big.hasDepthPrior[newp], big.isFromSensor[newp])
+        ids = [int(i) for i in ids]
+        assert not (set(ids) & set(gone)) and not (set(ids) & set(alive))
+        top = max(top, max(ids))
+        for i, h in zip(ids, hosts):
+            host_of[i] = int(h)
+        alive += ids
+        tg = np.array([(host_of[i] + 1 + (step & 1)) % 3 for i in ids])
+        G.insertResiduals(np.array(ids, np.int32), tg, hasMatcher=np.zeros(len(ids), np.uint8), matcher=np.zeros((len(ids), 2)))
+        res |= {(i, int(t)) for i, t in zip(ids, tg)}
+        order = [int(i) for i in G.makeIDX()]
+        assert sorted(order) == sorted(alive)
+        ex = G.residual_table()["exists"]
+        idx = {i: k for k, i in enumerate(order)}
+        want = np.zeros_like(ex)
+        for (i, t) in res:
+            want[t, idx[i]] = 1
+        assert np.array_equal(ex, want), step
+    assert top < n0 + 2 * 40                                                   # 40 live new + 40 retired and not yet re-issued, never more
