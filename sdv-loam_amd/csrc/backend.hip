@@ -2719,7 +2719,6 @@ int sdvgn_ef_optimize_finish(sdvgn_ef* e, double* lastEnergy_out, float* relbs_m
         HIPCHK(hipStreamSynchronize(e->stream));
         if (e->fin_dev) SDVGN_DFREE(e->fin_dev);
         if (e->fin_host) SDVGN_HFREE(e->fin_host);
-    if (e->jstage_dev) SDVGN_DFREE(e->jstage_dev);
         e->fin_dev = nullptr; e->fin_host = nullptr; e->fin_bytes = 0;
         const size_t cap = (std::max(need, (size_t)e->slots_cap + 8 * (size_t)e->max_points) + 15) / 16 * 16;
         HIPCHK(SDVGN_DMALLOC(&e->fin_dev, cap));
@@ -3141,8 +3140,6 @@ int sdvgn_ef_optimize_immature(sdvgn_ef* e, int n, const int* host, const float*
     if (bytes > e->imm_stage_bytes) {
         HIPCHK(hipStreamSynchronize(e->stream));
         if (e->imm_stage) SDVGN_HFREE(e->imm_stage);
-    if (e->fin_host) SDVGN_HFREE(e->fin_host);
-    if (e->jstage_dev) SDVGN_DFREE(e->jstage_dev);
         e->imm_stage = nullptr; e->imm_stage_bytes = 0;
         HIPCHK(SDVGN_HMALLOC(&e->imm_stage, bytes * 2));
         e->imm_stage_bytes = bytes * 2;

@@ -73,3 +73,39 @@ def test_immature_follows_frame_state_updates(orc):
         bad = W.host.copy()
         bad[0] = 9
         G.optimizeImmature(bad, *a[1:])
+
+
+def test_staging_buffers_of_different_entry_points_do_not_free_each_other(orc):
+    """Regression (round 5): the grow paths of sdvgn_ef_optimize_immature's and sdvgn_ef_optimize_finish's staging blocks had picked up each other's
+    `free` lines -- the first growth of one left the other entry point with a dangling pinned / device pointer (a use-after-free only a call
+    ORDER exposes: finish, then a first immature call, then finish again; residual Jacobians set, then a first finish, then set again).
+    Two handles run the same calls in orders that do / do not cross the grow paths: same results; under SDVGN_FREE_POISON / quarantine the
+    old code faults here."""
+    W, A, O = _pair(8)
+    _, B, _ = _pair(8)
+    imin, imax, eth = _args(W, 8)
+    a = (W.host, W.u, W.v, imin, imax, eth, W.color, W.weights, W.isFromSensor)
+    # B grows the immature staging FIRST (nothing else allocated yet); A grows it between two finish calls
+    rb0 = B.optimizeImmature(*a)
+    ta, tb = A.optimize(3), B.optimize(3)
+    assert np.array_equal(ta, tb)
+    fa, fb = A.optimize_finish(), B.optimize_finish()
+    ra = A.optimizeImmature(*a)
+    rb = B.optimizeImmature(*a)
+    _same(ra, rb)
+    ta, tb = A.optimize(2), B.optimize(2)
+    assert np.array_equal(ta, tb)
+    fa, fb = A.optimize_finish(), B.optimize_finish()
+    assert fa[0] == fb[0]
+    for x, y in zip(fa[1:], fb[1:]):
+        assert np.array_equal(x, y)
+    # residual Jacobians staged, then the first finish of a handle, then staged again (form A of the drop-in followed by the library's own tail)
+    _, C, _ = _pair(8)
+    _, D, _ = _pair(8)
+    J = np.random.default_rng(1).normal(0, 1, (W.nR, 24)).astype(np.float32)
+    C.set_residual_jacobians(J)
+    D.optimize_finish(); D.set_residual_jacobians(J)       # D: finish grew its block before any Jacobian staging existed
+    C.optimize_finish()
+    C.set_residual_jacobians(J)
+    xc, xd = C.solveSystemF(0, 1e-4), D.solveSystemF(0, 1e-4)
+    assert np.array_equal(xc, xd)
