@@ -79,8 +79,8 @@ def test_staging_buffers_of_different_entry_points_do_not_free_each_other(orc):
     """Regression (round 5): the grow paths of sdvgn_ef_optimize_immature's and sdvgn_ef_optimize_finish's staging blocks had picked up each other's
     `free` lines -- the first growth of one left the other entry point with a dangling pinned / device pointer (a use-after-free only a call
     ORDER exposes: finish, then a first immature call, then finish again; residual Jacobians set, then a first finish, then set again).
-    Two handles run the same calls in orders that do / do not cross the grow paths: same results; under SDVGN_FREE_POISON / quarantine the
-    old code faults here."""
+    Two handles run the same calls in orders that do / do not cross the grow paths: same results (the old code aborts here: it writes into a pinned
+    block it has freed)."""
     W, A, O = _pair(8)
     _, B, _ = _pair(8)
     imin, imax, eth = _args(W, 8)
