@@ -86,3 +86,15 @@ def test_batch_entry_points_refuse_host_only_handles(sdvgn_lib):
     assert L.sdvgn_ef_optimize_batch(C.cast(arr, C.c_void_p), 1, 6, 0, None) < 0
     for h in hs:
         L.sdvgn_ef_destroy(h)
+
+
+def test_c_host_loop_harness_builds_against_the_header_alone(sdvgn_lib, tmp_path):
+    """tools/kf_host_loop.c (the bench's key-frame cycle from a plain-C host loop) is a consumer of include/sdvgn.h and nothing else: it compiles
+    as C99 with -Wall -Werror against the header, links libsdvgn.so and exports kf_host_loop (no GPU needed to load it)."""
+    import subprocess
+    out = tmp_path / "libkfloop.so"
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "kf_host_loop.c"), "-L", os.path.join(ROOT, "sdv-loam_amd"), "-lsdvgn",
+                           "-Wl,-rpath," + os.path.join(ROOT, "sdv-loam_amd"), "-o", str(out)])
+    lib = ctypes.CDLL(str(out))
+    assert hasattr(lib, "kf_host_loop")
