@@ -55,3 +55,39 @@ def test_only_the_two_members_were_replaced(sdvgn_lib):
         return body
     assert any("sdvgn_ef_solve_system" in c for c in calls(SSF))
     assert any("sdvgn_tracker_track" in c for c in calls(TNC))
+
+
+OPT = "_ZN8sdv_loam10FullSystem8optimizeEi"
+needs_dropin_opt = pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref",
+                                                                      "libref_dropin_opt.so")), reason="oracle/_ref/libref_dropin_opt.so not built here")
+
+
+@needs_dropin_opt
+def test_form_b_replaces_exactly_full_system_optimize(sdvgn_lib):
+    """oracle/_ref/libref_dropin_opt.so (INTEGRATION.md form B) without a GPU: same reference symbols as the all-CPU library, FullSystem::optimize is
+    the definition of oracle/dropin/FullSystemOptimizeGPU.cpp -- it calls sdvgn_ef_optimize / _optimize_finish / _make_idx and the edit entry points,
+    and reaches the product through include/sdvgn.h alone."""
+    from oracle import dropin, refpin
+    path = os.path.join(os.path.dirname(dropin.dropin_path()), "libref_dropin_opt.so")
+    L = dropin.dropin_opt_lib()
+    assert L is not None
+    for name in ("sdvgn_dropin_opt_calls", "sdvgn_dropin_opt_stats", "sdvgn_dropin_opt_release", "ref_ef_keyframe_tail"):
+        assert hasattr(L, name), name
+    def syms(p):      # functions and members of namespace sdv_loam (std:: template instances over its types are the drop-in's own containers)
+        out = subprocess.check_output(["nm", "-D", "--defined-only", p], text=True)
+        return {ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith(("_ZN8sdv_loam", "_ZNK8sdv_loam"))}
+    assert syms(refpin.ref_path()) == syms(path)
+    out = subprocess.check_output(["nm", "-D", path], text=True)
+    undefined = {ln.split()[-1] for ln in out.splitlines() if " U " in ln}
+    for name in ("sdvgn_ef_optimize", "sdvgn_ef_optimize_finish", "sdvgn_ef_make_idx", "sdvgn_ef_insert_frame", "sdvgn_ef_insert_points", "sdvgn_ef_insert_residuals",
+                 "sdvgn_ef_remove_points", "sdvgn_ef_remove_frame", "sdvgn_ef_drop_residuals", "sdvgn_ef_update_residuals", "sdvgn_ef_get_residual_table"):
+        assert name in undefined, name
+    assert not [u for u in undefined if u.startswith("orc_")]          # nothing of the oracle port
+    dis = subprocess.check_output(["objdump", "-d", "--no-show-raw-insn", path], text=True)
+    body, on = [], False
+    for ln in dis.splitlines():
+        if ln.endswith(">:"):
+            on = ("<" + OPT) in ln
+        elif on and "call" in ln:
+            body.append(ln)
+    assert any("sdvgn_ef_optimize@" in c or "sdvgn_ef_optimize>" in c for c in body) and any("sdvgn_ef_optimize_finish" in c for c in body)
