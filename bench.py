@@ -1239,7 +1239,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_backend(Wh)
     if rank == 0:
-        print(json.dumps(out))
+        # ONE stdout line: the contract's keys only, < 4 kB (tools/bench_line.py; round 5's 21.8 kB line came back `parsed: null` from the driver).
+        # Everything else -- per-row extras, A/B legs, CPU sub-figures -- goes to bench_extras.json; a numbers-only digest goes to stderr.
+        from tools import bench_line
+        roof["bytes_per_launch"] = alg
+        roof["short_note"] = "%d residuals x %d B / mean duration of the in-loop launches (rocprofv3 kernel trace, child run)" % (W.nR, LINEARIZE_BYTES_PER_RES) \
+            if (lin_trace and "mean_ms" in lin_trace) else "%d residuals x %d B / back-to-back launch duration (HIP events on the library stream)" % (W.nR, LINEARIZE_BYTES_PER_RES)
+        bench_line.write_extras(out, ROOT)
+        sys.stderr.write(bench_line.digest(out) + "\n")
+        sys.stderr.flush()
+        print(bench_line.compact_line(out), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -1,0 +1,74 @@
+"""The bench's ONE stdout line stays under 4 kB and parses (the 21.8 kB line of round 5 came back `parsed: null`)."""
+import json
+import os
+
+from tools import bench_line
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CANNED = os.path.join(ROOT, "profiles", "r05_bench_driver_flags.json")      # round 5's full result dictionary, 21.8 kB on one line
+
+
+def _canned():
+    with open(CANNED) as f:
+        txt = f.read()
+    line = [ln for ln in txt.splitlines() if ln.startswith("{")][-1]
+    assert len(line) > 16000            # the size that did not parse
+    return json.loads(line)
+
+
+def test_compact_line_is_small_and_round_trips():
+    out = _canned()
+    s = bench_line.compact_line(out)
+    assert "\n" not in s and len(s) < 4096, len(s)
+    d = json.loads(s)
+    for k in bench_line.CONTRACT_KEYS:
+        assert k in d, k
+    assert d["value"] == float("%.6g" % out["value"]) and d["steps"] == out["steps"] and d["warmup"] == out["warmup"]
+    assert set(bench_line.CONFIG_KEYS) <= set(d["config"]) and "model" not in d["config"]
+    for k in bench_line.ROOFLINE_KEYS:
+        assert k in d["roofline"], k
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-5
+    assert d["roofline"]["in_loop_trace"]["mean_ms"] > 0
+    for k in bench_line.CPU_KEYS:
+        assert k in d["cpu_baseline"], k
+    assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["cores"] >= 1
+    assert set(d["value_runs"]) == {"n", "median", "min", "max"}
+    for v in (d["roofline"].get("note"), d["config"]["parallelism"]):
+        assert v is None or len(v) <= 400
+    assert len(d["roofline"]["note"]) <= bench_line.MAX_NOTE
+
+
+def test_compact_line_survives_hostile_values():
+    out = _canned()
+    out["value"] = float("nan")
+    out["roofline"]["traffic"] = float("inf")
+    out["config"]["workload"] = "w" * 5000
+    out["config"]["parallelism"] = "p" * 5000
+    out["cpu_baseline"]["sample"] = "s" * 5000
+    out["roofline"]["note"] = "n" * 5000
+    out["cpu_baseline"] = dict(out["cpu_baseline"], junk={"a": list(range(1000))})
+    s = bench_line.compact_line(out)
+    assert len(s) < 4096
+    d = json.loads(s)
+    assert d["value"] is None and d["roofline"]["traffic"] is None
+
+
+def test_compact_line_without_cpu_leg_and_multi_gpu():
+    out = _canned()
+    out.pop("cpu_baseline")
+    out["n_gpus"] = 8
+    out["config"]["rccl_ranks"] = 8
+    out["config"]["collectives_per_body"] = 1.2
+    d = json.loads(bench_line.compact_line(out))
+    assert d["cpu_baseline"] is None and d["config"]["rccl_ranks"] == 8 and d["n_gpus"] == 8
+
+
+def test_extras_file_holds_everything(tmp_path):
+    out = _canned()
+    os.makedirs(tmp_path / "gpurun_out")
+    written = bench_line.write_extras(out, str(tmp_path))
+    assert len(written) == 2
+    back = json.load(open(written[0]))
+    assert set(back) == set(out) and back["tracker"].keys() == out["tracker"].keys()
+    assert bench_line.digest(out).startswith("bench extras:")
