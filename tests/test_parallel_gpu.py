@@ -186,4 +186,4 @@ def test_bench_gpus2_from_a_bare_shell(sdvgn_lib):
     assert "ONE all-reduce per loop body" in out["config"]["parallelism"] and out["scaling"] == "strong"
     # the line is checkable: all-reduces counted by the library inside the timed region, per loop body (12 bodies in 2 calls: (12 + 2) / 12), and
     # the size of the RCCL communicator (0 here: two ranks on one GPU cannot form an RCCL clique, the collectives go through gloo)
-    assert abs(out["config"]["collectives_per_body"] - 14.0 / 12.0) < 1e-9 and out["config"]["rccl_ranks"] == 0
+    assert abs(out["config"]["collectives_per_body"] - 14.0 / 12.0) < 1e-5 and out["config"]["rccl_ranks"] == 0
