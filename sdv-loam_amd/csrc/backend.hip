@@ -628,6 +628,13 @@ static int ef_sync_window(sdvgn_ef* e) {
         ef_prepare_nullspace(e, n);
         std::memcpy(W.nsN, e->ns_N.data(), sizeof(double) * (size_t)n * k);
         std::memcpy(W.nsNpi, e->ns_Npi.data(), sizeof(double) * (size_t)n * k);
+        // orthogonalize(&x, 0) (EnergyFunctional.cpp:615-648) subtracts 0.5 (N Npi^T + Npi N^T) x: that matrix, for the one-wave tail of the device solve
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                double a = 0;
+                for (int q = 0; q < k; ++q) a += e->ns_N[(size_t)i * k + q] * e->ns_Npi[(size_t)j * k + q] + e->ns_Npi[(size_t)i * k + q] * e->ns_N[(size_t)j * k + q];
+                W.nsP[(size_t)i * n + j] = 0.5 * a;
+            }
     }
     // (by a kernel reading the pinned block: for 68 kB the copy engine's start-up costs more than the transfer)
     static_assert(sizeof(SolveWindow) % 8 == 0, "copied as 8-byte words");
@@ -1899,10 +1906,10 @@ static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_st
     const int head = 1 + n_recl, rest = (nblk + 1) / 2 + (do_step ? (io.en_em_trial ? 2 : 1) : 0);   // + step (+ energy) workgroups
     const SelArgs sel = e->pend_sel;
     if (e->own_stream) {   // a window that runs beside others: no spinning workgroups (see k_ef_tail_resub)
-        k_ef_tail_resub<<<head, kSolveLanes, 0, e->stream>>>(io, e->pend_rc, n_recl, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup,
+        k_ef_tail_resub<<<head, kTailLanes, 0, e->stream>>>(io, e->pend_rc, n_recl, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup,
                                                              e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, nblk, 0, 0,
                                                              sel, -1, nullptr);
-        k_ef_tail_resub<<<rest, kSolveLanes, 0, e->stream>>>(io, e->pend_rc, n_recl, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup,
+        k_ef_tail_resub<<<rest, kTailLanes, 0, e->stream>>>(io, e->pend_rc, n_recl, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup,
                                                              e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, nblk, head, 1,
                                                              sel, -1, nullptr);
     } else {
@@ -1912,7 +1919,7 @@ static int ef_launch_solve(sdvgn_ef* e, int iteration, double lambda, bool do_st
         ReclArgs rcl = e->pend_rc;
         unsigned long long* thw = has_sel ? e->xw_dev + 500 : nullptr;
         if (has_sel && has_rc && rcl.th == sel.th_out) { rcl.thw = thw; rcl.thseq = (unsigned)io.done_seq; }
-        k_ef_tail_resub<<<head + rest + has_sel, kSolveLanes, 0, e->stream>>>(
+        k_ef_tail_resub<<<head + rest + has_sel, kTailLanes, 0, e->stream>>>(
             io, rcl, n_recl, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt,
             e->pdeltaF_alt, nblk, 0, 0, sel, has_sel ? head + rest : -1, thw);
         e->pend_sel_valid = false;
@@ -1975,7 +1982,7 @@ static int ef_launch_spec_solve(sdvgn_ef* e, int iteration_next, double lambda_n
     io.wait_xw = main_solve_in_flight ? e->xw_dev + 498 : nullptr; io.wait_seq = (unsigned)e->seq_solve;
     const ReclArgs no_rc{};
     const SelArgs no_sel{};
-    k_ef_tail_lookahead<<<1, kSolveLanes, 0, e->side>>>(io, no_rc, 0, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial, -1.0f,
+    k_ef_tail_lookahead<<<1, kTailLanes, 0, e->side>>>(io, no_rc, 0, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial, -1.0f,
                                                    e->pid_alt, e->pidz_alt, e->pdeltaF_alt, 0, 0, 0, no_sel, -1, nullptr);
     HIPCHK(hipGetLastError());
     e->spec_last_buf = buf; e->spec_last_seq = io.done_seq;
@@ -2010,9 +2017,9 @@ static int ef_launch_spec_rest(sdvgn_ef* e, int iteration, double lambda, float 
     if (has_sel && has_rc && rcl.th == sel.th_out) { rcl.thw = thw; rcl.thseq = (unsigned)io.done_seq; }
     // the re-classification in ONE pass (one slot per lane): beside the factorisation four workgroups walking ~8 slots per lane were hidden,
     // here they would be the launch's duration (measured: 19 us for resubstitute + step with them, profiles/r04_notes.txt)
-    const int n_recl = has_rc ? (rcl.nP + rcl.np_last * (rcl.nF - 1) + kSolveLanes - 1) / kSolveLanes : 0;
+    const int n_recl = has_rc ? (rcl.nP + rcl.np_last * (rcl.nF - 1) + kTailLanes - 1) / kTailLanes : 0;
     const int lead = 1 + n_recl;                              // block indices [1, lead): the re-classification; block 0 (the factorisation) is not launched
-    k_ef_resub_after_reject<<<lead - 1 + rest + has_sel, kSolveLanes, 0, e->stream>>>(
+    k_ef_resub_after_reject<<<lead - 1 + rest + has_sel, kTailLanes, 0, e->stream>>>(
         io, rcl, n_recl, e->C, e->A, e->precalc_dev, e->phost_dev, e->pidepth_backup, e->stats_partial + (e->nP / 64 + 2), step_fac, e->pid_alt, e->pidz_alt,
         e->pdeltaF_alt, nblk, /*first_block=*/1, /*no_wait=*/0, sel, has_sel ? lead + rest : -1, thw);
     e->pend_sel_valid = false; e->pend_rc_valid = false;

@@ -1179,65 +1179,79 @@ __device__ __forceinline__ unsigned poll_tagged_u32(const unsigned long long* w,
     return (unsigned)v;
 }
 
-// (body of HALF a workgroup of 1024 lanes: group g = threadIdx.x >> 9 takes the 64-point block `blk`, wave t of the group target t; the
-// kernel -- k_ef_tail_resub, backend_solve.inc -- runs these workgroups beside the factorisation workgroup whose solution they wait for,
-// with their own loads already in flight, plus one workgroup that performs the calib / frame part of doStepFromBackup and writes the
-// precalc table of the stepped state)
+// (body of a workgroup of 512 lanes = 8 waves: it takes the two 64-point blocks blk0 and blk0 + 1; wave t forms the term of target t for both,
+// waves 0 and 1 then finish one block each.  The kernel -- k_ef_tail_resub, backend_solve.inc -- runs these workgroups beside the factorisation
+// workgroup whose solution they wait for, with their own loads already in flight, plus one workgroup that performs the calib / frame part of
+// doStepFromBackup and writes the precalc table of the stepped state)
 struct ResubSmem { float part[2][kMaxFrames][2][64]; float sx[4 + kMaxFrames * kMaxFrames * 6]; };
 __device__ __forceinline__ void resubstitute_body(const EFConst& C, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
                                                   const int* __restrict__ phost, const ResubX* Xp, float* __restrict__ backup,
                                                   double* __restrict__ stats_partial, float step_fac,
                                                   float* __restrict__ pid_w, float* __restrict__ pidz_w, float* __restrict__ pdeltaF_w,
-                                                  int n_point_blocks, int blk, ResubSmem& S, const unsigned long long* xw /*NULL: Xp is complete*/, unsigned seq) {
-    float (*part)[2][64] = S.part[threadIdx.x >> 9];
+                                                  int n_point_blocks, int blk0, ResubSmem& S, const unsigned long long* xw /*NULL: Xp is complete*/, unsigned seq) {
     float* sx = S.sx;
     const int lane = threadIdx.x & 63, t = (threadIdx.x >> 6) & 7;
-    const int p = blk * 64 + lane;
     const size_t slots = (size_t)C.nF * C.nP;
-    const bool inP = p < C.nP;
-    const bool slot_ok = inP && t < C.nF;
     // every global input of this thread up front (independent loads; all slots / points have storage behind them), the
     // dependent decisions afterwards: two memory round trips instead of five
-    const size_t s = slot_ok ? (size_t)t * C.nP + p : 0;
-    const int h = inP ? phost[p] : 0;
-    const uint8_t fl = A.rflags[s];
-    float jp[6];
+    int p[2], h[2];
+    bool inP[2];
+    uint8_t fl[2];
+    float jp[2][6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) jp[i] = A.JpJd[(size_t)i * slots + s];
-    float bsum = 0, hca[4] = {0, 0, 0, 0}, hdi = 0, pidv = 0;
-    uint8_t sens = 0;
-    if (t == 0 && inP) {
-        bsum = A.pbdSum[p];
+    for (int q = 0; q < 2; ++q) {
+        p[q] = (blk0 + q) * 64 + lane;
+        inP[q] = p[q] < C.nP;
+        const bool slot_ok = inP[q] && t < C.nF;
+        const size_t s = slot_ok ? (size_t)t * C.nP + p[q] : 0;
+        h[q] = inP[q] ? phost[p[q]] : 0;
+        fl[q] = A.rflags[s];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) hca[i] = A.pHcdA[(size_t)i * C.nP + p];
-        hdi = A.pHdi[p]; pidv = A.pid[p]; sens = A.psensor[p];
+        for (int i = 0; i < 6; ++i) jp[q][i] = A.JpJd[(size_t)i * slots + s];
     }
+    // the wave that finishes block t (t < 2) needs the point's own terms
+    const int qf = t & 1;
+    const bool fin = t < 2;
+    const int pf = (fin && inP[qf]) ? p[qf] : 0;
+    const float bsum = A.pbdSum[pf];
+    float hca[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hca[i] = A.pHcdA[(size_t)i * C.nP + pf];
+    const float hdi = A.pHdi[pf], pidv = A.pid[pf];
+    const uint8_t sens = A.psensor[pf];
     // one pass over the argument block into LDS (the per-lane host index below would otherwise turn every use into a
     // vector load from the kernel-argument segment)
     __builtin_amdgcn_sched_barrier(0);
-    const bool mine = inP && precalc[h * C.nF + h].np != 0;
+    bool mine[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) mine[q] = inP[q] && precalc[h[q] * C.nF + h[q]].np != 0;
     // this thread's loads above are in flight while the solution is being computed; its words of xc / xAd arrive tagged (same launch) or are in memory
     if ((int)threadIdx.x < 4 + C.nF * C.nF * 6)     // (what the factorisation workgroup writes: xc and nF * nF rows of xAd)
         sx[threadIdx.x] = xw ? __uint_as_float(poll_tagged_u32(xw + threadIdx.x, seq, A.err)) : reinterpret_cast<const float*>(Xp)[threadIdx.x];
     __syncthreads();
     const float* xc = sx;
     const float* xAd = sx + 4;
-    float dotv = 0.0f, good = 0.0f;
-    if (mine && t < C.nF) {
-        if ((fl & RF_EXISTS) && (fl & RF_ACTIVE)) {
-            good = 1.0f;
-            const float* xa = xAd + (size_t)(C.nF * h + t) * 6;
-            float sum = 0;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) sum += xa[i] * jp[i];
-            dotv = sum;
+    for (int q = 0; q < 2; ++q) {
+        float dotv = 0.0f, good = 0.0f;
+        if (mine[q] && t < C.nF) {
+            if ((fl[q] & RF_EXISTS) && (fl[q] & RF_ACTIVE)) {
+                good = 1.0f;
+                const float* xa = xAd + (size_t)(C.nF * h[q] + t) * 6;
+                float sum = 0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) sum += xa[i] * jp[q][i];
+                dotv = sum;
+            }
         }
+        S.part[q][t][0][lane] = dotv; S.part[q][t][1][lane] = good;
     }
-    part[t][0][lane] = dotv; part[t][1][lane] = good;
     __syncthreads();
-    if (t != 0) return;
+    if (!fin) return;
+    float (*part)[2][64] = S.part[qf];
+    const int blk = blk0 + qf;
     double s2 = 0, sa = 0;
-    if (mine) {
+    if (mine[qf]) {
         float b = bsum;
         float dot = 0;
 #pragma unroll
@@ -1249,14 +1263,14 @@ __device__ __forceinline__ void resubstitute_body(const EFConst& C, const EFArra
         }
         float step = 0.0f;
         if (ngood > 0 && !sens) step = -b * hdi;
-        A.pstep[p] = step;
+        A.pstep[pf] = step;
         const float idb = pidv * (1.0f / SDVGN_SCALE_IDEPTH);
-        backup[p] = idb;
+        backup[pf] = idb;
         if (step_fac >= 0.0f) {
             const float v = idb + step_fac * step;
-            pid_w[p] = SDVGN_SCALE_IDEPTH * v;
-            pidz_w[p] = SDVGN_SCALE_IDEPTH * v;
-            pdeltaF_w[p] = v - v;
+            pid_w[pf] = SDVGN_SCALE_IDEPTH * v;
+            pidz_w[pf] = SDVGN_SCALE_IDEPTH * v;
+            pdeltaF_w[pf] = v - v;
         }
         s2 = (double)(step * step);
         sa = (double)fabsf(idb);
@@ -1312,29 +1326,33 @@ __device__ __forceinline__ unsigned sel_key(int p, int nF, int nP, int own0, int
     return __float_as_uint(v) & 0x7FFFFFFFu;  // -0.0f counts as 0
 }
 
-// body for one workgroup of kSelLanes lanes
-template <int SRC>
+// body for one workgroup of LANES lanes (1024: the select kernels and the statistics launches; 512: as a workgroup of the factorisation's launch).
+// The result does not depend on LANES (an exact selection).  Lane t owns the 2048 / LANES adjacent histogram bins from t * (2048 / LANES).
+template <int SRC, int LANES = kSelLanes>
 __device__ __forceinline__ void select_th_body(int nF, int nP, int own0, int own1, const uint8_t* __restrict__ rflags, const float* __restrict__ wo,
                                                const double* __restrict__ cand, const float* __restrict__ th_prev, float* __restrict__ th_out,
                                                float* __restrict__ log_slot, SelectSmem& S,
                                                unsigned long long* __restrict__ thw = nullptr /* the thresholds as tagged words too: a reader in the same launch */, unsigned thseq = 0) {
+    constexpr int VPT = kSelLanes * kSelVPT / LANES;      // keys in registers: 16384 points whatever LANES is
+    constexpr int BPL = 2 * kSelLanes / LANES;            // histogram bins per lane
+    static_assert(LANES % 64 == 0 && LANES <= kSelLanes && (2 * kSelLanes) % LANES == 0, "select_th_body: lane count");
     unsigned* s_hist = S.hist; unsigned* s_wsum = S.wsum; unsigned* s_sel = S.sel;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned key[kSelVPT];
+    unsigned key[VPT];
     {   // all loads of this lane in ONE batch (clamped addresses), the candidate tests afterwards: one memory round trip, not 16
-        uint8_t fl[kSelVPT];
-        float v[kSelVPT];
-        double c[kSelVPT];
+        uint8_t fl[VPT];
+        float v[VPT];
+        double c[VPT];
 #pragma unroll
-        for (int i = 0; i < kSelVPT; ++i) {
-            const int p = min(tid + i * kSelLanes, nP - 1);
+        for (int i = 0; i < VPT; ++i) {
+            const int p = min(tid + i * LANES, nP - 1);
             if (SRC == 0) { const size_t s = (size_t)(nF - 1) * nP + p; fl[i] = rflags[s]; v[i] = wo[s]; }
             else c[i] = cand[p];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < kSelVPT; ++i) {
-            const int p = tid + i * kSelLanes;
+        for (int i = 0; i < VPT; ++i) {
+            const int p = tid + i * LANES;
             bool ok = p < nP;
             float e;
             if (SRC == 0) { ok = ok && (fl[i] & RF_EXISTS) && !(fl[i] & RF_LINEARIZED) && p >= own0 && p < own1; e = v[i]; }
@@ -1343,7 +1361,7 @@ __device__ __forceinline__ void select_th_body(int nF, int nP, int own0, int own
             key[i] = ok ? (__float_as_uint(e) & 0x7FFFFFFFu) : 0xFFFFFFFFu;
         }
     }
-    const int p_tail = kSelLanes * kSelVPT;
+    const int p_tail = LANES * VPT;
     // MSB-first radix select with LDS histograms, 11 + 11 + 9 bits: per pass every key that still matches the prefix adds 1 to its
     // digit's bin (integer LDS atomics: order-free, deterministic), a block scan finds the bin holding rank k.  (A compare-and-count
     // descent, 2 bits per step, costs 16384 keys x 3 compares x 17 steps on ONE CU's vector units: measured 26 us; this: ~5 us.)
@@ -1353,31 +1371,37 @@ __device__ __forceinline__ void select_th_body(int nF, int nP, int own0, int own
     for (int pass = 0; pass < 3; ++pass) {
         const int shift = pass == 0 ? 20 : (pass == 1 ? 9 : 0);
         const int nb = pass == 2 ? 512 : 2048;
-        s_hist[tid] = 0; s_hist[tid + kSelLanes] = 0;
+#pragma unroll
+        for (int q = 0; q < BPL; ++q) s_hist[tid + q * LANES] = 0;
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < kSelVPT; ++i)
+        for (int i = 0; i < VPT; ++i)
             if ((key[i] & pmask) == prefix) atomicAdd(&s_hist[(key[i] >> shift) & (nb - 1)], 1u);
-        for (int p0 = p_tail; p0 < nP; p0 += kSelLanes) {   // windows beyond 16384 points: re-read (uniform trip count)
+        for (int p0 = p_tail; p0 < nP; p0 += LANES) {   // windows beyond 16384 points: re-read (uniform trip count)
             const unsigned k = sel_key<SRC>(p0 + tid, nF, nP, own0, own1, rflags, wo, cand);
             if ((k & pmask) == prefix) atomicAdd(&s_hist[(k >> shift) & (nb - 1)], 1u);
         }
         __syncthreads();
-        // lane t owns bins 2t, 2t+1: exclusive block scan of the pair sums
-        const unsigned c0 = s_hist[2 * tid], c1 = s_hist[2 * tid + 1];
-        const unsigned incl = wave_scan_dpp_u32(c0 + c1);
+        // lane t owns bins BPL t .. BPL t + BPL - 1: exclusive block scan of the lanes' sums
+        unsigned cb[BPL], mysum = 0;
+#pragma unroll
+        for (int q = 0; q < BPL; ++q) { cb[q] = s_hist[BPL * tid + q]; mysum += cb[q]; }
+        const unsigned incl = wave_scan_dpp_u32(mysum);
         if (lane == 63) s_wsum[wave] = incl;
         __syncthreads();
         unsigned before = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < kSelLanes / 64; ++w) { const unsigned t = s_wsum[w]; if (w < wave) before += t; total += t; }
+        for (int w = 0; w < LANES / 64; ++w) { const unsigned t = s_wsum[w]; if (w < wave) before += t; total += t; }
         if (pass == 0) { N = (int)total; kth = (int)(0.7f * (float)N); }   // setting_frameEnergyTHN * allResVec.size(): float product, truncated
         if (N == 0) break;
-        const unsigned excl = before + incl - (c0 + c1);
-        if ((unsigned)kth >= excl && (unsigned)kth < excl + c0 + c1) {     // exactly one lane
-            const bool second = (unsigned)kth >= excl + c0;
-            s_sel[0] = 2 * tid + (second ? 1 : 0);
-            s_sel[1] = excl + (second ? c0 : 0);
+        const unsigned excl = before + incl - mysum;
+        if ((unsigned)kth >= excl && (unsigned)kth < excl + mysum) {     // exactly one lane
+            unsigned below = excl;
+            int bin = 0;
+#pragma unroll
+            for (int q = 0; q < BPL - 1; ++q) if ((unsigned)kth >= below + cb[q] && bin == q) { below += cb[q]; bin = q + 1; }
+            s_sel[0] = BPL * tid + bin;
+            s_sel[1] = below;
         }
         __syncthreads();
         prefix |= s_sel[0] << shift;
