@@ -1183,12 +1183,16 @@ __device__ __forceinline__ unsigned poll_tagged_u32(const unsigned long long* w,
 // waves 0 and 1 then finish one block each.  The kernel -- k_ef_tail_resub, backend_solve.inc -- runs these workgroups beside the factorisation
 // workgroup whose solution they wait for, with their own loads already in flight, plus one workgroup that performs the calib / frame part of
 // doStepFromBackup and writes the precalc table of the stepped state)
-struct ResubSmem { float part[2][kMaxFrames][2][64]; float sx[4 + kMaxFrames * kMaxFrames * 6]; };
+struct ResubSmem { float part[2][kMaxFrames][2][64]; float sx[4 + kMaxFrames * kMaxFrames * 6]; unsigned xs[2 * (4 + 6 * kMaxFrames)]; };
+// xsol / adHostF: the solution x of the device-side solve (doubles, SolveSys::x) and the host adjoints (SolveWindow::adHostF, [h + t nF][36]): every
+// workgroup forms xc = (float) x[0..3] and xAd[nF h + t] = x_h AH(h,t) + x_t adTarget (resubstituteF_MT's frame part, EnergyFunctional.cpp:221-240; adTargetF =
+// diag(SCALE_XI_TRANS x3, SCALE_XI_ROT x3), :36-48; float arithmetic like the reference) from the 52 doubles itself -- until round 6 the factorisation
+// workgroup did that for everybody and published 388 words; now it publishes x the moment it has it.
 __device__ __forceinline__ void resubstitute_body(const EFConst& C, const EFArrays& A, const PrecalcDev* __restrict__ precalc,
-                                                  const int* __restrict__ phost, const ResubX* Xp, float* __restrict__ backup,
+                                                  const int* __restrict__ phost, const double* __restrict__ xsol, const float* __restrict__ adHostF, float* __restrict__ backup,
                                                   double* __restrict__ stats_partial, float step_fac,
                                                   float* __restrict__ pid_w, float* __restrict__ pidz_w, float* __restrict__ pdeltaF_w,
-                                                  int n_point_blocks, int blk0, ResubSmem& S, const unsigned long long* xw /*NULL: Xp is complete*/, unsigned seq) {
+                                                  int n_point_blocks, int blk0, ResubSmem& S, const unsigned long long* xw /*NULL: xsol is complete*/, unsigned seq) {
     float* sx = S.sx;
     const int lane = threadIdx.x & 63, t = (threadIdx.x >> 6) & 7;
     const size_t slots = (size_t)C.nF * C.nP;
@@ -1219,15 +1223,38 @@ __device__ __forceinline__ void resubstitute_body(const EFConst& C, const EFArra
     for (int i = 0; i < 4; ++i) hca[i] = A.pHcdA[(size_t)i * C.nP + pf];
     const float hdi = A.pHdi[pf], pidv = A.pid[pf];
     const uint8_t sens = A.psensor[pf];
+    // lane v of the workgroup forms word v of {xc[4], xAd[nF * nF][6]}: its column of the pair's adjoint
+    const int nxw = 4 + C.nF * C.nF * 6, nsol = 4 + 6 * C.nF;
+    const int v = min((int)threadIdx.x, nxw - 1);
+    const int vk = v >= 4 ? (v - 4) / 6 : 0, vc = v >= 4 ? (v - 4) - 6 * vk : 0, vh = vk / C.nF, vt = vk - vh * C.nF;
+    float ahc[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) ahc[q] = adHostF[(size_t)(vh + vt * C.nF) * 36 + q * 6 + vc];
     // one pass over the argument block into LDS (the per-lane host index below would otherwise turn every use into a
     // vector load from the kernel-argument segment)
     __builtin_amdgcn_sched_barrier(0);
     bool mine[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) mine[q] = inP[q] && precalc[h[q] * C.nF + h[q]].np != 0;
-    // this thread's loads above are in flight while the solution is being computed; its words of xc / xAd arrive tagged (same launch) or are in memory
-    if ((int)threadIdx.x < 4 + C.nF * C.nF * 6)     // (what the factorisation workgroup writes: xc and nF * nF rows of xAd)
-        sx[threadIdx.x] = xw ? __uint_as_float(poll_tagged_u32(xw + threadIdx.x, seq, A.err)) : reinterpret_cast<const float*>(Xp)[threadIdx.x];
+    // this thread's loads above are in flight while the solution is being computed; its words of x arrive tagged (same launch: (hi, lo) pairs behind the
+    // kXwFloats words of the earlier layout) or are in memory
+    if ((int)threadIdx.x < 2 * nsol) {
+        const int i = (int)threadIdx.x >> 1;
+        S.xs[threadIdx.x] = xw ? poll_tagged_u32(xw + kXwFloats + threadIdx.x, seq, A.err)
+                               : (unsigned)((threadIdx.x & 1) ? __double2loint(xsol[i]) : __double2hiint(xsol[i]));
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nxw) {
+        auto xd = [&](int i) -> double { return __hiloint2double((int)S.xs[2 * i], (int)S.xs[2 * i + 1]); };
+        if (threadIdx.x < 4) sx[threadIdx.x] = (float)xd((int)threadIdx.x);
+        else {
+            const float sTf[6] = {0.5f, 0.5f, 0.5f, 1.0f, 1.0f, 1.0f};
+            float a = 0, b = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { a += (float)xd(4 + 6 * vh + q) * ahc[q]; b += (float)xd(4 + 6 * vt + q) * (q == vc ? sTf[vc] : 0.0f); }
+            sx[4 + (size_t)(C.nF * vh + vt) * 6 + vc] = a + b;
+        }
+    }
     __syncthreads();
     const float* xc = sx;
     const float* xAd = sx + 4;
