@@ -69,6 +69,7 @@ struct WinEdit;   // backend_window.inc
 WinEdit* win_new();
 void win_delete(WinEdit*);
 void win_forget(WinEdit*);
+bool ef_win_is_open(const WinEdit*);
 
 template <typename T>
 int dev_alloc_tagged(T** p, size_t n, const char* tag) { return gmem::dmalloc_impl((void**)p, sizeof(T) * (n ? n : 1), alignof(T), tag) == hipSuccess ? 0 : -1; }
@@ -1338,6 +1339,12 @@ int sdvgn_ef_set_points(sdvgn_ef* e, int nP, const int* host, const float* u, co
                         const float* color8, const float* weights8, const unsigned char* hasDepthPrior, const unsigned char* isFromSensor) {
     if (!e || nP < 0 || nP > e->max_points || e->nF < 1) return SDVGN_E_ARG;
     if (nP > 0 && (!host || !u || !v || !idepth || !idepth_zero || !color8 || !weights8 || !hasDepthPrior || !isFromSensor)) return SDVGN_E_ARG;
+    // a reload of the point table ends the resident window (ids, slot-addressed residual tables): without this a set_points / set_residuals
+    // sequence that skips set_frames left table_mode and the old id tables in place, and the next optimize_finish copied nF * nP bytes into
+    // a caller buffer of nR.  An open edit session must be committed first.
+    if (e->win && ef_win_is_open(e->win)) return SDVGN_E_STATE;
+    e->table_mode = false;
+    if (e->win) win_forget(e->win);
     EF_DEVICE(e);
     e->phost.assign(host, host + nP);
     e->hostP0.assign(e->nF + 1, 0);
@@ -1389,6 +1396,9 @@ int sdvgn_ef_set_residuals(sdvgn_ef* e, int nR, const int* point, const int* tar
                            const double* matcher, const unsigned char* isLinearized, const unsigned char* isActive) {
     if (!e || nR < 0 || e->nP < 1) return SDVGN_E_ARG;
     if (nR > 0 && (!point || !target || !state_state || !hasMatcher || !matcher || !isLinearized || !isActive)) return SDVGN_E_ARG;
+    if (e->win && ef_win_is_open(e->win)) return SDVGN_E_STATE;
+    e->table_mode = false;                  // (a caller-side residual list again: see sdvgn_ef_set_points)
+    if (e->win) win_forget(e->win);
     EF_DEVICE(e);
     const size_t slots = (size_t)e->nF * e->nP;
     std::vector<uint8_t> flags(slots, 0);

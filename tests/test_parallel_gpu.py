@@ -187,3 +187,59 @@ def test_bench_gpus2_from_a_bare_shell(sdvgn_lib):
     # the line is checkable: all-reduces counted by the library inside the timed region, per loop body (12 bodies in 2 calls: (12 + 2) / 12), and
     # the size of the RCCL communicator (0 here: two ranks on one GPU cannot form an RCCL clique, the collectives go through gloo)
     assert abs(out["config"]["collectives_per_body"] - 14.0 / 12.0) < 1e-5 and out["config"]["rccl_ranks"] == 0
+
+
+def _rccl_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from sdv_loam_amd import parallel
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    W = _window("perturbed")
+    S = parallel.ShardedEnergyFunctional(W, rank, world, rank)
+    c0 = S.collective_count()
+    tr = S.optimize(6, want_trace=True)
+    vs, st, idp = S.ef.state()
+    lo, hi = parallel.shard_hosts(W.nF, world)[rank]
+    mine = (W.host >= lo) & (W.host < hi)
+    ranks = int(S.ef.L.sdvgn_ef_rccl_ranks(S.ef.h_)) if S.direct_rccl else 0
+    q.put((rank, np.asarray(tr), vs, st, idp[mine], np.nonzero(mine)[0], S.collective_count() - c0, bool(S.direct_rccl), ranks))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_two_gpus_direct_rccl(sdvgn_lib):
+    """The sharded window with a REAL RCCL communicator of two ranks on two devices (until now RCCL had only ever run with one
+    rank; this box class has one GPU, so the test skips here and runs wherever >= 2 GPUs are visible -- before the driver's SCALE run meets the path
+    for the first time): the library issues ncclAllReduce itself (sdvgn_ef_rccl_ranks == 2), ONE all-reduce per loop body + one per call, and the
+    accept / reject trace and the final state are those of the single-GPU call."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (found %d)" % torch.cuda.device_count())
+    import torch.multiprocessing as mp
+    from sdv_loam_amd import backend_api
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda r: r[0])
+    W = _window("perturbed")
+    G = backend_api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
+    tr = G.optimize(6)
+    vs, st, idp = G.state()
+    for rank, trr, vsr, str_, idr, idx, ncoll, direct, ranks in res:
+        assert direct and ranks == 2
+        assert len(trr) == len(tr) and np.array_equal(trr[:, :3], tr[:, :3])
+        assert np.allclose(trr[:, 3:6], tr[:, 3:6], rtol=1e-9, atol=1e-9) and np.allclose(trr[:, 7:], tr[:, 7:], rtol=1e-6, atol=1e-12)
+        assert np.allclose(vsr, vs, rtol=1e-10) and np.allclose(str_, st, rtol=1e-7, atol=1e-12) and np.allclose(idr, idp[idx], rtol=1e-6)
+        assert ncoll == len(tr) + 1
+    assert np.array_equal(res[0][1], res[1][1])
