@@ -405,6 +405,11 @@ int sdvgn_ef_optimize(sdvgn_ef* ef, int mnumOptIts, int flags /* bit0: run exact
  * with sdvgn_ef_get_state / its own FrameHessian (evalPT = PRE_worldToCam of the newest frame) and the states with
  * sdvgn_ef_get_residual_state (lastResiduals bookkeeping, :128-134). */
 int sdvgn_ef_optimize_finish(sdvgn_ef* ef, double* lastEnergy_out, float* relbs_max, int* ngood_inc, unsigned char* removed);
+/* AccumulatedSCHessianSSE::addPoint (AccumulatedSCHessian.cpp:12-21) zeroes PointHessian::maxRelBaseline (and idepth_hessian) of a point it finds
+ * WITHOUT an active residual -- in every solveSystemF of the loop, not only the last one: a point that has none in one iteration and regains one later
+ * (applyRes of an accepted step) restarts its running maximum.  out[nP] (dense index): 1 if some solve of the LAST sdvgn_ef_optimize call found the point
+ * so; a caller that mirrors maxRelBaseline applies `if (out[p]) maxRelBaseline = 0` BEFORE folding sdvgn_ef_optimize_finish's relbs_max in.  Returns nP. */
+int sdvgn_ef_get_point_nogood(sdvgn_ef* ef, unsigned char* out);
 /* ---- key-frame cycle around optimize: marginalisation (SURVEY 8 row b2 mode 2, EnergyFunctional.cpp:434-597) -------------------------
  * void EFResidual::fixLinearizationF(EnergyFunctional*)   EnergyFunctionalStructs.cpp:45-55, for every ACTIVE residual of the points with
  * mask[p] != 0 (FullSystem::flagPointsForRemoval calls it after re-linearising + applying those residuals, FullSystem.cpp:771-783 --

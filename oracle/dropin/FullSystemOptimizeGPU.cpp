@@ -417,6 +417,8 @@ float FullSystem::optimize(int mnumOptIts) {
     std::vector<int> ngood(nP);
     std::vector<unsigned char> removed((size_t)nF * nP);
     GPU_CK(sdvgn_ef_optimize_finish(g.h, &lastE, relbs.data(), ngood.data(), removed.data()));
+    std::vector<unsigned char> nogood(nP);
+    GPU_CK(sdvgn_ef_get_point_nogood(g.h, nogood.data()));
     g.us_gpu = us_since(t_1);
 
     // ---- step 4: what FullSystem::optimize leaves behind ----
@@ -484,6 +486,7 @@ float FullSystem::optimize(int mnumOptIts) {
             for (int k = 0; k < 4; ++k) p->Hcd_accAF[k] = o[2 + k];
             p->HdiF = o[6]; p->bdSumF = o[7];
             // AccumulatedSCHessianSSE::addPoint of the last solveSystemF (AccumulatedSCHessian.cpp:12-28)
+            if (nogood[i]) ph->maxRelBaseline = 0;                                 // (some solve of the loop met the point without an active residual: :14-21)
             if (o[6] == 0.0f) { ph->idepth_hessian = 0; ph->maxRelBaseline = 0; }
             else { float H = p->Hdd_accAF + p->Hdd_accLF + p->priorF; if (H < 1e-10) H = 1e-10; ph->idepth_hessian = H; }
             // linearizeAll(true), the isNew bookkeeping (FullSystemOptimize.cpp:34-47)

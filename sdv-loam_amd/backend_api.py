@@ -39,6 +39,7 @@ PROTOTYPES = [
     ("sdvgn_ef_get_residual_J", C.c_int, [vp, C.c_int, f32p]),
     ("sdvgn_ef_get_residual_state", C.c_int, [vp, vp, vp, vp, vp, vp]),
     ("sdvgn_ef_get_points", C.c_int, [vp, f32p]),
+    ("sdvgn_ef_get_point_nogood", C.c_int, [vp, vp]),
     ("sdvgn_ef_get_top_acc", C.c_int, [vp, f64p, vp]),
     ("sdvgn_ef_get_iteration_times", C.c_int, [vp, vp, C.c_int]),
     ("sdvgn_debug_phase_report", C.c_int, [C.c_int]),
@@ -315,6 +316,13 @@ class EnergyFunctional:
         rm = np.zeros(self.nF * self.nP if table else max(self.nR, 1), np.uint8)
         self._check(self.L.sdvgn_ef_optimize_finish(self.h_, C.byref(e), rb.ctypes.data_as(vp), ng.ctypes.data_as(vp), rm.ctypes.data_as(vp)))
         return e.value, rb, ng, (rm.reshape(self.nF, self.nP) if table else rm[:self.nR])
+
+    def point_nogood(self):
+        """per point: 1 if some solveSystemF of the last optimize() found it without an active residual (AccumulatedSCHessian.cpp:14-21 zeroes
+        PointHessian::maxRelBaseline there)"""
+        out = np.zeros(max(self.nP, 1), np.uint8)
+        self._check(self.L.sdvgn_ef_get_point_nogood(self.h_, out.ctypes.data_as(vp)))
+        return out[:self.nP]
 
     def frame_energy_th(self):
         th = np.zeros(self.nF, np.float32)

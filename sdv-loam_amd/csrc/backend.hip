@@ -179,6 +179,7 @@ struct sdvgn_ef {
     float *renergy = nullptr, *renergy_new = nullptr, *renergy_wo = nullptr, *rres_toZero = nullptr, *J = nullptr, *JpJd = nullptr;
     float *pHddA = nullptr, *pbdA = nullptr, *pHcdA = nullptr, *pHddL = nullptr, *pbdL = nullptr, *pHcdL = nullptr, *pHdi = nullptr,
           *pbdSum = nullptr, *pHcd = nullptr, *pstep = nullptr;
+    uint8_t* pnogood = nullptr;    // EFArrays::pnogood
     float* images = nullptr;
     float* img_stage = nullptr;
     int *phost_dev = nullptr, *hostP0_dev = nullptr;
@@ -292,7 +293,7 @@ static void ef_fill_arrays(sdvgn_ef* e) {
     A.frameTH_r = e->th_dev; A.frameTH_w = e->th_dev;
     A.J = e->J; A.JpJd = e->JpJd;
     A.pHddA = e->pHddA; A.pbdA = e->pbdA; A.pHcdA = e->pHcdA; A.pHddL = e->pHddL; A.pbdL = e->pbdL; A.pHcdL = e->pHcdL;
-    A.pHdi = e->pHdi; A.pbdSum = e->pbdSum; A.pHcd = e->pHcd; A.pstep = e->pstep;
+    A.pHdi = e->pHdi; A.pbdSum = e->pbdSum; A.pHcd = e->pHcd; A.pstep = e->pstep; A.pnogood = e->pnogood;
     A.images = e->images;
     A.img_slots = 0;
     for (int t = 0; t < SDVGN_MAX_FRAMES; ++t) A.img_slots |= (unsigned)(e->img_slot[t] & 7) << (4 * t);
@@ -1104,7 +1105,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     bad |= dev_alloc(&e->J, 2 * (size_t)kJPlanes * slots) | dev_alloc(&e->JpJd, 6 * slots);
     bad |= dev_alloc(&e->rflags_alt, slots) | dev_alloc(&e->rstate_alt, slots) | dev_alloc(&e->renergy_alt, slots) | dev_alloc(&e->JpJd_alt, 6 * slots);
     bad |= dev_alloc(&e->pHddA, mp) | dev_alloc(&e->pbdA, mp) | dev_alloc(&e->pHcdA, 4 * mp) | dev_alloc(&e->pHddL, mp) | dev_alloc(&e->pbdL, mp) | dev_alloc(&e->pHcdL, 4 * mp);
-    bad |= dev_alloc(&e->pHdi, mp) | dev_alloc(&e->pbdSum, mp) | dev_alloc(&e->pHcd, 4 * mp) | dev_alloc(&e->pstep, mp);
+    bad |= dev_alloc(&e->pHdi, mp) | dev_alloc(&e->pbdSum, mp) | dev_alloc(&e->pHcd, 4 * mp) | dev_alloc(&e->pstep, mp) | dev_alloc(&e->pnogood, mp);
     bad |= dev_alloc(&e->images, (size_t)SDVGN_MAX_FRAMES * w * h * 3) | dev_alloc(&e->img_stage, (size_t)w * h);
     bad |= dev_alloc(&e->phost_dev, mp) | dev_alloc(&e->hostP0_dev, SDVGN_MAX_FRAMES + 1);
     bad |= dev_alloc(&e->precalc_dev, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES) | dev_alloc(&e->precalc_alt, SDVGN_MAX_FRAMES * SDVGN_MAX_FRAMES);
@@ -1188,7 +1189,7 @@ void sdvgn_ef_destroy(sdvgn_ef* e) {
     ef_release_comm(e);
     void* ptrs[] = {e->pu, e->pv, e->pidz, e->pid, e->pidepth_backup, e->ppriorF, e->pdeltaF, e->pcolor, e->pweights, e->psensor, e->rflags,
                     e->rstate, e->rstate_new, e->rmatcher, e->renergy, e->renergy_new, e->renergy_wo, e->rres_toZero, e->J, e->JpJd, e->pHddA,
-                    e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->images, e->img_stage,
+                    e->pbdA, e->pHcdA, e->pHddL, e->pbdL, e->pHcdL, e->pHdi, e->pbdSum, e->pHcd, e->pstep, e->pnogood, e->images, e->img_stage,
                     e->phost_dev, e->hostP0_dev, e->precalc_dev, e->energy_partial, e->top_partial, e->sc_partial, e->nres_partial, e->acc_dev,
                     e->stats_dev, e->stats_partial, e->imm_pc_dev, e->rstate_new2, e->renergy_new2, e->renergy_wo2,
                     e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->precalc_alt, e->dbg_stamps, e->marg_mask_dev, e->drop_mask_dev, e->th_dev, e->fin_dev,
@@ -2264,6 +2265,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     const bool reuse_after_reject = (flags & 4) != 0;      // opt-in: the solve after a rejected step reuses the stitched system (see header)
     const bool no_spec_solve = (flags & 16) != 0;          // A/B and tests: do not solve the rejected case ahead on the side stream
     e->pend_sel_valid = e->pend_rc_valid = false;           // nothing of an earlier (failed) call is carried over
+    HIPCHK(hipMemsetAsync(e->pnogood, 0, (size_t)e->nP, e->stream));      // sdvgn_ef_get_point_nogood: "during THIS call"
     e->time_lin = (flags & 8) != 0;                          // measurement: event pair around every k_ef_linearize launch
     e->lin_ev_used = 0; e->lin_ms.clear();
     struct TimeLinGuard { sdvgn_ef* e; ~TimeLinGuard() { e->time_lin = false; } } time_lin_guard{e};
@@ -3100,6 +3102,14 @@ int sdvgn_ef_get_residual_state(sdvgn_ef* e, int* state_state, int* state_new, f
         if (isActive) isActive[i] = (fl[s] & RF_ACTIVE) ? 1 : 0;
     }
     return SDVGN_OK;
+}
+
+int sdvgn_ef_get_point_nogood(sdvgn_ef* e, unsigned char* out) {
+    if (!e || !out || e->nP < 1) return SDVGN_E_STATE;
+    EF_DEVICE(e);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(out, e->pnogood, (size_t)e->nP, hipMemcpyDeviceToHost));
+    return e->nP;
 }
 
 int sdvgn_ef_get_points(sdvgn_ef* e, float* out9) {

@@ -90,6 +90,7 @@ struct EFArrays {
     float* pHddL; float* pbdL; float* pHcdL;
     float* pHdi; float* pbdSum; float* pHcd;  // SC inputs (Hcd = A + L)
     float* pstep;
+    uint8_t* pnogood;        // [nP] set when a solve finds the point without an active residual (AccumulatedSCHessian.cpp:14-21 zeroes PointHessian::maxRelBaseline there); cleared by sdvgn_ef_optimize
     // images
     const float* images;     // [image slot][w*h*3]; frame t's image lives in slot ef_img_slot(A, t)
     // frameEnergyTH per frame [nF]: the set k_ef_linearize classifies with / the set k_ef_select_th writes (one per state_New* set,
@@ -621,6 +622,7 @@ __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, 
     for (int i = 0; i < 4; ++i) { A.pHcdA[(size_t)i * C.nP + p] = sum[2 + i]; A.pHcdL[(size_t)i * C.nP + p] = sum[8 + i]; }
     // AccumulatedSCHessian.cpp:12-34
     if (sum[12] == 0.0f) {
+        if (A.pnogood) A.pnogood[p] = 1;
         A.pHdi[p] = 0; A.pbdSum[p] = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) A.pHcd[(size_t)i * C.nP + p] = 0;
