@@ -451,6 +451,53 @@ class RefEF(OracleEF):
         self.L.orc_ef_set_residuals(self.h_, n, c(point, np.int32), c(target, np.int32), st, c(hasMatcher, np.uint8), c(matcher, np.float64).reshape(-1), z, z)
         self.nR += n
 
+    # ---- the per-frame rows around the window (oracle/ref_glue_ef.cpp): immature points, traceNewCoarse, activatePointsMT ----
+    def add_immature(self, host, u, v, idepth_min, idepth_max, my_type=None, quality=None, status=None, interval=None, isFromSensor=None):
+        """immature points by the reference's own constructor (FullSystem::makeNewTraces), with a given trace state; returns the number kept"""
+        R = self.L._L
+        c = np.ascontiguousarray
+        n = len(host)
+        R.ref_ef_add_immature.argtypes = [vp, C.c_int, i32p, i32p, i32p, f32p, f32p, f32p, f32p, i32p, f32p, u8p]
+        R.ref_ef_add_immature.restype = C.c_int
+        d = lambda a, v_, t: c(np.full(n, v_, t) if a is None else a, t)      # noqa: E731
+        return int(R.ref_ef_add_immature(self.h_, n, c(host, np.int32), c(u, np.int32), c(v, np.int32), d(my_type, 1.0, np.float32), c(idepth_min, np.float32),
+                                         c(idepth_max, np.float32), d(quality, 10000.0, np.float32), d(status, 5, np.int32), d(interval, 0.0, np.float32),
+                                         d(isFromSensor, 0, np.uint8)))
+
+    def trace_new_frame(self, image, camToWorld7, exposure=1.0, a=0.0, b=0.0):
+        """FullSystem::traceNewCoarse (FullSystem.cpp:519-553) of every immature point of the window on a new frame"""
+        R = self.L._L
+        R.ref_ef_trace_new_frame.argtypes = [vp, f32p, f64p, C.c_float, C.c_double, C.c_double]
+        R.ref_ef_trace_new_frame(self.h_, np.ascontiguousarray(image, np.float32).reshape(-1), np.ascontiguousarray(camToWorld7, np.float64), exposure, a, b)
+
+    def immature(self):
+        """dict of the immature points' state in frameHessians / immaturePoints order (status -1: a slot the reference has emptied)"""
+        R = self.L._L
+        R.ref_ef_get_immature.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        R.ref_ef_get_immature.restype = C.c_int
+        n = int(R.ref_ef_get_immature(self.h_, None, None, None, None, None, None, None, None, None))
+        host, st = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        u, v, imin, imax, q, iv = (np.zeros(n, np.float32) for _ in range(6))
+        uv = np.zeros((n, 2), np.float32)
+        p = lambda a: a.ctypes.data_as(vp)      # noqa: E731
+        if n:
+            R.ref_ef_get_immature(self.h_, p(host), p(u), p(v), p(imin), p(imax), p(q), p(st), p(uv), p(iv))
+        return dict(host=host, u=u, v=v, idepth_min=imin, idepth_max=imax, quality=q, status=st, lastTraceUV=uv, interval=iv)
+
+    def activate_points(self):
+        """FullSystem::activatePointsMT (FullSystem.cpp:569-717) + makeIDX; the new points join the point list.  Returns (number activated, u, v, host, target bit masks)"""
+        R = self.L._L
+        R.ref_ef_activate_points.argtypes = [vp]
+        R.ref_ef_activate_points.restype = C.c_int
+        R.ref_ef_get_new_points.argtypes = [vp, C.c_int, f32p, f32p, i32p, vp]
+        R.ref_ef_num_points.argtypes = [vp]; R.ref_ef_num_residuals.argtypes = [vp]
+        n = int(R.ref_ef_activate_points(self.h_))
+        u, v, host, tg = np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.uint32)
+        if n:
+            R.ref_ef_get_new_points(self.h_, n, u, v, host, tg.ctypes.data_as(vp))
+        self.nP = int(R.ref_ef_num_points(self.h_)); self.nR = int(R.ref_ef_num_residuals(self.h_))
+        return n, u[:n], v[:n], host[:n], tg[:n]
+
     def point_stats(self):
         rb = np.zeros(self.nP, np.float32)
         ng = np.zeros(self.nP, np.int32)

@@ -126,6 +126,65 @@ class DropinOptEF(RefEF):
         super().__del__()
 
 
+_FRAME_LIB = None
+
+
+def dropin_frame_lib():
+    """oracle/_ref/libref_dropin_frame.so (oracle/Makefile target `dropin_frame`, form B+): as libref_dropin_opt.so, plus FullSystem::traceNewCoarse,
+    FullSystem::activatePointsMT_Reductor, CoarseTracker::makeCoarseDepthL0, CoarseTracker::structPoseEstimation and Reprojector::reprojectMap replaced by
+    oracle/dropin/FullSystemFrameGPU.cpp; None when it has not been built"""
+    global _FRAME_LIB
+    if _FRAME_LIB is not None:
+        return _FRAME_LIB
+    p = os.path.join(_HERE, "_ref", "libref_dropin_frame.so")
+    if not os.path.exists(p):
+        return None
+    from sdv_loam_amd import api
+    api.load_library()
+    L = C.CDLL(p)
+    L.sdvgn_dropin_opt_calls.restype = C.c_ulonglong
+    L.sdvgn_dropin_opt_calls.argtypes = [C.c_void_p]
+    L.sdvgn_dropin_opt_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.sdvgn_dropin_opt_release.argtypes = [C.c_void_p]
+    L.sdvgn_dropin_frame_stats.argtypes = [C.POINTER(C.c_double)]
+    L.sdvgn_dropin_frame_release.argtypes = []
+    L.ref_ef_full_system.restype = C.c_void_p
+    L.ref_ef_full_system.argtypes = [C.c_void_p]
+    for name in ("sdvgn_dropin_tracker_calls",):
+        getattr(L, name).restype = C.c_ulonglong
+        getattr(L, name).argtypes = [C.c_void_p]
+    for name in ("sdvgn_dropin_tracker_release", "sdvgn_dropin_tracker_invalidate"):
+        getattr(L, name).restype = None
+        getattr(L, name).argtypes = [C.c_void_p]
+    _FRAME_LIB = L
+    return L
+
+
+def frame_stats(L=None):
+    """counters of oracle/dropin/FullSystemFrameGPU.cpp since the last release: which of the reference's per-frame call sites reached the GPU, how often"""
+    L = L or dropin_frame_lib()
+    out = (C.c_double * 9)()
+    L.sdvgn_dropin_frame_stats(out)
+    k = ("trace_calls", "trace_points", "trace_registrations", "activate_calls", "activate_points", "template_calls", "struct_pose_calls", "reproject_calls",
+         "reproject_candidates")
+    return dict(zip(k, [int(x) for x in out]))
+
+
+class DropinFrameEF(DropinOptEF):
+    """RefEF on libref_dropin_frame.so (form B+): optimize on the resident window AND the per-frame rows -- traceNewCoarse, the activation's
+    optimizeImmaturePoint batch, the next tracking template -- on the GPU, at the reference's own call sites."""
+
+    @classmethod
+    def _raw_lib(cls):
+        L = dropin_frame_lib()
+        if L is None:
+            raise RuntimeError("oracle/_ref/libref_dropin_frame.so has not been built (needs /root/reference; `make -C oracle dropin_frame`)")
+        return L
+
+    def frame_stats(self):
+        return frame_stats(self.L._L)
+
+
 _DROPIN_TRACKER_LIB = None
 
 
@@ -185,9 +244,9 @@ class RefFullSystemTracking:
         from . import refpin
         self.np = np
         self.dropin = dropin
-        L = dropin_lib() if dropin else refpin.ref_lib()
+        L = (dropin_frame_lib() if dropin == "frame" else dropin_lib()) if dropin else refpin.ref_lib()
         if L is None:
-            raise RuntimeError("oracle/_ref/libref%s.so has not been built" % ("_dropin" if dropin else ""))
+            raise RuntimeError("oracle/_ref/libref%s.so has not been built" % (("_dropin_frame" if dropin == "frame" else "_dropin") if dropin else ""))
         self.L = L
         f32 = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
         f64 = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")

@@ -9,17 +9,10 @@
 // pc_color, built by the reference's own makeCoarseDepthL0 on the host, row a3 of SURVEY.md section 8 "keep on host"), the intrinsics
 // makeK left in the object and the new frame's pyramid dIp[] are handed over as they are; the member leaves behind exactly what the
 // reference's leaves behind: the refined pose and affine parameters, lastResiduals, lastFlowIndicators, newFrame.
-#include "FullSystem/CoarseTracker.h"
-#include "FullSystem/HessianBlocks.h"
+#include "dropin_shared.hpp"
 #include "util/globalCalib.h"
 #include "util/settings.h"
 
-extern "C" {
-#include "sdvgn.h"
-}
-
-#include <cstdio>
-#include <cstdlib>
 #include <map>
 #include <mutex>
 
@@ -30,19 +23,56 @@ struct GpuTracker {
     int w = 0, hgt = 0, levels = 0;
     const sdv_loam::FrameHessian* ref = nullptr;      // the template that is on the device
     int ref_id = -1, ref_n0 = -1;
-    const sdv_loam::FrameHessian* cur = nullptr;      // the new frame whose pyramid is on the device
+    const sdv_loam::FrameHessian* cur = nullptr;      // the new frame whose pyramid is on the device ...
+    int cur_id = -1;                                  // ... and its FrameShell::id (the address of a deleted frame may be handed out again)
     unsigned long long calls = 0;
 };
 std::mutex g_mu;
 std::map<const sdv_loam::CoarseTracker*, GpuTracker> g_handles;   // (a member `sdvgn_tracker* gpu` in a real integration)
 
-void die(const char* what, int rc) {
-    fprintf(stderr, "CoarseTrackerGPU: %s failed: %s (%d)\n", what, sdvgn_error_string(rc), rc);
-    abort();
+[[noreturn]] void ct_die(const char* what, int rc) { sdvgn_dropin::die("CoarseTrackerGPU", what, rc); }
+#define GPU_CK(call) do { const int _rc = (call); if (_rc < 0) ct_die(#call, _rc); } while (0)
+
+// the handle of a CoarseTracker, created on first use
+GpuTracker& gpu_of(sdv_loam::CoarseTracker* ct) {
+    GpuTracker* gp;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        gp = &g_handles[ct];
+    }
+    GpuTracker& g = *gp;
+    // (the geometry of the global calibration, util/globalCalib.h: what CoarseTracker::makeK copies into w[] / h[] -- which a tracker that has not been
+    // given its first template yet has not run)
+    if (g.h && (g.w != sdv_loam::wG[0] || g.hgt != sdv_loam::hG[0] || g.levels != sdv_loam::pyrLevelsUsed)) { sdvgn_tracker_destroy(g.h); g.h = nullptr; }
+    if (!g.h) {
+        g.w = sdv_loam::wG[0]; g.hgt = sdv_loam::hG[0]; g.levels = sdv_loam::pyrLevelsUsed;
+        GPU_CK(sdvgn_tracker_create(&g.h, /*device*/ 0, g.w, g.hgt, g.levels, /*max_points*/ g.w * g.hgt, /*max_batch*/ 32, nullptr));
+        g.ref = nullptr; g.cur = nullptr;
+    }
+    return g;
 }
-#define GPU_CK(call) do { const int _rc = (call); if (_rc < 0) die(#call, _rc); } while (0)
+void set_new_frame(GpuTracker& g, sdv_loam::FrameHessian* fh) {
+    if (g.cur == fh && g.cur_id == fh->shell->id) return;             // once per frame, not once per pose hypothesis
+    for (int l = 0; l < sdv_loam::pyrLevelsUsed; ++l)
+        GPU_CK(sdvgn_tracker_set_new_pyr(g.h, l, reinterpret_cast<const float*>(fh->dIp[l]), fh->ab_exposure));
+    g.cur = fh; g.cur_id = fh->shell->id;
+}
 
 }  // namespace
+
+namespace sdvgn_dropin {
+sdvgn_tracker* tracker_handle(CoarseTracker* ct) { return gpu_of(ct).h; }
+void tracker_set_new_frame(CoarseTracker* ct, FrameHessian* fh) { set_new_frame(gpu_of(ct), fh); }
+sdvgn_tracker* tracker_holding(const FrameHessian* fh) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_handles) if (kv.second.h && kv.second.cur == fh && kv.second.cur_id == fh->shell->id) return kv.second.h;
+    return nullptr;
+}
+void tracker_mark_ref_on_device(CoarseTracker* ct) {
+    GpuTracker& g = gpu_of(ct);
+    g.ref = ct->lastRef; g.ref_id = ct->refFrameID; g.ref_n0 = -2;      // (-2: "whatever pc_n[0] says": see trackNewestCoarse)
+}
+}  // namespace sdvgn_dropin
 
 extern "C" unsigned long long sdvgn_dropin_tracker_calls(const void* ct) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -74,31 +104,16 @@ bool CoarseTracker::trackNewestCoarse(FrameHessian* newFrameHessian, SE3& lastTo
     lastFlowIndicators.setConstant(1000);
     newFrame = newFrameHessian;
 
-    GpuTracker* gp;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        gp = &g_handles[this];
-    }
-    GpuTracker& g = *gp;
-    if (g.h && (g.w != w[0] || g.hgt != h[0] || g.levels != pyrLevelsUsed)) { sdvgn_tracker_destroy(g.h); g.h = nullptr; }
-    if (!g.h) {
-        g.w = w[0]; g.hgt = h[0]; g.levels = pyrLevelsUsed;
-        GPU_CK(sdvgn_tracker_create(&g.h, /*device*/ 0, w[0], h[0], pyrLevelsUsed, /*max_points*/ w[0] * h[0], /*max_batch*/ 32, nullptr));
-        g.ref = nullptr; g.cur = nullptr;
-    }
+    GpuTracker& g = gpu_of(this);
     ++g.calls;
     GPU_CK(sdvgn_tracker_set_settings(g.h, setting_huberTH, setting_coarseCutoffTH, setting_affineOptModeA, setting_affineOptModeB));
     GPU_CK(sdvgn_tracker_make_K(g.h, fx[0], fy[0], cx[0], cy[0]));     // what makeK(HCalib) derived the pyramid of intrinsics from (:77-106)
-    if (g.ref != lastRef || g.ref_id != refFrameID || g.ref_n0 != pc_n[0]) {   // once per key-frame: the template of setCoarseTrackingRef (:649-660)
+    if (g.ref != lastRef || g.ref_id != refFrameID || (g.ref_n0 != pc_n[0] && g.ref_n0 != -2)) {   // once per key-frame: the template of setCoarseTrackingRef (:649-660)
         for (int l = 0; l < pyrLevelsUsed; ++l) GPU_CK(sdvgn_tracker_set_ref(g.h, l, pc_n[l], pc_u[l], pc_v[l], pc_idepth[l], pc_color[l]));
         g.ref = lastRef; g.ref_id = refFrameID; g.ref_n0 = pc_n[0];
     }
     GPU_CK(sdvgn_tracker_set_ref_frame(g.h, lastRef->ab_exposure, lastRef_aff_g2l.a, lastRef_aff_g2l.b));
-    if (g.cur != newFrameHessian) {                                   // once per frame, not once per pose hypothesis
-        for (int l = 0; l < pyrLevelsUsed; ++l)
-            GPU_CK(sdvgn_tracker_set_new_pyr(g.h, l, reinterpret_cast<const float*>(newFrameHessian->dIp[l]), newFrameHessian->ab_exposure));
-        g.cur = newFrameHessian;
-    }
+    set_new_frame(g, newFrameHessian);
     double aff[2] = {aff_g2l_out.a, aff_g2l_out.b};
     double minRes[5], lastRes[5], flow[3];
     for (int i = 0; i < 5; ++i) minRes[i] = minResForAbort[i];
@@ -107,7 +122,7 @@ bool CoarseTracker::trackNewestCoarse(FrameHessian* newFrameHessian, SE3& lastTo
     for (int k = 0; k < 4; ++k) pose7[k] = lastToNew_out.so3().data()[k];
     for (int k = 0; k < 3; ++k) pose7[4 + k] = lastToNew_out.translation()[k];
     const int ok = sdvgn_tracker_track(g.h, pose7, aff, coarsestLvl, minRes, lastRes, flow);
-    if (ok < 0) die("sdvgn_tracker_track", ok);
+    if (ok < 0) ct_die("sdvgn_tracker_track", ok);
     for (int k = 0; k < 4; ++k) lastToNew_out.so3().data()[k] = pose7[k];
     for (int k = 0; k < 3; ++k) lastToNew_out.translation()[k] = pose7[4 + k];
     aff_g2l_out.a = aff[0]; aff_g2l_out.b = aff[1];

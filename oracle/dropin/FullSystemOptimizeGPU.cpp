@@ -32,61 +32,27 @@
 // dominates is serial and the reference's own: dropResidual + deleteOut of the toRemove list (1.4-3.2 ms), the new / gone point lists (0.4-1.2 ms).
 // SDVGN_DROPIN_TIMING=1 prints where a call's host time goes.
 // There is no CPU fallback: a failing sdvgn_* call aborts like the reference's live asserts do.
-#include "FullSystem/FullSystem.h"
+#include "dropin_shared.hpp"
 #include "FullSystem/ResidualProjections.h"
-#include "FullSystem/HessianBlocks.h"
 #include "FullSystem/Residuals.h"
-#include "OptimizationBackend/EnergyFunctional.h"
-#include "OptimizationBackend/EnergyFunctionalStructs.h"
 #include "util/globalCalib.h"
 #include "util/globalFuncs.h"
 
-extern "C" {
-#include "sdvgn.h"
-}
-
 #include <chrono>
-#include <cstdio>
-#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
 #include <thread>
-#include <unordered_map>
-#include <vector>
+
+using namespace sdvgn_dropin;
 
 namespace {
 
-using namespace sdv_loam;
-
-struct ResMirror { int uid = -1; unsigned char hasMatcher = 0; float mx = 0, my = 0; int seen = 0; };   // the device's residual point -> frame column k
-struct PointMirror {
-    const EFPoint* p = nullptr; const PointHessian* ph = nullptr;
-    float u = 0, v = 0; int host_uid = -1;      // (a deleted point's addresses may be handed out again: the identity is the pair of objects AND what they describe)
-    int seen = 0, n_res = 0;
-    ResMirror r[SDVGN_MAX_FRAMES];
-};
-struct GpuWindow {
-    sdvgn_ef* h = nullptr;
-    int w = 0, hgt = 0, max_points = 0;
-    std::vector<const FrameHessian*> frames;        // device frame order
-    std::vector<int> frame_uid, frame_col;          // FrameShell::id, mirror column of every device frame
-    int col_uid[SDVGN_MAX_FRAMES];                  // uid of the frame that owns mirror column k (-1: free)
-    std::unordered_map<const EFPoint*, int> id_of;  // EFPoint -> library point id
-    std::vector<PointMirror> pts;                   // by id
-    int epoch = 0;
-    unsigned long long calls = 0, frames_uploaded = 0, points_inserted = 0, points_removed = 0, res_inserted = 0, res_dropped = 0, res_updated = 0;
-    double us_sync = 0, us_gpu = 0, us_writeback = 0;   // of the last call
-    GpuWindow() { for (int& c : col_uid) c = -1; }
-};
 std::mutex g_mu;
 std::map<const FullSystem*, GpuWindow> g_windows;   // (a member `GpuWindow gpu` in a real integration)
 
-void die(const char* what, int rc) {
-    fprintf(stderr, "FullSystemOptimizeGPU: %s failed: %s (%d)\n", what, sdvgn_error_string(rc), rc);
-    abort();
-}
-#define GPU_CK(call) do { const int _rc = (call); if (_rc < 0) die(#call, _rc); } while (0)
+[[noreturn]] void fs_die(const char* what, int rc) { sdvgn_dropin::die("FullSystemOptimizeGPU", what, rc); }
+#define GPU_CK(call) do { const int _rc = (call); if (_rc < 0) fs_die(#call, _rc); } while (0)
 double us_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
 
 int dropin_threads() {
@@ -127,6 +93,10 @@ void pose7(const SE3& T, double* o) {     // Sophus data(): [qx qy qz qw], then 
     for (int k = 0; k < 4; ++k) o[k] = q[k];
     for (int k = 0; k < 3; ++k) o[4 + k] = T.translation()[k];
 }
+
+}  // namespace
+
+namespace sdvgn_dropin {
 
 GpuWindow& window_for(const FullSystem* fs, int nP) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -220,7 +190,7 @@ void sync_window(GpuWindow& g, EnergyFunctional* ef, const std::vector<EFPoint*>
     for (int t = 0; t < nF; ++t) {
         const FrameHessian* fh = ef->frames[t]->data;
         if (t < (int)g.frames.size()) {
-            if (g.frames[t] != fh) die("frame order of the window differs from the device's", -1);
+            if (g.frames[t] != fh) fs_die("frame order of the window differs from the device's", -1);
             continue;
         }
         double ev[7], st[10], sz[10];
@@ -229,7 +199,7 @@ void sync_window(GpuWindow& g, EnergyFunctional* ef, const std::vector<EFPoint*>
         GPU_CK(sdvgn_ef_insert_frame(g.h, ev, st, sz, ef->frames[t]->frameID, fh->ab_exposure, fh->frameEnergyTH, (const float*)fh->dI, nullptr));
         int col = 0;
         while (col < SDVGN_MAX_FRAMES && g.col_uid[col] >= 0) ++col;
-        if (col == SDVGN_MAX_FRAMES) die("more than SDVGN_MAX_FRAMES key-frames", -1);
+        if (col == SDVGN_MAX_FRAMES) fs_die("more than SDVGN_MAX_FRAMES key-frames", -1);
         g.col_uid[col] = fh->shell->id;
         g.frames.push_back(fh); g.frame_uid.push_back(fh->shell->id); g.frame_col.push_back(col);
         ++g.frames_uploaded;
@@ -337,9 +307,10 @@ void sync_window(GpuWindow& g, EnergyFunctional* ef, const std::vector<EFPoint*>
     GPU_CK(sdvgn_ef_set_precalc(g.h));
     L.lap("prior + nullspaces + adjoints + precalc");
     L.print("sync");
+    ++g.syncs;
 }
 
-}  // namespace
+}  // namespace sdvgn_dropin
 
 // test / bench hooks (C linkage)
 extern "C" unsigned long long sdvgn_dropin_opt_calls(const void* fs) {
@@ -389,7 +360,7 @@ float FullSystem::optimize(int mnumOptIts) {
     std::vector<double> trace((size_t)cap * stride, 0.0);
     const int fixed = setting_minOptIterations >= mnumOptIts ? 1 : 0;        // (`canbreak && iteration >= setting_minOptIterations`, :456; default 1 = the library's)
     const int its = sdvgn_ef_optimize(g.h, mnumOptIts, fixed, trace.data(), stride, cap);
-    if (its < 0) die("sdvgn_ef_optimize", its);
+    if (its < 0) fs_die("sdvgn_ef_optimize", its);
     if (!setting_debugout_runquiet) {     // the reference's console lines (:414-425), from the device's trace
         printf("OPTIMIZE %d pts (GPU window: %llu key-frame images uploaded so far)!\n", ef->nPoints, g.frames_uploaded);
         for (int i = 0; i < its; ++i) {
@@ -497,7 +468,7 @@ float FullSystem::optimize(int mnumOptIts) {
                 PointFrameResidual* r = ph->residuals[k];
                 const int t = r->efResidual->targetIDX;
                 const size_t s = (size_t)t * nP + i;
-                if (!ex[s] && !removed[s]) die("a residual of the host graph does not exist on the device", -1);
+                if (!ex[s] && !removed[s]) fs_die("a residual of the host graph does not exist on the device", -1);
                 r->state_NewEnergyWithOutlier = ewo[s];
                 r->state_NewState = (ResState)snew[s];
                 r->state_NewEnergy = enn[s];

@@ -651,4 +651,106 @@ void ref_ef_load_report(void* e, int* color_mismatch, double* image_grad_maxdiff
     RefEF* E = (RefEF*)e; *color_mismatch = E->color_mismatch; *image_grad_maxdiff = E->image_grad_maxdiff;
 }
 
+// ---- the per-frame rows around the window: immature points, FullSystem::traceNewCoarse, FullSystem::activatePointsMT ----------------------
+// Immature points on the window's key-frames, created by the reference's own constructor (ImmaturePoint.cpp:17-45: colour, weights, gradH, energyTH from
+// the host's image) the way FullSystem::makeNewTraces creates them (FullSystem.cpp:1273-1356; a point whose energyTH is not finite is deleted like there),
+// with the trace state given (what earlier frames would have left; idepth_max = NaN and status 5 = a point never traced).  Returns the number kept.
+int ref_ef_add_immature(void* e, int n, const int* host, const int* u, const int* v, const float* my_type, const float* idepth_min, const float* idepth_max,
+                        const float* quality, const int* status, const float* interval, const uint8_t* isFromSensor) {
+    RefEF* E = (RefEF*)e; E->on();
+    FullSystem* fs = E->fs;
+    int kept = 0;
+    for (int i = 0; i < n; ++i) {
+        FrameHessian* fh = fs->frameHessians[host[i]];
+        ImmaturePoint* ip = new ImmaturePoint(u[i], v[i], fh, my_type[i], &fs->Hcalib);
+        if (!std::isfinite(ip->energyTH)) { delete ip; continue; }
+        ip->idepth_min = idepth_min[i]; ip->idepth_max = idepth_max[i]; ip->quality = quality[i];
+        ip->lastTraceStatus = (ImmaturePointStatus)status[i]; ip->lastTracePixelInterval = interval[i];
+        ip->lastTraceUV = Vec2f(-1, -1);
+        ip->isFromSensor = isFromSensor[i] != 0;
+        ip->idepth_fromSensor = 0.5f * (idepth_min[i] + idepth_max[i]);
+        ip->type = ImmaturePoint::CORNER;
+        fh->immaturePoints.push_back(ip);
+        ++kept;
+    }
+    return kept;
+}
+// FullSystem::traceNewCoarse (FullSystem.cpp:519-553) on a NEW frame (not part of the window): its image through the reference's makeImages, its pose and
+// brightness through setEvalPT_scaled like FullSystem::addActiveFrame's callers do before tracing (:1010-1017, :1040-1047)
+void ref_ef_trace_new_frame(void* e, const float* color_lvl0, const double* camToWorld7, float exposure, double a, double b) {
+    RefEF* E = (RefEF*)e; E->on();
+    FullSystem* fs = E->fs;
+    FrameShell* sh = new FrameShell();
+    static int next_new_frame_id = 100000;          // (every new frame its own id, like FullSystem::addActiveFrame's allFrameHistory.size())
+    sh->id = sh->incoming_id = next_new_frame_id++;
+    sh->camToWorld = pose_from7(camToWorld7);
+    sh->aff_g2l = AffLight(a, b);
+    FrameHessian* fh = new FrameHessian();
+    fh->shell = sh; fh->dI = 0; fh->ab_exposure = exposure;
+    for (int l = 0; l < PYR_LEVELS; ++l) { fh->dIp[l] = 0; fh->absSquaredGrad[l] = 0; }
+    std::vector<float> c(color_lvl0, color_lvl0 + (size_t)E->g.w * E->g.h);
+    fh->makeImages(c.data(), &fs->Hcalib);
+    for (int l = 0; l < pyrLevelsUsed; ++l) {      // rows 0 / h-1 of the gradient planes, which makeImages leaves uninitialised: zero on both sides
+        const int wl = wG[l], hl = hG[l];
+        for (int x = 0; x < wl; ++x) for (int k = 1; k < 3; ++k) { fh->dIp[l][x][k] = 0; fh->dIp[l][(size_t)wl * (hl - 1) + x][k] = 0; }
+    }
+    fh->setEvalPT_scaled(sh->camToWorld.inverse(), sh->aff_g2l);
+    E->last_log = capture_stdout([&] { fs->traceNewCoarse(fh); });
+    for (int l = pyrLevelsUsed; l < PYR_LEVELS; ++l) { fh->dIp[l] = 0; fh->absSquaredGrad[l] = 0; }
+    delete fh;            // (~FrameHessian frees the pyramid levels in use)
+    delete sh;
+}
+// the immature points in frameHessians / immaturePoints order (a slot the reference has emptied reads status -1); returns their number
+int ref_ef_get_immature(void* e, int* host, float* u, float* v, float* idepth_min, float* idepth_max, float* quality, int* status, float* uv2, float* interval) {
+    RefEF* E = (RefEF*)e;
+    FullSystem* fs = E->fs;
+    int n = 0;
+    for (size_t h = 0; h < fs->frameHessians.size(); ++h)
+        for (ImmaturePoint* ip : fs->frameHessians[h]->immaturePoints) {
+            if (host) {
+                host[n] = (int)h;
+                if (!ip) { status[n] = -1; u[n] = v[n] = idepth_min[n] = idepth_max[n] = quality[n] = interval[n] = NAN; uv2[2 * n] = uv2[2 * n + 1] = NAN; }
+                else {
+                    u[n] = ip->u; v[n] = ip->v; idepth_min[n] = ip->idepth_min; idepth_max[n] = ip->idepth_max; quality[n] = ip->quality;
+                    status[n] = (int)ip->lastTraceStatus; uv2[2 * n] = ip->lastTraceUV[0]; uv2[2 * n + 1] = ip->lastTraceUV[1]; interval[n] = ip->lastTracePixelInterval;
+                }
+            }
+            ++n;
+        }
+    return n;
+}
+// FullSystem::activatePointsMT (FullSystem.cpp:569-717), the reference's own function: the distance map, the choice of the points to activate, their
+// optimisation (activatePointsMT_Reductor -> optimizeImmaturePoint), insertPoint / insertResidual of the ones that made it, deletion of the others.
+// The new PointHessians join the handle's point list (indices behind the ones set so far, in frame / pointHessians order); returns their number.
+int ref_ef_activate_points(void* e) {
+    RefEF* E = (RefEF*)e; E->on();
+    FullSystem* fs = E->fs;
+    E->last_log = capture_stdout([&] { fs->activatePointsMT(); });
+    fs->ef->makeIDX();                                                                      // FullSystem.cpp:1103
+    std::set<PointHessian*> known(E->phs.begin(), E->phs.end());
+    int added = 0;
+    for (FrameHessian* fh : fs->frameHessians)
+        for (PointHessian* ph : fh->pointHessians)
+            if (!known.count(ph)) {
+                E->phs.push_back(ph);
+                for (PointFrameResidual* r : ph->residuals) { E->prs.push_back(r); E->r_point.push_back((int)E->phs.size() - 1); }
+                ++added;
+            }
+    return added;
+}
+// u, v, host (window index) and the target frames (bit t set) of the LAST n points of the handle's point list
+void ref_ef_get_new_points(void* e, int n, float* u, float* v, int* host, unsigned* targets) {
+    RefEF* E = (RefEF*)e;
+    const size_t n0 = E->phs.size() - (size_t)n;
+    for (int i = 0; i < n; ++i) {
+        PointHessian* ph = E->phs[n0 + i];
+        u[i] = ph->u; v[i] = ph->v; host[i] = ph->host->idx;
+        unsigned m = 0;
+        for (PointFrameResidual* r : ph->residuals) m |= 1u << r->target->idx;
+        targets[i] = m;
+    }
+}
+int ref_ef_num_points(void* e) { return (int)((RefEF*)e)->phs.size(); }
+int ref_ef_num_residuals(void* e) { return (int)((RefEF*)e)->prs.size(); }
+
 }  // extern "C"
