@@ -1231,6 +1231,7 @@ def main():
             out["value_keyframe_update_inclusive"] = kf
             dl = bench_legs.dropin_legs(W9, want_cpu=not args.no_cpu)
             out["dropin"] = dl
+            out["dropin_frame"] = bench_legs.frame_legs(want_cpu=not args.no_cpu)
             for k_ in ("dropin_optimize", "dropin_optimize_4_host_threads", "dropin_solveSystemF", "cpu_reference"):
                 if isinstance(dl.get(k_), dict):
                     out[k_ + "_its_per_s"] = dl[k_]["its_per_s"]

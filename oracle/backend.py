@@ -469,6 +469,8 @@ class RefEF(OracleEF):
         R = self.L._L
         R.ref_ef_trace_new_frame.argtypes = [vp, f32p, f64p, C.c_float, C.c_double, C.c_double]
         R.ref_ef_trace_new_frame(self.h_, np.ascontiguousarray(image, np.float32).reshape(-1), np.ascontiguousarray(camToWorld7, np.float64), exposure, a, b)
+        R.ref_ef_last_seconds.restype = C.c_double
+        self.last_seconds = R.ref_ef_last_seconds()          # of the traceNewCoarse call alone
 
     def immature(self):
         """dict of the immature points' state in frameHessians / immaturePoints order (status -1: a slot the reference has emptied)"""
@@ -492,6 +494,8 @@ class RefEF(OracleEF):
         R.ref_ef_get_new_points.argtypes = [vp, C.c_int, f32p, f32p, i32p, vp]
         R.ref_ef_num_points.argtypes = [vp]; R.ref_ef_num_residuals.argtypes = [vp]
         n = int(R.ref_ef_activate_points(self.h_))
+        R.ref_ef_last_seconds.restype = C.c_double
+        self.last_seconds = R.ref_ef_last_seconds()          # of the activatePointsMT call alone
         u, v, host, tg = np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.uint32)
         if n:
             R.ref_ef_get_new_points(self.h_, n, u, v, host, tg.ctypes.data_as(vp))

@@ -695,7 +695,13 @@ void ref_ef_trace_new_frame(void* e, const float* color_lvl0, const double* camT
         for (int x = 0; x < wl; ++x) for (int k = 1; k < 3; ++k) { fh->dIp[l][x][k] = 0; fh->dIp[l][(size_t)wl * (hl - 1) + x][k] = 0; }
     }
     fh->setEvalPT_scaled(sh->camToWorld.inverse(), sh->aff_g2l);
-    E->last_log = capture_stdout([&] { fs->traceNewCoarse(fh); });
+    {   // (the call alone is timed: ref_ef_last_seconds)
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        E->last_log = capture_stdout([&] { fs->traceNewCoarse(fh); });
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        g_last_seconds = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    }
     for (int l = pyrLevelsUsed; l < PYR_LEVELS; ++l) { fh->dIp[l] = 0; fh->absSquaredGrad[l] = 0; }
     delete fh;            // (~FrameHessian frees the pyramid levels in use)
     delete sh;
@@ -725,7 +731,13 @@ int ref_ef_get_immature(void* e, int* host, float* u, float* v, float* idepth_mi
 int ref_ef_activate_points(void* e) {
     RefEF* E = (RefEF*)e; E->on();
     FullSystem* fs = E->fs;
-    E->last_log = capture_stdout([&] { fs->activatePointsMT(); });
+    {
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        E->last_log = capture_stdout([&] { fs->activatePointsMT(); });
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        g_last_seconds = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    }
     fs->ef->makeIDX();                                                                      // FullSystem.cpp:1103
     std::set<PointHessian*> known(E->phs.begin(), E->phs.end());
     int added = 0;

@@ -117,3 +117,54 @@ def dropin_legs(W9, want_cpu=True):
                    "objects on 4 host threads -- no faster, the serial part dominates); dropin_solveSystemF: oracle/dropin/EnergyFunctionalGPU.cpp (every plane "
                    "and the CPU-computed Jacobians re-sent per solve); cpu_reference: libref.so, 1 thread, Eigen stand-in (a lower bound of a real Eigen build)")
     return out
+
+
+def frame_legs(want_cpu=True):
+    """The reference's per-FRAME and per-key-frame host code around one window at the named shape (1241x376, 8 key-frames), all-CPU (libref.so) against
+    form B+ (libref_dropin_frame.so: traceNewCoarse, the activation's optimizeImmaturePoint batch, optimize and the next tracking template on the GPU, bound at
+    the reference's own call sites -- oracle/dropin/FullSystemFrameGPU.cpp).  Timed inside the glue, the reference's call alone: FullSystem::traceNewCoarse
+    on two new frames (~6 400 immature points), FullSystem::activatePointsMT, then makeKeyFrame's tail (optimize .. marginalizeFrame, setCoarseTrackingRef)."""
+    import oracle as orc
+    from oracle import dropin, refpin
+    from oracle.backend import RefEF
+    from sdv_loam_amd import synthetic as syn
+    if refpin.ref_lib() is None or dropin.dropin_frame_lib() is None:
+        return dict(error="oracle/_ref/libref.so / libref_dropin_frame.so not present on this machine")
+    WB = syn.make_window(w=1241, h=376, nF=10, pts_per_kf=2000, seed=1, calib=syn.KITTI00, state_sigma=3e-3, idepth_sigma=0.02, spacing=0.5)
+    nW = WB.nF - 2
+    frames = list(range(nW))
+    rng = np.random.default_rng(3)
+    in_win = np.isin(WB.host, frames)
+    active = np.nonzero(in_win & (rng.random(WB.nP) < 0.6))[0]
+    imm = np.nonzero(in_win & ~np.isin(np.arange(WB.nP), active))[0]
+    iu, iv = np.round(WB.u[imm]).astype(np.int32), np.round(WB.v[imm]).astype(np.int32)
+    ok = (iu > 8) & (iu < WB.w - 8) & (iv > 8) & (iv < WB.h - 8)
+    imm, iu, iv = imm[ok], iu[ok], iv[ok]
+    n0 = 4 + 6 * nW
+    S = syn.subwindow(WB, frames, active, HM=WB.HM[:n0, :n0], bM=WB.bM[:n0])
+    out = {}
+    legs = [("dropin_frame", dropin.DropinFrameEF)] + ([("cpu_reference", RefEF)] if want_cpu else [])
+    for key, cls in legs:
+        E = cls(S.w, S.h).set_levels(3).load(S)
+        E.compute_nullspaces()
+        kept = E.add_immature(WB.host[imm], iu, iv, np.zeros(len(imm), np.float32), np.full(len(imm), np.nan, np.float32))
+        tr = []
+        for f in (WB.nF - 2, WB.nF - 1, WB.nF - 2, WB.nF - 1):          # (two more passes over the same two frames: the steady state of the GPU side)
+            E.trace_new_frame(WB.images[f], orc.se3_inverse(WB.gt_worldToCam[f]))
+            tr.append(E.last_seconds)
+        n_act = E.activate_points()[0]
+        t_act = E.last_seconds
+        E.setAdjointsF(); E.setPrecalcValues()
+        E.keyframe_tail(6, [0], min_its=6)
+        row = dict(immature_points=int(kept), ms_trace_new_coarse_first=1e3 * tr[0], ms_trace_new_coarse=1e3 * float(np.median(tr[1:])), points_activated=int(n_act),
+                   ms_activate_points=1e3 * t_act, ms_keyframe_tail=1e3 * E.last_seconds, ms_optimize_in_tail=1e3 * E.last_optimize_seconds)
+        row["ms_per_frame"] = row["ms_trace_new_coarse"]
+        row["ms_per_keyframe"] = row["ms_trace_new_coarse"] + row["ms_activate_points"] + row["ms_keyframe_tail"]
+        if hasattr(E, "frame_stats"):
+            row["gpu_call_sites"] = E.frame_stats()
+        out[key] = row
+        del E
+    out["note"] = ("the reference's own FullSystem::traceNewCoarse / activatePointsMT / makeKeyFrame tail on a window of 8 key-frames at the named shape; dropin_frame = "
+                   "libref_dropin_frame.so (form B+); ms_per_frame = traceNewCoarse, ms_per_keyframe = traceNewCoarse + activatePointsMT + optimize .. marginalizeFrame "
+                   "+ setCoarseTrackingRef (tracking itself -- trackNewCoarse with reprojectMap and structPoseEstimation -- is timed in the tracker extras)")
+    return out

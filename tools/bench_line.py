@@ -141,7 +141,9 @@ def digest(out):
 
     for label, path in (("keyframe_update it/s", ("value_keyframe_update_inclusive", "value")),
                         ("dropin_optimize it/s", ("dropin_optimize_its_per_s",)),
-                        ("dropin_frame ms/frame", ("dropin_frame", "ms_per_frame_gpu")),
+                        ("dropin_frame ms/frame", ("dropin_frame", "dropin_frame", "ms_per_frame")),
+                        ("dropin_frame ms/key-frame", ("dropin_frame", "dropin_frame", "ms_per_keyframe")),
+                        ("cpu frame ms/key-frame", ("dropin_frame", "cpu_reference", "ms_per_keyframe")),
                         ("cpu_reference it/s", ("cpu_reference_its_per_s",)),
                         ("lockstep B8 speedup", ("batched_windows", "B8", "speedup_vs_sequential_calls")),
                         ("lockstep B16 frac", ("batched_windows", "roofline", "frac")),
