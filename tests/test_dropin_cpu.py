@@ -41,7 +41,7 @@ def test_only_the_two_members_were_replaced(sdvgn_lib):
     from oracle import dropin, refpin
     def syms(p):
         out = subprocess.check_output(["nm", "-D", "--defined-only", p], text=True)
-        return {ln.split()[-1] for ln in out.splitlines() if "sdv_loam" in ln}
+        return {ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith(("_ZN8sdv_loam", "_ZNK8sdv_loam"))}
     a, b = syms(refpin.ref_path()), syms(dropin.dropin_path())
     assert a == b
     dis = subprocess.check_output(["objdump", "-d", "--no-show-raw-insn", dropin.dropin_path()], text=True)
@@ -91,3 +91,47 @@ def test_form_b_replaces_exactly_full_system_optimize(sdvgn_lib):
         elif on and "call" in ln:
             body.append(ln)
     assert any("sdvgn_ef_optimize@" in c or "sdvgn_ef_optimize>" in c for c in body) and any("sdvgn_ef_optimize_finish" in c for c in body)
+
+
+FRAME_MEMBERS = {                                   # reference member -> the product entry point its form B+ definition must call
+    "_ZN8sdv_loam10FullSystem14traceNewCoarseEPNS_12FrameHessianE": "sdvgn_tracker_trace_points",
+    "_ZN8sdv_loam10FullSystem25activatePointsMT_Reductor": "sdvgn_ef_optimize_immature",
+    "_ZN8sdv_loam13CoarseTracker17makeCoarseDepthL0E": "sdvgn_tracker_make_coarse_depth",
+    "_ZN8sdv_loam13CoarseTracker20structPoseEstimationE": "sdvgn_tracker_struct_pose",
+    "_ZN8sdv_loam11Reprojector12reprojectMapE": "sdvgn_reproj_match",
+}
+needs_dropin_frame = pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref",
+                                                                        "libref_dropin_frame.so")), reason="oracle/_ref/libref_dropin_frame.so not built here")
+
+
+@needs_dropin_frame
+def test_form_b_plus_replaces_the_five_frame_level_members(sdvgn_lib):
+    """oracle/_ref/libref_dropin_frame.so (INTEGRATION.md form B+) without a GPU: the same sdv_loam symbols as the all-CPU library; each of the five
+    frame-level members (SURVEY.md section 8 f-rows) is the definition of oracle/dropin/FullSystemFrameGPU.cpp and calls its sdvgn_* entry point;
+    nothing of the oracle port is linked."""
+    from oracle import dropin, refpin
+    path = os.path.join(os.path.dirname(dropin.dropin_path()), "libref_dropin_frame.so")
+    L = dropin.dropin_frame_lib()
+    assert L is not None
+    for name in ("sdvgn_dropin_frame_stats", "sdvgn_dropin_frame_release", "sdvgn_dropin_opt_stats", "ref_ef_trace_new_frame", "ref_ef_activate_points"):
+        assert hasattr(L, name), name
+    def syms(p):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", p], text=True)
+        return {ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith(("_ZN8sdv_loam", "_ZNK8sdv_loam"))}
+    assert syms(refpin.ref_path()) == syms(path)
+    out = subprocess.check_output(["nm", "-D", path], text=True)
+    undefined = {ln.split()[-1] for ln in out.splitlines() if " U " in ln}
+    assert not [u for u in undefined if u.startswith("orc_")]
+    strong = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    dis = subprocess.check_output(["objdump", "-d", "--no-show-raw-insn", path], text=True)
+    calls, cur = {}, None
+    for ln in dis.splitlines():
+        if ln.endswith(">:"):
+            cur = ln.split("<", 1)[1][:-2]
+        elif cur is not None and "call" in ln:
+            calls.setdefault(cur, []).append(ln)
+    for member, entry in FRAME_MEMBERS.items():
+        full = [s for s in strong if s.startswith(member)]
+        assert len(full) == 1, (member, full)                     # defined once, strongly (the reference's own copy was weakened and lost)
+        assert entry in undefined, entry
+        assert any(entry in c for c in calls.get(full[0], [])), (member, entry)
