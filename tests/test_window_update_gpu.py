@@ -369,7 +369,7 @@ def test_point_table_reload_without_set_frames_ends_the_resident_window(api, big
     assert G.L.sdvgn_ef_set_residuals(G.h_, *args_r) == 0
     G.table_mode = False
     G.nP, G.nR = S.nP, S.nR
-    G.setPrecalcValues()
+    G.setAdjointsF(); G.setPrecalcValues()                 # (the commit above invalidated both, like every makeIDX)
     G.make_resident()
     tr = G.optimize(3)
     # a residual list of nR entries, guarded: the bytes behind it stay untouched
