@@ -923,6 +923,24 @@ __global__ void __launch_bounds__(kSelLanes) k_ef_stats_apply_select(const doubl
     apply_slot(nF, nP, A, precalc, phost, (size_t)(blockIdx.x - 1) * kSelLanes + threadIdx.x, nullptr, dec.verdict, dec.seq);
 }
 
+// The accept test of a trial step and the NEXT body's accumulate in ONE launch (optimize loop, one rank, applyRes fused into the linearise, the rejected
+// case solved ahead on the side stream): the last workgroup = sums + verdict (k_ef_stats_select's first workgroup), the others k_ef_acc_fused on the accepted case's
+// arguments.  The accumulate's inputs do not depend on the verdict (the linearise wrote the applied copies), its Gram tiles are scratch that only a reduce
+// behind an "accept" reads; the per-point planes are the one thing a rejected step must find untouched -- point_body's first wave looks at the tagged
+// verdict word before it stores (by then it is there: one round trip + a 900-term sum against two round trips + the per-point sums).  The statistics launch
+// (5.4 us of the 62 us chain of an accepted body) leaves the chain.
+struct StatsLaunch { const double* pe; int nE; const double* pl; int nL; const double* ps; int nS; double* out; volatile int* done_flag; int done_seq; DecideArgs dec; };
+__global__ void __launch_bounds__(256) k_ef_acc_stats(const PrecalcDev* __restrict__ precalc, EFConst Cin, EFArrays A, const int* __restrict__ phost,
+                                                      float* __restrict__ top_partial, int* __restrict__ nres_partial, int top_chunks,
+                                                      float* __restrict__ sc_partial, int sc_chunks, int n_sc, AccAlt alt, StatsLaunch st) {
+    if (blockIdx.x == gridDim.x - 1) {      // (the LAST workgroup: the accumulate's workgroups keep the ids -- and with them the XCDs, next to the linearise workgroups
+        __shared__ double s[4][256];        // whose Jacobians they read -- that k_ef_acc_fused gives them; the whole grid is resident at once)
+        sum_stats_body(st.pe, st.nE, st.pl, st.nL, st.ps, st.nS, st.out, st.done_flag, st.done_seq, s, st.dec);
+        return;
+    }
+    acc_fused_body(precalc, Cin, A, phost, top_partial, nres_partial, top_chunks, sc_partial, sc_chunks, n_sc, alt, (int)blockIdx.x);
+}
+
 // device buffer -> pinned host buffer + completion flag (waitflag.hpp): the read-back after an all-reduce without the copy engine
 __global__ void __launch_bounds__(256) k_ef_copy_publish(const double* __restrict__ src, double* __restrict__ dst, int n, unsigned* __restrict__ ctr,
                                                          volatile int* flag, int seq) {
@@ -1639,12 +1657,17 @@ static AccGeom ef_acc_geom(const sdvgn_ef* e) {
     g.ntop = g.pairs * kTopE; g.nsc = nF * kScE;
     return g;
 }
-static int ef_accumulate(sdvgn_ef* e, bool with_reduce, const AccAlt* alt = nullptr) {
+// st: the statistics + accept test of the trial step as workgroup 0 of the accumulate's launch (k_ef_acc_stats; alt->verdict_word set by the caller)
+static int ef_accumulate(sdvgn_ef* e, bool with_reduce, const AccAlt* alt = nullptr, const StatsLaunch* st = nullptr) {
     const AccGeom g = ef_acc_geom(e);
     const int nF = e->nF, n_top = g.chunks * g.pairs, n_pt = (e->nP + 63) / 64;
+    if (st && !(alt && alt->verdict_word && alt->skip_on_reject && g.sc_ppb == 64)) return SDVGN_E_STATE;
     if (g.sc_ppb == 64) {
         const int n_sc = nF * g.sc_chunks;
-        const AccAlt none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+        const AccAlt none{};
+        if (st) k_ef_acc_stats<<<1 + n_sc + n_top, 256, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, e->sc_partial,
+                                                                        g.sc_chunks, n_sc, *alt, *st);
+        else
         k_ef_acc_fused<<<n_sc + n_top, 256, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, e->sc_partial, g.sc_chunks, n_sc,
                                                             alt ? *alt : none);
     } else {
@@ -2144,8 +2167,10 @@ static double host_prior_energy(const sdvgn_ef* e) {   // calcLEnergyF_MT: frame
 // with_apply: applyRes of this linearisation in the same launch, unconditionally (the call's initial linearizeAll + applyRes: statistics
 // workgroup + apply workgroups side by side, nothing to wait for) -- single rank, shared stream only
 // fused: applyRes of this linearisation was computed by the linearise itself (EFArrays::rflags_w): sums, accept test (+ the select in the last body) only
+// merged_out (fused, not the final body): nothing is launched -- the arguments of the statistics workgroup go to *merged_out and the caller makes it workgroup 0 of
+// the next body's accumulate (k_ef_acc_stats); the bookkeeping (sequence number of the host's flag, the pending select) is this function's either way
 static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideArgs* dec = nullptr, bool final_body = false, bool with_apply = false,
-                                  bool fused = false) {   // second half: the sums (+ threshold select)
+                                  bool fused = false, StatsLaunch* merged_out = nullptr) {   // second half: the sums (+ threshold select)
     const int n_partials = e->lin_partials, nL = e->lin_nL;
     const int nS = (e->nP + 63) / 64;
     const double* ps = e->stats_partial + (e->nP / 64 + 2);
@@ -2167,6 +2192,9 @@ static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideAr
         const DecideArgs none{0, 0, 0, nullptr, 0, nullptr, 0, nullptr};
         if (fused) {
             const bool sel_now = final_body || !defer_select;
+            if (merged_out && (sel_now || !dec)) return SDVGN_E_STATE;
+            if (merged_out) *merged_out = StatsLaunch{e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host, e->flags_host + 2, ++e->seq_stats, *dec};
+            else
             k_ef_stats_select<<<sel_now ? 2 : 1, kSelLanes, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host,
                                                                            e->flags_host + 2, ++e->seq_stats, a, dec ? *dec : none);
             if (sel_now) defer_select = false;
@@ -2300,7 +2328,11 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     // statistics workgroup anyway, the linearise grows by the 30 bytes per residual applyRes writes (in-loop 16.1 -> 17.0 us, statistics launch
     // 5.7 -> 5.4 us, headline 15.0 k it/s either way; profiles/r04_notes.txt) -- so the single-window loop keeps applyRes as workgroups of the
     // statistics launch unless SDVGN_FUSED_APPLY is set (tests run both: bit-identical)
-    const bool fused = defer && !e->own_stream && !ef_sharded(e) && e->rflags_alt && !e->deltaF_nonzero && getenv("SDVGN_FUSED_APPLY") != nullptr;
+    // Round 6: fused is the default -- with it the accumulate of the next body does not read anything the accept test decides, and the test itself becomes a workgroup
+    // of that accumulate's launch (k_ef_acc_stats; SDVGN_DEBUG_FLAGS bit 9 keeps the statistics a launch of their own).  SDVGN_FUSED_APPLY=0: the old form.
+    const char* fused_env = getenv("SDVGN_FUSED_APPLY");
+    const bool fused = defer && !e->own_stream && !ef_sharded(e) && e->rflags_alt && !e->deltaF_nonzero && !(fused_env && fused_env[0] == '0');
+    const bool merge_stats = fused && !(e->C.debug_flags & 512);
     struct ApplyTargetGuard { sdvgn_ef* e; ~ApplyTargetGuard() { ef_set_apply_target(e, false); } } apply_target_guard{e};
     if (onecoll) {
         // the call's one extra collective: initial linearizeAll + applyRes + accumulate, their sums and accumulators in one message
@@ -2396,6 +2428,8 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         // device-side accept test: the statistics launch waits for the host's parts of the comparison (after the mirror below), the
         // linearise does not
         const bool dev_decide = defer && !zero_differs;
+        bool stats_deferred = false;
+        DecideArgs dec_deferred{};
         if (!dev_decide && (rc = take_initial_energies())) return rc;          // (that path launches its statistics right behind the linearise)
         const bool spec = onecoll && !zero_differs;
         const bool fused_body = fused && dev_decide;       // the trial linearise leaves its applyRes in the second copies
@@ -2417,7 +2451,11 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             dec.En = dec.EM = 0; dec.en_em = e->en_em_dev + 2 * st_trial;
             dec.rhs = lastEnergy + lastEnergyL + lastEnergyM; dec.accept_dev = e->accept_dev; dec.on = 1;
             dec.verdict = (unsigned*)(e->accept_dev + 4); dec.seq = (unsigned)(++e->seq_verdict) & 0x7fffffffu;
-            if ((rc = linearize_launch_stats(e, defer, &dec, /*final_body=*/iteration + 1 == mnumOptIts, false, fused_body))) return rc;
+            // (merge_stats: the launch waits until the host knows whether it queues the next body's accumulate -- `may_break` below needs the solve's sums --
+            // and then rides in that launch; the linearise it follows runs for 16 us from here)
+            stats_deferred = merge_stats && fused_body && spec_pending && !reuse_after_reject && iteration + 1 < mnumOptIts && ef_acc_geom(e).sc_ppb == 64;
+            dec_deferred = dec;
+            if (!stats_deferred && (rc = linearize_launch_stats(e, defer, &dec, /*final_body=*/iteration + 1 == mnumOptIts, false, fused_body))) return rc;
         }
         g_pt.stop(PT_ACCUM);
         // x is in pinned memory as soon as the solve kernel is through: mirror doStepFromBackup on the host (FrameHessian::setState,
@@ -2449,18 +2487,29 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
             // (not when this body may be the call's last one -- the step is small enough for `canbreak`, whose second half the host only
             // learns with the sums: the per-point planes must hold what the LAST executed solveSystemF left, like the reference's EFPoints)
             const bool may_break = !fixed_its && iteration >= 1 && sqrtf(sumR / nF) < 0.00005 * thOpt;
+            if (stats_deferred && may_break) {       // no accumulate to ride in: the statistics as a launch of their own after all
+                if ((rc = linearize_launch_stats(e, defer, &dec_deferred, /*final_body=*/false, false, fused_body))) return rc;
+                stats_deferred = false;
+            }
             if (!reuse_after_reject && !may_break && iteration + 1 < mnumOptIts && ef_acc_geom(e).sc_ppb == 64) {
                 // (when the rejected case has been solved ahead, a rejection leaves this accumulate without a reader: it returns at once)
                 // (fused applyRes: the accepted case reads the copies the trial linearise wrote, the rejected one the kept copies)
                 if (fused_body) ef_flip_applied(e);
                 const AccAlt alt{e->accept_dev, e->pid_alt, e->pidz_alt, e->pdeltaF_alt, e->calib_dev + e->st_cur, e->precalc_alt, spec_pending ? 1 : 0,
                                  fused_body ? e->rflags_alt : nullptr, fused_body ? e->rstate_alt : nullptr, fused_body ? e->renergy_alt : nullptr,
-                                 fused_body ? e->JpJd_alt : nullptr};
+                                 fused_body ? e->JpJd_alt : nullptr, stats_deferred ? dec_deferred.verdict : nullptr, dec_deferred.seq};
+                if (stats_deferred) {
+                    StatsLaunch st;
+                    if ((rc = linearize_launch_stats(e, defer, &dec_deferred, /*final_body=*/false, false, fused_body, &st))) return rc;
+                    rc = ef_accumulate(e, /*with_reduce=*/true, &alt, &st);
+                    stats_deferred = false;
+                } else
                 rc = ef_accumulate(e, /*with_reduce=*/true, &alt);
                 if (fused_body) ef_flip_applied(e);        // (back: the verdict is not known yet)
                 if (rc) return rc;
                 pre_accumulated = true;
             }
+            if (stats_deferred && (rc = linearize_launch_stats(e, defer, &dec_deferred, /*final_body=*/false, false, fused_body))) return rc;   // (cannot happen: same conditions)
         }
         g_pt.stop(PT_STEP);
         double newEnergy, newEnergyL, sID, sNID;

@@ -503,6 +503,17 @@ __global__ void __launch_bounds__(256) k_ef_apply_revert(int nF, int nP, EFArray
 // Schur accumulation: HdiF, bdSumF, Hcd.  Workgroup = 64 points x 8 waves; wave t reads the residual slot of target
 // frame t (coalesced: consecutive lanes = consecutive points), lanes of wave 0 add the 8 targets in ascending order.
 struct PointSmem { float part[kMaxFrames][13][64]; };
+struct PointOut { int p; bool nogood; float HddA, bdA, HddL, bdL, HcdA[4], HcdL[4], hdi, bds, Hcd[4]; };
+__device__ __forceinline__ void point_store(const EFArrays& A, int nP, const PointOut& o) {
+    const int p = o.p;
+    A.pHddA[p] = o.HddA; A.pbdA[p] = o.bdA; A.pHddL[p] = o.HddL; A.pbdL[p] = o.bdL;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { A.pHcdA[(size_t)i * nP + p] = o.HcdA[i]; A.pHcdL[(size_t)i * nP + p] = o.HcdL[i]; }
+    if (o.nogood && A.pnogood) A.pnogood[p] = 1;
+    A.pHdi[p] = o.hdi; A.pbdSum[p] = o.bds;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) A.pHcd[(size_t)i * nP + p] = o.Hcd[i];
+}
 
 // body for one workgroup of 256 threads = the points [p_base, p_base + p_count), p_count <= 64; wave w handles targets w and w + 4.
 // MODE 0: solveSystemF (addPoint<0> and <1> + accumulateSCF head, shiftPriorToZero = true).
@@ -514,7 +525,10 @@ __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, 
                                            const int* __restrict__ phost, int p_base, int p_count, PointSmem& S,
                                            const uint8_t* __restrict__ mask = nullptr, float* __restrict__ prior_w = nullptr,
                                            float (*pt_out)[64] = nullptr /* [6][64] LDS: Hcd[4], bdSum, Schur weight of the tile's points */,
-                                           int h_tile = -1 /* >= 0: every point of the tile is hosted by this key-frame of the rank's shard: no phost / table loads ahead of the flags */) {
+                                           int h_tile = -1 /* >= 0: every point of the tile is hosted by this key-frame of the rank's shard: no phost / table loads ahead of the flags */,
+                                           const unsigned* verdict = nullptr /* non-NULL: the accept test of the step these sums belong to is being taken by another workgroup of
+                                                                               THIS launch (k_ef_acc_stats): the per-point planes are written only if it says accept */,
+                                           unsigned verdict_seq = 0) {
     float (*part)[13][64] = S.part;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (pt_out && wave == 0) {
@@ -616,32 +630,43 @@ __device__ __forceinline__ void point_body(const EFConst& C, const EFArrays& A, 
     for (int tt = 0; tt < C.nF; ++tt)
 #pragma unroll
         for (int i = 0; i < 13; ++i) sum[i] += part[tt][i][lane];
-    const float bdA = sum[0], HddA = sum[1], bdL = sum[6], HddL = sum[7];
-    A.pHddA[p] = HddA; A.pbdA[p] = bdA; A.pHddL[p] = HddL; A.pbdL[p] = bdL;
+    // the point's outputs (AccumulatedSCHessian.cpp:12-34 for the last six)
+    PointOut o;
+    o.p = p;
+    o.HddA = sum[1]; o.bdA = sum[0]; o.HddL = sum[7]; o.bdL = sum[6];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { A.pHcdA[(size_t)i * C.nP + p] = sum[2 + i]; A.pHcdL[(size_t)i * C.nP + p] = sum[8 + i]; }
-    // AccumulatedSCHessian.cpp:12-34
-    if (sum[12] == 0.0f) {
-        if (A.pnogood) A.pnogood[p] = 1;
-        A.pHdi[p] = 0; A.pbdSum[p] = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) A.pHcd[(size_t)i * C.nP + p] = 0;
-        return;
+    for (int i = 0; i < 4; ++i) { o.HcdA[i] = sum[2 + i]; o.HcdL[i] = sum[8 + i]; }
+    o.nogood = sum[12] == 0.0f;
+    float hdi = 0.0f, bds = 0.0f;
+    if (!o.nogood) {
+        float prior = prior_in;
+        if (MODE == 2) { prior *= 600.0f * 600.0f; prior_w[p] = prior; }   // setting_idepthFixPriorMargFac, EnergyFunctional.cpp:527
+        float H = o.HddA + o.HddL + prior;
+        if (H < 1e-10) H = 1e-10;
+        hdi = (float)(1.0 / H);
+        bds = o.bdA + o.bdL;
+        if (MODE != 2) bds += prior * delta_in;  // shiftPriorToZero == true in accumulateSCF_MT, false in marginalizePointsF
     }
-    float prior = prior_in;
-    if (MODE == 2) { prior *= 600.0f * 600.0f; prior_w[p] = prior; }   // setting_idepthFixPriorMargFac, EnergyFunctional.cpp:527
-    float H = HddA + HddL + prior;
-    if (H < 1e-10) H = 1e-10;
-    const float hdi = (float)(1.0 / H);
-    A.pHdi[p] = hdi;
-    float bds = bdA + bdL;
-    if (MODE != 2) bds += prior * delta_in;  // shiftPriorToZero == true in accumulateSCF_MT, false in marginalizePointsF
-    A.pbdSum[p] = bds;
+    o.hdi = hdi; o.bds = bds;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) A.pHcd[(size_t)i * C.nP + p] = sum[2 + i] + sum[8 + i];
-    if (pt_out) {   // the fused accumulate's Schur Gram takes these from LDS (weight 0 for LiDAR points, AccumulatedSCHessian.cpp:36-37)
+    for (int i = 0; i < 4; ++i) o.Hcd[i] = o.nogood ? 0.0f : sum[2 + i] + sum[8 + i];
+    bool go = true;
+    if (verdict) {   // (everything above ran on the accepted case's inputs; a rejected step must find the planes of the kept state untouched.  Storing later -- behind the
+        // workgroup's Gram phase -- was measured: the launch 9.3 -> 10.0 us, the stores then trail the workgroup; by here the word has normally arrived)
+        unsigned w = 0;
+        int polls = 0;
+        for (;;) {
+            w = __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((w >> 1) == verdict_seq || ++polls > (1 << 18)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if ((w >> 1) != verdict_seq) ef_raise(A.err, 1u);
+        go = (w >> 1) == verdict_seq && (w & 1u);
+    }
+    if (go) point_store(A, C.nP, o);
+    if (pt_out && !o.nogood) {   // the fused accumulate's Schur Gram takes these from LDS (weight 0 for LiDAR points, AccumulatedSCHessian.cpp:36-37)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pt_out[i][lane] = sum[2 + i] + sum[8 + i];
+        for (int i = 0; i < 4; ++i) pt_out[i][lane] = o.Hcd[i];
         pt_out[4][lane] = bds;
         pt_out[5][lane] = sensor_in ? 0.0f : hdi;
     }
@@ -961,7 +986,10 @@ __global__ void __launch_bounds__(256) k_ef_sc_gram(EFConst C, EFArrays A, const
 // verdict means this accumulate has no reader -- the planes it would rewrite already hold the kept state's values: every workgroup returns at once
 struct AccAlt { const int* verdict; const float* pid; const float* pidz; const float* pdeltaF; const CalibDev* calib; const PrecalcDev* precalc; int skip_on_reject;
                 // (fused applyRes: the planes applyRes writes also exist twice; NULL = they do not depend on the verdict)
-                uint8_t* rflags; int8_t* rstate; float* renergy; float* JpJd; };
+                uint8_t* rflags; int8_t* rstate; float* renergy; float* JpJd;
+                // (k_ef_acc_stats: the accept test is a workgroup of the SAME launch -- the accumulate runs on the accepted case's arguments without looking at
+                // `verdict`, its only writes outside scratch, the per-point planes, wait for this tagged word; requires skip_on_reject)
+                const unsigned* verdict_word; unsigned verdict_seq; };
 // (body for workgroup b of the launch: k_ef_acc_fused launches it for one window, k_lock_acc -- backend_lockstep.inc -- for B windows in one grid)
 __device__ __forceinline__ void acc_fused_body(const PrecalcDev* __restrict__ precalc, const EFConst& Cin, EFArrays A,
                                                const int* __restrict__ phost, float* __restrict__ top_partial,
@@ -970,7 +998,7 @@ __device__ __forceinline__ void acc_fused_body(const PrecalcDev* __restrict__ pr
     const PrecalcDev* __restrict__ ranges = precalc;   // point ranges / shard flags are the same in both tables: read them without waiting for the verdict
     // the verdict word is FETCHED here and LOOKED AT where the state-dependent inputs are first needed: tested at once it heads the chain
     // verdict -> point range -> flags -> values of every Schur workgroup with a round trip of its own
-    const int vd = alt.verdict ? *alt.verdict : 1;
+    const int vd = (alt.verdict && !alt.verdict_word) ? *alt.verdict : 1;
     if (alt.skip_on_reject && vd == 0) return;   // (uniform over the grid: before any barrier)
     // (fused applyRes: which copy of the flags / JpJd planes is current depends on the verdict; the Schur workgroups' first loads of them wait for
     // the point range anyway, which was fetched together with the verdict)
@@ -992,7 +1020,7 @@ __device__ __forceinline__ void acc_fused_body(const PrecalcDev* __restrict__ pr
         }
         if (vd == 0) { A.pid = alt.pid; A.pidz = alt.pidz; A.pdeltaF = alt.pdeltaF; A.calib = alt.calib; precalc = alt.precalc; }
         const EFConst C = ef_const(Cin, A);
-        if (begin < np) point_body(C, A, precalc, phost, P0 + begin, end - begin, S.p, nullptr, nullptr, pt, h);   // (np != 0: the host is this rank's)
+        if (begin < np) point_body(C, A, precalc, phost, P0 + begin, end - begin, S.p, nullptr, nullptr, pt, h, alt.verdict_word, alt.verdict_seq);   // (np != 0: the host is this rank's)
         else if (wave == 0) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) pt[i][threadIdx.x & 63] = 0.0f;

@@ -812,26 +812,36 @@ def test_lockstep_refuses_what_it_does_not_take(api, orc, window):
 
 @pytest.mark.parametrize("seed,its", [(2, 12), (3, 6), (4, 7)])
 def test_fused_apply_single_window_is_bit_identical(api, orc, seed, its, monkeypatch):
-    """SDVGN_FUSED_APPLY=1: the linearise leaves applyRes in the second copies of the flag / state / energy / JpJd planes and an accepted step swaps
-    pointers (what the batched launch sequence always does) instead of apply workgroups in the statistics launch -- same trace, states, planes,
-    next solve and loop tail, bit for bit; also after operations that write the planes in place between two calls (fixLinearization)."""
+    """The loop's default since round 6 (B): the linearise leaves applyRes in the second copies of the flag / state / energy / JpJd planes, an accepted step swaps
+    pointers, and the accept test is a workgroup of the next body's accumulate launch (k_ef_acc_stats) -- against SDVGN_FUSED_APPLY=0 (A: apply workgroups in a
+    statistics launch of its own, the form of rounds 3-5) and against the fused form with the statistics as their own launch (C: SDVGN_DEBUG_FLAGS bit 9):
+    same trace, states, planes, next solve and loop tail, bit for bit; also after operations that write the planes in place between two calls (fixLinearization)."""
     from sdv_loam_amd import synthetic as syn
     kw = {} if seed == 2 else dict(state_sigma=1e-3, idepth_sigma=0.01)
     W = low_thresholds(syn.make_window(w=640, h=240, nF=5, pts_per_kf=300, seed=seed, calib=dict(fx=400., fy=410., cx=319.5, cy=119.5), **kw))
+    monkeypatch.delenv("SDVGN_FUSED_APPLY", raising=False)
+    monkeypatch.delenv("SDVGN_DEBUG_FLAGS", raising=False)
     A = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
     B = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)
-    monkeypatch.delenv("SDVGN_FUSED_APPLY", raising=False)
+    monkeypatch.setenv("SDVGN_DEBUG_FLAGS", "512")
+    Cw = api.EnergyFunctional(W.w, W.h, max_points=W.nP).load(W)      # (the flags are read when the window is loaded)
+    monkeypatch.delenv("SDVGN_DEBUG_FLAGS")
+    monkeypatch.setenv("SDVGN_FUSED_APPLY", "0")
     ta = A.optimize(its, fixed_its=True)
-    monkeypatch.setenv("SDVGN_FUSED_APPLY", "1")
+    monkeypatch.delenv("SDVGN_FUSED_APPLY")
     tb = B.optimize(its, fixed_its=True)
-    assert np.array_equal(ta, tb)
+    tc = Cw.optimize(its, fixed_its=True)
+    assert np.array_equal(ta, tb) and np.array_equal(ta, tc)
+    assert 0 < ta[:, 2].sum() < len(ta) or seed != 2                   # (seed 2: accepted and rejected steps both occur)
     _same_window_result(A, B)
+    _same_window_result(A, Cw)
     assert np.array_equal(A.residual_J(0), B.residual_J(0))
     mask = (np.arange(W.nP) % 3 == 0).astype(np.uint8)
     A.fixLinearization(mask); B.fixLinearization(mask)
     tb2 = B.optimize(5, fixed_its=True)
-    monkeypatch.delenv("SDVGN_FUSED_APPLY")
+    monkeypatch.setenv("SDVGN_FUSED_APPLY", "0")
     ta2 = A.optimize(5, fixed_its=True)
+    monkeypatch.delenv("SDVGN_FUSED_APPLY")
     assert np.array_equal(ta2, tb2)
     _same_window_result(A, B)
     ea, eb = A.optimize_finish(), B.optimize_finish()
