@@ -77,6 +77,9 @@ int dev_alloc_tagged(T** p, size_t n, const char* tag) { return gmem::dmalloc_im
 
 }  // namespace
 
+// (arguments of the statistics workgroup -- sum_stats_body below -- and of the accept test it may carry)
+struct DecideArgs { double En, EM, rhs; int* accept_dev; int on; unsigned* verdict; unsigned seq; const double* en_em; };
+struct StatsLaunch { const double* pe; int nE; const double* pl; int nL; const double* ps; int nS; double* out; volatile int* done_flag; int done_seq; DecideArgs dec; };
 struct sdvgn_ef {
     int device = 0, w = 0, h = 0, max_points = 0;
     hipStream_t stream = nullptr;
@@ -180,6 +183,11 @@ struct sdvgn_ef {
     float *pHddA = nullptr, *pbdA = nullptr, *pHcdA = nullptr, *pHddL = nullptr, *pbdL = nullptr, *pHcdL = nullptr, *pHdi = nullptr,
           *pbdSum = nullptr, *pHcd = nullptr, *pstep = nullptr;
     uint8_t* pnogood = nullptr;    // EFArrays::pnogood
+    uint8_t nogood_epoch = 0;      // epoch of the last optimize call (0: none yet)
+    // the statistics of the call's INITIAL linearizeAll, not launched yet: nothing needs them before the first accept test, so they ride as a workgroup of the first
+    // body's accumulate (k_ef_acc_stats) instead of a 5 us launch between that linearise and that accumulate; ef_flush_stats launches them alone if no accumulate comes
+    StatsLaunch pend_stats{};
+    bool pend_stats_valid = false;
     float* images = nullptr;
     float* img_stage = nullptr;
     int *phost_dev = nullptr, *hostP0_dev = nullptr;
@@ -282,6 +290,12 @@ static void ef_select_new_set(sdvgn_ef* e, int write, int prev, int th_read = -1
     A.frameTH_w = e->th_dev + (size_t)write * SDVGN_MAX_FRAMES;
 }
 constexpr int kThLog = 1024;
+// a new epoch for EFArrays::pnogood ("during THIS optimize call"): the plane is cleared once per 255 calls instead of by a memset launch at the head of every call
+static int ef_next_nogood_epoch(sdvgn_ef* e, hipStream_t s) {
+    if (e->nogood_epoch == 255) { HIPCHK(hipMemsetAsync(e->pnogood, 0, (size_t)e->max_points, s)); e->nogood_epoch = 0; }
+    e->A.nogood_epoch = ++e->nogood_epoch;
+    return SDVGN_OK;
+}
 
 static void ef_fill_arrays(sdvgn_ef* e) {
     EFArrays& A = e->A;
@@ -293,7 +307,7 @@ static void ef_fill_arrays(sdvgn_ef* e) {
     A.frameTH_r = e->th_dev; A.frameTH_w = e->th_dev;
     A.J = e->J; A.JpJd = e->JpJd;
     A.pHddA = e->pHddA; A.pbdA = e->pbdA; A.pHcdA = e->pHcdA; A.pHddL = e->pHddL; A.pbdL = e->pbdL; A.pHcdL = e->pHcdL;
-    A.pHdi = e->pHdi; A.pbdSum = e->pbdSum; A.pHcd = e->pHcd; A.pstep = e->pstep; A.pnogood = e->pnogood;
+    A.pHdi = e->pHdi; A.pbdSum = e->pbdSum; A.pHcd = e->pHcd; A.pstep = e->pstep; A.pnogood = e->pnogood; A.nogood_epoch = e->nogood_epoch;
     A.images = e->images;
     A.img_slots = 0;
     for (int t = 0; t < SDVGN_MAX_FRAMES; ++t) A.img_slots |= (unsigned)(e->img_slot[t] & 7) << (4 * t);
@@ -834,7 +848,6 @@ __global__ void __launch_bounds__(256) k_ef_point_stats(EFConst Cin, EFArrays A,
 // conditional k_ef_apply queued right behind it (accept_dev) and for the host (out[4]).
 // en_em (device, may be NULL): the prior energy and the M energy of the stepped state as step_energy_body left them -- then En / EM of this block
 // are ignored and the host need not have seen x when it queues the launch; the two values go back to the host in out[5], out[7]
-struct DecideArgs { double En, EM, rhs; int* accept_dev; int on; unsigned* verdict; unsigned seq; const double* en_em; };
 __device__ __forceinline__ void sum_stats_body(const double* __restrict__ pe, int nE, const double* __restrict__ pl, int nL,
                                                const double* __restrict__ ps, int nS, double* __restrict__ out, volatile int* done_flag, int done_seq,
                                                double (*s)[256], const DecideArgs& dec = DecideArgs{0, 0, 0, nullptr, 0, nullptr, 0, nullptr}) {
@@ -929,7 +942,6 @@ __global__ void __launch_bounds__(kSelLanes) k_ef_stats_apply_select(const doubl
 // behind an "accept" reads; the per-point planes are the one thing a rejected step must find untouched -- point_body's first wave looks at the tagged
 // verdict word before it stores (by then it is there: one round trip + a 900-term sum against two round trips + the per-point sums).  The statistics launch
 // (5.4 us of the 62 us chain of an accepted body) leaves the chain.
-struct StatsLaunch { const double* pe; int nE; const double* pl; int nL; const double* ps; int nS; double* out; volatile int* done_flag; int done_seq; DecideArgs dec; };
 __global__ void __launch_bounds__(256) k_ef_acc_stats(const PrecalcDev* __restrict__ precalc, EFConst Cin, EFArrays A, const int* __restrict__ phost,
                                                       float* __restrict__ top_partial, int* __restrict__ nres_partial, int top_chunks,
                                                       float* __restrict__ sc_partial, int sc_chunks, int n_sc, AccAlt alt, StatsLaunch st) {
@@ -1157,6 +1169,7 @@ int sdvgn_ef_create(sdvgn_ef** out, int device, int w, int h, int max_points, vo
     std::memset(e->stats_host, 0, sizeof(double) * 8);   // [0..3] sums, [4] verdict, [6] (as unsigned) the sticky intra-launch wait error word
     HIPCHK(SDVGN_DMALLOC((void**)&e->accept_dev, 64));
     HIPCHK(hipMemset(e->accept_dev, 0, 64));
+    HIPCHK(hipMemset(e->pnogood, 0, (size_t)e->max_points));      // (epochs, ef_next_nogood_epoch: the plane starts clean)
     HIPCHK(SDVGN_HMALLOC((void**)&e->flags_host, 64));
     HIPCHK(SDVGN_HMALLOC((void**)&e->th_log, sizeof(float) * kThLog));
     HIPCHK(SDVGN_HMALLOC((void**)&e->win_host, 2 * sizeof(SolveWindow)));
@@ -1657,16 +1670,29 @@ static AccGeom ef_acc_geom(const sdvgn_ef* e) {
     g.ntop = g.pairs * kTopE; g.nsc = nF * kScE;
     return g;
 }
+static int ef_flush_stats(sdvgn_ef* e) {      // the pending initial statistics as a launch of their own
+    if (!e->pend_stats_valid) return SDVGN_OK;
+    e->pend_stats_valid = false;
+    const StatsLaunch& st = e->pend_stats;
+    const SelArgs nosel{};
+    k_ef_stats_select<<<1, kSelLanes, 0, e->stream>>>(st.pe, st.nE, st.pl, st.nL, st.ps, st.nS, st.out, st.done_flag, st.done_seq, nosel, st.dec);
+    HIPCHK(hipGetLastError());
+    return SDVGN_OK;
+}
 // st: the statistics + accept test of the trial step as workgroup 0 of the accumulate's launch (k_ef_acc_stats; alt->verdict_word set by the caller)
 static int ef_accumulate(sdvgn_ef* e, bool with_reduce, const AccAlt* alt = nullptr, const StatsLaunch* st = nullptr) {
     const AccGeom g = ef_acc_geom(e);
     const int nF = e->nF, n_top = g.chunks * g.pairs, n_pt = (e->nP + 63) / 64;
     if (st && !(alt && alt->verdict_word && alt->skip_on_reject && g.sc_ppb == 64)) return SDVGN_E_STATE;
+    if (e->pend_stats_valid) {       // the initial linearizeAll's statistics: with this launch when it can carry them, alone and first otherwise
+        if (!st && !alt && g.sc_ppb == 64) { st = &e->pend_stats; e->pend_stats_valid = false; }
+        else { const int rcf = ef_flush_stats(e); if (rcf) return rcf; }
+    }
     if (g.sc_ppb == 64) {
         const int n_sc = nF * g.sc_chunks;
         const AccAlt none{};
         if (st) k_ef_acc_stats<<<1 + n_sc + n_top, 256, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, e->sc_partial,
-                                                                        g.sc_chunks, n_sc, *alt, *st);
+                                                                        g.sc_chunks, n_sc, alt ? *alt : none, *st);
         else
         k_ef_acc_fused<<<n_sc + n_top, 256, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, e->sc_partial, g.sc_chunks, n_sc,
                                                             alt ? *alt : none);
@@ -2192,8 +2218,8 @@ static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideAr
         const DecideArgs none{0, 0, 0, nullptr, 0, nullptr, 0, nullptr};
         if (fused) {
             const bool sel_now = final_body || !defer_select;
-            if (merged_out && (sel_now || !dec)) return SDVGN_E_STATE;
-            if (merged_out) *merged_out = StatsLaunch{e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host, e->flags_host + 2, ++e->seq_stats, *dec};
+            if (merged_out && sel_now) return SDVGN_E_STATE;
+            if (merged_out) *merged_out = StatsLaunch{e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host, e->flags_host + 2, ++e->seq_stats, dec ? *dec : none};
             else
             k_ef_stats_select<<<sel_now ? 2 : 1, kSelLanes, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host,
                                                                            e->flags_host + 2, ++e->seq_stats, a, dec ? *dec : none);
@@ -2292,8 +2318,8 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     const bool relinearize_on_reject = (flags & 2) != 0;   // run the reference's redundant re-linearisation literally (A/B timing, tests)
     const bool reuse_after_reject = (flags & 4) != 0;      // opt-in: the solve after a rejected step reuses the stitched system (see header)
     const bool no_spec_solve = (flags & 16) != 0;          // A/B and tests: do not solve the rejected case ahead on the side stream
-    e->pend_sel_valid = e->pend_rc_valid = false;           // nothing of an earlier (failed) call is carried over
-    HIPCHK(hipMemsetAsync(e->pnogood, 0, (size_t)e->nP, e->stream));      // sdvgn_ef_get_point_nogood: "during THIS call"
+    e->pend_sel_valid = e->pend_rc_valid = e->pend_stats_valid = false;           // nothing of an earlier (failed) call is carried over
+    { const int rce = ef_next_nogood_epoch(e, e->stream); if (rce) return rce; }      // sdvgn_ef_get_point_nogood: "during THIS call"
     e->time_lin = (flags & 8) != 0;                          // measurement: event pair around every k_ef_linearize launch
     e->lin_ev_used = 0; e->lin_ms.clear();
     struct TimeLinGuard { sdvgn_ef* e; ~TimeLinGuard() { e->time_lin = false; } } time_lin_guard{e};
@@ -2343,7 +2369,9 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         ef_set_apply_target(e, true);
         rc = linearize_launch_kernels(e);
         ef_set_apply_target(e, false);
-        if (rc || (rc = linearize_launch_stats(e, defer, nullptr, false, false, /*fused=*/true))) return rc;
+        // (merge_stats: the sums are not launched here -- they ride in the first body's accumulate, ef_accumulate / take_initial_energies)
+        if (rc || (rc = linearize_launch_stats(e, defer, nullptr, false, false, /*fused=*/true, (merge_stats && mnumOptIts > 0) ? &e->pend_stats : nullptr))) return rc;
+        e->pend_stats_valid = merge_stats && mnumOptIts > 0;
         ef_flip_applied(e);
     } else
     if (defer && !e->own_stream) {   // linearise, then its statistics and applyRes in ONE launch (they do not depend on each other)
@@ -2357,6 +2385,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     auto take_initial_energies = [&]() -> int {
         if (!initial_pending) return SDVGN_OK;
         initial_pending = false;
+        { const int rcf = ef_flush_stats(e); if (rcf) return rcf; }      // (normally launched long ago, inside the first body's accumulate)
         HIPCHK(wait_flag(e->flags_host + 2, e->seq_stats, e->stream));
         lastEnergy = e->stats_host[0];
         lastEnergyL = En_initial + (double)(float)e->stats_host[1];       // linearize_wait's expression, with the mirror as it was at the launch
@@ -3158,6 +3187,7 @@ int sdvgn_ef_get_point_nogood(sdvgn_ef* e, unsigned char* out) {
     EF_DEVICE(e);
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(out, e->pnogood, (size_t)e->nP, hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->nP; ++i) out[i] = (e->nogood_epoch != 0 && out[i] == e->nogood_epoch) ? 1 : 0;
     return e->nP;
 }
 

@@ -90,7 +90,8 @@ struct EFArrays {
     float* pHddL; float* pbdL; float* pHcdL;
     float* pHdi; float* pbdSum; float* pHcd;  // SC inputs (Hcd = A + L)
     float* pstep;
-    uint8_t* pnogood;        // [nP] set when a solve finds the point without an active residual (AccumulatedSCHessian.cpp:14-21 zeroes PointHessian::maxRelBaseline there); cleared by sdvgn_ef_optimize
+    uint8_t* pnogood;        // [nP] takes nogood_epoch when a solve finds the point without an active residual (AccumulatedSCHessian.cpp:14-21 zeroes PointHessian::maxRelBaseline
+    uint8_t nogood_epoch;    // there); every sdvgn_ef_optimize call has its own epoch (1..255: no memset launch per call), sdvgn_ef_get_point_nogood compares
     // images
     const float* images;     // [image slot][w*h*3]; frame t's image lives in slot ef_img_slot(A, t)
     // frameEnergyTH per frame [nF]: the set k_ef_linearize classifies with / the set k_ef_select_th writes (one per state_New* set,
@@ -509,7 +510,7 @@ __device__ __forceinline__ void point_store(const EFArrays& A, int nP, const Poi
     A.pHddA[p] = o.HddA; A.pbdA[p] = o.bdA; A.pHddL[p] = o.HddL; A.pbdL[p] = o.bdL;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { A.pHcdA[(size_t)i * nP + p] = o.HcdA[i]; A.pHcdL[(size_t)i * nP + p] = o.HcdL[i]; }
-    if (o.nogood && A.pnogood) A.pnogood[p] = 1;
+    if (o.nogood && A.pnogood) A.pnogood[p] = A.nogood_epoch;
     A.pHdi[p] = o.hdi; A.pbdSum[p] = o.bds;
 #pragma unroll
     for (int i = 0; i < 4; ++i) A.pHcd[(size_t)i * nP + p] = o.Hcd[i];
