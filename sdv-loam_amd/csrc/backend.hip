@@ -2220,9 +2220,13 @@ static int linearize_launch_stats(sdvgn_ef* e, bool defer_select, const DecideAr
             const bool sel_now = final_body || !defer_select;
             if (merged_out && sel_now) return SDVGN_E_STATE;
             if (merged_out) *merged_out = StatsLaunch{e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host, e->flags_host + 2, ++e->seq_stats, dec ? *dec : none};
-            else
-            k_ef_stats_select<<<sel_now ? 2 : 1, kSelLanes, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host,
-                                                                           e->flags_host + 2, ++e->seq_stats, a, dec ? *dec : none);
+            else {
+                // (the loop's last body: the select as a launch of its own BEHIND the sums -- the host waits for the sums' flag, not for the 8 us of serial passes of
+                // the select, which then run while the call returns; as the second workgroup of this launch they set its duration and the host's wait)
+                k_ef_stats_select<<<1, kSelLanes, 0, e->stream>>>(e->energy_partial, n_partials, e->stats_partial, nL, ps, nS, e->stats_host,
+                                                                 e->flags_host + 2, ++e->seq_stats, a, dec ? *dec : none);
+                if (sel_now) k_ef_select_th<0><<<1, kSelLanes, 0, e->stream>>>(a.nF, a.nP, a.own0, a.own1, a.rflags, a.wo, nullptr, a.th_prev, a.th_out, a.log_slot);
+            }
             if (sel_now) defer_select = false;
         } else
         if (dec && dec->verdict && final_body && !e->own_stream) {
@@ -2447,8 +2451,9 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
         e->A.calib = e->calib_dev + st_trial;
         ef_select_new_set(e, 1 - e->new_cur, e->new_cur);                                 // trial linearisation goes to the other set
         th_idx.push_back(e->th_log_n % kThLog);
-        // ... and this body's own rejected case goes to the side stream now: same system (it is in SolveSys::tri), 100 x the damping, next iteration
         spec_pending = false;
+        // ... and this body's own rejected case goes to the side stream now: same system (it is in SolveSys::tri), 100 x the damping, next iteration
+        // (queued AHEAD of the trial linearise, so that its one workgroup has its CU before the linearise fills the chip; behind it: measured, no difference)
         if (spec_enabled && !zero_differs && e->sys_valid && iteration + 1 < mnumOptIts) {
             if ((rc = ef_launch_spec_solve(e, iteration + 1, lambda * 1e2, /*main_solve_in_flight=*/!from_spec))) return rc;
             spec_pending = true;
