@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 TRACKER_BYTES_PER_POINT = 64     # 16 B point record + 4 taps x 12 B {I,dx,dy}
 LINEARIZE_BYTES_PER_RES = 584    # 76 point + 16 matcher + 384 gathers + 96 J out + 12 state
+FUSED_APPLY_BYTES_PER_RES = 30   # what the loop's launches additionally write since round 6 (applyRes fused into the linearise: flags 1 + state 1 + energy 4 + JpJdF 24)
 
 
 def parse():
@@ -1244,6 +1245,8 @@ def main():
         # Everything else -- per-row extras, A/B legs, CPU sub-figures -- goes to bench_extras.json; a numbers-only digest goes to stderr.
         from tools import bench_line
         roof["bytes_per_launch"] = alg
+        # the in-loop launches also perform applyRes (their k_ef_stats_apply pass is gone): with the bytes that adds, for comparison with earlier rounds' 0.51
+        roof["frac_incl_fused_apply_bytes"] = (W.nR * (LINEARIZE_BYTES_PER_RES + FUSED_APPLY_BYTES_PER_RES)) / (ms_lin * 1e-3) / 1e9 / HBM_PEAK_GBS
         roof["short_note"] = "%d residuals x %d B / mean duration of the in-loop launches (rocprofv3 kernel trace, child run)" % (W.nR, LINEARIZE_BYTES_PER_RES) \
             if (lin_trace and "mean_ms" in lin_trace) else "%d residuals x %d B / back-to-back launch duration (HIP events on the library stream)" % (W.nR, LINEARIZE_BYTES_PER_RES)
         bench_line.write_extras(out, ROOT)

@@ -53,7 +53,7 @@ def compact(out):
     tr = roof.get("in_loop_trace") or {}
     if isinstance(tr, dict) and "mean_ms" in tr:
         r["in_loop_trace"] = {"mean_ms": _num(tr.get("mean_ms")), "launches": _num(tr.get("launches"))}
-    for k in ("back_to_back_ms", "hbm_copy_kernel_float4_GBps", "frac_of_practical_peak", "bytes_per_launch"):
+    for k in ("back_to_back_ms", "hbm_copy_kernel_float4_GBps", "frac_of_practical_peak", "bytes_per_launch", "frac_incl_fused_apply_bytes"):
         if roof.get(k) is not None:
             r[k] = _num(roof.get(k))
     r["note"] = _clip(roof.get("short_note") or "algorithmic bytes per launch / mean in-loop launch duration (kernel trace); details: bench_extras.json")
