@@ -945,12 +945,13 @@ __global__ void __launch_bounds__(kSelLanes) k_ef_stats_apply_select(const doubl
 __global__ void __launch_bounds__(256) k_ef_acc_stats(const PrecalcDev* __restrict__ precalc, EFConst Cin, EFArrays A, const int* __restrict__ phost,
                                                       float* __restrict__ top_partial, int* __restrict__ nres_partial, int top_chunks,
                                                       float* __restrict__ sc_partial, int sc_chunks, int n_sc, AccAlt alt, StatsLaunch st) {
+    __shared__ AccSmem S;
     if (blockIdx.x == gridDim.x - 1) {      // (the LAST workgroup: the accumulate's workgroups keep the ids -- and with them the XCDs, next to the linearise workgroups
-        __shared__ double s[4][256];        // whose Jacobians they read -- that k_ef_acc_fused gives them; the whole grid is resident at once)
-        sum_stats_body(st.pe, st.nE, st.pl, st.nL, st.ps, st.nS, st.out, st.done_flag, st.done_seq, s, st.dec);
+        // whose Jacobians they read -- that k_ef_acc_fused gives them; the whole grid is resident at once: 4 workgroups per CU, the sums in the accumulate's own LDS)
+        sum_stats_body(st.pe, st.nE, st.pl, st.nL, st.ps, st.nS, st.out, st.done_flag, st.done_seq, S.stats, st.dec);
         return;
     }
-    acc_fused_body(precalc, Cin, A, phost, top_partial, nres_partial, top_chunks, sc_partial, sc_chunks, n_sc, alt, (int)blockIdx.x);
+    acc_fused_body(S, precalc, Cin, A, phost, top_partial, nres_partial, top_chunks, sc_partial, sc_chunks, n_sc, alt, (int)blockIdx.x);
 }
 
 // device buffer -> pinned host buffer + completion flag (waitflag.hpp): the read-back after an all-reduce without the copy engine

@@ -991,8 +991,11 @@ struct AccAlt { const int* verdict; const float* pid; const float* pidz; const f
                 // (k_ef_acc_stats: the accept test is a workgroup of the SAME launch -- the accumulate runs on the accepted case's arguments without looking at
                 // `verdict`, its only writes outside scratch, the per-point planes, wait for this tagged word; requires skip_on_reject)
                 const unsigned* verdict_word; unsigned verdict_seq; };
+// the accumulate's LDS: one union for the three kinds of workgroup -- and for the statistics workgroup k_ef_acc_stats adds (a separate 8 kB array took the
+// kernel from 4 to 3 workgroups per CU: 768 places for its 769 workgroups, the statistics workgroup -- the LAST one -- waited for a place)
+union AccSmem { TopGramSmem t; PointSmem p; ScGramSmem s; double stats[4][256]; __device__ AccSmem() {} };
 // (body for workgroup b of the launch: k_ef_acc_fused launches it for one window, k_lock_acc -- backend_lockstep.inc -- for B windows in one grid)
-__device__ __forceinline__ void acc_fused_body(const PrecalcDev* __restrict__ precalc, const EFConst& Cin, EFArrays A,
+__device__ __forceinline__ void acc_fused_body(AccSmem& S, const PrecalcDev* __restrict__ precalc, const EFConst& Cin, EFArrays A,
                                                const int* __restrict__ phost, float* __restrict__ top_partial,
                                                int* __restrict__ nres_partial, int top_chunks, float* __restrict__ sc_partial,
                                                int sc_chunks, int n_sc, const AccAlt& alt, const int b) {
@@ -1004,7 +1007,6 @@ __device__ __forceinline__ void acc_fused_body(const PrecalcDev* __restrict__ pr
     // (fused applyRes: which copy of the flags / JpJd planes is current depends on the verdict; the Schur workgroups' first loads of them wait for
     // the point range anyway, which was fetched together with the verdict)
     if (vd == 0 && alt.rflags) { A.rflags = alt.rflags; A.rstate = alt.rstate; A.renergy = alt.renergy; A.JpJd = alt.JpJd; }
-    __shared__ union U { TopGramSmem t; PointSmem p; ScGramSmem s; __device__ U() {} } S;
     if (b < n_sc) {
         const int h = b / sc_chunks, bx = b - h * sc_chunks;
         const int2 rg = *reinterpret_cast<const int2*>(&ranges[h * Cin.nF + h].P0);   // {P0, np} in one load; np == 0 outside this rank's shard
@@ -1045,7 +1047,8 @@ __global__ void __launch_bounds__(256) k_ef_acc_fused(const PrecalcDev* __restri
                                                       const int* __restrict__ phost, float* __restrict__ top_partial,
                                                       int* __restrict__ nres_partial, int top_chunks, float* __restrict__ sc_partial,
                                                       int sc_chunks, int n_sc, AccAlt alt) {
-    acc_fused_body(precalc, Cin, A, phost, top_partial, nres_partial, top_chunks, sc_partial, sc_chunks, n_sc, alt, (int)blockIdx.x);
+    __shared__ AccSmem S;
+    acc_fused_body(S, precalc, Cin, A, phost, top_partial, nres_partial, top_chunks, sc_partial, sc_chunks, n_sc, alt, (int)blockIdx.x);
 }
 
 // ---- marginalizePointsF (EnergyFunctional.cpp:514-549): the same three bodies in MODE 2 over the points flagged by `mask` ----
