@@ -946,12 +946,14 @@ __global__ void __launch_bounds__(256) k_ef_acc_stats(const PrecalcDev* __restri
                                                       float* __restrict__ top_partial, int* __restrict__ nres_partial, int top_chunks,
                                                       float* __restrict__ sc_partial, int sc_chunks, int n_sc, AccAlt alt, StatsLaunch st) {
     __shared__ AccSmem S;
-    if (blockIdx.x == gridDim.x - 1) {      // (the LAST workgroup: the accumulate's workgroups keep the ids -- and with them the XCDs, next to the linearise workgroups
-        // whose Jacobians they read -- that k_ef_acc_fused gives them; the whole grid is resident at once: 4 workgroups per CU, the sums in the accumulate's own LDS)
-        sum_stats_body(st.pe, st.nE, st.pl, st.nL, st.ps, st.nS, st.out, st.done_flag, st.done_seq, S.stats, st.dec);
+    // workgroup 0 = the sums (dispatched first: the verdict is out ~1 us earlier than from the grid's last workgroup); 1..7 leave at once; the accumulate's workgroups
+    // follow from id 8 on, i.e. they keep the XCDs k_ef_acc_fused gives them (id mod 8), next to the linearise workgroups whose Jacobians they read.  The whole grid is
+    // resident at once (4 workgroups per CU, the sums in the accumulate's own LDS).
+    if (blockIdx.x < 8) {
+        if (blockIdx.x == 0) sum_stats_body(st.pe, st.nE, st.pl, st.nL, st.ps, st.nS, st.out, st.done_flag, st.done_seq, S.stats, st.dec);
         return;
     }
-    acc_fused_body(S, precalc, Cin, A, phost, top_partial, nres_partial, top_chunks, sc_partial, sc_chunks, n_sc, alt, (int)blockIdx.x);
+    acc_fused_body(S, precalc, Cin, A, phost, top_partial, nres_partial, top_chunks, sc_partial, sc_chunks, n_sc, alt, (int)blockIdx.x - 8);
 }
 
 // device buffer -> pinned host buffer + completion flag (waitflag.hpp): the read-back after an all-reduce without the copy engine
@@ -1692,7 +1694,7 @@ static int ef_accumulate(sdvgn_ef* e, bool with_reduce, const AccAlt* alt = null
     if (g.sc_ppb == 64) {
         const int n_sc = nF * g.sc_chunks;
         const AccAlt none{};
-        if (st) k_ef_acc_stats<<<1 + n_sc + n_top, 256, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, e->sc_partial,
+        if (st) k_ef_acc_stats<<<8 + n_sc + n_top, 256, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, e->sc_partial,
                                                                         g.sc_chunks, n_sc, alt ? *alt : none, *st);
         else
         k_ef_acc_fused<<<n_sc + n_top, 256, 0, e->stream>>>(e->precalc_dev, e->C, e->A, e->phost_dev, e->top_partial, e->nres_partial, g.chunks, e->sc_partial, g.sc_chunks, n_sc,
