@@ -1,5 +1,12 @@
 /* sdvgn_debug.h -- PRIVATE diagnostics entry points of libsdvgn.so (profiling experiments under tools/, never part of the drop-in
  * boundary declared in include/sdvgn.h).  The symbols are exported so that the experiment scripts can reach them through ctypes. */
+/* Environment switches the library reads (A/B measurements and tests; none is needed in normal use):
+ *   SDVGN_DEBUG_FLAGS   bit 1 (2) / 2 (4) / 7 (128): experiments of the diagnostic k_ef_linearize instantiation only; bit 5 (32): its stage stamps; bit 6 (64): stamps of the
+ *                       small solve; bit 8 (256): one residual group per k_ef_linearize workgroup; bit 9 (512): the accept test of a trial step as a launch of its own
+ *                       (k_ef_stats_select) instead of a workgroup of the next body's accumulate (k_ef_acc_stats) -- read when a window is loaded
+ *   SDVGN_FUSED_APPLY=0 applyRes as workgroups of the statistics launch (the loop of rounds 3-5) instead of fused into the linearise
+ *   SDVGN_PROFILE=1     host wall time per phase of the optimize loop (sdvgn_debug_phase_report); SDVGN_OPT_TIMING=1: the pre-loop phases of every call
+ *   SDVGN_PMC_SAFE=1    no look-ahead solve on the side stream (counter passes under a serialising profiler) */
 #pragma once
 #include "../../include/sdvgn.h"
 #ifdef __cplusplus
