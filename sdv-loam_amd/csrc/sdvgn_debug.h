@@ -6,7 +6,7 @@
  *                       (k_ef_stats_select) instead of a workgroup of the next body's accumulate (k_ef_acc_stats) -- read when a window is loaded
  *   SDVGN_FUSED_APPLY=0 applyRes as workgroups of the statistics launch (the loop of rounds 3-5) instead of fused into the linearise
  *   SDVGN_PROFILE=1     host wall time per phase of the optimize loop (sdvgn_debug_phase_report); SDVGN_OPT_TIMING=1: the pre-loop phases of every call
- *   SDVGN_PMC_SAFE=1    no look-ahead solve on the side stream (counter passes under a serialising profiler) */
+ *   (SDVGN_PMC_SAFE is read by tools/pmc_linearize.py, not by the library: it restricts the counter groups and runs the loop without the look-ahead solve) */
 #pragma once
 #include "../../include/sdvgn.h"
 #ifdef __cplusplus
