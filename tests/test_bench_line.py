@@ -72,3 +72,20 @@ def test_extras_file_holds_everything(tmp_path):
     back = json.load(open(written[0]))
     assert set(back) == set(out) and back["tracker"].keys() == out["tracker"].keys()
     assert bench_line.digest(out).startswith("bench extras:")
+
+
+def test_bench_imports_its_rows_from_tools():
+    """bench.py keeps the headline; the other rows live in tools/bench_rows.py (round 6) and are imported by name -- a missing one is an ImportError here, not
+    at the end of a GPU run"""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    rows = importlib.import_module("tools.bench_rows")
+    bench = importlib.import_module("bench")
+    for name in ("tracker_extras", "cfg5_extras", "reproject_extras", "trace_extras", "immature_extras", "marginalize_extras", "event_ms", "event_avg_ms",
+                 "tracker_problem", "load_tracker", "distinct_batch"):
+        assert getattr(bench, name) is getattr(rows, name), name
+    assert bench.LINEARIZE_BYTES_PER_RES == 584 and bench.FUSED_APPLY_BYTES_PER_RES == 30
+    assert sum(1 for _ in open(os.path.join(root, "bench.py"))) < 900
