@@ -30,6 +30,11 @@ def row(b):
     return [(b[order[i + 1]] - b[order[i]]) / 100.0 for i in range(len(order) - 1)]
 
 
+def step_row(b):
+    return "frame-step workgroup relative to x published (stamp 4), us: x seen %.2f | states + SE(3) exp done %.2f | precalc table written %.2f" % (
+        (b[11] - b[4]) / 100.0, (b[12] - b[4]) / 100.0, (b[13] - b[4]) / 100.0)
+
+
 def stitch_row(b):
     return "k_ef_stitch, host 0 part 0 (us): 0->8 loads %.2f | 8->9 products (T1, TC, B = A_h D_h, (h,h) terms) %.2f | 9->10 shares %.2f" % (
         (b[8] - b[0]) / 100.0, (b[9] - b[8]) / 100.0, (b[10] - b[9]) / 100.0)
@@ -49,5 +54,6 @@ for rep in range(5):
     G.solveSystemF(2, 0.1)
     if rep == 4:
         print(stitch_row(stamps()))
+        print(step_row(stamps()))
     r = row(stamps())
     print("solveSystemF #%d back to back (us): " % rep + " | ".join("%s %.2f" % (n, v) for n, v in zip(names, r)) + " | sum %.2f" % sum(r))
