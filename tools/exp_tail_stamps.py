@@ -45,15 +45,16 @@ rows = []
 for rep in range(6):
     G.load(W)
     G.optimize(6, fixed_its=True)
-    rows.append(row(stamps()))
+    b_loop = stamps()
+    rows.append(row(b_loop))
 rows = np.array(rows[1:])
 print("inside optimize(6), last body (us): " + " | ".join("%s %.2f" % (n, v) for n, v in zip(names, np.median(rows, axis=0))) + " | sum %.2f" % np.median(rows.sum(axis=1)))
+print("last body of that call: " + step_row(b_loop))
 G.load(W)
 G.linearize() if hasattr(G, "linearize") else None
 for rep in range(5):
     G.solveSystemF(2, 0.1)
     if rep == 4:
         print(stitch_row(stamps()))
-        print(step_row(stamps()))
     r = row(stamps())
     print("solveSystemF #%d back to back (us): " % rep + " | ".join("%s %.2f" % (n, v) for n, v in zip(names, r)) + " | sum %.2f" % sum(r))
