@@ -410,6 +410,12 @@ int sdvgn_ef_optimize_finish(sdvgn_ef* ef, double* lastEnergy_out, float* relbs_
  * (applyRes of an accepted step) restarts its running maximum.  out[nP] (dense index): 1 if some solve of the LAST sdvgn_ef_optimize call found the point
  * so; a caller that mirrors maxRelBaseline applies `if (out[p]) maxRelBaseline = 0` BEFORE folding sdvgn_ef_optimize_finish's relbs_max in.  Returns nP. */
 int sdvgn_ef_get_point_nogood(sdvgn_ef* ef, unsigned char* out);
+/* (no member of the reference: its loop cannot fail this way)  A compute call that returned SDVGN_E_STATE because a workgroup gave up a bounded intra-launch wait,
+ * or because a commit carried a fixed linearisation over, leaves a STICKY error word on the handle: every later compute call fails until the window is loaded again
+ * through sdvgn_ef_set_frames.  A caller that keeps the window on the device from key-frame to key-frame can instead clear the word here once it has put the
+ * window right (dropped / re-sent what the failed call concerned, then sdvgn_ef_set_adjoints + sdvgn_ef_set_precalc): returns the word as it was (0: nothing was
+ * raised; bit 0 the accept verdict, bit 1 the solution, bit 3 a fixed linearisation in a commit), and the next solve accumulates anew. */
+int sdvgn_ef_clear_error(sdvgn_ef* ef);
 /* ---- key-frame cycle around optimize: marginalisation (SURVEY 8 row b2 mode 2, EnergyFunctional.cpp:434-597) -------------------------
  * void EFResidual::fixLinearizationF(EnergyFunctional*)   EnergyFunctionalStructs.cpp:45-55, for every ACTIVE residual of the points with
  * mask[p] != 0 (FullSystem::flagPointsForRemoval calls it after re-linearising + applying those residuals, FullSystem.cpp:771-783 --
@@ -442,7 +448,10 @@ int sdvgn_ef_get_res_toZero(sdvgn_ef* ef, float* res_toZero2, unsigned char* isL
  * reference's own commit point (EnergyFunctional.cpp:761-782) -- applies them ON THE DEVICE (one gather pass over the per-point planes and the
  * flags / state / matcher planes; new points and residual edits from 96- / 16-byte records the entry points leave in pinned memory and send
  * at once -- the argument arrays may be reused when a call returns -- resolved to table slots by the commit's kernels).  Until the commit
- * every other entry point sees the window of the last commit.  After it the tables are bit-identical with a reload of the same graph in the
+ * every other entry point sees the window of the last commit -- with ONE exception: the image slot of a frame removed in this session is free at once, and a
+ * sdvgn_ef_insert_frame of the same session may upload into it (with SDVGN_MAX_FRAMES frames in the window there is no other slot); a compute call between that
+ * insert and the commit would read the new image for the removed frame.  The reference's key-frame (marginalizeFrame ... insertFrame ... makeIDX, then optimize)
+ * has no such call; run sdvgn_ef_make_idx first if yours does.  After it the tables are bit-identical with a reload of the same graph in the
  * same order through the setters above.
  *   Points are addressed by ids (sdvgn_ef_insert_points returns them; a window loaded through sdvgn_ef_set_points has id = index) that stay
  *   valid until the point is removed; the id of a removed point may be returned for a new point after the NEXT commit, never before (an edit

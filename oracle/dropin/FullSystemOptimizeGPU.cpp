@@ -358,7 +358,11 @@ float FullSystem::optimize(int mnumOptIts) {
     const auto t_1 = std::chrono::steady_clock::now();
     const int cap = mnumOptIts > 0 ? mnumOptIts : 1, stride = 7 + n + 1;
     std::vector<double> trace((size_t)cap * stride, 0.0);
-    const int fixed = setting_minOptIterations >= mnumOptIts ? 1 : 0;        // (`canbreak && iteration >= setting_minOptIterations`, :456; default 1 = the library's)
+    // `canbreak && iteration >= setting_minOptIterations` (:456): the library's loop has the reference's default (1) built in and an all-bodies mode; any other
+    // value would silently run a different number of bodies than the reference -- refuse it
+    if (setting_minOptIterations != 1 && setting_minOptIterations < mnumOptIts)
+        fs_die("setting_minOptIterations other than 1 (or >= the iteration count) is not supported by this binding", setting_minOptIterations);
+    const int fixed = setting_minOptIterations >= mnumOptIts ? 1 : 0;
     const int its = sdvgn_ef_optimize(g.h, mnumOptIts, fixed, trace.data(), stride, cap);
     if (its < 0) fs_die("sdvgn_ef_optimize", its);
     if (!setting_debugout_runquiet) {     // the reference's console lines (:414-425), from the device's trace

@@ -40,6 +40,7 @@ PROTOTYPES = [
     ("sdvgn_ef_get_residual_state", C.c_int, [vp, vp, vp, vp, vp, vp]),
     ("sdvgn_ef_get_points", C.c_int, [vp, f32p]),
     ("sdvgn_ef_get_point_nogood", C.c_int, [vp, vp]),
+    ("sdvgn_ef_clear_error", C.c_int, [vp]),
     ("sdvgn_ef_get_top_acc", C.c_int, [vp, f64p, vp]),
     ("sdvgn_ef_get_iteration_times", C.c_int, [vp, vp, C.c_int]),
     ("sdvgn_debug_phase_report", C.c_int, [C.c_int]),
@@ -317,6 +318,10 @@ class EnergyFunctional:
         self._check(self.L.sdvgn_ef_optimize_finish(self.h_, C.byref(e), rb.ctypes.data_as(vp), ng.ctypes.data_as(vp), rm.ctypes.data_as(vp)))
         return e.value, rb, ng, (rm.reshape(self.nF, self.nP) if table else rm[:self.nR])
 
+    def clear_error(self):
+        """the handle's sticky error word as it was (0: none); cleared (sdvgn_ef_clear_error)"""
+        return self._check(self.L.sdvgn_ef_clear_error(self.h_))
+
     def point_nogood(self):
         """per point: 1 if some solveSystemF of the last optimize() found it without an active residual (AccumulatedSCHessian.cpp:14-21 zeroes
         PointHessian::maxRelBaseline there)"""
@@ -389,7 +394,7 @@ class EnergyFunctional:
         c = np.ascontiguousarray
         a = None if dI is None else c(dI, np.float32).reshape(-1)
         b = None if image is None else c(image, np.float32).reshape(-1)
-        self._keep = (a, b)      # (the upload is asynchronous: the buffers live until the commit)
+        self._keep = (getattr(self, "_keep", None) or []) + [(a, b)]      # (the uploads are asynchronous: every inserted frame's buffers live until the commit)
         idx = self._check(self.L.sdvgn_ef_insert_frame(self.h_, c(evalPT7, np.float64), c(state10, np.float64), c(state_zero10, np.float64), int(frameID),
                                                        float(ab_exposure), float(frameEnergyTH), None if a is None else a.ctypes.data,
                                                        None if b is None else b.ctypes.data))

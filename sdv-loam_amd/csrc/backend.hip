@@ -3190,6 +3190,18 @@ int sdvgn_ef_get_residual_state(sdvgn_ef* e, int* state_state, int* state_new, f
     return SDVGN_OK;
 }
 
+int sdvgn_ef_clear_error(sdvgn_ef* e) {
+    if (!e) return SDVGN_E_ARG;
+    if (!e->stats_host) return 0;
+    if (!e->host_only) { EF_DEVICE(e); HIPCHK(hipStreamSynchronize(e->stream)); }      // nothing in flight may still raise it
+    volatile unsigned* w = reinterpret_cast<volatile unsigned*>(e->stats_host + 6);
+    const unsigned was = *w;
+    *w = 0;
+    e->sys_valid = false;              // (whatever system the failed call left is not re-used)
+    e->pend_sel_valid = e->pend_rc_valid = e->pend_stats_valid = false;
+    return (int)was;
+}
+
 int sdvgn_ef_get_point_nogood(sdvgn_ef* e, unsigned char* out) {
     if (!e || !out || e->nP < 1) return SDVGN_E_STATE;
     EF_DEVICE(e);

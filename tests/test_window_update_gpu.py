@@ -381,3 +381,37 @@ def test_point_table_reload_without_set_frames_ends_the_resident_window(api, big
     # and it is the window a fresh handle holds after the same calls (same frames / states: taken over from the resident one)
     vs, st, idp = G.state()
     assert len(tr) >= 1 and np.isfinite(tr).all() and idp.shape == (S.nP,)
+
+
+def test_clear_error_lets_a_resident_window_recover(api, big):
+    """a commit that carries a residual with a fixed linearisation raises the handle's sticky error word (code 8) and every later compute
+    call fails with SDVGN_E_STATE -- until now only a reload through sdvgn_ef_set_frames cleared it.  sdvgn_ef_clear_error returns the word and clears it; once the
+    caller has removed the offending points the resident window optimises again."""
+    import copy
+    W8 = copy.copy(big)
+    rng = np.random.default_rng(3)
+    frames = [0, 1, 2, 3, 4]
+    pts = np.nonzero(np.isin(W8.host, frames))[0]
+    M = Mirror(api, W8, frames, pts, rng.random(W8.nR) < 0.9, seed=2)
+    G = M.G
+    assert G.clear_error() == 0                                  # nothing raised yet
+    G.optimize(2)
+    mask = (np.arange(G.nP) % 7 == 0).astype(np.uint8)           # every seventh point: fixLinearizationF, like flagPointsForRemoval's marginalised ones
+    G.fixLinearization(mask)
+    fixed = [M.order[i] for i in np.nonzero(mask)[0]]
+    G.removePoints(np.array([M.order[1]], np.int32))             # an edit session that does NOT remove them: the commit carries fixed linearisations over
+    order = [int(i) for i in G.makeIDX()]
+    G.setAdjointsF(); G.setPrecalcValues()
+    with pytest.raises(RuntimeError):
+        G.optimize(2)
+    with pytest.raises(RuntimeError):                            # sticky
+        G.optimize(2)
+    assert G.clear_error() & 8
+    assert G.clear_error() == 0
+    G.removePoints(np.array([i for i in fixed if i in order], np.int32))
+    order2 = [int(i) for i in G.makeIDX()]
+    assert not set(fixed) & set(order2)
+    G.setAdjointsF(); G.setPrecalcValues()
+    tr = G.optimize(3)
+    assert len(tr) >= 1 and np.isfinite(tr).all()
+    assert G.clear_error() == 0
