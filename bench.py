@@ -350,7 +350,7 @@ def run_protocol(runners, bodies, world, reload_with=None, warm=None, **opt_kw):
     barrier_sync(world)
     dt = time.perf_counter() - t0
     if os.environ.get("SDVGN_BENCH_DEBUG"):
-        sys.stderr.write("[bench] region %.1f us; calls returned at %s us\n" % (1e6 * dt, np.round(1e6 * np.array(marks[:8]), 1)))
+        sys.stderr.write("[bench] region %.1f us; bodies %s; calls returned at %s us\n" % (1e6 * dt, list(bodies)[:8], np.round(1e6 * np.array(marks[:8]), 1)))
     return max_over_ranks(dt, world), traces
 
 
