@@ -39,12 +39,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=4096, help="LM trials per launch for the batched tracker roofline run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--quick", action="store_true", help="skip the tracker extras and the PMC traffic passes")
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--pmc-child-tracker", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--lock-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--repeats", type=int, default=7, help="runs of the --steps/--warmup protocol; `value` is the median run")
-    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--worker", action="store_true", help="be the measuring process itself (a bare `python bench.py` starts one and passes its line and exit code on)")
     return ap.parse_args()
 
 
@@ -181,65 +177,7 @@ def cpu_baseline_reference(W, budget_s):
 
 
 # ------------------------------------------------------------------------------------------------------------
-def pmc_child():
-    """Body of the profiled child process: the window is loaded and k_ef_linearize is launched 20 times (SDVGN_PMC_LOOP=1: ten bodies of
-    the optimize loop instead, so that every kernel of the loop appears in the counters)."""
-    import torch  # noqa: F401
-    W, G = backend_setup(0)
-    G.set_arith(int(os.environ.get("SDVGN_BENCH_ARITH", "0")))
-    if os.environ.get("SDVGN_PMC_LOOP"):
-        # (--pmc runs the kernels of all streams one at a time: the side-stream look-ahead of the rejected case cannot overlap anything there
-        # and would only add its bounded wait to every body -- the loop runs without it)
-        G.optimize(10, fixed_its=True, want_trace=False, no_spec_solve=True)
-    else:
-        G.launch_linearize_only(20)
-    torch.cuda.synchronize()
-
-
-def pmc_child_tracker(batch):
-    """Body of the profiled child process: the 64-problem batched launch of the fused tracker kernel, 6 times."""
-    import torch  # noqa: F401
-    import oracle
-    from sdv_loam_amd import api
-    P = tracker_problem()
-    G = load_tracker(api, P, 0, max(batch, 64))
-    Gs, launch = distinct_batch(api, oracle, P, G, 0, batch, records=os.environ.get("SDVGN_BENCH_RECORDS") == "1")
-    for _ in range(6):
-        launch()
-    torch.cuda.synchronize()
-
-
-def trace_child():
-    """Body of the kernel-trace child: the headline protocol (fresh perturbed windows, optimize(6) each) on 8 windows, nothing else."""
-    import torch  # noqa: F401
-    from sdv_loam_amd import backend_api, synthetic as syn
-    Wh = syn.make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=syn.KITTI00, **HEAD_KW)
-    rs = [backend_api.EnergyFunctional(Wh.w, Wh.h, max_points=Wh.nP).load(Wh) for _ in range(8)]
-    for r in rs:
-        r.set_arith(int(os.environ.get("SDVGN_BENCH_ARITH", "0")))
-    rs[0].optimize(6, fixed_its=True, want_trace=False)
-    rs[0].load(Wh)
-    for r in rs:
-        r.optimize(6, fixed_its=True, want_trace=False)
-    torch.cuda.synchronize()
-
-
-def lock_child(B):
-    """Body of the profiled child for the batched launch: B windows of the named size, one warm-up sdvgn_ef_optimize_lockstep call, then the two
-    that count (fresh windows each time)."""
-    import torch  # noqa: F401
-    from sdv_loam_amd import backend_api, synthetic as syn
-    Wh = syn.make_window(w=1241, h=376, nF=8, pts_per_kf=2000, seed=0, calib=syn.KITTI00, **HEAD_KW)
-    hs = [backend_api.EnergyFunctional(Wh.w, Wh.h, max_points=Wh.nP).load(Wh) for _ in range(B)]
-    for _ in range(3):
-        for h_ in hs:
-            h_.load(Wh)
-        torch.cuda.synchronize()
-        backend_api.optimize_lockstep(hs, 6, fixed_its=True, want_trace=False)
-    torch.cuda.synchronize()
-
-
-def measure_inloop_kernel(kernel="k_ef_linearize", timeout=240, arith=0, child=("--trace-child",), keep=(8, 9), summary="inloop_trace_summary_arith%d.txt",
+def measure_inloop_kernel(kernel="k_ef_linearize", timeout=240, arith=0, child=("trace",), keep=(8, 9), summary="inloop_trace_summary_arith%d.txt",
                           what="the headline protocol alone: 8 fresh windows x optimize(6); the untimed warm-up call and the window loads before it are not in the table"):
     """Duration of every launch of `kernel` inside the optimize loops of the headline protocol, from a rocprofv3 --kernel-trace of a child
     process that runs nothing but that protocol (HIP event pairs around single launches inside a loop read several us too long)."""
@@ -252,7 +190,7 @@ def measure_inloop_kernel(kernel="k_ef_linearize", timeout=240, arith=0, child=(
         return None
     d = tempfile.mkdtemp(prefix="sdvgn_trace_", dir="/tmp")
     try:
-        subprocess.run([exe, "--kernel-trace", "-d", d, "-o", "tr", "--", sys.executable, os.path.abspath(__file__)] + list(child),
+        subprocess.run([exe, "--kernel-trace", "-d", d, "-o", "tr", "--", sys.executable, os.path.join(ROOT, "tools", "bench_children.py")] + list(child),
                        cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", SDVGN_BENCH_ARITH=str(arith)), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                        timeout=timeout, check=True)
         dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
@@ -275,7 +213,7 @@ def measure_inloop_kernel(kernel="k_ef_linearize", timeout=240, arith=0, child=(
             tot = sum(r[3] for r in rows)
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             with open(os.path.join(ROOT, "gpurun_out", summary % arith if "%d" in summary else summary), "w") as fsum:
-                fsum.write("# rocprofv3 --kernel-trace -- python bench.py %s   (SDVGN_BENCH_ARITH=%d; %s)\n" % (" ".join(child), arith, what))
+                fsum.write("# rocprofv3 --kernel-trace -- python tools/bench_children.py %s   (SDVGN_BENCH_ARITH=%d; %s)\n" % (" ".join(child), arith, what))
                 fsum.write("%-100s %8s %12s %10s %10s %10s %6s\n" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
                 for r in rows[:30]:
                     fsum.write("%-100s %8d %12.1f %10.3f %10.3f %10.3f %6.2f\n" % (r[0][:100], r[1], r[3] / 1e3, r[2] / 1e3, r[4] / 1e3, r[5] / 1e3, 100 * r[3] / tot))
@@ -289,7 +227,7 @@ def measure_inloop_kernel(kernel="k_ef_linearize", timeout=240, arith=0, child=(
         shutil.rmtree(d, ignore_errors=True)
 
 
-def measure_traffic(kernel="k_ef_linearize", timeout=240, child=("--pmc-child",), env_extra=None):
+def measure_traffic(kernel="k_ef_linearize", timeout=240, child=("pmc",), env_extra=None):
     """HBM-side bytes per launch of `kernel` from rocprofv3 PMC counters, two separate passes (FETCH_SIZE, WRITE_SIZE; the TCC
     block cannot hold both), corrected as MI355X_MICROARCH.md prescribes and as profiles/r01_counter_calibration.txt confirms
     for this project's access patterns: FETCH_SIZE x2 (128-B requests are tallied at 64 B), WRITE_SIZE x1, KiB -> bytes.
@@ -306,7 +244,7 @@ def measure_traffic(kernel="k_ef_linearize", timeout=240, child=("--pmc-child",)
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="sdvgn_pmc_", dir="/tmp")
             env = dict(os.environ, TMPDIR="/tmp", **(env_extra or {}))
-            subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__)] + list(child),
+            subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "tools", "bench_children.py")] + list(child),
                            cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
             dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
             con = sqlite3.connect(dbs[0])
@@ -356,18 +294,6 @@ def run_protocol(runners, bodies, world, reload_with=None, warm=None, **opt_kw):
 
 def main():
     args = parse()
-    if args.pmc_child:
-        pmc_child()
-        return
-    if args.pmc_child_tracker:
-        pmc_child_tracker(args.batch)
-        return
-    if args.trace_child:
-        trace_child()
-        return
-    if args.lock_child:
-        lock_child(args.lock_child)
-        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` from a bare shell: launch the N ranks ourselves (one process per GPU over RCCL), the way the driver
         # does with torch.distributed.run; rank 0 of the children prints the JSON line, which passes through
@@ -558,12 +484,12 @@ def main():
             # the bandwidth kernel of the batched launch at B = 16 (1.3 GB of window data, beyond the Infinity Cache): duration from a kernel trace
             # of a child that runs nothing else, HBM-side bytes from the PMC counters of the same child
             Bt = 16
-            ltr = measure_inloop_kernel(kernel="k_lock_linearize", child=("--lock-child", str(Bt)), keep=(2, 3), summary="lockstep_trace_summary_B16.txt",
+            ltr = measure_inloop_kernel(kernel="k_lock_linearize", child=("lock", str(Bt)), keep=(2, 3), summary="lockstep_trace_summary_B16.txt",
                                         what="%d windows of the named size, sdvgn_ef_optimize_lockstep(6) x 3 calls, the first one untimed" % Bt)
             alg_b = Bt * Wh.nR * LINEARIZE_BYTES_PER_RES
             if ltr and "mean_ms" in ltr:
                 ach = alg_b / (ltr["mean_ms"] * 1e-3) / 1e9
-                tb_, how_ = measure_traffic(kernel="k_lock_linearize", child=("--lock-child", str(Bt)))
+                tb_, how_ = measure_traffic(kernel="k_lock_linearize", child=("lock", str(Bt)))
                 batched["roofline"] = dict(bound="hbm", kernel="k_lock_linearize (B = %d windows in one launch)" % Bt, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                                            frac=ach / HBM_PEAK_GBS, traffic=tb_, traffic_note=how_, traffic_over_algorithmic=(tb_ / alg_b) if tb_ else None,
                                            in_loop_trace=ltr,
@@ -756,7 +682,7 @@ def main():
         import oracle
         out["tracker"] = tracker_extras(torch, local, args.batch, oracle, not args.no_cpu)
         out["cfg5_fp16_tolerance_study"] = cfg5_extras(torch, local, oracle, not args.no_cpu)
-        tb, how = measure_traffic(kernel="k_res_gs", child=("--pmc-child-tracker", "--batch", str(args.batch)))
+        tb, how = measure_traffic(kernel="k_res_gs", child=("pmc-tracker", str(args.batch)))
         alg_t = args.batch * 2000 * TRACKER_BYTES_PER_POINT
         bi = out["tracker"]["batched_independent_problems"]
         bi["hbm_traffic_bytes_per_launch"] = tb
@@ -766,7 +692,7 @@ def main():
             bi["hbm_traffic_GBps"] = tb / (ms_sp * 1e-3) / 1e9
             bi["hbm_traffic_frac_of_peak"] = bi["hbm_traffic_GBps"] / HBM_PEAK_GBS
         bi["traffic_note"] = how + "; exact arithmetic; sparse 24-byte gathers pull whole 128-byte lines, so the launch is bound by HBM TRAFFIC, not by its algorithmic bytes"
-        tbr, howr = measure_traffic(kernel="k_res_gs", child=("--pmc-child-tracker", "--batch", str(args.batch)), env_extra={"SDVGN_BENCH_RECORDS": "1"})
+        tbr, howr = measure_traffic(kernel="k_res_gs", child=("pmc-tracker", str(args.batch)), env_extra={"SDVGN_BENCH_RECORDS": "1"})
         rl = bi.get("record_layout")
         if rl is not None:
             rl["hbm_traffic_bytes_per_launch"] = tbr

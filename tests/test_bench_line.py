@@ -89,3 +89,15 @@ def test_bench_imports_its_rows_from_tools():
         assert getattr(bench, name) is getattr(rows, name), name
     assert bench.LINEARIZE_BYTES_PER_RES == 584 and bench.FUSED_APPLY_BYTES_PER_RES == 30
     assert sum(1 for _ in open(os.path.join(root, "bench.py"))) < 900
+
+
+def test_bench_has_no_hidden_child_modes():
+    """the processes the bench profiles are tools/bench_children.py's modes, not hidden flags of bench.py (VERDICT r05 hygiene)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "-child" not in src.replace("bench_children", "") and "argparse.SUPPRESS" not in src
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_children.py")], capture_output=True, text=True)
+    assert r.returncode != 0 and "bench_children.py trace" in (r.stderr + r.stdout)

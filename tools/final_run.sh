@@ -54,7 +54,7 @@ bash tools/pmc_loop_kernels.sh r06 > /dev/null 2>&1
 # the three forms of the loop on this box (default | accept test as a launch of its own | applyRes workgroups in the statistics launch: rounds 3-5), interleaved
 bash tools/ab_bench.sh 4 - SDVGN_DEBUG_FLAGS=512 SDVGN_FUSED_APPLY=0 2>&1 | sort -k2,2 -s > $O/ab_loop_forms.txt
 tail -12 $O/ab_loop_forms.txt
-cd /tmp && timeout 300 rocprofv3 --kernel-trace -d /tmp/gp -o g -- python /root/repo/bench.py --trace-child > /dev/null 2>&1
+cd /tmp && timeout 300 rocprofv3 --kernel-trace -d /tmp/gp -o g -- python /root/repo/tools/bench_children.py trace > /dev/null 2>&1
 cd /root/repo
 python tools/gap_report.py /tmp/gp 50 > $O/loop_timeline.txt 2>&1
 tail -3 $O/loop_timeline.txt

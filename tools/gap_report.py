@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of the main stream inside the optimize loops of the headline protocol: every kernel of the LAST traced optimize(6) call with its start relative to
 the previous kernel's end (the gap the host / the dispatcher leaves), from a rocprofv3 --kernel-trace database.
-    cd /tmp && rocprofv3 --kernel-trace -d /tmp/gp -o g -- python /root/repo/bench.py --trace-child ; python tools/gap_report.py /tmp/gp"""
+    cd /tmp && rocprofv3 --kernel-trace -d /tmp/gp -o g -- python /root/repo/tools/bench_children.py trace ; python tools/gap_report.py /tmp/gp"""
 import glob
 import sqlite3
 import sys

@@ -2,7 +2,7 @@
 """Hardware counters of k_ef_linearize (rocprofv3 --pmc, one pass per counter group, kernel trace only) on the cfg3 window.
 
 usage (GPU box):  python tools/pmc_linearize.py > profiles/rNN_linearize_counters.txt
-The profiled child is `bench.py --pmc-child`: the window is loaded and k_ef_linearize is launched 20 times back to back, alone.
+The profiled child is `tools/bench_children.py pmc`: the window is loaded and k_ef_linearize is launched 20 times back to back, alone.
 Values are per launch (mean over the launches), summed over all instances of the block as rocprofv3 reports them."""
 import os
 import shutil
@@ -36,11 +36,11 @@ def main():
     global GROUPS
     if os.environ.get("SDVGN_PMC_SAFE"):     # the TA / TCP / TD groups never returned on this pool (profiles/r02_notes.txt): SQ + TCC only
         GROUPS = [g for g in GROUPS if not g[0].startswith(("TA_", "TCP_", "TD_"))] + [["FETCH_SIZE"], ["WRITE_SIZE"]]
-    print("# rocprofv3 --pmc <group> --kernel-trace -- python bench.py --pmc-child   (MI355X; %s, mean per launch)" % kernel)
+    print("# rocprofv3 --pmc <group> --kernel-trace -- python tools/bench_children.py pmc   (MI355X; %s, mean per launch)" % kernel)
     for grp in GROUPS:
         d = tempfile.mkdtemp(prefix="sdvgn_pmc_", dir="/tmp")
         try:
-            subprocess.run([exe, "--pmc"] + grp + ["--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child"],
+            subprocess.run([exe, "--pmc"] + grp + ["--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "tools", "bench_children.py"), "pmc"],
                            cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
             dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
             con = sqlite3.connect(dbs[0])

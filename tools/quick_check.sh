@@ -5,7 +5,7 @@ mkdir -p gpurun_out/loop
 timeout 1500 python -m pytest ${@:-tests} -x -q -m gpu -p no:cacheprovider 2>&1 | tail -4
 bash tools/loop_bench.sh 3 2>&1 | tail -4
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace -d /tmp/qprof -o q -- python /root/repo/bench.py --trace-child > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace -d /tmp/qprof -o q -- python /root/repo/tools/bench_children.py trace > /dev/null 2>&1
 cd /root/repo
 python - <<'PY'
 import sqlite3, glob
