@@ -51,6 +51,7 @@ PROTOTYPES = [
     ("sdvgn_ef_marginalize_frame", C.c_int, [vp, C.c_int, vp, vp]),
     ("sdvgn_ef_get_res_toZero", C.c_int, [vp, vp, vp]),
     ("sdvgn_debug_read_stamps", C.c_int, [vp, vp, C.c_int]),
+    ("sdvgn_debug_loop_counters", C.c_int, [vp, vp]),
     ("sdvgn_debug_solve_stamps", C.c_int, [vp, vp]),
     ("sdvgn_ef_get_linearize_times", C.c_int, [vp, vp, C.c_int]),
     ("sdvgn_debug_launch_linearize", C.c_int, [vp, C.c_int]),
@@ -374,6 +375,12 @@ class EnergyFunctional:
         a, b = C.c_int(0), C.c_int(0)
         self._check(self.L.sdvgn_ef_get_look_ahead(self.h_, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def loop_counters(self):
+        """(look-ahead solves launched, bodies served by one, accept tests merged into the next accumulate, accumulates queued ahead) of the last optimize call"""
+        out = np.zeros(4, np.int32)
+        self._check(self.L.sdvgn_debug_loop_counters(self.h_, out.ctypes.data_as(vp)))
+        return tuple(int(v) for v in out)
 
     def iteration_times_us(self):
         n = self.L.sdvgn_ef_get_iteration_times(self.h_, None, 0)

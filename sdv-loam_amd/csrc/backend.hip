@@ -166,6 +166,7 @@ struct sdvgn_ef {
     size_t stats_cap = 0;          // doubles behind stats_dev: 4 statistics + max_points quantile candidates (sharded path)
     std::vector<double> iter_us;   // wall time of every loop body of the last sdvgn_ef_optimize call (microseconds)
     int n_accepted = 0;            // accepted steps of the last sdvgn_ef_optimize call
+    int n_merged_tests = 0, n_pre_acc = 0;      // of the last call: accept tests taken as a workgroup of the next body's accumulate (k_ef_acc_stats) / accumulates queued ahead of the verdict
     int n_spec_launched = 0, n_spec_used = 0;   // of the last call: rejected cases solved ahead on the side stream / bodies that started from such a solution
     // deferred work of the optimize loop (see linearize_launch): the threshold select of the last linearisation and the re-classification
     // after a rejected step ride in later launches as extra workgroups; whatever is still pending is launched on its own by ef_flush_pending
@@ -2408,6 +2409,7 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
     e->iter_us.clear();
     e->n_accepted = 0;
     e->n_spec_launched = e->n_spec_used = 0;
+    e->n_merged_tests = e->n_pre_acc = 0;
     std::vector<int> th_idx;   // th_log slot of every trial linearisation (trace only)
     bool host_restore_pending = false;
     bool pre_accumulated = false;   // the accumulate of the coming body was queued behind the previous body's accept test (AccAlt)
@@ -2540,11 +2542,13 @@ int sdvgn_ef_optimize(sdvgn_ef* e, int mnumOptIts, int flags, double* trace, int
                     if ((rc = linearize_launch_stats(e, defer, &dec_deferred, /*final_body=*/false, false, fused_body, &st))) return rc;
                     rc = ef_accumulate(e, /*with_reduce=*/true, &alt, &st);
                     stats_deferred = false;
+                    ++e->n_merged_tests;
                 } else
                 rc = ef_accumulate(e, /*with_reduce=*/true, &alt);
                 if (fused_body) ef_flip_applied(e);        // (back: the verdict is not known yet)
                 if (rc) return rc;
                 pre_accumulated = true;
+                ++e->n_pre_acc;
             }
             if (stats_deferred && (rc = linearize_launch_stats(e, defer, &dec_deferred, /*final_body=*/false, false, fused_body))) return rc;   // (cannot happen: same conditions)
         }
@@ -3078,6 +3082,11 @@ int sdvgn_debug_launch_pattern(sdvgn_ef* e, int pattern, int reps, int spin_us) 
     return SDVGN_OK;
 }
 
+int sdvgn_debug_loop_counters(sdvgn_ef* e, int* out4) {
+    if (!e || !out4) return SDVGN_E_ARG;
+    out4[0] = e->n_spec_launched; out4[1] = e->n_spec_used; out4[2] = e->n_merged_tests; out4[3] = e->n_pre_acc;
+    return SDVGN_OK;
+}
 int sdvgn_ef_get_accepted_steps(sdvgn_ef* e) { return e ? e->n_accepted : SDVGN_E_ARG; }
 int sdvgn_ef_get_look_ahead(sdvgn_ef* e, int* launched, int* used) {
     if (!e) return SDVGN_E_ARG;

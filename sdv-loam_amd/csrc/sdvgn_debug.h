@@ -25,6 +25,10 @@ int sdvgn_debug_solve_stamps(sdvgn_ef* ef, unsigned long long* out16);
 /* Diagnostics (SDVGN_DEBUG_FLAGS bit5 = 32 set when the handle is created): wall_clock64() stamps (10 ns) of k_ef_linearize's stages
  * from the last launch, [workgroup][wave][8] 64-bit words (tools/exp_linearize_stages.py).  Returns the number of words copied, 0 if the diagnostics are off. */
 int sdvgn_debug_read_stamps(sdvgn_ef* ef, unsigned long long* out, int cap_words);
+/* Which forms the LAST sdvgn_ef_optimize call's bodies took: out4 = { rejected cases solved ahead on the side stream, bodies that started from such a solution,
+ * accept tests taken as a workgroup of the next body's accumulate launch (k_ef_acc_stats), accumulates queued ahead of the verdict } -- a test asserts that the
+ * default loop really runs the fast forms (a silent fall-back to the older ones would only show as a slower bench) */
+int sdvgn_debug_loop_counters(sdvgn_ef* ef, int* out4);
 #ifdef __cplusplus
 }
 #endif

@@ -833,6 +833,11 @@ def test_fused_apply_single_window_is_bit_identical(api, orc, seed, its, monkeyp
     tc = Cw.optimize(its, fixed_its=True)
     assert np.array_equal(ta, tb) and np.array_equal(ta, tc)
     assert 0 < ta[:, 2].sum() < len(ta) or seed != 2                   # (seed 2: accepted and rejected steps both occur)
+    # the default loop really took the fast forms (a silent fall-back would only show as a slower bench): every body but the last queues its successor's accumulate
+    # ahead of the verdict with the accept test inside it; the two older forms never do the latter
+    la_b, _, merged_b, pre_b = B.loop_counters()
+    assert la_b == its - 1 and merged_b == its - 1 and pre_b == its - 1, B.loop_counters()
+    assert A.loop_counters()[2] == 0 and Cw.loop_counters()[2] == 0 and A.loop_counters()[3] == its - 1
     _same_window_result(A, B)
     _same_window_result(A, Cw)
     assert np.array_equal(A.residual_J(0), B.residual_J(0))
